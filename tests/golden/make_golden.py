@@ -1,0 +1,392 @@
+"""Generate tests/golden/*.npz by running the REFERENCE's own source files (read-only at
+/root/reference) on seeded inputs.  Run in the authoring container only:
+
+    python tests/golden/make_golden.py
+
+Each fixture stores inputs (or the seed recipe that regenerates them) and the outputs the
+reference produced.  No reference source text is stored.  The oracle (oracle/*.py) is
+checked against these in tests/test_oracle_*.py; the HIP path is checked against both.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+from torch import nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import _refload as R  # noqa: E402
+
+torch.set_num_threads(4)
+
+
+def npy(t):
+    if isinstance(t, torch.Tensor):
+        return t.detach().cpu().numpy()
+    return np.asarray(t)
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **{k: npy(v) for k, v in arrs.items()})
+    print("wrote %-28s %7.1f KB  keys=%d" % (name, os.path.getsize(path) / 1024, len(arrs)))
+
+
+def fill_params(module, seed, scale=0.05):
+    """Deterministic parameter recipe shared with the tests (tests/_recipes.py)."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in module.named_parameters():
+            v = torch.randn(p.shape, generator=g) * scale
+            if name.endswith("norm.weight") or ".norm" in name and name.endswith("weight") \
+                    or name.startswith("norm") and name.endswith("weight"):
+                v = v + 1.0
+            p.copy_(v)
+
+
+def checksum(module):
+    return float(sum(p.double().abs().sum() for p in module.parameters()))
+
+
+# --------------------------------------------------------------------------------------
+def gen_swin():
+    sw = R.ref("divergen.modeling.backbone.swintransformer")
+    # G1: WindowAttention fwd + bwd, window 7 and 12, head_dim 32
+    for ws in (7, 12):
+        torch.manual_seed(100 + ws)
+        N = ws * ws
+        attn = sw.WindowAttention(64, (ws, ws), 2)
+        fill_params(attn, 7 + ws, 0.1)
+        nW, B = 3, 2
+        x = torch.randn(nW * B, N, 64, requires_grad=True)
+        # 0/-100 mask with the reference's structure: region ids per token
+        ids = torch.randint(0, 3, (nW, N)).float()
+        mask = ids.unsqueeze(1) - ids.unsqueeze(2)
+        mask = mask.masked_fill(mask != 0, -100.0).masked_fill(mask == 0, 0.0)
+        mask[0] = 0
+        out = attn(x, mask)
+        g = torch.randn_like(out)
+        out.backward(g)
+        out_nomask = attn(x.detach(), None)
+        save("swin_attn_w%d" % ws,
+             x=x, mask=mask, g=g, out=out, out_nomask=out_nomask, dx=x.grad,
+             qkv_w=attn.qkv.weight, qkv_b=attn.qkv.bias, proj_w=attn.proj.weight,
+             proj_b=attn.proj.bias, table=attn.relative_position_bias_table,
+             index=attn.relative_position_index,
+             d_qkv_w=attn.qkv.weight.grad, d_qkv_b=attn.qkv.bias.grad,
+             d_proj_w=attn.proj.weight.grad, d_proj_b=attn.proj.bias.grad,
+             d_table=attn.relative_position_bias_table.grad)
+
+    # G2: BasicLayer (W-MSA + SW-MSA blocks, padding, PatchMerging with odd W)
+    for ws, H, W in ((7, 10, 13), (12, 14, 25)):
+        torch.manual_seed(200 + ws)
+        layer = sw.BasicLayer(dim=64, depth=2, num_heads=2, window_size=ws,
+                              drop_path=0.0, downsample=sw.PatchMerging)
+        fill_params(layer, 21 + ws, 0.08)
+        x = torch.randn(2, H * W, 64, requires_grad=True)
+        x_out, h, w, x_down, wh, ww = layer(x, H, W)
+        g1 = torch.randn_like(x_out)
+        g2 = torch.randn_like(x_down)
+        (x_out * g1).sum().add((x_down * g2).sum()).backward()
+        sd = {("p." + k): v for k, v in layer.state_dict().items()}
+        gr = {("g." + k): p.grad for k, p in layer.named_parameters()}
+        save("swin_layer_w%d" % ws, x=x, H=H, W=W, x_out=x_out, x_down=x_down, Wh=wh, Ww=ww,
+             g1=g1, g2=g2, dx=x.grad, **sd, **gr)
+
+    # G3: whole backbone, params by recipe
+    torch.manual_seed(300)
+    net = sw.SwinTransformer(embed_dim=32, depths=[2, 2, 2, 2], num_heads=[1, 2, 4, 8],
+                             window_size=7, drop_path_rate=0.0, out_indices=(1, 2, 3))
+    fill_params(net, 31, 0.05)
+    img = torch.randn(1, 3, 75, 110)
+    outs = net(img)
+    save("swin_full", img=img, param_seed=31, param_scale=0.05, param_checksum=checksum(net),
+         **{k: v for k, v in outs.items()})
+
+    # drop path (timm algorithm) under a fixed torch seed
+    blk = sw.SwinTransformerBlock(64, 2, window_size=7, shift_size=0, drop_path=0.3)
+    fill_params(blk, 41, 0.08)
+    blk.train()
+    blk.H, blk.W = 7, 7
+    x = torch.randn(8, 49, 64)
+    torch.manual_seed(4242)
+    y = blk(x, None)
+    save("swin_droppath", x=x, y=y, torch_seed=4242, rate=0.3,
+         **{("p." + k): v for k, v in blk.state_dict().items()})
+
+
+# --------------------------------------------------------------------------------------
+def _make_gt(n, h, w, ncls, gen, Instances, Boxes):
+    x1 = torch.rand(n, generator=gen) * (w - 40)
+    y1 = torch.rand(n, generator=gen) * (h - 40)
+    bw = 8 + torch.rand(n, generator=gen) * (w * 0.6)
+    bh = 8 + torch.rand(n, generator=gen) * (h * 0.6)
+    boxes = torch.stack([x1, y1, (x1 + bw).clamp(max=w), (y1 + bh).clamp(max=h)], 1)
+    inst = Instances((h, w))
+    inst.gt_boxes = Boxes(boxes)
+    inst.gt_classes = torch.randint(0, ncls, (n,), generator=gen)
+    return inst
+
+
+def gen_centernet():
+    cn = R.ref("centernet.modeling.dense_heads.centernet")
+    st = sys.modules["detectron2.structures"]
+    gen = torch.Generator().manual_seed(500)
+    net = cn.CenterNet(in_channels=16, num_classes=7, with_agn_hm=True, only_proposal=True,
+                       score_thresh=0.0001, reg_weight=1.0, not_norm_reg=True,
+                       pos_weight=0.5, neg_weight=0.5, ignore_high_fp=0.85,
+                       pre_nms_topk_train=60, post_nms_topk_train=40,
+                       nms_thresh_train=0.9, nms_thresh_test=0.9,
+                       centernet_head=nn.Identity())
+    net.train()
+    H, W = 256, 320
+    strides = (8, 16, 32, 64, 128)
+    feats = [torch.zeros(2, 16, -(-H // s), -(-W // s)) for s in strides]
+    grids = net.compute_grids(feats)
+    shapes = grids[0].new_tensor([(f.shape[2], f.shape[3]) for f in feats])
+    gts = [_make_gt(6, H, W, 7, gen, st.Instances, st.Boxes),
+           _make_gt(0, H, W, 7, gen, st.Instances, st.Boxes),
+           ]
+    # a third image reuses image 0 shapes: B must equal feature batch (2)
+    pos_inds, labels, reg_targets, hms = net._get_ground_truth(grids, shapes, gts)
+    gts2 = [_make_gt(9, H, W, 7, gen, st.Instances, st.Boxes),
+            _make_gt(3, H, W, 7, gen, st.Instances, st.Boxes)]
+    # include a tiny box and a huge one to hit level-range edges
+    gts2[1].gt_boxes.tensor[0] = torch.tensor([10.0, 12.0, 14.5, 15.0])
+    gts2[1].gt_boxes.tensor[1] = torch.tensor([0.0, 0.0, 320.0, 256.0])
+    pos2, lab2, reg2, hm2 = net._get_ground_truth(grids, shapes, gts2)
+    M = sum(g.shape[0] for g in grids) * 2
+    reg_pred = (torch.rand(M, 4, generator=gen) * 6).requires_grad_(True)
+    agn_logit = (torch.randn(M, generator=gen) * 2 - 2).requires_grad_(True)
+    losses = net.losses(pos2, lab2, reg2, hm2, None, reg_pred, agn_logit.clone())
+    total = sum(losses.values())
+    total.backward()
+    save("centernet_targets",
+         H=H, W=W, strides=np.array(strides),
+         gt0_boxes=gts[0].gt_boxes.tensor, gt0_classes=gts[0].gt_classes,
+         pos_inds=pos_inds, labels=labels, reg_targets=reg_targets, hms=hms,
+         gt2a_boxes=gts2[0].gt_boxes.tensor, gt2a_classes=gts2[0].gt_classes,
+         gt2b_boxes=gts2[1].gt_boxes.tensor, gt2b_classes=gts2[1].gt_classes,
+         pos2=pos2, lab2=lab2, reg2=reg2, hm2=hm2,
+         reg_pred=reg_pred, agn_logit=agn_logit,
+         loss_loc=losses["loss_centernet_loc"], loss_pos=losses["loss_centernet_agn_pos"],
+         loss_neg=losses["loss_centernet_agn_neg"],
+         d_reg_pred=reg_pred.grad, d_agn_logit=agn_logit.grad)
+
+    # predict_single_level (pre-NMS candidates): one level with > topk candidates
+    hm = torch.rand(2, 1, 16, 20, generator=gen)
+    hm[1] *= 1e-5  # second image: nothing above threshold except a few
+    hm[1, 0, 3, 4] = 0.5
+    reg = torch.rand(2, 4, 16, 20, generator=gen) * 5
+    res = net.predict_single_level(grids[1], hm, reg * 16, [(H, W), (H, W)], None, 1)
+    # topk(sorted=False) order is an implementation detail: store sorted by score
+    out = {}
+    for i, r in enumerate(res):
+        o = torch.argsort(r.scores, descending=True, stable=True)
+        out["boxes%d" % i] = r.pred_boxes.tensor[o]
+        out["scores%d" % i] = r.scores[o]
+    save("centernet_predict", hm=hm, reg=reg, stride=16, grids=grids[1], topk=60, thresh=0.0001, **out)
+
+    il = R.ref("centernet.modeling.layers.iou_loss")
+    p = torch.rand(50, 4, generator=gen) * 10
+    t = torch.rand(50, 4, generator=gen) * 10
+    w = torch.rand(50, generator=gen)
+    save("iou_loss", pred=p, target=t, weight=w,
+         giou_none=il.IOULoss("giou")(p, t, None, reduction="none"),
+         giou_sum_w=il.IOULoss("giou")(p, t, w, reduction="sum"))
+
+
+# --------------------------------------------------------------------------------------
+def gen_roi():
+    st = sys.modules["detectron2.structures"]
+    Boxes, pairwise_iou = st.Boxes, st.pairwise_iou
+    mt = R.ref("detectron2.modeling.matcher")
+    sm = R.ref("detectron2.modeling.sampling")
+    br = R.ref("detectron2.modeling.box_regression")
+    pl = R.ref("detectron2.modeling.poolers")
+    ut = R.ref("divergen.modeling.utils")
+    fr = R.ref("divergen.modeling.roi_heads.detic_fast_rcnn")
+    gen = torch.Generator().manual_seed(700)
+
+    def rboxes(n, s=300.0):
+        a = torch.rand(n, 2, generator=gen) * s
+        wh = 4 + torch.rand(n, 2, generator=gen) * s * 0.5
+        return torch.cat([a, a + wh], 1)
+
+    gt = rboxes(9)
+    pr = torch.cat([rboxes(400), gt + torch.randn(9, 4, generator=gen) * 3, gt])
+    iou = pairwise_iou(Boxes(gt), Boxes(pr))
+    outs = {}
+    for thr in (0.6, 0.7, 0.8):
+        m = mt.Matcher([thr], [0, 1], allow_low_quality_matches=False)
+        idx, lab = m(iou)
+        outs["match_idx_%d" % int(thr * 10)] = idx
+        outs["match_lab_%d" % int(thr * 10)] = lab
+    # subsample_labels under a fixed torch seed (randperm stream)
+    gt_classes = torch.randint(0, 20, (9,), generator=gen)
+    lab6 = outs["match_lab_6"]
+    cls = gt_classes[outs["match_idx_6"]].clone()
+    cls[lab6 == 0] = 20
+    torch.manual_seed(777)
+    pos_idx, neg_idx = sm.subsample_labels(cls, 64, 0.25, 20)
+    # box2box
+    tr = br.Box2BoxTransform(weights=(10.0, 10.0, 5.0, 5.0))
+    src = pr[-18:]
+    tgt = torch.cat([gt, gt])
+    deltas = tr.get_deltas(src, tgt)
+    big = deltas.clone()
+    big[0, 2] = 50.0  # exercise scale clamp
+    applied = tr.apply_deltas(big, src)
+    # level assignment
+    lv = pl.assign_boxes_to_levels([Boxes(pr[:200]), Boxes(pr[200:])], 3, 5, 224, 4)
+    save("roi_match", gt=gt, proposals=pr, iou=iou, gt_classes=gt_classes, cls=cls,
+         seed=777, pos_idx=pos_idx, neg_idx=neg_idx, deltas=deltas, deltas_in=big,
+         applied=applied, levels=lv, **outs)
+
+    # federated loss class sampling + sigmoid CE + box reg loss
+    C = 40
+    freq = (torch.rand(C, generator=gen) * 1000 + 1).float() ** 0.5
+    R_ = 96
+    logits = (torch.randn(R_, C + 1, generator=gen) * 2).requires_grad_(True)
+    gtc = torch.randint(0, C + 1, (R_,), generator=gen)
+    gtc[:40] = C  # plenty of background
+    fake = types.SimpleNamespace(use_fed_loss=True, freq_weight=freq, fed_loss_num_cat=10,
+                                 ignore_zero_cats=False, num_classes=C,
+                                 box_reg_loss_type="smooth_l1", smooth_l1_beta=0.0,
+                                 box2box_transform=tr)
+    torch.manual_seed(888)
+    appeared = ut.get_fed_loss_inds(gtc, 10, C, freq)
+    torch.manual_seed(888)
+    loss_cls = fr.DeticFastRCNNOutputLayers.sigmoid_cross_entropy_loss(fake, logits, gtc)
+    loss_cls.backward()
+    pb = rboxes(R_)
+    gb = pb + torch.randn(R_, 4, generator=gen) * 4
+    gb[:, 2:] = torch.max(gb[:, 2:], gb[:, :2] + 1)
+    pd = (torch.randn(R_, 4, generator=gen)).requires_grad_(True)
+    loss_box = fr.DeticFastRCNNOutputLayers.box_reg_loss(fake, pb, gb, pd, gtc, None, num_classes=C)
+    loss_box.backward()
+    save("roi_losses", freq=freq, logits=logits, gt_classes=gtc, seed=888, appeared=appeared,
+         loss_cls=loss_cls, d_logits=logits.grad, prop_boxes=pb, gt_boxes=gb, pred_deltas=pd,
+         loss_box=loss_box, d_pred_deltas=pd.grad, weights=np.array([10.0, 10.0, 5.0, 5.0]))
+
+
+# --------------------------------------------------------------------------------------
+def gen_compositor():
+    mp = R.ref("divergen.data.custom_build_copypaste_mapper")
+    rng = np.random.default_rng(7)
+    H, W = 96, 128
+
+    def ellipse_mask(x0, y0, x1, y1):
+        yy, xx = np.mgrid[0:H, 0:W]
+        cx, cy, rx, ry = (x0 + x1) / 2, (y0 + y1) / 2, (x1 - x0) / 2, (y1 - y0) / 2
+        return ((((xx - cx) / max(rx, 1)) ** 2 + ((yy - cy) / max(ry, 1)) ** 2) <= 1).astype(np.uint8)
+
+    img = rng.integers(0, 256, (3, H, W), dtype=np.uint8)
+    n = 5
+    masks = []
+    for i in range(n):
+        x0, y0 = rng.integers(0, W - 30), rng.integers(0, H - 30)
+        masks.append(ellipse_mask(x0, y0, x0 + rng.integers(6, 50), y0 + rng.integers(6, 40)))
+    masks = np.stack(masks)
+    dst = {"image": img.copy(), "gt_masks": masks.copy(), "gt_bboxes": mp.get_bboxes(masks),
+           "gt_labels": rng.integers(0, 100, n).astype(np.int64),
+           "instance_source": np.zeros(n, dtype=np.int64)}
+    fake = types.SimpleNamespace(bbox_occluded_thr=10, mask_occluded_thr=300, cp_method=["basic"])
+    K = 7
+    store = {"dst_image": img, "dst_masks": masks, "dst_boxes": dst["gt_bboxes"],
+             "dst_labels": dst["gt_labels"], "K": K}
+    for k in range(K):
+        h, w = int(rng.integers(8, 60)), int(rng.integers(8, 70))
+        rgba = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+        yy, xx = np.mgrid[0:h, 0:w]
+        m = ((((xx - w / 2) / (w / 2)) ** 2 + ((yy - h / 2) / (h / 2)) ** 2) <= 1).astype(np.uint8)
+        rgba[..., 3] *= m
+        x0, y0 = int(rng.integers(-w // 2, W - w // 2)), int(rng.integers(-h // 2, H - h // 2))
+        # what pad_to_hw's integer-translate warpAffine produces: shifted copy, zero border
+        canvas = np.zeros((4, H, W), np.uint8)
+        cm = np.zeros((1, H, W), np.uint8)
+        ys, xs = max(y0, 0), max(x0, 0)
+        ye, xe = min(y0 + h, H), min(x0 + w, W)
+        canvas[:, ys:ye, xs:xe] = rgba[ys - y0:ye - y0, xs - x0:xe - x0].transpose(2, 0, 1)
+        cm[0, ys:ye, xs:xe] = (rgba[ys - y0:ye - y0, xs - x0:xe - x0, 3] > 0)
+        src = {"image": canvas, "gt_masks": cm, "gt_bboxes": mp.get_bboxes(cm),
+               "gt_labels": np.array([1000 + k], dtype=np.int64)}
+        store["src%d_rgba" % k] = rgba
+        store["src%d_xy" % k] = np.array([x0, y0])
+        store["src%d_label" % k] = src["gt_labels"]
+        dst = mp.InstPool._copy_paste(fake, dst, src)
+    store.update(out_image=dst["image"], out_masks=dst["gt_masks"], out_boxes=dst["gt_bboxes"],
+                 out_labels=dst["gt_labels"], out_source=dst["instance_source"])
+    save("compositor", **store)
+
+
+# --------------------------------------------------------------------------------------
+def gen_solver():
+    ema_m = R.ref("divergen.ema")
+    lr = R.ref("detectron2.solver.lr_scheduler")
+    torch.manual_seed(900)
+    net = nn.Sequential(nn.Linear(6, 5), nn.LayerNorm(5), nn.Linear(5, 3))
+    ema = ema_m.ModelEma(net, 0.999)
+    opt = torch.optim.AdamW([{"params": [p], "lr": 1e-2} for p in net.parameters()], 1e-2,
+                            weight_decay=1e-4)
+    sched = lr.WarmupCosineLR(opt, 100, warmup_factor=1e-4, warmup_iters=10)
+    lrs = []
+    x = torch.randn(16, 6)
+    init = {("init." + k): v.clone() for k, v in net.state_dict().items()}
+    for it in range(12):
+        loss = (net(x) ** 2).sum() * 30
+        ema.update(net)
+        opt.zero_grad()
+        loss.backward()
+        for p in net.parameters():
+            torch.nn.utils.clip_grad_value_(p, 1.0)
+        opt.step()
+        lrs.append(opt.param_groups[0]["lr"])
+        sched.step()
+    save("solver", x=x, lrs=np.array(lrs), **init,
+         **{("final." + k): v for k, v in net.state_dict().items()},
+         **{("ema." + k): v for k, v in ema.state_dict().items()})
+
+
+def gen_heads():
+    fpn_m = sys.modules["detectron2.modeling.backbone.fpn"]
+    f5 = R.ref("centernet.modeling.backbone.fpn_p5")
+    ch = R.ref("centernet.modeling.dense_heads.centernet_head")
+    ss = sys.modules["detectron2.layers"].ShapeSpec
+    Backbone = sys.modules["detectron2.modeling.backbone"].Backbone
+
+    class Dummy(Backbone):
+        _out_features = ["swin1", "swin2", "swin3"]
+        _out_feature_channels = {"swin1": 8, "swin2": 16, "swin3": 32}
+        _out_feature_strides = {"swin1": 8, "swin2": 16, "swin3": 32}
+
+        def forward(self, x):
+            return x
+
+    torch.manual_seed(1000)
+    fpn = fpn_m.FPN(Dummy(), ["swin1", "swin2", "swin3"], 16, norm="",
+                    top_block=f5.LastLevelP6P7_P5(16, 16), fuse_type="sum")
+    fill_params(fpn, 51, 0.1)
+    feats = {"swin1": torch.randn(2, 8, 16, 24), "swin2": torch.randn(2, 16, 8, 12),
+             "swin3": torch.randn(2, 32, 4, 6)}
+    out = fpn(feats)
+    save("fpn", **{("in." + k): v for k, v in feats.items()},
+         **{("out." + k): v for k, v in out.items()},
+         **{("p." + k): v for k, v in fpn.state_dict().items()})
+
+    head = ch.CenterNetHead(in_channels=32, num_levels=2, num_classes=5, with_agn_hm=True,
+                            only_proposal=True, norm="GN", num_cls_convs=4, num_box_convs=4,
+                            num_share_convs=0, use_deformable=False, prior_prob=0.01)
+    fill_params(head, 61, 0.05)
+    xs = [torch.randn(2, 32, 12, 10), torch.randn(2, 32, 6, 5)]
+    clss, regs, hms = head(xs)
+    save("centernet_head", x0=xs[0], x1=xs[1], reg0=regs[0], reg1=regs[1], hm0=hms[0], hm1=hms[1],
+         **{("p." + k): v for k, v in head.state_dict().items()})
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["swin", "centernet", "roi", "compositor", "solver", "heads"]
+    for w in which:
+        globals()["gen_" + w]()

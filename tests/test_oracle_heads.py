@@ -1,0 +1,131 @@
+"""Oracle CenterNet / heads / compositor / solver vs outputs of the reference's own files."""
+import numpy as np
+import torch
+
+from oracle import centernet as C
+from oracle import compositor as K
+from oracle import heads as Hd
+from oracle import solver as S
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def _shapes(H, W, strides):
+    return [(-(-H // s), -(-W // s)) for s in strides]
+
+
+def test_centernet_targets(golden):
+    g = golden("centernet_targets")
+    H, W, st = int(g["H"]), int(g["W"]), tuple(int(s) for s in g["strides"])
+    shapes = _shapes(H, W, st)
+    pos, reg, hm = C.ground_truth([T(g["gt0_boxes"]), torch.zeros(0, 4)], shapes, st)
+    assert torch.equal(pos, T(g["pos_inds"]))
+    assert torch.equal(reg, T(g["reg_targets"]))
+    torch.testing.assert_close(hm, T(g["hms"]), atol=0, rtol=0)
+    pos2, reg2, hm2 = C.ground_truth([T(g["gt2a_boxes"]), T(g["gt2b_boxes"])], shapes, st)
+    assert torch.equal(pos2, T(g["pos2"]))
+    assert torch.equal(reg2, T(g["reg2"]))
+    torch.testing.assert_close(hm2, T(g["hm2"]), atol=0, rtol=0)
+
+
+def test_centernet_losses_and_grads(golden):
+    g = golden("centernet_targets")
+    rp = T(g["reg_pred"]).requires_grad_(True)
+    al = T(g["agn_logit"]).requires_grad_(True)
+    L = C.losses(T(g["pos2"]), T(g["reg2"]), T(g["hm2"]), rp, al)
+    torch.testing.assert_close(L["loss_centernet_loc"], T(g["loss_loc"]), atol=1e-6, rtol=1e-6)
+    torch.testing.assert_close(L["loss_centernet_agn_pos"], T(g["loss_pos"]), atol=1e-6, rtol=1e-6)
+    torch.testing.assert_close(L["loss_centernet_agn_neg"], T(g["loss_neg"]), atol=1e-5, rtol=1e-6)
+    sum(L.values()).backward()
+    torch.testing.assert_close(rp.grad, T(g["d_reg_pred"]), atol=1e-7, rtol=1e-5)
+    torch.testing.assert_close(al.grad, T(g["d_agn_logit"]), atol=1e-7, rtol=1e-5)
+
+
+def test_centernet_predict(golden):
+    g = golden("centernet_predict")
+    hm, reg = T(g["hm"]), T(g["reg"])
+    for i in range(2):
+        b, s = C.predict_level(T(g["grids"]), hm[i, 0].reshape(-1),
+                               (reg[i] * int(g["stride"])).permute(1, 2, 0).reshape(-1, 4),
+                               float(g["thresh"]), int(g["topk"]))
+        o = torch.argsort(s, descending=True, stable=True)
+        torch.testing.assert_close(s[o], T(g["scores%d" % i]), atol=0, rtol=0)
+        torch.testing.assert_close(b[o], T(g["boxes%d" % i]), atol=0, rtol=0)
+
+
+def test_giou(golden):
+    g = golden("iou_loss")
+    torch.testing.assert_close(C.giou_loss(T(g["pred"]), T(g["target"]), None, "none"), T(g["giou_none"]), atol=0, rtol=0)
+    torch.testing.assert_close(C.giou_loss(T(g["pred"]), T(g["target"]), T(g["weight"]), "sum"), T(g["giou_sum_w"]))
+
+
+def test_fed_loss_and_box_reg(golden):
+    g = golden("roi_losses")
+    logits = T(g["logits"]).requires_grad_(True)
+    gtc, freq = T(g["gt_classes"]), T(g["freq"])
+    torch.manual_seed(int(g["seed"]))
+    ap = Hd.fed_loss_inds(gtc, 10, 40, freq)
+    assert torch.equal(ap, T(g["appeared"]))
+    torch.manual_seed(int(g["seed"]))
+    l = Hd.sigmoid_ce_fed(logits, gtc, freq, 10)
+    torch.testing.assert_close(l, T(g["loss_cls"]), atol=1e-6, rtol=1e-6)
+    l.backward()
+    torch.testing.assert_close(logits.grad, T(g["d_logits"]), atol=1e-8, rtol=1e-5)
+    pd = T(g["pred_deltas"]).requires_grad_(True)
+    lb = Hd.box_reg_loss(T(g["prop_boxes"]), T(g["gt_boxes"]), pd, gtc, 40, tuple(g["weights"].tolist()))
+    torch.testing.assert_close(lb, T(g["loss_box"]), atol=1e-6, rtol=1e-6)
+    lb.backward()
+    torch.testing.assert_close(pd.grad, T(g["d_pred_deltas"]))
+
+
+def test_fpn_and_centernet_head(golden):
+    g = golden("fpn")
+    p = {k[2:]: T(g[k]) for k in g.files if k.startswith("p.")}
+    out = Hd.fpn({k[3:]: T(g[k]) for k in g.files if k.startswith("in.")}, p)
+    for k in ("p3", "p4", "p5", "p6", "p7"):
+        torch.testing.assert_close(out[k], T(g["out." + k]), atol=1e-5, rtol=1e-5)
+    g = golden("centernet_head")
+    p = {k[2:]: T(g[k]) for k in g.files if k.startswith("p.")}
+    regs, hms = Hd.centernet_head([T(g["x0"]), T(g["x1"])], p)
+    for i in range(2):
+        torch.testing.assert_close(regs[i], T(g["reg%d" % i]), atol=1e-5, rtol=1e-5)
+        torch.testing.assert_close(hms[i], T(g["hm%d" % i]), atol=1e-5, rtol=1e-5)
+
+
+def test_compositor_chain_bit_exact(golden):
+    g = golden("compositor")
+    pastes = [(g["src%d_rgba" % k], int(g["src%d_xy" % k][0]), int(g["src%d_xy" % k][1]), g["src%d_label" % k])
+              for k in range(int(g["K"]))]
+    out = K.composite(g["dst_image"], g["dst_masks"], g["dst_boxes"], g["dst_labels"], pastes)
+    assert np.array_equal(out["image"], g["out_image"])
+    assert np.array_equal(out["masks"], g["out_masks"])
+    assert np.array_equal(out["boxes"], g["out_boxes"])
+    assert np.array_equal(out["labels"], g["out_labels"])
+    assert np.array_equal(out["source"], g["out_source"])
+
+
+def test_solver_trajectory(golden):
+    g = golden("solver")
+    names = ["0.weight", "0.bias", "1.weight", "1.bias", "2.weight", "2.bias"]
+    p = {n: T(g["init." + n]).clone().requires_grad_(True) for n in names}
+    ema = {n: T(g["init." + n]).clone() for n in names}
+    m = {n: torch.zeros_like(p[n]) for n in names}
+    v = {n: torch.zeros_like(p[n]) for n in names}
+    x = T(g["x"])
+    for it in range(12):
+        h = torch.nn.functional.linear(x, p["0.weight"], p["0.bias"])
+        h = torch.nn.functional.layer_norm(h, (5,), p["1.weight"], p["1.bias"])
+        loss = (torch.nn.functional.linear(h, p["2.weight"], p["2.bias"]) ** 2).sum() * 30
+        for n in names:
+            S.ema_update(ema[n], p[n].detach(), 0.999)
+        grads = torch.autograd.grad(loss, [p[n] for n in names])
+        lr = S.warmup_cosine_lr(1e-2, it, 100, 10, 1e-4)
+        assert abs(lr - float(g["lrs"][it])) < 1e-12
+        with torch.no_grad():
+            for n, gr in zip(names, grads):
+                S.adamw_clip_step(p[n], gr, m[n], v[n], it + 1, lr, wd=1e-4, clip=1.0)
+    for n in names:
+        torch.testing.assert_close(p[n].detach(), T(g["final." + n]), atol=1e-6, rtol=1e-5)
+        torch.testing.assert_close(ema[n], T(g["ema." + n]), atol=1e-7, rtol=1e-6)

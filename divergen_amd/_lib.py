@@ -1,0 +1,88 @@
+"""ctypes binding of libdgx.so (C ABI: include/divergen_hip.h).
+
+There is NO fallback: if the library is missing or an op is called on a non-GPU tensor the call
+raises.  The CPU oracle lives under oracle/ and is never imported from this package.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libdgx.so")
+_lib = None
+
+c_p, c_i, c_f, c_i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
+
+# name -> (restype, argtypes); must list every symbol include/divergen_hip.h declares
+SIGNATURES = {
+    "dgx_build_arch": (ctypes.c_char_p, []),
+    "dgx_abi_version": (c_i, []),
+    "dgx_window_attention_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p]),
+    "dgx_window_attention_bwd": (c_i, [c_p] * 8 + [c_i, c_i, c_i, c_i, c_f, c_p]),
+    "dgx_window_gather": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "dgx_window_scatter": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "dgx_roi_align_fwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "dgx_roi_align_bwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "dgx_roi_pooler_fwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "dgx_roi_pooler_bwd": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "dgx_mask_crop": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "dgx_nms_sorted": (c_i, [c_p, c_i, c_f, c_p, c_p, c_p, c_p]),
+    "dgx_nms_workspace_words": (c_i64, [c_i]),
+    "dgx_iou_match": (c_i, [c_p, c_i, c_p, c_i, c_f, c_p, c_p, c_p, c_p]),
+    "dgx_centernet_targets": (c_i, [c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_f, c_f, c_p, c_p, c_p]),
+    "dgx_copy_paste": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p]),
+    "dgx_adamw_ema_step": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_f,
+                                 c_p, c_p, c_i, c_p, c_p]),
+}
+
+
+class DgxError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libdgx.so once.  Raises (loudly) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DgxError("libdgx.so is missing (%s): run `python -m divergen_amd.csrc.build` or "
+                           "__graft_entry__.build(); there is no CPU/eager fallback" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(code, what):
+    if code != 0:
+        raise DgxError("%s failed with code %d" % (what, code))
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  Must be a contiguous GPU tensor."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise DgxError("libdgx ops need GPU (ROCm) tensors; got a %s tensor -- no CPU fallback exists" % t.device)
+    if not t.is_contiguous():
+        raise DgxError("libdgx ops need contiguous tensors")
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+DGX_F32, DGX_BF16 = 0, 1
+
+
+def dtype_code(t):
+    if t.dtype == torch.float32:
+        return DGX_F32
+    if t.dtype == torch.bfloat16:
+        return DGX_BF16
+    raise DgxError("unsupported dtype %s (float32 / bfloat16 only)" % t.dtype)

@@ -1,0 +1,142 @@
+// Greedy NMS (bitmask + on-device sweep) and fused pairwise-IoU + Matcher for gfx950.
+// Integer outputs (keep flags, matched indices/labels) are bit-exact with the oracle: the IoU
+// float sequence is the reference's (torchvision nms: inter/(a_i+a_j-inter) > thr;
+// D2/structures/boxes.py:310-357: inter/(a1+a2-inter)), compiled with -ffp-contract=off.
+#include "dgx_common.h"
+
+// mask[i][cb] bit j: box (64*cb + j) has IoU > thr with box i and comes later in score order.
+__global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ boxes, int n, float thr, int nb,
+                                                      uint64_t* __restrict__ mask) {
+    const int rb = blockIdx.y, cb = blockIdx.x;
+    if (cb < rb) return;
+    __shared__ float cbx[64 * 4];
+    const int l = threadIdx.x;
+    const int cj = 64 * cb + l;
+    if (cj < n) {
+        cbx[4 * l + 0] = boxes[4 * cj + 0];
+        cbx[4 * l + 1] = boxes[4 * cj + 1];
+        cbx[4 * l + 2] = boxes[4 * cj + 2];
+        cbx[4 * l + 3] = boxes[4 * cj + 3];
+    }
+    __syncthreads();
+    const int i = 64 * rb + l;
+    if (i >= n) return;
+    const float ix1 = boxes[4 * i], iy1 = boxes[4 * i + 1], ix2 = boxes[4 * i + 2], iy2 = boxes[4 * i + 3];
+    const float iarea = (ix2 - ix1) * (iy2 - iy1);
+    const int cols = min(64, n - 64 * cb);
+    uint64_t bits = 0;
+    for (int j = (rb == cb ? l + 1 : 0); j < cols; ++j) {
+        const float jx1 = cbx[4 * j], jy1 = cbx[4 * j + 1], jx2 = cbx[4 * j + 2], jy2 = cbx[4 * j + 3];
+        const float jarea = (jx2 - jx1) * (jy2 - jy1);
+        const float xx1 = fmaxf(ix1, jx1), yy1 = fmaxf(iy1, jy1);
+        const float xx2 = fminf(ix2, jx2), yy2 = fminf(iy2, jy2);
+        const float w = fmaxf(0.0f, xx2 - xx1), h = fmaxf(0.0f, yy2 - yy1);
+        const float inter = w * h;
+        const float ovr = inter / (iarea + jarea - inter);
+        if (ovr > thr) bits |= 1ull << j;
+    }
+    mask[(int64_t)i * nb + cb] = bits;
+}
+
+// One workgroup walks the 64-box blocks in order: lane-serial resolve inside a block, then all
+// threads OR the rows of the kept boxes into the running "removed" vector held in LDS.
+__global__ __launch_bounds__(1024) void nms_sweep_kernel(const uint64_t* __restrict__ mask, int n, int nb,
+                                                         uint8_t* __restrict__ keep, int32_t* __restrict__ num_keep) {
+    extern __shared__ uint64_t remv[];  // [nb] + kept-list scratch
+    __shared__ int kept_rows[64];
+    __shared__ int kept_n;
+    __shared__ int total;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < nb; i += blockDim.x) remv[i] = 0;
+    if (tid == 0) total = 0;
+    __syncthreads();
+    for (int b = 0; b < nb; ++b) {
+        const int cnt = min(64, n - 64 * b);
+        if (tid < 64) {
+            // diagonal words of this block's rows
+            const uint64_t mine = tid < cnt ? mask[(int64_t)(64 * b + tid) * nb + b] : 0ull;
+            uint64_t cur = remv[b];
+            int k = 0;
+            for (int j = 0; j < cnt; ++j) {
+                const uint64_t row = __shfl(mine, j);
+                const bool alive = !((cur >> j) & 1ull);
+                if (alive) {
+                    cur |= row;
+                    if (tid == 0) kept_rows[k] = 64 * b + j;
+                    ++k;
+                }
+                if (tid == j) keep[64 * b + j] = alive ? 1 : 0;
+            }
+            if (tid == 0) { kept_n = k; total += k; }
+        }
+        __syncthreads();
+        const int kn = kept_n;
+        for (int cb = b + 1 + tid; cb < nb; cb += blockDim.x) {
+            uint64_t acc = remv[cb];
+            for (int k = 0; k < kn; ++k) acc |= mask[(int64_t)kept_rows[k] * nb + cb];
+            remv[cb] = acc;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) *num_keep = total;
+}
+
+extern "C" int64_t dgx_nms_workspace_words(int n) { return n <= 0 ? 0 : (int64_t)n * ((n + 63) / 64); }
+
+extern "C" int dgx_nms_sorted(const float* boxes, int n, float iou_thr, uint64_t* mask, uint8_t* keep,
+                              int32_t* num_keep, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (n < 0 || !num_keep) return DGX_ERR_BAD_ARG;
+    if (n == 0) {
+        hipMemsetAsync(num_keep, 0, sizeof(int32_t), st);
+        return DGX_OK;
+    }
+    if (!boxes || !mask || !keep) return DGX_ERR_BAD_ARG;
+    const int nb = (n + 63) / 64;
+    if ((size_t)nb * 8 > 60000) return DGX_ERR_UNSUPPORTED;  // removed-vector must fit LDS (n <= ~480k)
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(nb, nb), dim3(64), 0, st, boxes, n, iou_thr, nb, mask);
+    hipLaunchKernelGGL(nms_sweep_kernel, dim3(1), dim3(1024), (size_t)nb * 8, st, mask, n, nb, keep, num_keep);
+    DGX_LAUNCH_CHECK();
+    return DGX_OK;
+}
+
+// ---- pairwise IoU + Matcher -----------------------------------------------------------------
+__global__ __launch_bounds__(256) void iou_match_kernel(const float* __restrict__ gt, int M, const float* __restrict__ props,
+                                                        int N, float thr, int64_t* __restrict__ midx,
+                                                        int8_t* __restrict__ mlab, float* __restrict__ miou) {
+    extern __shared__ float g[];  // [M][5]: box + area
+    for (int i = threadIdx.x; i < M; i += blockDim.x) {
+        const float x1 = gt[4 * i], y1 = gt[4 * i + 1], x2 = gt[4 * i + 2], y2 = gt[4 * i + 3];
+        g[5 * i] = x1; g[5 * i + 1] = y1; g[5 * i + 2] = x2; g[5 * i + 3] = y2;
+        g[5 * i + 4] = (x2 - x1) * (y2 - y1);
+    }
+    __syncthreads();
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= N) return;
+    const float px1 = props[4 * j], py1 = props[4 * j + 1], px2 = props[4 * j + 2], py2 = props[4 * j + 3];
+    const float parea = (px2 - px1) * (py2 - py1);
+    float best = -1.0f;
+    int bi = 0;
+    for (int i = 0; i < M; ++i) {
+        const float w = fmaxf(fminf(g[5 * i + 2], px2) - fmaxf(g[5 * i], px1), 0.0f);
+        const float h = fmaxf(fminf(g[5 * i + 3], py2) - fmaxf(g[5 * i + 1], py1), 0.0f);
+        const float inter = w * h;
+        const float iou = inter > 0.0f ? inter / (g[5 * i + 4] + parea - inter) : 0.0f;
+        if (iou > best) { best = iou; bi = i; }  // first maximum wins (torch.max(dim=0))
+    }
+    if (M == 0) { best = 0.0f; bi = 0; }
+    midx[j] = bi;
+    mlab[j] = (M > 0 && best >= thr) ? 1 : 0;
+    if (miou) miou[j] = best;
+}
+
+extern "C" int dgx_iou_match(const float* gt, int M, const float* props, int N, float thr, int64_t* matched_idx,
+                             int8_t* matched_label, float* max_iou, void* stream) {
+    if (N <= 0) return DGX_OK;
+    if (!props || !matched_idx || !matched_label || M < 0 || (M > 0 && !gt)) return DGX_ERR_BAD_ARG;
+    if ((size_t)M * 20 > 60000) return DGX_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(iou_match_kernel, dim3((N + 255) / 256), dim3(256), (size_t)M * 20, (hipStream_t)stream, gt, M,
+                       props, N, thr, matched_idx, matched_label, max_iou);
+    DGX_LAUNCH_CHECK();
+    return DGX_OK;
+}

@@ -1,0 +1,291 @@
+// ROIAlign / multi-level ROIPooler / GT-mask crop for gfx950.
+//
+// HBM-bound gathers.  Features are channels-last (N,H,W,C): one workgroup per RoI, one lane per
+// channel, so every bilinear tap is a contiguous C*esize-byte read shared by the whole wave and the
+// sample geometry is wave-uniform (scalar registers).  The float sequence of the sample positions
+// and weights is the oracle's (oracle/roi_nms.c, torchvision's published algorithm) and this file
+// is compiled with -ffp-contract=off, so bin geometry and the boolean mask targets are bit-exact.
+// Backward scatters with hardware fp32 atomics into an fp32 (N,H,W,C) gradient.
+#include "dgx_common.h"
+
+#define MAX_LEVELS 4
+struct PoolLevels {
+    const void* feat[MAX_LEVELS];
+    float* grad[MAX_LEVELS];
+    int H[MAX_LEVELS], W[MAX_LEVELS];
+    float scale[MAX_LEVELS];
+    int num_levels, min_level;
+};
+
+struct Taps { int pos[4]; float w[4]; };
+
+__device__ __forceinline__ bool bilinear_taps(int H, int W, float y, float x, Taps& t) {
+    if (y < -1.0f || y > (float)H || x < -1.0f || x > (float)W) return false;
+    if (y <= 0) y = 0;
+    if (x <= 0) x = 0;
+    int y_low = (int)y, x_low = (int)x, y_high, x_high;
+    if (y_low >= H - 1) { y_high = y_low = H - 1; y = (float)y_low; } else y_high = y_low + 1;
+    if (x_low >= W - 1) { x_high = x_low = W - 1; x = (float)x_low; } else x_high = x_low + 1;
+    const float ly = y - y_low, lx = x - x_low, hy = 1.0f - ly, hx = 1.0f - lx;
+    t.pos[0] = y_low * W + x_low;   t.w[0] = hy * hx;
+    t.pos[1] = y_low * W + x_high;  t.w[1] = hy * lx;
+    t.pos[2] = y_high * W + x_low;  t.w[2] = ly * hx;
+    t.pos[3] = y_high * W + x_high; t.w[3] = ly * lx;
+    return true;
+}
+
+struct RoiGeom { float sw, sh, bin_w, bin_h; int gw, gh; float count; int b; };
+
+__device__ __forceinline__ RoiGeom roi_geom(const float* roi, float scale, int ph, int pw, int sampling_ratio, bool aligned) {
+    RoiGeom G;
+    G.b = (int)roi[0];
+    const float off = aligned ? 0.5f : 0.0f;
+    G.sw = roi[1] * scale - off;
+    G.sh = roi[2] * scale - off;
+    const float ew = roi[3] * scale - off, eh = roi[4] * scale - off;
+    float rw = ew - G.sw, rh = eh - G.sh;
+    if (!aligned) { rw = fmaxf(rw, 1.0f); rh = fmaxf(rh, 1.0f); }
+    G.bin_h = rh / (float)ph;
+    G.bin_w = rw / (float)pw;
+    G.gh = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rh / (float)ph);
+    G.gw = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rw / (float)pw);
+    G.count = (float)max(G.gh * G.gw, 1);
+    return G;
+}
+
+// level = floor(canonical_level + log2(sqrt(area)/224 + 1e-8)) clamped (poolers.py:50-58); evaluated
+// with exact power-of-two comparisons instead of log2 so it cannot straddle an integer.
+__device__ __forceinline__ int assign_level(const float* roi, int min_level, int num_levels) {
+    const float area = (roi[3] - roi[1]) * (roi[4] - roi[2]);
+    float t = sqrtf(area) / 224.0f + 1e-8f;
+    int lv = 4;
+    if (!(t > 0.0f)) return 0;  // degenerate / NaN: lowest level
+    while (t >= 2.0f && lv < 64) { t *= 0.5f; ++lv; }
+    while (t < 1.0f && lv > -64) { t *= 2.0f; --lv; }
+    lv -= min_level;
+    return lv < 0 ? 0 : (lv >= num_levels ? num_levels - 1 : lv);
+}
+
+template <typename T> __device__ __forceinline__ float ldf(const T* p);
+template <> __device__ __forceinline__ float ldf<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float ldf<uint16_t>(const uint16_t* p) { return bf2f(*p); }
+template <typename T> __device__ __forceinline__ void stf(T* p, float v);
+template <> __device__ __forceinline__ void stf<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void stf<uint16_t>(uint16_t* p, float v) { *p = f2bf(v); }
+
+// grid (R, nsplit): block handles bins [split*bpb, ...).  NCHW output goes through an LDS
+// transpose so that the (C, ph*pw) tile of a RoI is written as one contiguous run.
+template <typename T>
+__global__ __launch_bounds__(256) void roi_align_fwd_kernel(PoolLevels L, const float* __restrict__ rois, T* __restrict__ out,
+                                                            int32_t* __restrict__ levels_out, int C, int ph, int pw,
+                                                            int sampling_ratio, int aligned, int out_nhwc, int bins_per_block) {
+    extern __shared__ float tile[];  // [bins_per_block][C] when !out_nhwc
+    const int r = blockIdx.x;
+    const float* roi = rois + 5 * (int64_t)r;
+    const int lvl = L.num_levels > 1 ? assign_level(roi, L.min_level, L.num_levels) : 0;
+    if (levels_out && blockIdx.y == 0 && threadIdx.x == 0) levels_out[r] = lvl;
+    const T* feat = (const T*)L.feat[lvl];
+    const int H = L.H[lvl], W = L.W[lvl];
+    const RoiGeom G = roi_geom(roi, L.scale[lvl], ph, pw, sampling_ratio, aligned != 0);
+    const T* fb = feat + (int64_t)G.b * H * W * C;
+    const int bins = ph * pw;
+    const int bin0 = blockIdx.y * bins_per_block, bin1 = min(bins, bin0 + bins_per_block);
+    for (int bin = bin0; bin < bin1; ++bin) {
+        const int i = bin / pw, j = bin - i * pw;
+        for (int c = threadIdx.x; c < C; c += blockDim.x) {
+            float acc = 0.0f;
+            for (int iy = 0; iy < G.gh; ++iy) {
+                const float y = G.sh + i * G.bin_h + ((float)iy + 0.5f) * G.bin_h / (float)G.gh;
+                for (int ix = 0; ix < G.gw; ++ix) {
+                    const float x = G.sw + j * G.bin_w + ((float)ix + 0.5f) * G.bin_w / (float)G.gw;
+                    Taps t;
+                    if (!bilinear_taps(H, W, y, x, t)) continue;
+                    acc += t.w[0] * ldf(fb + (int64_t)t.pos[0] * C + c) + t.w[1] * ldf(fb + (int64_t)t.pos[1] * C + c) +
+                           t.w[2] * ldf(fb + (int64_t)t.pos[2] * C + c) + t.w[3] * ldf(fb + (int64_t)t.pos[3] * C + c);
+                }
+            }
+            const float v = acc / G.count;
+            if (out_nhwc) stf(out + ((int64_t)r * bins + bin) * C + c, v);
+            else tile[(bin - bin0) * C + c] = v;
+        }
+    }
+    if (!out_nhwc) {
+        __syncthreads();
+        const int nb = bin1 - bin0;
+        for (int idx = threadIdx.x; idx < nb * C; idx += blockDim.x) {
+            const int c = idx / nb, bb = idx - c * nb;
+            stf(out + ((int64_t)r * C + c) * bins + bin0 + bb, tile[bb * C + c]);
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void roi_align_bwd_kernel(PoolLevels L, const float* __restrict__ rois,
+                                                            const T* __restrict__ gout, int C, int ph, int pw,
+                                                            int sampling_ratio, int aligned, int out_nhwc, int bins_per_block) {
+    extern __shared__ float tile[];
+    const int r = blockIdx.x;
+    const float* roi = rois + 5 * (int64_t)r;
+    const int lvl = L.num_levels > 1 ? assign_level(roi, L.min_level, L.num_levels) : 0;
+    float* gfeat = L.grad[lvl];
+    const int H = L.H[lvl], W = L.W[lvl];
+    const RoiGeom G = roi_geom(roi, L.scale[lvl], ph, pw, sampling_ratio, aligned != 0);
+    float* gb = gfeat + (int64_t)G.b * H * W * C;
+    const int bins = ph * pw;
+    const int bin0 = blockIdx.y * bins_per_block, bin1 = min(bins, bin0 + bins_per_block);
+    if (!out_nhwc) {
+        const int nb = bin1 - bin0;
+        for (int idx = threadIdx.x; idx < nb * C; idx += blockDim.x) {
+            const int c = idx / nb, bb = idx - c * nb;
+            tile[bb * C + c] = ldf(gout + ((int64_t)r * C + c) * bins + bin0 + bb);
+        }
+        __syncthreads();
+    }
+    for (int bin = bin0; bin < bin1; ++bin) {
+        const int i = bin / pw, j = bin - i * pw;
+        for (int c = threadIdx.x; c < C; c += blockDim.x) {
+            const float go = out_nhwc ? ldf(gout + ((int64_t)r * bins + bin) * C + c) : tile[(bin - bin0) * C + c];
+            const float g = go / G.count;
+            for (int iy = 0; iy < G.gh; ++iy) {
+                const float y = G.sh + i * G.bin_h + ((float)iy + 0.5f) * G.bin_h / (float)G.gh;
+                for (int ix = 0; ix < G.gw; ++ix) {
+                    const float x = G.sw + j * G.bin_w + ((float)ix + 0.5f) * G.bin_w / (float)G.gw;
+                    Taps t;
+                    if (!bilinear_taps(H, W, y, x, t)) continue;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) atomicAdd(gb + (int64_t)t.pos[k] * C + c, g * t.w[k]);
+                }
+            }
+        }
+    }
+}
+
+static int launch_pool(bool fwd, const PoolLevels& L, const float* rois, const void* io, int32_t* levels_out, int C,
+                       int R, int ph, int pw, int sampling_ratio, int aligned, int out_nhwc, int dtype, void* stream) {
+    if (R <= 0) return DGX_OK;
+    if (!rois || !io || C <= 0 || ph <= 0 || pw <= 0) return DGX_ERR_BAD_ARG;
+    const int bins = ph * pw;
+    int bpb, nsplit;
+    if (out_nhwc) {
+        nsplit = R >= 2048 ? 1 : (R >= 512 ? 2 : 4);
+        if (nsplit > bins) nsplit = bins;
+        bpb = (bins + nsplit - 1) / nsplit;
+    } else {
+        bpb = (int)(65536 / ((size_t)C * 4));
+        if (bpb < 1) return DGX_ERR_UNSUPPORTED;
+        if (bpb > bins) bpb = bins;
+    }
+    nsplit = (bins + bpb - 1) / bpb;
+    const size_t sm = out_nhwc ? 0 : (size_t)bpb * C * 4;
+    dim3 grid(R, nsplit), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (fwd) {
+        if (dtype == DGX_BF16)
+            hipLaunchKernelGGL(roi_align_fwd_kernel<uint16_t>, grid, block, sm, st, L, rois, (uint16_t*)io, levels_out, C,
+                               ph, pw, sampling_ratio, aligned, out_nhwc, bpb);
+        else
+            hipLaunchKernelGGL(roi_align_fwd_kernel<float>, grid, block, sm, st, L, rois, (float*)io, levels_out, C, ph,
+                               pw, sampling_ratio, aligned, out_nhwc, bpb);
+    } else {
+        if (dtype == DGX_BF16)
+            hipLaunchKernelGGL(roi_align_bwd_kernel<uint16_t>, grid, block, sm, st, L, rois, (const uint16_t*)io, C, ph,
+                               pw, sampling_ratio, aligned, out_nhwc, bpb);
+        else
+            hipLaunchKernelGGL(roi_align_bwd_kernel<float>, grid, block, sm, st, L, rois, (const float*)io, C, ph, pw,
+                               sampling_ratio, aligned, out_nhwc, bpb);
+    }
+    DGX_LAUNCH_CHECK();
+    return DGX_OK;
+}
+
+extern "C" int dgx_roi_align_fwd(const void* feat, const float* rois, void* out, int N, int H, int W, int C, int R,
+                                 float spatial_scale, int ph, int pw, int sampling_ratio, int aligned, int out_nhwc,
+                                 int dtype, void* stream) {
+    (void)N;
+    PoolLevels L = {};
+    L.feat[0] = feat; L.H[0] = H; L.W[0] = W; L.scale[0] = spatial_scale; L.num_levels = 1; L.min_level = 0;
+    if (R > 0 && !feat) return DGX_ERR_BAD_ARG;
+    return launch_pool(true, L, rois, out, nullptr, C, R, ph, pw, sampling_ratio, aligned, out_nhwc, dtype, stream);
+}
+
+extern "C" int dgx_roi_align_bwd(const void* grad_out, const float* rois, float* grad_feat, int N, int H, int W, int C,
+                                 int R, float spatial_scale, int ph, int pw, int sampling_ratio, int aligned,
+                                 int out_nhwc, int dtype, void* stream) {
+    (void)N;
+    PoolLevels L = {};
+    L.grad[0] = grad_feat; L.H[0] = H; L.W[0] = W; L.scale[0] = spatial_scale; L.num_levels = 1; L.min_level = 0;
+    if (R > 0 && !grad_feat) return DGX_ERR_BAD_ARG;
+    return launch_pool(false, L, rois, grad_out, nullptr, C, R, ph, pw, sampling_ratio, aligned, out_nhwc, dtype, stream);
+}
+
+static int fill_levels(PoolLevels& L, const void* const* feats, float* const* grads, const int* Hs, const int* Ws,
+                       int num_levels, int min_level) {
+    if (num_levels < 1 || num_levels > MAX_LEVELS || !Hs || !Ws) return DGX_ERR_BAD_ARG;
+    L.num_levels = num_levels;
+    L.min_level = min_level;
+    for (int l = 0; l < num_levels; ++l) {
+        L.feat[l] = feats ? feats[l] : nullptr;
+        L.grad[l] = grads ? grads[l] : nullptr;
+        L.H[l] = Hs[l];
+        L.W[l] = Ws[l];
+        L.scale[l] = 1.0f / (float)(1 << (min_level + l));
+    }
+    return DGX_OK;
+}
+
+extern "C" int dgx_roi_pooler_fwd(const void* const* feats, const int* Hs, const int* Ws, int num_levels, int min_level,
+                                  const float* rois, void* out, int32_t* levels_out, int N, int C, int R, int ph, int pw,
+                                  int sampling_ratio, int out_nhwc, int dtype, void* stream) {
+    (void)N;
+    PoolLevels L = {};
+    if (!feats) return DGX_ERR_BAD_ARG;
+    int e = fill_levels(L, feats, nullptr, Hs, Ws, num_levels, min_level);
+    if (e) return e;
+    return launch_pool(true, L, rois, out, levels_out, C, R, ph, pw, sampling_ratio, 1, out_nhwc, dtype, stream);
+}
+
+extern "C" int dgx_roi_pooler_bwd(const void* grad_out, float* const* grad_feats, const int* Hs, const int* Ws,
+                                  int num_levels, int min_level, const float* rois, int N, int C, int R, int ph, int pw,
+                                  int sampling_ratio, int out_nhwc, int dtype, void* stream) {
+    (void)N;
+    PoolLevels L = {};
+    if (!grad_feats) return DGX_ERR_BAD_ARG;
+    int e = fill_levels(L, nullptr, grad_feats, Hs, Ws, num_levels, min_level);
+    if (e) return e;
+    return launch_pool(false, L, rois, grad_out, nullptr, C, R, ph, pw, sampling_ratio, 1, out_nhwc, dtype, stream);
+}
+
+// ---- GT mask crop: one workgroup per box, one lane per output pixel, byte taps --------------
+__global__ __launch_bounds__(256) void mask_crop_kernel(const uint8_t* __restrict__ masks, const float* __restrict__ boxes,
+                                                        const int32_t* __restrict__ mask_idx, uint8_t* __restrict__ out,
+                                                        int H, int W, int S) {
+    const int r = blockIdx.x;
+    const float roi[5] = {0.0f, boxes[4 * r], boxes[4 * r + 1], boxes[4 * r + 2], boxes[4 * r + 3]};
+    const RoiGeom G = roi_geom(roi, 1.0f, S, S, 0, true);
+    const uint8_t* m = masks + (int64_t)mask_idx[r] * H * W;
+    for (int bin = threadIdx.x; bin < S * S; bin += blockDim.x) {
+        const int i = bin / S, j = bin - i * S;
+        float acc = 0.0f;
+        for (int iy = 0; iy < G.gh; ++iy) {
+            const float y = G.sh + i * G.bin_h + ((float)iy + 0.5f) * G.bin_h / (float)G.gh;
+            for (int ix = 0; ix < G.gw; ++ix) {
+                const float x = G.sw + j * G.bin_w + ((float)ix + 0.5f) * G.bin_w / (float)G.gw;
+                Taps t;
+                if (!bilinear_taps(H, W, y, x, t)) continue;
+                acc += t.w[0] * (float)m[t.pos[0]] + t.w[1] * (float)m[t.pos[1]] + t.w[2] * (float)m[t.pos[2]] +
+                       t.w[3] * (float)m[t.pos[3]];
+            }
+        }
+        out[(int64_t)r * S * S + bin] = (acc / G.count) >= 0.5f ? 1 : 0;
+    }
+}
+
+extern "C" int dgx_mask_crop(const uint8_t* masks, const float* boxes, const int32_t* mask_idx, uint8_t* out, int M,
+                             int H, int W, int R, int S, void* stream) {
+    (void)M;
+    if (R <= 0) return DGX_OK;
+    if (!masks || !boxes || !mask_idx || !out || S <= 0) return DGX_ERR_BAD_ARG;
+    hipLaunchKernelGGL(mask_crop_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, masks, boxes, mask_idx, out, H, W, S);
+    DGX_LAUNCH_CHECK();
+    return DGX_OK;
+}

@@ -1,0 +1,379 @@
+// Swin window attention core for gfx950: one workgroup per (window, head), one wave per 16-row
+// strip, MFMA 16x16x32 bf16, fp32 softmax.  head_dim is 32 in every Swin size, so one MFMA spans
+// the whole QK^T contraction.  Reference semantics: DG/divergen/modeling/backbone/swintransformer.py:133-154.
+//
+// Forward ("swapped" orientation): S^T = K Q^T so that a lane owns ONE query (col = lane&15) and
+// 4 keys per tile; row max/sum are 2 xor-shuffles and P feeds the P*V MFMA straight from registers
+// (the k-slot permutation it implies is applied to the V^T image read from LDS).
+// Backward: a wave owns a 16-KEY strip (dK, dV and the rel-pos-bias gradient are wave-local and
+// the bias gradient accumulates in registers across the windows of a chunk); dS goes through LDS
+// once for dQ = dS K.
+#include "dgx_common.h"
+
+template <int WS> struct WinCfg;
+template <> struct WinCfg<12> { static constexpr int N = 144, NT = 9, NTK = 10, RS = 168, TBL = 529; };
+template <> struct WinCfg<7>  { static constexpr int N = 49,  NT = 4, NTK = 4,  RS = 72,  TBL = 169; };
+// NT  = ceil(N/16) strips (= waves per workgroup); NTK = NT rounded up to even (K=32 steps);
+// RS  = row stride (elements) of the transposed [32][NTK*16] LDS images; chosen so that the
+//       16 rows x 4 lane-groups of a ds_read_b64 hit 64 distinct banks (RS*2/4 = 4*odd mod 64).
+
+__device__ __forceinline__ bf16x8 ld_frag_global(const uint16_t* p, bool ok) {
+    bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    return ok ? *reinterpret_cast<const bf16x8*>(p) : z;
+}
+
+// transposed staging: src rows r (r < N valid) of 32 bf16 at src + r*row_stride -> T[d][r]
+template <int N, int NP, int RS>
+__device__ __forceinline__ void stage_transposed(uint16_t* T, const uint16_t* src, int64_t row_stride,
+                                                 int tid, int nthreads) {
+    constexpr int HALF = NP / 2;
+    for (int u = tid; u < HALF * 4; u += nthreads) {
+        const int c = u / HALF, m = u - c * HALF;
+        const int r0 = 2 * m, r1 = r0 + 1;
+        bf16x8 v0 = ld_frag_global(src + (int64_t)r0 * row_stride + 8 * c, r0 < N);
+        bf16x8 v1 = ld_frag_global(src + (int64_t)r1 * row_stride + 8 * c, r1 < N);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            uint32_t w = (uint32_t)(uint16_t)v0[i] | ((uint32_t)(uint16_t)v1[i] << 16);
+            *reinterpret_cast<uint32_t*>(&T[(8 * c + i) * RS + r0]) = w;
+        }
+    }
+}
+
+// B/A fragment from a transposed image: slots j<4 -> cols 32t+4g+j, j>=4 -> cols 32t+16+4g+(j-4)
+template <int RS>
+__device__ __forceinline__ bf16x8 ld_frag_T(const uint16_t* T, int row, int t, int g) {
+    const uint2 a = *reinterpret_cast<const uint2*>(&T[row * RS + 32 * t + 4 * g]);
+    const uint2 b = *reinterpret_cast<const uint2*>(&T[row * RS + 32 * t + 16 + 4 * g]);
+    u32x4 v = {a.x, a.y, b.x, b.y};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+// XCD-aware block -> (window, head): blocks that share an XCD (id % 8) walk the heads of one
+// window back to back, so the 64-byte head slices of a qkv row are served by one L2.
+__device__ __forceinline__ void block_to_window_head(int bid, int nH, int& b, int& h) {
+    const int xcd = bid & 7, slot = bid >> 3;
+    b = (slot / nH) * 8 + xcd;
+    h = slot % nH;
+}
+
+template <int WS>
+__global__ __launch_bounds__(WinCfg<WS>::NT * 64) void win_attn_fwd_kernel(
+    const uint16_t* __restrict__ qkv, const float* __restrict__ table, const int8_t* __restrict__ region,
+    uint16_t* __restrict__ out, float* __restrict__ lse, int B_, int nW, int nH, float scale) {
+    using Cf = WinCfg<WS>;
+    constexpr int N = Cf::N, NT = Cf::NT, NTK = Cf::NTK, NP = NTK * 16, RS = Cf::RS, TBL = Cf::TBL;
+    __shared__ __attribute__((aligned(16))) uint16_t Vt[32 * RS];
+    __shared__ float tbl[TBL];
+
+    int b, h;
+    block_to_window_head(blockIdx.x, nH, b, h);
+    if (b >= B_) return;
+    const int C = nH * 32;
+    const int64_t rowst = 3 * (int64_t)C;
+    const uint16_t* base = qkv + (int64_t)b * N * rowst + h * 32;
+    const int tid = threadIdx.x, nthreads = NT * 64;
+
+    for (int i = tid; i < TBL; i += nthreads) tbl[i] = table[i * nH + h];
+    stage_transposed<N, NP, RS>(Vt, base + 2 * C, rowst, tid, nthreads);
+    __syncthreads();
+
+    const int w = tid >> 6, l = tid & 63, g = l >> 4, c16 = l & 15;
+    const int qi = 16 * w + c16;
+    const bool qok = qi < N;
+    const bf16x8 qf = ld_frag_global(base + (int64_t)qi * rowst + 8 * g, qok);
+    const int8_t* reg = region ? region + (int64_t)(b % nW) * N : nullptr;
+    const int rq = (reg && qok) ? reg[qi] : 0;
+    const int yq = qi / WS, xq = qi - yq * WS;
+    const int base_q = (yq + WS - 1) * (2 * WS - 1) + (xq + WS - 1);
+
+    float p[NTK][4];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NTK; ++kt) {
+        const int kr = 16 * kt + c16;
+        const bf16x8 kf = ld_frag_global(base + C + (int64_t)kr * rowst + 8 * g, kr < N);
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 acc = mfma16(kf, qf, z);  // acc[r] = S^T[key 16kt+4g+r][query c16]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int key = 16 * kt + 4 * g + r;
+            float s = -INFINITY;
+            if (key < N) {
+                const int yk = key / WS, xk = key - yk * WS;
+                const int idx = qok ? base_q - (yk * (2 * WS - 1) + xk) : 0;
+                s = acc[r] * scale + tbl[idx];
+                if (reg && reg[key] != rq) s += -100.0f;
+            }
+            p[kt][r] = s;
+            mx = fmaxf(mx, s);
+        }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NTK; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float e = __expf(p[kt][r] - mx);
+            p[kt][r] = e;
+            sum += e;
+        }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    if (g == 0 && qok) lse[((int64_t)b * nH + h) * N + qi] = mx + __logf(sum);
+    const float inv = 1.0f / sum;
+
+    f32x4 o[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int t = 0; t < NTK / 2; ++t) {
+        u32x4 pk = {pack_bf2(p[2 * t][0], p[2 * t][1]), pack_bf2(p[2 * t][2], p[2 * t][3]),
+                    pack_bf2(p[2 * t + 1][0], p[2 * t + 1][1]), pack_bf2(p[2 * t + 1][2], p[2 * t + 1][3])};
+        // A = P^T-slot fragment: row (l&15) = query, slots (g, j) = keys {32t+4g+j, 32t+16+4g+j-4}
+        const bf16x8 pf = __builtin_bit_cast(bf16x8, pk);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            const bf16x8 vf = ld_frag_T<RS>(Vt, 16 * dt + c16, t, g);
+            o[dt] = mfma16(pf, vf, o[dt]);  // o[dt][r] = O[query 16w+4g+r][d 16dt+c16]
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float invr = __shfl(inv, 4 * g + r);
+        const int q = 16 * w + 4 * g + r;
+        if (q < N) {
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+                out[((int64_t)b * N + q) * C + h * 32 + 16 * dt + c16] = f2bf(o[dt][r] * invr);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ backward
+template <int WS>
+__global__ __launch_bounds__(WinCfg<WS>::NT * 64) void win_attn_bwd_kernel(
+    const uint16_t* __restrict__ qkv, const float* __restrict__ table, const int8_t* __restrict__ region,
+    const uint16_t* __restrict__ out, const float* __restrict__ lse, const uint16_t* __restrict__ dout,
+    uint16_t* __restrict__ dqkv, float* __restrict__ dtable, int B_, int nW, int nH, float scale, int chunk) {
+    using Cf = WinCfg<WS>;
+    constexpr int N = Cf::N, NT = Cf::NT, NTK = Cf::NTK, NP = NTK * 16, RS = Cf::RS, TBL = Cf::TBL;
+    constexpr int RR = 40;       // row stride (elements) of the row-major [NP][32] images
+    constexpr int RD = NP + 8;   // row stride of the dS image [NP][NP]
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint16_t* Qs = reinterpret_cast<uint16_t*>(smem);       // [NP][RR] row-major Q
+    uint16_t* dOs = Qs + NP * RR;                            // [NP][RR] row-major dO
+    uint16_t* Qt = dOs + NP * RR;                            // [32][RS]
+    uint16_t* dOt = Qt + 32 * RS;                            // [32][RS]
+    uint16_t* Kt = dOt + 32 * RS;                            // [32][RS]
+    uint16_t* dSs = Kt + 32 * RS;                            // [NP][RD]
+    float* lse_s = reinterpret_cast<float*>(dSs + NP * RD);  // [NP]
+    float* delta_s = lse_s + NP;                             // [NP]
+    float* tbl = delta_s + NP;                               // [TBL]
+    float* tblacc = tbl + TBL;                               // [TBL]
+
+    const int h = blockIdx.x % nH;
+    const int b0 = (blockIdx.x / nH) * chunk;
+    const int b1 = min(B_, b0 + chunk);
+    const int C = nH * 32;
+    const int64_t rowst = 3 * (int64_t)C;
+    const int tid = threadIdx.x, nthreads = NT * 64;
+    const int w = tid >> 6, l = tid & 63, g = l >> 4, c16 = l & 15;
+
+    for (int i = tid; i < TBL; i += nthreads) { tbl[i] = table[i * nH + h]; tblacc[i] = 0.f; }
+    for (int i = tid; i < NP * RD; i += nthreads) dSs[i] = 0;  // key columns never owned stay 0
+    const int key = 16 * w + c16;  // this lane's key in phase 1
+    const bool kok = key < N;
+    const int yk = key / WS, xk = key - yk * WS;
+    const int kbase = (WS - 1) * (2 * WS - 1) + (WS - 1) - (yk * (2 * WS - 1) + xk);
+    float dbias[NT][4];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dbias[i][r] = 0.f;
+
+    for (int b = b0; b < b1; ++b) {
+        const uint16_t* base = qkv + (int64_t)b * N * rowst + h * 32;
+        const uint16_t* dob = dout + (int64_t)b * N * C + h * 32;
+        const uint16_t* ob = out + (int64_t)b * N * C + h * 32;
+        __syncthreads();  // previous window's LDS consumers are done
+        // row-major Q / dO images + delta[q] = sum_d dO*O
+        for (int u = tid; u < NP * 4; u += nthreads) {
+            const int q = u >> 2, c = u & 3;
+            const bool ok = q < N;
+            const bf16x8 qv = ld_frag_global(base + (int64_t)q * rowst + 8 * c, ok);
+            const bf16x8 dv = ld_frag_global(dob + (int64_t)q * C + 8 * c, ok);
+            const bf16x8 ov = ld_frag_global(ob + (int64_t)q * C + 8 * c, ok);
+            *reinterpret_cast<bf16x8*>(&Qs[q * RR + 8 * c]) = qv;
+            *reinterpret_cast<bf16x8*>(&dOs[q * RR + 8 * c]) = dv;
+            float d = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) d += bf2f((uint16_t)dv[i]) * bf2f((uint16_t)ov[i]);
+            d += __shfl_xor(d, 1);
+            d += __shfl_xor(d, 2);
+            if (c == 0) {
+                delta_s[q] = d;
+                lse_s[q] = ok ? lse[((int64_t)b * nH + h) * N + q] : 0.f;
+            }
+        }
+        stage_transposed<N, NP, RS>(Qt, base, rowst, tid, nthreads);
+        stage_transposed<N, NP, RS>(dOt, dob, C, tid, nthreads);
+        stage_transposed<N, NP, RS>(Kt, base + C, rowst, tid, nthreads);
+        const bf16x8 kf = ld_frag_global(base + C + (int64_t)key * rowst + 8 * g, kok);
+        const bf16x8 vf = ld_frag_global(base + 2 * C + (int64_t)key * rowst + 8 * g, kok);
+        const int8_t* reg = region ? region + (int64_t)(b % nW) * N : nullptr;
+        const int rk = (reg && kok) ? reg[key] : 0;
+        __syncthreads();
+
+        // ---- phase 1: this wave's 16 keys x all queries, two query tiles (one K=32 step) at a time
+        f32x4 dV[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        f32x4 dK[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int t = 0; t < NTK / 2; ++t) {
+            uint32_t ppk[2][2], dpk[2][2];
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int qt = 2 * t + hh;
+                float pv[4] = {0.f, 0.f, 0.f, 0.f}, dsv[4] = {0.f, 0.f, 0.f, 0.f};
+                if (qt < NT) {
+                    const bf16x8 qa = *reinterpret_cast<const bf16x8*>(&Qs[(16 * qt + c16) * RR + 8 * g]);
+                    const bf16x8 da = *reinterpret_cast<const bf16x8*>(&dOs[(16 * qt + c16) * RR + 8 * g]);
+                    f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                    const f32x4 s = mfma16(qa, kf, z);    // s[r]  = S[q 16qt+4g+r][key]
+                    const f32x4 dp = mfma16(da, vf, z);   // dp[r] = dP[q][key]
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int q = 16 * qt + 4 * g + r;
+                        if (q < N && kok) {
+                            const int yq = q / WS, xq = q - yq * WS;
+                            float sv = s[r] * scale + tbl[kbase + yq * (2 * WS - 1) + xq];
+                            if (reg && reg[q] != rk) sv += -100.0f;
+                            pv[r] = __expf(sv - lse_s[q]);
+                            dsv[r] = pv[r] * (dp[r] - delta_s[q]);
+                            dbias[qt < NT ? qt : 0][r] += dsv[r];
+                        }
+                        dSs[q * RD + key] = f2bf(dsv[r]);
+                    }
+                }
+                ppk[hh][0] = pack_bf2(pv[0], pv[1]);
+                ppk[hh][1] = pack_bf2(pv[2], pv[3]);
+                dpk[hh][0] = pack_bf2(dsv[0], dsv[1]);
+                dpk[hh][1] = pack_bf2(dsv[2], dsv[3]);
+            }
+            u32x4 a = {ppk[0][0], ppk[0][1], ppk[1][0], ppk[1][1]};
+            u32x4 d = {dpk[0][0], dpk[0][1], dpk[1][0], dpk[1][1]};
+            const bf16x8 pf = __builtin_bit_cast(bf16x8, a);   // A = P^T : row = key, slots = queries
+            const bf16x8 df = __builtin_bit_cast(bf16x8, d);   // A = dS^T
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                dV[dt] = mfma16(pf, ld_frag_T<RS>(dOt, 16 * dt + c16, t, g), dV[dt]);
+                dK[dt] = mfma16(df, ld_frag_T<RS>(Qt, 16 * dt + c16, t, g), dK[dt]);
+            }
+        }
+        uint16_t* dqb = dqkv + (int64_t)b * N * rowst + h * 32;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int kk = 16 * w + 4 * g + r;
+            if (kk < N) {
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    dqb[(int64_t)kk * rowst + C + 16 * dt + c16] = f2bf(dK[dt][r] * scale);
+                    dqb[(int64_t)kk * rowst + 2 * C + 16 * dt + c16] = f2bf(dV[dt][r]);
+                }
+            }
+        }
+        __syncthreads();  // dS image complete
+        // ---- phase 2: dQ strip w = dS[16w.., :] K
+        f32x4 dQ[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int t = 0; t < NTK / 2; ++t) {
+            const bf16x8 sa = *reinterpret_cast<const bf16x8*>(&dSs[(16 * w + c16) * RD + 32 * t + 8 * g]);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const bf16x8 kb = *reinterpret_cast<const bf16x8*>(&Kt[(16 * dt + c16) * RS + 32 * t + 8 * g]);
+                dQ[dt] = mfma16(sa, kb, dQ[dt]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int q = 16 * w + 4 * g + r;
+            if (q < N) {
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+                    dqb[(int64_t)q * rowst + 16 * dt + c16] = f2bf(dQ[dt][r] * scale);
+            }
+        }
+    }
+    // ---- relative-position-bias gradient: registers -> LDS table (ds_add_f32) -> global atomics
+    if (kok) {
+#pragma unroll
+        for (int qt = 0; qt < NT; ++qt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int q = 16 * qt + 4 * g + r;
+                if (q < N) {
+                    const int yq = q / WS, xq = q - yq * WS;
+                    atomicAdd(&tblacc[kbase + yq * (2 * WS - 1) + xq], dbias[qt][r]);
+                }
+            }
+    }
+    __syncthreads();
+    for (int i = tid; i < TBL; i += nthreads) atomicAdd(&dtable[i * nH + h], tblacc[i]);
+}
+
+template <int WS>
+static size_t bwd_smem_bytes() {
+    using Cf = WinCfg<WS>;
+    constexpr int NP = Cf::NTK * 16;
+    return (size_t)(2 * NP * 40 + 3 * 32 * Cf::RS + NP * (NP + 8)) * 2 + (size_t)(2 * NP + 2 * Cf::TBL) * 4;
+}
+
+extern "C" int dgx_window_attention_fwd(const void* qkv, const float* table, const int8_t* region, void* out,
+                                        float* lse, int B_, int nW, int nH, int ws, float scale, void* stream) {
+    if (B_ <= 0) return DGX_OK;
+    if (!qkv || !table || !out || !lse || nH <= 0 || nW <= 0 || (region && B_ % nW)) return DGX_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = ((B_ + 7) / 8) * 8 * nH;
+    if (ws == 12)
+        hipLaunchKernelGGL(win_attn_fwd_kernel<12>, dim3(grid), dim3(WinCfg<12>::NT * 64), 0, st,
+                           (const uint16_t*)qkv, table, region, (uint16_t*)out, lse, B_, nW, nH, scale);
+    else if (ws == 7)
+        hipLaunchKernelGGL(win_attn_fwd_kernel<7>, dim3(grid), dim3(WinCfg<7>::NT * 64), 0, st,
+                           (const uint16_t*)qkv, table, region, (uint16_t*)out, lse, B_, nW, nH, scale);
+    else
+        return DGX_ERR_UNSUPPORTED;
+    DGX_LAUNCH_CHECK();
+    return DGX_OK;
+}
+
+extern "C" int dgx_window_attention_bwd(const void* qkv, const float* table, const int8_t* region, const void* out,
+                                        const float* lse, const void* dout, void* dqkv, float* dtable, int B_,
+                                        int nW, int nH, int ws, float scale, void* stream) {
+    if (B_ <= 0) return DGX_OK;
+    if (!qkv || !table || !out || !lse || !dout || !dqkv || !dtable || nH <= 0 || nW <= 0 || (region && B_ % nW))
+        return DGX_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    int chunk = (int)(((int64_t)B_ * nH + 1023) / 1024);
+    if (chunk < 1) chunk = 1;
+    const int grid = ((B_ + chunk - 1) / chunk) * nH;
+    if (ws == 12) {
+        static bool once = false;
+        const size_t sm = bwd_smem_bytes<12>();
+        if (!once) {
+            hipFuncSetAttribute((const void*)win_attn_bwd_kernel<12>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+            once = true;
+        }
+        hipLaunchKernelGGL(win_attn_bwd_kernel<12>, dim3(grid), dim3(WinCfg<12>::NT * 64), sm, st,
+                           (const uint16_t*)qkv, table, region, (const uint16_t*)out, lse, (const uint16_t*)dout,
+                           (uint16_t*)dqkv, dtable, B_, nW, nH, scale, chunk);
+    } else if (ws == 7) {
+        const size_t sm = bwd_smem_bytes<7>();
+        hipLaunchKernelGGL(win_attn_bwd_kernel<7>, dim3(grid), dim3(WinCfg<7>::NT * 64), sm, st,
+                           (const uint16_t*)qkv, table, region, (const uint16_t*)out, lse, (const uint16_t*)dout,
+                           (uint16_t*)dqkv, dtable, B_, nW, nH, scale, chunk);
+    } else {
+        return DGX_ERR_UNSUPPORTED;
+    }
+    DGX_LAUNCH_CHECK();
+    return DGX_OK;
+}

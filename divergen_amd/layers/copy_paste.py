@@ -1,0 +1,47 @@
+"""Instance copy-paste compositor ('basic' blend) on the GPU.
+Reference: DG/divergen/data/custom_build_copypaste_mapper.py:488-566, :79-92."""
+import numpy as np
+import torch
+
+from .. import _lib as L
+
+
+def copy_paste(image, masks, boxes, labels, pastes):
+    """image uint8 (3,H,W), masks uint8 (n,H,W), boxes f32 (n,4), labels i64 (n) -- GPU tensors.
+    pastes: list of (rgba uint8 numpy/tensor (h,w,4), x0, y0, label) applied in order.
+    Returns dict(image, masks, boxes, labels, source) exactly like the sequential reference."""
+    K = len(pastes)
+    dev = image.device
+    n0, H, W = masks.shape[0], image.shape[1], image.shape[2]
+    if K == 0:
+        return dict(image=image, masks=masks, boxes=boxes, labels=labels,
+                    source=torch.zeros(n0, dtype=torch.int64, device=dev))
+    desc, chunks, off = [], [], 0
+    for rgba, x0, y0, _ in pastes:
+        a = torch.as_tensor(np.ascontiguousarray(rgba) if isinstance(rgba, np.ndarray) else rgba).reshape(-1)
+        h, w = rgba.shape[0], rgba.shape[1]
+        desc.append([off, h, w, int(x0), int(y0)])
+        chunks.append(a)
+        off += (a.numel() + 3) // 4 * 4
+    flat = torch.zeros(off, dtype=torch.uint8)
+    for d, a in zip(desc, chunks):
+        flat[d[0]:d[0] + a.numel()] = a.cpu()
+    flat = flat.to(dev)
+    desc_t = torch.tensor(desc, dtype=torch.int32, device=dev)
+    image = image.contiguous().clone()
+    masks = masks.contiguous()
+    boxes0 = boxes.float().contiguous()
+    nobj = n0 + K
+    out_masks = torch.empty(nobj, H, W, dtype=torch.uint8, device=dev)
+    out_boxes = torch.empty(nobj, 4, dtype=torch.float32, device=dev)
+    out_valid = torch.empty(nobj, dtype=torch.uint8, device=dev)
+    stats = torch.empty(nobj * (K + 1) * 5 + H * W, dtype=torch.int32, device=dev)
+    L.check(L.lib().dgx_copy_paste(L.ptr(image), L.ptr(masks) if n0 else None, L.ptr(boxes0) if n0 else None, n0, H, W,
+                                   L.ptr(flat), L.ptr(desc_t), K, L.ptr(out_masks), L.ptr(out_boxes), L.ptr(out_valid),
+                                   L.ptr(stats), L.stream()), "dgx_copy_paste")
+    valid = out_valid.bool()
+    all_labels = torch.cat([labels.to(torch.int64), torch.tensor([int(np.asarray(p[3]).reshape(-1)[0]) for p in pastes],
+                                                                 dtype=torch.int64, device=dev)])
+    source = torch.cat([torch.zeros(n0, dtype=torch.int64, device=dev), torch.ones(K, dtype=torch.int64, device=dev)])
+    return dict(image=image, masks=out_masks[valid], boxes=out_boxes[valid], labels=all_labels[valid],
+                source=source[valid])

@@ -1,0 +1,96 @@
+"""ROIAlign / ROIPooler / GT-mask crop over channels-last features.
+Reference: D2/layers/roi_align.py:7-65, D2/modeling/poolers.py:22-245, D2/structures/masks.py:189-220."""
+import ctypes
+import math
+
+import torch
+
+from .. import _lib as L
+
+
+def _nhwc(feat):
+    """(N,C,H,W) logical tensor -> physical (N,H,W,C) contiguous view for the kernels."""
+    return feat.permute(0, 2, 3, 1).contiguous()
+
+
+class _ROIPooler(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rois, out_size, min_level, sampling_ratio, out_nhwc, aligned, scale0, *feats):
+        nl = len(feats)
+        f0 = feats[0]
+        N, C = f0.shape[0], f0.shape[1]
+        phys = [_nhwc(f) for f in feats]
+        R = rois.shape[0]
+        rois = rois.float().contiguous()
+        ph = pw = out_size
+        if out_nhwc:
+            out = torch.empty(R, ph, pw, C, dtype=f0.dtype, device=f0.device).permute(0, 3, 1, 2)
+            out_phys = out.permute(0, 2, 3, 1)
+        else:
+            out = torch.empty(R, C, ph, pw, dtype=f0.dtype, device=f0.device)
+            out_phys = out
+        Hs = (ctypes.c_int * nl)(*[f.shape[2] for f in feats])
+        Ws = (ctypes.c_int * nl)(*[f.shape[3] for f in feats])
+        if nl == 1:
+            L.check(L.lib().dgx_roi_align_fwd(L.ptr(phys[0]), L.ptr(rois), L.ptr(out_phys), N, Hs[0], Ws[0], C, R,
+                                              scale0, ph, pw, sampling_ratio, int(aligned), int(out_nhwc),
+                                              L.dtype_code(f0), L.stream()), "dgx_roi_align_fwd")
+        else:
+            ptrs = (ctypes.c_void_p * nl)(*[L.ptr(p) for p in phys])
+            L.check(L.lib().dgx_roi_pooler_fwd(ptrs, Hs, Ws, nl, min_level, L.ptr(rois), L.ptr(out_phys), None, N, C,
+                                               R, ph, pw, sampling_ratio, int(out_nhwc), L.dtype_code(f0), L.stream()),
+                    "dgx_roi_pooler_fwd")
+        ctx.save_for_backward(rois)
+        ctx.cfg = (out_size, min_level, sampling_ratio, out_nhwc, aligned, scale0, N, C,
+                   [tuple(f.shape) for f in feats], f0.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        (rois,) = ctx.saved_tensors
+        out_size, min_level, sampling_ratio, out_nhwc, aligned, scale0, N, C, shapes, dt = ctx.cfg
+        nl = len(shapes)
+        R = rois.shape[0]
+        g_phys = gout.permute(0, 2, 3, 1).contiguous() if out_nhwc else gout.contiguous()
+        grads = [torch.zeros(s[0], s[2], s[3], s[1], dtype=torch.float32, device=gout.device) for s in shapes]
+        Hs = (ctypes.c_int * nl)(*[s[2] for s in shapes])
+        Ws = (ctypes.c_int * nl)(*[s[3] for s in shapes])
+        if nl == 1:
+            L.check(L.lib().dgx_roi_align_bwd(L.ptr(g_phys), L.ptr(rois), L.ptr(grads[0]), N, Hs[0], Ws[0], C, R,
+                                              scale0, out_size, out_size, sampling_ratio, int(aligned), int(out_nhwc),
+                                              L.dtype_code(g_phys), L.stream()), "dgx_roi_align_bwd")
+        else:
+            ptrs = (ctypes.c_void_p * nl)(*[L.ptr(g) for g in grads])
+            L.check(L.lib().dgx_roi_pooler_bwd(L.ptr(g_phys), ptrs, Hs, Ws, nl, min_level, L.ptr(rois), N, C, R,
+                                               out_size, out_size, sampling_ratio, int(out_nhwc),
+                                               L.dtype_code(g_phys), L.stream()), "dgx_roi_pooler_bwd")
+        outs = [g.permute(0, 3, 1, 2).to(dt) for g in grads]
+        return (None,) * 7 + tuple(outs)
+
+
+def roi_align(feat, rois, spatial_scale, out_size, sampling_ratio=0, aligned=True, out_nhwc=False):
+    """feat (N,C,H,W) (any memory format), rois (R,5) -> (R,C,S,S)."""
+    return _ROIPooler.apply(rois, out_size, 0, sampling_ratio, out_nhwc, aligned, float(spatial_scale), feat)
+
+
+def roi_pooler(feats, rois, out_size, scales, sampling_ratio=0, out_nhwc=False):
+    """Multi-level ROIAlignV2 (poolers.py:185-245).  feats: list of (N,C,H,W); rois (R,5) with
+    batch index in column 0; scales: per-level spatial scales (powers of two)."""
+    min_level = int(round(-math.log2(scales[0])))
+    if len(feats) == 1:
+        return roi_align(feats[0], rois, scales[0], out_size, sampling_ratio, True, out_nhwc)
+    return _ROIPooler.apply(rois, out_size, min_level, sampling_ratio, out_nhwc, True, float(scales[0]), *feats)
+
+
+def mask_crop(masks, boxes, mask_idx, size):
+    """masks uint8/bool (M,H,W) on GPU, boxes (R,4), mask_idx (R) -> bool (R,size,size).
+    BitMasks.crop_and_resize (masks.py:189-220) without the fp32 mask copy."""
+    m = masks.view(torch.uint8) if masks.dtype == torch.bool else masks
+    m = m.contiguous()
+    boxes = boxes.float().contiguous()
+    idx = mask_idx.to(torch.int32).contiguous()
+    R = boxes.shape[0]
+    out = torch.empty(R, size, size, dtype=torch.uint8, device=boxes.device)
+    L.check(L.lib().dgx_mask_crop(L.ptr(m), L.ptr(boxes), L.ptr(idx), L.ptr(out), m.shape[0], m.shape[1], m.shape[2],
+                                  R, size, L.stream()), "dgx_mask_crop")
+    return out.view(torch.bool)

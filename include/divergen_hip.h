@@ -1,0 +1,177 @@
+/* divergen_hip.h -- C ABI of libdgx.so, the gfx950 (MI355X / CDNA4) kernel library behind the
+ * DiverGen training hot path.
+ *
+ * The reference (aim-uofa/DiverGen) has no FFI of its own: its "native" calls on this path are
+ * ATen / torchvision ops issued from Python.  Each entry point below replaces one such call site
+ * (cited as file:line; DG = DiverGen/, D2 = BSGAL/third_party/CenterNet2/detectron2/,
+ * CN = BSGAL/third_party/CenterNet2/projects/CenterNet2/centernet/).  INTEGRATION.md shows the
+ * ctypes stub a reference maintainer would add at each site.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer into caller-owned memory unless marked (host);
+ *   - tensors are dense, row-major in the order written in the comment;
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing synchronises;
+ *   - return value: 0 on success, DGX_ERR_* (<0) on bad arguments, or -(hipError_t) - 1000 for a
+ *     launch failure.  No exceptions cross the boundary.
+ *   - bf16 = raw uint16_t bfloat16 bits.  dtype selectors: DGX_F32 / DGX_BF16.
+ */
+#ifndef DIVERGEN_HIP_H
+#define DIVERGEN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DGX_OK 0
+#define DGX_ERR_BAD_ARG (-1)
+#define DGX_ERR_UNSUPPORTED (-2)
+#define DGX_F32 0
+#define DGX_BF16 1
+
+/* library / device identification; returns the gfx arch string the kernels were built for */
+const char* dgx_build_arch(void);
+int dgx_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Swin window attention core.  Replaces WindowAttention.forward between the qkv Linear and the
+ * proj Linear: q*scale, q@k^T, + relative_position_bias_table[relative_position_index],
+ * + shift mask, softmax (fp32), @v, head merge.   DG/divergen/modeling/backbone/swintransformer.py:133-154
+ *
+ *   qkv    bf16 (B_, N, 3, nH, 32)   output of the qkv Linear, N = ws*ws, head_dim fixed at 32
+ *   table  f32  ((2ws-1)^2, nH)      relative_position_bias_table
+ *   region i8   (nW, N) or NULL      region id of each token of each window position; the additive
+ *                                    mask of swintransformer.py:368-387 is (region[i]!=region[j]) ? -100 : 0;
+ *                                    B_ % nW == 0, window b uses row b % nW.  NULL = W-MSA (no mask)
+ *   out    bf16 (B_, N, nH*32)
+ *   lse    f32  (B_, nH, N)          log-sum-exp of each score row (saved for backward)
+ * ws in {7, 12}.
+ */
+int dgx_window_attention_fwd(const void* qkv, const float* table, const int8_t* region,
+                             void* out, float* lse, int B_, int nW, int nH, int ws, float scale,
+                             void* stream);
+
+/* Backward of the above.  dqkv bf16 (B_,N,3,nH,32) is fully overwritten; dtable f32 ((2ws-1)^2,nH)
+ * is ACCUMULATED into (caller zeroes it).  `out`/`lse` are the forward results. */
+int dgx_window_attention_bwd(const void* qkv, const float* table, const int8_t* region,
+                             const void* out, const float* lse, const void* dout,
+                             void* dqkv, float* dtable, int B_, int nW, int nH, int ws, float scale,
+                             void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Window gather / scatter: zero-pad to a multiple of ws, cyclic shift by -shift, window_partition
+ * (gather), and the exact inverse window_reverse + roll(+shift) + crop (scatter).
+ * swintransformer.py:216-233 and :239-251.  dtype DGX_BF16 or DGX_F32.
+ *   x  (B, H, W, C)      xw (B*nWh*nWw, ws*ws, C),  nWh = ceil(H/ws), nWw = ceil(W/ws)
+ * gather: xw <- x (padding tokens = 0).  scatter: x <- xw (padding tokens dropped). */
+int dgx_window_gather(const void* x, void* xw, int B, int H, int W, int C, int ws, int shift,
+                      int dtype, void* stream);
+int dgx_window_scatter(const void* xw, void* x, int B, int H, int W, int C, int ws, int shift,
+                       int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * ROIAlign (aligned=True/False, adaptive sampling when sampling_ratio == 0).  Replaces
+ * torchvision.ops.roi_align at D2/layers/roi_align.py:58-65 (callers D2/modeling/poolers.py:185-245).
+ *   feat   (N, H, W, C) channels-last, dtype f32 or bf16
+ *   rois   f32 (R, 5) = (batch_index, x1, y1, x2, y2) in image coordinates
+ *   out    (R, C, ph, pw) if out_nhwc == 0 else (R, ph, pw, C), same dtype as feat
+ * Backward accumulates (atomic add) into grad_feat f32 (N,H,W,C), which the caller zeroes. */
+int dgx_roi_align_fwd(const void* feat, const float* rois, void* out, int N, int H, int W, int C,
+                      int R, float spatial_scale, int ph, int pw, int sampling_ratio, int aligned,
+                      int out_nhwc, int dtype, void* stream);
+int dgx_roi_align_bwd(const void* grad_out, const float* rois, float* grad_feat, int N, int H,
+                      int W, int C, int R, float spatial_scale, int ph, int pw, int sampling_ratio,
+                      int aligned, int out_nhwc, int dtype, void* stream);
+
+/* Multi-level ROIPooler in one launch: level assignment floor(4 + log2(sqrt(area)/224 + 1e-8))
+ * clamped to [min_level, max_level] (D2/modeling/poolers.py:22-58) followed by ROIAlignV2 on the
+ * chosen level.  feats/grad_feats: (host) array of num_levels device pointers; Hs/Ws (host) ints;
+ * level l has spatial_scale = 2^-(min_level + l).  levels_out i32 (R) optional (may be NULL). */
+int dgx_roi_pooler_fwd(const void* const* feats, const int* Hs, const int* Ws, int num_levels,
+                       int min_level, const float* rois, void* out, int32_t* levels_out, int N,
+                       int C, int R, int ph, int pw, int sampling_ratio, int out_nhwc, int dtype,
+                       void* stream);
+int dgx_roi_pooler_bwd(const void* grad_out, float* const* grad_feats, const int* Hs, const int* Ws,
+                       int num_levels, int min_level, const float* rois, int N, int C, int R, int ph,
+                       int pw, int sampling_ratio, int out_nhwc, int dtype, void* stream);
+
+/* GT-mask crop for the mask loss: ROIAlign(S x S, scale 1, ratio 0, aligned) on uint8/bool masks
+ * and `>= 0.5`, without materialising the fp32 mask.  Replaces BitMasks.crop_and_resize,
+ * D2/structures/masks.py:189-220.
+ *   masks u8 (M, H, W);  boxes f32 (R,4);  mask_idx i32 (R) row of `masks` for each box;
+ *   out u8 (R, S, S) in {0,1}. */
+int dgx_mask_crop(const uint8_t* masks, const float* boxes, const int32_t* mask_idx, uint8_t* out,
+                  int M, int H, int W, int R, int S, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Greedy NMS on score-sorted boxes.  Replaces torchvision.ops.nms behind batched_nms
+ * (D2/layers/nms.py:9-20, CN/modeling/layers/ml_nms.py:26).
+ *   boxes  f32 (n,4) ALREADY SORTED by descending score (stable);   iou_thr: suppress when IoU > thr
+ *   mask   u64 workspace, n * ceil(n/64) words
+ *   keep   u8 (n) out: 1 = kept;  num_keep i32 (1) out */
+int dgx_nms_sorted(const float* boxes, int n, float iou_thr, uint64_t* mask, uint8_t* keep,
+                   int32_t* num_keep, void* stream);
+int64_t dgx_nms_workspace_words(int n);
+
+/* pairwise IoU + Matcher in one pass (no M x N matrix): for every proposal the best GT and the
+ * label from the thresholds.  D2/structures/boxes.py:310-357 + D2/modeling/matcher.py:62-104
+ * (single threshold, labels [0,1], no low-quality matches), callers
+ * DG/divergen/modeling/roi_heads/detic_roi_heads.py:136-190,273-307.
+ *   gt f32 (M,4), props f32 (N,4) -> matched_idx i64 (N), matched_label i8 (N), max_iou f32 (N) (optional)
+ * M == 0: idx 0, label 0. */
+int dgx_iou_match(const float* gt, int M, const float* props, int N, float thr,
+                  int64_t* matched_idx, int8_t* matched_label, float* max_iou, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * CenterNet dense target assignment for one batch, no M x N temporaries.
+ * CN/modeling/dense_heads/centernet.py:338-436 (+ :505-530, :551-562, :576-592).
+ *   gt_boxes f32 (sum n_i, 4); gt_offsets i32 (B+1) prefix offsets per image
+ *   level_hw i32 (L,2) (h,w) per level; strides i32 (L); soi f32 (L,2) size ranges -- these three
+ *   are small HOST arrays (configuration, not data)
+ *   reg_targets f32 (M*B, 4) and heatmap f32 (M*B) in the reference's level-major layout
+ *   (level, image, y, x); reg already divided by stride, -1e8/stride where ignored. */
+int dgx_centernet_targets(const float* gt_boxes, const int32_t* gt_offsets, int B,
+                          const int32_t* level_hw, const int32_t* strides, const float* soi, int L,
+                          float delta, float min_radius, float* reg_targets, float* heatmap,
+                          void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Instance copy-paste compositor ('basic' blend).  Replaces the per-paste numpy passes of
+ * InstPool._cat_a_new_image / _copy_paste / get_bboxes / blend_image:
+ * DG/divergen/data/custom_build_copypaste_mapper.py:488-566, :79-92;
+ * DG/divergen/data/transforms/custom_cp_method.py:5-9.
+ *   image   u8 (3,H,W) in/out;  masks u8 (n0,H,W) original instance masks
+ *   boxes0  f32 (n0,4) boxes of the original instances as the mapper holds them BEFORE pasting
+ *   K pastes, applied in order 0..K-1: src_rgba u8 concatenated (h_k, w_k, 4) patches,
+ *   src_desc i32 (K,5) = (byte offset into src_rgba, h, w, x0, y0) (x0,y0 may be negative)
+ * outputs (object i < n0 = original i, object n0+k = paste k):
+ *   out_masks u8 (n0+K, H, W) final mask of every object (occluded pixels cleared)
+ *   out_boxes f32 (n0+K, 4), out_valid u8 (n0+K): 1 if the object survives the reference's
+ *   occlusion filter (|box delta| <= 10 in all coords, or area > 300) at every step and, for
+ *   pastes, has a non-empty footprint.  The host compacts by out_valid (order preserved).
+ *   stats i32 workspace of (n0+K)*(K+1)*5 + H*W words (per-object histograms + per-pixel cover bits).
+ *   K <= 31. */
+int dgx_copy_paste(uint8_t* image, const uint8_t* masks, const float* boxes0, int n0, int H, int W,
+                   const uint8_t* src_rgba, const int32_t* src_desc, int K, uint8_t* out_masks,
+                   float* out_boxes, uint8_t* out_valid, int32_t* stats, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused parameter update over a flat arena: per-element gradient value clip, AdamW, EMA lerp of
+ * the PRE-step weights (the reference updates the EMA before optimizer.step: DG/train_net.py:262-284),
+ * optional bf16 shadow copy of the new weights.  Replaces the ~400 per-tensor param groups of
+ * DG/divergen/custom_solver.py:19-77 + D2/solver/build.py:24-75 + DG/divergen/ema.py:49-58.
+ *   p,g,m,v,ema f32 (n); lr_scale f32 (n_seg) per-segment lr multiplier, seg_end i64 (n_seg)
+ *   exclusive end offsets (or both NULL);  grad_scale multiplies g first (1/loss_scale, 1/world);
+ *   found_inf i32 (1) optional: if *found_inf != 0 the step is skipped (GradScaler semantics);
+ *   p_bf16 optional. */
+int dgx_adamw_ema_step(float* p, const float* g, float* m, float* v, float* ema, void* p_bf16,
+                       int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                       float clip_value, float grad_scale, int step, float ema_decay,
+                       const float* lr_scale, const int64_t* seg_end, int n_seg,
+                       const int32_t* found_inf, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIVERGEN_HIP_H */

@@ -1,0 +1,276 @@
+"""GPU parity tests proper: every libdgx kernel through the C ABI vs the CPU oracle and the golden
+fixtures generated from the reference's own files.  Integer / index / byte outputs are compared
+bit-exactly; floating point with the tolerance stated at each assert."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from divergen_amd import layers as la  # noqa: E402
+from oracle import centernet as OC  # noqa: E402
+from oracle import compositor as OK  # noqa: E402
+from oracle import roi as OR  # noqa: E402
+from oracle import solver as OS  # noqa: E402
+from oracle import swin as OSW  # noqa: E402
+
+DEV = "cuda"
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+# ------------------------------------------------------------------ window attention
+def _attn_ref(qkv, table, region, nH, ws, scale):
+    """fp32 oracle math on the bf16-rounded inputs (same contract as the kernel)."""
+    B_, N, _ = qkv.shape
+    q, k, v = qkv.float().reshape(B_, N, 3, nH, 32).permute(2, 0, 3, 1, 4)
+    s = (q * scale) @ k.transpose(-2, -1)
+    idx = OSW.relative_position_index(ws)
+    s = s + table[idx.reshape(-1)].reshape(N, N, nH).permute(2, 0, 1)[None]
+    if region is not None:
+        nW = region.shape[0]
+        r = region.float()
+        m = (r[:, None, :] != r[:, :, None]).float() * -100.0
+        s = (s.reshape(B_ // nW, nW, nH, N, N) + m[None, :, None]).reshape(B_, nH, N, N)
+    a = torch.softmax(s, -1)
+    return (a @ v).transpose(1, 2).reshape(B_, N, nH * 32)
+
+
+@pytest.mark.parametrize("ws,nH,B_,nW", [(7, 3, 8, 4), (12, 2, 6, 3), (12, 6, 19, 1), (7, 1, 3, 3)])
+def test_window_attention_fwd_bwd(ws, nH, B_, nW):
+    g = torch.Generator().manual_seed(ws * 100 + nH)
+    N = ws * ws
+    qkv = bf(torch.randn(B_, N, 3 * nH * 32, generator=g) * 1.5)
+    table = torch.randn((2 * ws - 1) ** 2, nH, generator=g)
+    region = torch.randint(0, 3, (nW, N), generator=g, dtype=torch.int8) if nW > 1 else None
+    if region is not None:
+        region[0] = 0
+    scale = 32 ** -0.5
+    qr = qkv.clone().float().requires_grad_(True)
+    tr = table.clone().requires_grad_(True)
+    ref = _attn_ref(qr, tr, region, nH, ws, scale)
+    go = bf(torch.randn(B_, N, nH * 32, generator=g))
+    ref.backward(go.float())
+
+    qd = qkv.to(DEV).requires_grad_(True)
+    td = table.to(DEV).requires_grad_(True)
+    out = la.window_attention_core(qd, td, region.to(DEV) if region is not None else None, nW, nH, ws, scale)
+    out.backward(go.to(DEV))
+    torch.cuda.synchronize()
+    # bf16 output of O(1) values: 1 bf16 ulp (2^-8 relative) + softmax bf16 P rounding
+    torch.testing.assert_close(out.float().cpu(), ref.detach(), atol=2e-2, rtol=2e-2)
+    torch.testing.assert_close(qd.grad.float().cpu(), qr.grad, atol=3e-2, rtol=3e-2)
+    torch.testing.assert_close(td.grad.cpu(), tr.grad, atol=5e-2, rtol=3e-2)
+
+
+@pytest.mark.parametrize("ws", [7, 12])
+def test_window_attention_vs_reference_golden(golden, ws):
+    """Golden from the reference's own WindowAttention (fp32); kernel consumes its qkv in bf16."""
+    g = golden("swin_attn_w%d" % ws)
+    x, mask = T(g["x"]), T(g["mask"])
+    qkv = torch.nn.functional.linear(x, T(g["qkv_w"]), T(g["qkv_b"]))
+    # recover region ids from the golden's 0/-100 mask rows: tokens with mask[i, j] == 0 share a region
+    nW, N, _ = mask.shape
+    region = torch.zeros(nW, N, dtype=torch.int8)
+    for w in range(nW):
+        seen = {}
+        for i in range(N):
+            key = tuple((mask[w, i] == 0).tolist())
+            region[w, i] = seen.setdefault(key, len(seen))
+    out = la.window_attention_core(bf(qkv).to(DEV), T(g["table"]).to(DEV), region.to(DEV), nW, 2, ws, 32 ** -0.5)
+    y = torch.nn.functional.linear(out.float().cpu(), T(g["proj_w"]), T(g["proj_b"]))
+    torch.testing.assert_close(y, T(g["out"]), atol=3e-2, rtol=3e-2)
+
+
+@pytest.mark.parametrize("B,H,W,C,ws,shift,dt", [(2, 10, 13, 64, 7, 3, torch.bfloat16), (1, 14, 25, 32, 12, 6, torch.float32),
+                                                  (2, 14, 14, 64, 7, 0, torch.bfloat16), (1, 24, 24, 8, 12, 0, torch.float32)])
+def test_window_gather_scatter_exact(B, H, W, C, ws, shift, dt):
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, H * W, C, generator=g).to(dt)
+    xp = torch.nn.functional.pad(x.reshape(B, H, W, C), (0, 0, 0, (ws - W % ws) % ws, 0, (ws - H % ws) % ws))
+    if shift:
+        xp = torch.roll(xp, (-shift, -shift), (1, 2))
+    ref = OSW.partition(xp, ws)
+    got = la.window_gather(x.to(DEV), H, W, ws, shift)
+    assert torch.equal(got.cpu(), ref)
+    Hp, Wp = xp.shape[1], xp.shape[2]
+    w = torch.randn(ref.shape, generator=g).to(dt)
+    back = OSW.unpartition(w, ws, Hp, Wp)
+    if shift:
+        back = torch.roll(back, (shift, shift), (1, 2))
+    back = back[:, :H, :W].reshape(B, H * W, C)
+    assert torch.equal(la.window_scatter(w.to(DEV), B, H, W, ws, shift).cpu(), back)
+
+
+# ------------------------------------------------------------------ ROIAlign / pooler / mask crop
+def _rand_rois(g, n, B, H, W):
+    xy = torch.rand(n, 2, generator=g) * torch.tensor([W * 0.7, H * 0.7])
+    wh = torch.rand(n, 2, generator=g) * torch.tensor([W * 0.6, H * 0.6]) + 0.5
+    b = torch.randint(0, B, (n, 1), generator=g).float()
+    return torch.cat([b, xy, xy + wh], 1)
+
+
+@pytest.mark.parametrize("nhwc", [False, True])
+def test_roi_align_kat_and_oracle(nhwc):
+    inp = torch.arange(25, dtype=torch.float32).reshape(1, 1, 5, 5)
+    rois = torch.tensor([[0, 1, 1, 3, 3]], dtype=torch.float32)
+    got = la.roi_align(inp.to(DEV), rois.to(DEV), 1.0, 4, 0, True, nhwc).cpu()[0, 0]
+    # D2T/layers/test_roi_align.py:36-41
+    assert np.allclose(got.numpy(), [[4.5, 5.0, 5.5, 6.0], [7.0, 7.5, 8.0, 8.5], [9.5, 10.0, 10.5, 11.0], [12.0, 12.5, 13.0, 13.5]])
+    g = torch.Generator().manual_seed(21)
+    feat = torch.randn(2, 256, 25, 34, generator=g)
+    rois = _rand_rois(g, 64, 2, 25 * 8, 34 * 8)
+    ref = OR.roi_align(feat, rois, 0.125, 7, 0, True)
+    fd = feat.to(DEV).requires_grad_(True)
+    got = la.roi_align(fd, rois.to(DEV), 0.125, 7, 0, True, nhwc)
+    # same fp32 op sequence -> only the tap accumulation order inside a 4-tap sum may differ: 1e-5
+    torch.testing.assert_close(got.cpu(), ref, atol=1e-5, rtol=1e-5)
+    go = torch.randn(ref.shape, generator=g)
+    got.backward(go.to(DEV))
+    gref = OR.roi_align_backward(go, rois, 0.125, tuple(feat.shape), 0, True)
+    torch.testing.assert_close(fd.grad.cpu(), gref, atol=1e-4, rtol=1e-4)  # atomic-add order
+    # empty roi list / empty box (D2T/layers/test_roi_align.py:111-128)
+    assert la.roi_align(feat.to(DEV), torch.zeros(0, 5, device=DEV), 0.125, 7).shape == (0, 256, 7, 7)
+    e = la.roi_align(feat.to(DEV), torch.tensor([[0, 3, 3, 3, 3.0]], device=DEV), 0.125, 7)
+    assert (e == 0).all()
+
+
+def test_roi_pooler_levels_bf16_and_mask_pool():
+    g = torch.Generator().manual_seed(22)
+    feats = [torch.randn(2, 256, 64 // s, 80 // s, generator=g) for s in (1, 2, 4)]
+    rois = _rand_rois(g, 200, 2, 512, 640)
+    rois[0, 1:] = torch.tensor([10.0, 10.0, 234.0, 234.0])   # sqrt(area) == 224 exactly -> level 4
+    rois[1, 1:] = torch.tensor([10.0, 10.0, 122.0, 122.0])   # 112 -> level 3
+    rois[2, 1:] = torch.tensor([0.0, 0.0, 448.0, 448.0])     # 448 -> level 5
+    scales = (1 / 8, 1 / 16, 1 / 32)
+    boxes = [rois[rois[:, 0] == b][:, 1:] for b in range(2)]
+    # oracle pools per image list; reorder rois to (image 0, image 1)
+    rois_sorted = torch.cat([torch.cat([torch.full((len(b), 1), float(i)), b], 1) for i, b in enumerate(boxes)])
+    ref = OR.roi_pooler(feats, boxes, 14, scales)
+    got = la.roi_pooler([f.to(DEV) for f in feats], rois_sorted.to(DEV), 14, scales, out_nhwc=True)
+    torch.testing.assert_close(got.cpu(), ref, atol=1e-5, rtol=1e-5)
+    got16 = la.roi_pooler([bf(f).to(DEV) for f in feats], rois_sorted.to(DEV), 7, scales)
+    ref16 = OR.roi_pooler([bf(f).float() for f in feats], boxes, 7, scales)
+    torch.testing.assert_close(got16.float().cpu(), ref16, atol=2e-2, rtol=1e-2)  # bf16 output rounding
+
+
+def test_mask_crop_bit_exact():
+    g = torch.Generator().manual_seed(23)
+    H, W, M = 200, 260, 6
+    yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    masks = torch.zeros(M, H, W, dtype=torch.bool)
+    for i in range(M):
+        cx, cy = torch.rand(2, generator=g) * torch.tensor([W, H])
+        rx, ry = torch.rand(2, generator=g) * 60 + 5
+        masks[i] = ((xx - cx) / rx) ** 2 + ((yy - cy) / ry) ** 2 <= 1
+    R = 40
+    idx = torch.randint(0, M, (R,), generator=g)
+    boxes = _rand_rois(g, R, 1, H, W)[:, 1:]
+    ref = OR.crop_and_resize(masks[idx], boxes, 28)
+    got = la.mask_crop(masks.to(DEV), boxes.to(DEV), idx.to(DEV), 28)
+    assert torch.equal(got.cpu(), ref)
+
+
+# ------------------------------------------------------------------ NMS / match
+def test_nms_bit_exact_and_batched():
+    g = torch.Generator().manual_seed(31)
+    for n, thr in ((1, 0.5), (65, 0.5), (700, 0.9), (3000, 0.6)):
+        xy = torch.rand(n, 2, generator=g) * 300
+        wh = torch.rand(n, 2, generator=g) * 80 + 2
+        boxes = torch.cat([xy, xy + wh], 1)
+        scores = torch.rand(n, generator=g)
+        scores[: n // 3] = scores[n // 2: n // 2 + n // 3]  # ties
+        ref = OR.nms(boxes, scores, thr)
+        got = la.nms(boxes.to(DEV), scores.to(DEV), thr)
+        assert got.cpu().tolist() == ref.tolist()
+    idxs = torch.randint(0, 4, (n,), generator=g)
+    ref = OR.batched_nms(boxes, scores, idxs, 0.5)
+    got = la.batched_nms(boxes.to(DEV), scores.to(DEV), idxs.to(DEV), 0.5)
+    assert got.cpu().tolist() == ref.tolist()
+    assert la.nms(torch.zeros(0, 4, device=DEV), torch.zeros(0, device=DEV), 0.5).numel() == 0
+
+
+def test_iou_match_bit_exact(golden):
+    g = golden("roi_match")
+    gt, pr = T(g["gt"]), T(g["proposals"])
+    for thr in (0.6, 0.7, 0.8):
+        idx, lab, miou = la.iou_match(gt.to(DEV), pr.to(DEV), thr, return_iou=True)
+        assert torch.equal(idx.cpu(), T(g["match_idx_%d" % int(thr * 10)]))
+        assert torch.equal(lab.cpu(), T(g["match_lab_%d" % int(thr * 10)]))
+        assert torch.equal(miou.cpu(), T(g["iou"]).max(0)[0])
+    idx, lab = la.iou_match(torch.zeros(0, 4, device=DEV), pr.to(DEV), 0.6)
+    assert (idx == 0).all() and (lab == 0).all()
+
+
+# ------------------------------------------------------------------ CenterNet targets
+def test_centernet_targets(golden):
+    g = golden("centernet_targets")
+    H, W, st = int(g["H"]), int(g["W"]), [int(s) for s in g["strides"]]
+    shapes = [(-(-H // s), -(-W // s)) for s in st]
+    for a, b, kr, kh in ((T(g["gt0_boxes"]), torch.zeros(0, 4), "reg_targets", "hms"),
+                         (T(g["gt2a_boxes"]), T(g["gt2b_boxes"]), "reg2", "hm2")):
+        reg, hm = la.centernet_targets([a.to(DEV), b.to(DEV)], shapes, st, OC.SOI)
+        assert torch.equal(reg.cpu(), T(g[kr]))                       # add/sub/div only: bit-exact
+        torch.testing.assert_close(hm.cpu(), T(g[kh]), atol=1e-6, rtol=1e-5)  # expf last ulp
+
+
+# ------------------------------------------------------------------ compositor
+def test_copy_paste_bit_exact(golden):
+    g = golden("compositor")
+    pastes = [(g["src%d_rgba" % k], int(g["src%d_xy" % k][0]), int(g["src%d_xy" % k][1]), g["src%d_label" % k])
+              for k in range(int(g["K"]))]
+    out = la.copy_paste(T(g["dst_image"]).to(DEV), T(g["dst_masks"]).to(DEV), T(g["dst_boxes"]).to(DEV),
+                        T(g["dst_labels"]).to(DEV), pastes)
+    assert np.array_equal(out["image"].cpu().numpy(), g["out_image"])
+    assert np.array_equal(out["masks"].cpu().numpy(), g["out_masks"])
+    assert np.array_equal(out["boxes"].cpu().numpy(), g["out_boxes"])
+    assert np.array_equal(out["labels"].cpu().numpy(), g["out_labels"])
+    assert np.array_equal(out["source"].cpu().numpy(), g["out_source"])
+
+
+def test_copy_paste_random_vs_oracle_full_size():
+    rng = np.random.default_rng(7)
+    H = W = 1024
+    n = 10
+    yy, xx = np.mgrid[0:H, 0:W]
+    masks = np.zeros((n, H, W), np.uint8)
+    for i in range(n):
+        cx, cy, rx, ry = rng.uniform(0, W), rng.uniform(0, H), rng.uniform(8, 200), rng.uniform(8, 200)
+        masks[i] = (((xx - cx) / rx) ** 2 + ((yy - cy) / ry) ** 2) <= 1
+    img = rng.integers(0, 256, (3, H, W), dtype=np.uint8)
+    boxes = OK.get_bboxes(masks)
+    labels = rng.integers(0, 1203, n).astype(np.int64)
+    pastes = []
+    for k in range(19):
+        s = int(rng.uniform(51, 307))
+        rgba = rng.integers(0, 256, (s, s, 4), dtype=np.uint8)
+        y2, x2 = np.mgrid[0:s, 0:s]
+        rgba[..., 3] *= ((((x2 - s / 2) / (s / 2)) ** 2 + ((y2 - s / 2) / (s / 2)) ** 2) <= 1).astype(np.uint8)
+        pastes.append((rgba, int(rng.integers(-s // 2, W - s // 2)), int(rng.integers(-s // 2, H - s // 2)), 2000 + k))
+    ref = OK.composite(img, masks, boxes, labels, pastes)
+    out = la.copy_paste(T(img).to(DEV), T(masks).to(DEV), T(boxes).to(DEV), T(labels).to(DEV), pastes)
+    for k in ("image", "masks", "boxes", "labels", "source"):
+        assert np.array_equal(out[k].cpu().numpy(), ref[k]), k
+
+
+# ------------------------------------------------------------------ optimizer
+def test_adamw_ema_step_vs_oracle():
+    g = torch.Generator().manual_seed(41)
+    n = 4 * 1000
+    p0 = torch.randn(n, generator=g)
+    p, m, v, ema = p0.clone(), torch.zeros(n), torch.zeros(n), p0.clone()
+    pd, md, vd, ed = p0.to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV), p0.to(DEV)
+    for step in range(1, 6):
+        gr = torch.randn(n, generator=g) * 3
+        OS.ema_update(ema, p, 0.999)
+        OS.adamw_clip_step(p, gr, m, v, step, 1e-3, wd=1e-4, clip=1.0)
+        la.adamw_ema_step(pd, gr.to(DEV), md, vd, ed, step, 1e-3, weight_decay=1e-4, clip_value=1.0, ema_decay=0.999)
+    torch.testing.assert_close(pd.cpu(), p, atol=1e-6, rtol=1e-5)
+    torch.testing.assert_close(ed.cpu(), ema, atol=1e-6, rtol=1e-6)
+    torch.testing.assert_close(vd.cpu(), v, atol=1e-7, rtol=1e-5)

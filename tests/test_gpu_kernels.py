@@ -64,9 +64,12 @@ def test_window_attention_fwd_bwd(ws, nH, B_, nW):
     out.backward(go.to(DEV))
     torch.cuda.synchronize()
     # bf16 output of O(1) values: 1 bf16 ulp (2^-8 relative) + softmax bf16 P rounding
-    torch.testing.assert_close(out.float().cpu(), ref.detach(), atol=2e-2, rtol=2e-2)
-    torch.testing.assert_close(qd.grad.float().cpu(), qr.grad, atol=3e-2, rtol=3e-2)
-    torch.testing.assert_close(td.grad.cpu(), tr.grad, atol=5e-2, rtol=3e-2)
+    # bf16 I/O, bf16 P/dS operands, fp32 accumulation: error budget 1.5% of the tensor's scale
+    def close(a, b, frac=0.015):
+        assert (a - b).abs().max() <= frac * b.abs().max(), ((a - b).abs().max(), b.abs().max())
+    close(out.float().cpu(), ref.detach())
+    close(qd.grad.float().cpu(), qr.grad)
+    close(td.grad.cpu(), tr.grad)
 
 
 @pytest.mark.parametrize("ws", [7, 12])

@@ -1,0 +1,127 @@
+// 3x3 (pad 1, stride 1|2) im2col / col2im on channels-last tensors for gfx950.  HBM-bound index
+// copies, 16 bytes per lane, consecutive lanes walk the channel dimension so every tap is a
+// contiguous C*esize-byte run.  The contraction itself runs as a plain library GEMM on the column
+// matrix; these two kernels replace MIOpen, whose bf16 NHWC path fell back to naive direct
+// convolution on this image (profiles/r01_smoke_swinT_miopen_kernel_stats.csv).
+//   col[(n,oy,ox)][(ky*3+kx)*C + c] = x[n][oy*s-1+ky][ox*s-1+kx][c]   (0 outside)
+//   dx[n][y][x][c] = sum over the <=9 (ky,kx,oy,ox) that read (y,x) of dcol[...]   (gather form)
+#include "dgx_common.h"
+
+__global__ __launch_bounds__(256) void im2col3x3_kernel(const uint4* __restrict__ x, uint4* __restrict__ col, int N, int H,
+                                                        int W, int vecC, int Ho, int Wo, int stride) {
+    const int64_t total = (int64_t)N * Ho * Wo * 9 * vecC;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int v = (int)(i % vecC);
+        int64_t t = i / vecC;
+        const int tap = (int)(t % 9);
+        t /= 9;
+        const int ox = (int)(t % Wo);
+        t /= Wo;
+        const int oy = (int)(t % Ho);
+        const int n = (int)(t / Ho);
+        const int iy = oy * stride - 1 + tap / 3, ix = ox * stride - 1 + tap % 3;
+        uint4 val = {0u, 0u, 0u, 0u};
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) val = x[(((int64_t)n * H + iy) * W + ix) * vecC + v];
+        col[i] = val;
+    }
+}
+
+template <typename T> struct V4;  // 16-byte vector of T with fp32 accumulate
+template <> struct V4<float> {
+    static constexpr int N = 4;
+    static __device__ void add(float* acc, const uint4& v) {
+        acc[0] += __uint_as_float(v.x); acc[1] += __uint_as_float(v.y);
+        acc[2] += __uint_as_float(v.z); acc[3] += __uint_as_float(v.w);
+    }
+    static __device__ uint4 pack(const float* a) {
+        return make_uint4(__float_as_uint(a[0]), __float_as_uint(a[1]), __float_as_uint(a[2]), __float_as_uint(a[3]));
+    }
+};
+template <> struct V4<uint16_t> {
+    static constexpr int N = 8;
+    static __device__ void add(float* acc, const uint4& v) {
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            acc[2 * k] += __uint_as_float(w[k] << 16);
+            acc[2 * k + 1] += __uint_as_float(w[k] & 0xffff0000u);
+        }
+    }
+    static __device__ uint4 pack(const float* a) {
+        return make_uint4(pack_bf2(a[0], a[1]), pack_bf2(a[2], a[3]), pack_bf2(a[4], a[5]), pack_bf2(a[6], a[7]));
+    }
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void col2im3x3_kernel(const uint4* __restrict__ dcol, uint4* __restrict__ dx, int N, int H,
+                                                        int W, int vecC, int Ho, int Wo, int stride) {
+    const int64_t total = (int64_t)N * H * W * vecC;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int v = (int)(i % vecC);
+        int64_t t = i / vecC;
+        const int xx = (int)(t % W);
+        t /= W;
+        const int yy = (int)(t % H);
+        const int n = (int)(t / H);
+        float acc[V4<T>::N];
+#pragma unroll
+        for (int k = 0; k < V4<T>::N; ++k) acc[k] = 0.f;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int ty = yy + 1 - ky;
+            if (ty < 0 || ty % stride) continue;
+            const int oy = ty / stride;
+            if (oy >= Ho) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int tx = xx + 1 - kx;
+                if (tx < 0 || tx % stride) continue;
+                const int ox = tx / stride;
+                if (ox >= Wo) continue;
+                V4<T>::add(acc, dcol[((((int64_t)n * Ho + oy) * Wo + ox) * 9 + ky * 3 + kx) * vecC + v]);
+            }
+        }
+        dx[i] = V4<T>::pack(acc);
+    }
+}
+
+static int conv_dims(int H, int W, int stride, int& Ho, int& Wo) {
+    if (stride != 1 && stride != 2) return DGX_ERR_UNSUPPORTED;
+    Ho = (H + 2 - 3) / stride + 1;
+    Wo = (W + 2 - 3) / stride + 1;
+    return DGX_OK;
+}
+
+extern "C" int dgx_im2col3x3(const void* x, void* col, int N, int H, int W, int C, int stride, int dtype, void* stream) {
+    if (N <= 0 || H <= 0 || W <= 0) return DGX_OK;
+    const int es = dtype == DGX_BF16 ? 2 : 4;
+    int Ho, Wo;
+    if (conv_dims(H, W, stride, Ho, Wo)) return DGX_ERR_UNSUPPORTED;
+    if (!x || !col || (C * es) % 16) return DGX_ERR_BAD_ARG;
+    const int vecC = C * es / 16;
+    const int64_t total = (int64_t)N * Ho * Wo * 9 * vecC;
+    const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(im2col3x3_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint4*)x, (uint4*)col, N, H,
+                       W, vecC, Ho, Wo, stride);
+    DGX_LAUNCH_CHECK();
+    return DGX_OK;
+}
+
+extern "C" int dgx_col2im3x3(const void* dcol, void* dx, int N, int H, int W, int C, int stride, int dtype, void* stream) {
+    if (N <= 0 || H <= 0 || W <= 0) return DGX_OK;
+    const int es = dtype == DGX_BF16 ? 2 : 4;
+    int Ho, Wo;
+    if (conv_dims(H, W, stride, Ho, Wo)) return DGX_ERR_UNSUPPORTED;
+    if (!dcol || !dx || (C * es) % 16) return DGX_ERR_BAD_ARG;
+    const int vecC = C * es / 16;
+    const int64_t total = (int64_t)N * H * W * vecC;
+    const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    if (dtype == DGX_BF16)
+        hipLaunchKernelGGL(col2im3x3_kernel<uint16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint4*)dcol,
+                           (uint4*)dx, N, H, W, vecC, Ho, Wo, stride);
+    else
+        hipLaunchKernelGGL(col2im3x3_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint4*)dcol,
+                           (uint4*)dx, N, H, W, vecC, Ho, Wo, stride);
+    DGX_LAUNCH_CHECK();
+    return DGX_OK;
+}

@@ -1,0 +1,112 @@
+"""Convolutions of the dense / RoI heads as GEMMs over channels-last tensors.
+
+  conv3x3      im2col (HIP) + library GEMM; backward = GEMM + col2im (HIP) and col^T @ dy
+  conv1x1      a Linear over NHWC pixels
+  patch_embed  4x4 stride-4 conv = Linear over unfolded 4x4x3 patches (a pure view)
+  deconv2x2    ConvTranspose2d(k=2,s=2) = Linear C -> 4*Cout per pixel + pixel shuffle (a view)
+
+Weights keep nn.Conv2d / nn.ConvTranspose2d layouts so reference checkpoints load unchanged.
+Inputs and outputs are logical (N,C,H,W) tensors in channels_last memory format (NHWC storage)."""
+import torch
+import torch.nn.functional as F
+
+from .. import _lib as L
+
+
+def _nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def _im2col(x_nhwc, stride):
+    N, H, W, C = x_nhwc.shape
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    col = torch.empty(N * Ho * Wo, 9 * C, dtype=x_nhwc.dtype, device=x_nhwc.device)
+    L.check(L.lib().dgx_im2col3x3(L.ptr(x_nhwc), L.ptr(col), N, H, W, C, stride, L.dtype_code(x_nhwc), L.stream()),
+            "dgx_im2col3x3")
+    return col, Ho, Wo
+
+
+class _Conv3x3(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride):
+        # x: NHWC contiguous (N,H,W,C); weight (Cout,Cin,3,3); compute dtype = x.dtype
+        N, H, W, C = x.shape
+        wm = weight.to(x.dtype).permute(2, 3, 1, 0).reshape(9 * C, -1)        # (ky,kx,ci) x co
+        col, Ho, Wo = _im2col(x, stride)
+        y = torch.addmm(bias.to(x.dtype), col, wm) if bias is not None else col @ wm
+        ctx.save_for_backward(col, wm)
+        ctx.cfg = (N, H, W, C, Ho, Wo, stride, weight.dtype, bias is not None, weight.shape)
+        return y.view(N, Ho, Wo, -1)
+
+    @staticmethod
+    def backward(ctx, gy):
+        col, wm = ctx.saved_tensors
+        N, H, W, C, Ho, Wo, stride, wdt, has_bias, wshape = ctx.cfg
+        g2 = gy.reshape(N * Ho * Wo, -1).to(col.dtype)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            dcol = (g2 @ wm.t()).contiguous()
+            gx = torch.empty(N, H, W, C, dtype=col.dtype, device=col.device)
+            L.check(L.lib().dgx_col2im3x3(L.ptr(dcol), L.ptr(gx), N, H, W, C, stride, L.dtype_code(gx), L.stream()),
+                    "dgx_col2im3x3")
+        if ctx.needs_input_grad[1]:
+            gw = (col.t() @ g2).view(3, 3, C, -1).permute(3, 2, 0, 1).to(wdt)
+        if has_bias and ctx.needs_input_grad[2]:
+            gb = g2.float().sum(0).to(wdt)
+        return gx, gw, gb, None
+
+
+def _compute_dtype(x):
+    return torch.bfloat16 if torch.is_autocast_enabled() else x.dtype
+
+
+def conv3x3(x, weight, bias=None, stride=1):
+    """x logical (N,C,H,W) -> logical (N,Cout,Ho,Wo), NHWC storage both sides."""
+    xh = _nhwc(x).to(_compute_dtype(x))
+    with torch.autocast("cuda", enabled=False):
+        y = _Conv3x3.apply(xh, weight, bias, stride)
+    return y.permute(0, 3, 1, 2)
+
+
+def conv1x1(x, weight, bias=None):
+    xh = _nhwc(x)
+    y = F.linear(xh, weight.view(weight.shape[0], -1), bias)
+    return y.permute(0, 3, 1, 2)
+
+
+def patch_embed4x4(x, weight, bias, patch=4):
+    """x (B,3,H,W) any layout, H,W multiples of `patch` -> tokens (B, H/4*W/4, embed)."""
+    B, Cin, H, W = x.shape
+    Hp, Wp = H // patch, W // patch
+    u = x.reshape(B, Cin, Hp, patch, Wp, patch).permute(0, 2, 4, 1, 3, 5).reshape(B, Hp * Wp, Cin * patch * patch)
+    return F.linear(u, weight.reshape(weight.shape[0], -1), bias), Hp, Wp
+
+
+def deconv2x2(x, weight, bias):
+    """ConvTranspose2d(kernel 2, stride 2): weight (Cin,Cout,2,2)."""
+    xh = _nhwc(x)
+    N, H, W, Cin = xh.shape
+    Cout = weight.shape[1]
+    wm = weight.permute(2, 3, 1, 0).reshape(4 * Cout, Cin)                   # (dy,dx,co) x ci
+    y = F.linear(xh, wm, bias.repeat(4) if bias is not None else None)        # (N,H,W,4*Cout)
+    y = y.view(N, H, W, 2, 2, Cout).permute(0, 1, 3, 2, 4, 5).reshape(N, 2 * H, 2 * W, Cout)
+    return y.permute(0, 3, 1, 2)
+
+
+class Conv2d(torch.nn.Conv2d):
+    """nn.Conv2d parameters, GEMM-path forward (1x1, and 3x3 pad 1 stride 1|2)."""
+
+    def forward(self, x):
+        k, s, p = self.kernel_size, self.stride, self.padding
+        if k == (1, 1) and s == (1, 1) and p == (0, 0):
+            return conv1x1(x, self.weight, self.bias)
+        if k == (3, 3) and p == (1, 1) and s[0] == s[1] and s[0] in (1, 2) and self.groups == 1:
+            return conv3x3(x, self.weight, self.bias, s[0])
+        raise L.DgxError("Conv2d %s/%s/%s is not on the hot path and has no HIP implementation" % (k, s, p))
+
+
+class ConvTranspose2d(torch.nn.ConvTranspose2d):
+    def forward(self, x):
+        if self.kernel_size == (2, 2) and self.stride == (2, 2) and self.padding == (0, 0):
+            return deconv2x2(x, self.weight, self.bias)
+        raise L.DgxError("only ConvTranspose2d(k=2, s=2) is built")

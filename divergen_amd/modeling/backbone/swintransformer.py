@@ -1,0 +1,261 @@
+"""Swin backbone with HIP window ops.  Module / parameter names follow the reference so its
+checkpoints load: DG/divergen/modeling/backbone/swintransformer.py (classes :28-634, size table
+:636-693, builders :695-731).
+
+Differences that are deliberate (MI355X-first):
+  * pad + roll + window_partition (and the inverse) are ONE index-mapped copy each (libdgx
+    dgx_window_gather/scatter) instead of 4 full-tensor passes;
+  * QK^T + rel-pos bias + shift mask + softmax + PV is ONE MFMA kernel per block
+    (dgx_window_attention_fwd/bwd); the (B_,nH,N,N) score tensor never exists in HBM;
+  * the SW-MSA mask is never materialised: an int8 region id per token (cached per (H,W)) is all
+    the kernel needs.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import BACKBONE_REGISTRY, ShapeSpec
+from ...layers.conv_ops import patch_embed4x4
+from ...layers import shift_regions, window_attention_core, window_gather, window_scatter
+
+
+def trunc_normal_(t, std=0.02):
+    return nn.init.trunc_normal_(t, std=std)
+
+
+class DropPath(nn.Module):
+    """timm==0.4.9 DropPath: per-sample Bernoulli keep, scale by 1/keep (not vendored by the reference)."""
+
+    def __init__(self, drop_prob=0.0):
+        super().__init__()
+        self.drop_prob = drop_prob
+
+    def forward(self, x):
+        if self.drop_prob == 0.0 or not self.training:
+            return x
+        keep = 1 - self.drop_prob
+        mask = keep + torch.rand((x.shape[0],) + (1,) * (x.ndim - 1), dtype=x.dtype, device=x.device)
+        return x.div(keep) * mask.floor_()
+
+
+class Mlp(nn.Module):
+    def __init__(self, in_features, hidden_features=None, out_features=None, drop=0.0):
+        super().__init__()
+        self.fc1 = nn.Linear(in_features, hidden_features or in_features)
+        self.act = nn.GELU()
+        self.fc2 = nn.Linear(hidden_features or in_features, out_features or in_features)
+
+    def forward(self, x):
+        return self.fc2(self.act(self.fc1(x)))
+
+
+class WindowAttention(nn.Module):
+    def __init__(self, dim, window_size, num_heads, qkv_bias=True, qk_scale=None):
+        super().__init__()
+        self.dim, self.window_size, self.num_heads = dim, window_size, num_heads
+        head_dim = dim // num_heads
+        if head_dim != 32:
+            raise ValueError("libdgx window attention is built for head_dim 32 (every Swin size); got %d" % head_dim)
+        self.scale = qk_scale or head_dim ** -0.5
+        ws = window_size[0]
+        self.relative_position_bias_table = nn.Parameter(torch.zeros((2 * ws - 1) * (2 * ws - 1), num_heads))
+        r = torch.arange(ws)
+        ii, jj = torch.meshgrid(r, r, indexing="ij")
+        pos = torch.stack([ii.reshape(-1), jj.reshape(-1)])
+        rel = pos[:, :, None] - pos[:, None, :]
+        self.register_buffer("relative_position_index", (rel[0] + ws - 1) * (2 * ws - 1) + (rel[1] + ws - 1))
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.proj = nn.Linear(dim, dim)
+        trunc_normal_(self.relative_position_bias_table, std=0.02)
+
+    def forward(self, x, region=None, nW=1):
+        """x (B_, N, C); region int8 (nW, N) or None (= the reference's `mask` argument)."""
+        qkv = self.qkv(x)
+        o = window_attention_core(qkv.to(torch.bfloat16), self.relative_position_bias_table, region, nW,
+                                  self.num_heads, self.window_size[0], self.scale)
+        return self.proj(o.to(x.dtype) if not torch.is_autocast_enabled() else o)
+
+
+class SwinTransformerBlock(nn.Module):
+    def __init__(self, dim, num_heads, window_size=7, shift_size=0, mlp_ratio=4.0, qkv_bias=True, qk_scale=None,
+                 drop_path=0.0):
+        super().__init__()
+        assert 0 <= shift_size < window_size
+        self.dim, self.num_heads, self.window_size, self.shift_size = dim, num_heads, window_size, shift_size
+        self.norm1 = nn.LayerNorm(dim)
+        self.attn = WindowAttention(dim, (window_size, window_size), num_heads, qkv_bias, qk_scale)
+        self.drop_path = DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
+        self.norm2 = nn.LayerNorm(dim)
+        self.mlp = Mlp(dim, int(dim * mlp_ratio))
+        self.H = self.W = None
+
+    def forward(self, x, region):
+        B, Ltok, C = x.shape
+        H, W = self.H, self.W
+        assert Ltok == H * W, "input feature has wrong size"
+        ws, sh = self.window_size, self.shift_size
+        h = self.norm1(x)
+        if torch.is_autocast_enabled():
+            h = h.to(torch.bfloat16)
+        xw = window_gather(h, H, W, ws, sh)
+        nW = (-(-H // ws)) * (-(-W // ws))
+        aw = self.attn(xw, region if sh > 0 else None, nW)
+        a = window_scatter(aw, B, H, W, ws, sh)
+        x = x + self.drop_path(a)
+        return x + self.drop_path(self.mlp(self.norm2(x)))
+
+
+class PatchMerging(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.dim = dim
+        self.reduction = nn.Linear(4 * dim, 2 * dim, bias=False)
+        self.norm = nn.LayerNorm(4 * dim)
+
+    def forward(self, x, H, W):
+        B, Ltok, C = x.shape
+        x = x.view(B, H, W, C)
+        if H % 2 or W % 2:
+            x = F.pad(x, (0, 0, 0, W % 2, 0, H % 2))
+        x = torch.cat([x[:, 0::2, 0::2], x[:, 1::2, 0::2], x[:, 0::2, 1::2], x[:, 1::2, 1::2]], -1)
+        return self.reduction(self.norm(x.view(B, -1, 4 * C)))
+
+
+class BasicLayer(nn.Module):
+    def __init__(self, dim, depth, num_heads, window_size=7, mlp_ratio=4.0, qkv_bias=True, qk_scale=None,
+                 drop_path=0.0, downsample=None, use_checkpoint=False):
+        super().__init__()
+        self.window_size, self.shift_size, self.depth, self.use_checkpoint = window_size, window_size // 2, depth, use_checkpoint
+        self.blocks = nn.ModuleList([
+            SwinTransformerBlock(dim, num_heads, window_size, 0 if i % 2 == 0 else window_size // 2, mlp_ratio,
+                                 qkv_bias, qk_scale, drop_path[i] if isinstance(drop_path, list) else drop_path)
+            for i in range(depth)])
+        self.downsample = downsample(dim=dim) if downsample is not None else None
+        self._regions = {}
+
+    def _region(self, H, W, device):
+        key = (H, W, str(device))
+        if key not in self._regions:
+            self._regions[key] = shift_regions(H, W, self.window_size).to(device)
+        return self._regions[key]
+
+    def forward(self, x, H, W):
+        region = self._region(H, W, x.device)
+        for blk in self.blocks:
+            blk.H, blk.W = H, W
+            if self.use_checkpoint:
+                x = torch.utils.checkpoint.checkpoint(blk, x, region, use_reentrant=False)
+            else:
+                x = blk(x, region)
+        if self.downsample is not None:
+            return x, H, W, self.downsample(x, H, W), (H + 1) // 2, (W + 1) // 2
+        return x, H, W, x, H, W
+
+
+class PatchEmbed(nn.Module):
+    def __init__(self, patch_size=4, in_chans=3, embed_dim=96, patch_norm=True):
+        super().__init__()
+        self.patch_size, self.embed_dim = (patch_size, patch_size), embed_dim
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
+        self.norm = nn.LayerNorm(embed_dim) if patch_norm else None
+
+    def forward(self, x):
+        _, _, H, W = x.shape
+        p = self.patch_size[0]
+        if W % p:
+            x = F.pad(x, (0, p - W % p))
+        if H % p:
+            x = F.pad(x, (0, 0, 0, p - H % p))
+        x, Wh, Ww = patch_embed4x4(x, self.proj.weight, self.proj.bias, p)
+        if self.norm is not None:
+            x = self.norm(x)
+        return x, Wh, Ww
+
+
+class Backbone(nn.Module):
+    def output_shape(self):
+        return {n: ShapeSpec(channels=self._out_feature_channels[n], stride=self._out_feature_strides[n])
+                for n in self._out_features}
+
+    @property
+    def size_divisibility(self):
+        return 0
+
+
+class SwinTransformer(Backbone):
+    def __init__(self, patch_size=4, in_chans=3, embed_dim=96, depths=(2, 2, 6, 2), num_heads=(3, 6, 12, 24),
+                 window_size=7, mlp_ratio=4.0, qkv_bias=True, qk_scale=None, drop_path_rate=0.2, patch_norm=True,
+                 out_indices=(0, 1, 2, 3), frozen_stages=-1, use_checkpoint=False):
+        super().__init__()
+        self.num_layers, self.embed_dim, self.out_indices, self.frozen_stages = len(depths), embed_dim, tuple(out_indices), frozen_stages
+        self.patch_embed = PatchEmbed(patch_size, in_chans, embed_dim, patch_norm)
+        dpr = [x.item() for x in torch.linspace(0, drop_path_rate, sum(depths))]
+        self.layers = nn.ModuleList()
+        for i in range(self.num_layers):
+            self.layers.append(BasicLayer(
+                dim=int(embed_dim * 2 ** i), depth=depths[i], num_heads=num_heads[i], window_size=window_size,
+                mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, qk_scale=qk_scale,
+                drop_path=dpr[sum(depths[:i]):sum(depths[:i + 1])],
+                downsample=PatchMerging if i < self.num_layers - 1 else None, use_checkpoint=use_checkpoint))
+        self.num_features = [int(embed_dim * 2 ** i) for i in range(self.num_layers)]
+        for i in self.out_indices:
+            self.add_module("norm%d" % i, nn.LayerNorm(self.num_features[i]))
+        self._out_features = ["swin%d" % i for i in self.out_indices]
+        self._out_feature_channels = {"swin%d" % i: embed_dim * 2 ** i for i in self.out_indices}
+        self._out_feature_strides = {"swin%d" % i: 2 ** (i + 2) for i in self.out_indices}
+
+    def init_weights(self, pretrained=None):
+        def _init(m):
+            if isinstance(m, nn.Linear):
+                trunc_normal_(m.weight, std=0.02)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+            elif isinstance(m, nn.LayerNorm):
+                nn.init.constant_(m.bias, 0)
+                nn.init.constant_(m.weight, 1.0)
+        self.apply(_init)
+
+    def forward(self, x):
+        x, Wh, Ww = self.patch_embed(x)
+        outs = {}
+        for i, layer in enumerate(self.layers):
+            x_out, H, W, x, Wh, Ww = layer(x, Wh, Ww)
+            if i in self.out_indices:
+                y = getattr(self, "norm%d" % i)(x_out)
+                # NHWC in memory, NCHW as a logical view: the registry contract sees (B,C,H,W)
+                outs["swin%d" % i] = y.view(-1, H, W, self.num_features[i]).permute(0, 3, 1, 2)
+        return outs
+
+
+size2config = {
+    "T": dict(window_size=7, embed_dim=96, depth=[2, 2, 6, 2], num_heads=[3, 6, 12, 24], drop_path_rate=0.2),
+    "S": dict(window_size=7, embed_dim=96, depth=[2, 2, 18, 2], num_heads=[3, 6, 12, 24], drop_path_rate=0.2),
+    "B": dict(window_size=7, embed_dim=128, depth=[2, 2, 18, 2], num_heads=[4, 8, 16, 32], drop_path_rate=0.3),
+    "B-22k": dict(window_size=7, embed_dim=128, depth=[2, 2, 18, 2], num_heads=[4, 8, 16, 32], drop_path_rate=0.3),
+    "B-22k-384": dict(window_size=12, embed_dim=128, depth=[2, 2, 18, 2], num_heads=[4, 8, 16, 32], drop_path_rate=0.3),
+    "L-22k": dict(window_size=7, embed_dim=192, depth=[2, 2, 18, 2], num_heads=[6, 12, 24, 48], drop_path_rate=0.3),
+    "L-22k-384": dict(window_size=12, embed_dim=192, depth=[2, 2, 18, 2], num_heads=[6, 12, 24, 48], drop_path_rate=0.3),
+}
+
+
+@BACKBONE_REGISTRY.register()
+def build_swintransformer_backbone(cfg, input_shape):
+    c = size2config[cfg.MODEL.SWIN.SIZE]
+    model = SwinTransformer(embed_dim=c["embed_dim"], window_size=c["window_size"], depths=c["depth"],
+                            num_heads=c["num_heads"], drop_path_rate=c["drop_path_rate"],
+                            out_indices=cfg.MODEL.SWIN.OUT_FEATURES, frozen_stages=-1,
+                            use_checkpoint=cfg.MODEL.SWIN.USE_CHECKPOINT)
+    model.init_weights(None)
+    return model
+
+
+@BACKBONE_REGISTRY.register()
+def build_swintransformer_fpn_backbone(cfg, input_shape):
+    from .fpn import FPN, LastLevelP6P7_P5
+    bottom_up = build_swintransformer_backbone(cfg, input_shape)
+    oc = cfg.MODEL.FPN.OUT_CHANNELS
+    return FPN(bottom_up=bottom_up, in_features=cfg.MODEL.FPN.IN_FEATURES, out_channels=oc, norm=cfg.MODEL.FPN.NORM,
+               top_block=LastLevelP6P7_P5(oc, oc), fuse_type=cfg.MODEL.FPN.FUSE_TYPE)

@@ -1,0 +1,233 @@
+"""CenterNet proposal generator (ONLY_PROPOSAL + WITH_AGN_HM configuration of DiverGen's YAMLs).
+Mirrors CN/modeling/dense_heads/centernet.py:30-737.
+
+MI355X-first changes: dense target assignment is one HIP kernel without M x N temporaries
+(dgx_centernet_targets); NMS is the on-device bitmask kernel (dgx_nms_sorted); the loss
+normalisers stay on the device (the reference's two `.item()` round trips after all-reduce,
+centernet.py:259-260,289, become device-side divisions); post-NMS top-k is taken on the GPU
+(no `.cpu()` kthvalue, centernet.py:727-731) with the same ">= k-th score" tie rule.
+"""
+import torch
+import torch.distributed as dist
+from torch import nn
+
+from .. import PROPOSAL_GENERATOR_REGISTRY
+from ...config import configurable
+from ...layers import centernet_targets, nms
+from ...structures import Boxes, Instances
+from ...utils.comm import get_world_size
+from .centernet_head import CenterNetHead
+
+INF = 100000000
+
+
+def reduce_sum(t):
+    if get_world_size() < 2:
+        return t
+    t = t.clone()
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
+@PROPOSAL_GENERATOR_REGISTRY.register()
+class CenterNet(nn.Module):
+    @configurable
+    def __init__(self, in_channels=256, *, num_classes=80, in_features=("p3", "p4", "p5", "p6", "p7"),
+                 strides=(8, 16, 32, 64, 128), score_thresh=0.05, hm_min_overlap=0.8, loc_loss_type="giou",
+                 min_radius=4, hm_focal_alpha=0.25, hm_focal_beta=4, loss_gamma=2.0, reg_weight=2.0,
+                 not_norm_reg=True, with_agn_hm=False, only_proposal=False, as_proposal=False, not_nms=False,
+                 pos_weight=1.0, neg_weight=1.0, sigmoid_clamp=1e-4, ignore_high_fp=-1.0, center_nms=False,
+                 sizes_of_interest=((0, 80), (64, 160), (128, 320), (256, 640), (512, 10000000)), more_pos=False,
+                 pre_nms_topk_train=1000, pre_nms_topk_test=1000, post_nms_topk_train=100, post_nms_topk_test=100,
+                 nms_thresh_train=0.6, nms_thresh_test=0.6, no_reduce=False, centernet_head=None, **unused):
+        super().__init__()
+        if not (only_proposal and with_agn_hm) or more_pos or center_nms or loc_loss_type != "giou":
+            raise NotImplementedError("only the shipped CenterNet2 proposal configuration "
+                                      "(ONLY_PROPOSAL, WITH_AGN_HM, giou, no MORE_POS/CENTER_NMS) is built")
+        self.num_classes, self.in_features, self.strides = num_classes, tuple(in_features), tuple(strides)
+        self.score_thresh, self.min_radius, self.hm_min_overlap = score_thresh, min_radius, hm_min_overlap
+        self.hm_focal_alpha, self.hm_focal_beta, self.loss_gamma = hm_focal_alpha, hm_focal_beta, loss_gamma
+        self.reg_weight, self.not_norm_reg, self.not_nms = reg_weight, not_norm_reg, not_nms
+        self.with_agn_hm, self.only_proposal = with_agn_hm, only_proposal
+        self.pos_weight, self.neg_weight = pos_weight, neg_weight
+        self.sigmoid_clamp, self.ignore_high_fp = sigmoid_clamp, ignore_high_fp
+        self.sizes_of_interest = [list(s) for s in sizes_of_interest]
+        self.pre_nms_topk_train, self.pre_nms_topk_test = pre_nms_topk_train, pre_nms_topk_test
+        self.post_nms_topk_train, self.post_nms_topk_test = post_nms_topk_train, post_nms_topk_test
+        self.nms_thresh_train, self.nms_thresh_test, self.no_reduce = nms_thresh_train, nms_thresh_test, no_reduce
+        self.centernet_head = centernet_head if centernet_head is not None else CenterNetHead(
+            in_channels=in_channels, num_levels=len(in_features), with_agn_hm=with_agn_hm, only_proposal=only_proposal)
+
+    @classmethod
+    def from_config(cls, cfg, input_shape):
+        c = cfg.MODEL.CENTERNET
+        return dict(in_channels=input_shape[c.IN_FEATURES[0]].channels, num_classes=c.NUM_CLASSES,
+                    in_features=c.IN_FEATURES, strides=c.FPN_STRIDES, score_thresh=c.INFERENCE_TH,
+                    loc_loss_type=c.LOC_LOSS_TYPE, hm_min_overlap=c.HM_MIN_OVERLAP, min_radius=c.MIN_RADIUS,
+                    hm_focal_alpha=c.HM_FOCAL_ALPHA, hm_focal_beta=c.HM_FOCAL_BETA, loss_gamma=c.LOSS_GAMMA,
+                    reg_weight=c.REG_WEIGHT, not_norm_reg=c.NOT_NORM_REG, with_agn_hm=c.WITH_AGN_HM,
+                    only_proposal=c.ONLY_PROPOSAL, as_proposal=c.AS_PROPOSAL, not_nms=c.NOT_NMS,
+                    pos_weight=c.POS_WEIGHT, neg_weight=c.NEG_WEIGHT, sigmoid_clamp=c.SIGMOID_CLAMP,
+                    ignore_high_fp=c.IGNORE_HIGH_FP, center_nms=c.CENTER_NMS, sizes_of_interest=c.SOI,
+                    more_pos=c.MORE_POS, pre_nms_topk_train=c.PRE_NMS_TOPK_TRAIN, pre_nms_topk_test=c.PRE_NMS_TOPK_TEST,
+                    post_nms_topk_train=c.POST_NMS_TOPK_TRAIN, post_nms_topk_test=c.POST_NMS_TOPK_TEST,
+                    nms_thresh_train=c.NMS_TH_TRAIN, nms_thresh_test=c.NMS_TH_TEST, no_reduce=c.NO_REDUCE,
+                    centernet_head=CenterNetHead(cfg, [input_shape[f] for f in c.IN_FEATURES]))
+
+    # ---------------------------------------------------------------- forward
+    def forward(self, images, features_dict, gt_instances):
+        features = [features_dict[f] for f in self.in_features]
+        _, reg_pred_per_level, agn_hm_pred_per_level = self.centernet_head(features)
+        reg_pred_per_level = [r.float() for r in reg_pred_per_level]
+        agn_hm_pred_per_level = [a.float() for a in agn_hm_pred_per_level]
+        grids = self.compute_grids(features)
+        shapes = [(int(x.shape[2]), int(x.shape[3])) for x in reg_pred_per_level]
+        if not self.training:
+            hms = [x.sigmoid() for x in agn_hm_pred_per_level]
+            proposals = self.predict_instances(grids, hms, reg_pred_per_level, images.image_sizes)
+            for p in proposals:
+                p.proposal_boxes = p.get("pred_boxes")
+                p.objectness_logits = p.get("scores")
+                p.remove("pred_boxes")
+            return proposals, {}
+        pos_inds, reg_targets, flattened_hms = self._get_ground_truth(shapes, gt_instances)
+        reg_pred = torch.cat([x.permute(0, 2, 3, 1).reshape(-1, 4) for x in reg_pred_per_level], dim=0)
+        agn_hm_pred = torch.cat([x.permute(0, 2, 3, 1).reshape(-1) for x in agn_hm_pred_per_level], dim=0)
+        losses = self.losses(pos_inds, reg_targets, flattened_hms, reg_pred, agn_hm_pred)
+        with torch.no_grad():
+            hms = [x.detach().sigmoid() for x in agn_hm_pred_per_level]
+            proposals = self.predict_instances(grids, hms, [r.detach() for r in reg_pred_per_level], images.image_sizes)
+        for p in proposals:
+            p.proposal_boxes = p.get("pred_boxes")
+            p.objectness_logits = p.get("scores")
+            p.remove("pred_boxes")
+            p.remove("scores")
+            p.remove("pred_classes")
+        return proposals, losses
+
+    def compute_grids(self, features):
+        grids = []
+        for level, f in enumerate(features):
+            h, w = f.shape[-2:]
+            s = self.strides[level]
+            xs = torch.arange(0, w * s, step=s, dtype=torch.float32, device=f.device)
+            ys = torch.arange(0, h * s, step=s, dtype=torch.float32, device=f.device)
+            yy, xx = torch.meshgrid(ys, xs, indexing="ij")
+            grids.append(torch.stack((xx.reshape(-1), yy.reshape(-1)), dim=1) + s // 2)
+        return grids
+
+    @torch.no_grad()
+    def _get_ground_truth(self, shapes, gt_instances):
+        boxes = [g.gt_boxes.tensor for g in gt_instances]
+        reg, hm = centernet_targets(boxes, shapes, self.strides, self.sizes_of_interest, self.hm_min_overlap,
+                                    self.min_radius)
+        return self._get_label_inds(boxes, shapes), reg, hm
+
+    def _get_label_inds(self, boxes_list, shapes):
+        """centernet.py:439-483 on the device (n x L integers per image)."""
+        dev = boxes_list[0].device
+        L, B = len(self.strides), len(boxes_list)
+        hw = torch.tensor(shapes, dtype=torch.int64, device=dev)
+        loc = hw[:, 0] * hw[:, 1]
+        bases = torch.cumsum(torch.cat([loc.new_zeros(1), B * loc[:-1]]), 0)
+        st = torch.tensor(self.strides, dtype=torch.float32, device=dev)
+        sr = torch.tensor(self.sizes_of_interest, dtype=torch.float32, device=dev)
+        out = []
+        for i, bx in enumerate(boxes_list):
+            c = (bx[:, [0, 1]] + bx[:, [2, 3]]) / 2
+            ci = (c[:, None, :] / st[None, :, None]).long()
+            ind = bases[None] + i * loc[None] + ci[:, :, 1] * hw[None, :, 1] + ci[:, :, 0]
+            crit = ((bx[:, 2:] - bx[:, :2]) ** 2).sum(dim=1) ** 0.5 / 2
+            cared = (crit[:, None] >= sr[None, :, 0]) & (crit[:, None] <= sr[None, :, 1])
+            out.append(ind[cared].reshape(-1))
+        return torch.cat(out, dim=0).long()
+
+    def losses(self, pos_inds, reg_targets, flattened_hms, reg_pred, agn_hm_pred):
+        world = get_world_size()
+        num_pos_local = torch.tensor([float(pos_inds.numel())], device=reg_pred.device)
+        total_num_pos = num_pos_local * world if self.no_reduce else reduce_sum(num_pos_local)
+        num_pos_avg = torch.clamp(total_num_pos / world, min=1.0)[0]
+        losses = {}
+        reg_mask = (reg_targets.max(dim=1)[0] >= 0).float()
+        w = flattened_hms.max(dim=1)[0]
+        reg_weight_map = (w * 0 + 1 if self.not_norm_reg else w) * reg_mask
+        s = reg_weight_map.sum()
+        reg_norm = torch.clamp((s if self.no_reduce else reduce_sum(s)) / (1 if self.no_reduce else world), min=1.0)
+        # masked (instead of index-selected) GIoU: identical sum, no nonzero() sync
+        tgt = torch.where(reg_mask[:, None] > 0, reg_targets, torch.ones_like(reg_targets))
+        prd = torch.where(reg_mask[:, None] > 0, reg_pred, torch.ones_like(reg_pred))
+        losses["loss_centernet_loc"] = self.reg_weight * (_giou(prd, tgt) * reg_weight_map).sum() / reg_norm
+        pos, neg = _binary_heatmap_focal_loss(agn_hm_pred, w, pos_inds, self.hm_focal_alpha, self.hm_focal_beta,
+                                              self.loss_gamma, self.sigmoid_clamp, self.ignore_high_fp)
+        losses["loss_centernet_agn_pos"] = self.pos_weight * pos / num_pos_avg
+        losses["loss_centernet_agn_neg"] = self.neg_weight * neg / num_pos_avg
+        return losses
+
+    # ---------------------------------------------------------------- decoding
+    @torch.no_grad()
+    def predict_instances(self, grids, hms, reg_pred, image_sizes):
+        B = hms[0].shape[0]
+        pre_topk = self.pre_nms_topk_train if self.training else self.pre_nms_topk_test
+        post_topk = self.post_nms_topk_train if self.training else self.post_nms_topk_test
+        thr_nms = self.nms_thresh_train if self.training else self.nms_thresh_test
+        per_img = [[] for _ in range(B)]
+        for l in range(len(grids)):
+            hm = hms[l].reshape(B, -1)                                           # (B, HW), C == 1
+            reg = (reg_pred[l] * self.strides[l]).permute(0, 2, 3, 1).reshape(B, -1, 4)
+            k = min(pre_topk, hm.shape[1])
+            vals, idx = torch.where(hm > self.score_thresh, hm, hm.new_full((), -1.0)).topk(k, dim=1)
+            g = grids[l][idx]                                                    # (B,k,2)
+            r = torch.gather(reg, 1, idx[:, :, None].expand(-1, -1, 4))
+            det = torch.stack([g[..., 0] - r[..., 0], g[..., 1] - r[..., 1], g[..., 0] + r[..., 2], g[..., 1] + r[..., 3]], -1)
+            det[..., 2] = torch.max(det[..., 2], det[..., 0] + 0.01)
+            det[..., 3] = torch.max(det[..., 3], det[..., 1] + 0.01)
+            for i in range(B):
+                per_img[i].append((det[i], vals[i]))
+        results = []
+        for i in range(B):
+            boxes = torch.cat([d for d, _ in per_img[i]])
+            sc = torch.cat([v for _, v in per_img[i]])
+            ok = sc > self.score_thresh
+            boxes, sc = boxes[ok], torch.sqrt(sc[ok])
+            if not self.not_nms:
+                keep = nms(boxes, sc, thr_nms)                                   # descending score order
+                boxes, sc = boxes[keep], sc[keep]
+            n = sc.shape[0]
+            if n > post_topk:
+                sorted_sc = torch.sort(sc, descending=True)[0]
+                kk = sc >= sorted_sc[post_topk - 1]
+                boxes, sc = boxes[kk], sc[kk]
+            inst = Instances(image_sizes[i])
+            inst.pred_boxes = Boxes(boxes)
+            inst.scores = sc
+            inst.pred_classes = torch.zeros_like(sc, dtype=torch.int64)
+            results.append(inst)
+        return results
+
+
+def _giou(pred, target):
+    """CN/modeling/layers/iou_loss.py:10-63 ('giou'), per-row loss."""
+    pl, pt, pr, pb = pred.unbind(1)
+    tl, tt, tr, tb = target.unbind(1)
+    ta, pa = (tl + tr) * (tt + tb), (pl + pr) * (pt + pb)
+    wi = torch.min(pl, tl) + torch.min(pr, tr)
+    hi = torch.min(pb, tb) + torch.min(pt, tt)
+    ac = (torch.max(pl, tl) + torch.max(pr, tr)) * (torch.max(pb, tb) + torch.max(pt, tt))
+    ai = wi * hi
+    au = ta + pa - ai
+    return 1 - ((ai + 1.0) / (au + 1.0) - (ac - au) / ac)
+
+
+def _binary_heatmap_focal_loss(inputs, targets, pos_inds, alpha, beta, gamma, sigmoid_clamp, ignore_high_fp):
+    """CN/modeling/layers/heatmap_focal_loss.py:51-85."""
+    pred = torch.clamp(inputs.sigmoid(), min=sigmoid_clamp, max=1 - sigmoid_clamp)
+    neg_weights = torch.pow(1 - targets, beta)
+    pos_pred = pred[pos_inds]
+    pos_loss = torch.log(pos_pred) * torch.pow(1 - pos_pred, gamma)
+    neg_loss = torch.log(1 - pred) * torch.pow(pred, gamma) * neg_weights
+    if ignore_high_fp > 0:
+        neg_loss = (pred < ignore_high_fp).float() * neg_loss
+    pos_loss, neg_loss = -pos_loss.sum(), -neg_loss.sum()
+    if alpha >= 0:
+        pos_loss, neg_loss = alpha * pos_loss, (1 - alpha) * neg_loss
+    return pos_loss, neg_loss

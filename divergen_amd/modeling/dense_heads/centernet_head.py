@@ -1,0 +1,76 @@
+"""CenterNet head (shared towers + agn_hm / bbox_pred).  Mirrors
+CN/modeling/dense_heads/centernet_head.py:13-162; parameter names (bbox_tower.{0,1,3,4,...},
+agn_hm, bbox_pred, scales.{l}.scale) follow the reference so checkpoints load."""
+import math
+
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from ...config import configurable
+from ...layers.conv_ops import Conv2d
+
+
+class Scale(nn.Module):
+    def __init__(self, init_value=1.0):
+        super().__init__()
+        self.scale = nn.Parameter(torch.FloatTensor([init_value]))
+
+    def forward(self, x):
+        return x * self.scale
+
+
+class CenterNetHead(nn.Module):
+    @configurable
+    def __init__(self, in_channels, num_levels, *, num_classes=80, with_agn_hm=False, only_proposal=False,
+                 norm="GN", num_cls_convs=4, num_box_convs=4, num_share_convs=0, use_deformable=False,
+                 prior_prob=0.01):
+        super().__init__()
+        assert not use_deformable, "USE_DEFORMABLE is False in every shipped config"
+        self.num_classes, self.with_agn_hm, self.only_proposal = num_classes, with_agn_hm, only_proposal
+        for name, n in (("cls", 0 if only_proposal else num_cls_convs), ("bbox", num_box_convs), ("share", num_share_convs)):
+            tower = []
+            for _ in range(n):
+                tower.append(Conv2d(in_channels, in_channels, 3, 1, 1, bias=True))
+                if norm == "GN":
+                    tower.append(nn.GroupNorm(32 if in_channels % 32 == 0 else 25, in_channels))
+                elif norm != "":
+                    raise NotImplementedError(norm)
+                tower.append(nn.ReLU())
+            self.add_module(name + "_tower", nn.Sequential(*tower))
+        self.bbox_pred = Conv2d(in_channels, 4, 3, 1, 1)
+        self.scales = nn.ModuleList([Scale(1.0) for _ in range(num_levels)])
+        for mod in (self.cls_tower, self.bbox_tower, self.share_tower, self.bbox_pred):
+            for l in mod.modules():
+                if isinstance(l, nn.Conv2d):
+                    nn.init.normal_(l.weight, std=0.01)
+                    nn.init.constant_(l.bias, 0)
+        nn.init.constant_(self.bbox_pred.bias, 8.0)
+        bias_value = -math.log((1 - prior_prob) / prior_prob)
+        if with_agn_hm:
+            self.agn_hm = Conv2d(in_channels, 1, 3, 1, 1)
+            nn.init.constant_(self.agn_hm.bias, bias_value)
+            nn.init.normal_(self.agn_hm.weight, std=0.01)
+        if not only_proposal:
+            self.cls_logits = Conv2d(in_channels, num_classes, 3, 1, 1)
+            nn.init.constant_(self.cls_logits.bias, bias_value)
+            nn.init.normal_(self.cls_logits.weight, std=0.01)
+
+    @classmethod
+    def from_config(cls, cfg, input_shape):
+        c = cfg.MODEL.CENTERNET
+        return dict(in_channels=[s.channels for s in input_shape][0], num_levels=len(input_shape),
+                    num_classes=c.NUM_CLASSES, with_agn_hm=c.WITH_AGN_HM, only_proposal=c.ONLY_PROPOSAL, norm=c.NORM,
+                    num_cls_convs=c.NUM_CLS_CONVS, num_box_convs=c.NUM_BOX_CONVS, num_share_convs=c.NUM_SHARE_CONVS,
+                    use_deformable=c.USE_DEFORMABLE, prior_prob=c.PRIOR_PROB)
+
+    def forward(self, x):
+        clss, bbox_reg, agn_hms = [], [], []
+        for l, feature in enumerate(x):
+            feature = self.share_tower(feature)
+            cls_tower = self.cls_tower(feature)
+            bbox_tower = self.bbox_tower(feature)
+            clss.append(None if self.only_proposal else self.cls_logits(cls_tower))
+            agn_hms.append(self.agn_hm(bbox_tower) if self.with_agn_hm else None)
+            bbox_reg.append(F.relu(self.scales[l](self.bbox_pred(bbox_tower))))
+        return clss, bbox_reg, agn_hms

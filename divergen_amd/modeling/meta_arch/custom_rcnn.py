@@ -1,0 +1,125 @@
+"""CustomRCNN meta-architecture.  Mirrors DG/divergen/modeling/meta_arch/custom_rcnn.py:24-207 over
+D2/modeling/meta_arch/rcnn.py:24-243 for the box-supervised path the shipped configs train.
+
+Precision: the reference runs the backbone under fp16 autocast + GradScaler and the heads in fp32
+(custom_rcnn.py:141-146).  Here cfg.FP16 selects bf16 autocast (no loss scaling needed) and, by
+default, keeps the dense/RoI head GEMMs and convolutions in bf16 as well (DGX_HEADS_FP32=1 restores
+fp32 heads); losses, box decoding and targets are always fp32."""
+import os
+
+import torch
+from torch import nn
+
+from .. import META_ARCH_REGISTRY, build_backbone, build_proposal_generator, build_roi_heads
+from ...config import configurable
+from ...structures import ImageList
+
+
+@META_ARCH_REGISTRY.register()
+class CustomRCNN(nn.Module):
+    @configurable
+    def __init__(self, *, backbone, proposal_generator, roi_heads, pixel_mean, pixel_std, input_format=None,
+                 vis_period=0, fp16=False, with_image_labels=False, roi_head_name="", **unused):
+        super().__init__()
+        assert proposal_generator is not None
+        if with_image_labels:
+            raise NotImplementedError("WITH_IMAGE_LABELS co-training is outside the shipped configs")
+        self.backbone, self.proposal_generator, self.roi_heads = backbone, proposal_generator, roi_heads
+        self.input_format, self.vis_period, self.fp16, self.roi_head_name = input_format, vis_period, fp16, roi_head_name
+        self.register_buffer("pixel_mean", torch.tensor(pixel_mean).view(-1, 1, 1), False)
+        self.register_buffer("pixel_std", torch.tensor(pixel_std).view(-1, 1, 1), False)
+        self.heads_fp32 = os.environ.get("DGX_HEADS_FP32", "0") == "1"
+        self.return_proposal = False
+
+    @classmethod
+    def from_config(cls, cfg):
+        backbone = build_backbone(cfg)
+        shape = backbone.output_shape()
+        return dict(backbone=backbone, proposal_generator=build_proposal_generator(cfg, shape),
+                    roi_heads=build_roi_heads(cfg, shape), input_format=cfg.INPUT.FORMAT, vis_period=cfg.VIS_PERIOD,
+                    pixel_mean=cfg.MODEL.PIXEL_MEAN, pixel_std=cfg.MODEL.PIXEL_STD, fp16=cfg.FP16,
+                    with_image_labels=cfg.WITH_IMAGE_LABELS, roi_head_name=cfg.MODEL.ROI_HEADS.NAME)
+
+    @property
+    def device(self):
+        return self.pixel_mean.device
+
+    def preprocess_image(self, batched_inputs):
+        """rcnn.py:220-227: H2D, (x - mean) / std, zero-pad to the backbone's divisibility."""
+        images = [x["image"].to(self.device, non_blocking=True) for x in batched_inputs]
+        images = [(x.float() - self.pixel_mean) / self.pixel_std for x in images]
+        return ImageList.from_tensors(images, self.backbone.size_divisibility)
+
+    def _features(self, images):
+        if self.fp16:
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                feats = self.backbone(images.tensor.to(memory_format=torch.channels_last))
+            if self.heads_fp32:
+                feats = {k: v.float() for k, v in feats.items()}
+            return feats
+        return self.backbone(images.tensor)
+
+    def forward(self, batched_inputs):
+        if not self.training:
+            return self.inference(batched_inputs)
+        images = self.preprocess_image(batched_inputs)
+        gt_instances = [x["instances"].to(self.device) for x in batched_inputs]
+        features = self._features(images)
+        heads_amp = self.fp16 and not self.heads_fp32
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=heads_amp):
+            proposals, proposal_losses = self.proposal_generator(images, features, gt_instances)
+            proposals, detector_losses = self.roi_heads(images, features, proposals, gt_instances, ann_type="box")
+        losses = {}
+        losses.update(detector_losses)
+        losses.update(proposal_losses)
+        return (proposals, losses) if self.return_proposal else losses
+
+    @torch.no_grad()
+    def inference(self, batched_inputs, do_postprocess=True):
+        assert not self.training
+        images = self.preprocess_image(batched_inputs)
+        features = self.backbone(images.tensor)
+        proposals, _ = self.proposal_generator(images, features, None)
+        results, _ = self.roi_heads(images, features, proposals)
+        if not do_postprocess:
+            return results
+        out = []
+        for r, inp, size in zip(results, batched_inputs, images.image_sizes):
+            out.append({"instances": detector_postprocess(r, inp.get("height", size[0]), inp.get("width", size[1]))})
+        return out
+
+
+def detector_postprocess(results, output_height, output_width, mask_threshold=0.5):
+    """D2/modeling/postprocessing.py: rescale boxes to the output resolution, paste masks."""
+    from ...structures import Boxes, Instances
+    sx, sy = output_width / results.image_size[1], output_height / results.image_size[0]
+    out = Instances((output_height, output_width), **results.get_fields())
+    b = out.pred_boxes.tensor.clone()
+    b[:, 0::2] *= sx
+    b[:, 1::2] *= sy
+    bx = Boxes(b)
+    bx.clip(out.image_size)
+    out.pred_boxes = bx
+    keep = bx.nonempty()
+    out = out[keep]
+    if out.has("pred_masks"):
+        out.pred_masks = paste_masks_in_image(out.pred_masks[:, 0], out.pred_boxes.tensor, (output_height, output_width),
+                                              mask_threshold)
+    return out
+
+
+def paste_masks_in_image(masks, boxes, image_shape, threshold=0.5):
+    """D2/layers/mask_ops.py paste via grid_sample (aligned sampling of the SxS probability map)."""
+    import torch.nn.functional as F
+    N = masks.shape[0]
+    H, W = image_shape
+    if N == 0:
+        return masks.new_empty((0, H, W), dtype=torch.bool)
+    x0, y0, x1, y1 = boxes.split(1, dim=1)
+    ys = torch.arange(0, H, device=masks.device, dtype=torch.float32) + 0.5
+    xs = torch.arange(0, W, device=masks.device, dtype=torch.float32) + 0.5
+    ys = (ys[None] - y0) / (y1 - y0) * 2 - 1
+    xs = (xs[None] - x0) / (x1 - x0) * 2 - 1
+    grid = torch.stack([xs[:, None, :].expand(N, H, W), ys[:, :, None].expand(N, H, W)], dim=3)
+    out = F.grid_sample(masks[:, None].float(), grid, align_corners=False)
+    return out[:, 0] >= threshold

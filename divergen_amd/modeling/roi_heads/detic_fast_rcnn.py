@@ -1,0 +1,193 @@
+"""DeticFastRCNNOutputLayers: cls_score / bbox_pred + sigmoid-CE with federated loss + L1 box loss.
+Mirrors DG/divergen/modeling/roi_heads/detic_fast_rcnn.py:31-466 and
+D2/modeling/roi_heads/fast_rcnn.py:45-460 for the configuration the shipped YAMLs select
+(USE_SIGMOID_CE, USE_FED_LOSS, CLS_AGNOSTIC_BBOX_REG, smooth_l1 beta 0, no zero-shot classifier)."""
+import json
+import math
+
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from ...config import configurable
+from ...layers import batched_nms
+from ...structures import Boxes, Instances
+from ...utils.events import get_event_storage
+from ..box_regression import Box2BoxTransform
+
+
+def load_class_freq(path="datasets/metadata/lvis_v1_train_cat_info.json", freq_weight=1.0):
+    """DG/divergen/modeling/utils.py:7-13."""
+    cat_info = json.load(open(path, "r"))
+    cat_info = torch.tensor([c["image_count"] for c in sorted(cat_info, key=lambda x: x["id"])])
+    return cat_info.float() ** freq_weight
+
+
+def get_fed_loss_inds(gt_classes, num_sample_cats, C, weight=None):
+    """DG/divergen/modeling/utils.py:16-28 (torch.unique + torch.multinomial keep the RNG contract)."""
+    appeared = torch.unique(gt_classes)
+    prob = appeared.new_ones(C + 1).float()
+    prob[-1] = 0
+    if len(appeared) < num_sample_cats:
+        if weight is not None:
+            prob[:C] = weight.float().clone()
+        prob[appeared] = 0
+        more = torch.multinomial(prob, num_sample_cats - len(appeared), replacement=False)
+        appeared = torch.cat([appeared, more])
+    return appeared
+
+
+def fast_rcnn_inference_single_image(boxes, scores, image_shape, score_thresh, nms_thresh, topk_per_image):
+    """D2/modeling/roi_heads/fast_rcnn.py:117-170."""
+    valid = torch.isfinite(boxes).all(dim=1) & torch.isfinite(scores).all(dim=1)
+    if not valid.all():
+        boxes, scores = boxes[valid], scores[valid]
+    scores = scores[:, :-1]
+    nreg = boxes.shape[1] // 4
+    b = Boxes(boxes.reshape(-1, 4))
+    b.clip(image_shape)
+    boxes = b.tensor.view(-1, nreg, 4)
+    filter_mask = scores > score_thresh
+    filter_inds = filter_mask.nonzero()
+    boxes = boxes[filter_inds[:, 0], 0] if nreg == 1 else boxes[filter_mask]
+    scores = scores[filter_mask]
+    keep = batched_nms(boxes, scores, filter_inds[:, 1], nms_thresh)
+    if topk_per_image >= 0:
+        keep = keep[:topk_per_image]
+    boxes, scores, filter_inds = boxes[keep], scores[keep], filter_inds[keep]
+    result = Instances(image_shape)
+    result.pred_boxes = Boxes(boxes)
+    result.scores = scores
+    result.pred_classes = filter_inds[:, 1]
+    return result, filter_inds[:, 0]
+
+
+def fast_rcnn_inference(boxes, scores, image_shapes, score_thresh, nms_thresh, topk_per_image):
+    res = [fast_rcnn_inference_single_image(b, s, sh, score_thresh, nms_thresh, topk_per_image)
+           for s, b, sh in zip(scores, boxes, image_shapes)]
+    return [x[0] for x in res], [x[1] for x in res]
+
+
+def _log_classification_stats(pred_logits, gt_classes, prefix="fast_rcnn"):
+    """fast_rcnn.py:88-114, kept on the device (writers convert lazily)."""
+    n = gt_classes.numel()
+    if n == 0:
+        return
+    with torch.no_grad():
+        pred = pred_logits.argmax(dim=1)
+        bg = pred_logits.shape[1] - 1
+        fg = (gt_classes >= 0) & (gt_classes < bg)
+        num_fg = fg.sum().clamp(min=1)
+        st = get_event_storage()
+        st.put_scalar(prefix + "/cls_accuracy", (pred == gt_classes).sum() / n)
+        st.put_scalar(prefix + "/fg_cls_accuracy", ((pred == gt_classes) & fg).sum() / num_fg)
+        st.put_scalar(prefix + "/false_negative", ((pred == bg) & fg).sum() / num_fg)
+
+
+class DeticFastRCNNOutputLayers(nn.Module):
+    @configurable
+    def __init__(self, input_shape, *, box2box_transform, num_classes, test_score_thresh=0.0, test_nms_thresh=0.5,
+                 test_topk_per_image=100, cls_agnostic_bbox_reg=False, smooth_l1_beta=0.0, box_reg_loss_type="smooth_l1",
+                 loss_weight=1.0, mult_proposal_score=False, use_sigmoid_ce=False, use_fed_loss=False,
+                 ignore_zero_cats=False, fed_loss_num_cat=50, prior_prob=0.01, cat_freq_path="",
+                 fed_loss_freq_weight=0.5, use_zeroshot_cls=False, divergen_box_loss=True, **unused):
+        super().__init__()
+        if use_zeroshot_cls or box_reg_loss_type != "smooth_l1":
+            raise NotImplementedError("USE_ZEROSHOT_CLS / non-smooth_l1 box losses are outside the shipped configs")
+        self.num_classes = num_classes
+        input_size = input_shape.channels * (input_shape.width or 1) * (input_shape.height or 1)
+        self.cls_score = nn.Linear(input_size, num_classes + 1)
+        self.bbox_pred = nn.Linear(input_size, (1 if cls_agnostic_bbox_reg else num_classes) * 4)
+        nn.init.normal_(self.cls_score.weight, std=0.01)
+        nn.init.normal_(self.bbox_pred.weight, std=0.001)
+        for l in (self.cls_score, self.bbox_pred):
+            nn.init.constant_(l.bias, 0)
+        self.box2box_transform, self.smooth_l1_beta = box2box_transform, smooth_l1_beta
+        self.test_score_thresh, self.test_nms_thresh, self.test_topk_per_image = test_score_thresh, test_nms_thresh, test_topk_per_image
+        self.mult_proposal_score, self.use_sigmoid_ce, self.use_fed_loss = mult_proposal_score, use_sigmoid_ce, use_fed_loss
+        self.ignore_zero_cats, self.fed_loss_num_cat, self.divergen_box_loss = ignore_zero_cats, fed_loss_num_cat, divergen_box_loss
+        if use_sigmoid_ce:
+            nn.init.constant_(self.cls_score.bias, -math.log((1 - prior_prob) / prior_prob))
+        if use_fed_loss or ignore_zero_cats:
+            fw = load_class_freq(cat_freq_path, fed_loss_freq_weight)
+            if use_fed_loss and len(fw) < num_classes:
+                fw = torch.cat([fw, fw.new_zeros(num_classes - len(fw))])
+            self.register_buffer("freq_weight", fw)
+        else:
+            self.freq_weight = None
+
+    @classmethod
+    def from_config(cls, cfg, input_shape, box2box_transform=None):
+        h = cfg.MODEL.ROI_BOX_HEAD
+        return dict(input_shape=input_shape,
+                    box2box_transform=box2box_transform or Box2BoxTransform(weights=h.BBOX_REG_WEIGHTS),
+                    num_classes=cfg.MODEL.ROI_HEADS.NUM_CLASSES, cls_agnostic_bbox_reg=h.CLS_AGNOSTIC_BBOX_REG,
+                    smooth_l1_beta=h.SMOOTH_L1_BETA, test_score_thresh=cfg.MODEL.ROI_HEADS.SCORE_THRESH_TEST,
+                    test_nms_thresh=cfg.MODEL.ROI_HEADS.NMS_THRESH_TEST, test_topk_per_image=cfg.TEST.DETECTIONS_PER_IMAGE,
+                    box_reg_loss_type=h.BBOX_REG_LOSS_TYPE, mult_proposal_score=h.MULT_PROPOSAL_SCORE,
+                    use_sigmoid_ce=h.USE_SIGMOID_CE, use_fed_loss=h.USE_FED_LOSS, ignore_zero_cats=h.IGNORE_ZERO_CATS,
+                    fed_loss_num_cat=h.FED_LOSS_NUM_CAT, prior_prob=h.PRIOR_PROB, cat_freq_path=h.CAT_FREQ_PATH,
+                    fed_loss_freq_weight=h.FED_LOSS_FREQ_WEIGHT, use_zeroshot_cls=h.USE_ZEROSHOT_CLS,
+                    divergen_box_loss=cfg.MODEL.USE_DIVERGEN_BOX_LOSS)
+
+    def forward(self, x, classifier_info=(None, None, None)):
+        if x.dim() > 2:
+            x = torch.flatten(x, start_dim=1)
+        return self.cls_score(x), self.bbox_pred(x)
+
+    def losses(self, predictions, proposals, classifier_info=(None, None, None)):
+        scores, deltas = predictions[0].float(), predictions[1].float()
+        gt_classes = torch.cat([p.gt_classes for p in proposals], dim=0) if len(proposals) else torch.empty(0)
+        _log_classification_stats(scores, gt_classes)
+        if len(proposals):
+            prop = torch.cat([p.proposal_boxes.tensor for p in proposals], dim=0)
+            gtb = torch.cat([(p.gt_boxes if p.has("gt_boxes") else p.proposal_boxes).tensor for p in proposals], dim=0)
+        else:
+            prop = gtb = torch.empty((0, 4), device=deltas.device)
+        loss_cls = self.sigmoid_cross_entropy_loss(scores, gt_classes) if self.use_sigmoid_ce else \
+            F.cross_entropy(scores, gt_classes, reduction="mean")
+        src = None
+        if not self.divergen_box_loss:
+            src = torch.cat([p.instance_source for p in proposals if len(p)], dim=0)
+        return {"loss_cls": loss_cls, "loss_box_reg": self.box_reg_loss(prop, gtb, deltas, gt_classes, src)}
+
+    def sigmoid_cross_entropy_loss(self, logits, gt_classes):
+        if logits.numel() == 0:
+            return logits.new_zeros([1])[0]
+        B, C = logits.shape[0], logits.shape[1] - 1
+        target = logits.new_zeros(B, C + 1)
+        target[torch.arange(B, device=logits.device), gt_classes] = 1
+        target = target[:, :C]
+        weight = 1
+        if self.use_fed_loss and self.freq_weight is not None:
+            appeared = get_fed_loss_inds(gt_classes, self.fed_loss_num_cat, C, self.freq_weight)
+            m = appeared.new_zeros(C + 1)
+            m[appeared] = 1
+            weight = weight * m[:C].view(1, C).float()
+        if self.ignore_zero_cats and self.freq_weight is not None:
+            weight = weight * (self.freq_weight.view(-1) > 1e-4).float().view(1, C)
+        ce = F.binary_cross_entropy_with_logits(logits[:, :-1], target, reduction="none")
+        return torch.sum(ce * weight) / B
+
+    def box_reg_loss(self, prop, gtb, deltas, gt_classes, instance_source=None):
+        fg = ((gt_classes >= 0) & (gt_classes < self.num_classes)).nonzero().squeeze(1)
+        fgd = deltas[fg] if deltas.shape[1] == 4 else deltas.view(-1, self.num_classes, 4)[fg, gt_classes[fg]]
+        tgt = self.box2box_transform.get_deltas(prop[fg], gtb[fg])
+        l = torch.abs(fgd - tgt) if self.smooth_l1_beta < 1e-5 else \
+            torch.where((fgd - tgt).abs() < self.smooth_l1_beta, 0.5 * (fgd - tgt) ** 2 / self.smooth_l1_beta,
+                        (fgd - tgt).abs() - 0.5 * self.smooth_l1_beta)
+        if instance_source is not None:
+            l = l[instance_source[fg] == 0]
+        return l.sum() / max(l.numel(), 1.0)
+
+    def predict_boxes(self, predictions, proposals):
+        if not len(proposals):
+            return []
+        deltas = predictions[1]
+        prop = torch.cat([p.proposal_boxes.tensor for p in proposals], dim=0)
+        return self.box2box_transform.apply_deltas(deltas, prop).split([len(p) for p in proposals])
+
+    def predict_probs(self, predictions, proposals):
+        s = predictions[0].float()
+        probs = s.sigmoid() if self.use_sigmoid_ce else F.softmax(s, dim=-1)
+        return probs.split([len(p) for p in proposals], dim=0)

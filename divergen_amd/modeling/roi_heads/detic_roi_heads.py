@@ -1,0 +1,249 @@
+"""DeticCascadeROIHeads: 3-stage cascade box head + class-agnostic mask head with instance_source
+plumbing.  Mirrors DG/divergen/modeling/roi_heads/detic_roi_heads.py:29-414 over
+D2/modeling/roi_heads/{cascade_rcnn.py:20-299, roi_heads.py:46-76,181-300}.
+
+MI355X-first: IoU + Matcher is one kernel per image with no (M x N) matrix; all RoI pooling is the
+multi-level NHWC HIP ROIAlign; statistics stay on the device."""
+import math
+
+import torch
+from torch import nn
+
+from .. import ROI_HEADS_REGISTRY, ShapeSpec
+from ...config import configurable
+from ...layers import iou_match
+from ...structures import Boxes, Instances
+from ...utils.events import get_event_storage
+from ..box_regression import Box2BoxTransform
+from .box_head import build_box_head
+from .detic_fast_rcnn import DeticFastRCNNOutputLayers, fast_rcnn_inference
+from .mask_head import build_mask_head
+from .poolers import ROIPooler
+
+
+class _ScaleGradient(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, scale):
+        ctx.scale = scale
+        return x
+
+    @staticmethod
+    def backward(ctx, g):
+        return g * ctx.scale, None
+
+
+def subsample_labels(labels, num_samples, positive_fraction, bg_label):
+    """D2/modeling/sampling.py:9-54 (two torch.randperm draws on the labels' device)."""
+    positive = ((labels != -1) & (labels != bg_label)).nonzero().squeeze(1)
+    negative = (labels == bg_label).nonzero().squeeze(1)
+    num_pos = min(positive.numel(), int(num_samples * positive_fraction))
+    num_neg = min(negative.numel(), num_samples - num_pos)
+    p1 = torch.randperm(positive.numel(), device=positive.device)[:num_pos]
+    p2 = torch.randperm(negative.numel(), device=negative.device)[:num_neg]
+    return positive[p1], negative[p2]
+
+
+def add_ground_truth_to_proposals(gt, proposals):
+    """D2/modeling/proposal_generator/proposal_utils.py:126-196."""
+    out = []
+    logit = math.log((1.0 - 1e-10) / (1 - (1.0 - 1e-10)))
+    for g, p in zip(gt, proposals):
+        gp = Instances(p.image_size, **g.get_fields())
+        gp.proposal_boxes = g.gt_boxes
+        gp.objectness_logits = logit * torch.ones(len(g), device=p.objectness_logits.device)
+        for key in p.get_fields().keys():
+            assert gp.has(key), "The attribute '{}' in `proposals` does not exist in `gt`".format(key)
+        sel = Instances(p.image_size, proposal_boxes=gp.proposal_boxes, objectness_logits=gp.objectness_logits)
+        out.append(Instances.cat([p, sel]))
+    return out
+
+
+def select_foreground_proposals(proposals, bg_label):
+    fg, masks = [], []
+    for p in proposals:
+        m = (p.gt_classes != -1) & (p.gt_classes != bg_label)
+        fg.append(p[m.nonzero().squeeze(1)])
+        masks.append(m)
+    return fg, masks
+
+
+@ROI_HEADS_REGISTRY.register()
+class DeticCascadeROIHeads(nn.Module):
+    @configurable
+    def __init__(self, *, num_classes, batch_size_per_image, positive_fraction, proposal_append_gt, box_in_features,
+                 box_pooler, box_heads, box_predictors, cascade_ious, mask_in_features=None, mask_pooler=None,
+                 mask_head=None, mult_proposal_score=False, mask_weight=1.0, divergen_mask_loss=True,
+                 one_class_per_proposal=False, **unused):
+        super().__init__()
+        self.num_classes, self.batch_size_per_image, self.positive_fraction = num_classes, batch_size_per_image, positive_fraction
+        self.proposal_append_gt = proposal_append_gt
+        self.box_in_features, self.box_pooler = box_in_features, box_pooler
+        self.box_head, self.box_predictor = nn.ModuleList(box_heads), nn.ModuleList(box_predictors)
+        self.num_cascade_stages, self.cascade_ious = len(box_heads), list(cascade_ious)
+        self.mask_on = mask_head is not None
+        if self.mask_on:
+            self.mask_in_features, self.mask_pooler, self.mask_head = mask_in_features, mask_pooler, mask_head
+        self.mult_proposal_score, self.mask_weight = mult_proposal_score, mask_weight
+        self.divergen_mask_loss, self.one_class_per_proposal = divergen_mask_loss, one_class_per_proposal
+
+    @classmethod
+    def from_config(cls, cfg, input_shape):
+        rh, bh, ch = cfg.MODEL.ROI_HEADS, cfg.MODEL.ROI_BOX_HEAD, cfg.MODEL.ROI_BOX_CASCADE_HEAD
+        in_features = rh.IN_FEATURES
+        scales = tuple(1.0 / input_shape[k].stride for k in in_features)
+        in_ch = [input_shape[f].channels for f in in_features]
+        assert len(set(in_ch)) == 1 and bh.CLS_AGNOSTIC_BBOX_REG and ch.IOUS[0] == rh.IOU_THRESHOLDS[0]
+        assert len(ch.BBOX_REG_WEIGHTS) == len(ch.IOUS)
+        pooled = ShapeSpec(channels=in_ch[0], width=bh.POOLER_RESOLUTION, height=bh.POOLER_RESOLUTION)
+        heads, preds = [], []
+        for w in ch.BBOX_REG_WEIGHTS:
+            h = build_box_head(cfg, pooled)
+            heads.append(h)
+            preds.append(DeticFastRCNNOutputLayers(cfg, h.output_shape, box2box_transform=Box2BoxTransform(weights=w)))
+        ret = dict(num_classes=rh.NUM_CLASSES, batch_size_per_image=rh.BATCH_SIZE_PER_IMAGE,
+                   positive_fraction=rh.POSITIVE_FRACTION, proposal_append_gt=rh.PROPOSAL_APPEND_GT,
+                   box_in_features=in_features,
+                   box_pooler=ROIPooler(bh.POOLER_RESOLUTION, scales, bh.POOLER_SAMPLING_RATIO, bh.POOLER_TYPE),
+                   box_heads=heads, box_predictors=preds, cascade_ious=ch.IOUS,
+                   mult_proposal_score=bh.MULT_PROPOSAL_SCORE, mask_weight=rh.MASK_WEIGHT,
+                   divergen_mask_loss=cfg.MODEL.USE_DIVERGEN_MASK_LOSS, one_class_per_proposal=rh.ONE_CLASS_PER_PROPOSAL)
+        if cfg.MODEL.MASK_ON:
+            mh = cfg.MODEL.ROI_MASK_HEAD
+            ret.update(mask_in_features=in_features,
+                       mask_pooler=ROIPooler(mh.POOLER_RESOLUTION, scales, mh.POOLER_SAMPLING_RATIO, mh.POOLER_TYPE, out_nhwc=True),
+                       mask_head=build_mask_head(cfg, ShapeSpec(channels=in_ch[0], width=mh.POOLER_RESOLUTION, height=mh.POOLER_RESOLUTION)))
+        return ret
+
+    # ------------------------------------------------------------ sampling / matching
+    @torch.no_grad()
+    def label_and_sample_proposals(self, proposals, targets):
+        if self.proposal_append_gt:
+            proposals = add_ground_truth_to_proposals(targets, proposals)
+        out, nfg, nbg = [], [], []
+        for p, t in zip(proposals, targets):
+            has_gt = len(t) > 0
+            midx, mlab = iou_match(t.gt_boxes.tensor, p.proposal_boxes.tensor, self.cascade_ious[0])
+            if has_gt:
+                gtc = t.gt_classes[midx]
+                gtc[mlab == 0] = self.num_classes
+            else:
+                gtc = torch.zeros_like(midx) + self.num_classes
+            fg_idx, bg_idx = subsample_labels(gtc, self.batch_size_per_image, self.positive_fraction, self.num_classes)
+            sidx = torch.cat([fg_idx, bg_idx], dim=0)
+            p = p[sidx]
+            p.gt_classes = gtc[sidx]
+            if has_gt:
+                st = midx[sidx]
+                for name, val in t.get_fields().items():
+                    if (name.startswith("gt_") or name == "instance_source") and not p.has(name):
+                        p.set(name, val[st])
+            nbg.append((p.gt_classes == self.num_classes).sum())
+            nfg.append(p.gt_classes.numel() - nbg[-1])
+            out.append(p)
+        st = get_event_storage()
+        st.put_scalar("roi_head/num_fg_samples", torch.stack([x.float() for x in nfg]).mean())
+        st.put_scalar("roi_head/num_bg_samples", torch.stack([x.float() for x in nbg]).mean())
+        return out
+
+    @torch.no_grad()
+    def _match_and_label_boxes(self, proposals, stage, targets):
+        nfg, nbg = [], []
+        for p, t in zip(proposals, targets):
+            midx, mlab = iou_match(t.gt_boxes.tensor, p.proposal_boxes.tensor, self.cascade_ious[stage])
+            src = None
+            if len(t) > 0:
+                gtc = t.gt_classes[midx]
+                gtc[mlab == 0] = self.num_classes
+                if t.has("instance_source"):
+                    src = t.instance_source[midx]
+                    src[mlab == 0] = 0
+                gtb = t.gt_boxes[midx]
+            else:
+                gtc = torch.zeros_like(midx) + self.num_classes
+                gtb = Boxes(t.gt_boxes.tensor.new_zeros((len(p), 4)))
+                if t.has("instance_source"):
+                    src = torch.zeros_like(midx)
+            p.gt_classes, p.gt_boxes = gtc, gtb
+            if src is not None:
+                p.instance_source = src
+            f = (mlab == 1).sum()
+            nfg.append(f.float())
+            nbg.append(mlab.numel() - f.float())
+        st = get_event_storage()
+        st.put_scalar("stage{}/roi_head/num_fg_samples".format(stage), torch.stack(nfg).mean())
+        st.put_scalar("stage{}/roi_head/num_bg_samples".format(stage), torch.stack(nbg).mean())
+        return proposals
+
+    def _create_proposals_from_boxes(self, boxes, image_sizes, logits):
+        out = []
+        for b, size, logit in zip(boxes, image_sizes, logits):
+            b = Boxes(b.detach())
+            b.clip(size)
+            if self.training:
+                inds = b.nonempty()
+                b, logit = b[inds], logit[inds]
+            out.append(Instances(size, proposal_boxes=b, objectness_logits=logit))
+        return out
+
+    def _run_stage(self, features, proposals, stage):
+        x = self.box_pooler(features, [p.proposal_boxes for p in proposals])
+        x = _ScaleGradient.apply(x, 1.0 / self.num_cascade_stages)
+        return self.box_predictor[stage](self.box_head[stage](x))
+
+    def _forward_box(self, features, proposals, targets=None):
+        if (not self.training) and self.mult_proposal_score:
+            pscores = [p.get("scores") if p.has("scores") else p.get("objectness_logits") for p in proposals]
+        features = [features[f] for f in self.box_in_features]
+        outs, prev = [], None
+        image_sizes = [x.image_size for x in proposals]
+        for k in range(self.num_cascade_stages):
+            if k > 0:
+                proposals = self._create_proposals_from_boxes(prev, image_sizes, [p.objectness_logits for p in proposals])
+                if self.training:
+                    proposals = self._match_and_label_boxes(proposals, k, targets)
+            preds = self._run_stage(features, proposals, k)
+            prev = self.box_predictor[k].predict_boxes(preds, proposals)
+            outs.append((self.box_predictor[k], preds, proposals))
+        if self.training:
+            losses = {}
+            st = get_event_storage()
+            for stage, (pred, preds, props) in enumerate(outs):
+                with st.name_scope("stage{}".format(stage)):
+                    sl = pred.losses(preds, props)
+                losses.update({k + "_stage{}".format(stage): v for k, v in sl.items()})
+            return losses
+        scores_per_stage = [h[0].predict_probs(h[1], h[2]) for h in outs]
+        scores = [sum(list(s)) * (1.0 / self.num_cascade_stages) for s in zip(*scores_per_stage)]
+        if self.mult_proposal_score:
+            scores = [(s * ps[:, None]) ** 0.5 for s, ps in zip(scores, pscores)]
+        if self.one_class_per_proposal:
+            scores = [s * (s == s[:, :-1].max(dim=1)[0][:, None]).float() for s in scores]
+        pred, preds, props = outs[-1]
+        boxes = pred.predict_boxes(preds, props)
+        inst, _ = fast_rcnn_inference(boxes, scores, image_sizes, pred.test_score_thresh, pred.test_nms_thresh,
+                                      pred.test_topk_per_image)
+        return inst
+
+    def _forward_mask(self, features, instances):
+        if not self.mask_on:
+            return {} if self.training else instances
+        if self.training:
+            instances, _ = select_foreground_proposals(instances, self.num_classes)
+            if not self.divergen_mask_loss:
+                instances = [i[i.instance_source == 0] for i in instances]
+        feats = [features[f] for f in self.mask_in_features]
+        boxes = [x.proposal_boxes if self.training else x.pred_boxes for x in instances]
+        return self.mask_head(self.mask_pooler(feats, boxes), instances)
+
+    def forward(self, images, features, proposals, targets=None, ann_type="box", **kwargs):
+        if self.training:
+            assert ann_type == "box", "image-label / caption co-training is outside the shipped configs"
+            proposals = self.label_and_sample_proposals(proposals, targets)
+            losses = self._forward_box(features, proposals, targets)
+            if targets[0].has("gt_masks"):
+                losses.update({k: v * self.mask_weight for k, v in self._forward_mask(features, proposals).items()})
+            elif self.mask_on:
+                losses["loss_mask"] = torch.zeros((1,), device=proposals[0].objectness_logits.device)[0]
+            return proposals, losses
+        inst = self._forward_box(features, proposals)
+        return self._forward_mask(features, inst), {}

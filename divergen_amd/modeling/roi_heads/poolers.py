@@ -1,0 +1,31 @@
+"""ROIPooler over the multi-level HIP ROIAlign.  Mirrors D2/modeling/poolers.py:93-245 (ROIAlignV2)."""
+import math
+
+import torch
+from torch import nn
+
+from ...layers import roi_pooler
+
+
+class ROIPooler(nn.Module):
+    def __init__(self, output_size, scales, sampling_ratio, pooler_type, canonical_box_size=224, canonical_level=4,
+                 out_nhwc=False):
+        super().__init__()
+        if pooler_type != "ROIAlignV2":
+            raise NotImplementedError("only POOLER_TYPE ROIAlignV2 (the shipped configs) is built, got %s" % pooler_type)
+        assert canonical_box_size == 224 and canonical_level == 4
+        self.output_size = output_size if isinstance(output_size, int) else output_size[0]
+        self.scales, self.sampling_ratio, self.out_nhwc = tuple(scales), sampling_ratio, out_nhwc
+        mn, mx = -math.log2(scales[0]), -math.log2(scales[-1])
+        assert math.isclose(mn, int(mn)) and math.isclose(mx, int(mx)), "Featuremap stride is not power of 2!"
+        self.min_level, self.max_level = int(mn), int(mx)
+        assert len(scales) == self.max_level - self.min_level + 1
+
+    def forward(self, x, box_lists):
+        """x: list of (N,C,H,W); box_lists: list[Boxes] per image -> (R, C, S, S)."""
+        assert len(x) == len(self.scales) and len(box_lists) == x[0].size(0)
+        boxes = torch.cat([b.tensor for b in box_lists], dim=0)
+        idx = torch.cat([torch.full((len(b),), float(i), dtype=boxes.dtype, device=boxes.device)
+                         for i, b in enumerate(box_lists)])
+        rois = torch.cat([idx[:, None], boxes], dim=1)
+        return roi_pooler(list(x), rois, self.output_size, self.scales, self.sampling_ratio, self.out_nhwc)

@@ -1,0 +1,261 @@
+"""Batched-input contract types: Boxes, Instances, ImageList, BitMasks.
+Surface of D2/structures/{boxes.py:130-357, instances.py, image_list.py:59-110, masks.py:88-245}."""
+import itertools
+from typing import Any, Dict, List, Tuple
+
+import torch
+import torch.nn.functional as F
+
+
+class Boxes:
+    """(N,4) fp32 XYXY boxes."""
+
+    def __init__(self, tensor):
+        if not isinstance(tensor, torch.Tensor):
+            tensor = torch.as_tensor(tensor, dtype=torch.float32)
+        tensor = tensor.to(torch.float32)
+        if tensor.numel() == 0:
+            tensor = tensor.reshape((-1, 4))
+        assert tensor.dim() == 2 and tensor.size(-1) == 4, tensor.size()
+        self.tensor = tensor
+
+    def clone(self):
+        return Boxes(self.tensor.clone())
+
+    def to(self, device):
+        return Boxes(self.tensor.to(device=device))
+
+    def area(self):
+        b = self.tensor
+        return (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+
+    def clip(self, box_size):
+        h, w = box_size
+        x1 = self.tensor[:, 0].clamp(min=0, max=w)
+        y1 = self.tensor[:, 1].clamp(min=0, max=h)
+        x2 = self.tensor[:, 2].clamp(min=0, max=w)
+        y2 = self.tensor[:, 3].clamp(min=0, max=h)
+        self.tensor = torch.stack((x1, y1, x2, y2), dim=-1)
+
+    def nonempty(self, threshold=0.0):
+        b = self.tensor
+        return ((b[:, 2] - b[:, 0]) > threshold) & ((b[:, 3] - b[:, 1]) > threshold)
+
+    def __getitem__(self, item):
+        if isinstance(item, int):
+            return Boxes(self.tensor[item].view(1, -1))
+        b = self.tensor[item]
+        assert b.dim() == 2, "Indexing on Boxes with {} failed to return a matrix!".format(item)
+        return Boxes(b)
+
+    def __len__(self):
+        return self.tensor.shape[0]
+
+    def __repr__(self):
+        return "Boxes(" + str(self.tensor) + ")"
+
+    def get_centers(self):
+        return (self.tensor[:, :2] + self.tensor[:, 2:]) / 2
+
+    @property
+    def device(self):
+        return self.tensor.device
+
+    @classmethod
+    def cat(cls, boxes_list):
+        if len(boxes_list) == 0:
+            return cls(torch.empty(0))
+        return cls(torch.cat([b.tensor for b in boxes_list], dim=0))
+
+
+def pairwise_iou(boxes1: Boxes, boxes2: Boxes):
+    """boxes.py:310-357 (torch ops; the training path uses layers.iou_match instead)."""
+    b1, b2 = boxes1.tensor, boxes2.tensor
+    wh = (torch.min(b1[:, None, 2:], b2[:, 2:]) - torch.max(b1[:, None, :2], b2[:, :2])).clamp_(min=0)
+    inter = wh.prod(dim=2)
+    return torch.where(inter > 0, inter / (boxes1.area()[:, None] + boxes2.area() - inter),
+                       torch.zeros(1, dtype=inter.dtype, device=inter.device))
+
+
+class BitMasks:
+    """(N,H,W) bool masks."""
+
+    def __init__(self, tensor):
+        if not isinstance(tensor, torch.Tensor):
+            tensor = torch.as_tensor(tensor)
+        tensor = tensor.to(torch.bool)
+        assert tensor.dim() == 3, tensor.size()
+        self.image_size = tensor.shape[1:]
+        self.tensor = tensor
+
+    def to(self, *args, **kwargs):
+        return BitMasks(self.tensor.to(*args, **kwargs))
+
+    @property
+    def device(self):
+        return self.tensor.device
+
+    def __getitem__(self, item):
+        if isinstance(item, int):
+            return BitMasks(self.tensor[item].unsqueeze(0))
+        m = self.tensor[item]
+        assert m.dim() == 3
+        return BitMasks(m)
+
+    def __len__(self):
+        return self.tensor.shape[0]
+
+    def nonempty(self):
+        return self.tensor.flatten(1).any(dim=1)
+
+    def crop_and_resize(self, boxes, mask_size):
+        """masks.py:189-220 through the byte-tap HIP crop (no fp32 mask copy)."""
+        from ..layers import mask_crop
+        idx = torch.arange(len(boxes), device=boxes.device, dtype=torch.int32)
+        return mask_crop(self.tensor, boxes, idx, mask_size)
+
+    def get_bounding_boxes(self):
+        boxes = torch.zeros(self.tensor.shape[0], 4, dtype=torch.float32)
+        x_any = torch.any(self.tensor, dim=1)
+        y_any = torch.any(self.tensor, dim=2)
+        for i in range(self.tensor.shape[0]):
+            x = torch.where(x_any[i, :])[0]
+            y = torch.where(y_any[i, :])[0]
+            if len(x) > 0 and len(y) > 0:
+                boxes[i, :] = torch.as_tensor([x[0], y[0], x[-1] + 1, y[-1] + 1], dtype=torch.float32)
+        return Boxes(boxes)
+
+    @staticmethod
+    def cat(lst):
+        return BitMasks(torch.cat([m.tensor for m in lst], dim=0))
+
+
+class Instances:
+    """Per-image bag of equal-length fields (instances.py)."""
+
+    def __init__(self, image_size: Tuple[int, int], **kwargs: Any):
+        object.__setattr__(self, "_image_size", image_size)
+        object.__setattr__(self, "_fields", {})
+        for k, v in kwargs.items():
+            self.set(k, v)
+
+    @property
+    def image_size(self):
+        return self._image_size
+
+    def __setattr__(self, name, val):
+        if name.startswith("_"):
+            object.__setattr__(self, name, val)
+        else:
+            self.set(name, val)
+
+    def __getattr__(self, name):
+        if name == "_fields" or name not in self._fields:
+            raise AttributeError("Cannot find field '{}' in the given Instances!".format(name))
+        return self._fields[name]
+
+    def set(self, name, value):
+        data_len = len(value)
+        if len(self._fields):
+            assert len(self) == data_len, "Adding a field of length {} to a Instances of length {}".format(data_len, len(self))
+        self._fields[name] = value
+
+    def has(self, name):
+        return name in self._fields
+
+    def remove(self, name):
+        del self._fields[name]
+
+    def get(self, name):
+        return self._fields[name]
+
+    def get_fields(self):
+        return self._fields
+
+    def to(self, *args, **kwargs):
+        ret = Instances(self._image_size)
+        for k, v in self._fields.items():
+            if hasattr(v, "to"):
+                v = v.to(*args, **kwargs)
+            ret.set(k, v)
+        return ret
+
+    def __getitem__(self, item):
+        if type(item) == int:
+            if item >= len(self) or item < -len(self):
+                raise IndexError("Instances index out of range!")
+            item = slice(item, None, len(self))
+        ret = Instances(self._image_size)
+        for k, v in self._fields.items():
+            ret.set(k, v[item])
+        return ret
+
+    def __len__(self):
+        for v in self._fields.values():
+            return v.__len__()
+        raise NotImplementedError("Empty Instances does not support __len__!")
+
+    @staticmethod
+    def cat(instance_lists):
+        assert len(instance_lists) > 0
+        if len(instance_lists) == 1:
+            return instance_lists[0]
+        image_size = instance_lists[0].image_size
+        ret = Instances(image_size)
+        for k in instance_lists[0]._fields.keys():
+            values = [i.get(k) for i in instance_lists]
+            v0 = values[0]
+            if isinstance(v0, torch.Tensor):
+                values = torch.cat(values, dim=0)
+            elif isinstance(v0, list):
+                values = list(itertools.chain(*values))
+            elif hasattr(type(v0), "cat"):
+                values = type(v0).cat(values)
+            else:
+                raise ValueError("Unsupported type {} for concatenation".format(type(v0)))
+            ret.set(k, values)
+        return ret
+
+    def __repr__(self):
+        return "Instances(num={}, size={}, fields=[{}])".format(
+            len(self) if self._fields else 0, self._image_size,
+            ", ".join("{}: {}".format(k, type(v).__name__) for k, v in self._fields.items()))
+
+
+class ImageList:
+    """Batch of images padded to a common, divisible size (image_list.py:59-110)."""
+
+    def __init__(self, tensor, image_sizes):
+        self.tensor = tensor
+        self.image_sizes = image_sizes
+
+    def __len__(self):
+        return len(self.image_sizes)
+
+    def __getitem__(self, idx):
+        size = self.image_sizes[idx]
+        return self.tensor[idx, ..., : size[0], : size[1]]
+
+    @property
+    def device(self):
+        return self.tensor.device
+
+    @staticmethod
+    def from_tensors(tensors, size_divisibility=0, pad_value=0.0):
+        assert len(tensors) > 0
+        image_sizes = [(im.shape[-2], im.shape[-1]) for im in tensors]
+        max_h = max(s[0] for s in image_sizes)
+        max_w = max(s[1] for s in image_sizes)
+        if size_divisibility > 1:
+            st = size_divisibility
+            max_h = (max_h + (st - 1)) // st * st
+            max_w = (max_w + (st - 1)) // st * st
+        if len(tensors) == 1:
+            h, w = image_sizes[0]
+            batched = F.pad(tensors[0], [0, max_w - w, 0, max_h - h], value=pad_value).unsqueeze_(0)
+        else:
+            shape = [len(tensors)] + list(tensors[0].shape[:-2]) + [max_h, max_w]
+            batched = tensors[0].new_full(shape, pad_value)
+            for img, pad_img in zip(tensors, batched):
+                pad_img[..., : img.shape[-2], : img.shape[-1]].copy_(img)
+        return ImageList(batched.contiguous(), image_sizes)

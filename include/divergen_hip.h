@@ -171,6 +171,18 @@ int dgx_adamw_ema_step(float* p, const float* g, float* m, float* v, float* ema,
                        const float* lr_scale, const int64_t* seg_end, int n_seg,
                        const int32_t* found_inf, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * 3x3 / pad 1 / stride 1|2 convolution as im2col + library GEMM on channels-last tensors.
+ * Replaces the cuDNN (here: MIOpen) calls behind nn.Conv2d at D2/modeling/backbone/fpn.py:126-154,
+ * CN/modeling/backbone/fpn_p5.py:30-33, CN/modeling/dense_heads/centernet_head.py:141-162 and
+ * D2/modeling/roi_heads/mask_head.py:209-284.
+ *   x   (N,H,W,C)                 col  (N*Ho*Wo, 9*C), tap-major (ky,kx,c)
+ *   col2im is the adjoint (gather form, fp32 accumulation): dx (N,H,W,C) <- dcol (N*Ho*Wo, 9*C). */
+int dgx_im2col3x3(const void* x, void* col, int N, int H, int W, int C, int stride, int dtype,
+                  void* stream);
+int dgx_col2im3x3(const void* dcol, void* dx, int N, int H, int W, int C, int stride, int dtype,
+                  void* stream);
+
 #ifdef __cplusplus
 }
 #endif

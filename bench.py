@@ -1,0 +1,232 @@
+"""bench.py -- images/sec of the DiverGen training step (Swin-L CenterNet2, 1024 px, LVIS-shaped
+synthetic data + copy-paste) on N MI355X of one node.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" = for the rank's 2 images: GPU copy-paste compositor (19 pastes/image) -> forward ->
+backward (gradient all-reduce over RCCL overlapped) -> fused clip+AdamW+EMA.  Inputs are resident in
+HBM when the timed region starts.  Prints ONE JSON line (rank 0)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=8)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--size", type=int, default=1024)
+    p.add_argument("--swin", default="L-22k-384")
+    p.add_argument("--batch", type=int, default=2, help="images per GPU (IMS_PER_BATCH 16 / 8 GPUs)")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-copy-paste", action="store_true")
+    return p.parse_args()
+
+
+def make_pastes(rng, size, k=19):
+    out = []
+    for i in range(k):
+        s = int(rng.uniform(0.05, 0.3) * size)
+        rgba = rng.integers(0, 256, (s, s, 4), dtype=np.uint8)
+        yy, xx = np.mgrid[0:s, 0:s]
+        rgba[..., 3] *= ((((xx - s / 2) / (s / 2)) ** 2 + ((yy - s / 2) / (s / 2)) ** 2) <= 1).astype(np.uint8)
+        out.append((rgba, int(rng.integers(-s // 2, size - s // 2)), int(rng.integers(-s // 2, size - s // 2)),
+                    int(rng.integers(1203, 1453))))
+    return out
+
+
+class KernelTimer:
+    """HIP events around one libdgx entry point, recorded on the stream the kernel is launched on."""
+
+    def __init__(self, lib, name):
+        self.lib, self.name, self.events, self.enabled = lib, name, [], False
+        self.orig = getattr(lib, name)
+
+        def wrapped(*a):
+            if not self.enabled:
+                return self.orig(*a)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = self.orig(*a)
+            e.record()
+            self.events.append((s, e, a))
+            return r
+        wrapped.argtypes, wrapped.restype = self.orig.argtypes, self.orig.restype
+        setattr(lib, name, wrapped)
+
+
+def cpu_baseline(swin, budget_s=25.0):
+    """Oracle (CPU restatement of the reference backbone, pinned on the reference's goldens) timed on
+    this box's host cores: Swin fwd+bwd on ONE image, at the largest power-of-two size that fits the
+    time budget; reported as 1024^2-equivalent images/s by token count."""
+    from oracle import swin as OSW
+    from tests._recipes import fill_state, swin_param_shapes
+    c = OSW.SIZE2CONFIG[swin]
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    p = fill_state(swin_param_shapes(c["embed_dim"], c["depths"], c["num_heads"], c["ws"]), 7, 0.02)
+    for v in p.values():
+        v.requires_grad_(True)
+    size, t = 128, None
+    while True:
+        img = torch.randn(1, 3, size, size)
+        t0 = time.time()
+        outs = OSW.swin_forward(img, p, c["embed_dim"], c["depths"], c["num_heads"], c["ws"])
+        sum(o.square().mean() for o in outs.values()).backward()
+        t = time.time() - t0
+        if t * 5 > budget_s or size >= 1024:
+            break
+        size *= 2
+    scale = (1024.0 / size) ** 2
+    return {"value": 1.0 / (t * scale), "unit": "images/s (1024^2-equivalent, Swin backbone fwd+bwd only)",
+            "cores": cores, "kind": "port",
+            "sample": "oracle/swin.py Swin-%s fwd+bwd, 1 image %dx%d, %.1f s, scaled x%.0f by pixel count" % (swin, size, size, t, scale)}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == a.gpus, "launch one process per GPU (WORLD_SIZE=%d, --gpus %d)" % (world, a.gpus)
+
+    from divergen_amd import _lib
+    from divergen_amd import layers as la
+    from divergen_amd.config import get_cfg
+    from divergen_amd.data import synthetic_batch
+    from divergen_amd.engine import ArenaReducer
+    from divergen_amd.modeling import build_model
+    from divergen_amd.solver import build_lr_scheduler, build_optimizer
+    from divergen_amd.structures import BitMasks, Boxes, Instances
+    from divergen_amd.utils.events import EventStorage
+
+    cfg = get_cfg()
+    cfg.merge_from_file(os.path.join(ROOT, "tests", "configs", "DiverGen_swinL.yaml"))
+    cfg.merge_from_list(["MODEL.SWIN.SIZE", a.swin, "INPUT.TRAIN_SIZE", a.size, "MODEL.ROI_BOX_HEAD.CAT_FREQ_PATH",
+                         os.path.join(ROOT, "tests", "configs", "metadata",
+                                      "ImageNet2012_filtered04_lvis_v1_train_cat_info_250.json")])
+    torch.manual_seed(cfg.SEED + rank)
+    model = build_model(cfg).train()
+    opt = build_optimizer(cfg, model)
+    sched = build_lr_scheduler(cfg, opt)
+    reducer = ArenaReducer(opt.arena)
+    reducer.broadcast_parameters()
+    if opt.ema is not None:
+        opt.ema.copy_(opt.arena.p)
+    nparams = sum(p.numel() for p in model.parameters())
+
+    base = synthetic_batch(a.batch, a.size, cfg.MODEL.ROI_HEADS.NUM_CLASSES, seed=1234 + rank, device=dev)
+    rng = np.random.default_rng(7 + rank)
+    pastes = [make_pastes(rng, a.size) for _ in range(a.batch)]
+    # pre-stage paste patches as device tensors so the timed region starts with inputs resident in HBM
+    pastes = [[(torch.from_numpy(r).to(dev), x, y, l) for r, x, y, l in ps] for ps in pastes]
+
+    def one_step():
+        batch = []
+        for d, ps in zip(base, pastes):
+            inst = d["instances"]
+            if a.no_copy_paste:
+                batch.append(d)
+                continue
+            out = la.copy_paste(d["image"], inst.gt_masks.tensor.view(torch.uint8), inst.gt_boxes.tensor,
+                                inst.gt_classes, ps)
+            ni = Instances(inst.image_size)
+            ni.gt_boxes, ni.gt_classes = Boxes(out["boxes"]), out["labels"]
+            ni.gt_masks, ni.instance_source = BitMasks(out["masks"]), out["source"]
+            batch.append({"image": out["image"], "instances": ni, "height": d["height"], "width": d["width"],
+                          "file_name": d["file_name"]})
+        opt.zero_grad()
+        losses = model(batch)
+        total = sum(losses.values())
+        total.backward()
+        scale = reducer.finish()
+        opt.step(grad_scale=scale)
+        sched.step()
+        return total
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    L = _lib.lib()
+    timers = {n: KernelTimer(L, n) for n in ("dgx_window_attention_fwd", "dgx_window_attention_bwd")}
+    with EventStorage(0):
+        for _ in range(a.warmup):
+            one_step()
+        sync()
+        for t in timers.values():
+            t.enabled = True
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            total = one_step()
+        sync()
+        dt = time.perf_counter() - t0
+    assert bool(torch.isfinite(total)), "non-finite loss"
+    tmax = torch.tensor([dt], device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax)
+    imgs = a.batch * world * a.steps
+
+    # roofline of the dominant libdgx kernel, from HIP events recorded around its launches
+    roof = None
+    best = None
+    for name, t in timers.items():
+        if not t.events:
+            continue
+        tot_ms, flops, nbytes = 0.0, 0.0, 0.0
+        for s, e, args in t.events:
+            tot_ms += s.elapsed_time(e)
+            if name.endswith("fwd"):
+                B_, nH, ws = args[5], args[7], args[8]
+                mm = 2
+            else:
+                B_, nH, ws = args[8], args[10], args[11]
+                mm = 5
+            N = ws * ws
+            flops += B_ * nH * mm * 2.0 * N * N * 32
+            nbytes += B_ * N * nH * 32 * 2 * (4 if mm == 2 else 9)
+        if best is None or tot_ms > best[1]:
+            best = (name, tot_ms, flops, nbytes, len(t.events))
+    if best is not None:
+        name, tot_ms, flops, nbytes, calls = best
+        ach = flops / (tot_ms * 1e-3) / 1e12
+        roof = {"kernel": name, "bound": "mfma", "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": ach / 2500.0,
+                "traffic": None, "avg_launch_us": tot_ms * 1e3 / calls, "launches": calls,
+                "algorithmic_gbytes_per_s": nbytes / (tot_ms * 1e-3) / 1e9}
+
+    if rank == 0:
+        line = {"metric": "images/sec (node) Swin-L CenterNet2 LVIS 1024px", "value": imgs / dt, "unit": "images/s",
+                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+                "data": "synthetic (random-init weights, LVIS-shaped boxes/masks, 19 RGBA pastes per image)",
+                "config": {"workload": "CenterNet2 Swin-%s, %dx%d, %d images/GPU, 1453 classes, GPU copy-paste + fwd + bwd + "
+                                       "fused clip/AdamW/EMA; configs/DiverGen_swinL.yaml" % (a.swin, a.size, a.size, a.batch),
+                           "global_batch": a.batch * world, "parallelism": "dp%d" % world, "params_M": nparams / 1e6},
+                "roofline": roof}
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(a.swin)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,75 @@
+"""Data-parallel gradient reduction over the flat gradient arena (one process per GPU, RCCL).
+
+Replaces torch DistributedDataParallel as used at DG/train_net.py:357-362
+(broadcast_buffers=False, find_unused_parameters=True): gradients already live contiguously in
+FlatArena.g, so a bucket is a SLICE of that arena -- no flatten/unflatten copies, no reducer graph
+walk.  Buckets are cut in reverse registration order (mask head -> box heads -> CenterNet head ->
+FPN -> Swin stage 3..0), each bucket's all-reduce is launched from the post-accumulate hook of its
+last gradient (RCCL runs it on its own stream, ordered after the producing kernels) and overlaps
+the rest of backward; buckets whose parameters received no gradient this step (the reference's
+'unused parameter' case, e.g. the mask head on a batch without masks) are flushed zero-filled at
+the end.  Averaging (1/world) is folded into the optimizer kernel's grad_scale.
+xGMI is point-to-point, so a ring all-reduce is bound by one ~153 GB/s link: buckets default to
+64 MiB (fewer, larger collectives) rather than DDP's 25 MiB."""
+import torch
+import torch.distributed as dist
+
+
+class ArenaReducer:
+    def __init__(self, arena, bucket_bytes=64 << 20, process_group=None):
+        self.arena, self.group = arena, process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        n = len(arena.params)
+        ends = arena.segment_ends()
+        self.buckets = []           # (start, end) element ranges, in launch (reverse) order
+        self.bucket_of = [0] * n
+        cap = bucket_bytes // 4
+        hi = n - 1
+        while hi >= 0:
+            lo = hi
+            while lo - 1 >= 0 and ends[hi] - arena.offsets[lo - 1] <= cap:
+                lo -= 1
+            for i in range(lo, hi + 1):
+                self.bucket_of[i] = len(self.buckets)
+            self.buckets.append((arena.offsets[lo], ends[hi], hi - lo + 1))
+            hi = lo - 1
+        self._pending = [b[2] for b in self.buckets]
+        self._launched = [False] * len(self.buckets)
+        self._works = []
+        if self.world > 1:
+            for i, p in enumerate(arena.params):
+                p.register_post_accumulate_grad_hook(self._make_hook(i))
+
+    def _make_hook(self, i):
+        b = self.bucket_of[i]
+
+        def hook(_param):
+            self._pending[b] -= 1
+            if self._pending[b] == 0:
+                self._launch(b)
+        return hook
+
+    def _launch(self, b):
+        if self._launched[b]:
+            return
+        self._launched[b] = True
+        s, e, _ = self.buckets[b]
+        self._works.append(dist.all_reduce(self.arena.g[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def broadcast_parameters(self, src=0):
+        """Same initial weights on every rank (DDP's constructor broadcast)."""
+        if self.world > 1:
+            dist.broadcast(self.arena.p, src=src, group=self.group)
+
+    def finish(self):
+        """Call after backward: flush never-ready buckets, wait for every collective.  Returns the
+        factor the optimizer must apply to the summed gradients."""
+        if self.world > 1:
+            for b in range(len(self.buckets)):
+                self._launch(b)
+            for w in self._works:
+                w.wait()
+        self._works = []
+        self._pending = [b[2] for b in self.buckets]
+        self._launched = [False] * len(self.buckets)
+        return 1.0 / self.world

@@ -18,15 +18,16 @@ def copy_paste(image, masks, boxes, labels, pastes):
                     source=torch.zeros(n0, dtype=torch.int64, device=dev))
     desc, chunks, off = [], [], 0
     for rgba, x0, y0, _ in pastes:
-        a = torch.as_tensor(np.ascontiguousarray(rgba) if isinstance(rgba, np.ndarray) else rgba).reshape(-1)
-        h, w = rgba.shape[0], rgba.shape[1]
+        a = rgba if isinstance(rgba, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(rgba))
+        h, w = int(a.shape[0]), int(a.shape[1])
+        a = a.to(dev, non_blocking=True).reshape(-1)
         desc.append([off, h, w, int(x0), int(y0)])
         chunks.append(a)
-        off += (a.numel() + 3) // 4 * 4
-    flat = torch.zeros(off, dtype=torch.uint8)
-    for d, a in zip(desc, chunks):
-        flat[d[0]:d[0] + a.numel()] = a.cpu()
-    flat = flat.to(dev)
+        pad = (-a.numel()) % 4
+        if pad:
+            chunks.append(torch.zeros(pad, dtype=torch.uint8, device=dev))
+        off += a.numel() + pad
+    flat = torch.cat(chunks)
     desc_t = torch.tensor(desc, dtype=torch.int32, device=dev)
     image = image.contiguous().clone()
     masks = masks.contiguous()

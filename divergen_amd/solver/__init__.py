@@ -1,0 +1,161 @@
+"""Solver: flat-arena fused AdamW(+value clip)+EMA, WarmupCosineLR, ModelEma surface.
+
+Reference: DG/divergen/custom_solver.py:19-77 (AdamW, one param group per tensor, per-param
+clip_grad_value_), D2/solver/build.py:24-112, D2/solver/lr_scheduler.py:171-238, DG/divergen/ema.py.
+
+MI355X-first: all trainable parameters live in ONE fp32 arena (parameters are views into it), so
+do gradients, Adam moments and the EMA copy.  A step is one HBM sweep of one kernel
+(dgx_adamw_ema_step: 36 B/param) instead of ~400 per-tensor clip + foreach-AdamW launches and a
+Python loop of ~400 EMA lerps; and the gradient arena is what the data-parallel reducer all-reduces
+in place, bucket by bucket, without flatten/unflatten copies."""
+import math
+from collections import OrderedDict
+
+import torch
+
+from ..layers import adamw_ema_step
+
+
+def warmup_cosine_lr(base_lr, it, max_iters, warmup_iters, warmup_factor, warmup_method="linear"):
+    """D2/solver/lr_scheduler.py:190-238."""
+    if it >= warmup_iters:
+        wf = 1.0
+    elif warmup_method == "constant":
+        wf = warmup_factor
+    elif warmup_method == "linear":
+        a = it / warmup_iters
+        wf = warmup_factor * (1 - a) + a
+    else:
+        raise ValueError("Unknown warmup method: {}".format(warmup_method))
+    return base_lr * wf * 0.5 * (1.0 + math.cos(math.pi * it / max_iters))
+
+
+class FlatArena:
+    """Re-homes every trainable parameter of `model` into one contiguous fp32 buffer (16-byte
+    aligned segments) and gives each a persistent .grad view into a second buffer."""
+
+    def __init__(self, model):
+        params, seen = [], set()
+        for name, p in model.named_parameters():
+            if p.requires_grad and id(p) not in seen:
+                seen.add(id(p))
+                params.append((name, p))
+        self.names = [n for n, _ in params]
+        self.params = [p for _, p in params]
+        dev = self.params[0].device
+        offs, n = [], 0
+        for p in self.params:
+            offs.append(n)
+            n += (p.numel() + 3) // 4 * 4
+        self.offsets, self.numel = offs, n
+        self.p = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.g = torch.zeros(n, dtype=torch.float32, device=dev)
+        for p, o in zip(self.params, offs):
+            v = self.p[o:o + p.numel()].view_as(p)
+            v.copy_(p.data)
+            p.data = v
+            p.grad = self.g[o:o + p.numel()].view_as(p)
+
+    def zero_grad(self):
+        self.g.zero_()
+
+    def segment_ends(self):
+        return [o + (p.numel() + 3) // 4 * 4 for o, p in zip(self.offsets, self.params)]
+
+
+class FusedAdamWEMA:
+    """Optimizer + EMA over a FlatArena.  API mirrors torch.optim (step/zero_grad/state_dict) as far
+    as the training loop and the checkpointer need."""
+
+    def __init__(self, arena, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4, clip_value=1.0,
+                 ema_decay=0.0, lr_multipliers=None):
+        self.arena, self.lr, self.betas, self.eps = arena, lr, betas, eps
+        self.weight_decay, self.clip_value, self.ema_decay = weight_decay, clip_value, ema_decay
+        self.m = torch.zeros_like(arena.p)
+        self.v = torch.zeros_like(arena.p)
+        self.ema = arena.p.clone() if ema_decay > 0 else None
+        self.step_count = 0
+        self.lr_scale = self.seg_end = None
+        if lr_multipliers is not None and any(abs(x - 1.0) > 0 for x in lr_multipliers):
+            self.lr_scale = torch.tensor(lr_multipliers, dtype=torch.float32, device=arena.p.device)
+            self.seg_end = torch.tensor(arena.segment_ends(), dtype=torch.int64, device=arena.p.device)
+        self.param_groups = [{"lr": lr}]
+
+    def zero_grad(self, set_to_none=False):
+        self.arena.zero_grad()
+
+    def step(self, grad_scale=1.0, found_inf=None):
+        self.step_count += 1
+        adamw_ema_step(self.arena.p, self.arena.g, self.m, self.v, self.ema, self.step_count, self.param_groups[0]["lr"],
+                       self.betas, self.eps, self.weight_decay, self.clip_value, grad_scale, self.ema_decay,
+                       lr_scale=self.lr_scale, seg_end=self.seg_end, found_inf=found_inf)
+
+    def state_dict(self):
+        return {"step": self.step_count, "exp_avg": self.m, "exp_avg_sq": self.v, "lr": self.param_groups[0]["lr"],
+                "names": self.arena.names, "offsets": self.arena.offsets}
+
+    def load_state_dict(self, sd):
+        self.step_count = int(sd["step"])
+        self.m.copy_(sd["exp_avg"])
+        self.v.copy_(sd["exp_avg_sq"])
+
+    # ---- EMA surface (DG/divergen/ema.py: state_dict / load_state_dict, keys = model state-dict keys)
+    def ema_state_dict(self, model):
+        out = OrderedDict()
+        view = {n: self.ema[o:o + p.numel()].view_as(p) for n, o, p in zip(self.arena.names, self.arena.offsets, self.arena.params)}
+        for k, v in model.state_dict().items():
+            out[k] = view[k] if k in view else v
+        return out
+
+    def load_ema_state_dict(self, sd):
+        for n, o, p in zip(self.arena.names, self.arena.offsets, self.arena.params):
+            key = n if n in sd else ("module." + n if "module." + n in sd else None)
+            if key is not None:
+                self.ema[o:o + p.numel()].view_as(p).copy_(sd[key])
+
+
+def build_optimizer(cfg, model):
+    """build_custom_optimizer (custom_solver.py:19-77) for OPTIMIZER == 'ADAMW' with value clipping."""
+    s = cfg.SOLVER
+    if not (s.USE_CUSTOM_SOLVER and s.OPTIMIZER == "ADAMW"):
+        raise NotImplementedError("only SOLVER.USE_CUSTOM_SOLVER with OPTIMIZER ADAMW (the shipped configs) is built")
+    assert s.CLIP_GRADIENTS.CLIP_TYPE == "value", "shipped configs clip by value"
+    arena = FlatArena(model)
+    mult = []
+    for name in arena.names:
+        m = 1.0
+        if "backbone" in name:
+            m *= s.BACKBONE_MULTIPLIER
+        if any(k in name for k in s.CUSTOM_MULTIPLIER_NAME):
+            m *= s.CUSTOM_MULTIPLIER
+        mult.append(m)
+    clip = s.CLIP_GRADIENTS.CLIP_VALUE if s.CLIP_GRADIENTS.ENABLED else 0.0
+    return FusedAdamWEMA(arena, s.BASE_LR, weight_decay=s.WEIGHT_DECAY, clip_value=clip, ema_decay=s.MODEL_EMA,
+                         lr_multipliers=mult)
+
+
+class WarmupCosineLR:
+    def __init__(self, optimizer, max_iters, warmup_factor=0.001, warmup_iters=1000, warmup_method="linear", last_epoch=-1):
+        self.opt, self.max_iters = optimizer, max_iters
+        self.wf, self.wi, self.wm = warmup_factor, warmup_iters, warmup_method
+        self.base_lr = optimizer.lr
+        self.last_epoch = last_epoch
+        self.step()
+
+    def step(self):
+        self.last_epoch += 1
+        self.opt.param_groups[0]["lr"] = warmup_cosine_lr(self.base_lr, self.last_epoch, self.max_iters, self.wi, self.wf, self.wm)
+
+    def state_dict(self):
+        return {"last_epoch": self.last_epoch}
+
+    def load_state_dict(self, sd):
+        self.last_epoch = sd["last_epoch"] - 1
+        self.step()
+
+
+def build_lr_scheduler(cfg, optimizer):
+    s = cfg.SOLVER
+    if s.LR_SCHEDULER_NAME != "WarmupCosineLR":
+        raise NotImplementedError(s.LR_SCHEDULER_NAME)
+    return WarmupCosineLR(optimizer, s.MAX_ITER, s.WARMUP_FACTOR, s.WARMUP_ITERS, s.WARMUP_METHOD)

@@ -1,0 +1,142 @@
+"""CPU tests of the host-side mirror: config surface, registries / state-dict key names, LR schedule,
+arena bucketing, and the world_size-2 gloo path of the arena reducer."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CFG = os.path.join(ROOT, "tests", "configs")
+FREQ = os.path.join(CFG, "metadata", "ImageNet2012_filtered04_lvis_v1_train_cat_info_250.json")
+
+
+def _cfg(name="DiverGen_swinL.yaml", opts=()):
+    from divergen_amd.config import get_cfg
+    cfg = get_cfg()
+    cfg.merge_from_file(os.path.join(CFG, name))
+    cfg.merge_from_list(["MODEL.DEVICE", "cpu", "MODEL.ROI_BOX_HEAD.CAT_FREQ_PATH", FREQ] + list(opts))
+    return cfg
+
+
+def test_reference_yamls_load_unchanged():
+    cfg = _cfg()
+    assert cfg.MODEL.META_ARCHITECTURE == "CustomRCNN" and cfg.MODEL.PROPOSAL_GENERATOR.NAME == "CenterNet"
+    assert cfg.MODEL.ROI_HEADS.NAME == "DeticCascadeROIHeads" and cfg.MODEL.ROI_HEADS.NUM_CLASSES == 1453
+    assert cfg.MODEL.BACKBONE.NAME == "build_swintransformer_fpn_backbone" and cfg.MODEL.SWIN.SIZE == "L-22k-384"
+    assert cfg.SOLVER.BASE_LR == 1e-4 and cfg.SOLVER.MODEL_EMA == 0.999 and cfg.SOLVER.IMS_PER_BATCH == 16
+    assert cfg.INPUT.TRAIN_SIZE == 896 and cfg.INPUT.INST_POOL_SAMPLE_TYPE == "cas_random" and cfg.FP16 is True
+    assert cfg.MODEL.CENTERNET.POST_NMS_TOPK_TRAIN == 2000 and cfg.MODEL.ROI_BOX_CASCADE_HEAD.IOUS == [0.6, 0.7, 0.8]
+    base = _cfg("baseline_swinL.yaml")
+    assert base.MODEL.ROI_HEADS.NUM_CLASSES == 1203 and base.INPUT.INST_POOL is False
+    with pytest.raises(KeyError):
+        cfg.merge_from_list(["MODEL.NO_SUCH_KEY", 1])
+    cfg.freeze()
+    with pytest.raises(AttributeError):
+        cfg.SEED = 1
+
+
+def test_registry_build_and_state_dict_keys():
+    from divergen_amd.modeling import build_model
+    model = build_model(_cfg(opts=["MODEL.SWIN.SIZE", "T"]))
+    keys = set(model.state_dict().keys())
+    for k in ["backbone.bottom_up.layers.2.blocks.5.attn.qkv.weight",
+              "backbone.bottom_up.layers.0.blocks.1.attn.relative_position_bias_table",
+              "backbone.bottom_up.layers.0.blocks.1.attn.relative_position_index",
+              "backbone.bottom_up.layers.1.downsample.reduction.weight", "backbone.bottom_up.norm3.bias",
+              "backbone.bottom_up.patch_embed.proj.weight", "backbone.fpn_lateral3.weight", "backbone.fpn_output5.bias",
+              "backbone.top_block.p6.weight", "backbone.top_block.p7.bias",
+              "proposal_generator.centernet_head.bbox_tower.0.weight", "proposal_generator.centernet_head.bbox_tower.10.bias",
+              "proposal_generator.centernet_head.agn_hm.weight", "proposal_generator.centernet_head.scales.4.scale",
+              "roi_heads.box_head.2.fc1.weight", "roi_heads.box_predictor.0.cls_score.bias",
+              "roi_heads.box_predictor.1.bbox_pred.weight", "roi_heads.box_predictor.2.freq_weight",
+              "roi_heads.mask_head.mask_fcn4.weight", "roi_heads.mask_head.deconv.weight", "roi_heads.mask_head.predictor.bias"]:
+        assert k in keys, k
+    sd = model.state_dict()
+    assert sd["roi_heads.box_predictor.0.cls_score.weight"].shape == (1454, 1024)
+    assert sd["roi_heads.box_head.0.fc1.weight"].shape == (1024, 256 * 7 * 7)
+    assert sd["backbone.bottom_up.layers.0.blocks.0.attn.relative_position_bias_table"].shape == (169, 3)
+    # the HIP path is the only path: a forward on CPU tensors must fail loudly
+    from divergen_amd._lib import DgxError
+    from divergen_amd.data import synthetic_batch
+    from divergen_amd.utils.events import EventStorage
+    with EventStorage(0), pytest.raises((DgxError, RuntimeError)):
+        model.train()(synthetic_batch(1, 64, 1453))
+
+
+def test_lr_schedule_and_arena_buckets(golden):
+    from divergen_amd.solver import warmup_cosine_lr
+    g = golden("solver")
+    for it in range(12):
+        assert abs(warmup_cosine_lr(1e-2, it, 100, 10, 1e-4) - float(g["lrs"][it])) < 1e-12
+    from divergen_amd.engine.ddp import ArenaReducer
+    from divergen_amd.solver import FlatArena
+    net = torch.nn.Sequential(torch.nn.Linear(10, 7), torch.nn.Linear(7, 5), torch.nn.Linear(5, 3))
+    ar = FlatArena(net)
+    assert ar.numel % 4 == 0 and all(o % 4 == 0 for o in ar.offsets)
+    assert all(p.data_ptr() == ar.p[o:].data_ptr() for p, o in zip(ar.params, ar.offsets))
+    red = ArenaReducer(ar, bucket_bytes=64 * 4)
+    # buckets tile the arena back to front, contiguously
+    assert red.buckets[0][1] == ar.numel and red.buckets[-1][0] == 0
+    for a, b in zip(red.buckets[:-1], red.buckets[1:]):
+        assert b[1] == a[0]
+    (net(torch.randn(4, 10)) ** 2).sum().backward()
+    assert ar.g.abs().sum() > 0 and ar.params[0].grad.data_ptr() == ar.g.data_ptr()
+
+
+def _ddp_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from divergen_amd.engine.ddp import ArenaReducer
+    from divergen_amd.solver import FlatArena
+    torch.manual_seed(100 + rank)  # different init per rank -> broadcast must equalise
+    net = torch.nn.Sequential(torch.nn.Linear(6, 9), torch.nn.ReLU(), torch.nn.Linear(9, 4), torch.nn.Linear(4, 2))
+    unused = torch.nn.Linear(3, 3)  # never used in forward: the "unused parameter" bucket
+    model = torch.nn.ModuleList([net, unused])
+    ar = FlatArena(model)
+    red = ArenaReducer(ar, bucket_bytes=40 * 4)
+    red.broadcast_parameters()
+    p0 = ar.p.clone()
+    x = torch.full((5, 6), float(rank + 1))
+    for _ in range(2):  # two iterations: bucket bookkeeping must reset
+        ar.zero_grad()
+        net(x).sum().backward()
+        scale = red.finish()
+    q.put((rank, p0, ar.g.clone() * scale))
+    dist.destroy_process_group()
+
+
+def test_arena_reducer_world2_gloo():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, p_a, g_a), (_, p_b, g_b) = res
+    assert torch.equal(p_a, p_b)            # parameters broadcast from rank 0
+    assert torch.allclose(g_a, g_b)         # averaged gradients identical on both ranks
+    # reference value: mean of the two single-rank gradients, computed locally with the same weights
+    from divergen_amd.solver import FlatArena
+    net = torch.nn.Sequential(torch.nn.Linear(6, 9), torch.nn.ReLU(), torch.nn.Linear(9, 4), torch.nn.Linear(4, 2))
+    model = torch.nn.ModuleList([net, torch.nn.Linear(3, 3)])
+    ar = FlatArena(model)
+    ar.p.copy_(p_a)
+    tot = torch.zeros_like(ar.g)
+    for r in range(2):
+        ar.zero_grad()
+        net(torch.full((5, 6), float(r + 1))).sum().backward()
+        tot += ar.g
+    assert torch.allclose(g_a, tot / 2, atol=1e-6)
+    assert (g_a[-12:] == 0).all()           # the unused layer's bucket was flushed zero-filled

@@ -60,18 +60,35 @@ def _compute_dtype(x):
     return torch.bfloat16 if torch.is_autocast_enabled() else x.dtype
 
 
+MIN_COUT = 8  # GEMMs with 1..4 output columns hit a GEMV path in the BLAS library whose host-side
+              # setup costs ~10 ms per call; zero-padded output channels keep them on the GEMM path
+
+
+def _pad_cout(weight, bias):
+    co = weight.shape[0]
+    if co >= MIN_COUT:
+        return weight, bias, co
+    pad = MIN_COUT - co
+    weight = torch.cat([weight, weight.new_zeros((pad,) + tuple(weight.shape[1:]))], 0)
+    if bias is not None:
+        bias = torch.cat([bias, bias.new_zeros(pad)], 0)
+    return weight, bias, co
+
+
 def conv3x3(x, weight, bias=None, stride=1):
     """x logical (N,C,H,W) -> logical (N,Cout,Ho,Wo), NHWC storage both sides."""
     xh = _nhwc(x).to(_compute_dtype(x))
+    weight, bias, co = _pad_cout(weight, bias)
     with torch.autocast("cuda", enabled=False):
         y = _Conv3x3.apply(xh, weight, bias, stride)
-    return y.permute(0, 3, 1, 2)
+    return y[..., :co].permute(0, 3, 1, 2)
 
 
 def conv1x1(x, weight, bias=None):
     xh = _nhwc(x)
+    weight, bias, co = _pad_cout(weight, bias)
     y = F.linear(xh, weight.view(weight.shape[0], -1), bias)
-    return y.permute(0, 3, 1, 2)
+    return y[..., :co].permute(0, 3, 1, 2)
 
 
 def patch_embed4x4(x, weight, bias, patch=4):

@@ -8,7 +8,7 @@ from torch import nn
 from torch.nn import functional as F
 
 from ...config import configurable
-from ...layers.conv_ops import Conv2d
+from ...layers.conv_ops import Conv2d, conv3x3
 
 
 class Scale(nn.Module):
@@ -71,6 +71,14 @@ class CenterNetHead(nn.Module):
             cls_tower = self.cls_tower(feature)
             bbox_tower = self.bbox_tower(feature)
             clss.append(None if self.only_proposal else self.cls_logits(cls_tower))
-            agn_hms.append(self.agn_hm(bbox_tower) if self.with_agn_hm else None)
-            bbox_reg.append(F.relu(self.scales[l](self.bbox_pred(bbox_tower))))
+            if self.with_agn_hm:
+                # agn_hm (1 ch) and bbox_pred (4 ch) read the same tower output: one im2col + one GEMM
+                both = conv3x3(bbox_tower, torch.cat([self.agn_hm.weight, self.bbox_pred.weight], 0),
+                               torch.cat([self.agn_hm.bias, self.bbox_pred.bias], 0))
+                agn_hms.append(both[:, :1])
+                reg = both[:, 1:5]
+            else:
+                agn_hms.append(None)
+                reg = self.bbox_pred(bbox_tower)
+            bbox_reg.append(F.relu(self.scales[l](reg)))
         return clss, bbox_reg, agn_hms

@@ -29,6 +29,9 @@ class CustomRCNN(nn.Module):
         self.register_buffer("pixel_mean", torch.tensor(pixel_mean).view(-1, 1, 1), False)
         self.register_buffer("pixel_std", torch.tensor(pixel_std).view(-1, 1, 1), False)
         self.heads_fp32 = os.environ.get("DGX_HEADS_FP32", "0") == "1"
+        # hipGraph capture of the static-shape backbone fwd+bwd (launch-bound otherwise: ~3.5k launches)
+        self.graph_backbone = os.environ.get("DGX_GRAPH_BACKBONE", "0") == "1"
+        self._graphed = {}
         self.return_proposal = False
 
     @classmethod
@@ -50,7 +53,22 @@ class CustomRCNN(nn.Module):
         images = [(x.float() - self.pixel_mean) / self.pixel_std for x in images]
         return ImageList.from_tensors(images, self.backbone.size_divisibility)
 
+    def _graphed_backbone(self, x):
+        key = (tuple(x.shape), self.fp16)
+        if key not in self._graphed:
+            names = list(self.backbone.output_shape().keys())
+            mod = _BackboneForGraph(self.backbone, names, self.fp16)
+            self._graphed[key] = (torch.cuda.make_graphed_callables(mod, (x.clone(),)), names)
+        fn, names = self._graphed[key]
+        return dict(zip(names, fn(x)))
+
     def _features(self, images):
+        if self.graph_backbone and self.training:
+            x = images.tensor.to(memory_format=torch.channels_last) if self.fp16 else images.tensor
+            feats = self._graphed_backbone(x)
+            if self.heads_fp32:
+                feats = {k: v.float() for k, v in feats.items()}
+            return feats
         if self.fp16:
             with torch.autocast("cuda", dtype=torch.bfloat16):
                 feats = self.backbone(images.tensor.to(memory_format=torch.channels_last))
@@ -87,6 +105,19 @@ class CustomRCNN(nn.Module):
         for r, inp, size in zip(results, batched_inputs, images.image_sizes):
             out.append({"instances": detector_postprocess(r, inp.get("height", size[0]), inp.get("width", size[1]))})
         return out
+
+
+class _BackboneForGraph(nn.Module):
+    """Tuple-output wrapper so torch.cuda.make_graphed_callables can capture backbone fwd+bwd."""
+
+    def __init__(self, backbone, names, amp):
+        super().__init__()
+        self.backbone, self.names, self.amp = backbone, names, amp
+
+    def forward(self, x):
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.amp, cache_enabled=False):
+            out = self.backbone(x)
+        return tuple(out[n] for n in self.names)
 
 
 def detector_postprocess(results, output_height, output_width, mask_threshold=0.5):

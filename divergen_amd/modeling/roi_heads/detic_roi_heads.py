@@ -186,9 +186,11 @@ class DeticCascadeROIHeads(nn.Module):
         return out
 
     def _run_stage(self, features, proposals, stage):
-        x = self.box_pooler(features, [p.proposal_boxes for p in proposals])
+        R = sum(len(p) for p in proposals)
+        x = self.box_pooler(features, [p.proposal_boxes for p in proposals], pad_to=256 if self.training else 0)
         x = _ScaleGradient.apply(x, 1.0 / self.num_cascade_stages)
-        return self.box_predictor[stage](self.box_head[stage](x))
+        scores, deltas = self.box_predictor[stage](self.box_head[stage](x))
+        return scores[:R], deltas[:R]
 
     def _forward_box(self, features, proposals, targets=None):
         if (not self.training) and self.mult_proposal_score:
@@ -233,7 +235,7 @@ class DeticCascadeROIHeads(nn.Module):
                 instances = [i[i.instance_source == 0] for i in instances]
         feats = [features[f] for f in self.mask_in_features]
         boxes = [x.proposal_boxes if self.training else x.pred_boxes for x in instances]
-        return self.mask_head(self.mask_pooler(feats, boxes), instances)
+        return self.mask_head(self.mask_pooler(feats, boxes, pad_to=64 if self.training else 0), instances)
 
     def forward(self, images, features, proposals, targets=None, ann_type="box", **kwargs):
         if self.training:

@@ -87,7 +87,7 @@ class MaskRCNNConvUpsampleHead(nn.Sequential):
         return x
 
     def forward(self, x, instances):
-        x = self.layers(x)
+        x = self.layers(x)[: sum(len(i) for i in instances)]   # drop the shape-padding RoIs
         if self.training:
             return {"loss_mask": mask_rcnn_loss(x, instances, self.vis_period) * self.loss_weight}
         mask_rcnn_inference(x, instances)

@@ -21,11 +21,17 @@ class ROIPooler(nn.Module):
         self.min_level, self.max_level = int(mn), int(mx)
         assert len(scales) == self.max_level - self.min_level + 1
 
-    def forward(self, x, box_lists):
-        """x: list of (N,C,H,W); box_lists: list[Boxes] per image -> (R, C, S, S)."""
+    def forward(self, x, box_lists, pad_to=0):
+        """x: list of (N,C,H,W); box_lists: list[Boxes] per image -> (R, C, S, S).
+        pad_to > 0 rounds R up to a multiple of pad_to with empty boxes (their output rows are zeros):
+        downstream GEMM shapes then repeat from step to step instead of changing with every RoI count,
+        which keeps the GEMM library's per-shape solution lookup out of the step."""
         assert len(x) == len(self.scales) and len(box_lists) == x[0].size(0)
         boxes = torch.cat([b.tensor for b in box_lists], dim=0)
         idx = torch.cat([torch.full((len(b),), float(i), dtype=boxes.dtype, device=boxes.device)
                          for i, b in enumerate(box_lists)])
         rois = torch.cat([idx[:, None], boxes], dim=1)
+        R = rois.shape[0]
+        if pad_to > 0 and R % pad_to:
+            rois = torch.cat([rois, rois.new_zeros(pad_to - R % pad_to, 5)], dim=0)
         return roi_pooler(list(x), rois, self.output_size, self.scales, self.sampling_ratio, self.out_nhwc)

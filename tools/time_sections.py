@@ -1,0 +1,66 @@
+"""Dev helper: wall time of each phase of the step with device syncs between phases."""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, ".")
+from divergen_amd.config import get_cfg
+from divergen_amd.data import synthetic_batch
+from divergen_amd.modeling import build_model
+from divergen_amd.solver import build_optimizer
+from divergen_amd.utils.events import EventStorage
+
+size = sys.argv[1] if len(sys.argv) > 1 else "L-22k-384"
+res = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+cfg = get_cfg()
+cfg.merge_from_file("tests/configs/DiverGen_swinL.yaml")
+cfg.merge_from_list(["MODEL.SWIN.SIZE", size, "MODEL.ROI_BOX_HEAD.CAT_FREQ_PATH",
+                     "tests/configs/metadata/ImageNet2012_filtered04_lvis_v1_train_cat_info_250.json"])
+torch.manual_seed(42)
+model = build_model(cfg).train()
+opt = build_optimizer(cfg, model)
+batch = synthetic_batch(2, res, cfg.MODEL.ROI_HEADS.NUM_CLASSES, device="cuda")
+
+
+def T():
+    torch.cuda.synchronize()
+    return time.perf_counter()
+
+
+with EventStorage(0):
+    for it in range(4):
+        t = [T()]
+        opt.zero_grad()
+        images = model.preprocess_image(batch)
+        gt = [x["instances"] for x in batch]
+        feats = model._features(images); t.append(T())
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            props, pl = model.proposal_generator(images, feats, gt); t.append(T())
+            props, dl = model.roi_heads(images, feats, props, gt); t.append(T())
+        total = sum(pl.values()) + sum(dl.values())
+        total.backward(); t.append(T())
+        opt.step(); t.append(T())
+        names = ["backbone_fwd", "proposal_gen", "roi_heads", "backward", "optimizer"]
+        print(it, "  ".join("%s %.1f" % (n, (b - a) * 1e3) for n, a, b in zip(names, t[:-1], t[1:])), "total %.1f ms" % ((t[-1] - t[0]) * 1e3))
+
+if os.environ.get("PROFILE"):
+    from torch.profiler import ProfilerActivity, profile
+    with EventStorage(0):
+        opt.zero_grad()
+        images = model.preprocess_image(batch)
+        gt = [x["instances"] for x in batch]
+        feats = model._features(images)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            props, pl = model.proposal_generator(images, feats, gt)
+            props, dl = model.roi_heads(images, feats, props, gt)
+        total = sum(pl.values()) + sum(dl.values())
+        torch.cuda.synchronize()
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+            total.backward()
+            torch.cuda.synchronize()
+    rows = [e for e in prof.key_averages(group_by_input_shape=True) if e.key in ("aten::mm", "aten::addmm", "aten::bmm")]
+    rows.sort(key=lambda e: -e.self_cpu_time_total)
+    for e in rows[:25]:
+        print("%-10s n=%3d cpu_total %8.1f us  cpu_avg %7.1f us  cuda_avg %7.1f us  %s" % (e.key, e.count, e.self_cpu_time_total, e.self_cpu_time_total / e.count, e.self_device_time_total / e.count, e.input_shapes))

@@ -71,10 +71,26 @@ __global__ __launch_bounds__(1024) void nms_sweep_kernel(const uint64_t* __restr
         }
         __syncthreads();
         const int kn = kept_n;
-        for (int cb = b + 1 + tid; cb < nb; cb += blockDim.x) {
-            uint64_t acc = remv[cb];
-            for (int k = 0; k < kn; ++k) acc |= mask[(int64_t)kept_rows[k] * nb + cb];
-            remv[cb] = acc;
+        // OR the kept rows into the running vector: columns across lanes (coalesced), the kept rows
+        // split over G row-groups so all 1024 threads have independent loads in flight
+        const int ncols = nb - b - 1;
+        if (ncols > 0 && kn > 0) {
+            int G = blockDim.x / ncols;
+            G = G < 1 ? 1 : (G > 8 ? 8 : G);
+            for (int idx = tid; idx < ncols * G; idx += blockDim.x) {
+                const int grp = idx / ncols, cb = b + 1 + (idx - grp * ncols);
+                uint64_t acc = 0;
+                int k = grp;
+                for (; k + 3 * G < kn; k += 4 * G) {
+                    const uint64_t a0 = mask[(int64_t)kept_rows[k] * nb + cb];
+                    const uint64_t a1 = mask[(int64_t)kept_rows[k + G] * nb + cb];
+                    const uint64_t a2 = mask[(int64_t)kept_rows[k + 2 * G] * nb + cb];
+                    const uint64_t a3 = mask[(int64_t)kept_rows[k + 3 * G] * nb + cb];
+                    acc |= a0 | a1 | a2 | a3;
+                }
+                for (; k < kn; k += G) acc |= mask[(int64_t)kept_rows[k] * nb + cb];
+                if (acc) atomicOr((unsigned long long*)&remv[cb], (unsigned long long)acc);
+            }
         }
         __syncthreads();
     }

@@ -6,6 +6,7 @@
 // and weights is the oracle's (oracle/roi_nms.c, torchvision's published algorithm) and this file
 // is compiled with -ffp-contract=off, so bin geometry and the boolean mask targets are bit-exact.
 // Backward scatters with hardware fp32 atomics into an fp32 (N,H,W,C) gradient.
+// (The GT-mask crop keeps the per-sample form: its thresholded output must be bit-exact.)
 #include "dgx_common.h"
 
 #define MAX_LEVELS 4
@@ -73,89 +74,102 @@ template <typename T> __device__ __forceinline__ void stf(T* p, float v);
 template <> __device__ __forceinline__ void stf<float>(float* p, float v) { *p = v; }
 template <> __device__ __forceinline__ void stf<uint16_t>(uint16_t* p, float v) { *p = f2bf(v); }
 
-// grid (R, nsplit): block handles bins [split*bpb, ...).  NCHW output goes through an LDS
-// transpose so that the (C, ph*pw) tile of a RoI is written as one contiguous run.
-template <typename T>
-__global__ __launch_bounds__(256) void roi_align_fwd_kernel(PoolLevels L, const float* __restrict__ rois, T* __restrict__ out,
-                                                            int32_t* __restrict__ levels_out, int C, int ph, int pw,
-                                                            int sampling_ratio, int aligned, int out_nhwc, int bins_per_block) {
-    extern __shared__ float tile[];  // [bins_per_block][C] when !out_nhwc
-    const int r = blockIdx.x;
-    const float* roi = rois + 5 * (int64_t)r;
-    const int lvl = L.num_levels > 1 ? assign_level(roi, L.min_level, L.num_levels) : 0;
-    if (levels_out && blockIdx.y == 0 && threadIdx.x == 0) levels_out[r] = lvl;
-    const T* feat = (const T*)L.feat[lvl];
-    const int H = L.H[lvl], W = L.W[lvl];
-    const RoiGeom G = roi_geom(roi, L.scale[lvl], ph, pw, sampling_ratio, aligned != 0);
-    const T* fb = feat + (int64_t)G.b * H * W * C;
-    const int bins = ph * pw;
-    const int bin0 = blockIdx.y * bins_per_block, bin1 = min(bins, bin0 + bins_per_block);
-    for (int bin = bin0; bin < bin1; ++bin) {
-        const int i = bin / pw, j = bin - i * pw;
-        for (int c = threadIdx.x; c < C; c += blockDim.x) {
-            float acc = 0.0f;
-            for (int iy = 0; iy < G.gh; ++iy) {
-                const float y = G.sh + i * G.bin_h + ((float)iy + 0.5f) * G.bin_h / (float)G.gh;
-                for (int ix = 0; ix < G.gw; ++ix) {
-                    const float x = G.sw + j * G.bin_w + ((float)ix + 0.5f) * G.bin_w / (float)G.gw;
-                    Taps t;
-                    if (!bilinear_taps(H, W, y, x, t)) continue;
-                    acc += t.w[0] * ldf(fb + (int64_t)t.pos[0] * C + c) + t.w[1] * ldf(fb + (int64_t)t.pos[1] * C + c) +
-                           t.w[2] * ldf(fb + (int64_t)t.pos[2] * C + c) + t.w[3] * ldf(fb + (int64_t)t.pos[3] * C + c);
-                }
-            }
-            const float v = acc / G.count;
-            if (out_nhwc) stf(out + ((int64_t)r * bins + bin) * C + c, v);
-            else tile[(bin - bin0) * C + c] = v;
-        }
+// Separable form.  The bilinear weight of a sample on a pixel is hat(y)*hat(x) and a bin's samples
+// form a tensor grid, so the total weight a bin puts on pixel (r,q) is WY[i][r]*WX[j][q] with 1-D
+// tables built once per RoI in LDS (same clamping / validity rules as the per-sample form).  A bin
+// then touches each pixel of its footprint once -- (bin_h+1)(bin_w+1) taps instead of
+// 4*ceil(bin_h)*ceil(bin_w) -- and backward issues one atomic per footprint pixel per bin.
+struct Span { int base, n; };
+
+__device__ __forceinline__ void build_axis_table(float* Wt, Span* sp, int nb, int stride_tbl, float start, float bin,
+                                                 int g, int extent, int tid, int tid0) {
+    const int i = tid - tid0;
+    if (i < 0 || i >= nb) return;
+    float* w = Wt + i * stride_tbl;
+    for (int k = 0; k < stride_tbl; ++k) w[k] = 0.0f;
+    int base = -1, hi = -1;
+    for (int s = 0; s < g; ++s) {
+        float y = start + i * bin + ((float)s + 0.5f) * bin / (float)g;
+        if (y < -1.0f || y > (float)extent) continue;
+        if (y <= 0) y = 0;
+        int lo = (int)y, up;
+        if (lo >= extent - 1) { up = lo = extent - 1; y = (float)lo; } else up = lo + 1;
+        const float l = y - lo, h = 1.0f - l;
+        if (base < 0) base = lo;
+        w[lo - base] += h;
+        w[up - base] += l;
+        hi = up;
     }
-    if (!out_nhwc) {
-        __syncthreads();
-        const int nb = bin1 - bin0;
-        for (int idx = threadIdx.x; idx < nb * C; idx += blockDim.x) {
-            const int c = idx / nb, bb = idx - c * nb;
-            stf(out + ((int64_t)r * C + c) * bins + bin0 + bb, tile[bb * C + c]);
-        }
-    }
+    sp[i].base = base < 0 ? 0 : base;
+    sp[i].n = base < 0 ? 0 : hi - base + 1;
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void roi_align_bwd_kernel(PoolLevels L, const float* __restrict__ rois,
-                                                            const T* __restrict__ gout, int C, int ph, int pw,
-                                                            int sampling_ratio, int aligned, int out_nhwc, int bins_per_block) {
-    extern __shared__ float tile[];
+// grid (R, nsplit): block handles bins [split*bpb, ...).  NCHW output goes through an LDS
+// transpose so that the (C, ph*pw) tile of a RoI is written as one contiguous run.
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void roi_align_sep_kernel(PoolLevels L, const float* __restrict__ rois, T* __restrict__ io,
+                                                            int32_t* __restrict__ levels_out, int C, int ph, int pw,
+                                                            int sampling_ratio, int aligned, int out_nhwc, int bins_per_block,
+                                                            int spy, int spx) {
+    extern __shared__ float smem[];
+    float* WY = smem;                      // [ph][spy]
+    float* WX = WY + ph * spy;             // [pw][spx]
+    Span* SY = reinterpret_cast<Span*>(WX + pw * spx);
+    Span* SX = SY + ph;
+    float* tile = reinterpret_cast<float*>(SX + pw);  // [bins_per_block][C] when !out_nhwc
     const int r = blockIdx.x;
     const float* roi = rois + 5 * (int64_t)r;
     const int lvl = L.num_levels > 1 ? assign_level(roi, L.min_level, L.num_levels) : 0;
-    float* gfeat = L.grad[lvl];
+    if (!BWD && levels_out && blockIdx.y == 0 && threadIdx.x == 0) levels_out[r] = lvl;
     const int H = L.H[lvl], W = L.W[lvl];
     const RoiGeom G = roi_geom(roi, L.scale[lvl], ph, pw, sampling_ratio, aligned != 0);
-    float* gb = gfeat + (int64_t)G.b * H * W * C;
+    build_axis_table(WY, SY, ph, spy, G.sh, G.bin_h, G.gh, H, threadIdx.x, 0);
+    build_axis_table(WX, SX, pw, spx, G.sw, G.bin_w, G.gw, W, threadIdx.x, 64);
     const int bins = ph * pw;
     const int bin0 = blockIdx.y * bins_per_block, bin1 = min(bins, bin0 + bins_per_block);
-    if (!out_nhwc) {
-        const int nb = bin1 - bin0;
+    const int nb = bin1 - bin0;
+    if (BWD && !out_nhwc) {
         for (int idx = threadIdx.x; idx < nb * C; idx += blockDim.x) {
             const int c = idx / nb, bb = idx - c * nb;
-            tile[bb * C + c] = ldf(gout + ((int64_t)r * C + c) * bins + bin0 + bb);
+            tile[bb * C + c] = ldf(io + ((int64_t)r * C + c) * bins + bin0 + bb);
         }
-        __syncthreads();
     }
+    __syncthreads();
+    const T* fb = BWD ? nullptr : (const T*)L.feat[lvl] + (int64_t)G.b * H * W * C;
+    float* gb = BWD ? L.grad[lvl] + (int64_t)G.b * H * W * C : nullptr;
     for (int bin = bin0; bin < bin1; ++bin) {
         const int i = bin / pw, j = bin - i * pw;
+        const Span sy = SY[i], sx = SX[j];
+        const float* wy = WY + i * spy;
+        const float* wx = WX + j * spx;
         for (int c = threadIdx.x; c < C; c += blockDim.x) {
-            const float go = out_nhwc ? ldf(gout + ((int64_t)r * bins + bin) * C + c) : tile[(bin - bin0) * C + c];
-            const float g = go / G.count;
-            for (int iy = 0; iy < G.gh; ++iy) {
-                const float y = G.sh + i * G.bin_h + ((float)iy + 0.5f) * G.bin_h / (float)G.gh;
-                for (int ix = 0; ix < G.gw; ++ix) {
-                    const float x = G.sw + j * G.bin_w + ((float)ix + 0.5f) * G.bin_w / (float)G.gw;
-                    Taps t;
-                    if (!bilinear_taps(H, W, y, x, t)) continue;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) atomicAdd(gb + (int64_t)t.pos[k] * C + c, g * t.w[k]);
+            if (BWD) {
+                const float go = out_nhwc ? ldf(io + ((int64_t)r * bins + bin) * C + c) : tile[(bin - bin0) * C + c];
+                const float g = go / G.count;
+                for (int ky = 0; ky < sy.n; ++ky) {
+                    const float gy = g * wy[ky];
+                    float* row = gb + ((int64_t)(sy.base + ky) * W + sx.base) * C + c;
+                    for (int kx = 0; kx < sx.n; ++kx) atomicAdd(row + (int64_t)kx * C, gy * wx[kx]);
                 }
+            } else {
+                float acc = 0.0f;
+                for (int ky = 0; ky < sy.n; ++ky) {
+                    const T* row = fb + ((int64_t)(sy.base + ky) * W + sx.base) * C + c;
+                    float racc = 0.0f;
+                    for (int kx = 0; kx < sx.n; ++kx) racc += wx[kx] * ldf(row + (int64_t)kx * C);
+                    acc += wy[ky] * racc;
+                }
+                const float v = acc / G.count;
+                if (out_nhwc) stf(io + ((int64_t)r * bins + bin) * C + c, v);
+                else tile[(bin - bin0) * C + c] = v;
             }
+        }
+    }
+    if (!BWD && !out_nhwc) {
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < nb * C; idx += blockDim.x) {
+            const int c = idx / nb, bb = idx - c * nb;
+            stf(io + ((int64_t)r * C + c) * bins + bin0 + bb, tile[bb * C + c]);
         }
     }
 }
@@ -163,36 +177,41 @@ __global__ __launch_bounds__(256) void roi_align_bwd_kernel(PoolLevels L, const 
 static int launch_pool(bool fwd, const PoolLevels& L, const float* rois, const void* io, int32_t* levels_out, int C,
                        int R, int ph, int pw, int sampling_ratio, int aligned, int out_nhwc, int dtype, void* stream) {
     if (R <= 0) return DGX_OK;
-    if (!rois || !io || C <= 0 || ph <= 0 || pw <= 0) return DGX_ERR_BAD_ARG;
+    if (!rois || !io || C <= 0 || ph <= 0 || pw <= 0 || ph > 64 || pw > 64) return DGX_ERR_BAD_ARG;
     const int bins = ph * pw;
+    int spy = 0, spx = 0;
+    for (int l = 0; l < L.num_levels; ++l) { spy = L.H[l] > spy ? L.H[l] : spy; spx = L.W[l] > spx ? L.W[l] : spx; }
+    spy += 1; spx += 1;
+    const size_t tbl = (size_t)(ph * spy + pw * spx) * 4 + (size_t)(ph + pw) * sizeof(Span);
     int bpb, nsplit;
     if (out_nhwc) {
         nsplit = R >= 2048 ? 1 : (R >= 512 ? 2 : 4);
         if (nsplit > bins) nsplit = bins;
         bpb = (bins + nsplit - 1) / nsplit;
     } else {
-        bpb = (int)(65536 / ((size_t)C * 4));
-        if (bpb < 1) return DGX_ERR_UNSUPPORTED;
+        if (tbl + (size_t)C * 4 > 64 * 1024) return DGX_ERR_UNSUPPORTED;
+        bpb = (int)((64 * 1024 - tbl) / ((size_t)C * 4));
         if (bpb > bins) bpb = bins;
     }
     nsplit = (bins + bpb - 1) / bpb;
-    const size_t sm = out_nhwc ? 0 : (size_t)bpb * C * 4;
+    const size_t sm = tbl + (out_nhwc ? 0 : (size_t)bpb * C * 4);
+    if (sm > 64 * 1024) return DGX_ERR_UNSUPPORTED;
     dim3 grid(R, nsplit), block(256);
     hipStream_t st = (hipStream_t)stream;
     if (fwd) {
         if (dtype == DGX_BF16)
-            hipLaunchKernelGGL(roi_align_fwd_kernel<uint16_t>, grid, block, sm, st, L, rois, (uint16_t*)io, levels_out, C,
-                               ph, pw, sampling_ratio, aligned, out_nhwc, bpb);
+            hipLaunchKernelGGL((roi_align_sep_kernel<uint16_t, false>), grid, block, sm, st, L, rois, (uint16_t*)io, levels_out,
+                               C, ph, pw, sampling_ratio, aligned, out_nhwc, bpb, spy, spx);
         else
-            hipLaunchKernelGGL(roi_align_fwd_kernel<float>, grid, block, sm, st, L, rois, (float*)io, levels_out, C, ph,
-                               pw, sampling_ratio, aligned, out_nhwc, bpb);
+            hipLaunchKernelGGL((roi_align_sep_kernel<float, false>), grid, block, sm, st, L, rois, (float*)io, levels_out, C,
+                               ph, pw, sampling_ratio, aligned, out_nhwc, bpb, spy, spx);
     } else {
         if (dtype == DGX_BF16)
-            hipLaunchKernelGGL(roi_align_bwd_kernel<uint16_t>, grid, block, sm, st, L, rois, (const uint16_t*)io, C, ph,
-                               pw, sampling_ratio, aligned, out_nhwc, bpb);
+            hipLaunchKernelGGL((roi_align_sep_kernel<uint16_t, true>), grid, block, sm, st, L, rois, (uint16_t*)io, nullptr, C,
+                               ph, pw, sampling_ratio, aligned, out_nhwc, bpb, spy, spx);
         else
-            hipLaunchKernelGGL(roi_align_bwd_kernel<float>, grid, block, sm, st, L, rois, (const float*)io, C, ph, pw,
-                               sampling_ratio, aligned, out_nhwc, bpb);
+            hipLaunchKernelGGL((roi_align_sep_kernel<float, true>), grid, block, sm, st, L, rois, (float*)io, nullptr, C, ph,
+                               pw, sampling_ratio, aligned, out_nhwc, bpb, spy, spx);
     }
     DGX_LAUNCH_CHECK();
     return DGX_OK;

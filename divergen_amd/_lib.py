@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libdgx.so")
+LIB_PATH = os.environ.get("DGX_LIB", os.path.join(_HERE, "csrc", "libdgx.so"))  # DGX_LIB: dev A/B builds
 _lib = None
 
 c_p, c_i, c_f, c_i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64

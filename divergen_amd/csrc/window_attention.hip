@@ -74,7 +74,7 @@ __global__ __launch_bounds__(WinCfg<WS>::NT * 64) void win_attn_fwd_kernel(
     const uint16_t* base = qkv + (int64_t)b * N * rowst + h * 32;
     const int tid = threadIdx.x, nthreads = NT * 64;
 
-    for (int i = tid; i < TBL; i += nthreads) tbl[i] = table[i * nH + h];
+    for (int i = tid; i < TBL; i += nthreads) tbl[i] = table[h * TBL + i];
     stage_transposed<N, NP, RS>(Vt, base + 2 * C, rowst, tid, nthreads);
     __syncthreads();
 
@@ -82,8 +82,8 @@ __global__ __launch_bounds__(WinCfg<WS>::NT * 64) void win_attn_fwd_kernel(
     const int qi = 16 * w + c16;
     const bool qok = qi < N;
     const bf16x8 qf = ld_frag_global(base + (int64_t)qi * rowst + 8 * g, qok);
-    const int8_t* reg = region ? region + (int64_t)(b % nW) * N : nullptr;
-    const int rq = (reg && qok) ? reg[qi] : 0;
+    const int8_t* reg = region + (int64_t)(b % nW) * N;
+    const int rq = qok ? reg[qi] : 0;
     const int yq = qi / WS, xq = qi - yq * WS;
     const int base_q = (yq + WS - 1) * (2 * WS - 1) + (xq + WS - 1);
 
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(WinCfg<WS>::NT * 64) void win_attn_fwd_kernel(
                 const int yk = key / WS, xk = key - yk * WS;
                 const int idx = qok ? base_q - (yk * (2 * WS - 1) + xk) : 0;
                 s = acc[r] * scale + tbl[idx];
-                if (reg && reg[key] != rq) s += -100.0f;
+                if (reg[key] != rq) s += -100.0f;
             }
             p[kt][r] = s;
             mx = fmaxf(mx, s);
@@ -167,9 +167,11 @@ __global__ __launch_bounds__(WinCfg<WS>::NT * 64) void win_attn_bwd_kernel(
     uint16_t* dOt = Qt + 32 * RS;                            // [32][RS]
     uint16_t* Kt = dOt + 32 * RS;                            // [32][RS]
     uint16_t* dSs = Kt + 32 * RS;                            // [NP][RD]
-    float* lse_s = reinterpret_cast<float*>(dSs + NP * RD);  // [NP]
+    float* lse_s = reinterpret_cast<float*>(dSs + NP * RD);  // [NP] (16-B aligned: read as float4)
     float* delta_s = lse_s + NP;                             // [NP]
-    float* tbl = delta_s + NP;                               // [TBL]
+    int* qoff_s = reinterpret_cast<int*>(delta_s + NP);      // [NP] rel-pos offset of query q
+    int* reg_s = qoff_s + NP;                                // [NP] region id of query q (this window)
+    float* tbl = reinterpret_cast<float*>(reg_s + NP);       // [TBL]
     float* tblacc = tbl + TBL;                               // [TBL]
 
     const int h = blockIdx.x % nH;
@@ -180,12 +182,15 @@ __global__ __launch_bounds__(WinCfg<WS>::NT * 64) void win_attn_bwd_kernel(
     const int tid = threadIdx.x, nthreads = NT * 64;
     const int w = tid >> 6, l = tid & 63, g = l >> 4, c16 = l & 15;
 
-    for (int i = tid; i < TBL; i += nthreads) { tbl[i] = table[i * nH + h]; tblacc[i] = 0.f; }
-    for (int i = tid; i < NP * RD; i += nthreads) dSs[i] = 0;  // key columns never owned stay 0
+    for (int i = tid; i < TBL; i += nthreads) { tbl[i] = table[h * TBL + i]; tblacc[i] = 0.f; }
+    // key columns N..NP-1 are never owned by a wave but are read by the last K=32 step of dQ: keep them 0
+    for (int i = tid; i < NP * (NP - N); i += nthreads) dSs[(i / (NP - N)) * RD + N + i % (NP - N)] = 0;
+    for (int i = tid; i < NP; i += nthreads) { const int yq = i / WS; qoff_s[i] = i < N ? yq * (2 * WS - 1) + (i - yq * WS) : 0; }
     const int key = 16 * w + c16;  // this lane's key in phase 1
     const bool kok = key < N;
     const int yk = key / WS, xk = key - yk * WS;
-    const int kbase = (WS - 1) * (2 * WS - 1) + (WS - 1) - (yk * (2 * WS - 1) + xk);
+    const int kbase = kok ? (WS - 1) * (2 * WS - 1) + (WS - 1) - (yk * (2 * WS - 1) + xk) : 0;
+    const float kneg = kok ? 0.0f : -INFINITY;   // padded key columns: p = 0
     float dbias[NT][4];
 #pragma unroll
     for (int i = 0; i < NT; ++i)
@@ -213,7 +218,8 @@ __global__ __launch_bounds__(WinCfg<WS>::NT * 64) void win_attn_bwd_kernel(
             d += __shfl_xor(d, 2);
             if (c == 0) {
                 delta_s[q] = d;
-                lse_s[q] = ok ? lse[((int64_t)b * nH + h) * N + q] : 0.f;
+                lse_s[q] = ok ? lse[((int64_t)b * nH + h) * N + q] : INFINITY;   // padded queries: p = 0
+                reg_s[q] = ok ? (int)region[(int64_t)(b % nW) * N + q] : 0;
             }
         }
         stage_transposed<N, NP, RS>(Qt, base, rowst, tid, nthreads);
@@ -221,8 +227,7 @@ __global__ __launch_bounds__(WinCfg<WS>::NT * 64) void win_attn_bwd_kernel(
         stage_transposed<N, NP, RS>(Kt, base + C, rowst, tid, nthreads);
         const bf16x8 kf = ld_frag_global(base + C + (int64_t)key * rowst + 8 * g, kok);
         const bf16x8 vf = ld_frag_global(base + 2 * C + (int64_t)key * rowst + 8 * g, kok);
-        const int8_t* reg = region ? region + (int64_t)(b % nW) * N : nullptr;
-        const int rk = (reg && kok) ? reg[key] : 0;
+        const int rk = kok ? (int)region[(int64_t)(b % nW) * N + key] : 0;
         __syncthreads();
 
         // ---- phase 1: this wave's 16 keys x all queries, two query tiles (one K=32 step) at a time
@@ -241,18 +246,27 @@ __global__ __launch_bounds__(WinCfg<WS>::NT * 64) void win_attn_bwd_kernel(
                     f32x4 z = {0.f, 0.f, 0.f, 0.f};
                     const f32x4 s = mfma16(qa, kf, z);    // s[r]  = S[q 16qt+4g+r][key]
                     const f32x4 dp = mfma16(da, vf, z);   // dp[r] = dP[q][key]
+                    const int q0 = 16 * qt + 4 * g;
+                    const float4 l4 = *reinterpret_cast<const float4*>(&lse_s[q0]);
+                    const float4 d4 = *reinterpret_cast<const float4*>(&delta_s[q0]);
+                    const int4 o4 = *reinterpret_cast<const int4*>(&qoff_s[q0]);
+                    const int4 r4 = *reinterpret_cast<const int4*>(&reg_s[q0]);
+                    const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dl[4] = {d4.x, d4.y, d4.z, d4.w};
+                    const int ov[4] = {o4.x, o4.y, o4.z, o4.w}, rv[4] = {r4.x, r4.y, r4.z, r4.w};
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int q = 16 * qt + 4 * g + r;
-                        if (q < N && kok) {
-                            const int yq = q / WS, xq = q - yq * WS;
-                            float sv = s[r] * scale + tbl[kbase + yq * (2 * WS - 1) + xq];
-                            if (reg && reg[q] != rk) sv += -100.0f;
-                            pv[r] = __expf(sv - lse_s[q]);
-                            dsv[r] = pv[r] * (dp[r] - delta_s[q]);
-                            dbias[qt < NT ? qt : 0][r] += dsv[r];
-                        }
-                        dSs[q * RD + key] = f2bf(dsv[r]);
+                        float sv = s[r] * scale + tbl[kbase + ov[r]] + kneg;
+                        if (rv[r] != rk) sv += -100.0f;
+                        pv[r] = __expf(sv - lv[r]);
+                        dsv[r] = pv[r] * (dp[r] - dl[r]);
+#if defined(DBIAS_LDS)
+                        atomicAdd(&tblacc[kbase + ov[r]], dsv[r]);
+#elif !defined(DIAG_NO_DBIAS)
+                        dbias[qt < NT ? qt : 0][r] += dsv[r];
+#endif
+#ifndef DIAG_NO_DSWRITE
+                        dSs[(q0 + r) * RD + key] = f2bf(dsv[r]);
+#endif
                     }
                 }
                 ppk[hh][0] = pack_bf2(pv[0], pv[1]);
@@ -269,6 +283,7 @@ __global__ __launch_bounds__(WinCfg<WS>::NT * 64) void win_attn_bwd_kernel(
                 dV[dt] = mfma16(pf, ld_frag_T<RS>(dOt, 16 * dt + c16, t, g), dV[dt]);
                 dK[dt] = mfma16(df, ld_frag_T<RS>(Qt, 16 * dt + c16, t, g), dK[dt]);
             }
+            __builtin_amdgcn_sched_barrier(0);   // keep the t-steps apart: shorter live ranges, no spills
         }
         uint16_t* dqb = dqkv + (int64_t)b * N * rowst + h * 32;
 #pragma unroll
@@ -284,6 +299,7 @@ __global__ __launch_bounds__(WinCfg<WS>::NT * 64) void win_attn_bwd_kernel(
         }
         __syncthreads();  // dS image complete
         // ---- phase 2: dQ strip w = dS[16w.., :] K
+#ifndef DIAG_NO_PHASE2
         f32x4 dQ[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
         for (int t = 0; t < NTK / 2; ++t) {
@@ -303,8 +319,10 @@ __global__ __launch_bounds__(WinCfg<WS>::NT * 64) void win_attn_bwd_kernel(
                     dqb[(int64_t)q * rowst + 16 * dt + c16] = f2bf(dQ[dt][r] * scale);
             }
         }
+#endif
     }
     // ---- relative-position-bias gradient: registers -> LDS table (ds_add_f32) -> global atomics
+#if !defined(DBIAS_LDS)
     if (kok) {
 #pragma unroll
         for (int qt = 0; qt < NT; ++qt)
@@ -317,15 +335,27 @@ __global__ __launch_bounds__(WinCfg<WS>::NT * 64) void win_attn_bwd_kernel(
                 }
             }
     }
+#endif
     __syncthreads();
-    for (int i = tid; i < TBL; i += nthreads) atomicAdd(&dtable[i * nH + h], tblacc[i]);
+    for (int i = tid; i < TBL; i += nthreads) atomicAdd(&dtable[h * TBL + i], tblacc[i]);
 }
 
 template <int WS>
 static size_t bwd_smem_bytes() {
     using Cf = WinCfg<WS>;
     constexpr int NP = Cf::NTK * 16;
-    return (size_t)(2 * NP * 40 + 3 * 32 * Cf::RS + NP * (NP + 8)) * 2 + (size_t)(2 * NP + 2 * Cf::TBL) * 4;
+    return (size_t)(2 * NP * 40 + 3 * 32 * Cf::RS + NP * (NP + 8)) * 2 + (size_t)(4 * NP + 2 * Cf::TBL) * 4 + 64;
+}
+
+// NULL region (W-MSA) is served by a process-lifetime all-zero row: one code path in the kernels
+// (the compiler's null/non-null loop versions differ 4x in speed for the backward kernel).
+static const int8_t* zero_region() {
+    static int8_t* z = nullptr;
+    if (!z) {
+        if (hipMalloc((void**)&z, 256) != hipSuccess) return nullptr;
+        (void)hipMemset(z, 0, 256);
+    }
+    return z;
 }
 
 extern "C" int dgx_window_attention_fwd(const void* qkv, const float* table, const int8_t* region, void* out,
@@ -333,6 +363,7 @@ extern "C" int dgx_window_attention_fwd(const void* qkv, const float* table, con
     if (B_ <= 0) return DGX_OK;
     if (!qkv || !table || !out || !lse || nH <= 0 || nW <= 0 || (region && B_ % nW)) return DGX_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
+    if (!region) { region = zero_region(); nW = 1; if (!region) return DGX_ERR_BAD_ARG; }
     const int grid = ((B_ + 7) / 8) * 8 * nH;
     if (ws == 12)
         hipLaunchKernelGGL(win_attn_fwd_kernel<12>, dim3(grid), dim3(WinCfg<12>::NT * 64), 0, st,
@@ -353,7 +384,11 @@ extern "C" int dgx_window_attention_bwd(const void* qkv, const float* table, con
     if (!qkv || !table || !out || !lse || !dout || !dqkv || !dtable || nH <= 0 || nW <= 0 || (region && B_ % nW))
         return DGX_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
-    int chunk = (int)(((int64_t)B_ * nH + 1023) / 1024);
+    if (!region) { region = zero_region(); nW = 1; if (!region) return DGX_ERR_BAD_ARG; }
+    // One workgroup per CU (LDS-limited) in a single round: per-workgroup setup (bias row, flush of the
+    // bias-gradient row) is amortised over the chunk; measured best among 256/512/768/2048 targets.
+    const int nchunks = nH >= 256 ? 1 : 256 / nH;
+    int chunk = (B_ + nchunks - 1) / nchunks;
     if (chunk < 1) chunk = 1;
     const int grid = ((B_ + chunk - 1) / chunk) * nH;
     if (ws == 12) {

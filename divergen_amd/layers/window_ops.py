@@ -33,7 +33,7 @@ class _WindowAttentionCore(torch.autograd.Function):
         B_, N, C3 = qkv.shape
         assert N == ws * ws and C3 == 3 * nH * 32, (qkv.shape, ws, nH)
         qkv = qkv.contiguous()
-        table = table.float().contiguous()
+        table = table.float().t().contiguous()          # (nH, T): one contiguous row per head
         out = torch.empty(B_, N, nH * 32, dtype=torch.bfloat16, device=qkv.device)
         lse = torch.empty(B_, nH, N, dtype=torch.float32, device=qkv.device)
         L.check(L.lib().dgx_window_attention_fwd(L.ptr(qkv), L.ptr(table), L.ptr(region), L.ptr(out), L.ptr(lse),
@@ -52,7 +52,7 @@ class _WindowAttentionCore(torch.autograd.Function):
         L.check(L.lib().dgx_window_attention_bwd(L.ptr(qkv), L.ptr(table), L.ptr(region), L.ptr(out), L.ptr(lse),
                                                  L.ptr(dout), L.ptr(dqkv), L.ptr(dtable), qkv.shape[0], nW, nH, ws,
                                                  scale, L.stream()), "dgx_window_attention_bwd")
-        return dqkv, dtable, None, None, None, None, None
+        return dqkv, dtable.t(), None, None, None, None, None
 
 
 def window_attention_core(qkv, table, region, nW, nH, ws, scale):

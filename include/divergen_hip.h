@@ -40,7 +40,7 @@ int dgx_abi_version(void);
  * + shift mask, softmax (fp32), @v, head merge.   DG/divergen/modeling/backbone/swintransformer.py:133-154
  *
  *   qkv    bf16 (B_, N, 3, nH, 32)   output of the qkv Linear, N = ws*ws, head_dim fixed at 32
- *   table  f32  ((2ws-1)^2, nH)      relative_position_bias_table
+ *   table  f32  (nH, (2ws-1)^2)      relative_position_bias_table TRANSPOSED (one contiguous row per head)
  *   region i8   (nW, N) or NULL      region id of each token of each window position; the additive
  *                                    mask of swintransformer.py:368-387 is (region[i]!=region[j]) ? -100 : 0;
  *                                    B_ % nW == 0, window b uses row b % nW.  NULL = W-MSA (no mask)
@@ -52,7 +52,7 @@ int dgx_window_attention_fwd(const void* qkv, const float* table, const int8_t* 
                              void* out, float* lse, int B_, int nW, int nH, int ws, float scale,
                              void* stream);
 
-/* Backward of the above.  dqkv bf16 (B_,N,3,nH,32) is fully overwritten; dtable f32 ((2ws-1)^2,nH)
+/* Backward of the above.  dqkv bf16 (B_,N,3,nH,32) is fully overwritten; dtable f32 (nH,(2ws-1)^2)
  * is ACCUMULATED into (caller zeroes it).  `out`/`lse` are the forward results. */
 int dgx_window_attention_bwd(const void* qkv, const float* table, const int8_t* region,
                              const void* out, const float* lse, const void* dout,

@@ -34,6 +34,8 @@ SIGNATURES = {
     "dgx_copy_paste": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p]),
     "dgx_im2col3x3": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "dgx_col2im3x3": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "dgx_wgrad_workspace_bytes": (c_i64, [c_i, c_i, c_i]),
+    "dgx_linear_wgrad": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p, c_p]),
     "dgx_adamw_ema_step": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_f,
                                  c_p, c_p, c_i, c_p, c_p]),
 }

@@ -1,0 +1,163 @@
+// Weight-gradient GEMM for gfx950:  C[Nn][Kk] (fp32, += ) = sum_m A[m][Nn] * B[m][Kk]
+// with A = dY and B = X both row-major bf16 and M (tokens) up to 131072 while Nn, Kk are a few
+// hundred to a few thousand.  The library GEMM runs this "TN, very long K" shape at 65-500 TF/s
+// (tools/wgrad_probe.py) because the small output gives it too few workgroups; here the M axis is
+// split across workgroups (split-K) and both operands are transposed on the way into LDS:
+//   tile 128(n) x 128(k) per workgroup, 4 waves x (4x4 MFMA 16x16x32 bf16 tiles), M-depth 64 per
+//   stage, double-buffered LDS images At[n][m], Bt[k][m] (row stride 72 -> conflict-free b128
+//   fragment reads), next stage prefetched into registers under the MFMAs; fp32 partial tiles go
+//   to a workspace and a second kernel folds the S slabs into the gradient arena (beta = 1).
+#include "dgx_common.h"
+
+namespace {
+constexpr int BT = 128;        // tile edge (both n and k)
+constexpr int BM = 64;         // m-depth per stage
+constexpr int RS = BM + 8;     // LDS row stride (elements)
+
+struct Stage { bf16x8 a[2][2], b[2][2]; };   // [pass][row of the pair]
+
+// LDS image [128 rows][RS]: 16-byte groups of a row are XOR-swizzled with (row>>3)&7 so that the
+// transposing stores (16 lanes = 16 rows 8 apart, same column) spread over banks (2-way instead of
+// 16-way) while fragment reads stay 16-byte aligned.
+__device__ __forceinline__ int lds_off(int row, int col) {
+    return row * RS + ((((col >> 3) ^ (row >> 3)) & 7) << 3) + (col & 7);
+}
+
+// thread (pair p = tid>>4 in 0..15, chunk c = tid&15): rows m0+2p(+32*pass), m0+2p+1, cols 8c..8c+7
+__device__ __forceinline__ void load_stage(Stage& st, const uint16_t* __restrict__ A, const uint16_t* __restrict__ B,
+                                           int64_t lda, int64_t ldb, int m0, int M, int n0, int Nn, int k0, int Kk, int tid) {
+    const int p = tid >> 4, c = tid & 15;
+    const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int m = m0 + 32 * ps + 2 * p + r;
+            const bool mok = m < M;
+            st.a[ps][r] = (mok && n0 + 8 * c < Nn) ? *reinterpret_cast<const bf16x8*>(A + (int64_t)m * lda + n0 + 8 * c) : z;
+            st.b[ps][r] = (mok && k0 + 8 * c < Kk) ? *reinterpret_cast<const bf16x8*>(B + (int64_t)m * ldb + k0 + 8 * c) : z;
+        }
+}
+
+__device__ __forceinline__ void store_stage(const Stage& st, uint16_t* At, uint16_t* Bt, int tid) {
+    const int p = tid >> 4, c = tid & 15;
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint32_t wa = (uint32_t)(uint16_t)st.a[ps][0][i] | ((uint32_t)(uint16_t)st.a[ps][1][i] << 16);
+            const uint32_t wb = (uint32_t)(uint16_t)st.b[ps][0][i] | ((uint32_t)(uint16_t)st.b[ps][1][i] << 16);
+            *reinterpret_cast<uint32_t*>(&At[lds_off(8 * c + i, 32 * ps + 2 * p)]) = wa;
+            *reinterpret_cast<uint32_t*>(&Bt[lds_off(8 * c + i, 32 * ps + 2 * p)]) = wb;
+        }
+}
+}  // namespace
+
+__global__ __launch_bounds__(256) void wgrad_partial_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ B,
+                                                            float* __restrict__ ws, int M, int Nn, int Kk, int64_t lda,
+                                                            int64_t ldb, int tiles_k, int slab) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t lds_raw[];     // [buf][A|B][BT*RS]
+    uint16_t (*lds)[2][BT * RS] = reinterpret_cast<uint16_t (*)[2][BT * RS]>(lds_raw);
+    const int tile = blockIdx.x, s = blockIdx.y;
+    const int n0 = (tile / tiles_k) * BT, k0 = (tile % tiles_k) * BT;
+    const int m_begin = s * slab, m_end = min(M, m_begin + slab);
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, g = l >> 4, c16 = l & 15;
+    const int wn = (w >> 1) * 64, wk = (w & 1) * 64;    // this wave's 64x64 quadrant
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    Stage st;
+    int buf = 0;
+    if (m_begin < m_end) load_stage(st, A, B, lda, ldb, m_begin, m_end, n0, Nn, k0, Kk, tid);
+    for (int m0 = m_begin; m0 < m_end; m0 += BM) {
+        uint16_t* At = lds[buf][0];
+        uint16_t* Bt = lds[buf][1];
+        store_stage(st, At, Bt, tid);
+        __syncthreads();
+        if (m0 + BM < m_end) load_stage(st, A, B, lda, ldb, m0 + BM, m_end, n0, Nn, k0, Kk, tid);
+#pragma unroll
+        for (int ks = 0; ks < BM / 32; ++ks) {
+            bf16x8 af[4], bfr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                af[i] = *reinterpret_cast<const bf16x8*>(&At[lds_off(wn + 16 * i + c16, 32 * ks + 8 * g)]);
+                bfr[i] = *reinterpret_cast<const bf16x8*>(&Bt[lds_off(wk + 16 * i + c16, 32 * ks + 8 * g)]);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(af[i], bfr[j], acc[i][j]);
+        }
+        buf ^= 1;   // the other buffer was last read one iteration ago, behind this iteration's barrier
+    }
+    float* out = ws + (int64_t)s * Nn * Kk;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = n0 + wn + 16 * i + 4 * g + r;
+            if (n >= Nn) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = k0 + wk + 16 * j + c16;
+                if (k < Kk) out[(int64_t)n * Kk + k] = acc[i][j][r];
+            }
+        }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float4* __restrict__ ws, float4* __restrict__ C, int64_t n4,
+                                                           int S, float beta) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        float4 a = {0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < S; ++s) {
+            const float4 v = ws[(int64_t)s * n4 + i];
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        if (beta != 0.f) {
+            const float4 c = C[i];
+            a.x += beta * c.x; a.y += beta * c.y; a.z += beta * c.z; a.w += beta * c.w;
+        }
+        C[i] = a;
+    }
+}
+
+static int wgrad_splits(int M, int Nn, int Kk) {
+    const int tiles = ((Nn + BT - 1) / BT) * ((Kk + BT - 1) / BT);
+    int S = (1024 + tiles - 1) / tiles;
+    const int maxS = (M + 4 * BM - 1) / (4 * BM);
+    if (S > maxS) S = maxS;
+    return S < 1 ? 1 : S;
+}
+
+extern "C" int64_t dgx_wgrad_workspace_bytes(int M, int Nn, int Kk) {
+    if (M <= 0 || Nn <= 0 || Kk <= 0) return 0;
+    return (int64_t)wgrad_splits(M, Nn, Kk) * Nn * Kk * 4;
+}
+
+extern "C" int dgx_linear_wgrad(const void* dy, const void* x, float* gw, int M, int Nn, int Kk, float beta,
+                                void* workspace, void* stream) {
+    if (M <= 0 || Nn <= 0 || Kk <= 0) return DGX_OK;
+    if (!dy || !x || !gw || !workspace || (Nn & 7) || (Kk & 7) || ((int64_t)Nn * Kk & 3)) return DGX_ERR_BAD_ARG;
+    const int tiles_n = (Nn + BT - 1) / BT, tiles_k = (Kk + BT - 1) / BT;
+    const int S = wgrad_splits(M, Nn, Kk);
+    int slab = (M + S - 1) / S;
+    slab = (slab + BM - 1) / BM * BM;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t sm = (size_t)4 * BT * RS * 2;
+    static bool once = false;
+    if (!once) {
+        (void)hipFuncSetAttribute((const void*)wgrad_partial_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+        once = true;
+    }
+    hipLaunchKernelGGL(wgrad_partial_kernel, dim3(tiles_n * tiles_k, S), dim3(256), sm, st, (const uint16_t*)dy,
+                       (const uint16_t*)x, (float*)workspace, M, Nn, Kk, (int64_t)Nn, (int64_t)Kk, tiles_k, slab);
+    const int64_t n4 = (int64_t)Nn * Kk / 4;
+    const int grid = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, st, (const float4*)workspace, (float4*)gw, n4, S, beta);
+    DGX_LAUNCH_CHECK();
+    return DGX_OK;
+}

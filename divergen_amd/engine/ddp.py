@@ -38,7 +38,11 @@ class ArenaReducer:
         self._works = []
         if self.world > 1:
             for i, p in enumerate(arena.params):
-                p.register_post_accumulate_grad_hook(self._make_hook(i))
+                hook = self._make_hook(i)
+                p.register_post_accumulate_grad_hook(hook)
+                # ops that write their gradient straight into the arena (layers/linear_ops.py) bypass
+                # AccumulateGrad and call this instead
+                p._dgx_ready = (lambda h=hook: h(None))
 
     def _make_hook(self, i):
         b = self.bucket_of[i]
@@ -60,6 +64,7 @@ class ArenaReducer:
         """Same initial weights on every rank (DDP's constructor broadcast)."""
         if self.world > 1:
             dist.broadcast(self.arena.p, src=src, group=self.group)
+            self.arena.sync_shadow()
 
     def finish(self):
         """Call after backward: flush never-ready buckets, wait for every collective.  Returns the

@@ -11,6 +11,7 @@ import torch
 import torch.nn.functional as F
 
 from .. import _lib as L
+from .linear_ops import accumulate_grad, linear, shadow
 
 
 def _nhwc(x):
@@ -31,10 +32,16 @@ class _Conv3x3(torch.autograd.Function):
     def forward(ctx, x, weight, bias, stride):
         # x: NHWC contiguous (N,H,W,C); weight (Cout,Cin,3,3); compute dtype = x.dtype
         N, H, W, C = x.shape
-        wm = weight.to(x.dtype).permute(2, 3, 1, 0).reshape(9 * C, -1)        # (ky,kx,ci) x co
+        bf = x.dtype == torch.bfloat16
+        w = shadow(weight) if bf else weight.to(x.dtype)
+        wm = w.permute(2, 3, 1, 0).reshape(9 * C, -1)                          # (ky,kx,ci) x co
         col, Ho, Wo = _im2col(x, stride)
-        y = torch.addmm(bias.to(x.dtype), col, wm) if bias is not None else col @ wm
+        if bias is not None:
+            y = torch.addmm(shadow(bias) if bf else bias.to(x.dtype), col, wm)
+        else:
+            y = col @ wm
         ctx.save_for_backward(col, wm)
+        ctx.weight, ctx.bias = weight, bias
         ctx.cfg = (N, H, W, C, Ho, Wo, stride, weight.dtype, bias is not None, weight.shape)
         return y.view(N, Ho, Wo, -1)
 
@@ -50,9 +57,15 @@ class _Conv3x3(torch.autograd.Function):
             L.check(L.lib().dgx_col2im3x3(L.ptr(dcol), L.ptr(gx), N, H, W, C, stride, L.dtype_code(gx), L.stream()),
                     "dgx_col2im3x3")
         if ctx.needs_input_grad[1]:
-            gw = (col.t() @ g2).view(3, 3, C, -1).permute(3, 2, 0, 1).to(wdt)
+            def wgrad():
+                if col.dtype == torch.bfloat16:
+                    g = torch.mm(col.t(), g2, out_dtype=torch.float32)
+                else:
+                    g = (col.t() @ g2).float()
+                return g.view(3, 3, C, -1).permute(3, 2, 0, 1)
+            gw = accumulate_grad(ctx.weight, wgrad)
         if has_bias and ctx.needs_input_grad[2]:
-            gb = g2.float().sum(0).to(wdt)
+            gb = accumulate_grad(ctx.bias, lambda: torch.sum(g2, 0, dtype=torch.float32))
         return gx, gw, gb, None
 
 
@@ -86,6 +99,8 @@ def conv3x3(x, weight, bias=None, stride=1):
 
 def conv1x1(x, weight, bias=None):
     xh = _nhwc(x)
+    if weight.shape[0] >= MIN_COUT and torch.is_autocast_enabled():
+        return linear(xh, weight, bias).permute(0, 3, 1, 2)     # arena path: no casts, fp32 wgrad in place
     weight, bias, co = _pad_cout(weight, bias)
     y = F.linear(xh, weight.view(weight.shape[0], -1), bias)
     return y[..., :co].permute(0, 3, 1, 2)

@@ -19,6 +19,7 @@ import torch.nn.functional as F
 
 from .. import BACKBONE_REGISTRY, ShapeSpec
 from ...layers.conv_ops import patch_embed4x4
+from ...layers.linear_ops import Linear
 from ...layers import shift_regions, window_attention_core, window_gather, window_scatter
 
 
@@ -44,9 +45,9 @@ class DropPath(nn.Module):
 class Mlp(nn.Module):
     def __init__(self, in_features, hidden_features=None, out_features=None, drop=0.0):
         super().__init__()
-        self.fc1 = nn.Linear(in_features, hidden_features or in_features)
+        self.fc1 = Linear(in_features, hidden_features or in_features)
         self.act = nn.GELU()
-        self.fc2 = nn.Linear(hidden_features or in_features, out_features or in_features)
+        self.fc2 = Linear(hidden_features or in_features, out_features or in_features)
 
     def forward(self, x):
         return self.fc2(self.act(self.fc1(x)))
@@ -67,8 +68,8 @@ class WindowAttention(nn.Module):
         pos = torch.stack([ii.reshape(-1), jj.reshape(-1)])
         rel = pos[:, :, None] - pos[:, None, :]
         self.register_buffer("relative_position_index", (rel[0] + ws - 1) * (2 * ws - 1) + (rel[1] + ws - 1))
-        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
-        self.proj = nn.Linear(dim, dim)
+        self.qkv = Linear(dim, dim * 3, bias=qkv_bias)
+        self.proj = Linear(dim, dim)
         trunc_normal_(self.relative_position_bias_table, std=0.02)
 
     def forward(self, x, region=None, nW=1):
@@ -112,7 +113,7 @@ class PatchMerging(nn.Module):
     def __init__(self, dim):
         super().__init__()
         self.dim = dim
-        self.reduction = nn.Linear(4 * dim, 2 * dim, bias=False)
+        self.reduction = Linear(4 * dim, 2 * dim, bias=False)
         self.norm = nn.LayerNorm(4 * dim)
 
     def forward(self, x, H, W):

@@ -6,6 +6,7 @@ from torch import nn
 
 from .. import ROI_BOX_HEAD_REGISTRY, ShapeSpec
 from ...config import configurable
+from ...layers.linear_ops import Linear
 from ..backbone.fpn import c2_xavier_fill
 
 
@@ -21,7 +22,7 @@ class FastRCNNConvFCHead(nn.Sequential):
         for k, fc_dim in enumerate(fc_dims):
             if k == 0:
                 self.add_module("flatten", nn.Flatten())
-            fc = nn.Linear(int(np.prod(self._output_size)), fc_dim)
+            fc = Linear(int(np.prod(self._output_size)), fc_dim)
             self.add_module("fc%d" % (k + 1), fc)
             self.add_module("fc_relu%d" % (k + 1), nn.ReLU())
             self.fcs.append(fc)

@@ -11,6 +11,7 @@ from torch.nn import functional as F
 
 from ...config import configurable
 from ...layers import batched_nms
+from ...layers.linear_ops import Linear
 from ...structures import Boxes, Instances
 from ...utils.events import get_event_storage
 from ..box_regression import Box2BoxTransform
@@ -96,8 +97,8 @@ class DeticFastRCNNOutputLayers(nn.Module):
             raise NotImplementedError("USE_ZEROSHOT_CLS / non-smooth_l1 box losses are outside the shipped configs")
         self.num_classes = num_classes
         input_size = input_shape.channels * (input_shape.width or 1) * (input_shape.height or 1)
-        self.cls_score = nn.Linear(input_size, num_classes + 1)
-        self.bbox_pred = nn.Linear(input_size, (1 if cls_agnostic_bbox_reg else num_classes) * 4)
+        self.cls_score = Linear(input_size, num_classes + 1)
+        self.bbox_pred = Linear(input_size, (1 if cls_agnostic_bbox_reg else num_classes) * 4)
         nn.init.normal_(self.cls_score.weight, std=0.01)
         nn.init.normal_(self.bbox_pred.weight, std=0.001)
         for l in (self.cls_score, self.bbox_pred):

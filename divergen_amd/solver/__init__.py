@@ -50,11 +50,18 @@ class FlatArena:
         self.offsets, self.numel = offs, n
         self.p = torch.zeros(n, dtype=torch.float32, device=dev)
         self.g = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.p16 = torch.zeros(n, dtype=torch.bfloat16, device=dev)   # bf16 shadow, refreshed by the optimizer kernel
         for p, o in zip(self.params, offs):
             v = self.p[o:o + p.numel()].view_as(p)
             v.copy_(p.data)
             p.data = v
             p.grad = self.g[o:o + p.numel()].view_as(p)
+            p._dgx16 = self.p16[o:o + p.numel()].view_as(p)
+        self.sync_shadow()
+
+    def sync_shadow(self):
+        """Re-derive the bf16 shadow from the fp32 weights (after init / broadcast / checkpoint load)."""
+        self.p16.copy_(self.p)
 
     def zero_grad(self):
         self.g.zero_()
@@ -88,6 +95,7 @@ class FusedAdamWEMA:
         self.step_count += 1
         adamw_ema_step(self.arena.p, self.arena.g, self.m, self.v, self.ema, self.step_count, self.param_groups[0]["lr"],
                        self.betas, self.eps, self.weight_decay, self.clip_value, grad_scale, self.ema_decay,
+                       p_bf16=self.arena.p16 if self.arena.p16.is_cuda else None,
                        lr_scale=self.lr_scale, seg_end=self.seg_end, found_inf=found_inf)
 
     def state_dict(self):

@@ -183,6 +183,17 @@ int dgx_im2col3x3(const void* x, void* col, int N, int H, int W, int C, int stri
 int dgx_col2im3x3(const void* dcol, void* dx, int N, int H, int W, int C, int stride, int dtype,
                   void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Weight gradient of a Linear / im2col convolution:  gw[Nn][Kk] = beta*gw + dy^T x  (fp32 out),
+ * dy bf16 (M,Nn), x bf16 (M,Kk), both row-major; M-split MFMA kernel + slab reduction.  Replaces the
+ * `grad_output.t().mm(input)` of nn.Linear's backward (call sites as dgx_window_attention_*: qkv /
+ * proj / fc1 / fc2 of swintransformer.py:118-120,35-37, box_head.py fc1/fc2) where the GEMM library
+ * runs the long-K transposed shape at a fraction of its rate.  Nn, Kk multiples of 8.
+ * workspace: dgx_wgrad_workspace_bytes(M,Nn,Kk) bytes of device scratch. */
+int64_t dgx_wgrad_workspace_bytes(int M, int Nn, int Kk);
+int dgx_linear_wgrad(const void* dy, const void* x, float* gw, int M, int Nn, int Kk, float beta,
+                     void* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -310,3 +310,17 @@ def test_conv3x3_matches_torch_cpu(stride, dt):
         tok, hp, wp_ = patch_embed4x4(img.to(DEV), wp.to(DEV), bp.to(DEV))
         refp = torch.nn.functional.conv2d(img, wp, bp, stride=4).flatten(2).transpose(1, 2)
         torch.testing.assert_close(tok.cpu(), refp, atol=1e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize("M,Nn,Kk", [(16384, 576, 192), (20000, 192, 768), (16384 + 17, 1152, 384), (17000, 64, 72)])
+def test_linear_wgrad_split_m(M, Nn, Kk):
+    from divergen_amd.layers.linear_ops import wgrad_into
+    g = torch.Generator().manual_seed(61)
+    dy = bf(torch.randn(M, Nn, generator=g))
+    x = bf(torch.randn(M, Kk, generator=g))
+    acc0 = torch.randn(Nn, Kk, generator=g)
+    ref = acc0 + dy.float().t() @ x.float()
+    acc = acc0.to(DEV).clone()
+    wgrad_into(acc, dy.to(DEV), x.to(DEV), 1.0)
+    # bf16 products are exact in fp32; only the fp32 summation order differs: 1e-5 of the result scale
+    assert (acc.cpu() - ref).abs().max() <= 2e-5 * ref.abs().max() + 1e-3

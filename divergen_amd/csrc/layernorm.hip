@@ -1,0 +1,220 @@
+// Fused LayerNorm for the Swin blocks (gfx950).  HBM-bound: one wave per token row, 16-byte lanes.
+//   forward : x fp32 (T,C) -> y bf16, optionally written straight in WINDOW order (zero rows for the
+//             padding tokens): LayerNorm + bf16 cast + pad + roll + window_partition in one pass
+//             (reads 4 B, writes 2 B per element) instead of LN (4+4) + cast (4+2) + gather (2+2).
+//   backward: dy bf16 (window order when gathered) + x + (mean, rstd) -> dx fp32, and per-block partial
+//             sums of dgamma / dbeta (a second tiny pass adds them into the gradient arena).
+// Reference semantics: nn.LayerNorm at swintransformer.py:213,255 followed by :216-233.
+#include "dgx_common.h"
+
+struct WinMap { int B, H, W, ws, shift, nWh, nWw; };   // ws == 0: identity (no gather)
+
+// output row index (window order) -> source token index, or -1 for a padding token
+__device__ __forceinline__ int64_t win_src(const WinMap& m, int64_t orow) {
+    const int N = m.ws * m.ws;
+    const int n = (int)(orow % N);
+    int64_t t = orow / N;
+    const int wc = (int)(t % m.nWw);
+    t /= m.nWw;
+    const int wr = (int)(t % m.nWh);
+    const int b = (int)(t / m.nWh);
+    int hh = wr * m.ws + n / m.ws + m.shift, ww = wc * m.ws + n % m.ws + m.shift;
+    const int Hp = m.nWh * m.ws, Wp = m.nWw * m.ws;
+    if (hh >= Hp) hh -= Hp;
+    if (ww >= Wp) ww -= Wp;
+    if (hh >= m.H || ww >= m.W) return -1;
+    return ((int64_t)b * m.H + hh) * m.W + ww;
+}
+
+// source token -> its row in window order
+__device__ __forceinline__ int64_t win_dst(const WinMap& m, int64_t tok) {
+    const int ww0 = (int)(tok % m.W);
+    int64_t t = tok / m.W;
+    const int hh0 = (int)(t % m.H);
+    const int b = (int)(t / m.H);
+    const int Hp = m.nWh * m.ws, Wp = m.nWw * m.ws;
+    int hs = hh0 - m.shift, wsx = ww0 - m.shift;
+    if (hs < 0) hs += Hp;
+    if (wsx < 0) wsx += Wp;
+    const int wr = hs / m.ws, wc = wsx / m.ws;
+    const int n = (hs - wr * m.ws) * m.ws + (wsx - wc * m.ws);
+    return (((int64_t)b * m.nWh + wr) * m.nWw + wc) * (m.ws * m.ws) + n;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, uint16_t* __restrict__ y,
+                                                     float* __restrict__ mean, float* __restrict__ rstd, int64_t T_out,
+                                                     int C, float eps, WinMap m) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t orow = wave; orow < T_out; orow += nwaves) {
+        const int64_t tok = m.ws ? win_src(m, orow) : orow;
+        uint2* yo = reinterpret_cast<uint2*>(y + orow * C);
+        if (tok < 0) {
+            for (int i = lane; i < C / 4; i += 64) yo[i] = make_uint2(0u, 0u);
+            continue;
+        }
+        const float4* xr = reinterpret_cast<const float4*>(x + tok * C);
+        float s = 0.f;
+        for (int i = lane; i < C / 4; i += 64) { const float4 v = xr[i]; s += (v.x + v.y) + (v.z + v.w); }
+        const float mu = wave_sum(s) / (float)C;
+        float q = 0.f;
+        for (int i = lane; i < C / 4; i += 64) {
+            const float4 v = xr[i];
+            const float a = v.x - mu, b = v.y - mu, c = v.z - mu, d = v.w - mu;
+            q += (a * a + b * b) + (c * c + d * d);
+        }
+        const float rs = rsqrtf(wave_sum(q) / (float)C + eps);
+        if (lane == 0) { mean[tok] = mu; rstd[tok] = rs; }
+        const float4* g4 = reinterpret_cast<const float4*>(gamma);
+        const float4* b4 = reinterpret_cast<const float4*>(beta);
+        for (int i = lane; i < C / 4; i += 64) {
+            const float4 v = xr[i], g = g4[i], b = b4[i];
+            yo[i] = make_uint2(pack_bf2((v.x - mu) * rs * g.x + b.x, (v.y - mu) * rs * g.y + b.y),
+                               pack_bf2((v.z - mu) * rs * g.z + b.z, (v.w - mu) * rs * g.w + b.w));
+        }
+    }
+}
+
+// NJ = ceil(C/256): float4 columns per lane
+template <int NJ>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const uint16_t* __restrict__ dy, const float* __restrict__ x,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     const float* __restrict__ gamma, float* __restrict__ dx,
+                                                     float* __restrict__ part, int64_t T, int C, WinMap m) {
+    __shared__ float red[2][NJ * 256];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + w;
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    float dg[NJ][4], db[NJ][4];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dg[j][k] = db[j][k] = 0.f;
+    const float4* g4 = reinterpret_cast<const float4*>(gamma);
+    for (int64_t tok = wave; tok < T; tok += nwaves) {
+        const int64_t drow = m.ws ? win_dst(m, tok) : tok;
+        const uint2* dyr = reinterpret_cast<const uint2*>(dy + drow * C);
+        const float4* xr = reinterpret_cast<const float4*>(x + tok * C);
+        const float mu = mean[tok], rs = rstd[tok];
+        float xh[NJ][4], gv[NJ][4];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int i = lane + 64 * j;
+            if (i < C / 4) {
+                const float4 v = xr[i], g = g4[i];
+                const uint2 d = dyr[i];
+                const float dv[4] = {__uint_as_float(d.x << 16), __uint_as_float(d.x & 0xffff0000u),
+                                     __uint_as_float(d.y << 16), __uint_as_float(d.y & 0xffff0000u)};
+                const float xv[4] = {v.x, v.y, v.z, v.w}, gg[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    xh[j][k] = (xv[k] - mu) * rs;
+                    gv[j][k] = dv[k] * gg[k];
+                    s1 += gv[j][k];
+                    s2 += gv[j][k] * xh[j][k];
+                    dg[j][k] += dv[k] * xh[j][k];
+                    db[j][k] += dv[k];
+                }
+            }
+        }
+        s1 = wave_sum(s1) / (float)C;
+        s2 = wave_sum(s2) / (float)C;
+        float4* dxr = reinterpret_cast<float4*>(dx + tok * C);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int i = lane + 64 * j;
+            if (i < C / 4)
+                dxr[i] = make_float4(rs * (gv[j][0] - s1 - xh[j][0] * s2), rs * (gv[j][1] - s1 - xh[j][1] * s2),
+                                     rs * (gv[j][2] - s1 - xh[j][2] * s2), rs * (gv[j][3] - s1 - xh[j][3] * s2));
+        }
+    }
+    // block partials: the 4 waves fold into one LDS row in turn -> one row of `part` per block: [block][2][C]
+    for (int turn = 0; turn < 4; ++turn) {
+        if (w == turn) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int c = (lane + 64 * j) * 4 + k;
+                    red[0][c] = turn ? red[0][c] + dg[j][k] : dg[j][k];
+                    red[1][c] = turn ? red[1][c] + db[j][k] : db[j][k];
+                }
+        }
+        __syncthreads();
+    }
+    for (int c = threadIdx.x; c < C; c += 256) {
+        part[((int64_t)blockIdx.x * 2 + 0) * C + c] = red[0][c];
+        part[((int64_t)blockIdx.x * 2 + 1) * C + c] = red[1][c];
+    }
+}
+
+// dgamma += sum_blocks part[b][0], dbeta += sum_blocks part[b][1]
+__global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* __restrict__ part, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, int nblk, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= 2 * C) return;
+    const int which = c / C, col = c - which * C;
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += part[((int64_t)b * 2 + which) * C + col];
+    float* dst = which ? dbeta : dgamma;
+    dst[col] += s;
+}
+
+static WinMap make_map(int B, int H, int W, int ws, int shift) {
+    WinMap m = {B, H, W, ws, shift, 0, 0};
+    if (ws > 0) { m.nWh = (H + ws - 1) / ws; m.nWw = (W + ws - 1) / ws; }
+    return m;
+}
+
+extern "C" int dgx_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y_bf16, float* mean,
+                                 float* rstd, int64_t T, int C, float eps, int B, int H, int W, int ws, int shift,
+                                 void* stream) {
+    if (T <= 0) return DGX_OK;
+    if (!x || !gamma || !beta || !y_bf16 || !mean || !rstd || (C & 3) || (ws > 0 && (int64_t)B * H * W != T))
+        return DGX_ERR_BAD_ARG;
+    const WinMap m = make_map(B, H, W, ws, shift);
+    const int64_t T_out = ws > 0 ? (int64_t)B * m.nWh * m.nWw * ws * ws : T;
+    const int grid = (int)((T_out + 3) / 4 < 8192 ? (T_out + 3) / 4 : 8192);
+    hipLaunchKernelGGL(ln_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, (uint16_t*)y_bf16, mean,
+                       rstd, T_out, C, eps, m);
+    DGX_LAUNCH_CHECK();
+    return DGX_OK;
+}
+
+extern "C" int dgx_layernorm_bwd_blocks(int64_t T) {
+    int64_t b = (T + 3) / 4;
+    return (int)(b < 512 ? (b < 1 ? 1 : b) : 512);
+}
+
+extern "C" int dgx_layernorm_bwd(const void* dy_bf16, const float* x, const float* mean, const float* rstd,
+                                 const float* gamma, float* dx, float* dgamma, float* dbeta, float* part, int64_t T, int C,
+                                 int B, int H, int W, int ws, int shift, void* stream) {
+    if (T <= 0) return DGX_OK;
+    if (!dy_bf16 || !x || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta || !part || (C & 3) || C > 1536 ||
+        (ws > 0 && (int64_t)B * H * W != T))
+        return DGX_ERR_BAD_ARG;
+    const WinMap m = make_map(B, H, W, ws, shift);
+    const int grid = dgx_layernorm_bwd_blocks(T);
+    hipStream_t st = (hipStream_t)stream;
+    const int nj = (C + 255) / 256;
+#define LN_BWD(NJ)                                                                                                     \
+    hipLaunchKernelGGL(ln_bwd_kernel<NJ>, dim3(grid), dim3(256), 0, st, (const uint16_t*)dy_bf16, x, mean, rstd, gamma, dx, \
+                       part, T, C, m)
+    if (nj <= 1) LN_BWD(1);
+    else if (nj <= 2) LN_BWD(2);
+    else if (nj <= 3) LN_BWD(3);
+    else LN_BWD(6);
+#undef LN_BWD
+    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, st, part, dgamma, dbeta, grid, C);
+    DGX_LAUNCH_CHECK();
+    return DGX_OK;
+}

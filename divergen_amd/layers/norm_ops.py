@@ -1,0 +1,61 @@
+"""Fused LayerNorm (+bf16 cast, + window gather) over libdgx.  Reference: nn.LayerNorm call sites
+swintransformer.py:213 (norm1, followed by pad/roll/partition :216-233) and :255 (norm2)."""
+import torch
+
+from .. import _lib as L
+from .linear_ops import accumulate_grad
+
+
+class _LayerNormBF16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, B, H, W, ws, shift):
+        assert x.dtype == torch.float32
+        x = x.contiguous()
+        C = x.shape[-1]
+        T = x.numel() // C
+        if ws > 0:
+            assert T == B * H * W
+            nW = (-(-H // ws)) * (-(-W // ws))
+            y = torch.empty(B * nW, ws * ws, C, dtype=torch.bfloat16, device=x.device)
+        else:
+            y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+        mean = torch.empty(T, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(T, dtype=torch.float32, device=x.device)
+        L.check(L.lib().dgx_layernorm_fwd(L.ptr(x), L.ptr(weight), L.ptr(bias), L.ptr(y), L.ptr(mean), L.ptr(rstd), T, C,
+                                          float(eps), B, H, W, ws, shift, L.stream()), "dgx_layernorm_fwd")
+        ctx.save_for_backward(x, mean, rstd)
+        ctx.weight, ctx.bias, ctx.cfg = weight, bias, (T, C, B, H, W, ws, shift)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, rstd = ctx.saved_tensors
+        weight, bias = ctx.weight, ctx.bias
+        T, C, B, H, W, ws, shift = ctx.cfg
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        nblk = L.lib().dgx_layernorm_bwd_blocks(T)
+        part = torch.empty(nblk * 2 * C, dtype=torch.float32, device=x.device)
+        in_arena = (weight.grad is not None and getattr(weight, "_dgx16", None) is not None
+                    and bias.grad is not None and getattr(bias, "_dgx16", None) is not None)
+        dg = weight.grad if in_arena else torch.zeros(C, dtype=torch.float32, device=x.device)
+        db = bias.grad if in_arena else torch.zeros(C, dtype=torch.float32, device=x.device)
+        L.check(L.lib().dgx_layernorm_bwd(L.ptr(dy), L.ptr(x), L.ptr(mean), L.ptr(rstd), L.ptr(weight), L.ptr(dx), L.ptr(dg),
+                                          L.ptr(db), L.ptr(part), T, C, B, H, W, ws, shift, L.stream()), "dgx_layernorm_bwd")
+        if in_arena:
+            for p in (weight, bias):
+                ready = getattr(p, "_dgx_ready", None)
+                if ready is not None:
+                    ready()
+            return dx, None, None, None, None, None, None, None, None
+        return dx, dg.to(weight.dtype), db.to(bias.dtype), None, None, None, None, None, None
+
+
+def layernorm_bf16(x, weight, bias, eps=1e-5):
+    """fp32 (..., C) -> LayerNorm -> bf16 (..., C)."""
+    return _LayerNormBF16.apply(x, weight, bias, eps, 0, 0, 0, 0, 0)
+
+
+def layernorm_window_gather(x, weight, bias, eps, B, H, W, ws, shift):
+    """fp32 (B, H*W, C) -> LayerNorm -> zero-pad, roll(-shift), partition -> bf16 (B*nW, ws*ws, C)."""
+    return _LayerNormBF16.apply(x, weight, bias, eps, B, H, W, ws, shift)

@@ -20,6 +20,7 @@ import torch.nn.functional as F
 from .. import BACKBONE_REGISTRY, ShapeSpec
 from ...layers.conv_ops import patch_embed4x4
 from ...layers.linear_ops import Linear
+from ...layers.norm_ops import layernorm_bf16, layernorm_window_gather
 from ...layers import shift_regions, window_attention_core, window_gather, window_scatter
 
 
@@ -98,15 +99,17 @@ class SwinTransformerBlock(nn.Module):
         H, W = self.H, self.W
         assert Ltok == H * W, "input feature has wrong size"
         ws, sh = self.window_size, self.shift_size
-        h = self.norm1(x)
-        if torch.is_autocast_enabled():
-            h = h.to(torch.bfloat16)
-        xw = window_gather(h, H, W, ws, sh)
+        fused = torch.is_autocast_enabled() and x.dtype == torch.float32 and C <= 1536
+        if fused:   # LN + bf16 cast + pad + roll + partition in one pass
+            xw = layernorm_window_gather(x, self.norm1.weight, self.norm1.bias, self.norm1.eps, B, H, W, ws, sh)
+        else:
+            xw = window_gather(self.norm1(x), H, W, ws, sh)
         nW = (-(-H // ws)) * (-(-W // ws))
         aw = self.attn(xw, region if sh > 0 else None, nW)
         a = window_scatter(aw, B, H, W, ws, sh)
         x = x + self.drop_path(a)
-        return x + self.drop_path(self.mlp(self.norm2(x)))
+        h2 = layernorm_bf16(x, self.norm2.weight, self.norm2.bias, self.norm2.eps) if fused else self.norm2(x)
+        return x + self.drop_path(self.mlp(h2))
 
 
 class PatchMerging(nn.Module):

@@ -41,13 +41,28 @@ __device__ __forceinline__ int64_t win_dst(const WinMap& m, int64_t tok) {
     return (((int64_t)b * m.nWh + wr) * m.nWw + wc) * (m.ws * m.ws) + n;
 }
 
+// 4 consecutive elements of a row as fp32, for fp32 or bf16 storage
+template <typename T> __device__ __forceinline__ float4 ld4(const T* row, int i);
+template <> __device__ __forceinline__ float4 ld4<float>(const float* row, int i) { return reinterpret_cast<const float4*>(row)[i]; }
+template <> __device__ __forceinline__ float4 ld4<uint16_t>(const uint16_t* row, int i) {
+    const uint2 d = reinterpret_cast<const uint2*>(row)[i];
+    return make_float4(__uint_as_float(d.x << 16), __uint_as_float(d.x & 0xffff0000u), __uint_as_float(d.y << 16),
+                       __uint_as_float(d.y & 0xffff0000u));
+}
+template <typename T> __device__ __forceinline__ void st4(T* row, int i, float4 v);
+template <> __device__ __forceinline__ void st4<float>(float* row, int i, float4 v) { reinterpret_cast<float4*>(row)[i] = v; }
+template <> __device__ __forceinline__ void st4<uint16_t>(uint16_t* row, int i, float4 v) {
+    reinterpret_cast<uint2*>(row)[i] = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
 
-__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+template <typename XT>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const XT* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, uint16_t* __restrict__ y,
                                                      float* __restrict__ mean, float* __restrict__ rstd, int64_t T_out,
                                                      int C, float eps, WinMap m) {
@@ -61,13 +76,13 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
             for (int i = lane; i < C / 4; i += 64) yo[i] = make_uint2(0u, 0u);
             continue;
         }
-        const float4* xr = reinterpret_cast<const float4*>(x + tok * C);
+        const XT* xr = x + tok * C;
         float s = 0.f;
-        for (int i = lane; i < C / 4; i += 64) { const float4 v = xr[i]; s += (v.x + v.y) + (v.z + v.w); }
+        for (int i = lane; i < C / 4; i += 64) { const float4 v = ld4<XT>(xr, i); s += (v.x + v.y) + (v.z + v.w); }
         const float mu = wave_sum(s) / (float)C;
         float q = 0.f;
         for (int i = lane; i < C / 4; i += 64) {
-            const float4 v = xr[i];
+            const float4 v = ld4<XT>(xr, i);
             const float a = v.x - mu, b = v.y - mu, c = v.z - mu, d = v.w - mu;
             q += (a * a + b * b) + (c * c + d * d);
         }
@@ -76,7 +91,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
         const float4* g4 = reinterpret_cast<const float4*>(gamma);
         const float4* b4 = reinterpret_cast<const float4*>(beta);
         for (int i = lane; i < C / 4; i += 64) {
-            const float4 v = xr[i], g = g4[i], b = b4[i];
+            const float4 v = ld4<XT>(xr, i), g = g4[i], b = b4[i];
             yo[i] = make_uint2(pack_bf2((v.x - mu) * rs * g.x + b.x, (v.y - mu) * rs * g.y + b.y),
                                pack_bf2((v.z - mu) * rs * g.z + b.z, (v.w - mu) * rs * g.w + b.w));
         }
@@ -84,10 +99,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 }
 
 // NJ = ceil(C/256): float4 columns per lane
-template <int NJ>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const uint16_t* __restrict__ dy, const float* __restrict__ x,
+template <int NJ, typename XT>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const uint16_t* __restrict__ dy, const XT* __restrict__ x,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                     const float* __restrict__ gamma, float* __restrict__ dx,
+                                                     const float* __restrict__ gamma, XT* __restrict__ dx,
                                                      float* __restrict__ part, int64_t T, int C, WinMap m) {
     __shared__ float red[2][NJ * 256];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -102,7 +117,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const uint16_t* __restrict_
     for (int64_t tok = wave; tok < T; tok += nwaves) {
         const int64_t drow = m.ws ? win_dst(m, tok) : tok;
         const uint2* dyr = reinterpret_cast<const uint2*>(dy + drow * C);
-        const float4* xr = reinterpret_cast<const float4*>(x + tok * C);
+        const XT* xr = x + tok * C;
         const float mu = mean[tok], rs = rstd[tok];
         float xh[NJ][4], gv[NJ][4];
         float s1 = 0.f, s2 = 0.f;
@@ -110,7 +125,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const uint16_t* __restrict_
         for (int j = 0; j < NJ; ++j) {
             const int i = lane + 64 * j;
             if (i < C / 4) {
-                const float4 v = xr[i], g = g4[i];
+                const float4 v = ld4<XT>(xr, i), g = g4[i];
                 const uint2 d = dyr[i];
                 const float dv[4] = {__uint_as_float(d.x << 16), __uint_as_float(d.x & 0xffff0000u),
                                      __uint_as_float(d.y << 16), __uint_as_float(d.y & 0xffff0000u)};
@@ -128,13 +143,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const uint16_t* __restrict_
         }
         s1 = wave_sum(s1) / (float)C;
         s2 = wave_sum(s2) / (float)C;
-        float4* dxr = reinterpret_cast<float4*>(dx + tok * C);
+        XT* dxr = dx + tok * C;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int i = lane + 64 * j;
             if (i < C / 4)
-                dxr[i] = make_float4(rs * (gv[j][0] - s1 - xh[j][0] * s2), rs * (gv[j][1] - s1 - xh[j][1] * s2),
-                                     rs * (gv[j][2] - s1 - xh[j][2] * s2), rs * (gv[j][3] - s1 - xh[j][3] * s2));
+                st4<XT>(dxr, i, make_float4(rs * (gv[j][0] - s1 - xh[j][0] * s2), rs * (gv[j][1] - s1 - xh[j][1] * s2),
+                                            rs * (gv[j][2] - s1 - xh[j][2] * s2), rs * (gv[j][3] - s1 - xh[j][3] * s2)));
         }
     }
     // block partials: the 4 waves fold into one LDS row in turn -> one row of `part` per block: [block][2][C]
@@ -157,16 +172,23 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const uint16_t* __restrict_
     }
 }
 
-// dgamma += sum_blocks part[b][0], dbeta += sum_blocks part[b][1]
+// dgamma += sum_blocks part[b][0], dbeta += sum_blocks part[b][1]; block = 64 columns x 4 row groups
 __global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* __restrict__ part, float* __restrict__ dgamma,
                                                               float* __restrict__ dbeta, int nblk, int C) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= 2 * C) return;
-    const int which = c / C, col = c - which * C;
+    __shared__ float red[4][64];
+    const int col2 = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
     float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += part[((int64_t)b * 2 + which) * C + col];
-    float* dst = which ? dbeta : dgamma;
-    dst[col] += s;
+    if (col2 < 2 * C) {
+        const int which = col2 / C, col = col2 - which * C;
+        for (int b = rg; b < nblk; b += 4) s += part[((int64_t)b * 2 + which) * C + col];
+    }
+    red[rg][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (rg == 0 && col2 < 2 * C) {
+        const int which = col2 / C, col = col2 - which * C;
+        float* dst = which ? dbeta : dgamma;
+        dst[col] += (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    }
 }
 
 static WinMap make_map(int B, int H, int W, int ws, int shift) {
@@ -175,17 +197,21 @@ static WinMap make_map(int B, int H, int W, int ws, int shift) {
     return m;
 }
 
-extern "C" int dgx_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y_bf16, float* mean,
+extern "C" int dgx_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y_bf16, float* mean,
                                  float* rstd, int64_t T, int C, float eps, int B, int H, int W, int ws, int shift,
-                                 void* stream) {
+                                 int x_dtype, void* stream) {
     if (T <= 0) return DGX_OK;
     if (!x || !gamma || !beta || !y_bf16 || !mean || !rstd || (C & 3) || (ws > 0 && (int64_t)B * H * W != T))
         return DGX_ERR_BAD_ARG;
     const WinMap m = make_map(B, H, W, ws, shift);
     const int64_t T_out = ws > 0 ? (int64_t)B * m.nWh * m.nWw * ws * ws : T;
     const int grid = (int)((T_out + 3) / 4 < 8192 ? (T_out + 3) / 4 : 8192);
-    hipLaunchKernelGGL(ln_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, (uint16_t*)y_bf16, mean,
-                       rstd, T_out, C, eps, m);
+    if (x_dtype == DGX_BF16)
+        hipLaunchKernelGGL(ln_fwd_kernel<uint16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, gamma,
+                           beta, (uint16_t*)y_bf16, mean, rstd, T_out, C, eps, m);
+    else
+        hipLaunchKernelGGL(ln_fwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)x, gamma, beta,
+                           (uint16_t*)y_bf16, mean, rstd, T_out, C, eps, m);
     DGX_LAUNCH_CHECK();
     return DGX_OK;
 }
@@ -195,9 +221,9 @@ extern "C" int dgx_layernorm_bwd_blocks(int64_t T) {
     return (int)(b < 512 ? (b < 1 ? 1 : b) : 512);
 }
 
-extern "C" int dgx_layernorm_bwd(const void* dy_bf16, const float* x, const float* mean, const float* rstd,
-                                 const float* gamma, float* dx, float* dgamma, float* dbeta, float* part, int64_t T, int C,
-                                 int B, int H, int W, int ws, int shift, void* stream) {
+extern "C" int dgx_layernorm_bwd(const void* dy_bf16, const void* x, const float* mean, const float* rstd,
+                                 const float* gamma, void* dx, float* dgamma, float* dbeta, float* part, int64_t T, int C,
+                                 int B, int H, int W, int ws, int shift, int x_dtype, void* stream) {
     if (T <= 0) return DGX_OK;
     if (!dy_bf16 || !x || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta || !part || (C & 3) || C > 1536 ||
         (ws > 0 && (int64_t)B * H * W != T))
@@ -206,15 +232,21 @@ extern "C" int dgx_layernorm_bwd(const void* dy_bf16, const float* x, const floa
     const int grid = dgx_layernorm_bwd_blocks(T);
     hipStream_t st = (hipStream_t)stream;
     const int nj = (C + 255) / 256;
-#define LN_BWD(NJ)                                                                                                     \
-    hipLaunchKernelGGL(ln_bwd_kernel<NJ>, dim3(grid), dim3(256), 0, st, (const uint16_t*)dy_bf16, x, mean, rstd, gamma, dx, \
-                       part, T, C, m)
+#define LN_BWD(NJ)                                                                                                         \
+    do {                                                                                                                   \
+        if (x_dtype == DGX_BF16)                                                                                           \
+            hipLaunchKernelGGL((ln_bwd_kernel<NJ, uint16_t>), dim3(grid), dim3(256), 0, st, (const uint16_t*)dy_bf16,       \
+                               (const uint16_t*)x, mean, rstd, gamma, (uint16_t*)dx, part, T, C, m);                        \
+        else                                                                                                               \
+            hipLaunchKernelGGL((ln_bwd_kernel<NJ, float>), dim3(grid), dim3(256), 0, st, (const uint16_t*)dy_bf16,          \
+                               (const float*)x, mean, rstd, gamma, (float*)dx, part, T, C, m);                              \
+    } while (0)
     if (nj <= 1) LN_BWD(1);
     else if (nj <= 2) LN_BWD(2);
     else if (nj <= 3) LN_BWD(3);
     else LN_BWD(6);
 #undef LN_BWD
-    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, st, part, dgamma, dbeta, grid, C);
+    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * C + 63) / 64), dim3(256), 0, st, part, dgamma, dbeta, grid, C);
     DGX_LAUNCH_CHECK();
     return DGX_OK;
 }

@@ -9,7 +9,7 @@ from .linear_ops import accumulate_grad
 class _LayerNormBF16(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, eps, B, H, W, ws, shift):
-        assert x.dtype == torch.float32
+        assert x.dtype in (torch.float32, torch.bfloat16)
         x = x.contiguous()
         C = x.shape[-1]
         T = x.numel() // C
@@ -22,7 +22,7 @@ class _LayerNormBF16(torch.autograd.Function):
         mean = torch.empty(T, dtype=torch.float32, device=x.device)
         rstd = torch.empty(T, dtype=torch.float32, device=x.device)
         L.check(L.lib().dgx_layernorm_fwd(L.ptr(x), L.ptr(weight), L.ptr(bias), L.ptr(y), L.ptr(mean), L.ptr(rstd), T, C,
-                                          float(eps), B, H, W, ws, shift, L.stream()), "dgx_layernorm_fwd")
+                                          float(eps), B, H, W, ws, shift, L.dtype_code(x), L.stream()), "dgx_layernorm_fwd")
         ctx.save_for_backward(x, mean, rstd)
         ctx.weight, ctx.bias, ctx.cfg = weight, bias, (T, C, B, H, W, ws, shift)
         return y
@@ -41,7 +41,7 @@ class _LayerNormBF16(torch.autograd.Function):
         dg = weight.grad if in_arena else torch.zeros(C, dtype=torch.float32, device=x.device)
         db = bias.grad if in_arena else torch.zeros(C, dtype=torch.float32, device=x.device)
         L.check(L.lib().dgx_layernorm_bwd(L.ptr(dy), L.ptr(x), L.ptr(mean), L.ptr(rstd), L.ptr(weight), L.ptr(dx), L.ptr(dg),
-                                          L.ptr(db), L.ptr(part), T, C, B, H, W, ws, shift, L.stream()), "dgx_layernorm_bwd")
+                                          L.ptr(db), L.ptr(part), T, C, B, H, W, ws, shift, L.dtype_code(x), L.stream()), "dgx_layernorm_bwd")
         if in_arena:
             for p in (weight, bias):
                 ready = getattr(p, "_dgx_ready", None)

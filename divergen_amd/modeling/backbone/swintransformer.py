@@ -99,7 +99,7 @@ class SwinTransformerBlock(nn.Module):
         H, W = self.H, self.W
         assert Ltok == H * W, "input feature has wrong size"
         ws, sh = self.window_size, self.shift_size
-        fused = torch.is_autocast_enabled() and x.dtype == torch.float32 and C <= 1536
+        fused = torch.is_autocast_enabled() and C <= 1536
         if fused:   # LN + bf16 cast + pad + roll + partition in one pass
             xw = layernorm_window_gather(x, self.norm1.weight, self.norm1.bias, self.norm1.eps, B, H, W, ws, sh)
         else:

@@ -197,17 +197,17 @@ int dgx_linear_wgrad(const void* dy, const void* x, float* gw, int M, int Nn, in
 /* ---------------------------------------------------------------------------------------------
  * Fused LayerNorm (+ bf16 cast + optional window gather).  Replaces norm1 + F.pad + torch.roll +
  * window_partition (swintransformer.py:213-233) and norm2 (:255) with one pass each way.
- *   x f32 (T,C) with T = B*H*W;  ws > 0: y bf16 is written in window order (B*nW, ws*ws, C), zero rows
+ *   x f32 or bf16 (x_dtype) (T,C) with T = B*H*W;  ws > 0: y bf16 is written in window order (B*nW, ws*ws, C), zero rows
  *   for padding tokens;  ws == 0: y bf16 (T,C).  mean/rstd f32 (T) are saved for backward.
- * Backward: dy bf16 in the same order as y -> dx f32 (T,C) written; dgamma/dbeta f32 (C) ACCUMULATED;
+ * Backward: dy bf16 in the same order as y -> dx (x_dtype) (T,C) written; dgamma/dbeta f32 (C) ACCUMULATED;
  *   part: f32 scratch of dgx_layernorm_bwd_blocks(T)*2*C.  C % 4 == 0, C <= 1536 for backward. */
-int dgx_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y_bf16, float* mean,
+int dgx_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y_bf16, float* mean,
                       float* rstd, int64_t T, int C, float eps, int B, int H, int W, int ws, int shift,
-                      void* stream);
+                      int x_dtype, void* stream);
 int dgx_layernorm_bwd_blocks(int64_t T);
-int dgx_layernorm_bwd(const void* dy_bf16, const float* x, const float* mean, const float* rstd,
-                      const float* gamma, float* dx, float* dgamma, float* dbeta, float* part, int64_t T,
-                      int C, int B, int H, int W, int ws, int shift, void* stream);
+int dgx_layernorm_bwd(const void* dy_bf16, const void* x, const float* mean, const float* rstd,
+                      const float* gamma, void* dx, float* dgamma, float* dbeta, float* part, int64_t T,
+                      int C, int B, int H, int W, int ws, int shift, int x_dtype, void* stream);
 
 #ifdef __cplusplus
 }

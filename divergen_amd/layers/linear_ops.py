@@ -39,7 +39,7 @@ def shadow(p):
 def accumulate_grad(p, make_grad_fp32, gemm_into=None):
     """Write a gradient into p's arena view.  Returns None if done in place (and signals the
     data-parallel reducer), else the gradient tensor for autograd to accumulate."""
-    g = p.grad
+    g = p.grad if p.is_leaf else None
     if g is not None and g.dtype == torch.float32 and getattr(p, "_dgx16", None) is not None:
         if gemm_into is not None:
             gemm_into(g)

@@ -36,8 +36,8 @@ class _LayerNormBF16(torch.autograd.Function):
         dx = torch.empty_like(x)
         nblk = L.lib().dgx_layernorm_bwd_blocks(T)
         part = torch.empty(nblk * 2 * C, dtype=torch.float32, device=x.device)
-        in_arena = (weight.grad is not None and getattr(weight, "_dgx16", None) is not None
-                    and bias.grad is not None and getattr(bias, "_dgx16", None) is not None)
+        in_arena = (weight.is_leaf and bias.is_leaf and weight.grad is not None and bias.grad is not None
+                    and getattr(weight, "_dgx16", None) is not None and getattr(bias, "_dgx16", None) is not None)
         dg = weight.grad if in_arena else torch.zeros(C, dtype=torch.float32, device=x.device)
         db = bias.grad if in_arena else torch.zeros(C, dtype=torch.float32, device=x.device)
         L.check(L.lib().dgx_layernorm_bwd(L.ptr(dy), L.ptr(x), L.ptr(mean), L.ptr(rstd), L.ptr(weight), L.ptr(dx), L.ptr(dg),

@@ -58,7 +58,12 @@ class CustomRCNN(nn.Module):
         if key not in self._graphed:
             names = list(self.backbone.output_shape().keys())
             mod = _BackboneForGraph(self.backbone, names, self.fp16)
-            self._graphed[key] = (torch.cuda.make_graphed_callables(mod, (x.clone(),)), names)
+            self._graphed[key] = (torch.cuda.make_graphed_callables(mod, (x.clone(),), allow_unused_input=True), names)
+            # the capture warm-up ran real backward passes whose in-place weight-gradient writes landed
+            # in the arena; this step's backward has not started yet, so clearing them is exact
+            for p in self.backbone.parameters():
+                if p.grad is not None:
+                    p.grad.zero_()
         fn, names = self._graphed[key]
         return dict(zip(names, fn(x)))
 

@@ -78,7 +78,7 @@ def cpu_baseline(swin, budget_s=25.0):
     p = fill_state(swin_param_shapes(c["embed_dim"], c["depths"], c["num_heads"], c["ws"]), 7, 0.02)
     for v in p.values():
         v.requires_grad_(True)
-    size, t = 192, None
+    size, t = 256, None
     t_start = time.time()
     while True:
         img = torch.randn(1, 3, size, size)
@@ -93,7 +93,7 @@ def cpu_baseline(swin, budget_s=25.0):
     scale = (1024.0 / size) ** 2
     return {"value": 1.0 / (t * scale), "unit": "images/s (1024^2-equivalent, Swin backbone fwd+bwd only)",
             "cores": cores, "kind": "port",
-            "sample": "oracle/swin.py Swin-%s fwd+bwd, 1 image %dx%d, %.1f s, scaled x%.0f by pixel count" % (swin, size, size, t, scale)}
+            "sample": "oracle/swin.py Swin-%s fwd+bwd (fp32, %d threads), 1 image %dx%d in %.1f s, x%.0f pixel-count scaling to 1024^2" % (swin, cores, size, size, t, scale)}
 
 
 def main():

@@ -24,7 +24,7 @@ import torch.distributed as dist  # noqa: E402
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=8)
+    p.add_argument("--steps", type=int, default=12)
     p.add_argument("--warmup", type=int, default=3)
     p.add_argument("--size", type=int, default=1024)
     p.add_argument("--swin", default="L-22k-384")
@@ -183,6 +183,7 @@ def main():
         t0 = time.perf_counter()
         for _ in range(a.steps):
             total = one_step()
+        t_issue = time.perf_counter() - t0     # host time to ENQUEUE the steps (diagnostic: CPU- vs GPU-bound)
         sync()
         dt = time.perf_counter() - t0
     assert bool(torch.isfinite(total)), "non-finite loss"
@@ -227,7 +228,8 @@ def main():
                 "config": {"workload": "CenterNet2 Swin-%s, %dx%d, %d images/GPU, 1453 classes, GPU copy-paste + fwd + bwd + "
                                        "fused clip/AdamW/EMA; configs/DiverGen_swinL.yaml" % (a.swin, a.size, a.size, a.batch),
                            "global_batch": a.batch * world, "parallelism": "dp%d" % world, "params_M": nparams / 1e6},
-                "roofline": roof}
+                "roofline": roof,
+                "host_issue_ms_per_step": t_issue / a.steps * 1e3}
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a.swin)
         print(json.dumps(line))

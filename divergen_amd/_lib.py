@@ -39,6 +39,8 @@ SIGNATURES = {
     "dgx_layernorm_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "dgx_layernorm_bwd_blocks": (c_i, [c_i64]),
     "dgx_layernorm_bwd": (c_i, [c_p] * 9 + [c_i64, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "dgx_residual_fwd": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "dgx_residual_bwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "dgx_adamw_ema_step": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_f,
                                  c_p, c_p, c_i, c_p, c_p]),
 }

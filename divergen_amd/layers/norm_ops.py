@@ -59,3 +59,32 @@ def layernorm_bf16(x, weight, bias, eps=1e-5):
 def layernorm_window_gather(x, weight, bias, eps, B, H, W, ws, shift):
     """fp32 (B, H*W, C) -> LayerNorm -> zero-pad, roll(-shift), partition -> bf16 (B*nW, ws*ws, C)."""
     return _LayerNormBF16.apply(x, weight, bias, eps, B, H, W, ws, shift)
+
+
+class _ResidualAdd(torch.autograd.Function):
+    """out = x + scale[b] * y;  y bf16 in token order (ws == 0) or window order (ws > 0)."""
+
+    @staticmethod
+    def forward(ctx, x, y, scale, B, H, W, ws, shift):
+        x = x.contiguous()
+        y = y.contiguous()
+        C = x.shape[-1]
+        out = torch.empty_like(x)
+        L.check(L.lib().dgx_residual_fwd(L.ptr(x), L.ptr(y), L.ptr(scale), L.ptr(out), B, H, W, C, ws, shift,
+                                         L.dtype_code(x), L.stream()), "dgx_residual_fwd")
+        ctx.scale, ctx.cfg, ctx.yshape = scale, (B, H, W, C, ws, shift), y.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, H, W, C, ws, shift = ctx.cfg
+        g = g.contiguous()
+        dy = torch.empty(ctx.yshape, dtype=torch.bfloat16, device=g.device)
+        L.check(L.lib().dgx_residual_bwd(L.ptr(g), L.ptr(ctx.scale), L.ptr(dy), B, H, W, C, ws, shift, L.dtype_code(g),
+                                         L.stream()), "dgx_residual_bwd")
+        return g, dy, None, None, None, None, None, None
+
+
+def residual_add(x, y, scale, B, H, W, ws=0, shift=0):
+    """x (B, H*W, C) fp32|bf16, y bf16 ((B, H*W, C) or windows (B*nW, ws*ws, C)), scale (B,) f32 or None."""
+    return _ResidualAdd.apply(x, y, scale, B, H, W, ws, shift)

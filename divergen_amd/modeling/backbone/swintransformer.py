@@ -20,7 +20,7 @@ import torch.nn.functional as F
 from .. import BACKBONE_REGISTRY, ShapeSpec
 from ...layers.conv_ops import patch_embed4x4
 from ...layers.linear_ops import Linear
-from ...layers.norm_ops import layernorm_bf16, layernorm_window_gather
+from ...layers.norm_ops import layernorm_bf16, layernorm_window_gather, residual_add
 from ...layers import shift_regions, window_attention_core, window_gather, window_scatter
 
 
@@ -106,10 +106,26 @@ class SwinTransformerBlock(nn.Module):
             xw = window_gather(self.norm1(x), H, W, ws, sh)
         nW = (-(-H // ws)) * (-(-W // ws))
         aw = self.attn(xw, region if sh > 0 else None, nW)
+        if fused and C % 8 == 0:
+            # window_reverse + roll + crop + DropPath + residual add: one pass each
+            s1, s2 = self._drop_scales(B, x.device)
+            x = residual_add(x, aw, s1, B, H, W, ws, sh)
+            h2 = layernorm_bf16(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+            return residual_add(x, self.mlp(h2), s2, B, H, W)
         a = window_scatter(aw, B, H, W, ws, sh)
         x = x + self.drop_path(a)
         h2 = layernorm_bf16(x, self.norm2.weight, self.norm2.bias, self.norm2.eps) if fused else self.norm2(x)
         return x + self.drop_path(self.mlp(h2))
+
+    def _drop_scales(self, B, device):
+        """Per-sample DropPath factors floor(keep + U)/keep for the attention and MLP branches of this
+        block (timm drop_path semantics; call sites swintransformer.py:254-255), one RNG draw for both."""
+        p = self.drop_path.drop_prob if isinstance(self.drop_path, DropPath) else 0.0
+        if p == 0.0 or not self.training:
+            return None, None
+        keep = 1.0 - p
+        s = torch.floor(keep + torch.rand(2, B, device=device, dtype=torch.float32)) / keep
+        return s[0], s[1]
 
 
 class PatchMerging(nn.Module):

@@ -209,6 +209,17 @@ int dgx_layernorm_bwd(const void* dy_bf16, const void* x, const float* mean, con
                       const float* gamma, void* dx, float* dgamma, float* dbeta, float* part, int64_t T,
                       int C, int B, int H, int W, int ws, int shift, int x_dtype, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Residual + DropPath epilogue of a Swin block: out = x + scale[b] * y, y bf16 in token order (ws == 0)
+ * or in window order (ws > 0: window_reverse + roll(+shift) + crop folded into the read).  Replaces
+ * swintransformer.py:239-255 (window_reverse, roll, crop, drop_path, add).  x/out dtype f32|bf16;
+ * scale f32 (B) or NULL (= 1).  Backward: dy (bf16, same order as y incl. zero padding rows) =
+ * scale[b] * g;  the gradient w.r.t. x is g itself (no kernel).  C % 8 == 0. */
+int dgx_residual_fwd(const void* x, const void* y_bf16, const float* scale, void* out, int B, int H, int W,
+                     int C, int ws, int shift, int x_dtype, void* stream);
+int dgx_residual_bwd(const void* g, const float* scale, void* dy_bf16, int B, int H, int W, int C, int ws,
+                     int shift, int g_dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -353,3 +353,37 @@ def test_fused_layernorm_fwd_bwd(B, H, W, C, ws, shift, xdt):
         torch.testing.assert_close(xd.grad.float().cpu(), xr.grad, atol=3e-2, rtol=1e-2)
     torch.testing.assert_close(gd.grad.cpu(), gr.grad, atol=2e-3, rtol=1e-3)
     torch.testing.assert_close(bd.grad.cpu(), br.grad, atol=2e-3, rtol=1e-3)
+
+
+@pytest.mark.parametrize("xdt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,H,W,C,ws,shift", [(2, 10, 13, 192, 7, 3), (1, 14, 25, 64, 12, 6), (3, 9, 9, 128, 0, 0), (2, 12, 12, 96 * 2, 12, 0)])
+def test_residual_droppath_scatter(B, H, W, C, ws, shift, xdt):
+    from divergen_amd.layers.norm_ops import residual_add
+    g = torch.Generator().manual_seed(81)
+    x = torch.randn(B, H * W, C, generator=g).to(xdt)
+    nW = (-(-H // ws)) * (-(-W // ws)) if ws else 0
+    y = bf(torch.randn((B * nW, ws * ws, C) if ws else (B, H * W, C), generator=g))
+    scale = torch.tensor([0.0, 1.0 / 0.7, 1.0 / 0.7][:B])
+    if ws:
+        Hp, Wp = -(-H // ws) * ws, -(-W // ws) * ws
+        yt = OSW.unpartition(y.float(), ws, Hp, Wp)
+        if shift:
+            yt = torch.roll(yt, (shift, shift), (1, 2))
+        yt = yt[:, :H, :W].reshape(B, H * W, C)
+    else:
+        yt = y.float()
+    ref = (x.float() + scale[:, None, None] * yt)
+    xd, yd = x.to(DEV).requires_grad_(True), y.to(DEV).requires_grad_(True)
+    out = residual_add(xd, yd, scale.to(DEV), B, H, W, ws, shift)
+    tol = dict(atol=1e-6, rtol=1e-6) if xdt == torch.float32 else dict(atol=3e-2, rtol=1e-2)
+    torch.testing.assert_close(out.float().cpu(), ref, **tol)
+    go = torch.randn(B, H * W, C, generator=g).to(xdt)
+    out.backward(go.to(DEV))
+    assert torch.equal(xd.grad.cpu(), go)
+    gs = scale[:, None, None] * go.float()
+    if ws:
+        gp = torch.nn.functional.pad(gs.reshape(B, H, W, C), (0, 0, 0, Wp - W, 0, Hp - H))
+        if shift:
+            gp = torch.roll(gp, (-shift, -shift), (1, 2))
+        gs = OSW.partition(gp, ws)
+    torch.testing.assert_close(yd.grad.float().cpu(), bf(gs).float(), atol=1e-2, rtol=1e-2)

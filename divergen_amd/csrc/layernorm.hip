@@ -172,22 +172,31 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const uint16_t* __restrict_
     }
 }
 
-// dgamma += sum_blocks part[b][0], dbeta += sum_blocks part[b][1]; block = 64 columns x 4 row groups
-__global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* __restrict__ part, float* __restrict__ dgamma,
-                                                              float* __restrict__ dbeta, int nblk, int C) {
-    __shared__ float red[4][64];
-    const int col2 = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
-    float s = 0.f;
-    if (col2 < 2 * C) {
-        const int which = col2 / C, col = col2 - which * C;
-        for (int b = rg; b < nblk; b += 4) s += part[((int64_t)b * 2 + which) * C + col];
+// dgamma += sum_blocks part[b][0], dbeta += sum_blocks part[b][1].
+// block = 64 float4 column-quads x 16 row groups (1024 threads): 1 KiB contiguous per row read
+__global__ __launch_bounds__(1024) void ln_param_reduce_kernel(const float* __restrict__ part, float* __restrict__ dgamma,
+                                                               float* __restrict__ dbeta, int nblk, int C) {
+    __shared__ float4 red[16][64];
+    const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int q = blockIdx.x * 64 + lane;          // float4 index inside the 2*C-wide partial row
+    const int nq = 2 * C / 4;
+    float4 s = {0.f, 0.f, 0.f, 0.f};
+    if (q < nq) {
+        const float4* p4 = reinterpret_cast<const float4*>(part);
+#pragma unroll 4
+        for (int b = rg; b < nblk; b += 16) {
+            const float4 v = p4[(int64_t)b * nq + q];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
     }
-    red[rg][threadIdx.x & 63] = s;
+    red[rg][lane] = s;
     __syncthreads();
-    if (rg == 0 && col2 < 2 * C) {
-        const int which = col2 / C, col = col2 - which * C;
-        float* dst = which ? dbeta : dgamma;
-        dst[col] += (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (rg == 0 && q < nq) {
+        float4 a = red[0][lane];
+        for (int r = 1; r < 16; ++r) { const float4 v = red[r][lane]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+        // the partial row is [dgamma(C) | dbeta(C)]; C % 4 == 0 so a quad never straddles the two
+        float* dst = (4 * q < C) ? dgamma + 4 * q : dbeta + (4 * q - C);
+        dst[0] += a.x; dst[1] += a.y; dst[2] += a.z; dst[3] += a.w;
     }
 }
 
@@ -246,7 +255,7 @@ extern "C" int dgx_layernorm_bwd(const void* dy_bf16, const void* x, const float
     else if (nj <= 3) LN_BWD(3);
     else LN_BWD(6);
 #undef LN_BWD
-    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * C + 63) / 64), dim3(256), 0, st, part, dgamma, dbeta, grid, C);
+    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * C / 4 + 63) / 64), dim3(1024), 0, st, part, dgamma, dbeta, grid, C);
     DGX_LAUNCH_CHECK();
     return DGX_OK;
 }

@@ -102,4 +102,6 @@ class Linear(nn.Linear):
     """nn.Linear parameters (checkpoint-compatible); bf16 GEMMs over the arena shadow."""
 
     def forward(self, x):
+        if x.dtype == torch.float32 and not torch.is_autocast_enabled():
+            return torch.nn.functional.linear(x, self.weight, self.bias)   # fp32 parity mode (cfg.FP16 off)
         return linear(x, self.weight, self.bias)

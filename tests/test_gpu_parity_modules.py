@@ -1,0 +1,205 @@
+"""GPU parity of the host-mirror MODULES (built on libdgx) against golden outputs of the reference's
+own source files (tests/golden/*.npz) and the CPU oracle.  fp32 paths: tight tolerances; bf16
+autocast paths: tolerance stated relative to the tensor scale."""
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+from oracle import heads as OH  # noqa: E402
+from oracle import roi as OR  # noqa: E402
+from tests._recipes import fill_state, swin_param_shapes  # noqa: E402
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def rel_close(a, b, frac):
+    err = float((a - b).abs().max())
+    scale = float(b.abs().max())
+    assert err <= frac * scale, (err, scale)
+
+
+def test_swin_backbone_vs_reference_golden(golden):
+    """Whole SwinTransformer (reference golden, fp32) vs the HIP-backed module under bf16 autocast."""
+    from divergen_amd.modeling.backbone.swintransformer import SwinTransformer
+    g = golden("swin_full")
+    net = SwinTransformer(embed_dim=32, depths=[2, 2, 2, 2], num_heads=[1, 2, 4, 8], window_size=7,
+                          drop_path_rate=0.0, out_indices=(1, 2, 3))
+    p = fill_state(swin_param_shapes(32, [2, 2, 2, 2], [1, 2, 4, 8], 7), int(g["param_seed"]), float(g["param_scale"]))
+    missing, unexpected = net.load_state_dict(p, strict=False)
+    assert not unexpected and all("relative_position_index" in m for m in missing)
+    net = net.to(DEV).train()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        outs = net(T(g["img"]).to(DEV))
+    for k in ("swin1", "swin2", "swin3"):
+        rel_close(outs[k].float().cpu(), T(g[k]), 0.04)      # 8 blocks of bf16 GEMMs + bf16 residual stream
+    # fp32 (no autocast) path: only the attention core runs in bf16
+    outs32 = net(T(g["img"]).to(DEV))
+    for k in ("swin1", "swin2", "swin3"):
+        rel_close(outs32[k].float().cpu(), T(g[k]), 0.02)
+
+
+@pytest.mark.parametrize("ws", [7, 12])
+def test_basic_layer_vs_reference_golden(golden, ws):
+    from divergen_amd.modeling.backbone.swintransformer import BasicLayer, PatchMerging
+    g = golden("swin_layer_w%d" % ws)
+    layer = BasicLayer(dim=64, depth=2, num_heads=2, window_size=ws, drop_path=0.0, downsample=PatchMerging)
+    sd = {k[2:]: T(g[k]) for k in g.files if k.startswith("p.")}
+    layer.load_state_dict(sd, strict=False)
+    layer = layer.to(DEV).train()
+    H, W = int(g["H"]), int(g["W"])
+    x = T(g["x"]).to(DEV).requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        x_out, _, _, x_down, wh, ww = layer(x, H, W)
+    assert (wh, ww) == (int(g["Wh"]), int(g["Ww"]))
+    rel_close(x_out.float().cpu(), T(g["x_out"]), 0.03)
+    rel_close(x_down.float().cpu(), T(g["x_down"]), 0.03)
+    ((x_out.float() * T(g["g1"]).to(DEV)).sum() + (x_down.float() * T(g["g2"]).to(DEV)).sum()).backward()
+    rel_close(x.grad.float().cpu(), T(g["dx"]), 0.05)
+    gq = dict(layer.named_parameters())["blocks.1.attn.qkv.weight"].grad
+    rel_close(gq.float().cpu(), T(g["g.blocks.1.attn.qkv.weight"]), 0.05)
+    gt = dict(layer.named_parameters())["blocks.1.attn.relative_position_bias_table"].grad
+    rel_close(gt.float().cpu(), T(g["g.blocks.1.attn.relative_position_bias_table"]), 0.06)
+
+
+def test_fpn_and_centernet_head_fp32_vs_reference_golden(golden):
+    from divergen_amd.modeling import ShapeSpec
+    from divergen_amd.modeling.backbone.fpn import FPN, LastLevelP6P7_P5
+    from divergen_amd.modeling.backbone.swintransformer import Backbone
+    from divergen_amd.modeling.dense_heads.centernet_head import CenterNetHead
+
+    class Dummy(Backbone):
+        _out_features = ["swin1", "swin2", "swin3"]
+        _out_feature_channels = {"swin1": 8, "swin2": 16, "swin3": 32}
+        _out_feature_strides = {"swin1": 8, "swin2": 16, "swin3": 32}
+
+        def forward(self, x):
+            return x
+
+    g = golden("fpn")
+    fpn = FPN(Dummy(), ["swin1", "swin2", "swin3"], 16, top_block=LastLevelP6P7_P5(16, 16))
+    fpn.load_state_dict({k[2:]: T(g[k]) for k in g.files if k.startswith("p.")})
+    fpn = fpn.to(DEV)
+    out = fpn({k[3:]: T(g[k]).to(DEV) for k in g.files if k.startswith("in.")})
+    for k in ("p3", "p4", "p5", "p6", "p7"):
+        torch.testing.assert_close(out[k].cpu(), T(g["out." + k]), atol=2e-4, rtol=1e-4)   # fp32 GEMM order
+    g = golden("centernet_head")
+    head = CenterNetHead(in_channels=32, num_levels=2, num_classes=5, with_agn_hm=True, only_proposal=True)
+    head.load_state_dict({k[2:]: T(g[k]) for k in g.files if k.startswith("p.")})
+    head = head.to(DEV)
+    _, regs, hms = head([T(g["x0"]).to(DEV), T(g["x1"]).to(DEV)])
+    for i in range(2):
+        torch.testing.assert_close(regs[i].cpu(), T(g["reg%d" % i]), atol=2e-4, rtol=1e-4)
+        torch.testing.assert_close(hms[i].cpu(), T(g["hm%d" % i]), atol=2e-4, rtol=1e-4)
+
+
+def test_centernet_targets_and_losses_vs_reference_golden(golden):
+    from divergen_amd.modeling.dense_heads.centernet import CenterNet
+    from divergen_amd.structures import Boxes, Instances
+    from divergen_amd.utils.events import EventStorage
+    g = golden("centernet_targets")
+    net = CenterNet(in_channels=16, num_classes=7, with_agn_hm=True, only_proposal=True, score_thresh=0.0001,
+                    reg_weight=1.0, not_norm_reg=True, pos_weight=0.5, neg_weight=0.5, ignore_high_fp=0.85,
+                    centernet_head=torch.nn.Identity()).to(DEV).train()
+    H, W, st = int(g["H"]), int(g["W"]), [int(s) for s in g["strides"]]
+    shapes = [(-(-H // s), -(-W // s)) for s in st]
+    gts = []
+    for k in ("gt2a_boxes", "gt2b_boxes"):
+        inst = Instances((H, W))
+        inst.gt_boxes = Boxes(T(g[k]).to(DEV))
+        gts.append(inst)
+    pos, reg, hm = net._get_ground_truth(shapes, gts)
+    assert torch.equal(pos.cpu(), T(g["pos2"]))                      # index tensor: bit-exact
+    assert torch.equal(reg.cpu(), T(g["reg2"]))
+    torch.testing.assert_close(hm.cpu(), T(g["hm2"]), atol=1e-6, rtol=1e-5)
+    rp = T(g["reg_pred"]).to(DEV).requires_grad_(True)
+    al = T(g["agn_logit"]).to(DEV).requires_grad_(True)
+    with EventStorage(0):
+        losses = net.losses(pos, reg, hm, rp, al)
+    # reference: fp32 losses within 1e-3 (north_star); here ~1e-6
+    torch.testing.assert_close(losses["loss_centernet_loc"].cpu(), T(g["loss_loc"]), atol=1e-5, rtol=1e-5)
+    torch.testing.assert_close(losses["loss_centernet_agn_pos"].cpu(), T(g["loss_pos"]), atol=1e-5, rtol=1e-5)
+    torch.testing.assert_close(losses["loss_centernet_agn_neg"].cpu(), T(g["loss_neg"]), atol=1e-5, rtol=1e-5)
+    sum(losses.values()).backward()
+    torch.testing.assert_close(rp.grad.cpu(), T(g["d_reg_pred"]), atol=1e-6, rtol=1e-4)
+    torch.testing.assert_close(al.grad.cpu(), T(g["d_agn_logit"]), atol=1e-6, rtol=1e-4)
+
+
+def test_detic_losses_vs_reference_golden(golden, monkeypatch):
+    import divergen_amd.modeling.roi_heads.detic_fast_rcnn as M
+    from divergen_amd.modeling.box_regression import Box2BoxTransform
+    g = golden("roi_losses")
+    appeared = T(g["appeared"]).to(DEV)
+    monkeypatch.setattr(M, "get_fed_loss_inds", lambda *a, **k: appeared)   # RNG-drawn class set from the golden
+    fake = types.SimpleNamespace(use_fed_loss=True, freq_weight=T(g["freq"]).to(DEV), fed_loss_num_cat=10,
+                                 ignore_zero_cats=False, num_classes=40, smooth_l1_beta=0.0,
+                                 box2box_transform=Box2BoxTransform(tuple(g["weights"].tolist())))
+    logits = T(g["logits"]).to(DEV).requires_grad_(True)
+    gtc = T(g["gt_classes"]).to(DEV)
+    l = M.DeticFastRCNNOutputLayers.sigmoid_cross_entropy_loss(fake, logits, gtc)
+    torch.testing.assert_close(l.cpu(), T(g["loss_cls"]), atol=1e-5, rtol=1e-5)
+    l.backward()
+    torch.testing.assert_close(logits.grad.cpu(), T(g["d_logits"]), atol=1e-7, rtol=1e-4)
+    pd = T(g["pred_deltas"]).to(DEV).requires_grad_(True)
+    lb = M.DeticFastRCNNOutputLayers.box_reg_loss(fake, T(g["prop_boxes"]).to(DEV), T(g["gt_boxes"]).to(DEV), pd, gtc)
+    torch.testing.assert_close(lb.cpu(), T(g["loss_box"]), atol=1e-5, rtol=1e-5)
+
+
+def test_mask_loss_vs_oracle():
+    from divergen_amd.modeling.roi_heads.mask_head import mask_rcnn_loss
+    from divergen_amd.structures import BitMasks, Boxes, Instances
+    from divergen_amd.utils.events import EventStorage
+    g = torch.Generator().manual_seed(91)
+    H, W = 120, 160
+    yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    insts, masks_l, boxes_l = [], [], []
+    for n in (5, 3):
+        m = torch.zeros(n, H, W, dtype=torch.bool)
+        for i in range(n):
+            cx, cy = torch.rand(2, generator=g) * torch.tensor([W, H])
+            m[i] = ((xx - cx) / 30) ** 2 + ((yy - cy) / 20) ** 2 <= 1
+        xy = torch.rand(n, 2, generator=g) * 80
+        b = torch.cat([xy, xy + torch.rand(n, 2, generator=g) * 60 + 4], 1)
+        inst = Instances((H, W))
+        inst.proposal_boxes, inst.gt_masks = Boxes(b.to(DEV)), BitMasks(m.to(DEV))
+        insts.append(inst)
+        masks_l.append(m)
+        boxes_l.append(b)
+    logits = torch.randn(8, 1, 28, 28, generator=g)
+    ref = OH.mask_loss(logits, masks_l, boxes_l)
+    with EventStorage(0):
+        got = mask_rcnn_loss(logits.to(DEV), insts)
+    torch.testing.assert_close(got.cpu(), ref, atol=1e-6, rtol=1e-5)   # identical bool targets -> identical BCE
+
+
+def test_fused_optimizer_trajectory_vs_reference_golden(golden):
+    """12 steps of AdamW + value clip + EMA + WarmupCosineLR on the golden's tiny net (reference:
+    torch.optim.AdamW + clip_grad_value_ + ModelEma + D2 WarmupCosineLR)."""
+    from divergen_amd.solver import FlatArena, FusedAdamWEMA, WarmupCosineLR
+    g = golden("solver")
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.LayerNorm(5), torch.nn.Linear(5, 3))
+    net.load_state_dict({k[5:]: T(g[k]) for k in g.files if k.startswith("init.")})
+    net = net.to(DEV)
+    arena = FlatArena(net)
+    opt = FusedAdamWEMA(arena, 1e-2, weight_decay=1e-4, clip_value=1.0, ema_decay=0.999)
+    sched = WarmupCosineLR(opt, 100, warmup_factor=1e-4, warmup_iters=10)
+    x = T(g["x"]).to(DEV)
+    for it in range(12):
+        assert abs(opt.param_groups[0]["lr"] - float(g["lrs"][it])) < 1e-12
+        opt.zero_grad()
+        ((net(x) ** 2).sum() * 30).backward()
+        opt.step()
+        sched.step()
+    sd = net.state_dict()
+    ema = opt.ema_state_dict(net)
+    for k in sd:
+        torch.testing.assert_close(sd[k].cpu(), T(g["final." + k]), atol=2e-6, rtol=2e-5)
+        torch.testing.assert_close(ema[k].cpu(), T(g["ema." + k]), atol=1e-6, rtol=1e-5)

@@ -1,0 +1,132 @@
+"""Checkpoint / resume.  Surface of D2/checkpoint/detection_checkpoint.py:15-120 + fvcore Checkpointer
+as DG/train_net.py:139-152,304 uses it: files model_XXXXXXX.pth / model_final.pth / last_checkpoint,
+contents {model, optimizer, scheduler, model_ema, iteration}; rank 0 writes; .pkl weights in D2 format
+(dict with 'model' of numpy arrays) load with exact-then-longest-suffix key matching (the name-matching
+heuristic of D2/checkpoint/c2_model_loading.py:209-335, reduced to what Swin/R50 pkls need)."""
+import logging
+import os
+import pickle
+
+import numpy as np
+import torch
+
+from ..utils import comm
+
+
+def _match_keys(model_keys, ckpt_keys):
+    """Map checkpoint keys to model keys: exact match first, else the model key that has the checkpoint
+    key as its longest '.'-aligned suffix (e.g. 'layers.0...' -> 'backbone.bottom_up.layers.0...')."""
+    mapping, used = {}, set()
+    mk = set(model_keys)
+    for ck in ckpt_keys:
+        if ck in mk:
+            mapping[ck] = ck
+            used.add(ck)
+    for ck in ckpt_keys:
+        if ck in mapping:
+            continue
+        best = None
+        for k in model_keys:
+            if k in used:
+                continue
+            if k.endswith("." + ck) or k == ck:
+                if best is None or len(k) < len(best):
+                    best = k
+        if best is not None:
+            mapping[ck] = best
+            used.add(best)
+    return mapping
+
+
+class DetectionCheckpointer:
+    def __init__(self, model, save_dir="", *, save_to_disk=None, **checkpointables):
+        self.model, self.save_dir = model, save_dir
+        self.checkpointables = dict(checkpointables)
+        self.save_to_disk = comm.is_main_process() if save_to_disk is None else save_to_disk
+        self.logger = logging.getLogger("divergen_amd")
+
+    # ---- save
+    def save(self, name, **kwargs):
+        if not self.save_dir or not self.save_to_disk:
+            return
+        data = {"model": self.model.state_dict()}
+        for k, obj in self.checkpointables.items():
+            data[k] = obj.state_dict()
+        data.update(kwargs)
+        os.makedirs(self.save_dir, exist_ok=True)
+        basename = "{}.pth".format(name)
+        path = os.path.join(self.save_dir, basename)
+        torch.save(data, path)
+        with open(os.path.join(self.save_dir, "last_checkpoint"), "w") as f:
+            f.write(basename)
+        self.logger.info("Saved checkpoint to %s", path)
+
+    # ---- load
+    def has_checkpoint(self):
+        return os.path.exists(os.path.join(self.save_dir, "last_checkpoint"))
+
+    def get_checkpoint_file(self):
+        with open(os.path.join(self.save_dir, "last_checkpoint")) as f:
+            return os.path.join(self.save_dir, f.read().strip())
+
+    def resume_or_load(self, path, *, resume=True):
+        if resume and self.has_checkpoint():
+            return self.load(self.get_checkpoint_file())
+        return self.load(path, checkpointables=[])
+
+    def _load_file(self, filename):
+        if filename.endswith(".pkl"):
+            with open(filename, "rb") as f:
+                data = pickle.load(f, encoding="latin1")
+            if "model" in data and "__author__" in data:
+                return data
+            if "blobs" in data:
+                data = data["blobs"]
+            data = {k: v for k, v in data.items() if not k.endswith("_momentum")}
+            return {"model": data, "__author__": "Caffe2", "matching_heuristics": True}
+        loaded = torch.load(filename, map_location="cpu", weights_only=False)
+        if "model" not in loaded:
+            loaded = {"model": loaded}
+        return loaded
+
+    def load(self, path, checkpointables=None):
+        if not path:
+            self.logger.info("No checkpoint found. Initializing model from scratch")
+            return {}
+        if not os.path.isfile(path):
+            raise FileNotFoundError("Checkpoint {} not found!".format(path))
+        ckpt = self._load_file(path)
+        sd = ckpt.pop("model")
+        sd = {k[7:] if k.startswith("module.") else k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v)
+              for k, v in sd.items()}
+        model_sd = self.model.state_dict()
+        mapping = _match_keys(list(model_sd.keys()), list(sd.keys()))
+        new_sd, skipped = {}, []
+        for ck, mk in mapping.items():
+            if tuple(model_sd[mk].shape) == tuple(sd[ck].shape):
+                new_sd[mk] = sd[ck]
+            else:
+                skipped.append((ck, tuple(sd[ck].shape), tuple(model_sd[mk].shape)))
+        incompatible = self.model.load_state_dict(new_sd, strict=False)
+        for ck, a, b in skipped:
+            self.logger.warning("Skip loading parameter '%s': checkpoint shape %s vs model shape %s", ck, a, b)
+        if incompatible.missing_keys:
+            self.logger.info("Keys not found in the checkpoint: %d", len(incompatible.missing_keys))
+        for k in (self.checkpointables if checkpointables is None else checkpointables):
+            if k in ckpt:
+                self.checkpointables[k].load_state_dict(ckpt.pop(k))
+        return ckpt
+
+
+class PeriodicCheckpointer:
+    def __init__(self, checkpointer, period, max_iter=None):
+        self.checkpointer, self.period, self.max_iter = checkpointer, int(period), max_iter
+
+    def step(self, iteration, **kwargs):
+        iteration = int(iteration)
+        extra = {"iteration": iteration}
+        extra.update(kwargs)
+        if (iteration + 1) % self.period == 0:
+            self.checkpointer.save("model_{:07d}".format(iteration), **extra)
+        if self.max_iter is not None and iteration >= self.max_iter - 1:
+            self.checkpointer.save("model_final", **extra)

@@ -1,1 +1,2 @@
 from .synthetic import synthetic_batch  # noqa
+from .samplers import InferenceSampler, RepeatFactorTrainingSampler, TrainingSampler  # noqa

@@ -1,0 +1,151 @@
+"""DiverGen copy-paste data path with the GPU compositor.
+
+Host-side mirror of InstPool (DG/divergen/data/custom_build_copypaste_mapper.py:94-566) for the shipped
+configuration (INST_POOL_FORMAT 'RGBA', INST_POOL_SAMPLE_TYPE 'cas_random', CP_METHOD ['basic'],
+USE_COPY_METHOD 'syn_copy'): class-balanced sampling of generated instances, size prior (Gaussian
+relative-area prior for LVIS classes with statistics, U(RANDOM_SCALE_MIN, MAX) of the source size for
+the rest), random placement -- all numpy/PIL on the CPU worker, with the same np.random call order --
+and ONE call into libdgx (dgx_copy_paste) for the pixels: image blend, mask occlusion updates, box
+recomputation and the occlusion filter of `_copy_paste`, for all pastes of the image at once."""
+import json
+import os
+from collections import defaultdict
+
+import numpy as np
+import torch
+
+from ..layers import copy_paste
+from ..structures import BitMasks, Boxes, Instances
+
+
+def largest_connected_component(mask):
+    """Role of get_largest_connect_component (mapper.py:25-36, cv2 contours): keep the largest blob."""
+    from scipy import ndimage
+    lab, n = ndimage.label(mask)
+    if n <= 1:
+        return mask
+    sizes = ndimage.sum(mask, lab, index=np.arange(1, n + 1))
+    return (lab == (1 + int(np.argmax(sizes)))).astype(mask.dtype)
+
+
+class InstPool:
+    def __init__(self, pool_json, train_size, area_stats_json=None, max_samples=20, random_scale=False,
+                 random_scale_min=0.1, random_scale_max=2.0, random_scale_min_size=5, use_largest_part=True,
+                 scale_min=10, scale_max=0.5, shape_jitter=0.2, mask_threshold=128,
+                 instance_filter_min=0.01, instance_filter_max=1.0, loader=None):
+        pool = json.load(open(pool_json)) if isinstance(pool_json, str) else pool_json
+        self.per_cat_pool = defaultdict(list)
+        self.dataset, self.data_to_cat = [], {}
+        for cat, paths in pool.items():
+            for p in paths:
+                self.per_cat_pool[int(cat)].append(len(self.dataset))
+                self.data_to_cat[p] = int(cat) - 1      # pool json keys are 1-based category ids
+                self.dataset.append(p)
+        self.cats = list(self.per_cat_pool.keys())
+        self.HWms = json.load(open(area_stats_json)) if area_stats_json and os.path.exists(area_stats_json) else {}
+        self.train_size, self.max_samples = train_size, max_samples
+        self.random_scale, self.rs_min, self.rs_max, self.rs_min_size = random_scale, random_scale_min, random_scale_max, random_scale_min_size
+        self.use_largest_part, self.scale_min, self.scale_max = use_largest_part, scale_min, scale_max
+        self.shape_jitter, self.mask_threshold = shape_jitter, mask_threshold
+        self.filter_min, self.filter_max = instance_filter_min, instance_filter_max
+        self.loader = loader or self._pil_loader
+
+    @staticmethod
+    def _pil_loader(path):
+        from PIL import Image
+        mask_path = None
+        if path.startswith("*"):
+            path = path[1:]
+        elif "|" in path:
+            path, mask_path = path.split("|")[:2]
+        rgba = np.array(Image.open(path).convert("RGBA"))
+        if mask_path is not None:
+            rgba[:, :, -1] = np.array(Image.open(mask_path))
+        return rgba
+
+    def sample_ids(self, nums):
+        """_get_cls_balanced_random_samples (mapper.py:263-296): class first, then instance in class."""
+        cats_pool = [self.per_cat_pool[c] for c in self.per_cat_pool if len(self.per_cat_pool[c]) > 0]
+        ids = []
+        if not cats_pool:
+            return ids
+        for _ in range(nums):
+            cid = np.random.randint(0, len(cats_pool))
+            ids.append(cats_pool[cid][np.random.randint(0, len(cats_pool[cid]))])
+        return ids
+
+    def load_rgba(self, key, image_hw):
+        """_load_RGBA (mapper.py:359-456): returns (rgba (h,w,4) uint8, label) or None when rejected."""
+        from PIL import Image
+        H, W = image_hw
+        label = self.data_to_cat[key]
+        try:
+            rgba = self.loader(key)
+        except Exception:
+            return None
+        if self.random_scale or str(label + 1) not in self.HWms:
+            s = np.random.uniform(self.rs_min, self.rs_max)
+            tw, th = int(rgba.shape[1] * s), int(rgba.shape[0] * s)
+            if tw < self.rs_min_size or th < self.rs_min_size or tw >= W or th >= H:
+                return None
+        else:
+            mean, std = self.HWms[str(label + 1)][:2]
+            smin = self.scale_min / H if isinstance(self.scale_min, int) else self.scale_min
+            smax = self.scale_max / H if isinstance(self.scale_max, int) else self.scale_max
+            area = np.clip(mean + np.random.randn() * std, smin, smax)
+            if not key.startswith("*"):
+                seg = (rgba[..., 3:] > self.mask_threshold).astype("uint8")
+                if self.use_largest_part:
+                    seg = largest_connected_component(seg[..., 0])[..., None]
+                ys, xs = np.where(seg[..., 0])
+                frac = len(ys) / float(seg.shape[0] * seg.shape[1])
+                if frac <= self.filter_min or frac >= self.filter_max:
+                    return None
+                y0, y1, x0, x1 = ys.min(), ys.max(), xs.min(), xs.max()
+                if y1 <= y0 or x1 <= x0:
+                    return None
+                rgba[:, :, 3:] *= seg
+                rgba = rgba[y0:y1 + 1, x0:x1 + 1]
+            scale = area ** 2 * H * W
+            ratio = rgba.shape[1] / rgba.shape[0] * np.random.uniform(1 - self.shape_jitter, 1 + self.shape_jitter)
+            tw = np.sqrt(ratio * scale)
+            th = tw / ratio
+            tw, th = int(tw), int(th)
+            if tw < 5 or tw >= W or th < 5 or th >= H:
+                return None
+        rgba = np.array(Image.fromarray(rgba, "RGBA").resize((tw, th), Image.BILINEAR))   # cv2.resize role
+        if np.random.rand() < 0.5:                                                          # RandomFlip(horizontal)
+            rgba = np.ascontiguousarray(rgba[:, ::-1])
+        return rgba, label
+
+    @staticmethod
+    def random_start_xy(rgba, train_hw):
+        """random_start_xy (mapper.py:45-57): offsets so that the patch centre stays inside the canvas."""
+        h, w = rgba.shape[:2]
+        x_mid, y_mid = (0 + w) / 2.0, (0 + h) / 2.0
+        H, W = train_hw
+        return np.random.randint(-x_mid, W - x_mid), np.random.randint(-y_mid, H - y_mid)
+
+    def __call__(self, data):
+        """get_mix_result('cas_random') (mapper.py:213-261) on one mapped sample dict."""
+        image = data["image"]
+        inst = data["instances"]
+        H, W = image.shape[-2:]
+        num = np.random.randint(0, self.max_samples)
+        pastes = []
+        for key in [self.dataset[i] for i in self.sample_ids(num)]:
+            r = self.load_rgba(key, (H, W))
+            if r is None:
+                continue
+            rgba, label = r
+            x0, y0 = self.random_start_xy(rgba, (H, W))
+            pastes.append((rgba, int(x0), int(y0), int(label)))
+        dev = image.device if image.is_cuda else torch.device("cuda")
+        out = copy_paste(image.to(dev), inst.gt_masks.tensor.to(dev).view(torch.uint8), inst.gt_boxes.tensor.to(dev),
+                         inst.gt_classes.to(dev), pastes)
+        ni = Instances((H, W))
+        ni.gt_boxes, ni.gt_classes = Boxes(out["boxes"]), out["labels"]
+        ni.gt_masks, ni.instance_source = BitMasks(out["masks"]), out["source"]
+        data = dict(data)
+        data["image"], data["instances"], data["height"], data["width"] = out["image"], ni, H, W
+        return data

@@ -28,6 +28,31 @@ __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
+// LDS transpose read (gfx950 ds_read_b64_tr_b16).  Measured semantics (tools/probes/tr_probe.hip): within
+// each 16-lane group, lane p supplies the address of an 8-byte chunk (4 bf16); result lane i, element j is
+// element (i & 3) of the chunk supplied by lane 4*j + (i >> 2).  With lane p pointing at row (p >> 2),
+// columns 4*(p & 3).. of a row-major [4][16] block, lane i receives column i of that block (rows 0..3):
+// exactly the k-contiguous MFMA operand layout, from an image stored the way global memory has it.
+//   lds_byte_addr: byte address (LDS address space) of THIS lane's chunk.
+__device__ __forceinline__ uint2 ds_read_tr16_b64(uint32_t lds_byte_addr) {
+    uint2 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(lds_byte_addr) : "memory");
+    return v;
+}
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+// 8 k-slots (two 4-row blocks at rows r0 and r0+4... given explicitly) of column block c0..c0+15 of a
+// row-major bf16 LDS image with row stride `rsb` bytes; p = lane & 15.
+__device__ __forceinline__ bf16x8 ld_frag_tr(uint32_t img, int rsb, int rowA, int rowB, int c0, int p) {
+    const uint32_t off = (uint32_t)((p >> 2) * rsb + (c0 + 4 * (p & 3)) * 2);
+    const uint2 a = ds_read_tr16_b64(img + rowA * rsb + off);
+    const uint2 b = ds_read_tr16_b64(img + rowB * rsb + off);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    u32x4 v = {a.x, a.y, b.x, b.y};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
 #define DGX_LAUNCH_CHECK()                                 \
     do {                                                   \
         hipError_t e__ = hipGetLastError();                \

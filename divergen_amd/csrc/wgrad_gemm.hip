@@ -2,62 +2,50 @@
 // with A = dY and B = X both row-major bf16 and M (tokens) up to 131072 while Nn, Kk are a few
 // hundred to a few thousand.  The library GEMM runs this "TN, very long K" shape at 65-500 TF/s
 // (tools/wgrad_probe.py) because the small output gives it too few workgroups; here the M axis is
-// split across workgroups (split-K) and both operands are transposed on the way into LDS:
+// split across workgroups (split-K):
 //   tile 128(n) x 128(k) per workgroup, 4 waves x (4x4 MFMA 16x16x32 bf16 tiles), M-depth 64 per
-//   stage, double-buffered LDS images At[n][m], Bt[k][m] (row stride 72 -> conflict-free b128
-//   fragment reads), next stage prefetched into registers under the MFMAs; fp32 partial tiles go
-//   to a workspace and a second kernel folds the S slabs into the gradient arena (beta = 1).
+//   stage.  Both operands are stored in LDS exactly as they sit in memory ([m][n], 16-byte stores)
+//   and the k-contiguous MFMA fragments come out of ds_read_b64_tr_b16 transpose reads, so no
+//   transposing pass exists anywhere.  Double-buffered LDS, next stage prefetched into registers
+//   under the MFMAs; fp32 partial tiles go to a workspace and a second kernel folds the S slabs into
+//   the gradient arena (beta = 1).
 #include "dgx_common.h"
 
 namespace {
-constexpr int BT = 128;        // tile edge (both n and k)
-constexpr int BM = 64;         // m-depth per stage
-constexpr int RS = BM + 8;     // LDS row stride (elements)
+constexpr int BT = 128;            // tile edge (both n and k)
+constexpr int BM = 64;             // m-depth per stage
+constexpr int RSB = BT * 2 + 16;   // LDS row stride in bytes (+16: consecutive rows shift 4 banks)
 
-struct Stage { bf16x8 a[2][2], b[2][2]; };   // [pass][row of the pair]
+struct Stage { bf16x8 a[4], b[4]; };
 
-// LDS image [128 rows][RS]: 16-byte groups of a row are XOR-swizzled with (row>>3)&7 so that the
-// transposing stores (16 lanes = 16 rows 8 apart, same column) spread over banks (2-way instead of
-// 16-way) while fragment reads stay 16-byte aligned.
-__device__ __forceinline__ int lds_off(int row, int col) {
-    return row * RS + ((((col >> 3) ^ (row >> 3)) & 7) << 3) + (col & 7);
-}
-
-// thread (pair p = tid>>4 in 0..15, chunk c = tid&15): rows m0+2p(+32*pass), m0+2p+1, cols 8c..8c+7
+// thread t: rows r = (t >> 4) + 16*i (i = 0..3), 16-byte column chunk c = t & 15
 __device__ __forceinline__ void load_stage(Stage& st, const uint16_t* __restrict__ A, const uint16_t* __restrict__ B,
                                            int64_t lda, int64_t ldb, int m0, int M, int n0, int Nn, int k0, int Kk, int tid) {
-    const int p = tid >> 4, c = tid & 15;
+    const int r = tid >> 4, c = tid & 15;
     const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-    for (int ps = 0; ps < 2; ++ps)
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int m = m0 + 32 * ps + 2 * p + r;
-            const bool mok = m < M;
-            st.a[ps][r] = (mok && n0 + 8 * c < Nn) ? *reinterpret_cast<const bf16x8*>(A + (int64_t)m * lda + n0 + 8 * c) : z;
-            st.b[ps][r] = (mok && k0 + 8 * c < Kk) ? *reinterpret_cast<const bf16x8*>(B + (int64_t)m * ldb + k0 + 8 * c) : z;
-        }
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + r + 16 * i;
+        const bool mok = m < M;
+        st.a[i] = (mok && n0 + 8 * c < Nn) ? *reinterpret_cast<const bf16x8*>(A + (int64_t)m * lda + n0 + 8 * c) : z;
+        st.b[i] = (mok && k0 + 8 * c < Kk) ? *reinterpret_cast<const bf16x8*>(B + (int64_t)m * ldb + k0 + 8 * c) : z;
+    }
 }
 
-__device__ __forceinline__ void store_stage(const Stage& st, uint16_t* At, uint16_t* Bt, int tid) {
-    const int p = tid >> 4, c = tid & 15;
+__device__ __forceinline__ void store_stage(const Stage& st, unsigned char* Ai, unsigned char* Bi, int tid) {
+    const int r = tid >> 4, c = tid & 15;
 #pragma unroll
-    for (int ps = 0; ps < 2; ++ps)
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const uint32_t wa = (uint32_t)(uint16_t)st.a[ps][0][i] | ((uint32_t)(uint16_t)st.a[ps][1][i] << 16);
-            const uint32_t wb = (uint32_t)(uint16_t)st.b[ps][0][i] | ((uint32_t)(uint16_t)st.b[ps][1][i] << 16);
-            *reinterpret_cast<uint32_t*>(&At[lds_off(8 * c + i, 32 * ps + 2 * p)]) = wa;
-            *reinterpret_cast<uint32_t*>(&Bt[lds_off(8 * c + i, 32 * ps + 2 * p)]) = wb;
-        }
+    for (int i = 0; i < 4; ++i) {
+        *reinterpret_cast<bf16x8*>(Ai + (r + 16 * i) * RSB + 16 * c) = st.a[i];
+        *reinterpret_cast<bf16x8*>(Bi + (r + 16 * i) * RSB + 16 * c) = st.b[i];
+    }
 }
 }  // namespace
 
 __global__ __launch_bounds__(256) void wgrad_partial_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ B,
                                                             float* __restrict__ ws, int M, int Nn, int Kk, int64_t lda,
                                                             int64_t ldb, int tiles_k, int slab) {
-    extern __shared__ __attribute__((aligned(16))) uint16_t lds_raw[];     // [buf][A|B][BT*RS]
-    uint16_t (*lds)[2][BT * RS] = reinterpret_cast<uint16_t (*)[2][BT * RS]>(lds_raw);
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];   // [buf][A|B][BM*RSB]
     const int tile = blockIdx.x, s = blockIdx.y;
     const int n0 = (tile / tiles_k) * BT, k0 = (tile % tiles_k) * BT;
     const int m_begin = s * slab, m_end = min(M, m_begin + slab);
@@ -74,18 +62,38 @@ __global__ __launch_bounds__(256) void wgrad_partial_kernel(const uint16_t* __re
     int buf = 0;
     if (m_begin < m_end) load_stage(st, A, B, lda, ldb, m_begin, m_end, n0, Nn, k0, Kk, tid);
     for (int m0 = m_begin; m0 < m_end; m0 += BM) {
-        uint16_t* At = lds[buf][0];
-        uint16_t* Bt = lds[buf][1];
-        store_stage(st, At, Bt, tid);
+        unsigned char* Ai = lds_raw + (size_t)(2 * buf) * BM * RSB;
+        unsigned char* Bi = Ai + (size_t)BM * RSB;
+        store_stage(st, Ai, Bi, tid);
         __syncthreads();
         if (m0 + BM < m_end) load_stage(st, A, B, lda, ldb, m0 + BM, m_end, n0, Nn, k0, Kk, tid);
+        const uint32_t a_img = lds_addr(Ai), b_img = lds_addr(Bi);
 #pragma unroll
         for (int ks = 0; ks < BM / 32; ++ks) {
+            const int r0 = 32 * ks + 8 * g;     // this lane group's 8 k-slots = rows r0..r0+7 of the image
+            const uint32_t offA = (uint32_t)((r0 + (c16 >> 2)) * RSB + 8 * (c16 & 3));
+            uint2 ra[4][2], rb[4][2];
+            // issue all 16 transpose reads, then ONE wait (the asm ties the registers to the wait so no
+            // MFMA can be scheduled above it)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ra[i][0] = ds_read_tr16_b64(a_img + offA + (wn + 16 * i) * 2);
+                ra[i][1] = ds_read_tr16_b64(a_img + offA + 4 * RSB + (wn + 16 * i) * 2);
+                rb[i][0] = ds_read_tr16_b64(b_img + offA + (wk + 16 * i) * 2);
+                rb[i][1] = ds_read_tr16_b64(b_img + offA + 4 * RSB + (wk + 16 * i) * 2);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(ra[0][0]), "+v"(ra[0][1]), "+v"(ra[1][0]), "+v"(ra[1][1]), "+v"(ra[2][0]), "+v"(ra[2][1]),
+                           "+v"(ra[3][0]), "+v"(ra[3][1]));
+            asm volatile("" : "+v"(rb[0][0]), "+v"(rb[0][1]), "+v"(rb[1][0]), "+v"(rb[1][1]), "+v"(rb[2][0]), "+v"(rb[2][1]),
+                              "+v"(rb[3][0]), "+v"(rb[3][1]));
             bf16x8 af[4], bfr[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                af[i] = *reinterpret_cast<const bf16x8*>(&At[lds_off(wn + 16 * i + c16, 32 * ks + 8 * g)]);
-                bfr[i] = *reinterpret_cast<const bf16x8*>(&Bt[lds_off(wk + 16 * i + c16, 32 * ks + 8 * g)]);
+                u32x4 va = {ra[i][0].x, ra[i][0].y, ra[i][1].x, ra[i][1].y};
+                u32x4 vb = {rb[i][0].x, rb[i][0].y, rb[i][1].x, rb[i][1].y};
+                af[i] = __builtin_bit_cast(bf16x8, va);
+                bfr[i] = __builtin_bit_cast(bf16x8, vb);
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -147,7 +155,7 @@ extern "C" int dgx_linear_wgrad(const void* dy, const void* x, float* gw, int M,
     int slab = (M + S - 1) / S;
     slab = (slab + BM - 1) / BM * BM;
     hipStream_t st = (hipStream_t)stream;
-    const size_t sm = (size_t)4 * BT * RS * 2;
+    const size_t sm = (size_t)4 * BM * RSB;
     static bool once = false;
     if (!once) {
         (void)hipFuncSetAttribute((const void*)wgrad_partial_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);

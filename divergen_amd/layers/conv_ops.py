@@ -11,7 +11,7 @@ import torch
 import torch.nn.functional as F
 
 from .. import _lib as L
-from .linear_ops import accumulate_grad, linear, shadow
+from .linear_ops import accumulate_grad, linear, shadow, wgrad_into
 
 
 def _nhwc(x):
@@ -59,7 +59,8 @@ class _Conv3x3(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             def wgrad():
                 if col.dtype == torch.bfloat16:
-                    g = torch.mm(col.t(), g2, out_dtype=torch.float32)
+                    g = torch.empty(9 * C, g2.shape[1], dtype=torch.float32, device=col.device)
+                    wgrad_into(g, col, g2.contiguous(), beta=0.0)      # M-split MFMA kernel for long M
                 else:
                     g = (col.t() @ g2).float()
                 return g.view(3, 3, C, -1).permute(3, 2, 0, 1)
@@ -111,6 +112,8 @@ def patch_embed4x4(x, weight, bias, patch=4):
     B, Cin, H, W = x.shape
     Hp, Wp = H // patch, W // patch
     u = x.reshape(B, Cin, Hp, patch, Wp, patch).permute(0, 2, 4, 1, 3, 5).reshape(B, Hp * Wp, Cin * patch * patch)
+    if torch.is_autocast_enabled():
+        return linear(u, weight, bias), Hp, Wp          # arena path: (embed, 3,4,4) is a (embed, 48) Linear weight
     return F.linear(u, weight.reshape(weight.shape[0], -1), bias), Hp, Wp
 
 

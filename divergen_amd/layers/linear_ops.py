@@ -12,7 +12,8 @@ import torch.nn as nn
 from .. import _lib as L
 
 BF16 = torch.bfloat16
-WGRAD_MIN_M = 16384   # measured crossover vs the library GEMM (tools/wgrad_probe2.py): long-M shapes only
+import os
+WGRAD_MIN_M = int(os.environ.get("DGX_WGRAD_MIN_M", 16384))   # measured crossover vs the library GEMM (tools/wgrad_probe2.py): long-M shapes only
 
 
 def wgrad_into(g2, dy2, x2, beta=1.0):

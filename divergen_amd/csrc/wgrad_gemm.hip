@@ -67,33 +67,17 @@ __global__ __launch_bounds__(256) void wgrad_partial_kernel(const uint16_t* __re
         store_stage(st, Ai, Bi, tid);
         __syncthreads();
         if (m0 + BM < m_end) load_stage(st, A, B, lda, ldb, m0 + BM, m_end, n0, Nn, k0, Kk, tid);
-        const uint32_t a_img = lds_addr(Ai), b_img = lds_addr(Bi);
+        // this lane's chunk: row 8g + (c16 >> 2) of the 32-row k-step, 8-byte column chunk c16 & 3
+        DGX_LDS const uint16_t* a_l = lds_opaque(reinterpret_cast<const uint16_t*>(Ai + (8 * g + (c16 >> 2)) * RSB) + wn + 4 * (c16 & 3));
+        DGX_LDS const uint16_t* b_l = lds_opaque(reinterpret_cast<const uint16_t*>(Bi + (8 * g + (c16 >> 2)) * RSB) + wk + 4 * (c16 & 3));
 #pragma unroll
         for (int ks = 0; ks < BM / 32; ++ks) {
-            const int r0 = 32 * ks + 8 * g;     // this lane group's 8 k-slots = rows r0..r0+7 of the image
-            const uint32_t offA = (uint32_t)((r0 + (c16 >> 2)) * RSB + 8 * (c16 & 3));
-            uint2 ra[4][2], rb[4][2];
-            // issue all 16 transpose reads, then ONE wait (the asm ties the registers to the wait so no
-            // MFMA can be scheduled above it)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                ra[i][0] = ds_read_tr16_b64(a_img + offA + (wn + 16 * i) * 2);
-                ra[i][1] = ds_read_tr16_b64(a_img + offA + 4 * RSB + (wn + 16 * i) * 2);
-                rb[i][0] = ds_read_tr16_b64(b_img + offA + (wk + 16 * i) * 2);
-                rb[i][1] = ds_read_tr16_b64(b_img + offA + 4 * RSB + (wk + 16 * i) * 2);
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)"
-                         : "+v"(ra[0][0]), "+v"(ra[0][1]), "+v"(ra[1][0]), "+v"(ra[1][1]), "+v"(ra[2][0]), "+v"(ra[2][1]),
-                           "+v"(ra[3][0]), "+v"(ra[3][1]));
-            asm volatile("" : "+v"(rb[0][0]), "+v"(rb[0][1]), "+v"(rb[1][0]), "+v"(rb[1][1]), "+v"(rb[2][0]), "+v"(rb[2][1]),
-                              "+v"(rb[3][0]), "+v"(rb[3][1]));
+            constexpr int RSE = RSB / 2;   // row stride in elements
             bf16x8 af[4], bfr[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                u32x4 va = {ra[i][0].x, ra[i][0].y, ra[i][1].x, ra[i][1].y};
-                u32x4 vb = {rb[i][0].x, rb[i][0].y, rb[i][1].x, rb[i][1].y};
-                af[i] = __builtin_bit_cast(bf16x8, va);
-                bfr[i] = __builtin_bit_cast(bf16x8, vb);
+                af[i] = tr_frag(a_l, 32 * ks * RSE + 16 * i, (32 * ks + 4) * RSE + 16 * i);
+                bfr[i] = tr_frag(b_l, 32 * ks * RSE + 16 * i, (32 * ks + 4) * RSE + 16 * i);
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)

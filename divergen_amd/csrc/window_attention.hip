@@ -49,6 +49,15 @@ __device__ __forceinline__ bf16x8 ld_frag_T(const uint16_t* T, int row, int t, i
     return __builtin_bit_cast(bf16x8, v);
 }
 
+// row-major staging of NP rows x 32 bf16 (rows >= N zero-filled) with 16-byte stores; row stride RR elems
+template <int N, int NP, int RR>
+__device__ __forceinline__ void stage_rows(uint16_t* img, const uint16_t* src, int64_t row_stride, int tid, int nthreads) {
+    for (int u = tid; u < NP * 4; u += nthreads) {
+        const int r = u >> 2, c = u & 3;
+        *reinterpret_cast<bf16x8*>(&img[r * RR + 8 * c]) = ld_frag_global(src + (int64_t)r * row_stride + 8 * c, r < N);
+    }
+}
+
 // XCD-aware block -> (window, head): blocks that share an XCD (id % 8) walk the heads of one
 // window back to back, so the 64-byte head slices of a qkv row are served by one L2.
 __device__ __forceinline__ void block_to_window_head(int bid, int nH, int& b, int& h) {
@@ -63,7 +72,8 @@ __global__ __launch_bounds__(WinCfg<WS>::NT * 64) void win_attn_fwd_kernel(
     uint16_t* __restrict__ out, float* __restrict__ lse, int B_, int nW, int nH, float scale) {
     using Cf = WinCfg<WS>;
     constexpr int N = Cf::N, NT = Cf::NT, NTK = Cf::NTK, NP = NTK * 16, RS = Cf::RS, TBL = Cf::TBL;
-    __shared__ __attribute__((aligned(16))) uint16_t Vt[32 * RS];
+    constexpr int RR = 40;   // row stride (elements) of the row-major V image
+    __shared__ __attribute__((aligned(16))) uint16_t Vs[NP * RR];
     __shared__ float tbl[TBL];
 
     int b, h;
@@ -75,7 +85,7 @@ __global__ __launch_bounds__(WinCfg<WS>::NT * 64) void win_attn_fwd_kernel(
     const int tid = threadIdx.x, nthreads = NT * 64;
 
     for (int i = tid; i < TBL; i += nthreads) tbl[i] = table[h * TBL + i];
-    stage_transposed<N, NP, RS>(Vt, base + 2 * C, rowst, tid, nthreads);
+    stage_rows<N, NP, RR>(Vs, base + 2 * C, rowst, tid, nthreads);
     __syncthreads();
 
     const int w = tid >> 6, l = tid & 63, g = l >> 4, c16 = l & 15;
@@ -126,17 +136,16 @@ __global__ __launch_bounds__(WinCfg<WS>::NT * 64) void win_attn_fwd_kernel(
     const float inv = 1.0f / sum;
 
     f32x4 o[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    DGX_LDS const uint16_t* v_l4 = tr_lane_ptr(Vs, RR, 4 * g, 0, c16);
 #pragma unroll
     for (int t = 0; t < NTK / 2; ++t) {
         u32x4 pk = {pack_bf2(p[2 * t][0], p[2 * t][1]), pack_bf2(p[2 * t][2], p[2 * t][3]),
                     pack_bf2(p[2 * t + 1][0], p[2 * t + 1][1]), pack_bf2(p[2 * t + 1][2], p[2 * t + 1][3])};
         // A = P^T-slot fragment: row (l&15) = query, slots (g, j) = keys {32t+4g+j, 32t+16+4g+j-4}
         const bf16x8 pf = __builtin_bit_cast(bf16x8, pk);
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-            const bf16x8 vf = ld_frag_T<RS>(Vt, 16 * dt + c16, t, g);
-            o[dt] = mfma16(pf, vf, o[dt]);  // o[dt][r] = O[query 16w+4g+r][d 16dt+c16]
-        }
+        // B = V with the same k-slot order as P: keys {32t+4g+j, 32t+16+4g+j}, straight from the row-major image
+        o[0] = mfma16(pf, tr_frag(v_l4, 32 * t * RR, (32 * t + 16) * RR), o[0]);  // o[dt][r] = O[query 16w+4g+r][d 16dt+c16]
+        o[1] = mfma16(pf, tr_frag(v_l4, 32 * t * RR + 16, (32 * t + 16) * RR + 16), o[1]);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -151,23 +160,36 @@ __global__ __launch_bounds__(WinCfg<WS>::NT * 64) void win_attn_fwd_kernel(
 }
 
 // ------------------------------------------------------------------------------------ backward
+#ifdef DIAG_CLOCK
+__device__ unsigned long long dgx_clk[16];
+#define CLK(i) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && (threadIdx.x >> 6) == DIAG_WAVE) { const unsigned long long t__ = clock64(); dgx_clk[i] += t__ - tprev; tprev = t__; } } while (0)
+#else
+#define CLK(i)
+#endif
+
+// One window's worth of global loads for one thread, held in registers while the previous window computes.
+struct BwdPrefetch {
+    bf16x8 q, d, o, k;   // this thread's 16-byte chunk (row tid>>2, chunk tid&3) of Q, dO, O, K
+    bf16x8 v;            // phase-1 operand: V[key 16w + c16][8g .. 8g+7]
+    float lse;           // chunk-0 threads: lse / region id of the row
+    int reg;
+};
+
 template <int WS>
 __global__ __launch_bounds__(WinCfg<WS>::NT * 64) void win_attn_bwd_kernel(
     const uint16_t* __restrict__ qkv, const float* __restrict__ table, const int8_t* __restrict__ region,
     const uint16_t* __restrict__ out, const float* __restrict__ lse, const uint16_t* __restrict__ dout,
     uint16_t* __restrict__ dqkv, float* __restrict__ dtable, int B_, int nW, int nH, float scale, int chunk) {
     using Cf = WinCfg<WS>;
-    constexpr int N = Cf::N, NT = Cf::NT, NTK = Cf::NTK, NP = NTK * 16, RS = Cf::RS, TBL = Cf::TBL;
+    constexpr int N = Cf::N, NT = Cf::NT, NTK = Cf::NTK, NP = NTK * 16, TBL = Cf::TBL;
     constexpr int RR = 40;       // row stride (elements) of the row-major [NP][32] images
-    constexpr int RD = NP + 8;   // row stride of the dS image [NP][NP]
+    constexpr int RD = NP + 8;   // row stride of the dS^T image [key][query]; RD/2 dwords = 4*odd (mod 64)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint16_t* Qs = reinterpret_cast<uint16_t*>(smem);       // [NP][RR] row-major Q
     uint16_t* dOs = Qs + NP * RR;                            // [NP][RR] row-major dO
-    uint16_t* Qt = dOs + NP * RR;                            // [32][RS]
-    uint16_t* dOt = Qt + 32 * RS;                            // [32][RS]
-    uint16_t* Kt = dOt + 32 * RS;                            // [32][RS]
-    uint16_t* dSs = Kt + 32 * RS;                            // [NP][RD]
-    float* lse_s = reinterpret_cast<float*>(dSs + NP * RD);  // [NP] (16-B aligned: read as float4)
+    uint16_t* Ks = dOs + NP * RR;                            // [NP][RR] row-major K
+    uint16_t* dSt = Ks + NP * RR;                            // [NP keys][RD] dS^T (bf16)
+    float* lse_s = reinterpret_cast<float*>(dSt + NP * RD);  // [NP] (16-B aligned: read as float4)
     float* delta_s = lse_s + NP;                             // [NP]
     int* qoff_s = reinterpret_cast<int*>(delta_s + NP);      // [NP] rel-pos offset of query q
     int* reg_s = qoff_s + NP;                                // [NP] region id of query q (this window)
@@ -181,54 +203,101 @@ __global__ __launch_bounds__(WinCfg<WS>::NT * 64) void win_attn_bwd_kernel(
     const int64_t rowst = 3 * (int64_t)C;
     const int tid = threadIdx.x, nthreads = NT * 64;
     const int w = tid >> 6, l = tid & 63, g = l >> 4, c16 = l & 15;
-
-    for (int i = tid; i < TBL; i += nthreads) { tbl[i] = table[h * TBL + i]; tblacc[i] = 0.f; }
-    // key columns N..NP-1 are never owned by a wave but are read by the last K=32 step of dQ: keep them 0
-    for (int i = tid; i < NP * (NP - N); i += nthreads) dSs[(i / (NP - N)) * RD + N + i % (NP - N)] = 0;
-    for (int i = tid; i < NP; i += nthreads) { const int yq = i / WS; qoff_s[i] = i < N ? yq * (2 * WS - 1) + (i - yq * WS) : 0; }
-    const int key = 16 * w + c16;  // this lane's key in phase 1
+    const int srow = tid >> 2, sc = tid & 3;   // staging role: row, 16-byte chunk
+    const bool stager = tid < N * 4;
+    const int key = 16 * w + c16;              // this lane's key in phase 1
     const bool kok = key < N;
+    // transpose-read lane pointers: phase 1 k-slots are rows {32t+4g+j, 32t+16+4g+j}; phase 2 rows 32t+8g+j
+    DGX_LDS const uint16_t* q_l4 = tr_lane_ptr(Qs, RR, 4 * g, 0, c16);
+    DGX_LDS const uint16_t* do_l4 = tr_lane_ptr(dOs, RR, 4 * g, 0, c16);
+    DGX_LDS const uint16_t* k_l8 = tr_lane_ptr(Ks, RR, 8 * g, 0, c16);
+    DGX_LDS const uint16_t* ds_l8 = tr_lane_ptr(dSt, RD, 8 * g, 16 * w, c16);
+    DGX_LDS uint16_t* img_st = lds_opaque(Qs + srow * RR + 8 * sc);         // staging destinations
+    DGX_LDS float* meta_st = lds_opaque(lse_s + srow);                      // lse_s / delta_s / qoff_s / reg_s are NP apart
+    // phase-1 lane pointers (everything in the unrolled loop is one of these + a constant)
+    DGX_LDS const uint16_t* q_row = lds_opaque(Qs + c16 * RR + 8 * g);      // A fragment of query tile qt: + 16*qt*RR
+    DGX_LDS const uint16_t* do_row = lds_opaque(dOs + c16 * RR + 8 * g);
+    DGX_LDS const float* lse_g = lds_opaque(lse_s + 4 * g);                 // rows 16*qt + 4g .. +3
+    DGX_LDS const float* delta_g = lds_opaque(delta_s + 4 * g);
+    DGX_LDS const int* qoff_g = lds_opaque(qoff_s + 4 * g);
+    DGX_LDS const int* reg_g = lds_opaque(reg_s + 4 * g);
+    DGX_LDS uint16_t* ds_w = lds_opaque(dSt + key * RD + 4 * g);            // dS^T row `key`, queries 16*qt + 4g ..
+
+    // global addressing = uniform (SGPR) window base + one 32-bit lane offset per access pattern
+    const uint32_t st_qk_c = (uint32_t)(srow * (int)rowst + 8 * sc);     // staging chunk inside this window's qkv rows
+    const uint32_t st_o_c = (uint32_t)(srow * C + 8 * sc);               // ... inside out / dout rows
+    const uint32_t v_off_c = (uint32_t)((kok ? key : 0) * (int)rowst + 8 * g);
+    const uint32_t row4_c = (uint32_t)((16 * w + 4 * g) * (int)rowst + c16);   // output rows 16w + 4g (+ r via the base)
+    auto issue = [&](int b, BwdPrefetch& P) {
+        const uint16_t* base = qkv + (int64_t)b * N * rowst + h * 32;
+        const uint16_t* dob = dout + (int64_t)b * N * C + h * 32;
+        const uint16_t* ob = out + (int64_t)b * N * C + h * 32;
+        const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        P.q = P.d = P.o = P.k = z;
+        P.lse = INFINITY;
+        P.reg = 0;
+        // opaque copies: the 64-bit addresses are rebuilt per window (2 VALU each) instead of living in
+        // ~20 registers across the whole loop
+        uint32_t st_qk = st_qk_c, st_o = st_o_c, v_off = v_off_c;
+        asm volatile("" : "+v"(st_qk), "+v"(st_o), "+v"(v_off));
+        if (stager) {
+            P.q = *reinterpret_cast<const bf16x8*>(base + st_qk);
+            P.k = *reinterpret_cast<const bf16x8*>(base + C + st_qk);
+            P.d = *reinterpret_cast<const bf16x8*>(dob + st_o);
+            P.o = *reinterpret_cast<const bf16x8*>(ob + st_o);
+            P.lse = (lse + ((int64_t)b * nH + h) * N)[(uint32_t)srow];
+            P.reg = (int)(region + (int64_t)(b % nW) * N)[(uint32_t)srow];
+        }
+        P.v = *reinterpret_cast<const bf16x8*>(base + 2 * C + v_off);
+        if (!kok) P.v = z;
+    };
+
+    // ---- one-time LDS setup: bias row, zero padding rows/columns, rel-pos offsets
+    for (int i = tid; i < TBL; i += nthreads) { tbl[i] = table[h * TBL + i]; tblacc[i] = 0.f; }
+    for (int i = tid; i < (NP - N) * RR; i += nthreads) { Qs[N * RR + i] = 0; dOs[N * RR + i] = 0; Ks[N * RR + i] = 0; }
+    for (int i = tid; i < (NP - N) * RD; i += nthreads) dSt[N * RD + i] = 0;   // padded key rows feed the last K=32 step of dQ
+    for (int i = tid; i < NP; i += nthreads) {
+        const int yq = i / WS;
+        qoff_s[i] = i < N ? yq * (2 * WS - 1) + (i - yq * WS) : 0;
+        if (i >= N) { lse_s[i] = INFINITY; delta_s[i] = 0.f; reg_s[i] = 0; }   // padded queries: p = 0
+    }
     const int yk = key / WS, xk = key - yk * WS;
     const int kbase = kok ? (WS - 1) * (2 * WS - 1) + (WS - 1) - (yk * (2 * WS - 1) + xk) : 0;
     const float kneg = kok ? 0.0f : -INFINITY;   // padded key columns: p = 0
+    DGX_LDS const float* tbl_k = lds_opaque(tbl + kbase);
     float dbias[NT][4];
 #pragma unroll
     for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) dbias[i][r] = 0.f;
 
+    BwdPrefetch P;
+    if (b0 < b1) issue(b0, P);
     for (int b = b0; b < b1; ++b) {
-        const uint16_t* base = qkv + (int64_t)b * N * rowst + h * 32;
-        const uint16_t* dob = dout + (int64_t)b * N * C + h * 32;
-        const uint16_t* ob = out + (int64_t)b * N * C + h * 32;
         __syncthreads();  // previous window's LDS consumers are done
-        // row-major Q / dO images + delta[q] = sum_d dO*O
-        for (int u = tid; u < NP * 4; u += nthreads) {
-            const int q = u >> 2, c = u & 3;
-            const bool ok = q < N;
-            const bf16x8 qv = ld_frag_global(base + (int64_t)q * rowst + 8 * c, ok);
-            const bf16x8 dv = ld_frag_global(dob + (int64_t)q * C + 8 * c, ok);
-            const bf16x8 ov = ld_frag_global(ob + (int64_t)q * C + 8 * c, ok);
-            *reinterpret_cast<bf16x8*>(&Qs[q * RR + 8 * c]) = qv;
-            *reinterpret_cast<bf16x8*>(&dOs[q * RR + 8 * c]) = dv;
+#ifdef DIAG_CLOCK
+        unsigned long long tprev = clock64();
+#endif
+        if (stager) {
+            *reinterpret_cast<DGX_LDS bf16x8*>(img_st) = P.q;                   // Qs, dOs, Ks are NP*RR apart
+            *reinterpret_cast<DGX_LDS bf16x8*>(img_st + NP * RR) = P.d;
+            *reinterpret_cast<DGX_LDS bf16x8*>(img_st + 2 * NP * RR) = P.k;
             float d = 0.f;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) d += bf2f((uint16_t)dv[i]) * bf2f((uint16_t)ov[i]);
+            for (int i = 0; i < 8; ++i) d += bf2f((uint16_t)P.d[i]) * bf2f((uint16_t)P.o[i]);
             d += __shfl_xor(d, 1);
             d += __shfl_xor(d, 2);
-            if (c == 0) {
-                delta_s[q] = d;
-                lse_s[q] = ok ? lse[((int64_t)b * nH + h) * N + q] : INFINITY;   // padded queries: p = 0
-                reg_s[q] = ok ? (int)region[(int64_t)(b % nW) * N + q] : 0;
-            }
+            if (sc == 0) { meta_st[NP] = d; meta_st[0] = P.lse; reinterpret_cast<DGX_LDS int*>(meta_st)[3 * NP] = P.reg; }
         }
-        stage_transposed<N, NP, RS>(Qt, base, rowst, tid, nthreads);
-        stage_transposed<N, NP, RS>(dOt, dob, C, tid, nthreads);
-        stage_transposed<N, NP, RS>(Kt, base + C, rowst, tid, nthreads);
-        const bf16x8 kf = ld_frag_global(base + C + (int64_t)key * rowst + 8 * g, kok);
-        const bf16x8 vf = ld_frag_global(base + 2 * C + (int64_t)key * rowst + 8 * g, kok);
-        const int rk = kok ? (int)region[(int64_t)(b % nW) * N + key] : 0;
+        const bf16x8 vf = P.v;
+        CLK(0);
         __syncthreads();
+        CLK(1);
+#if !defined(PREFETCH_LATE)
+        if (b + 1 < b1) issue(b + 1, P);   // next window's loads fly under this window's math
+#endif
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(&Ks[(kok ? key : 0) * RR + 8 * g]);
+        const int rk = reg_s[kok ? key : 0];
 
         // ---- phase 1: this wave's 16 keys x all queries, two query tiles (one K=32 step) at a time
         f32x4 dV[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -241,101 +310,99 @@ __global__ __launch_bounds__(WinCfg<WS>::NT * 64) void win_attn_bwd_kernel(
                 const int qt = 2 * t + hh;
                 float pv[4] = {0.f, 0.f, 0.f, 0.f}, dsv[4] = {0.f, 0.f, 0.f, 0.f};
                 if (qt < NT) {
-                    const bf16x8 qa = *reinterpret_cast<const bf16x8*>(&Qs[(16 * qt + c16) * RR + 8 * g]);
-                    const bf16x8 da = *reinterpret_cast<const bf16x8*>(&dOs[(16 * qt + c16) * RR + 8 * g]);
+                    const bf16x8 qa = *reinterpret_cast<DGX_LDS const bf16x8*>(q_row + 16 * qt * RR);
+                    const bf16x8 da = *reinterpret_cast<DGX_LDS const bf16x8*>(do_row + 16 * qt * RR);
                     f32x4 z = {0.f, 0.f, 0.f, 0.f};
                     const f32x4 s = mfma16(qa, kf, z);    // s[r]  = S[q 16qt+4g+r][key]
                     const f32x4 dp = mfma16(da, vf, z);   // dp[r] = dP[q][key]
-                    const int q0 = 16 * qt + 4 * g;
-                    const float4 l4 = *reinterpret_cast<const float4*>(&lse_s[q0]);
-                    const float4 d4 = *reinterpret_cast<const float4*>(&delta_s[q0]);
-                    const int4 o4 = *reinterpret_cast<const int4*>(&qoff_s[q0]);
-                    const int4 r4 = *reinterpret_cast<const int4*>(&reg_s[q0]);
-                    const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dl[4] = {d4.x, d4.y, d4.z, d4.w};
-                    const int ov[4] = {o4.x, o4.y, o4.z, o4.w}, rv[4] = {r4.x, r4.y, r4.z, r4.w};
+                    const f32x4 lv = *reinterpret_cast<DGX_LDS const f32x4*>(lse_g + 16 * qt);
+                    const f32x4 dl = *reinterpret_cast<DGX_LDS const f32x4*>(delta_g + 16 * qt);
+                    const i32x4 ov = *reinterpret_cast<DGX_LDS const i32x4*>(qoff_g + 16 * qt);
+                    const i32x4 rv = *reinterpret_cast<DGX_LDS const i32x4*>(reg_g + 16 * qt);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        float sv = s[r] * scale + tbl[kbase + ov[r]] + kneg;
-                        if (rv[r] != rk) sv += -100.0f;
+                        float sv = s[r] * scale + tbl_k[ov[r]] + kneg;
+                        sv += rv[r] != rk ? -100.0f : 0.0f;
                         pv[r] = __expf(sv - lv[r]);
                         dsv[r] = pv[r] * (dp[r] - dl[r]);
-#if defined(DBIAS_LDS)
-                        atomicAdd(&tblacc[kbase + ov[r]], dsv[r]);
-#elif !defined(DIAG_NO_DBIAS)
                         dbias[qt < NT ? qt : 0][r] += dsv[r];
-#endif
-#ifndef DIAG_NO_DSWRITE
-                        dSs[(q0 + r) * RD + key] = f2bf(dsv[r]);
-#endif
                     }
                 }
                 ppk[hh][0] = pack_bf2(pv[0], pv[1]);
                 ppk[hh][1] = pack_bf2(pv[2], pv[3]);
                 dpk[hh][0] = pack_bf2(dsv[0], dsv[1]);
                 dpk[hh][1] = pack_bf2(dsv[2], dsv[3]);
+                // dS^T image row = key, 4 consecutive queries: one 8-byte store
+                if (qt < NT)
+                    *reinterpret_cast<DGX_LDS u32x2*>(ds_w + 16 * qt) = u32x2{dpk[hh][0], dpk[hh][1]};
+#ifndef NO_HH_BARRIER
+                __builtin_amdgcn_sched_barrier(0);   // one query tile at a time: its 40-odd temporaries die before the next starts
+#endif
             }
             u32x4 a = {ppk[0][0], ppk[0][1], ppk[1][0], ppk[1][1]};
             u32x4 d = {dpk[0][0], dpk[0][1], dpk[1][0], dpk[1][1]};
             const bf16x8 pf = __builtin_bit_cast(bf16x8, a);   // A = P^T : row = key, slots = queries
             const bf16x8 df = __builtin_bit_cast(bf16x8, d);   // A = dS^T
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt) {
-                dV[dt] = mfma16(pf, ld_frag_T<RS>(dOt, 16 * dt + c16, t, g), dV[dt]);
-                dK[dt] = mfma16(df, ld_frag_T<RS>(Qt, 16 * dt + c16, t, g), dK[dt]);
-            }
+            // B operands = dO / Q rows {32t+4g+j, 32t+16+4g+j} (the k-slot order of P^T / dS^T), by transpose reads
+            dV[0] = mfma16(pf, tr_frag(do_l4, 32 * t * RR, (32 * t + 16) * RR), dV[0]);
+            dV[1] = mfma16(pf, tr_frag(do_l4, 32 * t * RR + 16, (32 * t + 16) * RR + 16), dV[1]);
+            dK[0] = mfma16(df, tr_frag(q_l4, 32 * t * RR, (32 * t + 16) * RR), dK[0]);
+            dK[1] = mfma16(df, tr_frag(q_l4, 32 * t * RR + 16, (32 * t + 16) * RR + 16), dK[1]);
             __builtin_amdgcn_sched_barrier(0);   // keep the t-steps apart: shorter live ranges, no spills
         }
+        CLK(2);
         uint16_t* dqb = dqkv + (int64_t)b * N * rowst + h * 32;
+        uint32_t row4 = row4_c;
+        asm volatile("" : "+v"(row4));   // same: store addresses are per-window temporaries
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int kk = 16 * w + 4 * g + r;
-            if (kk < N) {
+            if (16 * w + 4 * g + r < N) {
+                uint16_t* dkr = dqb + r * rowst + C;      // uniform
+                uint16_t* dvr = dqb + r * rowst + 2 * C;
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
-                    dqb[(int64_t)kk * rowst + C + 16 * dt + c16] = f2bf(dK[dt][r] * scale);
-                    dqb[(int64_t)kk * rowst + 2 * C + 16 * dt + c16] = f2bf(dV[dt][r]);
+                    dkr[row4 + 16 * dt] = f2bf(dK[dt][r] * scale);
+                    dvr[row4 + 16 * dt] = f2bf(dV[dt][r]);
                 }
             }
         }
-        __syncthreads();  // dS image complete
-        // ---- phase 2: dQ strip w = dS[16w.., :] K
-#ifndef DIAG_NO_PHASE2
+        CLK(3);
+        __syncthreads();  // dS^T image complete
+        CLK(4);
+#if defined(PREFETCH_LATE)
+        if (b + 1 < b1) issue(b + 1, P);   // next window's loads fly under phase 2 (phase 1 has no registers to spare)
+#endif
+        // ---- phase 2: dQ strip w = dS[16w.., :] K ; A = dS rows (queries 16w + c16) out of the key-major image
         f32x4 dQ[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
         for (int t = 0; t < NTK / 2; ++t) {
-            const bf16x8 sa = *reinterpret_cast<const bf16x8*>(&dSs[(16 * w + c16) * RD + 32 * t + 8 * g]);
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt) {
-                const bf16x8 kb = *reinterpret_cast<const bf16x8*>(&Kt[(16 * dt + c16) * RS + 32 * t + 8 * g]);
-                dQ[dt] = mfma16(sa, kb, dQ[dt]);
-            }
+            const bf16x8 sa = tr_frag(ds_l8, 32 * t * RD, (32 * t + 4) * RD);   // k-slots = keys 32t+8g .. +7 for A and B
+            dQ[0] = mfma16(sa, tr_frag(k_l8, 32 * t * RR, (32 * t + 4) * RR), dQ[0]);
+            dQ[1] = mfma16(sa, tr_frag(k_l8, 32 * t * RR + 16, (32 * t + 4) * RR + 16), dQ[1]);
         }
+        CLK(5);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int q = 16 * w + 4 * g + r;
-            if (q < N) {
+            if (16 * w + 4 * g + r < N) {
+                uint16_t* dqr = dqb + r * rowst;          // uniform
 #pragma unroll
-                for (int dt = 0; dt < 2; ++dt)
-                    dqb[(int64_t)q * rowst + 16 * dt + c16] = f2bf(dQ[dt][r] * scale);
+                for (int dt = 0; dt < 2; ++dt) dqr[row4 + 16 * dt] = f2bf(dQ[dt][r] * scale);
             }
         }
-#endif
+        CLK(6);
     }
     // ---- relative-position-bias gradient: registers -> LDS table (ds_add_f32) -> global atomics
-#if !defined(DBIAS_LDS)
+    int kb = kbase;
+    asm volatile("" : "+v"(kb));   // opaque: keeps the 36 scatter addresses from being hoisted above the window loop
     if (kok) {
 #pragma unroll
         for (int qt = 0; qt < NT; ++qt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int q = 16 * qt + 4 * g + r;
-                if (q < N) {
-                    const int yq = q / WS, xq = q - yq * WS;
-                    atomicAdd(&tblacc[kbase + yq * (2 * WS - 1) + xq], dbias[qt][r]);
-                }
+                if (q < N) atomicAdd(&tblacc[kb + qoff_s[q]], dbias[qt][r]);
             }
     }
-#endif
     __syncthreads();
     for (int i = tid; i < TBL; i += nthreads) atomicAdd(&dtable[h * TBL + i], tblacc[i]);
 }
@@ -344,7 +411,7 @@ template <int WS>
 static size_t bwd_smem_bytes() {
     using Cf = WinCfg<WS>;
     constexpr int NP = Cf::NTK * 16;
-    return (size_t)(2 * NP * 40 + 3 * 32 * Cf::RS + NP * (NP + 8)) * 2 + (size_t)(4 * NP + 2 * Cf::TBL) * 4 + 64;
+    return (size_t)(3 * NP * 40 + NP * (NP + 8)) * 2 + (size_t)(4 * NP + 2 * Cf::TBL) * 4 + 64;
 }
 
 // NULL region (W-MSA) is served by a process-lifetime all-zero row: one code path in the kernels

@@ -26,4 +26,4 @@ def bench(B_, nH, ws=12, nW=1, iters=20):
     fl = B_ * nH * 4.0 * N * N * 32
     print("B_=%5d nH=%2d nW=%3d  fwd %7.1f us (%6.1f TF/s)  bwd %7.1f us (%6.1f TF/s)  units %d  bwd ns/unit/CU %.0f" % (
         B_, nH, nW, tf, fl / tf / 1e6, tb, 2.5 * fl / tb / 1e6, B_ * nH, tb * 1e3 * 256 / (B_ * nH)))
-bench(968, 6, iters=3); bench(72, 24, iters=3)
+bench(968, 6); bench(968, 6); bench(242, 12); bench(72, 24); bench(18, 48)

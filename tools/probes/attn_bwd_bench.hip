@@ -1,0 +1,41 @@
+// Standalone timing harness for the window-attention kernels (no torch): hipcc -DDIAG_CLOCK -DDIAG_WAVE=0 ...
+#include "../../divergen_amd/csrc/window_attention.hip"
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+int main(int argc, char** argv) {
+    const int B_ = argc > 1 ? atoi(argv[1]) : 968, nH = argc > 2 ? atoi(argv[2]) : 6, N = 144, C = nH * 32;
+    size_t nq = (size_t)B_ * N * 3 * C, no = (size_t)B_ * N * C;
+    std::vector<uint16_t> h(nq);
+    for (size_t i = 0; i < nq; ++i) h[i] = 0x3c00 + (rand() & 0x3ff) - ((rand() & 1) << 15);  // ~ +-[0.0078..0.0156]... small bf16
+    uint16_t *qkv, *out, *dout, *dqkv; float *table, *lse, *dtable;
+    hipMalloc(&qkv, nq * 2); hipMalloc(&dqkv, nq * 2); hipMalloc(&out, no * 2); hipMalloc(&dout, no * 2);
+    hipMalloc(&table, 529 * nH * 4); hipMalloc(&dtable, 529 * nH * 4); hipMalloc(&lse, (size_t)B_ * nH * N * 4);
+    hipMemcpy(qkv, h.data(), nq * 2, hipMemcpyHostToDevice);
+    hipMemcpy(dout, h.data(), no * 2, hipMemcpyHostToDevice);
+    hipMemset(table, 0, 529 * nH * 4); hipMemset(dtable, 0, 529 * nH * 4);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int it = 0; it < 3; ++it) {
+        dgx_window_attention_fwd(qkv, table, nullptr, out, lse, B_, 1, nH, 12, 0.17677f, nullptr);
+        dgx_window_attention_bwd(qkv, table, nullptr, out, lse, dout, dqkv, dtable, B_, 1, nH, 12, 0.17677f, nullptr);
+    }
+    hipDeviceSynchronize();
+#ifdef DIAG_CLOCK
+    unsigned long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(dgx_clk), z, sizeof z);
+#endif
+    const int iters = 10; float msf = 0, msb = 0, ms;
+    for (int it = 0; it < iters; ++it) {
+        hipEventRecord(e0); dgx_window_attention_fwd(qkv, table, nullptr, out, lse, B_, 1, nH, 12, 0.17677f, nullptr);
+        hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1); msf += ms;
+        hipEventRecord(e0); dgx_window_attention_bwd(qkv, table, nullptr, out, lse, dout, dqkv, dtable, B_, 1, nH, 12, 0.17677f, nullptr);
+        hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1); msb += ms;
+    }
+    printf("B_=%d nH=%d fwd %.1f us bwd %.1f us\n", B_, nH, msf / iters * 1e3, msb / iters * 1e3);
+#ifdef DIAG_CLOCK
+    hipMemcpyFromSymbol(z, HIP_SYMBOL(dgx_clk), sizeof z);
+    const int nchunks = 256 / nH; const int chunk = (B_ + nchunks - 1) / nchunks;
+    const char* nm[] = {"load+stage", "sync1", "phase1", "dKdV store", "sync2", "phase2", "dQ store"};
+    for (int i = 0; i < 7; ++i) printf("  %-12s %8.0f cycles/window\n", nm[i], (double)z[i] / iters / chunk);
+#endif
+    return 0;
+}

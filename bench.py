@@ -206,7 +206,7 @@ def main():
                 B_, nH, ws = args[5], args[7], args[8]
                 mm = 2
             else:
-                B_, nH, ws = args[8], args[10], args[11]
+                B_, nH, ws = args[10], args[12], args[13]
                 mm = 5
             N = ws * ws
             flops += B_ * nH * mm * 2.0 * N * N * 32

@@ -19,7 +19,7 @@ SIGNATURES = {
     "dgx_build_arch": (ctypes.c_char_p, []),
     "dgx_abi_version": (c_i, []),
     "dgx_window_attention_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p]),
-    "dgx_window_attention_bwd": (c_i, [c_p] * 8 + [c_i, c_i, c_i, c_i, c_f, c_p]),
+    "dgx_window_attention_bwd": (c_i, [c_p] * 8 + [c_i64, c_i64, c_i, c_i, c_i, c_i, c_f, c_p]),
     "dgx_window_gather": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "dgx_window_scatter": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "dgx_roi_align_fwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
@@ -38,7 +38,9 @@ SIGNATURES = {
     "dgx_linear_wgrad": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p, c_p]),
     "dgx_layernorm_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "dgx_layernorm_bwd_blocks": (c_i, [c_i64]),
-    "dgx_layernorm_bwd": (c_i, [c_p] * 9 + [c_i64, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "dgx_layernorm_bwd": (c_i, [c_p] * 10 + [c_i64, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "dgx_colsum_workspace_bytes": (c_i64, [c_i, c_i]),
+    "dgx_colsum_bf16": (c_i, [c_p, c_p, c_i, c_i, c_f, c_p, c_p]),
     "dgx_residual_fwd": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "dgx_residual_bwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "dgx_adamw_ema_step": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_f,

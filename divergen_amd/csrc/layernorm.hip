@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const XT* __restrict__ x, c
 template <int NJ, typename XT>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const uint16_t* __restrict__ dy, const XT* __restrict__ x,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                     const float* __restrict__ gamma, XT* __restrict__ dx,
+                                                     const float* __restrict__ gamma, const XT* dres, XT* dx,
                                                      float* __restrict__ part, int64_t T, int C, WinMap m) {
     __shared__ float red[2][NJ * 256];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -144,12 +144,19 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const uint16_t* __restrict_
         s1 = wave_sum(s1) / (float)C;
         s2 = wave_sum(s2) / (float)C;
         XT* dxr = dx + tok * C;
+        const XT* drr = dres ? dres + tok * C : nullptr;   // gradient arriving on the residual branch (may alias dx)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int i = lane + 64 * j;
-            if (i < C / 4)
-                st4<XT>(dxr, i, make_float4(rs * (gv[j][0] - s1 - xh[j][0] * s2), rs * (gv[j][1] - s1 - xh[j][1] * s2),
-                                            rs * (gv[j][2] - s1 - xh[j][2] * s2), rs * (gv[j][3] - s1 - xh[j][3] * s2)));
+            if (i < C / 4) {
+                float4 o = make_float4(rs * (gv[j][0] - s1 - xh[j][0] * s2), rs * (gv[j][1] - s1 - xh[j][1] * s2),
+                                       rs * (gv[j][2] - s1 - xh[j][2] * s2), rs * (gv[j][3] - s1 - xh[j][3] * s2));
+                if (drr) {
+                    const float4 a = ld4<XT>(drr, i);
+                    o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+                }
+                st4<XT>(dxr, i, o);
+            }
         }
     }
     // block partials: the 4 waves fold into one LDS row in turn -> one row of `part` per block: [block][2][C]
@@ -231,8 +238,8 @@ extern "C" int dgx_layernorm_bwd_blocks(int64_t T) {
 }
 
 extern "C" int dgx_layernorm_bwd(const void* dy_bf16, const void* x, const float* mean, const float* rstd,
-                                 const float* gamma, void* dx, float* dgamma, float* dbeta, float* part, int64_t T, int C,
-                                 int B, int H, int W, int ws, int shift, int x_dtype, void* stream) {
+                                 const float* gamma, const void* dres, void* dx, float* dgamma, float* dbeta, float* part,
+                                 int64_t T, int C, int B, int H, int W, int ws, int shift, int x_dtype, void* stream) {
     if (T <= 0) return DGX_OK;
     if (!dy_bf16 || !x || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta || !part || (C & 3) || C > 1536 ||
         (ws > 0 && (int64_t)B * H * W != T))
@@ -245,10 +252,10 @@ extern "C" int dgx_layernorm_bwd(const void* dy_bf16, const void* x, const float
     do {                                                                                                                   \
         if (x_dtype == DGX_BF16)                                                                                           \
             hipLaunchKernelGGL((ln_bwd_kernel<NJ, uint16_t>), dim3(grid), dim3(256), 0, st, (const uint16_t*)dy_bf16,       \
-                               (const uint16_t*)x, mean, rstd, gamma, (uint16_t*)dx, part, T, C, m);                        \
+                               (const uint16_t*)x, mean, rstd, gamma, (const uint16_t*)dres, (uint16_t*)dx, part, T, C, m);                        \
         else                                                                                                               \
             hipLaunchKernelGGL((ln_bwd_kernel<NJ, float>), dim3(grid), dim3(256), 0, st, (const uint16_t*)dy_bf16,          \
-                               (const float*)x, mean, rstd, gamma, (float*)dx, part, T, C, m);                              \
+                               (const float*)x, mean, rstd, gamma, (const float*)dres, (float*)dx, part, T, C, m);                              \
     } while (0)
     if (nj <= 1) LN_BWD(1);
     else if (nj <= 2) LN_BWD(2);

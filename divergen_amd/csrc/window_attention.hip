@@ -179,7 +179,8 @@ template <int WS>
 __global__ __launch_bounds__(WinCfg<WS>::NT * 64) void win_attn_bwd_kernel(
     const uint16_t* __restrict__ qkv, const float* __restrict__ table, const int8_t* __restrict__ region,
     const uint16_t* __restrict__ out, const float* __restrict__ lse, const uint16_t* __restrict__ dout,
-    uint16_t* __restrict__ dqkv, float* __restrict__ dtable, int B_, int nW, int nH, float scale, int chunk) {
+    uint16_t* __restrict__ dqkv, float* __restrict__ dtable, int B_, int nW, int nH, float scale, int chunk,
+    int64_t dt_sh, int64_t dt_si) {
     using Cf = WinCfg<WS>;
     constexpr int N = Cf::N, NT = Cf::NT, NTK = Cf::NTK, NP = NTK * 16, TBL = Cf::TBL;
     constexpr int RR = 40;       // row stride (elements) of the row-major [NP][32] images
@@ -404,7 +405,7 @@ __global__ __launch_bounds__(WinCfg<WS>::NT * 64) void win_attn_bwd_kernel(
             }
     }
     __syncthreads();
-    for (int i = tid; i < TBL; i += nthreads) atomicAdd(&dtable[h * TBL + i], tblacc[i]);
+    for (int i = tid; i < TBL; i += nthreads) atomicAdd(&dtable[h * dt_sh + i * dt_si], tblacc[i]);
 }
 
 template <int WS>
@@ -445,8 +446,9 @@ extern "C" int dgx_window_attention_fwd(const void* qkv, const float* table, con
 }
 
 extern "C" int dgx_window_attention_bwd(const void* qkv, const float* table, const int8_t* region, const void* out,
-                                        const float* lse, const void* dout, void* dqkv, float* dtable, int B_,
-                                        int nW, int nH, int ws, float scale, void* stream) {
+                                        const float* lse, const void* dout, void* dqkv, float* dtable,
+                                        int64_t dtable_stride_head, int64_t dtable_stride_index, int B_, int nW, int nH,
+                                        int ws, float scale, void* stream) {
     if (B_ <= 0) return DGX_OK;
     if (!qkv || !table || !out || !lse || !dout || !dqkv || !dtable || nH <= 0 || nW <= 0 || (region && B_ % nW))
         return DGX_ERR_BAD_ARG;
@@ -467,12 +469,12 @@ extern "C" int dgx_window_attention_bwd(const void* qkv, const float* table, con
         }
         hipLaunchKernelGGL(win_attn_bwd_kernel<12>, dim3(grid), dim3(WinCfg<12>::NT * 64), sm, st,
                            (const uint16_t*)qkv, table, region, (const uint16_t*)out, lse, (const uint16_t*)dout,
-                           (uint16_t*)dqkv, dtable, B_, nW, nH, scale, chunk);
+                           (uint16_t*)dqkv, dtable, B_, nW, nH, scale, chunk, dtable_stride_head, dtable_stride_index);
     } else if (ws == 7) {
         const size_t sm = bwd_smem_bytes<7>();
         hipLaunchKernelGGL(win_attn_bwd_kernel<7>, dim3(grid), dim3(WinCfg<7>::NT * 64), sm, st,
                            (const uint16_t*)qkv, table, region, (const uint16_t*)out, lse, (const uint16_t*)dout,
-                           (uint16_t*)dqkv, dtable, B_, nW, nH, scale, chunk);
+                           (uint16_t*)dqkv, dtable, B_, nW, nH, scale, chunk, dtable_stride_head, dtable_stride_index);
     } else {
         return DGX_ERR_UNSUPPORTED;
     }

@@ -40,7 +40,7 @@ class _LayerNormBF16(torch.autograd.Function):
                     and getattr(weight, "_dgx16", None) is not None and getattr(bias, "_dgx16", None) is not None)
         dg = weight.grad if in_arena else torch.zeros(C, dtype=torch.float32, device=x.device)
         db = bias.grad if in_arena else torch.zeros(C, dtype=torch.float32, device=x.device)
-        L.check(L.lib().dgx_layernorm_bwd(L.ptr(dy), L.ptr(x), L.ptr(mean), L.ptr(rstd), L.ptr(weight), L.ptr(dx), L.ptr(dg),
+        L.check(L.lib().dgx_layernorm_bwd(L.ptr(dy), L.ptr(x), L.ptr(mean), L.ptr(rstd), L.ptr(weight), None, L.ptr(dx), L.ptr(dg),
                                           L.ptr(db), L.ptr(part), T, C, B, H, W, ws, shift, L.dtype_code(x), L.stream()), "dgx_layernorm_bwd")
         if in_arena:
             for p in (weight, bias):

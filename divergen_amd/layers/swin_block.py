@@ -1,0 +1,154 @@
+"""One Swin block as ONE autograd node with a hand-written backward.
+
+Reference: SwinTransformerBlock.forward (DG/divergen/modeling/backbone/swintransformer.py:201-257) =
+LN -> pad/roll/partition -> WindowAttention (:126-157) -> reverse/roll/crop -> DropPath + residual ->
+LN -> Mlp (:40-46) -> DropPath + residual.
+
+The eager composition of the same kernels costs ~25 autograd nodes per block (x24 blocks) and the step is
+bound by the host issuing them, not by the GPU.  Here forward and backward are straight-line sequences of
+libdgx kernels and library GEMMs: no autograd bookkeeping between them, weight gradients accumulate in
+fp32 directly in the gradient arena (and signal the data-parallel reducer per parameter), bias gradients
+come from the column-sum kernel, the residual-branch gradient is folded into the LayerNorm backward, and
+the bias-table gradient is scattered by the attention kernel straight into the parameter's gradient.
+Used when every parameter of the block lives in a FlatArena (training); anything else takes the
+composed path in swintransformer.py, which runs the same kernels in the same order.
+"""
+import torch
+
+from .. import _lib as L
+from .linear_ops import BF16, shadow, wgrad_into
+
+
+def arena_resident(params):
+    return all(p.is_leaf and getattr(p, "_dgx16", None) is not None and p.grad is not None
+               and p.grad.dtype == torch.float32 for p in params)
+
+
+def _ready(*params):
+    for p in params:
+        r = getattr(p, "_dgx_ready", None)
+        if r is not None:
+            r()
+
+
+def colsum_into(gb, dy2, beta=1.0):
+    """gb fp32 (N,) = beta*gb + dy2.sum(0); dy2 bf16 (M, N)."""
+    M, N = dy2.shape
+    lib = L.lib()
+    ws = torch.empty(max(int(lib.dgx_colsum_workspace_bytes(M, N)), 4), dtype=torch.uint8, device=dy2.device)
+    L.check(lib.dgx_colsum_bf16(L.ptr(dy2), L.ptr(gb), M, N, float(beta), L.ptr(ws), L.stream()), "dgx_colsum_bf16")
+
+
+def _linear_bwd(dy2, x2, weight, bias, w16):
+    """Gradients of y = x W^T + b into the arena; returns dx (bf16)."""
+    wgrad_into(weight.grad.view(weight.shape[0], -1), dy2, x2)
+    if bias is not None:
+        colsum_into(bias.grad, dy2)
+        _ready(weight, bias)
+    else:
+        _ready(weight)
+    return torch.mm(dy2, w16)
+
+
+class _SwinBlockFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, region, s1, s2, cfg, n1w, n1b, qw, qb, table, pw, pb, n2w, n2b, w1, b1, w2, b2):
+        B, H, W, ws, shift, nH, scale, eps1, eps2 = cfg
+        lib, st, dev = L.lib(), L.stream(), x.device
+        x = x.contiguous()
+        C = x.shape[-1]
+        T = B * H * W
+        code = L.dtype_code(x)
+        nW = (-(-H // ws)) * (-(-W // ws))
+        B_, N = B * nW, ws * ws
+        Tw = B_ * N
+        f32 = torch.float32
+        # LN1 + bf16 + pad + roll + partition
+        xw = torch.empty(Tw, C, dtype=BF16, device=dev)
+        mean1 = torch.empty(T, dtype=f32, device=dev)
+        rstd1 = torch.empty(T, dtype=f32, device=dev)
+        L.check(lib.dgx_layernorm_fwd(x.data_ptr(), n1w.data_ptr(), n1b.data_ptr(), xw.data_ptr(), mean1.data_ptr(),
+                                      rstd1.data_ptr(), T, C, eps1, B, H, W, ws, shift, code, st), "dgx_layernorm_fwd")
+        # attention
+        qw16, pw16, w116, w216 = shadow(qw), shadow(pw), shadow(w1), shadow(w2)
+        qkv = torch.addmm(shadow(qb), xw, qw16.t())
+        tableT = table.detach().t().contiguous()
+        o = torch.empty(Tw, C, dtype=BF16, device=dev)
+        lse = torch.empty(B_, nH, N, dtype=f32, device=dev)
+        L.check(lib.dgx_window_attention_fwd(qkv.data_ptr(), tableT.data_ptr(), L.ptr(region), o.data_ptr(), lse.data_ptr(),
+                                             B_, nW, nH, ws, scale, st), "dgx_window_attention_fwd")
+        pr = torch.addmm(shadow(pb), o, pw16.t())
+        # reverse + roll + crop + DropPath + residual
+        x1 = torch.empty_like(x)
+        L.check(lib.dgx_residual_fwd(x.data_ptr(), pr.data_ptr(), L.ptr(s1), x1.data_ptr(), B, H, W, C, ws, shift, code, st),
+                "dgx_residual_fwd")
+        # LN2 + MLP + residual
+        h2 = torch.empty(T, C, dtype=BF16, device=dev)
+        mean2 = torch.empty(T, dtype=f32, device=dev)
+        rstd2 = torch.empty(T, dtype=f32, device=dev)
+        L.check(lib.dgx_layernorm_fwd(x1.data_ptr(), n2w.data_ptr(), n2b.data_ptr(), h2.data_ptr(), mean2.data_ptr(),
+                                      rstd2.data_ptr(), T, C, eps2, 0, 0, 0, 0, 0, code, st), "dgx_layernorm_fwd")
+        f1 = torch.addmm(shadow(b1), h2, w116.t())
+        a = torch.nn.functional.gelu(f1)
+        f2 = torch.addmm(shadow(b2), a, w216.t())
+        out = torch.empty_like(x)
+        L.check(lib.dgx_residual_fwd(x1.data_ptr(), f2.data_ptr(), L.ptr(s2), out.data_ptr(), B, H, W, C, 0, 0, code, st),
+                "dgx_residual_fwd")
+        ctx.save_for_backward(x, mean1, rstd1, xw, qkv, tableT, region, o, lse, x1, mean2, rstd2, h2, f1, a, s1, s2,
+                              qw16, pw16, w116, w216)
+        ctx.params = (n1w, n1b, qw, qb, table, pw, pb, n2w, n2b, w1, b1, w2, b2)
+        ctx.cfg = cfg
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (x, mean1, rstd1, xw, qkv, tableT, region, o, lse, x1, mean2, rstd2, h2, f1, a, s1, s2,
+         qw16, pw16, w116, w216) = ctx.saved_tensors
+        n1w, n1b, qw, qb, table, pw, pb, n2w, n2b, w1, b1, w2, b2 = ctx.params
+        B, H, W, ws, shift, nH, scale, eps1, eps2 = ctx.cfg
+        lib, st, dev = L.lib(), L.stream(), g.device
+        g = g.contiguous()
+        C = x.shape[-1]
+        T = B * H * W
+        code = L.dtype_code(x)
+        nW = (-(-H // ws)) * (-(-W // ws))
+        B_, N = B * nW, ws * ws
+        Tw = B_ * N
+        # MLP branch
+        df2 = torch.empty(T, C, dtype=BF16, device=dev)
+        L.check(lib.dgx_residual_bwd(g.data_ptr(), L.ptr(s2), df2.data_ptr(), B, H, W, C, 0, 0, code, st), "dgx_residual_bwd")
+        da = _linear_bwd(df2, a, w2, b2, w216)
+        df1 = torch.ops.aten.gelu_backward(da, f1)
+        dh2 = _linear_bwd(df1, h2, w1, b1, w116)
+        # LN2 backward + the residual-branch gradient g -> dx1
+        nblk = lib.dgx_layernorm_bwd_blocks(T)
+        part = torch.empty(nblk * 2 * C, dtype=torch.float32, device=dev)
+        dx1 = torch.empty_like(x)
+        L.check(lib.dgx_layernorm_bwd(dh2.data_ptr(), x1.data_ptr(), mean2.data_ptr(), rstd2.data_ptr(), n2w.data_ptr(),
+                                      g.data_ptr(), dx1.data_ptr(), n2w.grad.data_ptr(), n2b.grad.data_ptr(), part.data_ptr(),
+                                      T, C, 0, 0, 0, 0, 0, code, st), "dgx_layernorm_bwd")
+        _ready(n2w, n2b)
+        # attention branch
+        dpr = torch.empty(Tw, C, dtype=BF16, device=dev)
+        L.check(lib.dgx_residual_bwd(dx1.data_ptr(), L.ptr(s1), dpr.data_ptr(), B, H, W, C, ws, shift, code, st),
+                "dgx_residual_bwd")
+        do = _linear_bwd(dpr, o, pw, pb, pw16)
+        dqkv = torch.empty_like(qkv)
+        L.check(lib.dgx_window_attention_bwd(qkv.data_ptr(), tableT.data_ptr(), L.ptr(region), o.data_ptr(), lse.data_ptr(),
+                                             do.data_ptr(), dqkv.data_ptr(), table.grad.data_ptr(), 1, nH, B_, nW, nH, ws,
+                                             scale, st), "dgx_window_attention_bwd")
+        _ready(table)
+        dxw = _linear_bwd(dqkv, xw, qw, qb, qw16)
+        # LN1 backward through the window map, accumulated onto dx1 in place
+        L.check(lib.dgx_layernorm_bwd(dxw.data_ptr(), x.data_ptr(), mean1.data_ptr(), rstd1.data_ptr(), n1w.data_ptr(),
+                                      dx1.data_ptr(), dx1.data_ptr(), n1w.grad.data_ptr(), n1b.grad.data_ptr(), part.data_ptr(),
+                                      T, C, B, H, W, ws, shift, code, st), "dgx_layernorm_bwd")
+        _ready(n1w, n1b)
+        return (dx1,) + (None,) * 17
+
+
+def swin_block(x, region, s1, s2, cfg, params):
+    """x (B, H*W, C) fp32|bf16 -> same.  cfg = (B, H, W, ws, shift, nH, scale, eps1, eps2); params in the
+    order norm1.{w,b}, qkv.{w,b}, bias table, proj.{w,b}, norm2.{w,b}, fc1.{w,b}, fc2.{w,b}."""
+    with torch.autocast("cuda", enabled=False):
+        return _SwinBlockFn.apply(x, region, s1, s2, cfg, *params)

@@ -50,7 +50,7 @@ class _WindowAttentionCore(torch.autograd.Function):
         dqkv = torch.empty_like(qkv)
         dtable = torch.zeros_like(table)
         L.check(L.lib().dgx_window_attention_bwd(L.ptr(qkv), L.ptr(table), L.ptr(region), L.ptr(out), L.ptr(lse),
-                                                 L.ptr(dout), L.ptr(dqkv), L.ptr(dtable), qkv.shape[0], nW, nH, ws,
+                                                 L.ptr(dout), L.ptr(dqkv), L.ptr(dtable), dtable.shape[1], 1, qkv.shape[0], nW, nH, ws,
                                                  scale, L.stream()), "dgx_window_attention_bwd")
         return dqkv, dtable.t(), None, None, None, None, None
 

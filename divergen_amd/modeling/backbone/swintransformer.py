@@ -22,6 +22,10 @@ from ...layers.conv_ops import patch_embed4x4
 from ...layers.linear_ops import Linear
 from ...layers.norm_ops import layernorm_bf16, layernorm_window_gather, residual_add
 from ...layers import shift_regions, window_attention_core, window_gather, window_scatter
+from ...layers.swin_block import arena_resident, swin_block
+
+import os
+_FUSED_BLOCK = os.environ.get("DGX_FUSED_BLOCK", "1") == "1"
 
 
 def trunc_normal_(t, std=0.02):
@@ -100,6 +104,15 @@ class SwinTransformerBlock(nn.Module):
         assert Ltok == H * W, "input feature has wrong size"
         ws, sh = self.window_size, self.shift_size
         fused = torch.is_autocast_enabled() and C <= 1536
+        if fused and C % 8 == 0 and x.is_cuda and _FUSED_BLOCK and torch.is_grad_enabled():
+            params = (self.norm1.weight, self.norm1.bias, self.attn.qkv.weight, self.attn.qkv.bias,
+                      self.attn.relative_position_bias_table, self.attn.proj.weight, self.attn.proj.bias,
+                      self.norm2.weight, self.norm2.bias, self.mlp.fc1.weight, self.mlp.fc1.bias,
+                      self.mlp.fc2.weight, self.mlp.fc2.bias)
+            if arena_resident(params):   # one autograd node for the whole block
+                s1, s2 = self._drop_scales(B, x.device)
+                cfg = (B, H, W, ws, sh, self.num_heads, self.attn.scale, self.norm1.eps, self.norm2.eps)
+                return swin_block(x, region if sh > 0 else None, s1, s2, cfg, params)
         if fused:   # LN + bf16 cast + pad + roll + partition in one pass
             xw = layernorm_window_gather(x, self.norm1.weight, self.norm1.bias, self.norm1.eps, B, H, W, ws, sh)
         else:

@@ -52,11 +52,14 @@ int dgx_window_attention_fwd(const void* qkv, const float* table, const int8_t* 
                              void* out, float* lse, int B_, int nW, int nH, int ws, float scale,
                              void* stream);
 
-/* Backward of the above.  dqkv bf16 (B_,N,3,nH,32) is fully overwritten; dtable f32 (nH,(2ws-1)^2)
- * is ACCUMULATED into (caller zeroes it).  `out`/`lse` are the forward results. */
+/* Backward of the above.  dqkv bf16 (B_,N,3,nH,32) is fully overwritten; the bias-table gradient is
+ * ACCUMULATED (atomic fp32 adds) into dtable[h*dtable_stride_head + i*dtable_stride_index], so the
+ * caller can point it at the parameter's own (T, nH) gradient (strides 1, nH) or at a zeroed
+ * (nH, T) scratch (strides T, 1).  `out`/`lse` are the forward results. */
 int dgx_window_attention_bwd(const void* qkv, const float* table, const int8_t* region,
                              const void* out, const float* lse, const void* dout,
-                             void* dqkv, float* dtable, int B_, int nW, int nH, int ws, float scale,
+                             void* dqkv, float* dtable, int64_t dtable_stride_head,
+                             int64_t dtable_stride_index, int B_, int nW, int nH, int ws, float scale,
                              void* stream);
 
 /* ---------------------------------------------------------------------------------------------
@@ -200,14 +203,16 @@ int dgx_linear_wgrad(const void* dy, const void* x, float* gw, int M, int Nn, in
  *   x f32 or bf16 (x_dtype) (T,C) with T = B*H*W;  ws > 0: y bf16 is written in window order (B*nW, ws*ws, C), zero rows
  *   for padding tokens;  ws == 0: y bf16 (T,C).  mean/rstd f32 (T) are saved for backward.
  * Backward: dy bf16 in the same order as y -> dx (x_dtype) (T,C) written; dgamma/dbeta f32 (C) ACCUMULATED;
- *   part: f32 scratch of dgx_layernorm_bwd_blocks(T)*2*C.  C % 4 == 0, C <= 1536 for backward. */
+ *   part: f32 scratch of dgx_layernorm_bwd_blocks(T)*2*C.  C % 4 == 0, C <= 1536 for backward.
+ *   dres (backward, nullable, dtype of x, may alias dx): gradient arriving on the residual branch that
+ *   bypasses the norm (x + f(LN(x)), swintransformer.py:254-255); dx = dres + LN-gradient in one pass. */
 int dgx_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y_bf16, float* mean,
                       float* rstd, int64_t T, int C, float eps, int B, int H, int W, int ws, int shift,
                       int x_dtype, void* stream);
 int dgx_layernorm_bwd_blocks(int64_t T);
 int dgx_layernorm_bwd(const void* dy_bf16, const void* x, const float* mean, const float* rstd,
-                      const float* gamma, void* dx, float* dgamma, float* dbeta, float* part, int64_t T,
-                      int C, int B, int H, int W, int ws, int shift, int x_dtype, void* stream);
+                      const float* gamma, const void* dres, void* dx, float* dgamma, float* dbeta, float* part,
+                      int64_t T, int C, int B, int H, int W, int ws, int shift, int x_dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Residual + DropPath epilogue of a Swin block: out = x + scale[b] * y, y bf16 in token order (ws == 0)
@@ -219,6 +224,13 @@ int dgx_residual_fwd(const void* x, const void* y_bf16, const float* scale, void
                      int C, int ws, int shift, int x_dtype, void* stream);
 int dgx_residual_bwd(const void* g, const float* scale, void* dy_bf16, int B, int H, int W, int C, int ws,
                      int shift, int g_dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Bias gradient of nn.Linear (the sum over rows autograd performs for the bias of qkv/proj/fc1/fc2,
+ * swintransformer.py:36-46,101-108): out[n] = beta*out[n] + sum_m dy[m][n]; dy bf16 (M, N) row-major,
+ * out fp32.  N % 8 == 0.  workspace: dgx_colsum_workspace_bytes(M, N) bytes. */
+int64_t dgx_colsum_workspace_bytes(int M, int N);
+int dgx_colsum_bf16(const void* dy_bf16, float* out, int M, int N, float beta, void* workspace, void* stream);
 
 #ifdef __cplusplus
 }

@@ -387,3 +387,50 @@ def test_residual_droppath_scatter(B, H, W, C, ws, shift, xdt):
             gp = torch.roll(gp, (-shift, -shift), (1, 2))
         gs = OSW.partition(gp, ws)
     torch.testing.assert_close(yd.grad.float().cpu(), bf(gs).float(), atol=1e-2, rtol=1e-2)
+
+
+@pytest.mark.parametrize("M,N", [(1, 8), (37, 200), (8192, 768), (10368, 2304), (5, 1536)])
+def test_colsum_bias_gradient(M, N):
+    """Bias gradient = column sum of the bf16 output gradient, accumulated (beta = 1) in fp32."""
+    from divergen_amd.layers.swin_block import colsum_into
+    g = torch.Generator().manual_seed(91)
+    dy = bf(torch.randn(M, N, generator=g))
+    acc0 = torch.randn(N, generator=g)
+    acc = acc0.clone().to(DEV)
+    colsum_into(acc, dy.to(DEV))
+    ref = acc0.double() + dy.double().sum(0)
+    # fp32 accumulation of exactly-representable bf16 values: error ~ sqrt(M) * 2^-24 * |sum of magnitudes|
+    assert (acc.cpu().double() - ref).abs().max() <= 1e-6 * (dy.double().abs().sum(0).max() + 1)
+    acc2 = acc0.clone().to(DEV)
+    colsum_into(acc2, dy.to(DEV), beta=0.0)
+    assert (acc2.cpu().double() - dy.double().sum(0)).abs().max() <= 1e-6 * (dy.double().abs().sum(0).max() + 1)
+
+
+@pytest.mark.parametrize("xdt", [torch.float32, torch.bfloat16])
+def test_layernorm_bwd_residual_input(xdt):
+    """dx = dres + LN-gradient in one pass, in place (dres aliasing dx) and out of place."""
+    from divergen_amd import _lib as L
+    B, H, W, C, ws, shift = 2, 14, 11, 384, 7, 3
+    g = torch.Generator().manual_seed(93)
+    x = torch.randn(B, H * W, C, generator=g).to(xdt).to(DEV)
+    gam, bet = torch.randn(C, generator=g).to(DEV), torch.randn(C, generator=g).to(DEV)
+    from divergen_amd.layers.norm_ops import layernorm_window_gather
+    xr = x.clone().requires_grad_(True)
+    out = layernorm_window_gather(xr, gam.clone().requires_grad_(True), bet.clone().requires_grad_(True), 1e-5, B, H, W, ws, shift)
+    go = bf(torch.randn(out.shape, generator=g)).to(DEV)
+    out.backward(go)
+    dres = torch.randn(B, H * W, C, generator=g).to(xdt).to(DEV)
+    want = (dres.float() + xr.grad.float())
+    T = B * H * W
+    mean = x.float().mean(-1).reshape(-1).contiguous()
+    rstd = (x.float().var(-1, unbiased=False) + 1e-5).rsqrt().reshape(-1).contiguous()
+    lib = L.lib()
+    part = torch.empty(lib.dgx_layernorm_bwd_blocks(T) * 2 * C, dtype=torch.float32, device=DEV)
+    for inplace in (False, True):
+        dx = dres.clone() if inplace else torch.empty_like(x)
+        src = dx if inplace else dres
+        dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+        L.check(lib.dgx_layernorm_bwd(L.ptr(go), L.ptr(x), L.ptr(mean), L.ptr(rstd), L.ptr(gam), L.ptr(src), L.ptr(dx), L.ptr(dg),
+                                      L.ptr(db), L.ptr(part), T, C, B, H, W, ws, shift, L.dtype_code(x), L.stream()), "ln_bwd")
+        tol = dict(atol=2e-4, rtol=1e-3) if xdt == torch.float32 else dict(atol=6e-2, rtol=2e-2)
+        torch.testing.assert_close(dx.float().cpu(), want.cpu(), **tol)

@@ -203,3 +203,40 @@ def test_fused_optimizer_trajectory_vs_reference_golden(golden):
     for k in sd:
         torch.testing.assert_close(sd[k].cpu(), T(g["final." + k]), atol=2e-6, rtol=2e-5)
         torch.testing.assert_close(ema[k].cpu(), T(g["ema." + k]), atol=1e-6, rtol=1e-5)
+
+
+@pytest.mark.parametrize("xdt,shift", [(torch.float32, 0), (torch.bfloat16, 6), (torch.float32, 6)])
+def test_fused_swin_block_equals_composed_path(xdt, shift, monkeypatch):
+    """The single-node Swin block (divergen_amd/layers/swin_block.py) runs the same kernels in the same order
+    as the composed path: outputs and input gradients must be bitwise equal, parameter gradients equal up to the
+    order of fp32 atomic / split-M additions."""
+    from divergen_amd.modeling.backbone import swintransformer as S
+    from divergen_amd.solver import FlatArena
+    torch.manual_seed(5)
+    dim, nH, ws, B, H, W = 192, 6, 12, 2, 30, 26
+    blk = S.SwinTransformerBlock(dim, nH, window_size=ws, shift_size=shift, drop_path=0.2).to(DEV).train()
+    for p in blk.parameters():
+        torch.nn.init.normal_(p, std=0.05)
+    blk.H, blk.W = H, W
+    arena = FlatArena(blk)
+    from divergen_amd.layers import shift_regions
+    region = shift_regions(H, W, ws).to(DEV) if shift else None
+    x0 = torch.randn(B, H * W, dim, device=DEV).to(xdt)
+    go = torch.randn(B, H * W, dim, device=DEV).to(xdt)
+    res = {}
+    for fused in (True, False):
+        monkeypatch.setattr(S, "_FUSED_BLOCK", fused)
+        arena.zero_grad()
+        torch.manual_seed(11)           # same DropPath draw
+        x = x0.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = blk(x, region)
+        y.backward(go)
+        res[fused] = (y.detach().clone(), x.grad.clone(), arena.g.clone())
+    assert res[True][0].dtype == res[False][0].dtype
+    assert torch.equal(res[True][0], res[False][0])
+    assert torch.equal(res[True][1], res[False][1]) or (res[True][1].float() - res[False][1].float()).abs().max() <= (
+        1e-6 if xdt == torch.float32 else 2e-2) * res[False][1].float().abs().max()
+    ga, gb = res[True][2], res[False][2]
+    assert ga.abs().max() > 0
+    assert (ga - gb).abs().max() <= 2e-3 * gb.abs().max()

@@ -17,7 +17,7 @@ int main(int argc, char** argv) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int it = 0; it < 3; ++it) {
         dgx_window_attention_fwd(qkv, table, nullptr, out, lse, B_, 1, nH, 12, 0.17677f, nullptr);
-        dgx_window_attention_bwd(qkv, table, nullptr, out, lse, dout, dqkv, dtable, B_, 1, nH, 12, 0.17677f, nullptr);
+        dgx_window_attention_bwd(qkv, table, nullptr, out, lse, dout, dqkv, dtable, 529, 1, B_, 1, nH, 12, 0.17677f, nullptr);
     }
     hipDeviceSynchronize();
 #ifdef DIAG_CLOCK
@@ -27,7 +27,7 @@ int main(int argc, char** argv) {
     for (int it = 0; it < iters; ++it) {
         hipEventRecord(e0); dgx_window_attention_fwd(qkv, table, nullptr, out, lse, B_, 1, nH, 12, 0.17677f, nullptr);
         hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1); msf += ms;
-        hipEventRecord(e0); dgx_window_attention_bwd(qkv, table, nullptr, out, lse, dout, dqkv, dtable, B_, 1, nH, 12, 0.17677f, nullptr);
+        hipEventRecord(e0); dgx_window_attention_bwd(qkv, table, nullptr, out, lse, dout, dqkv, dtable, 529, 1, B_, 1, nH, 12, 0.17677f, nullptr);
         hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1); msb += ms;
     }
     printf("B_=%d nH=%d fwd %.1f us bwd %.1f us\n", B_, nH, msf / iters * 1e3, msb / iters * 1e3);

@@ -14,6 +14,12 @@ _lib = None
 
 c_p, c_i, c_f, c_i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
 
+
+class WgradProblem(ctypes.Structure):
+    """struct dgx_wgrad_problem (include/divergen_hip.h)."""
+    _fields_ = [("dy", c_p), ("x", c_p), ("gw", c_p), ("M", c_i), ("Nn", c_i), ("Kk", c_i)]
+
+
 # name -> (restype, argtypes); must list every symbol include/divergen_hip.h declares
 SIGNATURES = {
     "dgx_build_arch": (ctypes.c_char_p, []),
@@ -39,6 +45,8 @@ SIGNATURES = {
     "dgx_layernorm_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "dgx_layernorm_bwd_blocks": (c_i, [c_i64]),
     "dgx_layernorm_bwd": (c_i, [c_p] * 10 + [c_i64, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "dgx_wgrad_grouped_workspace_bytes": (c_i64, [ctypes.POINTER(WgradProblem), c_i]),
+    "dgx_linear_wgrad_grouped": (c_i, [ctypes.POINTER(WgradProblem), c_i, c_f, c_p, c_p]),
     "dgx_colsum_workspace_bytes": (c_i64, [c_i, c_i]),
     "dgx_colsum_bf16": (c_i, [c_p, c_p, c_i, c_i, c_f, c_p, c_p]),
     "dgx_residual_fwd": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),

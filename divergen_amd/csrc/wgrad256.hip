@@ -1,0 +1,320 @@
+// Grouped weight-gradient GEMM for gfx950:  for each problem p:  C_p[Nn][Kk] = beta*C_p + sum_m A_p[m][Nn] * B_p[m][Kk]
+// (A = dY, B = X, row-major bf16; C fp32 in the gradient arena).  One launch covers the (up to 8) weight
+// gradients of a transformer block, so that 256x256 output tiles -- the size at which a CU is MFMA-bound
+// rather than LDS-bound: 64 MFMAs per 32 transpose reads -- still fill the 256 CUs with a SMALL M-split
+// (2-3 slabs instead of 7-28 for one matrix alone); the split's fp32 partial tiles are what a
+// small-output / long-contraction GEMM otherwise drowns in.
+//   workgroup = 4 waves, wave = 128x128 quadrant = 8x8 MFMA 16x16x32 bf16 tiles (256 accumulator
+//   registers), M-depth 64 per stage; both operands sit in LDS exactly as in memory ([m][n], 16-byte
+//   stores, 32-byte row padding = conflict-free ds_read_b64_tr_b16 within a 16-lane group);
+//   double-buffered LDS (2 x 68 KiB), next stage prefetched into registers under the MFMAs.
+//   Partials go to a workspace; a second (also grouped) kernel folds them into the arena.
+#include "dgx_common.h"
+
+namespace {
+constexpr int T256 = 256;               // tile edge
+constexpr int BM256 = 32;               // m-depth per stage (one K=32 MFMA step)
+constexpr int NB256 = 4;                // LDS stage buffers: the stage being computed + 3 in flight
+constexpr int OPB256 = BM256 * T256 * 2;       // bytes of one operand image per stage (16 KiB)
+constexpr int STB256 = 2 * OPB256;             // bytes per stage (A then B)
+constexpr int MAXP256 = 8;
+
+struct Prob256 {
+    const uint16_t* A;
+    const uint16_t* B;
+    float* C;
+    float* ws;          // partial tiles [S][Nn][Kk]
+    int M, Nn, Kk, tiles_k, tiles, S, slab, wg0;
+    int64_t red0;       // first float4 of this problem in the reduce kernel's index space
+};
+struct Params256 {
+    Prob256 p[MAXP256];
+    int n, total, per_xcd;
+    float beta;
+};
+
+// 16 bytes per lane from a raw buffer straight into LDS (no staging registers): lane i of the wave lands at
+// lds_wave_base + 16*i.  Out-of-range lanes (voff >= num_records) do not touch memory.  The caller orders the
+// data with s_waitcnt vmcnt + barrier; the compiler does not track these loads.
+__device__ __forceinline__ void buffer_load_lds16(uint32_t voff, u32x4 rsrc, uint32_t lds_wave_base) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(voff), "s"(rsrc), "s"(lds_wave_base)
+                 : "memory");
+}
+__device__ __forceinline__ u32x4 make_rsrc(const void* base, uint32_t bytes) {
+    const uint64_t a = (uint64_t)base;
+    return u32x4{(uint32_t)a, (uint32_t)(a >> 32) & 0xffffu, bytes, 0x00020000u};
+}
+// MFMA with the accumulator pinned to the AGPR half of the register file: 256 accumulator registers + two
+// fragment sets do not fit the 256 architectural VGPRs, and left to itself the allocator shuttles accumulator
+// tiles between the two halves around every MFMA.  Each accumulator is touched once per 64 MFMAs, far beyond
+// the MFMA->SrcC hazard window, so no software wait states are needed inside the loop.
+__device__ __forceinline__ void mfma16_agpr(f32x4& c, bf16x8 a, bf16x8 b) {
+    asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+}  // namespace
+
+#ifdef DIAG_CLOCK
+__device__ unsigned long long w256_clk[8];
+#define WCLK(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long t__ = clock64(); w256_clk[i] += t__ - tprev; tprev = t__; } } while (0)
+#else
+#define WCLK(i)
+#endif
+// LDS image of one operand stage: [32 rows (m)][256 columns] bf16, 512-byte rows, NO padding (a wave-wide
+// LDS-direct load writes 1 KiB = two whole rows).  Bank conflicts of the transpose reads (4 consecutive rows,
+// same columns) are removed by an XOR swizzle of the 16-byte chunk index:  physical = logical ^ ((row & 3) << 1).
+__global__ __launch_bounds__(256) void wgrad256_partial_kernel(Params256 P) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds_raw[];   // [NB256][A|B][32][512 B]
+    // XCD-aware order: workgroups that share an XCD (blockIdx % 8, one L2 each) take CONSECUTIVE logical ids =
+    // neighbouring tiles of one (problem, slab), i.e. they stream the same dY / X panels through that L2
+    const int L = (blockIdx.x & 7) * P.per_xcd + (blockIdx.x >> 3);
+    if (L >= P.total) return;
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < MAXP256; ++i)
+        if (i < P.n && L >= P.p[i].wg0) pi = i;
+    const Prob256 q = P.p[pi];
+    const int local = L - q.wg0;
+    const int s = local / q.tiles, tile = local - s * q.tiles;
+#ifdef DIAG_SAMEPANEL   // every workgroup streams the same two panels: isolates the CU-side limit from L2 / fabric
+    const int n0 = 0, k0 = 0;
+    const int m_begin = 0, m_end = min(q.M, q.slab);
+#else
+    const int n0 = (tile / q.tiles_k) * T256, k0 = (tile % q.tiles_k) * T256;
+    const int m_begin = s * q.slab, m_end = min(q.M, m_begin + q.slab);
+#endif
+    const int nst = (m_end - m_begin + BM256 - 1) / BM256;
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, g = l >> 4, c16 = l & 15;
+    const int wn = (w >> 1) * 128, wk = (w & 1) * 128;    // this wave's quadrant
+
+    // ---- loader role: load j (0..3) of a stage brings rows 2*(4j + w), +1 of each operand; this lane's slot is
+    // row-in-pair l >> 5, physical chunk l & 31, i.e. logical chunk (l & 31) ^ ((row & 3) << 1), row & 3 = 2*(w&1) + (l>>5)
+    const int rip = l >> 5;
+    const int lc = (l & 31) ^ (((2 * (w & 1) + rip) & 3) << 1);
+    const uint32_t OOB = 0x80000000u;
+    const uint32_t vA = (n0 + 8 * lc < q.Nn) ? (uint32_t)(((2 * w + rip) * q.Nn + n0 + 8 * lc) * 2) : OOB;
+    const uint32_t vB = (k0 + 8 * lc < q.Kk) ? (uint32_t)(((2 * w + rip) * q.Kk + k0 + 8 * lc) * 2) : OOB;
+    const u32x4 rA = make_rsrc(q.A, (uint32_t)((int64_t)m_end * q.Nn * 2));   // rows >= m_end are out of range
+    const u32x4 rB = make_rsrc(q.B, (uint32_t)((int64_t)m_end * q.Kk * 2));
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(DGX_LDS unsigned char*)lds_raw;
+    const uint32_t ldsw = __builtin_amdgcn_readfirstlane(lds0 + 1024u * w);
+    // one LDS-direct load (16 B per lane, 1 KiB per wave) of stage st: h = 0..3 -> A rows 8h.., h = 4..7 -> B rows 8(h-4)..
+    auto issue1 = [&](int st, int h) {
+        const uint32_t row0 = (uint32_t)(m_begin + st * BM256);
+        const uint32_t dst = ldsw + (uint32_t)(st & (NB256 - 1)) * STB256;
+        const int j = h & 3;
+        if (h < 4) buffer_load_lds16(vA + (row0 + 8 * j) * (uint32_t)(q.Nn * 2), rA, dst + 4096u * j);
+        else buffer_load_lds16(vB + (row0 + 8 * j) * (uint32_t)(q.Kk * 2), rB, dst + OPB256 + 4096u * j);
+    };
+    auto issue = [&](int st) {
+#pragma unroll
+        for (int h = 0; h < 8; ++h) issue1(st, h);
+    };
+
+    // ---- MFMA role: fragment i = 4a + b of an operand = columns base + 16 i .. +15, k-slots = rows 8g .. 8g+7.
+    // Lane p (= c16) reads row 8g + (p >> 2) (+4), 8-byte piece (p & 3) of the 16 columns; under the swizzle
+    // that is physical byte  row*512 + colbase*2 + 32*(i ^ x) + 16*hi + 8*lo,  x = p >> 2, hi = (p>>1)&1, lo = p&1;
+    // i ^ x = 4a + (b ^ x): four lane-dependent bases per operand, everything else is an immediate.
+    const int x = c16 >> 2, hi = (c16 >> 1) & 1, lo = c16 & 1;
+    uint32_t fa[4], fb[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const uint32_t o = (uint32_t)((8 * g + x) * 512 + 32 * (b ^ x) + 16 * hi + 8 * lo);
+        fa[b] = o + wn * 2;
+        fb[b] = OPB256 + o + wk * 2;
+    }
+
+    f32x4 acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // Software pipeline: while the MFMAs of stage st run out of registers, the transpose reads of stage st+1
+    // fill the other fragment set and the LDS-direct loads of stages st+2 .. st+4 are in flight.
+    auto read_frag = [&](int st, int f, bf16x8 (&af)[8], bf16x8 (&bfr)[8]) {   // f = 0..7: A fragment f, 8..15: B fragment f-8
+        DGX_LDS const unsigned char* sb = (DGX_LDS const unsigned char*)lds_raw + (st & (NB256 - 1)) * STB256;
+        const int i = f & 7;
+        if (f < 8) af[i] = tr_frag(reinterpret_cast<DGX_LDS const uint16_t*>(sb + fa[i & 3]), 64 * (i >> 2), 64 * (i >> 2) + 4 * 256);
+        else bfr[i] = tr_frag(reinterpret_cast<DGX_LDS const uint16_t*>(sb + fb[i & 3]), 64 * (i >> 2), 64 * (i >> 2) + 4 * 256);
+    };
+    auto read_frags = [&](int st, bf16x8 (&af)[8], bf16x8 (&bfr)[8]) {
+#pragma unroll
+        for (int f = 0; f < 16; ++f) read_frag(st, f, af, bfr);
+    };
+    auto mfmas = [&](const bf16x8 (&af)[8], const bf16x8 (&bfr)[8]) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) mfma16_agpr(acc[i][j], af[i], bfr[j]);
+    };
+    // One pipeline step.  Stage st+1 must have landed for everyone; then, in 16 groups pinned by scheduling
+    // barriers, the wave issues {a global->LDS load of stage st+4 (every other group), the two transpose reads of
+    // one fragment of stage st+1, four MFMAs of stage st}.  The three pipes (TA 64 B/clk, LDS, MFMA) are fed at
+    // their own rates; issued in bulk, the loads and reads fill their queues and stall the wave's MFMA issue.
+    auto step = [&](int st, const bf16x8 (&caf)[8], const bf16x8 (&cbf)[8], bf16x8 (&naf)[8], bf16x8 (&nbf)[8]) {
+        wait_vmcnt<16>();                                      // own loads of stage st+1 done (st+2, st+3 may fly)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // own LDS reads of stage st done before its buffer is recycled
+        __syncthreads();
+#pragma unroll
+        for (int gq = 0; gq < 16; ++gq) {
+            if ((gq & 1) == 0) issue1(st + 4, gq >> 1);        // into the buffer stage st used
+            read_frag(st + 1, gq, naf, nbf);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = 4 * gq + u;
+                mfma16_agpr(acc[e >> 3][e & 7], caf[e >> 3], cbf[e & 7]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    bf16x8 af0[8], bf0[8], af1[8], bf1[8];
+    issue(0);
+    issue(1);
+    issue(2);
+    issue(3);
+    wait_vmcnt<24>();
+    __syncthreads();
+    read_frags(0, af0, bf0);
+    int st = 0;
+    for (; st + 2 <= nst; st += 2) {
+        step(st, af0, bf0, af1, bf1);
+        step(st + 1, af1, bf1, af0, bf0);
+    }
+    if (st < nst) mfmas(af0, bf0);   // odd stage count: the last stage's fragments are already in registers
+    wait_vmcnt<0>();
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // last MFMA -> accumulator read-out hazard
+    // unsplit problems (S == 1) fold straight into the gradient; split ones leave a partial tile for the reduce kernel
+    const bool direct = q.S == 1;
+    float* out = direct ? q.C : q.ws + (int64_t)s * q.Nn * q.Kk;
+    const float beta = direct ? P.beta : 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = n0 + wn + 16 * i + 4 * g + r;
+            if (n >= q.Nn) continue;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = k0 + wk + 16 * j + c16;
+                if (k < q.Kk) {
+                    float* o = out + (int64_t)n * q.Kk + k;
+                    *o = beta != 0.f ? beta * *o + acc[i][j][r] : acc[i][j][r];
+                }
+            }
+        }
+}
+
+__global__ __launch_bounds__(256) void wgrad256_reduce_kernel(Params256 P, int64_t total4) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
+        int pi = 0;
+#pragma unroll
+        for (int k = 1; k < MAXP256; ++k)
+            if (k < P.n && P.p[k].S > 1 && i >= P.p[k].red0) pi = k;
+        const Prob256& q = P.p[pi];
+        const int64_t e = i - q.red0, n4 = (int64_t)q.Nn * q.Kk / 4;
+        const float4* ws = reinterpret_cast<const float4*>(q.ws);
+        float4 a = {0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < q.S; ++s) {
+            const float4 v = ws[(int64_t)s * n4 + e];
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        float4* C = reinterpret_cast<float4*>(q.C);
+        if (P.beta != 0.f) {
+            const float4 c = C[e];
+            a.x += P.beta * c.x; a.y += P.beta * c.y; a.z += P.beta * c.z; a.w += P.beta * c.w;
+        }
+        C[e] = a;
+    }
+}
+
+// rows per workgroup R (multiple of BM256) such that sum_p tiles_p * ceil(M_p / R) fits one round of 256 workgroups
+static void plan256(const dgx_wgrad_problem* pr, int n, int* S, int* slab) {
+    int tiles[MAXP256], maxM = 0;
+    for (int i = 0; i < n; ++i) {
+        tiles[i] = ((pr[i].Nn + T256 - 1) / T256) * ((pr[i].Kk + T256 - 1) / T256);
+        if (pr[i].M > maxM) maxM = pr[i].M;
+    }
+    int R = BM256;
+    for (;; R += BM256) {
+        int64_t wgs = 0;
+        for (int i = 0; i < n; ++i) wgs += (int64_t)tiles[i] * ((pr[i].M + R - 1) / R);
+        if (wgs <= 256 || R >= maxM) break;
+    }
+    for (int i = 0; i < n; ++i) {
+        S[i] = (pr[i].M + R - 1) / R;
+        if (S[i] < 1) S[i] = 1;
+        int sl = (pr[i].M + S[i] - 1) / S[i];
+        slab[i] = (sl + BM256 - 1) / BM256 * BM256;
+    }
+}
+
+static int64_t ws_floats256(const dgx_wgrad_problem* pr, int n, const int* S, int64_t* off) {
+    int64_t tot = 0;
+    for (int i = 0; i < n; ++i) {
+        if (off) off[i] = tot;
+        if (S[i] > 1) tot += (int64_t)S[i] * pr[i].Nn * pr[i].Kk;
+    }
+    return tot;
+}
+
+extern "C" int64_t dgx_wgrad_grouped_workspace_bytes(const dgx_wgrad_problem* problems, int n) {
+    if (!problems || n <= 0 || n > MAXP256) return 0;
+    int S[MAXP256], slab[MAXP256];
+    plan256(problems, n, S, slab);
+    return ws_floats256(problems, n, S, nullptr) * 4;
+}
+
+extern "C" int dgx_linear_wgrad_grouped(const dgx_wgrad_problem* problems, int n, float beta, void* workspace,
+                                        void* stream) {
+    if (n <= 0) return DGX_OK;
+    if (!problems || n > MAXP256) return DGX_ERR_BAD_ARG;
+    for (int i = 0; i < n; ++i) {
+        const dgx_wgrad_problem& p = problems[i];
+        if (!p.dy || !p.x || !p.gw || p.M <= 0 || p.Nn <= 0 || p.Kk <= 0 || (p.Nn & 7) || (p.Kk & 7)) return DGX_ERR_BAD_ARG;
+        if ((int64_t)p.M * p.Nn * 2 >= (1ll << 31) || (int64_t)p.M * p.Kk * 2 >= (1ll << 31)) return DGX_ERR_UNSUPPORTED;
+    }
+    int S[MAXP256], slab[MAXP256];
+    int64_t off[MAXP256];
+    plan256(problems, n, S, slab);
+    ws_floats256(problems, n, S, off);
+    Params256 P;
+    P.n = n;
+    P.beta = beta;
+    int wg = 0;
+    int64_t red = 0;
+    for (int i = 0; i < n; ++i) {
+        const dgx_wgrad_problem& p = problems[i];
+        Prob256& q = P.p[i];
+        q.A = (const uint16_t*)p.dy;
+        q.B = (const uint16_t*)p.x;
+        q.C = p.gw;
+        q.ws = (float*)workspace + off[i];
+        q.M = p.M; q.Nn = p.Nn; q.Kk = p.Kk;
+        q.tiles_k = (p.Kk + T256 - 1) / T256;
+        q.S = S[i];
+        q.slab = slab[i];
+        q.tiles = ((p.Nn + T256 - 1) / T256) * q.tiles_k;
+        q.wg0 = wg;
+        q.red0 = red;
+        wg += q.tiles * S[i];
+        if (S[i] > 1) red += (int64_t)p.Nn * p.Kk / 4;   // unsplit problems are finished by the GEMM kernel itself
+    }
+    for (int i = n; i < MAXP256; ++i) P.p[i] = P.p[0];
+    hipStream_t st = (hipStream_t)stream;
+    const size_t sm = (size_t)NB256 * STB256;
+    static bool once = false;
+    if (!once) {
+        (void)hipFuncSetAttribute((const void*)wgrad256_partial_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+        once = true;
+    }
+    P.total = wg;
+    P.per_xcd = (wg + 7) / 8;
+    hipLaunchKernelGGL(wgrad256_partial_kernel, dim3(8 * P.per_xcd), dim3(256), sm, st, P);
+    if (red > 0) {
+        const int grid = (int)((red + 255) / 256 < 8192 ? (red + 255) / 256 : 8192);
+        hipLaunchKernelGGL(wgrad256_reduce_kernel, dim3(grid), dim3(256), 0, st, P, red);
+    }
+    DGX_LAUNCH_CHECK();
+    return DGX_OK;
+}

@@ -31,6 +31,22 @@ def wgrad_into(g2, dy2, x2, beta=1.0):
         torch.addmm(g2, dy2.t(), x2, out_dtype=torch.float32, out=g2)
 
 
+def wgrad_grouped(problems, beta=1.0):
+    """[(g2 fp32 (Nn,Kk), dy2 bf16 (M,Nn), x2 bf16 (M,Kk)), ...] (<= 8): g2 = beta*g2 + dy2^T x2, ONE launch
+    (dgx_linear_wgrad_grouped: 256x256 MFMA tiles, M-split sized for the whole group)."""
+    n = len(problems)
+    arr = (L.WgradProblem * n)()
+    for i, (g2, dy2, x2) in enumerate(problems):
+        assert g2.is_contiguous() and dy2.is_contiguous() and x2.is_contiguous()
+        assert dy2.dtype == BF16 and x2.dtype == BF16 and g2.dtype == torch.float32
+        arr[i].dy, arr[i].x, arr[i].gw = dy2.data_ptr(), x2.data_ptr(), g2.data_ptr()
+        arr[i].M, arr[i].Nn, arr[i].Kk = dy2.shape[0], dy2.shape[1], x2.shape[1]
+    lib = L.lib()
+    nbytes = int(lib.dgx_wgrad_grouped_workspace_bytes(arr, n))
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=problems[0][1].device)
+    L.check(lib.dgx_linear_wgrad_grouped(arr, n, float(beta), L.ptr(ws), L.stream()), "dgx_linear_wgrad_grouped")
+
+
 def shadow(p):
     """bf16 view of a parameter: the arena shadow if present, else a cast (CPU tests, pre-arena)."""
     s = getattr(p, "_dgx16", None)

@@ -16,7 +16,7 @@ composed path in swintransformer.py, which runs the same kernels in the same ord
 import torch
 
 from .. import _lib as L
-from .linear_ops import BF16, shadow, wgrad_into
+from .linear_ops import BF16, shadow, wgrad_grouped
 
 
 def arena_resident(params):
@@ -39,14 +39,13 @@ def colsum_into(gb, dy2, beta=1.0):
     L.check(lib.dgx_colsum_bf16(L.ptr(dy2), L.ptr(gb), M, N, float(beta), L.ptr(ws), L.stream()), "dgx_colsum_bf16")
 
 
-def _linear_bwd(dy2, x2, weight, bias, w16):
-    """Gradients of y = x W^T + b into the arena; returns dx (bf16)."""
-    wgrad_into(weight.grad.view(weight.shape[0], -1), dy2, x2)
+def _linear_bwd(dy2, x2, weight, bias, w16, wgrads):
+    """Bias gradient of y = x W^T + b into the arena, weight gradient queued for the block's grouped
+    weight-gradient launch; returns dx (bf16)."""
+    wgrads.append((weight.grad.view(weight.shape[0], -1), dy2, x2))
     if bias is not None:
         colsum_into(bias.grad, dy2)
-        _ready(weight, bias)
-    else:
-        _ready(weight)
+        _ready(bias)
     return torch.mm(dy2, w16)
 
 
@@ -117,9 +116,10 @@ class _SwinBlockFn(torch.autograd.Function):
         # MLP branch
         df2 = torch.empty(T, C, dtype=BF16, device=dev)
         L.check(lib.dgx_residual_bwd(g.data_ptr(), L.ptr(s2), df2.data_ptr(), B, H, W, C, 0, 0, code, st), "dgx_residual_bwd")
-        da = _linear_bwd(df2, a, w2, b2, w216)
+        wgrads = []
+        da = _linear_bwd(df2, a, w2, b2, w216, wgrads)
         df1 = torch.ops.aten.gelu_backward(da, f1)
-        dh2 = _linear_bwd(df1, h2, w1, b1, w116)
+        dh2 = _linear_bwd(df1, h2, w1, b1, w116, wgrads)
         # LN2 backward + the residual-branch gradient g -> dx1
         nblk = lib.dgx_layernorm_bwd_blocks(T)
         part = torch.empty(nblk * 2 * C, dtype=torch.float32, device=dev)
@@ -132,18 +132,21 @@ class _SwinBlockFn(torch.autograd.Function):
         dpr = torch.empty(Tw, C, dtype=BF16, device=dev)
         L.check(lib.dgx_residual_bwd(dx1.data_ptr(), L.ptr(s1), dpr.data_ptr(), B, H, W, C, ws, shift, code, st),
                 "dgx_residual_bwd")
-        do = _linear_bwd(dpr, o, pw, pb, pw16)
+        do = _linear_bwd(dpr, o, pw, pb, pw16, wgrads)
         dqkv = torch.empty_like(qkv)
         L.check(lib.dgx_window_attention_bwd(qkv.data_ptr(), tableT.data_ptr(), L.ptr(region), o.data_ptr(), lse.data_ptr(),
                                              do.data_ptr(), dqkv.data_ptr(), table.grad.data_ptr(), 1, nH, B_, nW, nH, ws,
                                              scale, st), "dgx_window_attention_bwd")
         _ready(table)
-        dxw = _linear_bwd(dqkv, xw, qw, qb, qw16)
+        dxw = _linear_bwd(dqkv, xw, qw, qb, qw16, wgrads)
         # LN1 backward through the window map, accumulated onto dx1 in place
         L.check(lib.dgx_layernorm_bwd(dxw.data_ptr(), x.data_ptr(), mean1.data_ptr(), rstd1.data_ptr(), n1w.data_ptr(),
                                       dx1.data_ptr(), dx1.data_ptr(), n1w.grad.data_ptr(), n1b.grad.data_ptr(), part.data_ptr(),
                                       T, C, B, H, W, ws, shift, code, st), "dgx_layernorm_bwd")
         _ready(n1w, n1b)
+        # the four weight gradients of the block: one grouped launch (256x256 tiles, small M-split)
+        wgrad_grouped(wgrads)
+        _ready(w2, w1, pw, qw)
         return (dx1,) + (None,) * 17
 
 

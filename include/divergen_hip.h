@@ -226,6 +226,21 @@ int dgx_residual_bwd(const void* g, const float* scale, void* dy_bf16, int B, in
                      int shift, int g_dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Grouped form of dgx_linear_wgrad: the weight gradients of several Linear layers (the four of a Swin
+ * block: qkv/proj/fc1/fc2, swintransformer.py:101-108,36-46) in ONE launch, so that large output tiles
+ * fill the GPU with a small M-split.  n <= 8 problems; for each gw (Nn,Kk) = beta*gw + dy^T x.
+ * Nn % 8 == 0, Kk % 8 == 0.  workspace: dgx_wgrad_grouped_workspace_bytes(problems, n) bytes. */
+typedef struct dgx_wgrad_problem {
+    const void* dy;   /* bf16 (M, Nn) row-major */
+    const void* x;    /* bf16 (M, Kk) row-major */
+    float* gw;        /* f32 (Nn, Kk) */
+    int M, Nn, Kk;
+} dgx_wgrad_problem;
+int64_t dgx_wgrad_grouped_workspace_bytes(const dgx_wgrad_problem* problems, int n);
+int dgx_linear_wgrad_grouped(const dgx_wgrad_problem* problems, int n, float beta, void* workspace,
+                             void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Bias gradient of nn.Linear (the sum over rows autograd performs for the bias of qkv/proj/fc1/fc2,
  * swintransformer.py:36-46,101-108): out[n] = beta*out[n] + sum_m dy[m][n]; dy bf16 (M, N) row-major,
  * out fp32.  N % 8 == 0.  workspace: dgx_colsum_workspace_bytes(M, N) bytes. */

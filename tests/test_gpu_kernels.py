@@ -434,3 +434,29 @@ def test_layernorm_bwd_residual_input(xdt):
                                       L.ptr(db), L.ptr(part), T, C, B, H, W, ws, shift, L.dtype_code(x), L.stream()), "ln_bwd")
         tol = dict(atol=2e-4, rtol=1e-3) if xdt == torch.float32 else dict(atol=6e-2, rtol=2e-2)
         torch.testing.assert_close(dx.float().cpu(), want.cpu(), **tol)
+
+
+@pytest.mark.parametrize("shapes", [
+    [(8192, 768, 3072), (8192, 3072, 768), (10368, 768, 768), (10368, 2304, 768)],     # Swin-L stage 2 block
+    [(100, 192, 264), (8192, 40, 768), (4000, 768, 776)],                                # ragged: partial stages / tiles
+    [(2048, 1536, 1536)],                                                                # unsplit (S == 1): direct epilogue
+    [(33, 8, 8)],
+])
+def test_linear_wgrad_grouped(shapes):
+    """Grouped 256x256 weight-gradient kernel: gw = beta*gw + dy^T x per problem, fp32 accumulation."""
+    from divergen_amd.layers.linear_ops import wgrad_grouped
+    g = torch.Generator().manual_seed(97)
+    probs, refs = [], []
+    for (M, Nn, Kk) in shapes:
+        dy, x = bf(torch.randn(M, Nn, generator=g) * 0.5), bf(torch.randn(M, Kk, generator=g) * 0.5)
+        g0 = torch.randn(Nn, Kk, generator=g)
+        refs.append(g0.double() + dy.double().t() @ x.double())
+        probs.append((g0.clone().to(DEV), dy.to(DEV), x.to(DEV)))
+    wgrad_grouped(probs, beta=1.0)
+    for (gw, _, _), ref in zip(probs, refs):
+        # bf16 products are exact in fp32; only the fp32 summation order differs
+        assert (gw.cpu().double() - ref).abs().max() <= 2e-5 * ref.abs().max() + 1e-3
+    wgrad_grouped(probs, beta=0.0)
+    for (gw, dy, x), ref in zip(probs, refs):
+        ref0 = dy.cpu().double().t() @ x.cpu().double()
+        assert (gw.cpu().double() - ref0).abs().max() <= 2e-5 * ref0.abs().max() + 1e-3

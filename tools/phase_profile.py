@@ -1,0 +1,63 @@
+"""Dev helper: torch-profiler kernel table for ONE phase of the step (fwd_bb | fwd_heads | backward)."""
+import sys
+import torch
+sys.path.insert(0, ".")
+from torch.profiler import ProfilerActivity, profile
+from divergen_amd.config import get_cfg
+from divergen_amd.data import synthetic_batch
+from divergen_amd.modeling import build_model
+from divergen_amd.solver import build_optimizer
+from divergen_amd.utils.events import EventStorage
+
+phase = sys.argv[1] if len(sys.argv) > 1 else "backward"
+cfg = get_cfg()
+cfg.merge_from_file("tests/configs/DiverGen_swinL.yaml")
+cfg.merge_from_list(["MODEL.ROI_BOX_HEAD.CAT_FREQ_PATH", "tests/configs/metadata/ImageNet2012_filtered04_lvis_v1_train_cat_info_250.json"])
+torch.manual_seed(42)
+model = build_model(cfg).train()
+opt = build_optimizer(cfg, model)
+batch = synthetic_batch(2, 1024, cfg.MODEL.ROI_HEADS.NUM_CLASSES, device="cuda")
+
+
+def run(prof_phase=None):
+    ctx = {}
+
+    def P(name):
+        if prof_phase == name:
+            torch.cuda.synchronize()
+            ctx["p"] = profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA])
+            ctx["p"].__enter__()
+
+    def Q(name):
+        if prof_phase == name:
+            torch.cuda.synchronize()
+            ctx["p"].__exit__(None, None, None)
+    opt.zero_grad()
+    images = model.preprocess_image(batch)
+    gt = [x["instances"] for x in batch]
+    P("fwd_bb"); feats = model._features(images); Q("fwd_bb")
+    P("fwd_heads")
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        props, pl = model.proposal_generator(images, feats, gt)
+        props, dl = model.roi_heads(images, feats, props, gt)
+    total = sum(pl.values()) + sum(dl.values())
+    Q("fwd_heads")
+    P("backward"); total.backward(); Q("backward")
+    opt.step()
+    return ctx.get("p")
+
+
+with EventStorage(0):
+    for _ in range(3):
+        run()
+    prof = run(phase)
+rows = [e for e in prof.key_averages() if e.self_device_time_total > 0]
+rows.sort(key=lambda e: -e.self_device_time_total)
+tot = sum(e.self_device_time_total for e in rows)
+print("phase %s: device time %.2f ms, %d kernel launches" % (phase, tot / 1e3, sum(e.count for e in rows)))
+for e in rows[:45]:
+    print("%8.3f ms  n=%4d  avg %7.1f us  %s" % (e.self_device_time_total / 1e3, e.count, e.self_device_time_total / e.count, e.key[:130]))
+rows = sorted(prof.key_averages(), key=lambda e: -e.self_cpu_time_total)
+print("--- host side: total self cpu %.2f ms" % (sum(e.self_cpu_time_total for e in rows) / 1e3))
+for e in rows[:40]:
+    print("%8.3f ms  n=%4d  avg %7.1f us  %s" % (e.self_cpu_time_total / 1e3, e.count, e.self_cpu_time_total / e.count, e.key[:100]))

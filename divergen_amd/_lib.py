@@ -35,6 +35,8 @@ SIGNATURES = {
     "dgx_mask_crop": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "dgx_nms_sorted": (c_i, [c_p, c_i, c_f, c_p, c_p, c_p, c_p]),
     "dgx_nms_workspace_words": (c_i64, [c_i]),
+    "dgx_nms_batched_workspace_words": (c_i64, [c_i, c_i]),
+    "dgx_nms_batched": (c_i, [c_p, c_p, c_p, c_i, c_i, c_f, c_i, c_p, c_p, c_i, c_p, c_p]),
     "dgx_iou_match": (c_i, [c_p, c_i, c_p, c_i, c_f, c_p, c_p, c_p, c_p]),
     "dgx_centernet_targets": (c_i, [c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_f, c_f, c_p, c_p, c_p]),
     "dgx_copy_paste": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p]),

@@ -116,6 +116,148 @@ extern "C" int dgx_nms_sorted(const float* boxes, int n, float iou_thr, uint64_t
     return DGX_OK;
 }
 
+// ---- batched NMS with device-resident counts --------------------------------------------------
+// Same arithmetic as above for B images at once; the number of candidates per image is read from device
+// memory (no host round trip), the sweep stops at max_keep (+ score ties) and emits the kept indices
+// compacted in score order.
+__global__ __launch_bounds__(64) void nms_mask_batched_kernel(const float* __restrict__ boxes_all, const int32_t* __restrict__ n_valid,
+                                                              int K, float thr, int nb, uint64_t* __restrict__ mask_all) {
+    const int rb = blockIdx.y, cb = blockIdx.x, b = blockIdx.z;
+    const int n = min(n_valid[b], K);
+    if (cb < rb || 64 * cb >= n) return;
+    const float* boxes = boxes_all + (int64_t)b * K * 4;
+    uint64_t* mask = mask_all + (int64_t)b * K * nb;
+    __shared__ float cbx[64 * 4];
+    const int l = threadIdx.x;
+    const int cj = 64 * cb + l;
+    if (cj < n) {
+        cbx[4 * l + 0] = boxes[4 * cj + 0];
+        cbx[4 * l + 1] = boxes[4 * cj + 1];
+        cbx[4 * l + 2] = boxes[4 * cj + 2];
+        cbx[4 * l + 3] = boxes[4 * cj + 3];
+    }
+    __syncthreads();
+    const int i = 64 * rb + l;
+    if (i >= n) return;
+    const float ix1 = boxes[4 * i], iy1 = boxes[4 * i + 1], ix2 = boxes[4 * i + 2], iy2 = boxes[4 * i + 3];
+    const float iarea = (ix2 - ix1) * (iy2 - iy1);
+    const int cols = min(64, n - 64 * cb);
+    uint64_t bits = 0;
+    for (int j = (rb == cb ? l + 1 : 0); j < cols; ++j) {
+        const float jx1 = cbx[4 * j], jy1 = cbx[4 * j + 1], jx2 = cbx[4 * j + 2], jy2 = cbx[4 * j + 3];
+        const float jarea = (jx2 - jx1) * (jy2 - jy1);
+        const float xx1 = fmaxf(ix1, jx1), yy1 = fmaxf(iy1, jy1);
+        const float xx2 = fminf(ix2, jx2), yy2 = fminf(iy2, jy2);
+        const float w = fmaxf(0.0f, xx2 - xx1), h = fmaxf(0.0f, yy2 - yy1);
+        const float inter = w * h;
+        const float ovr = inter / (iarea + jarea - inter);
+        if (ovr > thr) bits |= 1ull << j;
+    }
+    mask[(int64_t)i * nb + cb] = bits;
+}
+
+__device__ __forceinline__ uint64_t uniform64(uint64_t v) {
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t readlane64(uint64_t v, int lane) {
+    const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)v, lane), hi = __builtin_amdgcn_readlane((uint32_t)(v >> 32), lane);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// One workgroup per image.  Inside a 64-box block the survivors are found by a SCALAR loop over the kept
+// boxes only (find-first-set on the alive word, readlane of that row's diagonal word); then all threads OR
+// the kept rows into the running "removed" vector in LDS.
+__global__ __launch_bounds__(1024) void nms_sweep_batched_kernel(const uint64_t* __restrict__ mask_all, const float* __restrict__ scores_all,
+                                                                 const int32_t* __restrict__ n_valid, int K, int nb, int max_keep,
+                                                                 int32_t* __restrict__ keep_idx_all, int cap, int32_t* __restrict__ num_keep) {
+    extern __shared__ uint64_t remv[];  // [nb]
+    __shared__ int kept_rows[64];
+    __shared__ int kept_n, total, done;
+    __shared__ float tie_score;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int n = min(n_valid[b], K);
+    const int nbv = (n + 63) / 64;
+    const uint64_t* mask = mask_all + (int64_t)b * K * nb;
+    const float* scores = scores_all ? scores_all + (int64_t)b * K : nullptr;
+    int32_t* keep_idx = keep_idx_all + (int64_t)b * cap;
+    for (int i = tid; i < nb; i += blockDim.x) remv[i] = 0;
+    for (int i = tid; i < cap; i += blockDim.x) keep_idx[i] = -1;
+    if (tid == 0) { total = 0; done = 0; tie_score = 0.f; }
+    __syncthreads();
+    for (int blk = 0; blk < nbv; ++blk) {
+        if (tid < 64) {
+            const int cnt = min(64, n - 64 * blk);
+            const uint64_t mine = tid < cnt ? mask[(int64_t)(64 * blk + tid) * nb + blk] : 0ull;
+            const uint64_t vbits = cnt == 64 ? ~0ull : ((1ull << cnt) - 1ull);
+            uint64_t alive = uniform64(~remv[blk] & vbits);
+            const int tot = __builtin_amdgcn_readfirstlane(total);
+            float tie = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, tie_score)));
+            int k = 0, stop = 0;
+            while (alive) {
+                const int j = __builtin_ctzll(alive);
+                const int idx = 64 * blk + j;
+                if (max_keep > 0 && tot + k >= max_keep) {
+                    // quota reached: only boxes tied with the max_keep-th kept score are still eligible
+                    // (the reference keeps every survivor with score >= the k-th score, centernet.py:727-731)
+                    if (!scores || scores[idx] != tie) { stop = 1; break; }
+                }
+                if (tid == 0) {
+                    kept_rows[k] = idx;
+                    if (tot + k < cap) keep_idx[tot + k] = idx;
+                }
+                ++k;
+                if (max_keep > 0 && scores && tot + k == max_keep) tie = scores[idx];
+                alive &= ~(readlane64(mine, j) | (1ull << j));
+            }
+            if (max_keep > 0 && !scores && tot + k >= max_keep) stop = 1;
+            if (tid == 0) { kept_n = k; total = tot + k; done = stop; tie_score = tie; }
+        }
+        __syncthreads();
+        const int kn = kept_n;
+        if (done) break;
+        const int ncols = nbv - blk - 1;
+        if (ncols > 0 && kn > 0) {
+            int G = blockDim.x / ncols;
+            G = G < 1 ? 1 : (G > 8 ? 8 : G);
+            for (int idx = tid; idx < ncols * G; idx += blockDim.x) {
+                const int grp = idx / ncols, cb = blk + 1 + (idx - grp * ncols);
+                uint64_t acc = 0;
+                int k = grp;
+                for (; k + 3 * G < kn; k += 4 * G) {
+                    const uint64_t a0 = mask[(int64_t)kept_rows[k] * nb + cb];
+                    const uint64_t a1 = mask[(int64_t)kept_rows[k + G] * nb + cb];
+                    const uint64_t a2 = mask[(int64_t)kept_rows[k + 2 * G] * nb + cb];
+                    const uint64_t a3 = mask[(int64_t)kept_rows[k + 3 * G] * nb + cb];
+                    acc |= a0 | a1 | a2 | a3;
+                }
+                for (; k < kn; k += G) acc |= mask[(int64_t)kept_rows[k] * nb + cb];
+                if (acc) atomicOr((unsigned long long*)&remv[cb], (unsigned long long)acc);
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) num_keep[b] = total < cap ? total : cap;
+}
+
+extern "C" int64_t dgx_nms_batched_workspace_words(int B, int K) {
+    return (B <= 0 || K <= 0) ? 0 : (int64_t)B * K * ((K + 63) / 64);
+}
+
+extern "C" int dgx_nms_batched(const float* boxes, const float* scores, const int32_t* n_valid, int B, int K, float iou_thr,
+                               int max_keep, uint64_t* mask, int32_t* keep_idx, int cap, int32_t* num_keep, void* stream) {
+    if (B <= 0) return DGX_OK;
+    if (K <= 0 || !boxes || !n_valid || !mask || !keep_idx || !num_keep || cap <= 0 || max_keep < 0) return DGX_ERR_BAD_ARG;
+    const int nb = (K + 63) / 64;
+    if ((size_t)nb * 8 > 60000 || B > 65535) return DGX_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(nms_mask_batched_kernel, dim3(nb, nb, B), dim3(64), 0, st, boxes, n_valid, K, iou_thr, nb, mask);
+    hipLaunchKernelGGL(nms_sweep_batched_kernel, dim3(B), dim3(1024), (size_t)nb * 8, st, mask, scores, n_valid, K, nb, max_keep,
+                       keep_idx, cap, num_keep);
+    DGX_LAUNCH_CHECK();
+    return DGX_OK;
+}
+
 // ---- pairwise IoU + Matcher -----------------------------------------------------------------
 __global__ __launch_bounds__(256) void iou_match_kernel(const float* __restrict__ gt, int M, const float* __restrict__ props,
                                                         int N, float thr, int64_t* __restrict__ midx,

@@ -5,7 +5,7 @@ needs ROCm tensors and libdgx.so; nothing here falls back to eager PyTorch or th
 """
 from .window_ops import window_attention_core, window_gather, window_scatter, shift_regions  # noqa
 from .roi_ops import roi_align, roi_pooler, mask_crop  # noqa
-from .box_ops import nms, batched_nms, iou_match  # noqa
+from .box_ops import nms, batched_nms, iou_match, nms_batched_sorted  # noqa
 from .dense_ops import centernet_targets  # noqa
 from .copy_paste import copy_paste  # noqa
 from .optim_ops import adamw_ema_step  # noqa

@@ -21,6 +21,25 @@ def nms(boxes, scores, iou_threshold):
     return order[keep.bool()]
 
 
+def nms_batched_sorted(boxes, scores, n_valid, iou_threshold, max_keep=0, cap=None):
+    """Greedy NMS for B images at once without a host round trip.
+    boxes (B,K,4) f32 sorted by descending score per image, scores (B,K) f32 (sorted) or None,
+    n_valid (B) int32 on the device.  Returns keep_idx (B,cap) int32 (-1 padded, score order) and
+    num_keep (B) int32.  max_keep > 0 stops at that many kept boxes (+ score ties, as the reference's
+    ">= k-th score" rule)."""
+    B, K, _ = boxes.shape
+    cap = cap or (max_keep + 64 if max_keep > 0 else K)
+    boxes = boxes.float().contiguous()
+    lib = L.lib()
+    ws = torch.empty(max(int(lib.dgx_nms_batched_workspace_words(B, K)), 1), dtype=torch.int64, device=boxes.device)
+    keep_idx = torch.empty(B, cap, dtype=torch.int32, device=boxes.device)
+    num_keep = torch.empty(B, dtype=torch.int32, device=boxes.device)
+    sc = scores.float().contiguous() if scores is not None else None
+    L.check(lib.dgx_nms_batched(L.ptr(boxes), L.ptr(sc), L.ptr(n_valid.to(torch.int32).contiguous()), B, K, float(iou_threshold),
+                                int(max_keep), L.ptr(ws), L.ptr(keep_idx), cap, L.ptr(num_keep), L.stream()), "dgx_nms_batched")
+    return keep_idx, num_keep
+
+
 def batched_nms(boxes, scores, idxs, iou_threshold):
     """Per-class NMS via the coordinate-offset strategy (one of torchvision's two, same keep set)."""
     if boxes.numel() == 0:

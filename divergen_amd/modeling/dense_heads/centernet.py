@@ -13,7 +13,7 @@ from torch import nn
 
 from .. import PROPOSAL_GENERATOR_REGISTRY
 from ...config import configurable
-from ...layers import centernet_targets, nms
+from ...layers import centernet_targets, nms, nms_batched_sorted
 from ...structures import Boxes, Instances
 from ...utils.comm import get_world_size
 from .centernet_head import CenterNetHead
@@ -183,24 +183,43 @@ class CenterNet(nn.Module):
             det[..., 3] = torch.max(det[..., 3], det[..., 1] + 0.01)
             for i in range(B):
                 per_img[i].append((det[i], vals[i]))
+        # Fixed-shape, sync-free from here: every image keeps its K = sum_l k_l candidates; the ones at or below
+        # the score threshold sort to the end and the device-side count tells the NMS kernel where to stop.
+        boxes = torch.stack([torch.cat([d for d, _ in per_img[i]]) for i in range(B)])          # (B,K,4)
+        sc = torch.stack([torch.cat([v for _, v in per_img[i]]) for i in range(B)])             # (B,K)
+        ok = sc > self.score_thresh
+        n_valid = ok.sum(1).to(torch.int32)
+        sc = torch.where(ok, torch.sqrt(sc.clamp(min=0)), sc.new_full((), -1.0))
+        sc, order = torch.sort(sc, dim=1, descending=True, stable=True)
+        boxes = torch.gather(boxes, 1, order[:, :, None].expand(-1, -1, 4))
+        K = sc.shape[1]
+        if not self.not_nms:
+            cap = min(K, post_topk + 64)
+            keep_idx, num_keep = nms_batched_sorted(boxes, sc, n_valid, thr_nms, max_keep=post_topk, cap=cap)
+            kidx = keep_idx.clamp(min=0).long()
+            boxes = torch.gather(boxes, 1, kidx[:, :, None].expand(-1, -1, 4))
+            sc = torch.gather(sc, 1, kidx)
+        else:
+            # no NMS: the reference's top-k-with-ties rule applied to the score-sorted candidates
+            cap = min(K, post_topk + 64)
+            kth = sc[:, min(post_topk, K) - 1:min(post_topk, K)]
+            num_keep = torch.minimum(n_valid, ((sc >= kth) & (sc >= 0)).sum(1).to(torch.int32)).clamp(max=cap)
+            boxes, sc = boxes[:, :cap], sc[:, :cap]
+        valid = torch.arange(boxes.shape[1], device=sc.device)[None, :] < num_keep[:, None]
+        boxes = boxes * valid[:, :, None]
+        sc = torch.where(valid, sc, torch.zeros_like(sc))
         results = []
+        counts = None if self.training else num_keep.tolist()      # inference returns exact-length lists (one sync)
         for i in range(B):
-            boxes = torch.cat([d for d, _ in per_img[i]])
-            sc = torch.cat([v for _, v in per_img[i]])
-            ok = sc > self.score_thresh
-            boxes, sc = boxes[ok], torch.sqrt(sc[ok])
-            if not self.not_nms:
-                keep = nms(boxes, sc, thr_nms)                                   # descending score order
-                boxes, sc = boxes[keep], sc[keep]
-            n = sc.shape[0]
-            if n > post_topk:
-                sorted_sc = torch.sort(sc, descending=True)[0]
-                kk = sc >= sorted_sc[post_topk - 1]
-                boxes, sc = boxes[kk], sc[kk]
             inst = Instances(image_sizes[i])
-            inst.pred_boxes = Boxes(boxes)
-            inst.scores = sc
-            inst.pred_classes = torch.zeros_like(sc, dtype=torch.int64)
+            if counts is None:      # training: fixed length + validity flags (the sampler ignores padded rows)
+                inst.pred_boxes = Boxes(boxes[i])
+                inst.scores = sc[i]
+                inst.proposal_valid = valid[i]
+            else:
+                inst.pred_boxes = Boxes(boxes[i, :counts[i]])
+                inst.scores = sc[i, :counts[i]]
+            inst.pred_classes = torch.zeros_like(inst.scores, dtype=torch.int64)
             results.append(inst)
         return results
 

@@ -51,9 +51,13 @@ def add_ground_truth_to_proposals(gt, proposals):
         gp = Instances(p.image_size, **g.get_fields())
         gp.proposal_boxes = g.gt_boxes
         gp.objectness_logits = logit * torch.ones(len(g), device=p.objectness_logits.device)
+        if p.has("proposal_valid"):     # fixed-length proposal lists (training): ground-truth rows are always valid
+            gp.proposal_valid = torch.ones(len(g), dtype=torch.bool, device=p.objectness_logits.device)
         for key in p.get_fields().keys():
             assert gp.has(key), "The attribute '{}' in `proposals` does not exist in `gt`".format(key)
         sel = Instances(p.image_size, proposal_boxes=gp.proposal_boxes, objectness_logits=gp.objectness_logits)
+        if p.has("proposal_valid"):
+            sel.proposal_valid = gp.proposal_valid
         out.append(Instances.cat([p, sel]))
     return out
 
@@ -128,6 +132,10 @@ class DeticCascadeROIHeads(nn.Module):
                 gtc[mlab == 0] = self.num_classes
             else:
                 gtc = torch.zeros_like(midx) + self.num_classes
+            if p.has("proposal_valid"):
+                # padding rows of a fixed-length proposal list: label -1 = "ignore", never sampled
+                gtc = torch.where(p.proposal_valid, gtc, torch.full_like(gtc, -1))
+                p.remove("proposal_valid")
             fg_idx, bg_idx = subsample_labels(gtc, self.batch_size_per_image, self.positive_fraction, self.num_classes)
             sidx = torch.cat([fg_idx, bg_idx], dim=0)
             p = p[sidx]

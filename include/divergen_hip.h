@@ -117,6 +117,22 @@ int dgx_nms_sorted(const float* boxes, int n, float iou_thr, uint64_t* mask, uin
                    int32_t* num_keep, void* stream);
 int64_t dgx_nms_workspace_words(int n);
 
+/* The same NMS for B images in one launch with DEVICE-resident candidate counts (the reference reads the
+ * counts back to the host between the score filter and nms, CN/modeling/dense_heads/centernet.py:690-737).
+ *   boxes   f32 (B, K, 4) per image sorted by descending score; rows >= n_valid[b] are ignored
+ *   scores  f32 (B, K) the sorted scores, or NULL; only used for the tie rule of max_keep
+ *   n_valid i32 (B)
+ *   max_keep: 0 = keep every survivor; else the sweep stops once max_keep boxes are kept, except that
+ *            survivors tied with the max_keep-th kept score are kept too (centernet.py:727-731 keeps
+ *            every survivor with score >= the k-th score)
+ *   mask    u64 workspace, dgx_nms_batched_workspace_words(B, K) words
+ *   keep_idx i32 (B, cap) out: indices (in the sorted order) of the kept boxes, ascending, -1 padded
+ *   num_keep i32 (B) out (<= cap) */
+int64_t dgx_nms_batched_workspace_words(int B, int K);
+int dgx_nms_batched(const float* boxes, const float* scores, const int32_t* n_valid, int B, int K,
+                    float iou_thr, int max_keep, uint64_t* mask, int32_t* keep_idx, int cap,
+                    int32_t* num_keep, void* stream);
+
 /* pairwise IoU + Matcher in one pass (no M x N matrix): for every proposal the best GT and the
  * label from the thresholds.  D2/structures/boxes.py:310-357 + D2/modeling/matcher.py:62-104
  * (single threshold, labels [0,1], no low-quality matches), callers

@@ -199,6 +199,33 @@ def test_nms_bit_exact_and_batched():
     assert la.nms(torch.zeros(0, 4, device=DEV), torch.zeros(0, device=DEV), 0.5).numel() == 0
 
 
+@pytest.mark.parametrize("max_keep", [0, 40, 400])
+def test_nms_batched_device_counts_bit_exact(max_keep):
+    """B images in one launch, candidate counts on the device, early stop at max_keep with the reference's
+    '>= k-th score' tie rule: kept indices must equal the oracle's (NMS, then top-k with ties)."""
+    g = torch.Generator().manual_seed(37)
+    B, K = 3, 1500
+    nv = [1500, 777, 0]
+    xy = torch.rand(B, K, 2, generator=g) * 400
+    wh = torch.rand(B, K, 2, generator=g) * 70 + 2
+    boxes = torch.cat([xy, xy + wh], -1)
+    scores = torch.rand(B, K, generator=g)
+    scores[:, 100:500] = scores[:, 600:1000]            # plenty of exact ties
+    scores, order = torch.sort(scores, dim=1, descending=True, stable=True)
+    boxes = torch.gather(boxes, 1, order[:, :, None].expand(-1, -1, 4))
+    keep_idx, num_keep = la.nms_batched_sorted(boxes.to(DEV), scores.to(DEV), torch.tensor(nv, dtype=torch.int32, device=DEV), 0.5,
+                                               max_keep=max_keep, cap=K if max_keep == 0 else max_keep + 64)
+    for b in range(B):
+        ref = OR.nms(boxes[b, :nv[b]], scores[b, :nv[b]], 0.5).tolist() if nv[b] else []   # indices in sorted order, ascending
+        if max_keep and len(ref) > max_keep:
+            kth = scores[b, ref[max_keep - 1]]
+            ref = [i for i in ref if scores[b, i] >= kth]
+        n = int(num_keep[b])
+        assert n == len(ref)
+        assert keep_idx[b, :n].cpu().tolist() == ref
+        assert bool((keep_idx[b, n:] == -1).all())
+
+
 def test_iou_match_bit_exact(golden):
     g = golden("roi_match")
     gt, pr = T(g["gt"]), T(g["proposals"])

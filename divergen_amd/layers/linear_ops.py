@@ -47,6 +47,27 @@ def wgrad_grouped(problems, beta=1.0):
     L.check(lib.dgx_linear_wgrad_grouped(arr, n, float(beta), L.ptr(ws), L.stream()), "dgx_linear_wgrad_grouped")
 
 
+_READY_SUSPENDED = [False]
+
+
+class suspend_ready:
+    """Context: gradient-ready callbacks (data-parallel reducer) are not fired -- used while a segment is being
+    captured into a hipGraph, whose warm-up backward passes are not part of any training step."""
+
+    def __enter__(self):
+        self.prev = _READY_SUSPENDED[0]
+        _READY_SUSPENDED[0] = True
+
+    def __exit__(self, *a):
+        _READY_SUSPENDED[0] = self.prev
+
+
+def notify_ready(p):
+    r = getattr(p, "_dgx_ready", None)
+    if r is not None and not _READY_SUSPENDED[0] and not torch.cuda.is_current_stream_capturing():
+        r()
+
+
 def shadow(p):
     """bf16 view of a parameter: the arena shadow if present, else a cast (CPU tests, pre-arena)."""
     s = getattr(p, "_dgx16", None)
@@ -62,9 +83,7 @@ def accumulate_grad(p, make_grad_fp32, gemm_into=None):
             gemm_into(g)
         else:
             g.add_(make_grad_fp32())
-        ready = getattr(p, "_dgx_ready", None)
-        if ready is not None:
-            ready()
+        notify_ready(p)
         return None
     return make_grad_fp32().to(p.dtype)
 

@@ -3,7 +3,7 @@ swintransformer.py:213 (norm1, followed by pad/roll/partition :216-233) and :255
 import torch
 
 from .. import _lib as L
-from .linear_ops import accumulate_grad
+from .linear_ops import accumulate_grad, notify_ready
 
 
 class _LayerNormBF16(torch.autograd.Function):
@@ -44,9 +44,7 @@ class _LayerNormBF16(torch.autograd.Function):
                                           L.ptr(db), L.ptr(part), T, C, B, H, W, ws, shift, L.dtype_code(x), L.stream()), "dgx_layernorm_bwd")
         if in_arena:
             for p in (weight, bias):
-                ready = getattr(p, "_dgx_ready", None)
-                if ready is not None:
-                    ready()
+                notify_ready(p)
             return dx, None, None, None, None, None, None, None, None
         return dx, dg.to(weight.dtype), db.to(bias.dtype), None, None, None, None, None, None
 

@@ -16,7 +16,7 @@ composed path in swintransformer.py, which runs the same kernels in the same ord
 import torch
 
 from .. import _lib as L
-from .linear_ops import BF16, shadow, wgrad_grouped
+from .linear_ops import BF16, notify_ready, shadow, wgrad_grouped
 
 
 def arena_resident(params):
@@ -26,9 +26,7 @@ def arena_resident(params):
 
 def _ready(*params):
     for p in params:
-        r = getattr(p, "_dgx_ready", None)
-        if r is not None:
-            r()
+        notify_ready(p)
 
 
 def colsum_into(gb, dy2, beta=1.0):

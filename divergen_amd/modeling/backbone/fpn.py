@@ -73,6 +73,16 @@ class FPN(Backbone):
 
     def forward(self, x):
         feats = self.bottom_up(x)
+        seg = self.__dict__.get("_segment")
+        if seg is None:
+            from ...utils.graphs import GraphedSegment
+            seg = self.__dict__["_segment"] = GraphedSegment(_TopDown(self))
+        ins = tuple(feats[f] for f in self.in_features)
+        if self.training and seg.usable(ins):          # static shapes: replay the captured forward / backward graphs
+            return dict(zip(self._out_features, seg(*ins)))
+        return self._top_down(feats)
+
+    def _top_down(self, feats):
         results = []
         prev = self.lateral_convs[0](feats[self.in_features[-1]])
         results.append(self.output_convs[0](prev))
@@ -88,3 +98,21 @@ class FPN(Backbone):
                 results[self._out_features.index(self.top_block.in_feature)]
             results.extend(self.top_block(src))
         return dict(zip(self._out_features, results))
+
+
+class _TopDown(nn.Module):
+    """FPN minus its bottom-up network, tensors in / tuple out: the unit captured as a hipGraph."""
+
+    def __init__(self, fpn):
+        super().__init__()
+        self.__dict__["fpn"] = fpn          # not a registered child: the FPN owns the parameters
+        self.amp = False
+
+    def parameters(self, recurse=True):
+        return (p for n, p in self.__dict__["fpn"].named_parameters() if not n.startswith("bottom_up."))
+
+    def forward(self, *ins):
+        fpn = self.__dict__["fpn"]
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.amp, cache_enabled=False):
+            out = fpn._top_down(dict(zip(fpn.in_features, ins)))
+        return tuple(out[k] for k in fpn._out_features)

@@ -77,7 +77,7 @@ class CenterNet(nn.Module):
     # ---------------------------------------------------------------- forward
     def forward(self, images, features_dict, gt_instances):
         features = [features_dict[f] for f in self.in_features]
-        _, reg_pred_per_level, agn_hm_pred_per_level = self.centernet_head(features)
+        reg_pred_per_level, agn_hm_pred_per_level = self._run_head(features)
         reg_pred_per_level = [r.float() for r in reg_pred_per_level]
         agn_hm_pred_per_level = [a.float() for a in agn_hm_pred_per_level]
         grids = self.compute_grids(features)
@@ -104,6 +104,19 @@ class CenterNet(nn.Module):
             p.remove("scores")
             p.remove("pred_classes")
         return proposals, losses
+
+    def _run_head(self, features):
+        """Tower + predictors on every level; in training the whole thing is one captured hipGraph pair."""
+        seg = self.__dict__.get("_segment")
+        if seg is None:
+            from ...utils.graphs import GraphedSegment
+            seg = self.__dict__["_segment"] = GraphedSegment(_HeadSegment(self.centernet_head))
+        if self.training and self.with_agn_hm and seg.usable(features):
+            out = seg(*features)
+            n = len(features)
+            return list(out[:n]), list(out[n:])
+        _, reg, hm = self.centernet_head(features)
+        return reg, hm
 
     def compute_grids(self, features):
         grids = []
@@ -222,6 +235,20 @@ class CenterNet(nn.Module):
             inst.pred_classes = torch.zeros_like(inst.scores, dtype=torch.int64)
             results.append(inst)
         return results
+
+
+class _HeadSegment(nn.Module):
+    """CenterNetHead with tensors in / tuple out (regression maps then heat maps): the unit captured as a hipGraph."""
+
+    def __init__(self, head):
+        super().__init__()
+        self.head = head
+        self.amp = False
+
+    def forward(self, *feats):
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.amp, cache_enabled=False):
+            _, reg, hm = self.head(list(feats))
+        return tuple(reg) + tuple(hm)
 
 
 def _giou(pred, target):

@@ -1,0 +1,46 @@
+"""hipGraph capture of static-shape model segments (forward AND backward).
+
+The dense heads (FPN top-down path, CenterNet tower) are a few hundred tiny kernels whose shapes depend only
+on the padded image size; eagerly the host needs longer to issue them than the GPU needs to run them.  A
+segment is captured once per input signature with torch.cuda.make_graphed_callables and replayed afterwards:
+two graph launches (forward, backward) instead of ~10^3 kernel launches.  The reference has no counterpart (it
+runs these modules eagerly: D2/modeling/backbone/fpn.py:113-154, CN/modeling/dense_heads/centernet_head.py:141-162).
+
+Segments must be free of host syncs, data-dependent shapes and Python-side effects.  Parameter gradients are
+written in place into the gradient arena by the captured kernels; the data-parallel reducer is not signalled
+from inside a replay (its per-parameter callbacks are Python) and flushes those buckets in finish()."""
+import os
+
+import torch
+
+from ..layers import linear_ops
+
+ENABLED = os.environ.get("DGX_GRAPH_HEADS", "1") == "1"
+
+
+class GraphedSegment:
+    def __init__(self, module):
+        self.module = module           # nn.Module: forward(*tensors) -> tuple of tensors
+        self._fns = {}
+
+    def usable(self, inputs):
+        return (ENABLED and torch.is_grad_enabled() and all(t.is_cuda for t in inputs)
+                and not torch.cuda.is_current_stream_capturing())
+
+    def __call__(self, *inputs):
+        key = tuple((tuple(t.shape), t.dtype, t.requires_grad, tuple(t.stride())) for t in inputs) + (torch.is_autocast_enabled(),)
+        fn = self._fns.get(key)
+        if fn is None:
+            self.module.amp = torch.is_autocast_enabled()
+            sample = tuple(t.detach().clone().requires_grad_(t.requires_grad) for t in inputs)
+            # capture outside the caller's autocast region (its weight-cast cache cannot be captured); the segment
+            # module re-enters autocast itself with the cache off
+            with linear_ops.suspend_ready(), torch.autocast("cuda", enabled=False):
+                fn = torch.cuda.make_graphed_callables(self.module, sample, allow_unused_input=True)
+            # the capture warm-up ran real backward passes whose in-place gradient writes landed in the arena;
+            # this step's backward has not started yet, so clearing them is exact
+            for p in self.module.parameters():
+                if p.grad is not None:
+                    p.grad.zero_()
+            self._fns[key] = fn
+        return fn(*inputs)

@@ -79,3 +79,32 @@ def test_training_step_losses_and_update():
     # bf16 shadow follows the fp32 weights; EMA moved by (1-decay) of the pre-step weights
     assert torch.equal(opt.arena.p16, opt.arena.p.to(torch.bfloat16))
     assert torch.allclose(opt.ema, p_before, rtol=1e-6, atol=1e-7)   # ema(p0, p0) = p0 (fp32 rounding) at the first step
+
+
+def test_graphed_head_segments_match_eager(monkeypatch):
+    """FPN top-down + CenterNet tower replayed as hipGraphs (utils/graphs.py) vs issued eagerly: same losses and
+    same gradients (fp32 atomics / split-sum order only), on the first (capturing) AND on a later (replaying) step."""
+    from divergen_amd.data import synthetic_batch
+    from divergen_amd.utils import graphs
+    from divergen_amd.utils.events import EventStorage
+    res = {}
+    for on in (False, True):
+        monkeypatch.setattr(graphs, "ENABLED", on)
+        cfg, model, opt = _build(False)
+        batch = synthetic_batch(2, 256, cfg.MODEL.ROI_HEADS.NUM_CLASSES, device="cuda")
+        outs = []
+        with EventStorage(0):
+            for it in range(3):
+                torch.manual_seed(100 + it)      # same sampling RNG in both runs
+                opt.zero_grad()
+                losses = model(batch)
+                sum(losses.values()).backward()
+                torch.cuda.synchronize()
+                outs.append(({k: float(v) for k, v in losses.items()}, opt.arena.g.clone()))
+        res[on] = outs
+    for it in range(3):
+        l0, g0 = res[False][it]
+        l1, g1 = res[True][it]
+        for k in l0:
+            assert abs(l0[k] - l1[k]) <= 2e-3 * abs(l0[k]) + 1e-5, (it, k, l0[k], l1[k])
+        assert float((g0 - g1).abs().max()) <= 2e-2 * float(g0.abs().max()), it

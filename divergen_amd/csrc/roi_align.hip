@@ -174,6 +174,101 @@ __global__ __launch_bounds__(256) void roi_align_sep_kernel(PoolLevels L, const 
     }
 }
 
+// Vectorised form of the kernel above for C % 8 == 0 and channels-last OUTPUT: a lane owns 8 consecutive channels
+// (one 16-byte load per tap for bf16 features), C/8 lanes cover a pixel and the 256/(C/8) lane groups of the
+// workgroup walk different bins at the same time.  Same tables, same summation order per channel.
+template <typename T> struct Vec8;
+template <> struct Vec8<uint16_t> {
+    static __device__ __forceinline__ void load(const uint16_t* p, float (&v)[8]) {
+        const u32x4 r = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(r[i] << 16); v[2 * i + 1] = __uint_as_float(r[i] & 0xffff0000u); }
+    }
+    static __device__ __forceinline__ void store(uint16_t* p, const float (&v)[8]) {
+        *reinterpret_cast<u32x4*>(p) = u32x4{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+    }
+};
+template <> struct Vec8<float> {
+    static __device__ __forceinline__ void load(const float* p, float (&v)[8]) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[i] = a[i]; v[4 + i] = b[i]; }
+    }
+    static __device__ __forceinline__ void store(float* p, const float (&v)[8]) {
+        *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
+    }
+};
+
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void roi_align_vec_kernel(PoolLevels L, const float* __restrict__ rois, T* __restrict__ io,
+                                                            int32_t* __restrict__ levels_out, int C, int ph, int pw,
+                                                            int sampling_ratio, int aligned, int bins_per_block, int spy, int spx) {
+    extern __shared__ float smem[];
+    float* WY = smem;                      // [ph][spy]
+    float* WX = WY + ph * spy;             // [pw][spx]
+    Span* SY = reinterpret_cast<Span*>(WX + pw * spx);
+    Span* SX = SY + ph;
+    const int r = blockIdx.x;
+    const float* roi = rois + 5 * (int64_t)r;
+    const int lvl = L.num_levels > 1 ? assign_level(roi, L.min_level, L.num_levels) : 0;
+    if (!BWD && levels_out && blockIdx.y == 0 && threadIdx.x == 0) levels_out[r] = lvl;
+    const int H = L.H[lvl], W = L.W[lvl];
+    const RoiGeom G = roi_geom(roi, L.scale[lvl], ph, pw, sampling_ratio, aligned != 0);
+    build_axis_table(WY, SY, ph, spy, G.sh, G.bin_h, G.gh, H, threadIdx.x, 0);
+    build_axis_table(WX, SX, pw, spx, G.sw, G.bin_w, G.gw, W, threadIdx.x, 64);
+    __syncthreads();
+    const int bins = ph * pw;
+    const int bin0 = blockIdx.y * bins_per_block, bin1 = min(bins, bin0 + bins_per_block);
+    const int CV = C >> 3, nslots = 256 / CV;
+    const int cv = threadIdx.x % CV, slot = threadIdx.x / CV;
+    if (slot >= nslots) return;
+    const T* fb = BWD ? nullptr : (const T*)L.feat[lvl] + (int64_t)G.b * H * W * C + 8 * cv;
+    // backward: lane owns channels cv, cv + CV, ..., so that one atomic instruction covers CV consecutive floats
+    float* gb = BWD ? L.grad[lvl] + (int64_t)G.b * H * W * C + cv : nullptr;
+    for (int bin = bin0 + slot; bin < bin1; bin += nslots) {
+        const int i = bin / pw, j = bin - i * pw;
+        const Span sy = SY[i], sx = SX[j];
+        const float* wy = WY + i * spy;
+        const float* wx = WX + j * spx;
+        T* iop = io + ((int64_t)r * bins + bin) * C + 8 * cv;
+        if (BWD) {
+            float g[8];
+            const T* gop = io + ((int64_t)r * bins + bin) * C + cv;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) g[e] = ldf(gop + CV * e) / G.count;
+            for (int ky = 0; ky < sy.n; ++ky) {
+                float* row = gb + ((int64_t)(sy.base + ky) * W + sx.base) * C;
+                const float wyk = wy[ky];
+                for (int kx = 0; kx < sx.n; ++kx) {
+                    const float wxk = wx[kx];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) atomicAdd(row + (int64_t)kx * C + CV * e, (g[e] * wyk) * wxk);
+                }
+            }
+        } else {
+            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int ky = 0; ky < sy.n; ++ky) {
+                const T* row = fb + ((int64_t)(sy.base + ky) * W + sx.base) * C;
+                float racc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                for (int kx = 0; kx < sx.n; ++kx) {
+                    float v[8];
+                    Vec8<T>::load(row + (int64_t)kx * C, v);
+                    const float wxk = wx[kx];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) racc[e] += wxk * v[e];
+                }
+                const float wyk = wy[ky];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += wyk * racc[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = acc[e] / G.count;
+            Vec8<T>::store(iop, acc);
+        }
+    }
+}
+
 static int launch_pool(bool fwd, const PoolLevels& L, const float* rois, const void* io, int32_t* levels_out, int C,
                        int R, int ph, int pw, int sampling_ratio, int aligned, int out_nhwc, int dtype, void* stream) {
     if (R <= 0) return DGX_OK;
@@ -198,6 +293,19 @@ static int launch_pool(bool fwd, const PoolLevels& L, const float* rois, const v
     if (sm > 64 * 1024) return DGX_ERR_UNSUPPORTED;
     dim3 grid(R, nsplit), block(256);
     hipStream_t st = (hipStream_t)stream;
+    if (out_nhwc && (C & 7) == 0 && C <= 2048 && 256 % (C >> 3) == 0) {   // 8 channels per lane, several bins in flight
+        bool aligned16 = true;
+        for (int l = 0; l < L.num_levels; ++l)
+            aligned16 = aligned16 && (((uintptr_t)(fwd ? L.feat[l] : (const void*)L.grad[l]) & 15) == 0);
+        if (aligned16 && ((uintptr_t)io & 15) == 0) {
+#define VEC_LAUNCH(TT, BW) hipLaunchKernelGGL((roi_align_vec_kernel<TT, BW>), grid, block, tbl, st, L, rois, (TT*)io, fwd ? levels_out : nullptr, C, ph, pw, sampling_ratio, aligned, bpb, spy, spx)
+            if (fwd) { if (dtype == DGX_BF16) VEC_LAUNCH(uint16_t, false); else VEC_LAUNCH(float, false); }
+            else { if (dtype == DGX_BF16) VEC_LAUNCH(uint16_t, true); else VEC_LAUNCH(float, true); }
+#undef VEC_LAUNCH
+            DGX_LAUNCH_CHECK();
+            return DGX_OK;
+        }
+    }
     if (fwd) {
         if (dtype == DGX_BF16)
             hipLaunchKernelGGL((roi_align_sep_kernel<uint16_t, false>), grid, block, sm, st, L, rois, (uint16_t*)io, levels_out,

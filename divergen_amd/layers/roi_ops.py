@@ -23,25 +23,31 @@ class _ROIPooler(torch.autograd.Function):
         R = rois.shape[0]
         rois = rois.float().contiguous()
         ph = pw = out_size
-        if out_nhwc:
+        # the kernel always writes channels-last (8 channels per lane, 16-byte taps); a (C, ph, pw)-ordered result
+        # (what the box head's first FC expects) is one transposing copy of the small pooled tensor
+        vec = C % 8 == 0
+        if out_nhwc or vec:
             out = torch.empty(R, ph, pw, C, dtype=f0.dtype, device=f0.device).permute(0, 3, 1, 2)
             out_phys = out.permute(0, 2, 3, 1)
         else:
             out = torch.empty(R, C, ph, pw, dtype=f0.dtype, device=f0.device)
             out_phys = out
+        k_nhwc = out_nhwc or vec
         Hs = (ctypes.c_int * nl)(*[f.shape[2] for f in feats])
         Ws = (ctypes.c_int * nl)(*[f.shape[3] for f in feats])
         if nl == 1:
             L.check(L.lib().dgx_roi_align_fwd(L.ptr(phys[0]), L.ptr(rois), L.ptr(out_phys), N, Hs[0], Ws[0], C, R,
-                                              scale0, ph, pw, sampling_ratio, int(aligned), int(out_nhwc),
+                                              scale0, ph, pw, sampling_ratio, int(aligned), int(k_nhwc),
                                               L.dtype_code(f0), L.stream()), "dgx_roi_align_fwd")
         else:
             ptrs = (ctypes.c_void_p * nl)(*[L.ptr(p) for p in phys])
             L.check(L.lib().dgx_roi_pooler_fwd(ptrs, Hs, Ws, nl, min_level, L.ptr(rois), L.ptr(out_phys), None, N, C,
-                                               R, ph, pw, sampling_ratio, int(out_nhwc), L.dtype_code(f0), L.stream()),
+                                               R, ph, pw, sampling_ratio, int(k_nhwc), L.dtype_code(f0), L.stream()),
                     "dgx_roi_pooler_fwd")
+        if k_nhwc and not out_nhwc:
+            out = out.contiguous()
         ctx.save_for_backward(rois)
-        ctx.cfg = (out_size, min_level, sampling_ratio, out_nhwc, aligned, scale0, N, C,
+        ctx.cfg = (out_size, min_level, sampling_ratio, k_nhwc, aligned, scale0, N, C,
                    [tuple(f.shape) for f in feats], f0.dtype)
         return out
 

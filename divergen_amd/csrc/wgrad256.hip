@@ -63,6 +63,8 @@ __device__ unsigned long long w256_clk[8];
 // LDS image of one operand stage: [32 rows (m)][256 columns] bf16, 512-byte rows, NO padding (a wave-wide
 // LDS-direct load writes 1 KiB = two whole rows).  Bank conflicts of the transpose reads (4 consecutive rows,
 // same columns) are removed by an XOR swizzle of the 16-byte chunk index:  physical = logical ^ ((row & 3) << 1).
+// (Additionally moving the rows of the second lane group of an LDS cycle, (row >> 3) & 1, to the other 32 banks
+// was measured and is NOT faster on hardware, so the simpler swizzle stays.)
 __global__ __launch_bounds__(256) void wgrad256_partial_kernel(Params256 P) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds_raw[];   // [NB256][A|B][32][512 B]
     // XCD-aware order: workgroups that share an XCD (blockIdx % 8, one L2 each) take CONSECUTIVE logical ids =

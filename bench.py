@@ -46,6 +46,16 @@ def make_pastes(rng, size, k=19):
     return out
 
 
+# HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc, corrected as the
+# MI355X guide prescribes); None where no pass was taken.  Filled from profiles/r01_pmc.json when present.
+PMC_TRAFFIC = {}
+try:
+    with open(os.path.join(ROOT, "profiles", "r01_pmc.json")) as _f:
+        PMC_TRAFFIC = {k: v.get("hbm_bytes_per_launch") for k, v in json.load(_f).items()}
+except (OSError, ValueError):
+    pass
+
+
 class KernelTimer:
     """HIP events around one libdgx entry point, recorded on the stream the kernel is launched on."""
 
@@ -173,7 +183,7 @@ def main():
         torch.cuda.synchronize()
 
     L = _lib.lib()
-    timers = {n: KernelTimer(L, n) for n in ("dgx_window_attention_fwd", "dgx_window_attention_bwd")}
+    timers = {n: KernelTimer(L, n) for n in ("dgx_linear_wgrad_grouped", "dgx_window_attention_fwd", "dgx_window_attention_bwd")}
     with EventStorage(0):
         for _ in range(a.warmup):
             one_step()
@@ -193,32 +203,45 @@ def main():
     dt = float(tmax)
     imgs = a.batch * world * a.steps
 
-    # roofline of the dominant libdgx kernel, from HIP events recorded around its launches
-    roof = None
-    best = None
+    # roofline objects from HIP events recorded (on the launch stream) around every call of the three heaviest
+    # libdgx entry points inside the timed region; "roofline" = the one with the largest total time
+    def work(name, args):
+        """-> (flops, algorithmic bytes) of one call."""
+        if name == "dgx_linear_wgrad_grouped":
+            fl = by = 0.0
+            for i in range(args[1]):
+                p = args[0][i]
+                fl += 2.0 * p.M * p.Nn * p.Kk
+                by += 2.0 * p.M * (p.Nn + p.Kk) + 8.0 * p.Nn * p.Kk      # dY, X read once (bf16); fp32 gradient read + written
+            return fl, by
+        if name.endswith("fwd"):
+            B_, nH, ws, mm, io = args[5], args[7], args[8], 2, 4            # QK^T, PV;  q,k,v in + out
+        else:
+            B_, nH, ws, mm, io = args[10], args[12], args[13], 5, 8         # S, dP, dV, dK, dQ;  q,k,v,o,do in + dq,dk,dv out
+        N = ws * ws
+        return B_ * nH * mm * 2.0 * N * N * 32, B_ * nH * N * (32 * 2 * io + 4)
+
+    objs = []
     for name, t in timers.items():
         if not t.events:
             continue
-        tot_ms, flops, nbytes = 0.0, 0.0, 0.0
-        for s, e, args in t.events:
-            tot_ms += s.elapsed_time(e)
-            if name.endswith("fwd"):
-                B_, nH, ws = args[5], args[7], args[8]
-                mm = 2
-            else:
-                B_, nH, ws = args[10], args[12], args[13]
-                mm = 5
-            N = ws * ws
-            flops += B_ * nH * mm * 2.0 * N * N * 32
-            nbytes += B_ * N * nH * 32 * 2 * (4 if mm == 2 else 9)
-        if best is None or tot_ms > best[1]:
-            best = (name, tot_ms, flops, nbytes, len(t.events))
-    if best is not None:
-        name, tot_ms, flops, nbytes, calls = best
-        ach = flops / (tot_ms * 1e-3) / 1e12
-        roof = {"kernel": name, "bound": "mfma", "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": ach / 2500.0,
-                "traffic": None, "avg_launch_us": tot_ms * 1e3 / calls, "launches": calls,
-                "algorithmic_gbytes_per_s": nbytes / (tot_ms * 1e-3) / 1e9}
+        tot_ms = sum(s.elapsed_time(e) for s, e, _ in t.events)
+        fl = by = 0.0
+        for _, _, args in t.events:
+            f, b_ = work(name, args)
+            fl += f
+            by += b_
+        tf, gbs = fl / (tot_ms * 1e-3) / 1e12, by / (tot_ms * 1e-3) / 1e9
+        # window attention at head_dim 32 is 72 FLOP/B -- under the ~310 FLOP/B ridge, i.e. HBM-bound; the 256x256
+        # weight-gradient tiles are MFMA-bound
+        mfma = name == "dgx_linear_wgrad_grouped"
+        objs.append({"kernel": name, "bound": "mfma" if mfma else "hbm", "achieved": tf if mfma else gbs,
+                     "peak": 2500.0 if mfma else 8000.0, "unit": "TFLOP/s" if mfma else "GB/s",
+                     "frac": (tf / 2500.0) if mfma else (gbs / 8000.0), "traffic": PMC_TRAFFIC.get(name),
+                     "avg_launch_us": tot_ms * 1e3 / len(t.events), "launches": len(t.events), "total_ms_per_step": tot_ms / a.steps,
+                     "tflops": tf, "algorithmic_gbytes_per_s": gbs})
+    objs.sort(key=lambda o: -o["total_ms_per_step"])
+    roof = objs[0] if objs else None
 
     if rank == 0:
         line = {"metric": "images/sec (node) Swin-L CenterNet2 LVIS 1024px", "value": imgs / dt, "unit": "images/s",
@@ -228,7 +251,7 @@ def main():
                 "config": {"workload": "CenterNet2 Swin-%s, %dx%d, %d images/GPU, 1453 classes, GPU copy-paste + fwd + bwd + "
                                        "fused clip/AdamW/EMA; configs/DiverGen_swinL.yaml" % (a.swin, a.size, a.size, a.batch),
                            "global_batch": a.batch * world, "parallelism": "dp%d" % world, "params_M": nparams / 1e6},
-                "roofline": roof,
+                "roofline": roof, "roofline_other": objs[1:],
                 "host_issue_ms_per_step": t_issue / a.steps * 1e3}
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a.swin)

@@ -16,6 +16,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+from divergen_amd.tuning import enable as _enable_tuned_gemm  # noqa: E402  (no torch import inside)
+_enable_tuned_gemm()
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -51,7 +54,7 @@ def make_pastes(rng, size, k=19):
 PMC_TRAFFIC = {}
 try:
     with open(os.path.join(ROOT, "profiles", "r01_pmc.json")) as _f:
-        PMC_TRAFFIC = {k: v.get("hbm_bytes_per_launch") for k, v in json.load(_f).items()}
+        PMC_TRAFFIC = {k: v.get("hbm_bytes_per_launch") for k, v in json.load(_f).items() if isinstance(v, dict)}
 except (OSError, ValueError):
     pass
 

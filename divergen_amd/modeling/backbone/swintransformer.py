@@ -136,6 +136,9 @@ class SwinTransformerBlock(nn.Module):
         p = self.drop_path.drop_prob if isinstance(self.drop_path, DropPath) else 0.0
         if p == 0.0 or not self.training:
             return None, None
+        pre = self.__dict__.pop("_dp_scales", None)      # drawn for all blocks at once by SwinTransformer.forward
+        if pre is not None and pre.shape[1] == B:
+            return pre[0], pre[1]
         keep = 1.0 - p
         s = torch.floor(keep + torch.rand(2, B, device=device, dtype=torch.float32)) / keep
         return s[0], s[1]
@@ -251,13 +254,33 @@ class SwinTransformer(Backbone):
                 nn.init.constant_(m.weight, 1.0)
         self.apply(_init)
 
+    def _draw_drop_path(self, B, device):
+        """All blocks' DropPath factors floor(keep_i + U)/keep_i in one RNG call (4 tiny kernels per step instead
+        of 4 per block); same per-sample Bernoulli(keep_i) law as timm's drop_path at each of the 2 call sites."""
+        blocks = [blk for layer in self.layers for blk in layer.blocks]
+        probs = [blk.drop_path.drop_prob if isinstance(blk.drop_path, DropPath) else 0.0 for blk in blocks]
+        if not self.training or not any(probs):
+            return
+        keep = getattr(self, "_dp_keep", None)
+        if keep is None or keep.device != device:
+            keep = self._dp_keep = (1.0 - torch.tensor(probs, dtype=torch.float32, device=device)).view(-1, 1, 1)
+        s = torch.floor(keep + torch.rand(len(blocks), 2, B, device=device, dtype=torch.float32)) / keep
+        for i, blk in enumerate(blocks):
+            if probs[i] > 0:
+                blk.__dict__["_dp_scales"] = s[i]
+
     def forward(self, x):
+        self._draw_drop_path(x.shape[0], x.device)
         x, Wh, Ww = self.patch_embed(x)
         outs = {}
         for i, layer in enumerate(self.layers):
             x_out, H, W, x, Wh, Ww = layer(x, Wh, Ww)
             if i in self.out_indices:
-                y = getattr(self, "norm%d" % i)(x_out)
+                nm = getattr(self, "norm%d" % i)
+                if torch.is_autocast_enabled() and x_out.is_cuda and self.num_features[i] <= 1536 and self.num_features[i] % 4 == 0:
+                    y = layernorm_bf16(x_out, nm.weight, nm.bias, nm.eps)      # fused LN -> bf16 (what autocast hands the FPN)
+                else:
+                    y = nm(x_out)
                 # NHWC in memory, NCHW as a logical view: the registry contract sees (B,C,H,W)
                 outs["swin%d" % i] = y.view(-1, H, W, self.num_features[i]).permute(0, 3, 1, 2)
         return outs

@@ -17,10 +17,12 @@ import os
 import sys
 import time
 
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+from divergen_amd.tuning import enable as _enable_tuned_gemm  # noqa: E402
+_enable_tuned_gemm()      # library-GEMM algorithm table for this model's shapes (before the first GEMM)
+
+import torch  # noqa: E402
 
 from divergen_amd.checkpoint import DetectionCheckpointer, PeriodicCheckpointer  # noqa: E402
 from divergen_amd.config import add_centernet_config, add_divergen_config, get_cfg  # noqa: E402

@@ -1,0 +1,187 @@
+// GroupNorm (+ optional ReLU) over channels-last activations for the CenterNet tower
+// (CN/modeling/dense_heads/centernet_head.py:52-75: Conv3x3 -> GroupNorm(32, 256) -> ReLU, x4 per level).
+// x (N, HW, C) bf16, 8 channels per group (C = 8 G): one 16-byte vector = one group at one pixel, so every
+// pass is a fully coalesced stream.  HBM-bound: forward reads x twice + writes y once; backward reads x, dy twice.
+//   stats   : one workgroup per (n, g): mean / rstd in fp32 (two-pass over the L2-resident group: exact centred variance)
+//   apply   : y = relu?((x - mean) * rstd * gamma + beta)
+//   bwd red : per (n, g): s1 = sum dyh*gamma, s2 = sum dyh*gamma*xhat and the per-channel sums for dgamma / dbeta
+//   bwd dx  : dx = rstd * (dyh*gamma - (s1 + xhat*s2)/m),  dyh = dy * (y > 0)
+#include "dgx_common.h"
+
+namespace {
+__device__ __forceinline__ void unpack8(const u32x4 r, float (&v)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(r[i] << 16); v[2 * i + 1] = __uint_as_float(r[i] & 0xffff0000u); }
+}
+__device__ __forceinline__ u32x4 pack8(const float (&v)[8]) {
+    return u32x4{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+}
+__device__ __forceinline__ float block_sum(float v, float* red) {   // 256 threads
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+}  // namespace
+
+__global__ __launch_bounds__(256) void gn_stats_kernel(const uint16_t* __restrict__ x, float* __restrict__ mean, float* __restrict__ rstd,
+                                                       int HW, int C, int G, float eps) {
+    __shared__ float red[4];
+    const int n = blockIdx.x / G, g = blockIdx.x % G;
+    const uint16_t* base = x + (int64_t)n * HW * C + 8 * g;
+    float s = 0.f;
+    for (int p = threadIdx.x; p < HW; p += 256) {
+        float v[8];
+        unpack8(*reinterpret_cast<const u32x4*>(base + (int64_t)p * C), v);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += v[i];
+    }
+    const float m = (float)HW * 8.0f;
+    const float mu = block_sum(s, red) / m;
+    float q = 0.f;
+    for (int p = threadIdx.x; p < HW; p += 256) {
+        float v[8];
+        unpack8(*reinterpret_cast<const u32x4*>(base + (int64_t)p * C), v);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const float d = v[i] - mu; q += d * d; }
+    }
+    const float var = block_sum(q, red) / m;
+    if (threadIdx.x == 0) { mean[blockIdx.x] = mu; rstd[blockIdx.x] = rsqrtf(var + eps); }
+}
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(const uint16_t* __restrict__ x, const float* __restrict__ mean,
+                                                       const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, uint16_t* __restrict__ y, int64_t total_vec,
+                                                       int HW, int C, int G, int relu) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total_vec; i += (int64_t)gridDim.x * 256) {
+        const int g = (int)(i % G);
+        const int n = (int)(i / ((int64_t)HW * G));
+        const float mu = mean[n * G + g], rs = rstd[n * G + g];
+        float v[8], o[8];
+        unpack8(reinterpret_cast<const u32x4*>(x)[i], v);
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + 8 * g), g1 = *reinterpret_cast<const f32x4*>(gamma + 8 * g + 4);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + 8 * g), b1 = *reinterpret_cast<const f32x4*>(beta + 8 * g + 4);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float gm = k < 4 ? g0[k] : g1[k - 4], bt = k < 4 ? b0[k] : b1[k - 4];
+            const float t = (v[k] - mu) * rs * gm + bt;
+            o[k] = relu ? fmaxf(t, 0.f) : t;
+        }
+        reinterpret_cast<u32x4*>(y)[i] = pack8(o);
+    }
+}
+
+// part: [N*G][18] = s1, s2, dgamma[8], dbeta[8]
+__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            float* __restrict__ part, int HW, int C, int G, int relu) {
+    __shared__ float red[4];
+    const int n = blockIdx.x / G, g = blockIdx.x % G;
+    const int64_t off = (int64_t)n * HW * C + 8 * g;
+    const float mu = mean[blockIdx.x], rs = rstd[blockIdx.x];
+    float gm[8], bt[8], dg[8], db[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { gm[k] = gamma[8 * g + k]; bt[k] = beta[8 * g + k]; dg[k] = db[k] = 0.f; }
+    float s1 = 0.f, s2 = 0.f;
+    for (int p = threadIdx.x; p < HW; p += 256) {
+        float v[8], d[8];
+        unpack8(*reinterpret_cast<const u32x4*>(x + off + (int64_t)p * C), v);
+        unpack8(*reinterpret_cast<const u32x4*>(dy + off + (int64_t)p * C), d);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float xh = (v[k] - mu) * rs;
+            const float dh = (relu && !(xh * gm[k] + bt[k] > 0.f)) ? 0.f : d[k];
+            dg[k] += dh * xh;
+            db[k] += dh;
+            s1 += dh * gm[k];
+            s2 += dh * gm[k] * xh;
+        }
+    }
+    float* out = part + (int64_t)blockIdx.x * 18;
+    float r = block_sum(s1, red);
+    if (threadIdx.x == 0) out[0] = r;
+    r = block_sum(s2, red);
+    if (threadIdx.x == 0) out[1] = r;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        r = block_sum(dg[k], red);
+        if (threadIdx.x == 0) out[2 + k] = r;
+        r = block_sum(db[k], red);
+        if (threadIdx.x == 0) out[10 + k] = r;
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_bwd_dx_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy,
+                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        const float* __restrict__ part, uint16_t* __restrict__ dx, int64_t total_vec,
+                                                        int HW, int C, int G, int relu) {
+    const float inv_m = 1.0f / ((float)HW * 8.0f);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total_vec; i += (int64_t)gridDim.x * 256) {
+        const int g = (int)(i % G);
+        const int n = (int)(i / ((int64_t)HW * G));
+        const int ng = n * G + g;
+        const float mu = mean[ng], rs = rstd[ng], s1 = part[(int64_t)ng * 18], s2 = part[(int64_t)ng * 18 + 1];
+        float v[8], d[8], o[8];
+        unpack8(reinterpret_cast<const u32x4*>(x)[i], v);
+        unpack8(reinterpret_cast<const u32x4*>(dy)[i], d);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float gm = gamma[8 * g + k], bt = beta[8 * g + k];
+            const float xh = (v[k] - mu) * rs;
+            const float dh = (relu && !(xh * gm + bt > 0.f)) ? 0.f : d[k];
+            o[k] = rs * (dh * gm - (s1 + xh * s2) * inv_m);
+        }
+        reinterpret_cast<u32x4*>(dx)[i] = pack8(o);
+    }
+}
+
+// dgamma[c] += sum_n part[n][g][2 + k], dbeta likewise (c = 8 g + k)
+__global__ __launch_bounds__(256) void gn_bwd_param_kernel(const float* __restrict__ part, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta, int N, int C, int G) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const int g = c >> 3, k = c & 7;
+    float a = 0.f, b = 0.f;
+    for (int n = 0; n < N; ++n) {
+        a += part[((int64_t)n * G + g) * 18 + 2 + k];
+        b += part[((int64_t)n * G + g) * 18 + 10 + k];
+    }
+    dgamma[c] += a;
+    dbeta[c] += b;
+}
+
+extern "C" int dgx_groupnorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                                 int N, int HW, int C, int G, float eps, int relu, void* stream) {
+    if (N <= 0 || HW <= 0) return DGX_OK;
+    if (!x || !gamma || !beta || !y || !mean || !rstd || C != 8 * G) return DGX_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(N * G), dim3(256), 0, st, (const uint16_t*)x, mean, rstd, HW, C, G, eps);
+    const int64_t tv = (int64_t)N * HW * G;
+    const int grid = (int)((tv + 255) / 256 < 4096 ? (tv + 255) / 256 : 4096);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(grid), dim3(256), 0, st, (const uint16_t*)x, mean, rstd, gamma, beta, (uint16_t*)y, tv, HW,
+                       C, G, relu);
+    DGX_LAUNCH_CHECK();
+    return DGX_OK;
+}
+
+extern "C" int dgx_groupnorm_bwd(const void* x, const void* dy, const float* mean, const float* rstd, const float* gamma,
+                                 const float* beta, void* dx, float* dgamma, float* dbeta, float* part, int N, int HW, int C, int G,
+                                 int relu, void* stream) {
+    if (N <= 0 || HW <= 0) return DGX_OK;
+    if (!x || !dy || !mean || !rstd || !gamma || !beta || !dx || !dgamma || !dbeta || !part || C != 8 * G) return DGX_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(N * G), dim3(256), 0, st, (const uint16_t*)x, (const uint16_t*)dy, mean, rstd, gamma,
+                       beta, part, HW, C, G, relu);
+    const int64_t tv = (int64_t)N * HW * G;
+    const int grid = (int)((tv + 255) / 256 < 4096 ? (tv + 255) / 256 : 4096);
+    hipLaunchKernelGGL(gn_bwd_dx_kernel, dim3(grid), dim3(256), 0, st, (const uint16_t*)x, (const uint16_t*)dy, mean, rstd, gamma, beta,
+                       part, (uint16_t*)dx, tv, HW, C, G, relu);
+    hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((C + 255) / 256), dim3(256), 0, st, part, dgamma, dbeta, N, C, G);
+    DGX_LAUNCH_CHECK();
+    return DGX_OK;
+}

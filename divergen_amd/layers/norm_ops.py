@@ -86,3 +86,56 @@ class _ResidualAdd(torch.autograd.Function):
 def residual_add(x, y, scale, B, H, W, ws=0, shift=0):
     """x (B, H*W, C) fp32|bf16, y bf16 ((B, H*W, C) or windows (B*nW, ws*ws, C)), scale (B,) f32 or None."""
     return _ResidualAdd.apply(x, y, scale, B, H, W, ws, shift)
+
+
+class _GroupNormReLU(torch.autograd.Function):
+    """GroupNorm (8 channels per group) + optional ReLU on channels-last bf16 activations (libdgx dgx_groupnorm_*).
+    x: physical (N, H, W, C) bf16 contiguous."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, G, eps, relu):
+        N, H, W, C = x.shape
+        y = torch.empty_like(x)
+        mean = torch.empty(N * G, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(N * G, dtype=torch.float32, device=x.device)
+        w32, b32 = weight.detach().float().contiguous(), bias.detach().float().contiguous()
+        L.check(L.lib().dgx_groupnorm_fwd(L.ptr(x), L.ptr(w32), L.ptr(b32), L.ptr(y), L.ptr(mean), L.ptr(rstd), N, H * W, C, G,
+                                          float(eps), int(relu), L.stream()), "dgx_groupnorm_fwd")
+        ctx.save_for_backward(x, mean, rstd, w32, b32)
+        ctx.weight, ctx.bias, ctx.cfg = weight, bias, (N, H, W, C, G, relu)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, rstd, w32, b32 = ctx.saved_tensors
+        weight, bias = ctx.weight, ctx.bias
+        N, H, W, C, G, relu = ctx.cfg
+        dy = dy.contiguous()
+        if dy.dtype != torch.bfloat16:
+            dy = dy.to(torch.bfloat16)
+        dx = torch.empty_like(x)
+        part = torch.empty(N * G * 18, dtype=torch.float32, device=x.device)
+        in_arena = (weight.is_leaf and bias.is_leaf and weight.grad is not None and bias.grad is not None
+                    and weight.grad.dtype == torch.float32 and getattr(weight, "_dgx16", None) is not None
+                    and getattr(bias, "_dgx16", None) is not None)
+        dg = weight.grad if in_arena else torch.zeros(C, dtype=torch.float32, device=x.device)
+        db = bias.grad if in_arena else torch.zeros(C, dtype=torch.float32, device=x.device)
+        L.check(L.lib().dgx_groupnorm_bwd(L.ptr(x), L.ptr(dy), L.ptr(mean), L.ptr(rstd), L.ptr(w32), L.ptr(b32), L.ptr(dx), L.ptr(dg),
+                                          L.ptr(db), L.ptr(part), N, H * W, C, G, int(relu), L.stream()), "dgx_groupnorm_bwd")
+        if in_arena:
+            notify_ready(weight)
+            notify_ready(bias)
+            return dx, None, None, None, None, None
+        return dx, dg.to(weight.dtype), db.to(bias.dtype), None, None, None
+
+
+def groupnorm_relu(x, weight, bias, num_groups, eps=1e-5, relu=True):
+    """x logical (N, C, H, W) with channels-last storage, bf16 -> same.  Falls back to torch for other layouts."""
+    N, C, H, W = x.shape
+    if not (x.is_cuda and x.dtype == torch.bfloat16 and C == 8 * num_groups):
+        y = torch.nn.functional.group_norm(x, num_groups, weight, bias, eps)
+        return torch.relu(y) if relu else y
+    xp = x.permute(0, 2, 3, 1).contiguous()
+    with torch.autocast("cuda", enabled=False):
+        y = _GroupNormReLU.apply(xp, weight, bias, num_groups, eps, relu)
+    return y.permute(0, 3, 1, 2)

@@ -8,6 +8,7 @@ from torch import nn
 from torch.nn import functional as F
 
 from ...config import configurable
+from ...layers.norm_ops import groupnorm_relu
 from ...layers.conv_ops import Conv2d, conv3x3
 
 
@@ -64,12 +65,29 @@ class CenterNetHead(nn.Module):
                     num_cls_convs=c.NUM_CLS_CONVS, num_box_convs=c.NUM_BOX_CONVS, num_share_convs=c.NUM_SHARE_CONVS,
                     use_deformable=c.USE_DEFORMABLE, prior_prob=c.PRIOR_PROB)
 
+    @staticmethod
+    def _run_tower(tower, x):
+        """nn.Sequential of (Conv2d, GroupNorm, ReLU) triples; GroupNorm + ReLU go out as one channels-last kernel
+        pair when the activation is bf16 (autocast) -- no NCHW<->NHWC copies between the convolutions."""
+        mods = list(tower)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if (isinstance(m, nn.GroupNorm) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+                    and x.is_cuda and x.dtype == torch.bfloat16 and m.num_channels == 8 * m.num_groups):
+                x = groupnorm_relu(x, m.weight, m.bias, m.num_groups, m.eps, relu=True)
+                i += 2
+            else:
+                x = m(x)
+                i += 1
+        return x
+
     def forward(self, x):
         clss, bbox_reg, agn_hms = [], [], []
         for l, feature in enumerate(x):
-            feature = self.share_tower(feature)
-            cls_tower = self.cls_tower(feature)
-            bbox_tower = self.bbox_tower(feature)
+            feature = self._run_tower(self.share_tower, feature)
+            cls_tower = self._run_tower(self.cls_tower, feature)
+            bbox_tower = self._run_tower(self.bbox_tower, feature)
             clss.append(None if self.only_proposal else self.cls_logits(cls_tower))
             if self.with_agn_hm:
                 # agn_hm (1 ch) and bbox_pred (4 ch) read the same tower output: one im2col + one GEMM

@@ -263,6 +263,18 @@ int dgx_linear_wgrad_grouped(const dgx_wgrad_problem* problems, int n, float bet
 int64_t dgx_colsum_workspace_bytes(int M, int N);
 int dgx_colsum_bf16(const void* dy_bf16, float* out, int M, int N, float beta, void* workspace, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * GroupNorm (+ ReLU) over channels-last bf16 activations with 8 channels per group: the Conv -> GroupNorm(32)
+ * -> ReLU unit of the CenterNet tower (CN/modeling/dense_heads/centernet_head.py:52-75; torch.nn.GroupNorm
+ * semantics: biased variance over (HW, C/G), eps inside the sqrt).  x, y, dy, dx bf16 (N, HW, C); C == 8*G.
+ * mean / rstd f32 (N*G) saved by forward.  Backward ACCUMULATES into dgamma / dbeta (f32 C);
+ * part: f32 scratch N*G*18. */
+int dgx_groupnorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                      int N, int HW, int C, int G, float eps, int relu, void* stream);
+int dgx_groupnorm_bwd(const void* x, const void* dy, const float* mean, const float* rstd, const float* gamma,
+                      const float* beta, void* dx, float* dgamma, float* dbeta, float* part, int N, int HW,
+                      int C, int G, int relu, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -487,3 +487,28 @@ def test_linear_wgrad_grouped(shapes):
     for (gw, dy, x), ref in zip(probs, refs):
         ref0 = dy.cpu().double().t() @ x.cpu().double()
         assert (gw.cpu().double() - ref0).abs().max() <= 2e-5 * ref0.abs().max() + 1e-3
+
+
+@pytest.mark.parametrize("N,H,W,G,relu", [(2, 16, 12, 32, True), (1, 5, 7, 4, False), (2, 64, 64, 32, True)])
+def test_groupnorm_relu_channels_last(N, H, W, G, relu):
+    """Fused GroupNorm(+ReLU) on channels-last bf16 vs torch fp32 group_norm on the same bf16-rounded input."""
+    from divergen_amd.layers.norm_ops import groupnorm_relu
+    C = 8 * G
+    g = torch.Generator().manual_seed(99)
+    x = bf(torch.randn(N, C, H, W, generator=g) * 1.5 + 0.3)
+    gam, bet = torch.randn(C, generator=g), torch.randn(C, generator=g) * 0.5
+    go = bf(torch.randn(N, C, H, W, generator=g))
+    xr, gr, br = x.float().requires_grad_(True), gam.clone().requires_grad_(True), bet.clone().requires_grad_(True)
+    ref = torch.nn.functional.group_norm(xr, G, gr, br, 1e-5)
+    if relu:
+        ref = torch.relu(ref)
+    ref.backward(go.float())
+    xd = x.to(DEV).to(memory_format=torch.channels_last).requires_grad_(True)
+    gd, bd = gam.to(DEV).requires_grad_(True), bet.to(DEV).requires_grad_(True)
+    out = groupnorm_relu(xd, gd, bd, G, 1e-5, relu=relu)
+    out.backward(go.to(DEV))
+    # outputs / dx are stored in bf16 (2^-8 relative); parameter gradients are fp32 sums
+    torch.testing.assert_close(out.float().cpu(), ref.detach(), atol=4e-2, rtol=2e-2)
+    torch.testing.assert_close(xd.grad.float().cpu(), xr.grad, atol=4e-2, rtol=3e-2)
+    torch.testing.assert_close(gd.grad.cpu(), gr.grad, atol=2e-2 * (H * W) ** 0.5, rtol=2e-2)
+    torch.testing.assert_close(bd.grad.cpu(), br.grad, atol=2e-2 * (H * W) ** 0.5, rtol=2e-2)

@@ -20,6 +20,11 @@ class WgradProblem(ctypes.Structure):
     _fields_ = [("dy", c_p), ("x", c_p), ("gw", c_p), ("M", c_i), ("Nn", c_i), ("Kk", c_i)]
 
 
+class ColsumProblem(ctypes.Structure):
+    """struct dgx_colsum_problem (include/divergen_hip.h)."""
+    _fields_ = [("dy", c_p), ("out", c_p), ("M", c_i), ("N", c_i)]
+
+
 # name -> (restype, argtypes); must list every symbol include/divergen_hip.h declares
 SIGNATURES = {
     "dgx_build_arch": (ctypes.c_char_p, []),
@@ -53,6 +58,8 @@ SIGNATURES = {
     "dgx_groupnorm_bwd": (c_i, [c_p] * 10 + [c_i, c_i, c_i, c_i, c_i, c_p]),
     "dgx_colsum_workspace_bytes": (c_i64, [c_i, c_i]),
     "dgx_colsum_bf16": (c_i, [c_p, c_p, c_i, c_i, c_f, c_p, c_p]),
+    "dgx_colsum_grouped_workspace_bytes": (c_i64, [ctypes.POINTER(ColsumProblem), c_i]),
+    "dgx_colsum_grouped": (c_i, [ctypes.POINTER(ColsumProblem), c_i, c_f, c_p, c_p]),
     "dgx_residual_fwd": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "dgx_residual_bwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "dgx_adamw_ema_step": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_f,

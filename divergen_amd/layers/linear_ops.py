@@ -13,18 +13,17 @@ from .. import _lib as L
 
 BF16 = torch.bfloat16
 import os
-WGRAD_MIN_M = int(os.environ.get("DGX_WGRAD_MIN_M", 16384))   # measured crossover vs the library GEMM (tools/wgrad_probe2.py): long-M shapes only
+WGRAD_MIN_M = int(os.environ.get("DGX_WGRAD_MIN_M", 4096))   # measured crossover vs the library GEMM (tools/wgrad_probe2.py): long-M shapes only
 
 
 def wgrad_into(g2, dy2, x2, beta=1.0):
-    """g2 fp32 (Nn,Kk) = beta*g2 + dy2^T x2 through the M-split HIP kernel when shapes allow."""
+    """g2 fp32 (Nn,Kk) = beta*g2 + dy2^T x2: the 256x256 split-M MFMA kernel (dgx_linear_wgrad_grouped, here a group
+    of one) for the long contractions of this model, the library GEMM for short ones."""
     M, Nn = dy2.shape
     Kk = x2.shape[1]
-    if (dy2.is_cuda and M >= WGRAD_MIN_M and Nn % 8 == 0 and Kk % 8 == 0 and g2.is_contiguous()
-            and dy2.dtype == BF16 and x2.dtype == BF16):
-        ws = torch.empty(L.lib().dgx_wgrad_workspace_bytes(M, Nn, Kk), dtype=torch.uint8, device=dy2.device)
-        L.check(L.lib().dgx_linear_wgrad(L.ptr(dy2), L.ptr(x2), L.ptr(g2), M, Nn, Kk, float(beta), L.ptr(ws), L.stream()),
-                "dgx_linear_wgrad")
+    if (dy2.is_cuda and M >= WGRAD_MIN_M and Nn % 8 == 0 and Kk % 8 == 0 and g2.is_contiguous() and dy2.is_contiguous()
+            and x2.is_contiguous() and dy2.dtype == BF16 and x2.dtype == BF16 and M * max(Nn, Kk) * 2 < (1 << 31)):
+        wgrad_grouped([(g2, dy2, x2)], beta)
     elif beta == 0.0:
         torch.mm(dy2.t(), x2, out_dtype=torch.float32, out=g2)
     else:

@@ -37,13 +37,21 @@ def colsum_into(gb, dy2, beta=1.0):
     L.check(lib.dgx_colsum_bf16(L.ptr(dy2), L.ptr(gb), M, N, float(beta), L.ptr(ws), L.stream()), "dgx_colsum_bf16")
 
 
+def colsum_grouped(problems, beta=1.0):
+    """[(gb fp32 (N,), dy2 bf16 (M, N)), ...] (<= 8): gb = beta*gb + dy2.sum(0) for all of them in two launches."""
+    n = len(problems)
+    arr = (L.ColsumProblem * n)()
+    for i, (gb, dy2) in enumerate(problems):
+        arr[i].dy, arr[i].out, arr[i].M, arr[i].N = dy2.data_ptr(), gb.data_ptr(), dy2.shape[0], dy2.shape[1]
+    lib = L.lib()
+    ws = torch.empty(max(int(lib.dgx_colsum_grouped_workspace_bytes(arr, n)), 4), dtype=torch.uint8, device=problems[0][1].device)
+    L.check(lib.dgx_colsum_grouped(arr, n, float(beta), L.ptr(ws), L.stream()), "dgx_colsum_grouped")
+
+
 def _linear_bwd(dy2, x2, weight, bias, w16, wgrads):
     """Bias gradient of y = x W^T + b into the arena, weight gradient queued for the block's grouped
-    weight-gradient launch; returns dx (bf16)."""
-    wgrads.append((weight.grad.view(weight.shape[0], -1), dy2, x2))
-    if bias is not None:
-        colsum_into(bias.grad, dy2)
-        _ready(bias)
+    weight-gradient / bias-gradient launches; returns dx (bf16)."""
+    wgrads.append((weight.grad.view(weight.shape[0], -1), dy2, x2, bias))
     return torch.mm(dy2, w16)
 
 
@@ -143,8 +151,9 @@ class _SwinBlockFn(torch.autograd.Function):
                                       T, C, B, H, W, ws, shift, code, st), "dgx_layernorm_bwd")
         _ready(n1w, n1b)
         # the four weight gradients of the block: one grouped launch (256x256 tiles, small M-split)
-        wgrad_grouped(wgrads)
-        _ready(w2, w1, pw, qw)
+        wgrad_grouped([(g, d, x_) for g, d, x_, _ in wgrads])
+        colsum_grouped([(b.grad, d) for _, d, _, b in wgrads if b is not None])
+        _ready(w2, w1, pw, qw, b2, b1, pb, qb)
         return (dx1,) + (None,) * 17
 
 

@@ -262,6 +262,14 @@ int dgx_linear_wgrad_grouped(const dgx_wgrad_problem* problems, int n, float bet
  * out fp32.  N % 8 == 0.  workspace: dgx_colsum_workspace_bytes(M, N) bytes. */
 int64_t dgx_colsum_workspace_bytes(int M, int N);
 int dgx_colsum_bf16(const void* dy_bf16, float* out, int M, int N, float beta, void* workspace, void* stream);
+/* grouped form: n <= 8 (dy, out, M, N) problems -- the bias gradients of a whole block -- in two launches */
+typedef struct dgx_colsum_problem {
+    const void* dy;   /* bf16 (M, N) row-major */
+    float* out;       /* f32 (N) */
+    int M, N;
+} dgx_colsum_problem;
+int64_t dgx_colsum_grouped_workspace_bytes(const dgx_colsum_problem* problems, int n);
+int dgx_colsum_grouped(const dgx_colsum_problem* problems, int n, float beta, void* workspace, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * GroupNorm (+ ReLU) over channels-last bf16 activations with 8 channels per group: the Conv -> GroupNorm(32)

@@ -351,6 +351,12 @@ def test_linear_wgrad_split_m(M, Nn, Kk):
     wgrad_into(acc, dy.to(DEV), x.to(DEV), 1.0)
     # bf16 products are exact in fp32; only the fp32 summation order differs: 1e-5 of the result scale
     assert (acc.cpu() - ref).abs().max() <= 2e-5 * ref.abs().max() + 1e-3
+    # the single-problem 128x128 kernel of the same ABI family (dgx_linear_wgrad) stays covered through the C ABI
+    from divergen_amd import _lib as L
+    acc2, dyd, xd = acc0.to(DEV).clone(), dy.to(DEV), x.to(DEV)
+    ws = torch.empty(L.lib().dgx_wgrad_workspace_bytes(M, Nn, Kk), dtype=torch.uint8, device=DEV)
+    L.check(L.lib().dgx_linear_wgrad(L.ptr(dyd), L.ptr(xd), L.ptr(acc2), M, Nn, Kk, 1.0, L.ptr(ws), L.stream()), "dgx_linear_wgrad")
+    assert (acc2.cpu() - ref).abs().max() <= 2e-5 * ref.abs().max() + 1e-3
 
 
 @pytest.mark.parametrize("xdt", [torch.float32, torch.bfloat16])
@@ -512,3 +518,16 @@ def test_groupnorm_relu_channels_last(N, H, W, G, relu):
     torch.testing.assert_close(xd.grad.float().cpu(), xr.grad, atol=4e-2, rtol=3e-2)
     torch.testing.assert_close(gd.grad.cpu(), gr.grad, atol=2e-2 * (H * W) ** 0.5, rtol=2e-2)
     torch.testing.assert_close(bd.grad.cpu(), br.grad, atol=2e-2 * (H * W) ** 0.5, rtol=2e-2)
+
+
+def test_colsum_grouped():
+    from divergen_amd.layers.swin_block import colsum_grouped
+    g = torch.Generator().manual_seed(92)
+    probs, refs = [], []
+    for M, N in [(8192, 768), (10368, 2304), (37, 200), (5, 1536)]:
+        dy, a0 = bf(torch.randn(M, N, generator=g)), torch.randn(N, generator=g)
+        refs.append(a0.double() + dy.double().sum(0))
+        probs.append((a0.to(DEV), dy.to(DEV)))
+    colsum_grouped(probs)
+    for (acc, dy), ref in zip(probs, refs):
+        assert (acc.cpu().double() - ref).abs().max() <= 1e-6 * (dy.cpu().double().abs().sum(0).max() + 1)

@@ -66,7 +66,12 @@ __device__ __forceinline__ void block_to_window_head(int bid, int nH, int& b, in
     h = slot % nH;
 }
 
-template <int WS>
+// Softmax runs in the log2 domain: the bias row is pre-multiplied by log2(e) when it is staged in LDS and the
+// score is one FMA, s2 = qk * (scale*log2e) + bias2 (the -100 of the shift mask becomes -100*log2e), so that
+// p = exp2(s2 - max2) is a bare v_exp_f32.  MASKED = false (W-MSA blocks) drops the region compare entirely.
+#define DGX_LOG2E 1.4426950408889634f
+#define DGX_LN2 0.6931471805599453f
+template <int WS, bool MASKED>
 __global__ __launch_bounds__(WinCfg<WS>::NT * 64) void win_attn_fwd_kernel(
     const uint16_t* __restrict__ qkv, const float* __restrict__ table, const int8_t* __restrict__ region,
     uint16_t* __restrict__ out, float* __restrict__ lse, int B_, int nW, int nH, float scale) {
@@ -75,6 +80,8 @@ __global__ __launch_bounds__(WinCfg<WS>::NT * 64) void win_attn_fwd_kernel(
     constexpr int RR = 40;   // row stride (elements) of the row-major V image
     __shared__ __attribute__((aligned(16))) uint16_t Vs[NP * RR];
     __shared__ float tbl[TBL];
+    __shared__ __attribute__((aligned(16))) int koff_s[NP];   // rel-pos offset of key k: yk*(2WS-1) + xk
+    __shared__ __attribute__((aligned(16))) int kreg_s[NP];   // region id of key k (this window); padded keys: -1
 
     int b, h;
     block_to_window_head(blockIdx.x, nH, b, h);
@@ -84,7 +91,13 @@ __global__ __launch_bounds__(WinCfg<WS>::NT * 64) void win_attn_fwd_kernel(
     const uint16_t* base = qkv + (int64_t)b * N * rowst + h * 32;
     const int tid = threadIdx.x, nthreads = NT * 64;
 
-    for (int i = tid; i < TBL; i += nthreads) tbl[i] = table[h * TBL + i];
+    const int8_t* reg = region + (int64_t)(b % nW) * N;
+    for (int i = tid; i < TBL; i += nthreads) tbl[i] = table[h * TBL + i] * DGX_LOG2E;
+    for (int i = tid; i < NP; i += nthreads) {
+        const int yk = i / WS;
+        koff_s[i] = i < N ? yk * (2 * WS - 1) + (i - yk * WS) : 0;
+        kreg_s[i] = (MASKED && i < N) ? (int)reg[i] : -1;
+    }
     stage_rows<N, NP, RR>(Vs, base + 2 * C, rowst, tid, nthreads);
     __syncthreads();
 
@@ -92,10 +105,13 @@ __global__ __launch_bounds__(WinCfg<WS>::NT * 64) void win_attn_fwd_kernel(
     const int qi = 16 * w + c16;
     const bool qok = qi < N;
     const bf16x8 qf = ld_frag_global(base + (int64_t)qi * rowst + 8 * g, qok);
-    const int8_t* reg = region + (int64_t)(b % nW) * N;
-    const int rq = qok ? reg[qi] : 0;
+    const int rq = (MASKED && qok) ? (int)reg[qi] : 0;
     const int yq = qi / WS, xq = qi - yq * WS;
-    const int base_q = (yq + WS - 1) * (2 * WS - 1) + (xq + WS - 1);
+    const int base_q = qok ? (yq + WS - 1) * (2 * WS - 1) + (xq + WS - 1) : (WS - 1) * (2 * WS - 1) + (WS - 1);
+    const float scale2 = scale * DGX_LOG2E;
+    DGX_LDS const float* tbl_q = lds_opaque(tbl + base_q);
+    DGX_LDS const int* koff_g = lds_opaque(koff_s + 4 * g);
+    DGX_LDS const int* kreg_g = lds_opaque(kreg_s + 4 * g);
 
     float p[NTK][4];
     float mx = -INFINITY;
@@ -105,16 +121,14 @@ __global__ __launch_bounds__(WinCfg<WS>::NT * 64) void win_attn_fwd_kernel(
         const bf16x8 kf = ld_frag_global(base + C + (int64_t)kr * rowst + 8 * g, kr < N);
         f32x4 z = {0.f, 0.f, 0.f, 0.f};
         const f32x4 acc = mfma16(kf, qf, z);  // acc[r] = S^T[key 16kt+4g+r][query c16]
+        const i32x4 ko = *reinterpret_cast<DGX_LDS const i32x4*>(koff_g + 16 * kt);
+        i32x4 kr4 = {0, 0, 0, 0};
+        if (MASKED) kr4 = *reinterpret_cast<DGX_LDS const i32x4*>(kreg_g + 16 * kt);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int key = 16 * kt + 4 * g + r;
-            float s = -INFINITY;
-            if (key < N) {
-                const int yk = key / WS, xk = key - yk * WS;
-                const int idx = qok ? base_q - (yk * (2 * WS - 1) + xk) : 0;
-                s = acc[r] * scale + tbl[idx];
-                if (reg[key] != rq) s += -100.0f;
-            }
+            float s = __builtin_fmaf(acc[r], scale2, tbl_q[-ko[r]]);
+            if (MASKED) s += kr4[r] != rq ? -100.0f * DGX_LOG2E : 0.0f;
+            if (NP != N && 16 * kt + 4 * g + r >= N) s = -INFINITY;   // padded key columns (NTK rounds the key tiles up to even)
             p[kt][r] = s;
             mx = fmaxf(mx, s);
         }
@@ -126,13 +140,13 @@ __global__ __launch_bounds__(WinCfg<WS>::NT * 64) void win_attn_fwd_kernel(
     for (int kt = 0; kt < NTK; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float e = __expf(p[kt][r] - mx);
+            const float e = __builtin_amdgcn_exp2f(p[kt][r] - mx);
             p[kt][r] = e;
             sum += e;
         }
     sum += __shfl_xor(sum, 16);
     sum += __shfl_xor(sum, 32);
-    if (g == 0 && qok) lse[((int64_t)b * nH + h) * N + qi] = mx + __logf(sum);
+    if (g == 0 && qok) lse[((int64_t)b * nH + h) * N + qi] = mx * DGX_LN2 + __logf(sum);   // natural-log LSE, as before
     const float inv = 1.0f / sum;
 
     f32x4 o[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -175,7 +189,7 @@ struct BwdPrefetch {
     int reg;
 };
 
-template <int WS>
+template <int WS, bool MASKED>
 __global__ __launch_bounds__(WinCfg<WS>::NT * 64) void win_attn_bwd_kernel(
     const uint16_t* __restrict__ qkv, const float* __restrict__ table, const int8_t* __restrict__ region,
     const uint16_t* __restrict__ out, const float* __restrict__ lse, const uint16_t* __restrict__ dout,
@@ -209,19 +223,19 @@ __global__ __launch_bounds__(WinCfg<WS>::NT * 64) void win_attn_bwd_kernel(
     const int key = 16 * w + c16;              // this lane's key in phase 1
     const bool kok = key < N;
     // transpose-read lane pointers: phase 1 k-slots are rows {32t+4g+j, 32t+16+4g+j}; phase 2 rows 32t+8g+j
-    DGX_LDS const uint16_t* q_l4 = tr_lane_ptr(Qs, RR, 4 * g, 0, c16);
-    DGX_LDS const uint16_t* do_l4 = tr_lane_ptr(dOs, RR, 4 * g, 0, c16);
+    DGX_LDS const uint16_t* q_l4 = tr_lane_ptr(Qs, RR, 4 * g, 0, c16);       // dOs / Ks images are NP*RR / 2*NP*RR further on
+    DGX_LDS const uint16_t* do_l4 = q_l4 + NP * RR;
     DGX_LDS const uint16_t* k_l8 = tr_lane_ptr(Ks, RR, 8 * g, 0, c16);
     DGX_LDS const uint16_t* ds_l8 = tr_lane_ptr(dSt, RD, 8 * g, 16 * w, c16);
     DGX_LDS uint16_t* img_st = lds_opaque(Qs + srow * RR + 8 * sc);         // staging destinations
     DGX_LDS float* meta_st = lds_opaque(lse_s + srow);                      // lse_s / delta_s / qoff_s / reg_s are NP apart
     // phase-1 lane pointers (everything in the unrolled loop is one of these + a constant)
     DGX_LDS const uint16_t* q_row = lds_opaque(Qs + c16 * RR + 8 * g);      // A fragment of query tile qt: + 16*qt*RR
-    DGX_LDS const uint16_t* do_row = lds_opaque(dOs + c16 * RR + 8 * g);
-    DGX_LDS const float* lse_g = lds_opaque(lse_s + 4 * g);                 // rows 16*qt + 4g .. +3
-    DGX_LDS const float* delta_g = lds_opaque(delta_s + 4 * g);
-    DGX_LDS const int* qoff_g = lds_opaque(qoff_s + 4 * g);
-    DGX_LDS const int* reg_g = lds_opaque(reg_s + 4 * g);
+    DGX_LDS const uint16_t* do_row = q_row + NP * RR;
+    DGX_LDS const float* lse_g = lds_opaque(lse_s + 4 * g);                 // rows 16*qt + 4g .. +3; the four arrays are NP apart
+    DGX_LDS const float* delta_g = lse_g + NP;
+    DGX_LDS const int* qoff_g = reinterpret_cast<DGX_LDS const int*>(lse_g) + 2 * NP;
+    DGX_LDS const int* reg_g = reinterpret_cast<DGX_LDS const int*>(lse_g) + 3 * NP;
     DGX_LDS uint16_t* ds_w = lds_opaque(dSt + key * RD + 4 * g);            // dS^T row `key`, queries 16*qt + 4g ..
 
     // global addressing = uniform (SGPR) window base + one 32-bit lane offset per access pattern
@@ -254,7 +268,7 @@ __global__ __launch_bounds__(WinCfg<WS>::NT * 64) void win_attn_bwd_kernel(
     };
 
     // ---- one-time LDS setup: bias row, zero padding rows/columns, rel-pos offsets
-    for (int i = tid; i < TBL; i += nthreads) { tbl[i] = table[h * TBL + i]; tblacc[i] = 0.f; }
+    for (int i = tid; i < TBL; i += nthreads) { tbl[i] = table[h * TBL + i] * DGX_LOG2E; tblacc[i] = 0.f; }   // log2 domain
     for (int i = tid; i < (NP - N) * RR; i += nthreads) { Qs[N * RR + i] = 0; dOs[N * RR + i] = 0; Ks[N * RR + i] = 0; }
     for (int i = tid; i < (NP - N) * RD; i += nthreads) dSt[N * RD + i] = 0;   // padded key rows feed the last K=32 step of dQ
     for (int i = tid; i < NP; i += nthreads) {
@@ -265,6 +279,7 @@ __global__ __launch_bounds__(WinCfg<WS>::NT * 64) void win_attn_bwd_kernel(
     const int yk = key / WS, xk = key - yk * WS;
     const int kbase = kok ? (WS - 1) * (2 * WS - 1) + (WS - 1) - (yk * (2 * WS - 1) + xk) : 0;
     const float kneg = kok ? 0.0f : -INFINITY;   // padded key columns: p = 0
+    const float scale2 = scale * DGX_LOG2E;
     DGX_LDS const float* tbl_k = lds_opaque(tbl + kbase);
     float dbias[NT][4];
 #pragma unroll
@@ -288,7 +303,7 @@ __global__ __launch_bounds__(WinCfg<WS>::NT * 64) void win_attn_bwd_kernel(
             for (int i = 0; i < 8; ++i) d += bf2f((uint16_t)P.d[i]) * bf2f((uint16_t)P.o[i]);
             d += __shfl_xor(d, 1);
             d += __shfl_xor(d, 2);
-            if (sc == 0) { meta_st[NP] = d; meta_st[0] = P.lse; reinterpret_cast<DGX_LDS int*>(meta_st)[3 * NP] = P.reg; }
+            if (sc == 0) { meta_st[NP] = d; meta_st[0] = P.lse * DGX_LOG2E; reinterpret_cast<DGX_LDS int*>(meta_st)[3 * NP] = P.reg; }
         }
         const bf16x8 vf = P.v;
         CLK(0);
@@ -298,7 +313,7 @@ __global__ __launch_bounds__(WinCfg<WS>::NT * 64) void win_attn_bwd_kernel(
         if (b + 1 < b1) issue(b + 1, P);   // next window's loads fly under this window's math
 #endif
         const bf16x8 kf = *reinterpret_cast<const bf16x8*>(&Ks[(kok ? key : 0) * RR + 8 * g]);
-        const int rk = reg_s[kok ? key : 0];
+        const int rk = MASKED ? reg_s[kok ? key : 0] : 0;
 
         // ---- phase 1: this wave's 16 keys x all queries, two query tiles (one K=32 step) at a time
         f32x4 dV[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -319,12 +334,14 @@ __global__ __launch_bounds__(WinCfg<WS>::NT * 64) void win_attn_bwd_kernel(
                     const f32x4 lv = *reinterpret_cast<DGX_LDS const f32x4*>(lse_g + 16 * qt);
                     const f32x4 dl = *reinterpret_cast<DGX_LDS const f32x4*>(delta_g + 16 * qt);
                     const i32x4 ov = *reinterpret_cast<DGX_LDS const i32x4*>(qoff_g + 16 * qt);
-                    const i32x4 rv = *reinterpret_cast<DGX_LDS const i32x4*>(reg_g + 16 * qt);
+                    i32x4 rv = {0, 0, 0, 0};
+                    if (MASKED) rv = *reinterpret_cast<DGX_LDS const i32x4*>(reg_g + 16 * qt);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        float sv = s[r] * scale + tbl_k[ov[r]] + kneg;
-                        sv += rv[r] != rk ? -100.0f : 0.0f;
-                        pv[r] = __expf(sv - lv[r]);
+                        float sv = __builtin_fmaf(s[r], scale2, tbl_k[ov[r]]);       // log2 domain (bias row, lse pre-scaled)
+                        if (N % 16 != 0) sv += kneg;
+                        if (MASKED) sv += rv[r] != rk ? -100.0f * DGX_LOG2E : 0.0f;
+                        pv[r] = __builtin_amdgcn_exp2f(sv - lv[r]);
                         dsv[r] = pv[r] * (dp[r] - dl[r]);
                         dbias[qt < NT ? qt : 0][r] += dsv[r];
                     }
@@ -431,14 +448,14 @@ extern "C" int dgx_window_attention_fwd(const void* qkv, const float* table, con
     if (B_ <= 0) return DGX_OK;
     if (!qkv || !table || !out || !lse || nH <= 0 || nW <= 0 || (region && B_ % nW)) return DGX_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
+    const bool masked = region != nullptr;
     if (!region) { region = zero_region(); nW = 1; if (!region) return DGX_ERR_BAD_ARG; }
     const int grid = ((B_ + 7) / 8) * 8 * nH;
-    if (ws == 12)
-        hipLaunchKernelGGL(win_attn_fwd_kernel<12>, dim3(grid), dim3(WinCfg<12>::NT * 64), 0, st,
-                           (const uint16_t*)qkv, table, region, (uint16_t*)out, lse, B_, nW, nH, scale);
-    else if (ws == 7)
-        hipLaunchKernelGGL(win_attn_fwd_kernel<7>, dim3(grid), dim3(WinCfg<7>::NT * 64), 0, st,
-                           (const uint16_t*)qkv, table, region, (uint16_t*)out, lse, B_, nW, nH, scale);
+#define FWD_LAUNCH(WSV, MK) hipLaunchKernelGGL((win_attn_fwd_kernel<WSV, MK>), dim3(grid), dim3(WinCfg<WSV>::NT * 64), 0, st, \
+                                              (const uint16_t*)qkv, table, region, (uint16_t*)out, lse, B_, nW, nH, scale)
+    if (ws == 12) { if (masked) FWD_LAUNCH(12, true); else FWD_LAUNCH(12, false); }
+    else if (ws == 7) { if (masked) FWD_LAUNCH(7, true); else FWD_LAUNCH(7, false); }
+#undef FWD_LAUNCH
     else
         return DGX_ERR_UNSUPPORTED;
     DGX_LAUNCH_CHECK();
@@ -453,6 +470,7 @@ extern "C" int dgx_window_attention_bwd(const void* qkv, const float* table, con
     if (!qkv || !table || !out || !lse || !dout || !dqkv || !dtable || nH <= 0 || nW <= 0 || (region && B_ % nW))
         return DGX_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
+    const bool masked = region != nullptr;
     if (!region) { region = zero_region(); nW = 1; if (!region) return DGX_ERR_BAD_ARG; }
     // One workgroup per CU (LDS-limited) in a single round: per-workgroup setup (bias row, flush of the
     // bias-gradient row) is amortised over the chunk; measured best among 256/512/768/2048 targets.
@@ -460,24 +478,26 @@ extern "C" int dgx_window_attention_bwd(const void* qkv, const float* table, con
     int chunk = (B_ + nchunks - 1) / nchunks;
     if (chunk < 1) chunk = 1;
     const int grid = ((B_ + chunk - 1) / chunk) * nH;
+#define BWD_ARGS (const uint16_t*)qkv, table, region, (const uint16_t*)out, lse, (const uint16_t*)dout, (uint16_t*)dqkv, dtable, B_, nW, nH, \
+                 scale, chunk, dtable_stride_head, dtable_stride_index
     if (ws == 12) {
         static bool once = false;
         const size_t sm = bwd_smem_bytes<12>();
         if (!once) {
-            hipFuncSetAttribute((const void*)win_attn_bwd_kernel<12>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+            (void)hipFuncSetAttribute((const void*)win_attn_bwd_kernel<12, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+            (void)hipFuncSetAttribute((const void*)win_attn_bwd_kernel<12, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
             once = true;
         }
-        hipLaunchKernelGGL(win_attn_bwd_kernel<12>, dim3(grid), dim3(WinCfg<12>::NT * 64), sm, st,
-                           (const uint16_t*)qkv, table, region, (const uint16_t*)out, lse, (const uint16_t*)dout,
-                           (uint16_t*)dqkv, dtable, B_, nW, nH, scale, chunk, dtable_stride_head, dtable_stride_index);
+        if (masked) hipLaunchKernelGGL((win_attn_bwd_kernel<12, true>), dim3(grid), dim3(WinCfg<12>::NT * 64), sm, st, BWD_ARGS);
+        else hipLaunchKernelGGL((win_attn_bwd_kernel<12, false>), dim3(grid), dim3(WinCfg<12>::NT * 64), sm, st, BWD_ARGS);
     } else if (ws == 7) {
         const size_t sm = bwd_smem_bytes<7>();
-        hipLaunchKernelGGL(win_attn_bwd_kernel<7>, dim3(grid), dim3(WinCfg<7>::NT * 64), sm, st,
-                           (const uint16_t*)qkv, table, region, (const uint16_t*)out, lse, (const uint16_t*)dout,
-                           (uint16_t*)dqkv, dtable, B_, nW, nH, scale, chunk, dtable_stride_head, dtable_stride_index);
+        if (masked) hipLaunchKernelGGL((win_attn_bwd_kernel<7, true>), dim3(grid), dim3(WinCfg<7>::NT * 64), sm, st, BWD_ARGS);
+        else hipLaunchKernelGGL((win_attn_bwd_kernel<7, false>), dim3(grid), dim3(WinCfg<7>::NT * 64), sm, st, BWD_ARGS);
     } else {
         return DGX_ERR_UNSUPPORTED;
     }
+#undef BWD_ARGS
     DGX_LAUNCH_CHECK();
     return DGX_OK;
 }

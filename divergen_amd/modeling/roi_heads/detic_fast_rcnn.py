@@ -17,6 +17,10 @@ from ...utils.events import get_event_storage
 from ..box_regression import Box2BoxTransform
 
 
+import os
+_FUSED_LOSSES = os.environ.get("DGX_FUSED_LOSSES", "1") == "1"
+
+
 def load_class_freq(path="datasets/metadata/lvis_v1_train_cat_info.json", freq_weight=1.0):
     """DG/divergen/modeling/utils.py:7-13."""
     cat_info = json.load(open(path, "r"))
@@ -36,6 +40,61 @@ def get_fed_loss_inds(gt_classes, num_sample_cats, C, weight=None):
         more = torch.multinomial(prob, num_sample_cats - len(appeared), replacement=False)
         appeared = torch.cat([appeared, more])
     return appeared
+
+
+def fed_loss_class_mask(gt_classes, num_sample_cats, C, weight):
+    """get_fed_loss_inds (DG/divergen/modeling/utils.py:16-28) as a (C+1,) 0/1 mask, without reading anything back
+    to the host: the classes that appear, plus -- when fewer than num_sample_cats appear -- classes drawn without
+    replacement with probability ~ weight among the others.  torch.multinomial(prob, k, replacement=False) IS
+    `topk(prob / Exponential(1), k)`; the same draw is made here with k = num_sample_cats and only the first
+    num_sample_cats - n_appeared of it kept, so the class SET is the one the reference code would obtain from the
+    same generator state (when n_appeared >= num_sample_cats the reference draws nothing: the streams then differ)."""
+    app = torch.zeros(C + 1, dtype=torch.bool, device=gt_classes.device)
+    app[gt_classes] = True
+    prob = torch.ones(C + 1, dtype=torch.float32, device=gt_classes.device) if weight is None else \
+        torch.cat([weight.float(), weight.new_zeros(1).float()])
+    prob[C] = 0
+    prob = prob.masked_fill(app, 0)
+    q = prob / torch.empty_like(prob).exponential_(1)
+    k = min(num_sample_cats, C + 1)
+    vals, idx = torch.topk(q, k)
+    need = num_sample_cats - app.sum()                       # device scalar
+    take = (torch.arange(k, device=q.device) < need) & (vals > 0)
+    m = app.clone()
+    m[idx] = m[idx] | take
+    return m
+
+
+class _DeticLosses(torch.autograd.Function):
+    """loss_cls, loss_box_reg and the classification statistics of one cascade stage: libdgx dgx_detic_losses."""
+
+    @staticmethod
+    def forward(ctx, logits, deltas, gt_classes, class_w, prop, gtb, src, weights):
+        from ... import _lib as L
+        R, C1 = logits.shape
+        logits, deltas = logits.contiguous(), deltas.contiguous()
+        if deltas.dtype != logits.dtype:
+            deltas = deltas.to(logits.dtype)
+        dlogits = torch.empty_like(logits)
+        dsign = torch.empty(R, 4, dtype=torch.float32, device=logits.device)
+        out = torch.empty(16, dtype=torch.float32, device=logits.device)
+        part = torch.empty(max(R, 1) * 8, dtype=torch.float32, device=logits.device)
+        L.check(L.lib().dgx_detic_losses(L.ptr(logits), L.ptr(deltas), L.ptr(gt_classes.contiguous()),
+                                         L.ptr(class_w.float().contiguous()) if class_w is not None else None,
+                                         L.ptr(prop.float().contiguous()), L.ptr(gtb.float().contiguous()),
+                                         L.ptr(src.contiguous()) if src is not None else None, R, C1 - 1,
+                                         float(weights[0]), float(weights[1]), float(weights[2]), float(weights[3]),
+                                         L.ptr(dlogits), L.ptr(dsign), L.ptr(out), L.ptr(part), L.dtype_code(logits), L.stream()),
+                "dgx_detic_losses")
+        ctx.save_for_backward(dlogits, dsign, out)
+        ctx.ddt = deltas.dtype
+        ctx.mark_non_differentiable(out)
+        return out[8], out[9], out
+
+    @staticmethod
+    def backward(ctx, g_cls, g_box, _):
+        dlogits, dsign, out = ctx.saved_tensors
+        return dlogits * g_cls.to(dlogits.dtype), (dsign * (g_box * out[10])).to(ctx.ddt), None, None, None, None, None, None
 
 
 def fast_rcnn_inference_single_image(boxes, scores, image_shape, score_thresh, nms_thresh, topk_per_image):
@@ -136,7 +195,32 @@ class DeticFastRCNNOutputLayers(nn.Module):
             x = torch.flatten(x, start_dim=1)
         return self.cls_score(x), self.bbox_pred(x)
 
+    def _fused_losses(self, predictions, proposals):
+        """One kernel pair for loss_cls + loss_box_reg + logging statistics (sigmoid CE, class-agnostic L1)."""
+        scores, deltas = predictions
+        gt_classes = torch.cat([p.gt_classes for p in proposals], dim=0)
+        prop = torch.cat([p.proposal_boxes.tensor for p in proposals], dim=0)
+        gtb = torch.cat([(p.gt_boxes if p.has("gt_boxes") else p.proposal_boxes).tensor for p in proposals], dim=0)
+        src = None if self.divergen_box_loss else torch.cat([p.instance_source for p in proposals if len(p)], dim=0)
+        C = scores.shape[1] - 1
+        w = None
+        if self.use_fed_loss and self.freq_weight is not None:
+            w = fed_loss_class_mask(gt_classes, self.fed_loss_num_cat, C, self.freq_weight)[:C].float()
+        if self.ignore_zero_cats and self.freq_weight is not None:
+            z = (self.freq_weight.view(-1) > 1e-4).float()
+            w = z if w is None else w * z
+        with torch.autocast("cuda", enabled=False):
+            loss_cls, loss_box, out = _DeticLosses.apply(scores, deltas, gt_classes, w, prop, gtb, src, self.box2box_transform.weights)
+        st = get_event_storage()
+        st.put_scalar("fast_rcnn/cls_accuracy", out[11])
+        st.put_scalar("fast_rcnn/fg_cls_accuracy", out[12])
+        st.put_scalar("fast_rcnn/false_negative", out[13])
+        return {"loss_cls": loss_cls, "loss_box_reg": loss_box}
+
     def losses(self, predictions, proposals, classifier_info=(None, None, None)):
+        if (_FUSED_LOSSES and len(proposals) and predictions[0].is_cuda and predictions[0].shape[0] > 0 and self.use_sigmoid_ce
+                and predictions[1].shape[1] == 4 and self.smooth_l1_beta < 1e-5):
+            return self._fused_losses(predictions, proposals)
         scores, deltas = predictions[0].float(), predictions[1].float()
         gt_classes = torch.cat([p.gt_classes for p in proposals], dim=0) if len(proposals) else torch.empty(0)
         _log_classification_stats(scores, gt_classes)

@@ -283,6 +283,23 @@ int dgx_groupnorm_bwd(const void* x, const void* dy, const float* mean, const fl
                       const float* beta, void* dx, float* dgamma, float* dbeta, float* part, int N, int HW,
                       int C, int G, int relu, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Detic box-head losses of one cascade stage in one pass: sigmoid cross-entropy with per-class weights
+ * (federated loss / zero-category mask, detic_fast_rcnn.py:271-304), class-agnostic L1 box regression on the
+ * Box2Box deltas of the foreground rows [with instance_source == 0] (:160-235, box_regression.py:43-118) and the
+ * classification statistics of D2 fast_rcnn.py:88-114 -- forward values AND gradients.
+ *   logits (R, C+1), deltas (R, 4): f32 or bf16 (dtype);  gt_classes i64 (R) in [0, C] (C = background, <0 ignored
+ *   for the box term);  class_w f32 (C) or NULL (= 1);  prop, gtb f32 (R,4);  src i64 (R) or NULL
+ *   dlogits (R, C+1) same dtype as logits  = d loss_cls / d logits
+ *   dsign   f32 (R, 4)                     = sign(deltas - target) on selected rows, else 0
+ *   out16   f32 [16]: [8] loss_cls, [9] loss_box_reg, [10] 1/max(4*rows,1) (scale of dsign in backward),
+ *                     [11] cls_accuracy, [12] fg_cls_accuracy, [13] false_negative, [0..6] the raw sums
+ *   part    f32 scratch R*8 */
+int dgx_detic_losses(const void* logits, const void* deltas, const int64_t* gt_classes, const float* class_w,
+                     const float* prop, const float* gtb, const int64_t* src, int R, int C, float wx, float wy,
+                     float ww, float wh, void* dlogits, float* dsign, float* out16, float* part, int dtype,
+                     void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -240,3 +240,55 @@ def test_fused_swin_block_equals_composed_path(xdt, shift, monkeypatch):
     ga, gb = res[True][2], res[False][2]
     assert ga.abs().max() > 0
     assert (ga - gb).abs().max() <= 2e-3 * gb.abs().max()
+
+
+def test_fused_detic_losses_vs_reference_golden(golden):
+    """dgx_detic_losses (one pass: sigmoid CE with the federated class weights + L1 box regression + gradients) against
+    the outputs of the reference's own loss methods (golden 'roi_losses')."""
+    import divergen_amd.modeling.roi_heads.detic_fast_rcnn as M
+    g = golden("roi_losses")
+    C = 40
+    w = torch.zeros(C + 1)
+    w[T(g["appeared"]).long()] = 1
+    for dt, tol in ((torch.float32, 1e-5), (torch.bfloat16, 2e-2)):
+        logits = T(g["logits"]).to(DEV).to(dt).requires_grad_(True)
+        pd = T(g["pred_deltas"]).to(DEV).to(dt).requires_grad_(True)
+        gtc = T(g["gt_classes"]).to(DEV)
+        lc, lb, out = M._DeticLosses.apply(logits, pd, gtc, w[:C].to(DEV), T(g["prop_boxes"]).to(DEV), T(g["gt_boxes"]).to(DEV), None,
+                                           tuple(g["weights"].tolist()))
+        torch.testing.assert_close(lc.float().cpu(), T(g["loss_cls"]), atol=tol, rtol=tol)
+        torch.testing.assert_close(lb.float().cpu(), T(g["loss_box"]), atol=tol, rtol=tol)
+        (lc + lb).backward()
+        torch.testing.assert_close(logits.grad.float().cpu(), T(g["d_logits"]), atol=1e-7 if dt == torch.float32 else 2e-4, rtol=1e-4 if dt == torch.float32 else 2e-2)
+        # box gradient: sign(pred - target) / (4 * selected rows) on foreground rows
+        fgm = (gtc >= 0) & (gtc < C)
+        assert float(pd.grad.float()[~fgm].abs().max()) == 0.0
+        assert torch.allclose(pd.grad.float()[fgm].abs(), torch.full_like(pd.grad.float()[fgm], 1.0 / (4 * int(fgm.sum()))), rtol=1e-2)
+        # statistics = D2 fast_rcnn.py:88-114 on the same logits
+        pred = logits.detach().float().argmax(1)
+        assert abs(float(out[11]) - float((pred == gtc).float().mean())) < 1e-6
+
+
+def test_fed_loss_class_mask_matches_reference_draw():
+    """The sync-free class-set draw keeps the reference's set for the same generator state (multinomial without
+    replacement == top-k of prob / Exponential(1)), and its invariants."""
+    import divergen_amd.modeling.roi_heads.detic_fast_rcnn as M
+    C, K = 1203, 50
+    g = torch.Generator().manual_seed(3)
+    weight = (torch.rand(C, generator=g) ** 2).to(DEV)
+    weight[::7] = 0
+    for n_app in (0, 5, 49, 50, 80):
+        gt = torch.cat([torch.randperm(C, generator=g)[:n_app], torch.full((30,), C)]).to(DEV)      # + background rows
+        torch.manual_seed(1234)
+        ref = M.get_fed_loss_inds(gt, K, C, weight)
+        torch.manual_seed(1234)
+        m = M.fed_loss_class_mask(gt, K, C, weight)
+        app = torch.unique(gt)
+        assert bool(m[app].all())
+        assert int(m.sum()) == max(len(app), K)
+        extra = m.clone()
+        extra[app] = False
+        assert bool((weight[extra[:C].nonzero().squeeze(1)] > 0).all())
+        ref_m = torch.zeros(C + 1, dtype=torch.bool, device=DEV)
+        ref_m[ref] = True
+        assert torch.equal(m, ref_m), n_app

@@ -1,5 +1,8 @@
 """Dev helper: per-shape GEMM time in one training step (torch profiler, record_shapes)."""
-import os, sys, time, torch
+import os, sys, time
+sys.path.insert(0, ".")
+from divergen_amd.tuning import enable as _e; _e()
+import torch
 sys.path.insert(0, ".")
 from torch.profiler import ProfilerActivity, profile
 from divergen_amd.config import get_cfg

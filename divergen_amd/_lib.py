@@ -54,6 +54,8 @@ SIGNATURES = {
     "dgx_layernorm_bwd": (c_i, [c_p] * 10 + [c_i64, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "dgx_wgrad_grouped_workspace_bytes": (c_i64, [ctypes.POINTER(WgradProblem), c_i]),
     "dgx_linear_wgrad_grouped": (c_i, [ctypes.POINTER(WgradProblem), c_i, c_f, c_p, c_p]),
+    "dgx_cascade_refine": (c_i, [c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_i, c_f, c_f, c_f, c_f, c_f,
+                                 c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p]),
     "dgx_detic_losses": (c_i, [c_p] * 7 + [c_i, c_i, c_f, c_f, c_f, c_f, c_p, c_p, c_p, c_p, c_i, c_p]),
     "dgx_groupnorm_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_p]),
     "dgx_groupnorm_bwd": (c_i, [c_p] * 10 + [c_i, c_i, c_i, c_i, c_i, c_p]),

@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void detic_rows_kernel(const T* __restrict__ l
     const int64_t g = gt[r];
     const T* x = logits + (int64_t)r * (C + 1);
     T* dx = dlogits + (int64_t)r * (C + 1);
-    const float invR = 1.0f / (float)R;
+    const bool row_on = g >= 0;      // gt < 0: "ignore" row (dropped by the reference before the loss): no loss, no gradient
     float loss = 0.f, best = -INFINITY;
     int besti = 0x7fffffff;
     for (int c = threadIdx.x; c <= C; c += 256) {
@@ -44,8 +44,8 @@ __global__ __launch_bounds__(256) void detic_rows_kernel(const T* __restrict__ l
             const float t = (g == c) ? 1.0f : 0.0f;
             // torch's binary_cross_entropy_with_logits: (1 - t) x + m + log(exp(-m) + exp(-x - m)),  m = max(-x, 0)
             const float m = fmaxf(-v, 0.0f);
-            loss += w * ((1.0f - t) * v + m + logf(expf(-m) + expf(-v - m)));
-            st1<T>(dx + c, w * (1.0f / (1.0f + expf(-v)) - t) * invR);
+            if (row_on) loss += w * ((1.0f - t) * v + m + logf(expf(-m) + expf(-v - m)));
+            st1<T>(dx + c, row_on ? w * (1.0f / (1.0f + expf(-v)) - t) : 0.0f);      // scaled by 1/rows in backward
         } else {
             st1<T>(dx + c, 0.0f);      // the background column carries no loss
         }
@@ -93,15 +93,15 @@ __global__ __launch_bounds__(256) void detic_rows_kernel(const T* __restrict__ l
         o[0] = L;
         o[1] = lb;
         o[2] = sel;
-        o[3] = (bi == g) ? 1.0f : 0.0f;
+        o[3] = (row_on && bi == g) ? 1.0f : 0.0f;
         o[4] = (bi == g && fg) ? 1.0f : 0.0f;
         o[5] = (bi == C && fg) ? 1.0f : 0.0f;
         o[6] = fg ? 1.0f : 0.0f;
-        o[7] = 0.0f;
+        o[7] = row_on ? 1.0f : 0.0f;
     }
 }
 
-// out[0..6] = column sums of part over rows (fixed order), then the final normalisations
+// out[0..7] = column sums of part over rows (fixed order), then the final normalisations
 __global__ __launch_bounds__(256) void detic_fold_kernel(const float* __restrict__ part, int R, float* __restrict__ out) {
     __shared__ float red[4][NPART];
     float a[NPART];
@@ -125,11 +125,13 @@ __global__ __launch_bounds__(256) void detic_fold_kernel(const float* __restrict
     __syncthreads();
     if (threadIdx.x == 0) {
         const float rows = out[2];
-        out[8] = out[0] / (float)R;                        // loss_cls
+        const float nrow = fmaxf(out[7], 1.0f);            // rows that take part (all of them unless some are "ignore")
+        out[14] = 1.0f / nrow;                             // backward scale of the classification term
+        out[8] = out[0] / nrow;                            // loss_cls
         out[9] = out[1] / fmaxf(4.0f * rows, 1.0f);        // loss_box_reg
         out[10] = 1.0f / fmaxf(4.0f * rows, 1.0f);         // backward scale of the box term
         const float nfg = fmaxf(out[6], 1.0f);
-        out[11] = out[3] / (float)R;                       // cls_accuracy
+        out[11] = out[3] / nrow;                           // cls_accuracy
         out[12] = out[4] / nfg;                            // fg_cls_accuracy
         out[13] = out[5] / nfg;                            // false_negative
     }

@@ -94,7 +94,7 @@ class _DeticLosses(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_cls, g_box, _):
         dlogits, dsign, out = ctx.saved_tensors
-        return dlogits * g_cls.to(dlogits.dtype), (dsign * (g_box * out[10])).to(ctx.ddt), None, None, None, None, None, None
+        return dlogits * (g_cls * out[14]).to(dlogits.dtype), (dsign * (g_box * out[10])).to(ctx.ddt), None, None, None, None, None, None
 
 
 def fast_rcnn_inference_single_image(boxes, scores, image_shape, score_thresh, nms_thresh, topk_per_image):
@@ -195,13 +195,28 @@ class DeticFastRCNNOutputLayers(nn.Module):
             x = torch.flatten(x, start_dim=1)
         return self.cls_score(x), self.bbox_pred(x)
 
+    @property
+    def fused_supported(self):
+        """The one-pass loss / cascade kernels cover the shipped recipe: sigmoid CE, class-agnostic L1 box regression."""
+        return _FUSED_LOSSES and self.use_sigmoid_ce and self.bbox_pred.out_features == 4 and self.smooth_l1_beta < 1e-5
+
+    def fused_ok(self, scores, deltas):
+        return (_FUSED_LOSSES and scores.is_cuda and scores.shape[0] > 0 and self.use_sigmoid_ce and deltas.shape[1] == 4
+                and self.smooth_l1_beta < 1e-5)
+
     def _fused_losses(self, predictions, proposals):
-        """One kernel pair for loss_cls + loss_box_reg + logging statistics (sigmoid CE, class-agnostic L1)."""
         scores, deltas = predictions
         gt_classes = torch.cat([p.gt_classes for p in proposals], dim=0)
         prop = torch.cat([p.proposal_boxes.tensor for p in proposals], dim=0)
         gtb = torch.cat([(p.gt_boxes if p.has("gt_boxes") else p.proposal_boxes).tensor for p in proposals], dim=0)
         src = None if self.divergen_box_loss else torch.cat([p.instance_source for p in proposals if len(p)], dim=0)
+        return self.losses_from_tensors(scores, deltas, gt_classes, prop, gtb, src)
+
+    def losses_from_tensors(self, scores, deltas, gt_classes, prop, gtb, src):
+        """One kernel pair for loss_cls + loss_box_reg + logging statistics (sigmoid CE, class-agnostic L1);
+        rows with gt_classes < 0 are ignored.  `src` (instance_source) is used only when the DiverGen box loss is off."""
+        if self.divergen_box_loss:
+            src = None
         C = scores.shape[1] - 1
         w = None
         if self.use_fed_loss and self.freq_weight is not None:
@@ -218,8 +233,7 @@ class DeticFastRCNNOutputLayers(nn.Module):
         return {"loss_cls": loss_cls, "loss_box_reg": loss_box}
 
     def losses(self, predictions, proposals, classifier_info=(None, None, None)):
-        if (_FUSED_LOSSES and len(proposals) and predictions[0].is_cuda and predictions[0].shape[0] > 0 and self.use_sigmoid_ce
-                and predictions[1].shape[1] == 4 and self.smooth_l1_beta < 1e-5):
+        if len(proposals) and self.fused_ok(predictions[0], predictions[1]):
             return self._fused_losses(predictions, proposals)
         scores, deltas = predictions[0].float(), predictions[1].float()
         gt_classes = torch.cat([p.gt_classes for p in proposals], dim=0) if len(proposals) else torch.empty(0)

@@ -200,7 +200,67 @@ class DeticCascadeROIHeads(nn.Module):
         scores, deltas = self.box_predictor[stage](self.box_head[stage](x))
         return scores[:R], deltas[:R]
 
+    def _forward_box_train(self, features, proposals, targets):
+        """Training cascade with the stage hand-over (decode, clip, re-match, gather: `_create_proposals_from_boxes` +
+        `_match_and_label_boxes` + `predict_boxes`) as ONE kernel per stage over the whole batch (dgx_cascade_refine) and
+        the losses of each stage as one kernel pair (dgx_detic_losses).  An empty refined box -- a row the reference
+        drops -- becomes an "ignore" row instead (label -1), so no shape depends on the data."""
+        import ctypes
+        from ... import _lib as L
+        dev = proposals[0].proposal_boxes.tensor.device
+        B = len(proposals)
+        counts = [len(p) for p in proposals]
+        row0 = (ctypes.c_int * (B + 1))(*([0] + list(torch.tensor(counts).cumsum(0).tolist())))
+        gts = [len(t) for t in targets]
+        gt0 = (ctypes.c_int * (B + 1))(*([0] + list(torch.tensor(gts).cumsum(0).tolist())))
+        img_h = (ctypes.c_float * B)(*[float(p.image_size[0]) for p in proposals])
+        img_w = (ctypes.c_float * B)(*[float(p.image_size[1]) for p in proposals])
+        R = sum(counts)
+        gt_boxes = torch.cat([t.gt_boxes.tensor for t in targets]).float().contiguous()
+        gt_classes = torch.cat([t.gt_classes for t in targets]).contiguous()
+        has_src = all(t.has("instance_source") for t in targets)
+        gt_src = torch.cat([t.instance_source for t in targets]).contiguous() if has_src else None
+        prop = torch.cat([p.proposal_boxes.tensor for p in proposals]).float().contiguous()
+        gtc = torch.cat([p.gt_classes for p in proposals])
+        gtb = torch.cat([(p.gt_boxes if p.has("gt_boxes") else p.proposal_boxes).tensor for p in proposals]).float()
+        src = torch.cat([p.instance_source for p in proposals]) if all(p.has("instance_source") for p in proposals) else None
+        feats = [features[f] for f in self.box_in_features]
+        st = get_event_storage()
+        losses, valid, deltas = {}, None, None
+        wts = self.box_predictor[0].box2box_transform
+        for k in range(self.num_cascade_stages):
+            if k > 0:
+                tr = self.box_predictor[k - 1].box2box_transform
+                d = deltas.detach().contiguous()
+                nb = torch.empty(R, 4, dtype=torch.float32, device=dev)
+                nvalid = torch.empty(R, dtype=torch.uint8, device=dev)
+                gtc = torch.empty(R, dtype=torch.int64, device=dev)
+                gtb = torch.empty(R, 4, dtype=torch.float32, device=dev)
+                src = torch.empty(R, dtype=torch.int64, device=dev) if has_src else None
+                nfg = torch.empty(1, dtype=torch.int32, device=dev)
+                L.check(L.lib().dgx_cascade_refine(L.ptr(prop), L.ptr(d), L.ptr(valid), B, row0, gt0, img_h, img_w, L.ptr(gt_boxes),
+                                                   L.ptr(gt_classes), L.ptr(gt_src), float(self.cascade_ious[k]), self.num_classes,
+                                                   float(tr.weights[0]), float(tr.weights[1]), float(tr.weights[2]), float(tr.weights[3]),
+                                                   float(tr.scale_clamp), L.ptr(nb), L.ptr(nvalid), L.ptr(gtc), L.ptr(gtb), L.ptr(src),
+                                                   L.ptr(nfg), L.dtype_code(d), L.stream()), "dgx_cascade_refine")
+                prop, valid = nb, nvalid
+                f = nfg[0].float()
+                st.put_scalar("stage{}/roi_head/num_fg_samples".format(k), f / B)
+                st.put_scalar("stage{}/roi_head/num_bg_samples".format(k), (R - f) / B)
+            boxes = [Boxes(b) for b in prop.split(counts)]
+            x = self.box_pooler(feats, boxes, pad_to=256)
+            x = _ScaleGradient.apply(x, 1.0 / self.num_cascade_stages)
+            scores, deltas = self.box_predictor[k](self.box_head[k](x))
+            scores, deltas = scores[:R], deltas[:R]
+            with st.name_scope("stage{}".format(k)):
+                sl = self.box_predictor[k].losses_from_tensors(scores, deltas, gtc, prop, gtb, src)
+            losses.update({n + "_stage{}".format(k): v for n, v in sl.items()})
+        return losses
+
     def _forward_box(self, features, proposals, targets=None):
+        if (self.training and targets is not None and len(proposals) and sum(len(p) for p in proposals) > 0
+                and proposals[0].proposal_boxes.tensor.is_cuda and all(bp.fused_supported for bp in self.box_predictor)):
+            return self._forward_box_train(features, proposals, targets)
         if (not self.training) and self.mult_proposal_score:
             pscores = [p.get("scores") if p.has("scores") else p.get("objectness_logits") for p in proposals]
         features = [features[f] for f in self.box_in_features]

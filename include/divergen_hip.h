@@ -290,15 +290,32 @@ int dgx_groupnorm_bwd(const void* x, const void* dy, const float* mean, const fl
  * classification statistics of D2 fast_rcnn.py:88-114 -- forward values AND gradients.
  *   logits (R, C+1), deltas (R, 4): f32 or bf16 (dtype);  gt_classes i64 (R) in [0, C] (C = background, <0 ignored
  *   for the box term);  class_w f32 (C) or NULL (= 1);  prop, gtb f32 (R,4);  src i64 (R) or NULL
- *   dlogits (R, C+1) same dtype as logits  = d loss_cls / d logits
+ *   rows with gt_classes < 0 are "ignore" rows: no loss, no gradient, not counted in the normalisers
+ *   dlogits (R, C+1) same dtype as logits  = rows * d loss_cls / d logits   (multiply by out16[14] = 1/rows)
  *   dsign   f32 (R, 4)                     = sign(deltas - target) on selected rows, else 0
  *   out16   f32 [16]: [8] loss_cls, [9] loss_box_reg, [10] 1/max(4*rows,1) (scale of dsign in backward),
- *                     [11] cls_accuracy, [12] fg_cls_accuracy, [13] false_negative, [0..6] the raw sums
+ *                     [11] cls_accuracy, [12] fg_cls_accuracy, [13] false_negative, [14] 1/rows, [0..7] the raw sums
  *   part    f32 scratch R*8 */
 int dgx_detic_losses(const void* logits, const void* deltas, const int64_t* gt_classes, const float* class_w,
                      const float* prop, const float* gtb, const int64_t* src, int R, int C, float wx, float wy,
                      float ww, float wh, void* dlogits, float* dsign, float* out16, float* part, int dtype,
                      void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Hand-over between two cascade stages for all images of the batch in one launch
+ * (detic_roi_heads.py:192-244 `_forward_box`, `_create_proposals_from_boxes`, :136-190 `_match_and_label_boxes`):
+ * boxes = clip(apply_deltas(deltas, prop)) (box_regression.py:76-118, class-agnostic), valid_out = valid_in & nonempty,
+ * then pairwise IoU + Matcher (threshold iou_thr, labels {0,1}) against the image's own ground truth and the gather
+ * of the match: out_cls = gt class | num_classes (background) | -1 (row dropped by the reference: empty box),
+ * out_gtb = matched gt box (zeros without ground truth), out_src = instance_source of a foreground match else 0.
+ *   prop f32 (R,4); deltas (R,4) f32|bf16; valid_in u8 (R) or NULL; HOST arrays row0/gt0 (B+1 prefix offsets of the
+ *   RoI rows / GT rows of each image), img_h/img_w (B);  gt_* concatenated over images; gt_src may be NULL (then
+ *   out_src may be NULL);  num_fg i32 (1) out = foreground matches over the batch.  B <= 32. */
+int dgx_cascade_refine(const float* prop, const void* deltas, const uint8_t* valid_in, int B, const int* row0,
+                       const int* gt0, const float* img_h, const float* img_w, const float* gt_boxes,
+                       const int64_t* gt_classes, const int64_t* gt_src, float iou_thr, int num_classes, float wx,
+                       float wy, float ww, float wh, float scale_clamp, float* boxes, uint8_t* valid_out,
+                       int64_t* out_cls, float* out_gtb, int64_t* out_src, int32_t* num_fg, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

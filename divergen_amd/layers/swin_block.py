@@ -94,7 +94,8 @@ class _SwinBlockFn(torch.autograd.Function):
         L.check(lib.dgx_layernorm_fwd(x1.data_ptr(), n2w.data_ptr(), n2b.data_ptr(), h2.data_ptr(), mean2.data_ptr(),
                                       rstd2.data_ptr(), T, C, eps2, 0, 0, 0, 0, 0, code, st), "dgx_layernorm_fwd")
         f1 = torch.addmm(shadow(b1), h2, w116.t())
-        a = torch.nn.functional.gelu(f1)
+        a = torch.empty_like(f1)
+        L.check(lib.dgx_gelu_fwd(f1.data_ptr(), a.data_ptr(), f1.numel(), st), "dgx_gelu_fwd")
         f2 = torch.addmm(shadow(b2), a, w216.t())
         out = torch.empty_like(x)
         L.check(lib.dgx_residual_fwd(x1.data_ptr(), f2.data_ptr(), L.ptr(s2), out.data_ptr(), B, H, W, C, 0, 0, code, st),
@@ -124,8 +125,12 @@ class _SwinBlockFn(torch.autograd.Function):
         L.check(lib.dgx_residual_bwd(g.data_ptr(), L.ptr(s2), df2.data_ptr(), B, H, W, C, 0, 0, code, st), "dgx_residual_bwd")
         wgrads = []
         da = _linear_bwd(df2, a, w2, b2, w216, wgrads)
-        df1 = torch.ops.aten.gelu_backward(da, f1)
-        dh2 = _linear_bwd(df1, h2, w1, b1, w116, wgrads)
+        # GELU backward + the fc1 bias gradient (column sums of df1) in one pass
+        df1 = torch.empty_like(f1)
+        gws = torch.empty(max(int(lib.dgx_gelu_bwd_workspace_bytes(f1.shape[0], f1.shape[1])), 4), dtype=torch.uint8, device=dev)
+        L.check(lib.dgx_gelu_bwd_colsum(da.data_ptr(), f1.data_ptr(), df1.data_ptr(), b1.grad.data_ptr(), f1.shape[0], f1.shape[1], 1.0,
+                                        gws.data_ptr(), st), "dgx_gelu_bwd_colsum")
+        dh2 = _linear_bwd(df1, h2, w1, None, w116, wgrads)
         # LN2 backward + the residual-branch gradient g -> dx1
         nblk = lib.dgx_layernorm_bwd_blocks(T)
         part = torch.empty(nblk * 2 * C, dtype=torch.float32, device=dev)

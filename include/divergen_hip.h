@@ -317,6 +317,17 @@ int dgx_cascade_refine(const float* prop, const void* deltas, const uint8_t* val
                        float wy, float ww, float wh, float scale_clamp, float* boxes, uint8_t* valid_out,
                        int64_t* out_cls, float* out_gtb, int64_t* out_src, int32_t* num_fg, int dtype, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Exact (erf) GELU of the Swin MLP on bf16 activations (swintransformer.py:40-46, nn.GELU()).
+ *   dgx_gelu_fwd: y = gelu(x), n elements (n % 8 == 0).
+ *   dgx_gelu_bwd_colsum: dx (M, N) = dy * gelu'(x) and, when bias_grad != NULL, bias_grad (N) = beta*bias_grad +
+ *   column sums of the bf16 dx (the fc1 bias gradient) from the same pass.  N % 8 == 0;
+ *   workspace dgx_gelu_bwd_workspace_bytes(M, N) bytes. */
+int dgx_gelu_fwd(const void* x, void* y, int64_t n, void* stream);
+int64_t dgx_gelu_bwd_workspace_bytes(int M, int N);
+int dgx_gelu_bwd_colsum(const void* dy, const void* x, void* dx, float* bias_grad, int M, int N, float beta,
+                        void* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -531,3 +531,26 @@ def test_colsum_grouped():
     colsum_grouped(probs)
     for (acc, dy), ref in zip(probs, refs):
         assert (acc.cpu().double() - ref).abs().max() <= 1e-6 * (dy.cpu().double().abs().sum(0).max() + 1)
+
+
+def test_gelu_fwd_bwd_with_bias_gradient():
+    """Exact GELU on bf16 and its backward fused with the bias-gradient column sums vs torch fp32 on the same inputs."""
+    from divergen_amd import _lib as L
+    g = torch.Generator().manual_seed(95)
+    M, N = 777, 1536
+    x, dy = bf(torch.randn(M, N, generator=g) * 2), bf(torch.randn(M, N, generator=g))
+    xd, dyd = x.to(DEV), dy.to(DEV)
+    y, dx = torch.empty_like(xd), torch.empty_like(xd)
+    bg0 = torch.randn(N, generator=g)
+    bg = bg0.to(DEV).clone()
+    lib = L.lib()
+    L.check(lib.dgx_gelu_fwd(L.ptr(xd), L.ptr(y), xd.numel(), L.stream()), "gelu_fwd")
+    ws = torch.empty(int(lib.dgx_gelu_bwd_workspace_bytes(M, N)), dtype=torch.uint8, device=DEV)
+    L.check(lib.dgx_gelu_bwd_colsum(L.ptr(dyd), L.ptr(xd), L.ptr(dx), L.ptr(bg), M, N, 1.0, L.ptr(ws), L.stream()), "gelu_bwd")
+    xr = x.float().requires_grad_(True)
+    ref = torch.nn.functional.gelu(xr)
+    ref.backward(dy.float())
+    torch.testing.assert_close(y.float().cpu(), ref.detach(), atol=1e-2, rtol=8e-3)        # bf16 output rounding
+    torch.testing.assert_close(dx.float().cpu(), xr.grad, atol=1e-2, rtol=8e-3)
+    want = bg0.double() + dx.cpu().double().sum(0)                                          # sums of the bf16 dx, fp32 accumulate
+    assert (bg.cpu().double() - want).abs().max() <= 1e-5 * (dx.cpu().double().abs().sum(0).max() + 1)

@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void gelu_bwd_colsum_kernel(const uint16_t* __
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const float cdf = 0.5f * (1.0f + erff(v[k] * kInvSqrt2));
-                const float pdf = expf(-0.5f * v[k] * v[k]) * kInvSqrt2Pi;
+                const float pdf = __expf(-0.5f * v[k] * v[k]) * kInvSqrt2Pi;
                 d[k] = g[k] * (cdf + v[k] * pdf);
             }
             const u32x4 pk = pack8g(d);

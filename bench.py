@@ -114,11 +114,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # DGX_FORCE_DEVICE / DGX_DIST_BACKEND exist for ONE purpose: exercising the multi-rank code path (reducer hooks,
+    # graph capture next to collectives, CenterNet normaliser all-reduces) on a single-GPU box with gloo
+    if "DGX_FORCE_DEVICE" in os.environ:
+        local = int(os.environ["DGX_FORCE_DEVICE"])
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("DGX_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     assert world == a.gpus, "launch one process per GPU (WORLD_SIZE=%d, --gpus %d)" % (world, a.gpus)
     # DGX_GRAPH_BACKBONE=1 (opt-in) replays the static-shape backbone fwd+bwd as a hipGraph: -6 % step
     # time at N=1 (the step is CPU-launch-bound), but per-kernel HIP events (the roofline object) and the

@@ -78,41 +78,60 @@ def pairwise_iou(boxes1: Boxes, boxes2: Boxes):
 
 
 class BitMasks:
-    """(N,H,W) bool masks."""
+    """(N,H,W) bool masks (D2/structures/masks.py:87-255).
 
-    def __init__(self, tensor):
+    Indexing with an index / boolean tensor is LAZY: the result shares the mask storage and carries the row
+    indices.  The RoI heads index the ground-truth masks of an image with its 512 sampled proposals (and again with
+    the foreground subset); materialising that is a 0.5 GB gather per image at 1024^2 that the reference pays
+    (Instances.__getitem__), while the only consumer -- crop_and_resize -- reads a few rows through the index."""
+
+    def __init__(self, tensor, index=None):
         if not isinstance(tensor, torch.Tensor):
             tensor = torch.as_tensor(tensor)
         tensor = tensor.to(torch.bool)
         assert tensor.dim() == 3, tensor.size()
         self.image_size = tensor.shape[1:]
-        self.tensor = tensor
+        self._base = tensor
+        self._index = index          # None = identity
+
+    @property
+    def tensor(self):
+        if self._index is not None:      # materialise on demand
+            self._base, self._index = self._base[self._index], None
+        return self._base
 
     def to(self, *args, **kwargs):
-        return BitMasks(self.tensor.to(*args, **kwargs))
+        base = self._base.to(*args, **kwargs)
+        return BitMasks(base, None if self._index is None else self._index.to(base.device))
 
     @property
     def device(self):
-        return self.tensor.device
+        return self._base.device
 
     def __getitem__(self, item):
         if isinstance(item, int):
             return BitMasks(self.tensor[item].unsqueeze(0))
+        if isinstance(item, torch.Tensor) and item.dim() == 1 and item.dtype in (torch.int64, torch.int32, torch.bool):
+            cur = self._index if self._index is not None else torch.arange(self._base.shape[0], device=self._base.device)
+            return BitMasks(self._base, cur[item.to(cur.device)])
         m = self.tensor[item]
         assert m.dim() == 3
         return BitMasks(m)
 
     def __len__(self):
-        return self.tensor.shape[0]
+        return self._base.shape[0] if self._index is None else self._index.shape[0]
 
     def nonempty(self):
         return self.tensor.flatten(1).any(dim=1)
 
     def crop_and_resize(self, boxes, mask_size):
-        """masks.py:189-220 through the byte-tap HIP crop (no fp32 mask copy)."""
+        """masks.py:189-220 through the byte-tap HIP crop (no fp32 mask copy, rows addressed through the index)."""
         from ..layers import mask_crop
-        idx = torch.arange(len(boxes), device=boxes.device, dtype=torch.int32)
-        return mask_crop(self.tensor, boxes, idx, mask_size)
+        if self._index is None:
+            idx = torch.arange(len(boxes), device=boxes.device, dtype=torch.int32)
+        else:
+            idx = self._index.to(device=boxes.device, dtype=torch.int32)
+        return mask_crop(self._base, boxes, idx, mask_size)
 
     def get_bounding_boxes(self):
         boxes = torch.zeros(self.tensor.shape[0], 4, dtype=torch.float32)

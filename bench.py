@@ -165,22 +165,44 @@ def main():
     # pre-stage paste patches as device tensors so the timed region starts with inputs resident in HBM
     pastes = [[(torch.from_numpy(r).to(dev), x, y, l) for r, x, y, l in ps] for ps in pastes]
 
-    def one_step():
+    # The copy-paste compositor is the data-loading side of the step (the reference runs it in loader workers,
+    # DG/divergen/data/custom_build_copypaste_mapper.py): it depends on nothing the optimizer produces, so the batch of
+    # step t+1 is composited on a side HIP stream while step t trains, and its one data-dependent shape (objects that
+    # end up fully covered are dropped) is read back from THAT stream instead of draining the training stream.
+    # Every step still composites exactly one batch inside the timed region.
+    side = torch.cuda.Stream()
+
+    def compose():
         batch = []
-        for d, ps in zip(base, pastes):
-            inst = d["instances"]
-            if a.no_copy_paste:
-                batch.append(d)
-                continue
-            out = la.copy_paste(d["image"], inst.gt_masks.tensor.view(torch.uint8), inst.gt_boxes.tensor,
-                                inst.gt_classes, ps)
-            ni = Instances(inst.image_size)
-            ni.gt_boxes, ni.gt_classes = Boxes(out["boxes"]), out["labels"]
-            ni.gt_masks, ni.instance_source = BitMasks(out["masks"]), out["source"]
-            batch.append({"image": out["image"], "instances": ni, "height": d["height"], "width": d["width"],
-                          "file_name": d["file_name"]})
+        with torch.cuda.stream(side):
+            for d, ps in zip(base, pastes):
+                inst = d["instances"]
+                if a.no_copy_paste:
+                    batch.append(d)
+                    continue
+                out = la.copy_paste(d["image"], inst.gt_masks.tensor.view(torch.uint8), inst.gt_boxes.tensor,
+                                    inst.gt_classes, ps)
+                ni = Instances(inst.image_size)
+                ni.gt_boxes, ni.gt_classes = Boxes(out["boxes"]), out["labels"]
+                ni.gt_masks, ni.instance_source = BitMasks(out["masks"]), out["source"]
+                batch.append({"image": out["image"], "instances": ni, "height": d["height"], "width": d["width"],
+                              "file_name": d["file_name"]})
+            ev = torch.cuda.Event()
+            ev.record(side)
+        return batch, ev
+
+    nxt = [compose()]
+
+    def one_step():
+        batch, ev = nxt[0]
+        torch.cuda.current_stream().wait_event(ev)      # the training stream consumes the composited tensors
+        for d in batch:                                  # ... and owns them from here on (allocator stream bookkeeping)
+            d["image"].record_stream(torch.cuda.current_stream())
+            if "instances" in d and d["instances"].has("gt_masks"):
+                d["instances"].gt_masks.tensor.record_stream(torch.cuda.current_stream())
         opt.zero_grad()
         losses = model(batch)
+        nxt[0] = compose()                               # next batch, concurrently with this step's backward
         total = sum(losses.values())
         total.backward()
         scale = reducer.finish()

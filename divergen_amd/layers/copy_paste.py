@@ -4,6 +4,7 @@ import numpy as np
 import torch
 
 from .. import _lib as L
+from ..utils.h2d import upload_i32
 
 
 def copy_paste(image, masks, boxes, labels, pastes):
@@ -28,7 +29,7 @@ def copy_paste(image, masks, boxes, labels, pastes):
             chunks.append(torch.zeros(pad, dtype=torch.uint8, device=dev))
         off += a.numel() + pad
     flat = torch.cat(chunks)
-    desc_t = torch.tensor(desc, dtype=torch.int32, device=dev)
+    desc_t = upload_i32(desc, dev).view(-1, 5)
     image = image.contiguous().clone()
     masks = masks.contiguous()
     boxes0 = boxes.float().contiguous()
@@ -41,8 +42,7 @@ def copy_paste(image, masks, boxes, labels, pastes):
                                    L.ptr(flat), L.ptr(desc_t), K, L.ptr(out_masks), L.ptr(out_boxes), L.ptr(out_valid),
                                    L.ptr(stats), L.stream()), "dgx_copy_paste")
     valid = out_valid.bool()
-    all_labels = torch.cat([labels.to(torch.int64), torch.tensor([int(np.asarray(p[3]).reshape(-1)[0]) for p in pastes],
-                                                                 dtype=torch.int64, device=dev)])
+    all_labels = torch.cat([labels.to(torch.int64), upload_i32([int(np.asarray(p[3]).reshape(-1)[0]) for p in pastes], dev).long()])
     source = torch.cat([torch.zeros(n0, dtype=torch.int64, device=dev), torch.ones(K, dtype=torch.int64, device=dev)])
     return dict(image=image, masks=out_masks[valid], boxes=out_boxes[valid], labels=all_labels[valid],
                 source=source[valid])

@@ -4,6 +4,7 @@ import ctypes
 import torch
 
 from .. import _lib as L
+from ..utils.h2d import upload_i32
 
 
 def centernet_targets(gt_boxes_list, level_hw, strides, soi, hm_min_overlap=0.8, min_radius=4):
@@ -17,7 +18,7 @@ def centernet_targets(gt_boxes_list, level_hw, strides, soi, hm_min_overlap=0.8,
         offs.append(offs[-1] + c)
     gt = torch.cat([b.float().reshape(-1, 4) for b in gt_boxes_list]).contiguous() if offs[-1] else \
         torch.zeros(1, 4, dtype=torch.float32, device=dev)
-    offs_t = torch.tensor(offs, dtype=torch.int32, device=dev)
+    offs_t = upload_i32(offs, dev)          # pinned + async: no stream stall for B+1 integers
     Lv = len(strides)
     M = sum(h * w for h, w in level_hw)
     reg = torch.empty(M * B, 4, dtype=torch.float32, device=dev)

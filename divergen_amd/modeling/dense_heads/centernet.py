@@ -134,30 +134,45 @@ class CenterNet(nn.Module):
         boxes = [g.gt_boxes.tensor for g in gt_instances]
         reg, hm = centernet_targets(boxes, shapes, self.strides, self.sizes_of_interest, self.hm_min_overlap,
                                     self.min_radius)
-        return self._get_label_inds(boxes, shapes), reg, hm
+        return self._get_label_inds(boxes, shapes, masked=boxes[0].is_cuda), reg, hm
 
-    def _get_label_inds(self, boxes_list, shapes):
-        """centernet.py:439-483 on the device (n x L integers per image)."""
+    def _get_label_inds(self, boxes_list, shapes, masked=False):
+        """centernet.py:439-483 on the device (n x L integers per image).  masked=True returns (indices, cared) of
+        fixed length sum_i n_i * L instead of the compacted index list: the selection `ind[cared]` is the only
+        data-dependent shape of the CenterNet losses and costs a device->host read per image."""
         dev = boxes_list[0].device
         L, B = len(self.strides), len(boxes_list)
-        hw = torch.tensor(shapes, dtype=torch.int64, device=dev)
-        loc = hw[:, 0] * hw[:, 1]
-        bases = torch.cumsum(torch.cat([loc.new_zeros(1), B * loc[:-1]]), 0)
-        st = torch.tensor(self.strides, dtype=torch.float32, device=dev)
-        sr = torch.tensor(self.sizes_of_interest, dtype=torch.float32, device=dev)
-        out = []
+        key = (tuple(map(tuple, shapes)), B, str(dev))
+        cache = self.__dict__.setdefault("_label_consts", {})
+        if key not in cache:     # constants of the feature-map geometry: uploaded once, not once per step
+            hw = torch.tensor(shapes, dtype=torch.int64, device=dev)
+            loc = hw[:, 0] * hw[:, 1]
+            bases = torch.cumsum(torch.cat([loc.new_zeros(1), B * loc[:-1]]), 0)
+            cache[key] = (hw, loc, bases, torch.tensor(self.strides, dtype=torch.float32, device=dev),
+                          torch.tensor(self.sizes_of_interest, dtype=torch.float32, device=dev))
+        hw, loc, bases, st, sr = cache[key]
+        out, keep = [], []
         for i, bx in enumerate(boxes_list):
-            c = (bx[:, [0, 1]] + bx[:, [2, 3]]) / 2
+            c = (bx[:, :2] + bx[:, 2:]) / 2          # (slices, not list indexing: a list index is uploaded every call)
             ci = (c[:, None, :] / st[None, :, None]).long()
             ind = bases[None] + i * loc[None] + ci[:, :, 1] * hw[None, :, 1] + ci[:, :, 0]
             crit = ((bx[:, 2:] - bx[:, :2]) ** 2).sum(dim=1) ** 0.5 / 2
             cared = (crit[:, None] >= sr[None, :, 0]) & (crit[:, None] <= sr[None, :, 1])
-            out.append(ind[cared].reshape(-1))
+            if masked:
+                out.append(ind.reshape(-1))
+                keep.append(cared.reshape(-1))
+            else:
+                out.append(ind[cared].reshape(-1))
+        if masked:
+            return torch.cat(out, dim=0).long(), torch.cat(keep, dim=0)
         return torch.cat(out, dim=0).long()
 
     def losses(self, pos_inds, reg_targets, flattened_hms, reg_pred, agn_hm_pred):
         world = get_world_size()
-        num_pos_local = torch.tensor([float(pos_inds.numel())], device=reg_pred.device)
+        if isinstance(pos_inds, tuple):      # (indices, cared): fixed length, count stays on the device
+            num_pos_local = pos_inds[1].sum().float().reshape(1)
+        else:
+            num_pos_local = torch.tensor([float(pos_inds.numel())], device=reg_pred.device)
         total_num_pos = num_pos_local * world if self.no_reduce else reduce_sum(num_pos_local)
         num_pos_avg = torch.clamp(total_num_pos / world, min=1.0)[0]
         losses = {}
@@ -268,8 +283,12 @@ def _binary_heatmap_focal_loss(inputs, targets, pos_inds, alpha, beta, gamma, si
     """CN/modeling/layers/heatmap_focal_loss.py:51-85."""
     pred = torch.clamp(inputs.sigmoid(), min=sigmoid_clamp, max=1 - sigmoid_clamp)
     neg_weights = torch.pow(1 - targets, beta)
-    pos_pred = pred[pos_inds]
-    pos_loss = torch.log(pos_pred) * torch.pow(1 - pos_pred, gamma)
+    if isinstance(pos_inds, tuple):          # masked form of the index selection: same sum, no data-dependent shape
+        pos_pred = pred[pos_inds[0]]
+        pos_loss = torch.log(pos_pred) * torch.pow(1 - pos_pred, gamma) * pos_inds[1].to(pred.dtype)
+    else:
+        pos_pred = pred[pos_inds]
+        pos_loss = torch.log(pos_pred) * torch.pow(1 - pos_pred, gamma)
     neg_loss = torch.log(1 - pred) * torch.pow(pred, gamma) * neg_weights
     if ignore_high_fp > 0:
         neg_loss = (pred < ignore_high_fp).float() * neg_loss

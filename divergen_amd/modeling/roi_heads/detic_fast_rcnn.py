@@ -50,19 +50,17 @@ def fed_loss_class_mask(gt_classes, num_sample_cats, C, weight):
     num_sample_cats - n_appeared of it kept, so the class SET is the one the reference code would obtain from the
     same generator state (when n_appeared >= num_sample_cats the reference draws nothing: the streams then differ)."""
     app = torch.zeros(C + 1, dtype=torch.bool, device=gt_classes.device)
-    app[gt_classes] = True
+    app.index_fill_(0, gt_classes, True)        # (in-place index ops with Python scalars upload the scalar: avoided)
     prob = torch.ones(C + 1, dtype=torch.float32, device=gt_classes.device) if weight is None else \
         torch.cat([weight.float(), weight.new_zeros(1).float()])
-    prob[C] = 0
+    prob[C:].zero_()
     prob = prob.masked_fill(app, 0)
     q = prob / torch.empty_like(prob).exponential_(1)
     k = min(num_sample_cats, C + 1)
     vals, idx = torch.topk(q, k)
     need = num_sample_cats - app.sum()                       # device scalar
     take = (torch.arange(k, device=q.device) < need) & (vals > 0)
-    m = app.clone()
-    m[idx] = m[idx] | take
-    return m
+    return app.index_put((idx,), app[idx] | take)
 
 
 class _DeticLosses(torch.autograd.Function):

@@ -117,7 +117,10 @@ def test_centernet_targets_and_losses_vs_reference_golden(golden):
         inst.gt_boxes = Boxes(T(g[k]).to(DEV))
         gts.append(inst)
     pos, reg, hm = net._get_ground_truth(shapes, gts)
-    assert torch.equal(pos.cpu(), T(g["pos2"]))                      # index tensor: bit-exact
+    # the product path keeps (indices, cared) at fixed length; the reference's compacted list is indices[cared]
+    assert isinstance(pos, tuple) and pos[0].shape == pos[1].shape
+    assert torch.equal(pos[0][pos[1]].cpu(), T(g["pos2"]))           # index tensor: bit-exact
+    assert torch.equal(net._get_label_inds([x.gt_boxes.tensor for x in gts], shapes).cpu(), T(g["pos2"]))
     assert torch.equal(reg.cpu(), T(g["reg2"]))
     torch.testing.assert_close(hm.cpu(), T(g["hm2"]), atol=1e-6, rtol=1e-5)
     rp = T(g["reg_pred"]).to(DEV).requires_grad_(True)

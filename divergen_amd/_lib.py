@@ -60,7 +60,8 @@ SIGNATURES = {
     "dgx_gelu_fwd": (c_i, [c_p, c_p, c_i64, c_p]),
     "dgx_gelu_bwd_workspace_bytes": (c_i64, [c_i, c_i]),
     "dgx_gelu_bwd_colsum": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_p, c_p]),
-    "dgx_groupnorm_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_p]),
+    "dgx_groupnorm_scratch_floats": (c_i64, [c_i, c_i, c_i]),
+    "dgx_groupnorm_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_p]),
     "dgx_groupnorm_bwd": (c_i, [c_p] * 10 + [c_i, c_i, c_i, c_i, c_i, c_p]),
     "dgx_colsum_workspace_bytes": (c_i64, [c_i, c_i]),
     "dgx_colsum_bf16": (c_i, [c_p, c_p, c_i, c_i, c_f, c_p, c_p]),

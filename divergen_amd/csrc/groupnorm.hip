@@ -27,29 +27,41 @@ __device__ __forceinline__ float block_sum(float v, float* red) {   // 256 threa
 }
 }  // namespace
 
-__global__ __launch_bounds__(256) void gn_stats_kernel(const uint16_t* __restrict__ x, float* __restrict__ mean, float* __restrict__ rstd,
-                                                       int HW, int C, int G, float eps) {
+// grid (N*G, S): slab s of the pixels of one (n, g).  Sums are taken of x - x0 (x0 = the group's first element) so that
+// var = E[d^2] - E[d]^2 does not cancel when the mean is large against the spread.  part[(ng*S + s)*2 + {0,1}].
+__global__ __launch_bounds__(256) void gn_stats_partial_kernel(const uint16_t* __restrict__ x, float* __restrict__ part, int HW, int C,
+                                                               int G, int S) {
     __shared__ float red[4];
-    const int n = blockIdx.x / G, g = blockIdx.x % G;
+    const int n = blockIdx.x / G, g = blockIdx.x % G, s = blockIdx.y;
     const uint16_t* base = x + (int64_t)n * HW * C + 8 * g;
-    float s = 0.f;
-    for (int p = threadIdx.x; p < HW; p += 256) {
+    const float x0 = bf2f(base[0]);
+    const int per = (HW + S - 1) / S, p0 = s * per, p1 = min(HW, p0 + per);
+    float a = 0.f, q = 0.f;
+    for (int p = p0 + threadIdx.x; p < p1; p += 256) {
         float v[8];
         unpack8(*reinterpret_cast<const u32x4*>(base + (int64_t)p * C), v);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) s += v[i];
+        for (int i = 0; i < 8; ++i) { const float d = v[i] - x0; a += d; q += d * d; }
     }
+    a = block_sum(a, red);
+    q = block_sum(q, red);
+    if (threadIdx.x == 0) { part[((int64_t)blockIdx.x * S + s) * 2] = a; part[((int64_t)blockIdx.x * S + s) * 2 + 1] = q; }
+}
+
+__global__ __launch_bounds__(256) void gn_stats_final_kernel(const uint16_t* __restrict__ x, const float* __restrict__ part,
+                                                             float* __restrict__ mean, float* __restrict__ rstd, int NG, int HW, int C,
+                                                             int G, int S, float eps) {
+    const int ng = blockIdx.x * 256 + threadIdx.x;
+    if (ng >= NG) return;
+    const int n = ng / G, g = ng % G;
+    const float x0 = bf2f(x[(int64_t)n * HW * C + 8 * g]);
+    float a = 0.f, q = 0.f;
+    for (int s = 0; s < S; ++s) { a += part[((int64_t)ng * S + s) * 2]; q += part[((int64_t)ng * S + s) * 2 + 1]; }
     const float m = (float)HW * 8.0f;
-    const float mu = block_sum(s, red) / m;
-    float q = 0.f;
-    for (int p = threadIdx.x; p < HW; p += 256) {
-        float v[8];
-        unpack8(*reinterpret_cast<const u32x4*>(base + (int64_t)p * C), v);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { const float d = v[i] - mu; q += d * d; }
-    }
-    const float var = block_sum(q, red) / m;
-    if (threadIdx.x == 0) { mean[blockIdx.x] = mu; rstd[blockIdx.x] = rsqrtf(var + eps); }
+    const float md = a / m;
+    const float var = fmaxf(q / m - md * md, 0.0f);
+    mean[ng] = x0 + md;
+    rstd[ng] = rsqrtf(var + eps);
 }
 
 __global__ __launch_bounds__(256) void gn_apply_kernel(const uint16_t* __restrict__ x, const float* __restrict__ mean,
@@ -74,11 +86,11 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const uint16_t* __restric
     }
 }
 
-// part: [N*G][18] = s1, s2, dgamma[8], dbeta[8]
+// part2: [N*G][S][18] = s1, s2, dgamma[8], dbeta[8] of slab s; folded into part [N*G][18] by gn_bwd_fold_kernel
 __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                            float* __restrict__ part, int HW, int C, int G, int relu) {
+                                                            float* __restrict__ part2, int HW, int C, int G, int relu, int S) {
     __shared__ float red[4];
     const int n = blockIdx.x / G, g = blockIdx.x % G;
     const int64_t off = (int64_t)n * HW * C + 8 * g;
@@ -87,7 +99,8 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const uint16_t* __re
 #pragma unroll
     for (int k = 0; k < 8; ++k) { gm[k] = gamma[8 * g + k]; bt[k] = beta[8 * g + k]; dg[k] = db[k] = 0.f; }
     float s1 = 0.f, s2 = 0.f;
-    for (int p = threadIdx.x; p < HW; p += 256) {
+    const int per = (HW + S - 1) / S, p0 = blockIdx.y * per, p1 = min(HW, p0 + per);
+    for (int p = p0 + threadIdx.x; p < p1; p += 256) {
         float v[8], d[8];
         unpack8(*reinterpret_cast<const u32x4*>(x + off + (int64_t)p * C), v);
         unpack8(*reinterpret_cast<const u32x4*>(dy + off + (int64_t)p * C), d);
@@ -101,7 +114,7 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const uint16_t* __re
             s2 += dh * gm[k] * xh;
         }
     }
-    float* out = part + (int64_t)blockIdx.x * 18;
+    float* out = part2 + ((int64_t)blockIdx.x * S + blockIdx.y) * 18;
     float r = block_sum(s1, red);
     if (threadIdx.x == 0) out[0] = r;
     r = block_sum(s2, red);
@@ -113,6 +126,15 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const uint16_t* __re
         r = block_sum(db[k], red);
         if (threadIdx.x == 0) out[10 + k] = r;
     }
+}
+
+__global__ __launch_bounds__(256) void gn_bwd_fold_kernel(const float* __restrict__ part2, float* __restrict__ part, int NG, int S) {
+    const int i = blockIdx.x * 256 + threadIdx.x;     // over NG*18
+    if (i >= NG * 18) return;
+    const int ng = i / 18, k = i % 18;
+    float a = 0.f;
+    for (int s = 0; s < S; ++s) a += part2[((int64_t)ng * S + s) * 18 + k];
+    part[i] = a;
 }
 
 __global__ __launch_bounds__(256) void gn_bwd_dx_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy,
@@ -155,12 +177,26 @@ __global__ __launch_bounds__(256) void gn_bwd_param_kernel(const float* __restri
     dbeta[c] += b;
 }
 
+// pixel slabs per (n, g) so that the two reduction kernels fill the GPU (N*G alone is 64 workgroups for a batch of 2)
+static int gn_slabs(int NG, int HW) {
+    int S = (1024 + NG - 1) / NG;
+    const int mx = (HW + 255) / 256;
+    if (S > mx) S = mx;
+    return S < 1 ? 1 : (S > 64 ? 64 : S);
+}
+
+extern "C" int64_t dgx_groupnorm_scratch_floats(int N, int HW, int G) { return (int64_t)N * G * (gn_slabs(N * G, HW) * 18 + 18); }
+
 extern "C" int dgx_groupnorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
-                                 int N, int HW, int C, int G, float eps, int relu, void* stream) {
+                                 float* scratch, int N, int HW, int C, int G, float eps, int relu, void* stream) {
     if (N <= 0 || HW <= 0) return DGX_OK;
     if (!x || !gamma || !beta || !y || !mean || !rstd || C != 8 * G) return DGX_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(N * G), dim3(256), 0, st, (const uint16_t*)x, mean, rstd, HW, C, G, eps);
+    const int S = gn_slabs(N * G, HW);
+    if (!scratch) return DGX_ERR_BAD_ARG;
+    hipLaunchKernelGGL(gn_stats_partial_kernel, dim3(N * G, S), dim3(256), 0, st, (const uint16_t*)x, scratch, HW, C, G, S);
+    hipLaunchKernelGGL(gn_stats_final_kernel, dim3((N * G + 255) / 256), dim3(256), 0, st, (const uint16_t*)x, scratch, mean, rstd, N * G,
+                       HW, C, G, S, eps);
     const int64_t tv = (int64_t)N * HW * G;
     const int grid = (int)((tv + 255) / 256 < 4096 ? (tv + 255) / 256 : 4096);
     hipLaunchKernelGGL(gn_apply_kernel, dim3(grid), dim3(256), 0, st, (const uint16_t*)x, mean, rstd, gamma, beta, (uint16_t*)y, tv, HW,
@@ -175,8 +211,11 @@ extern "C" int dgx_groupnorm_bwd(const void* x, const void* dy, const float* mea
     if (N <= 0 || HW <= 0) return DGX_OK;
     if (!x || !dy || !mean || !rstd || !gamma || !beta || !dx || !dgamma || !dbeta || !part || C != 8 * G) return DGX_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(N * G), dim3(256), 0, st, (const uint16_t*)x, (const uint16_t*)dy, mean, rstd, gamma,
-                       beta, part, HW, C, G, relu);
+    const int S = gn_slabs(N * G, HW);
+    float* part2 = part + (int64_t)N * G * 18;      // scratch layout: [N*G][18] folded, then [N*G][S][18]
+    hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(N * G, S), dim3(256), 0, st, (const uint16_t*)x, (const uint16_t*)dy, mean, rstd, gamma,
+                       beta, part2, HW, C, G, relu, S);
+    hipLaunchKernelGGL(gn_bwd_fold_kernel, dim3((N * G * 18 + 255) / 256), dim3(256), 0, st, part2, part, N * G, S);
     const int64_t tv = (int64_t)N * HW * G;
     const int grid = (int)((tv + 255) / 256 < 4096 ? (tv + 255) / 256 : 4096);
     hipLaunchKernelGGL(gn_bwd_dx_kernel, dim3(grid), dim3(256), 0, st, (const uint16_t*)x, (const uint16_t*)dy, mean, rstd, gamma, beta,

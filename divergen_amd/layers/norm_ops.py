@@ -99,7 +99,8 @@ class _GroupNormReLU(torch.autograd.Function):
         mean = torch.empty(N * G, dtype=torch.float32, device=x.device)
         rstd = torch.empty(N * G, dtype=torch.float32, device=x.device)
         w32, b32 = weight.detach().float().contiguous(), bias.detach().float().contiguous()
-        L.check(L.lib().dgx_groupnorm_fwd(L.ptr(x), L.ptr(w32), L.ptr(b32), L.ptr(y), L.ptr(mean), L.ptr(rstd), N, H * W, C, G,
+        scratch = torch.empty(int(L.lib().dgx_groupnorm_scratch_floats(N, H * W, G)), dtype=torch.float32, device=x.device)
+        L.check(L.lib().dgx_groupnorm_fwd(L.ptr(x), L.ptr(w32), L.ptr(b32), L.ptr(y), L.ptr(mean), L.ptr(rstd), L.ptr(scratch), N, H * W, C, G,
                                           float(eps), int(relu), L.stream()), "dgx_groupnorm_fwd")
         ctx.save_for_backward(x, mean, rstd, w32, b32)
         ctx.weight, ctx.bias, ctx.cfg = weight, bias, (N, H, W, C, G, relu)
@@ -114,7 +115,7 @@ class _GroupNormReLU(torch.autograd.Function):
         if dy.dtype != torch.bfloat16:
             dy = dy.to(torch.bfloat16)
         dx = torch.empty_like(x)
-        part = torch.empty(N * G * 18, dtype=torch.float32, device=x.device)
+        part = torch.empty(int(L.lib().dgx_groupnorm_scratch_floats(N, H * W, G)), dtype=torch.float32, device=x.device)
         in_arena = (weight.is_leaf and bias.is_leaf and weight.grad is not None and bias.grad is not None
                     and weight.grad.dtype == torch.float32 and getattr(weight, "_dgx16", None) is not None
                     and getattr(bias, "_dgx16", None) is not None)

@@ -276,9 +276,10 @@ int dgx_colsum_grouped(const dgx_colsum_problem* problems, int n, float beta, vo
  * -> ReLU unit of the CenterNet tower (CN/modeling/dense_heads/centernet_head.py:52-75; torch.nn.GroupNorm
  * semantics: biased variance over (HW, C/G), eps inside the sqrt).  x, y, dy, dx bf16 (N, HW, C); C == 8*G.
  * mean / rstd f32 (N*G) saved by forward.  Backward ACCUMULATES into dgamma / dbeta (f32 C);
- * part: f32 scratch N*G*18. */
+ * scratch / part: f32, dgx_groupnorm_scratch_floats(N, HW, G) elements (both directions). */
+int64_t dgx_groupnorm_scratch_floats(int N, int HW, int G);
 int dgx_groupnorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
-                      int N, int HW, int C, int G, float eps, int relu, void* stream);
+                      float* scratch, int N, int HW, int C, int G, float eps, int relu, void* stream);
 int dgx_groupnorm_bwd(const void* x, const void* dy, const float* mean, const float* rstd, const float* gamma,
                       const float* beta, void* dx, float* dgamma, float* dbeta, float* part, int N, int HW,
                       int C, int G, int relu, void* stream);

@@ -234,7 +234,7 @@ extern "C" int dgx_layernorm_fwd(const void* x, const float* gamma, const float*
 
 extern "C" int dgx_layernorm_bwd_blocks(int64_t T) {
     int64_t b = (T + 3) / 4;
-    return (int)(b < 512 ? (b < 1 ? 1 : b) : 512);
+    return (int)(b < 1024 ? (b < 1 ? 1 : b) : 1024);
 }
 
 extern "C" int dgx_layernorm_bwd(const void* dy_bf16, const void* x, const float* mean, const float* rstd,

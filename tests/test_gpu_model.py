@@ -110,3 +110,27 @@ def test_graphed_head_segments_match_eager(monkeypatch):
         # two separate runs: fp32 atomics (ROIAlign / bias-table scatters) and bf16 rounding reorder sums; a borderline
         # discrete decision (NMS / matching) may flip for a single RoI -> bound the worst element at 10 % of the scale
         assert float((g0 - g1).abs().max()) <= 1e-1 * float(g0.abs().max()), it
+
+
+def test_bf16_product_path_tracks_fp32_path():
+    """The product path (bf16 autocast, fused Swin block, hipGraph segments, fused losses) against the same model run
+    without autocast (fp32 activations, composed ops, torch LayerNorm/GroupNorm; only the attention core stays bf16):
+    every loss within 3 % -- the budget of bf16 activations through 24 blocks, not an fp32 parity claim."""
+    from divergen_amd.data import synthetic_batch
+    from divergen_amd.utils.events import EventStorage
+    out = {}
+    for fp16 in (True, False):
+        cfg, model, opt = _build(False)
+        model.fp16 = fp16
+        batch = synthetic_batch(2, 256, cfg.MODEL.ROI_HEADS.NUM_CLASSES, device="cuda")
+        with EventStorage(0):
+            torch.manual_seed(7)
+            opt.zero_grad()
+            losses = model(batch)
+            sum(losses.values()).backward()
+            torch.cuda.synchronize()
+        assert bool(torch.isfinite(opt.arena.g).all())
+        out[fp16] = {k: float(v) for k, v in losses.items()}
+    for k in out[True]:
+        a, b = out[True][k], out[False][k]
+        assert abs(a - b) <= 3e-2 * abs(b) + 2e-3, (k, a, b)

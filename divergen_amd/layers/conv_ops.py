@@ -11,7 +11,7 @@ import torch
 import torch.nn.functional as F
 
 from .. import _lib as L
-from .linear_ops import accumulate_grad, linear, shadow, wgrad_into
+from .linear_ops import accumulate_grad, linear, notify_ready, shadow, wgrad_into
 
 
 def _nhwc(x):
@@ -27,6 +27,14 @@ def _im2col(x_nhwc, stride):
     return col, Ho, Wo
 
 
+def _ohwi_matrix(t):
+    """(Cout, 9*Cin) row-major view of a weight-shaped arena tensor stored (Cout, kh, kw, Cin), else None."""
+    if t is None or t.dim() != 4:
+        return None
+    q = t.permute(0, 2, 3, 1)
+    return q.reshape(q.shape[0], -1) if q.is_contiguous() else None
+
+
 class _Conv3x3(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, stride):
@@ -34,7 +42,8 @@ class _Conv3x3(torch.autograd.Function):
         N, H, W, C = x.shape
         bf = x.dtype == torch.bfloat16
         w = shadow(weight) if bf else weight.to(x.dtype)
-        wm = w.permute(2, 3, 1, 0).reshape(9 * C, -1)                          # (ky,kx,ci) x co
+        wk = _ohwi_matrix(w) if bf else None          # arena weights stored (Cout,kh,kw,Cin): the GEMM operand as is
+        wm = wk.t() if wk is not None else w.permute(2, 3, 1, 0).reshape(9 * C, -1)     # (ky,kx,ci) x co
         col, Ho, Wo = _im2col(x, stride)
         if bias is not None:
             y = torch.addmm(shadow(bias) if bf else bias.to(x.dtype), col, wm)
@@ -56,7 +65,13 @@ class _Conv3x3(torch.autograd.Function):
             gx = torch.empty(N, H, W, C, dtype=col.dtype, device=col.device)
             L.check(L.lib().dgx_col2im3x3(L.ptr(dcol), L.ptr(gx), N, H, W, C, stride, L.dtype_code(gx), L.stream()),
                     "dgx_col2im3x3")
-        if ctx.needs_input_grad[1]:
+        gphys = _ohwi_matrix(ctx.weight.grad) if (ctx.weight.is_leaf and ctx.weight.grad is not None) else None
+        if (ctx.needs_input_grad[1] and gphys is not None and col.dtype == torch.bfloat16 and gphys.dtype == torch.float32
+                and getattr(ctx.weight, "_dgx16", None) is not None):
+            # weight gradient accumulated straight into the arena, in its stored (Cout, kh*kw*Cin) order
+            wgrad_into(gphys, g2.contiguous(), col, beta=1.0)
+            notify_ready(ctx.weight)
+        elif ctx.needs_input_grad[1]:
             def wgrad():
                 if col.dtype == torch.bfloat16:
                     g = torch.empty(9 * C, g2.shape[1], dtype=torch.float32, device=col.device)
@@ -66,7 +81,14 @@ class _Conv3x3(torch.autograd.Function):
                 return g.view(3, 3, C, -1).permute(3, 2, 0, 1)
             gw = accumulate_grad(ctx.weight, wgrad)
         if has_bias and ctx.needs_input_grad[2]:
-            gb = accumulate_grad(ctx.bias, lambda: torch.sum(g2, 0, dtype=torch.float32))
+            b = ctx.bias
+            if (b.is_leaf and b.grad is not None and b.grad.dtype == torch.float32 and getattr(b, "_dgx16", None) is not None
+                    and g2.dtype == torch.bfloat16 and g2.shape[1] % 8 == 0):
+                from .swin_block import colsum_into
+                colsum_into(b.grad, g2.contiguous())       # bias gradient summed straight into the arena
+                notify_ready(b)
+            else:
+                gb = accumulate_grad(b, lambda: torch.sum(g2, 0, dtype=torch.float32))
         return gx, gw, gb, None
 
 
@@ -130,6 +152,11 @@ def deconv2x2(x, weight, bias):
 
 class Conv2d(torch.nn.Conv2d):
     """nn.Conv2d parameters, GEMM-path forward (1x1, and 3x3 pad 1 stride 1|2)."""
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        if self.kernel_size == (3, 3) and self.groups == 1:
+            self.weight._dgx_ohwi = True       # FlatArena stores it (Cout, kh, kw, Cin): see solver.FlatArena.view
 
     def forward(self, x):
         k, s, p = self.kernel_size, self.stride, self.padding

@@ -52,12 +52,24 @@ class FlatArena:
         self.g = torch.zeros(n, dtype=torch.float32, device=dev)
         self.p16 = torch.zeros(n, dtype=torch.bfloat16, device=dev)   # bf16 shadow, refreshed by the optimizer kernel
         for p, o in zip(self.params, offs):
-            v = self.p[o:o + p.numel()].view_as(p)
+            v = self.view(self.p, p, o)
             v.copy_(p.data)
             p.data = v
-            p.grad = self.g[o:o + p.numel()].view_as(p)
-            p._dgx16 = self.p16[o:o + p.numel()].view_as(p)
+            p.grad = self.view(self.g, p, o)
+            p._dgx16 = self.view(self.p16, p, o)
         self.sync_shadow()
+
+    @staticmethod
+    def view(buf, p, o):
+        """The parameter-shaped view of `buf` at offset o.  3x3 convolution weights (tagged `_dgx_ohwi` by
+        layers.conv_ops.Conv2d) are STORED (Cout, kh, kw, Cin) -- the K-order of the im2col GEMM -- and exposed in the
+        reference's (Cout, Cin, kh, kw) shape as a permuted view: checkpoints see the reference layout, the GEMMs read
+        and write the arena directly (no per-step weight permutation, weight gradient accumulated in place)."""
+        flat = buf[o:o + p.numel()]
+        if getattr(p, "_dgx_ohwi", False) and p.dim() == 4:
+            co, ci, kh, kw = p.shape
+            return flat.view(co, kh, kw, ci).permute(0, 3, 1, 2)
+        return flat.view(p.shape)
 
     def sync_shadow(self):
         """Re-derive the bf16 shadow from the fp32 weights (after init / broadcast / checkpoint load)."""
@@ -110,7 +122,7 @@ class FusedAdamWEMA:
     # ---- EMA surface (DG/divergen/ema.py: state_dict / load_state_dict, keys = model state-dict keys)
     def ema_state_dict(self, model):
         out = OrderedDict()
-        view = {n: self.ema[o:o + p.numel()].view_as(p) for n, o, p in zip(self.arena.names, self.arena.offsets, self.arena.params)}
+        view = {n: self.arena.view(self.ema, p, o) for n, o, p in zip(self.arena.names, self.arena.offsets, self.arena.params)}
         for k, v in model.state_dict().items():
             out[k] = view[k] if k in view else v
         return out
@@ -119,7 +131,7 @@ class FusedAdamWEMA:
         for n, o, p in zip(self.arena.names, self.arena.offsets, self.arena.params):
             key = n if n in sd else ("module." + n if "module." + n in sd else None)
             if key is not None:
-                self.ema[o:o + p.numel()].view_as(p).copy_(sd[key])
+                self.arena.view(self.ema, p, o).copy_(sd[key])
 
 
 def build_optimizer(cfg, model):

@@ -554,3 +554,32 @@ def test_gelu_fwd_bwd_with_bias_gradient():
     torch.testing.assert_close(dx.float().cpu(), xr.grad, atol=1e-2, rtol=8e-3)
     want = bg0.double() + dx.cpu().double().sum(0)                                          # sums of the bf16 dx, fp32 accumulate
     assert (bg.cpu().double() - want).abs().max() <= 1e-5 * (dx.cpu().double().abs().sum(0).max() + 1)
+
+
+def test_conv3x3_arena_layout_and_in_place_gradients():
+    """A 3x3 Conv2d whose weight lives in a FlatArena: stored (Cout,kh,kw,Cin), exposed in the reference's shape; forward
+    reads the bf16 shadow as the GEMM operand, the weight / bias gradients accumulate in place in the arena."""
+    from divergen_amd.layers.conv_ops import Conv2d
+    from divergen_amd.solver import FlatArena
+    torch.manual_seed(3)
+    conv = Conv2d(32, 16, 3, 1, 1).to(DEV)
+    w0, b0 = conv.weight.detach().clone(), conv.bias.detach().clone()
+    arena = FlatArena(conv)
+    assert conv.weight.shape == (16, 32, 3, 3) and not conv.weight.is_contiguous()
+    assert torch.equal(conv.weight.detach(), w0)                                         # same logical values
+    assert conv.weight.detach().permute(0, 2, 3, 1).is_contiguous()                      # stored (Cout,kh,kw,Cin)
+    assert torch.equal(conv.state_dict()["weight"], w0)
+    x = torch.randn(2, 32, 20, 24, device=DEV).to(memory_format=torch.channels_last).requires_grad_(True)
+    go = torch.randn(2, 16, 20, 24, device=DEV)
+    for rep in range(2):          # twice: gradients ACCUMULATE in the arena
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = conv(x)
+        y.backward(go.to(y.dtype))
+    xr = bf(x.detach()).float().requires_grad_(True)
+    wr, br = bf(w0).float().requires_grad_(True), bf(b0).float().requires_grad_(True)
+    ref = torch.nn.functional.conv2d(xr, wr, br, padding=1)
+    ref.backward(bf(go).float())
+    torch.testing.assert_close(y.float(), ref.detach(), atol=3e-2, rtol=2e-2)
+    torch.testing.assert_close(conv.weight.grad, 2 * wr.grad, atol=2e-1, rtol=3e-2)      # logical view of the arena gradient
+    torch.testing.assert_close(conv.bias.grad, 2 * br.grad, atol=2e-1, rtol=3e-2)
+    assert float(arena.g.abs().sum()) > 0

@@ -7,6 +7,8 @@
 
 Weights keep nn.Conv2d / nn.ConvTranspose2d layouts so reference checkpoints load unchanged.
 Inputs and outputs are logical (N,C,H,W) tensors in channels_last memory format (NHWC storage)."""
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -155,7 +157,7 @@ class Conv2d(torch.nn.Conv2d):
 
     def __init__(self, *a, **k):
         super().__init__(*a, **k)
-        if self.kernel_size == (3, 3) and self.groups == 1:
+        if self.kernel_size == (3, 3) and self.groups == 1 and os.environ.get("DGX_CONV_OHWI", "1") == "1":
             self.weight._dgx_ohwi = True       # FlatArena stores it (Cout, kh, kw, Cin): see solver.FlatArena.view
 
     def forward(self, x):

@@ -11,6 +11,8 @@ the rest of backward; buckets whose parameters received no gradient this step (t
 the end.  Averaging (1/world) is folded into the optimizer kernel's grad_scale.
 xGMI is point-to-point, so a ring all-reduce is bound by one ~153 GB/s link: buckets default to
 64 MiB (fewer, larger collectives) rather than DDP's 25 MiB."""
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -36,7 +38,8 @@ class ArenaReducer:
         self._pending = [b[2] for b in self.buckets]
         self._launched = [False] * len(self.buckets)
         self._works = []
-        if self.world > 1:
+        self.active = self.world > 1 or (dist.is_initialized() and os.environ.get("DGX_FORCE_PG") == "1")
+        if self.active:
             for i, p in enumerate(arena.params):
                 hook = self._make_hook(i)
                 p.register_post_accumulate_grad_hook(hook)
@@ -62,14 +65,14 @@ class ArenaReducer:
 
     def broadcast_parameters(self, src=0):
         """Same initial weights on every rank (DDP's constructor broadcast)."""
-        if self.world > 1:
+        if self.active:
             dist.broadcast(self.arena.p, src=src, group=self.group)
             self.arena.sync_shadow()
 
     def finish(self):
         """Call after backward: flush never-ready buckets, wait for every collective.  Returns the
         factor the optimizer must apply to the summed gradients."""
-        if self.world > 1:
+        if self.active:
             for b in range(len(self.buckets)):
                 self._launch(b)
             for w in self._works:

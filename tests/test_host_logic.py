@@ -105,7 +105,9 @@ def _ddp_worker(rank, world, port, q):
         ar.zero_grad()
         net(x).sum().backward()
         scale = red.finish()
-    q.put((rank, p0, ar.g.clone() * scale))
+    # by value (numpy), not as shared-memory tensor handles: the handles die with this process and the parent may
+    # not have mapped them yet
+    q.put((rank, p0.numpy().copy(), (ar.g.clone() * scale).numpy().copy()))
     dist.destroy_process_group()
 
 
@@ -124,7 +126,7 @@ def test_arena_reducer_world2_gloo():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    (_, p_a, g_a), (_, p_b, g_b) = res
+    (_, p_a, g_a), (_, p_b, g_b) = [(r, torch.from_numpy(a), torch.from_numpy(b)) for r, a, b in res]
     assert torch.equal(p_a, p_b)            # parameters broadcast from rank 0
     assert torch.allclose(g_a, g_b)         # averaged gradients identical on both ranks
     # reference value: mean of the two single-rank gradients, computed locally with the same weights

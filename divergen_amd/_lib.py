@@ -56,6 +56,10 @@ SIGNATURES = {
     "dgx_linear_wgrad_grouped": (c_i, [ctypes.POINTER(WgradProblem), c_i, c_f, c_p, c_p]),
     "dgx_cascade_refine": (c_i, [c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_i, c_f, c_f, c_f, c_f, c_f,
                                  c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p]),
+    "dgx_paste_masks": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p]),
+    "dgx_paste_rle": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_p]),
+    "dgx_rle_encode": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
+    "dgx_rle_to_string": (c_i64, [c_p, c_i64, c_p, c_i64]),
     "dgx_detic_losses": (c_i, [c_p] * 7 + [c_i, c_i, c_f, c_f, c_f, c_f, c_p, c_p, c_p, c_p, c_i, c_p]),
     "dgx_gelu_fwd": (c_i, [c_p, c_p, c_i64, c_p]),
     "dgx_gelu_bwd_workspace_bytes": (c_i64, [c_i, c_i]),

@@ -125,8 +125,10 @@ class _BackboneForGraph(nn.Module):
         return tuple(out[n] for n in self.names)
 
 
-def detector_postprocess(results, output_height, output_width, mask_threshold=0.5):
-    """D2/modeling/postprocessing.py: rescale boxes to the output resolution, paste masks."""
+def detector_postprocess(results, output_height, output_width, mask_threshold=0.5, mask_format="bitmask"):
+    """D2/modeling/postprocessing.py: rescale boxes to the output resolution, paste masks.
+    mask_format="rle" (not in the reference): leave the masks as `pred_masks_rle` COCO run-length dicts, encoded on the GPU
+    straight from the SxS probabilities -- what the evaluator's results writer turns the bitmasks into anyway."""
     from ...structures import Boxes, Instances
     sx, sy = output_width / results.image_size[1], output_height / results.image_size[0]
     out = Instances((output_height, output_width), **results.get_fields())
@@ -138,24 +140,18 @@ def detector_postprocess(results, output_height, output_width, mask_threshold=0.
     out.pred_boxes = bx
     keep = bx.nonempty()
     out = out[keep]
-    if out.has("pred_masks"):
+    if out.has("pred_masks") and mask_format == "rle":
+        from ...layers.mask_ops import paste_masks_rle
+        rles = paste_masks_rle(out.pred_masks[:, 0], out.pred_boxes.tensor, (output_height, output_width), mask_threshold)
+        out.remove("pred_masks")
+        out.pred_masks_rle = rles
+    elif out.has("pred_masks"):
         out.pred_masks = paste_masks_in_image(out.pred_masks[:, 0], out.pred_boxes.tensor, (output_height, output_width),
                                               mask_threshold)
     return out
 
 
 def paste_masks_in_image(masks, boxes, image_shape, threshold=0.5):
-    """D2/layers/mask_ops.py paste via grid_sample (aligned sampling of the SxS probability map)."""
-    import torch.nn.functional as F
-    N = masks.shape[0]
-    H, W = image_shape
-    if N == 0:
-        return masks.new_empty((0, H, W), dtype=torch.bool)
-    x0, y0, x1, y1 = boxes.split(1, dim=1)
-    ys = torch.arange(0, H, device=masks.device, dtype=torch.float32) + 0.5
-    xs = torch.arange(0, W, device=masks.device, dtype=torch.float32) + 0.5
-    ys = (ys[None] - y0) / (y1 - y0) * 2 - 1
-    xs = (xs[None] - x0) / (x1 - x0) * 2 - 1
-    grid = torch.stack([xs[:, None, :].expand(N, H, W), ys[:, :, None].expand(N, H, W)], dim=3)
-    out = F.grid_sample(masks[:, None].float(), grid, align_corners=False)
-    return out[:, 0] >= threshold
+    """D2/layers/mask_ops.py:73 -- aligned bilinear paste of the SxS probability maps, on the GPU (dgx_paste_masks)."""
+    from ...layers.mask_ops import paste_masks_in_image as _paste
+    return _paste(masks, boxes, image_shape, threshold)

@@ -329,6 +329,26 @@ int64_t dgx_gelu_bwd_workspace_bytes(int M, int N);
 int dgx_gelu_bwd_colsum(const void* dy, const void* x, void* dx, float* bias_grad, int M, int N, float beta,
                         void* workspace, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Evaluation post-processing.  paste_masks_in_image (D2/layers/mask_ops.py:17-150; called from
+ * custom_rcnn.py:265-332 detector_postprocess): the SxS mask probabilities of detection n are sampled bilinearly
+ * (F.grid_sample, align_corners=False, zero padding) at every image pixel through its box and thresholded.
+ *   masks f32 (N,S,S) in [0,1];  boxes f32 (N,4) in output-image pixels;  out u8 (N,H,W) in {0,1}.
+ * dgx_paste_rle evaluates the same bits on the fly and emits, per detection, the COCO run-length encoding of the
+ * (H,W) mask (column-major order, first run counts zeros; what pycocotools.mask.encode produces before string
+ * compression, D2/evaluation/lvis_evaluation.py:80-97 / coco_evaluation instances_to_coco_json) without the N*H*W tensor:
+ *   counts i32 (N, cap) run lengths;  nruns i32 (N): number of runs, or -(needed) if it did not fit cap. */
+int dgx_paste_masks(const float* masks, const float* boxes, uint8_t* out, int N, int S, int H, int W,
+                    float threshold, void* stream);
+int dgx_paste_rle(const float* masks, const float* boxes, int32_t* counts, int32_t* nruns, int N, int S, int H,
+                  int W, float threshold, int cap, void* stream);
+/* Run lengths of existing bitmasks (bits u8 (N,H,W), non-zero = set), same output contract as dgx_paste_rle: the device
+ * form of mask_util.encode(np.array(mask[:, :, None], order="F")) at coco_evaluation.py:400-410. */
+int dgx_rle_encode(const uint8_t* bits, int32_t* counts, int32_t* nruns, int N, int H, int W, int cap, void* stream);
+/* HOST function: COCO compressed-RLE string of one run-length list (pycocotools maskApi.c rleToString, reached from
+ * coco_evaluation.py:406 mask_util.encode).  Returns the length written, or -(needed) if cap is too small. */
+int64_t dgx_rle_to_string(const int32_t* counts, int64_t n, char* out, int64_t cap);
+
 #ifdef __cplusplus
 }
 #endif

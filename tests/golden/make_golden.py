@@ -386,7 +386,30 @@ def gen_heads():
          **{("p." + k): v for k, v in head.state_dict().items()})
 
 
+def gen_postprocess():
+    """paste_masks_in_image (D2/layers/mask_ops.py:73) on seeded detections; output stored bit-packed."""
+    mo = R.ref("detectron2.layers.mask_ops")
+    g = torch.Generator().manual_seed(77)
+    H, W, S, N = 97, 131, 28, 24
+    # smooth blobs like sigmoid mask logits: low-res noise upsampled
+    low = torch.rand(N, 1, 5, 5, generator=g)
+    masks = torch.nn.functional.interpolate(low, size=(S, S), mode="bicubic", align_corners=False)[:, 0].clamp(0, 1)
+    cx, cy = torch.rand(N, generator=g) * W, torch.rand(N, generator=g) * H
+    bw, bh = torch.rand(N, generator=g) * 80 + 0.7, torch.rand(N, generator=g) * 60 + 0.7
+    boxes = torch.stack([cx - bw / 2, cy - bh / 2, cx + bw / 2, cy + bh / 2], 1)
+    boxes[0] = torch.tensor([0., 0., W, H])                      # whole image
+    boxes[1] = torch.tensor([-20.5, -10.25, 40.5, 30.0])          # partly outside (un-clipped boxes are legal inputs)
+    boxes[2] = torch.tensor([100.0, 50.0, 160.0, 120.0])
+    boxes[3] = torch.tensor([10.0, 10.0, 10.9, 10.9])             # sub-pixel box
+    masks[4] = 1.0                                                # solid
+    masks[5] = 0.0                                                # empty
+    out = mo.paste_masks_in_image(masks, boxes, (H, W), 0.5)
+    assert out.dtype == torch.bool and tuple(out.shape) == (N, H, W)
+    save("paste_masks", masks=masks, boxes=boxes, image_shape=np.array([H, W]),
+         out_bits=np.packbits(out.numpy().reshape(N, -1), axis=1), threshold=np.float32(0.5))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["swin", "centernet", "roi", "compositor", "solver", "heads"]
+    which = sys.argv[1:] or ["swin", "centernet", "roi", "compositor", "solver", "heads", "postprocess"]
     for w in which:
         globals()["gen_" + w]()

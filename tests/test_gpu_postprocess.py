@@ -1,0 +1,177 @@
+"""GPU parity of the evaluation post-processing path: dgx_paste_masks / dgx_paste_rle / dgx_rle_to_string
+through the C ABI vs the reference's own output (tests/golden/paste_masks.npz) and the oracle (oracle/postprocess.py)."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from divergen_amd import _lib  # noqa: E402
+from divergen_amd.layers import mask_ops as MO  # noqa: E402
+from oracle import postprocess as P  # noqa: E402
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+DEV = "cuda"
+
+
+def _golden():
+    z = np.load(os.path.join(G, "paste_masks.npz"))
+    H, W = [int(v) for v in z["image_shape"]]
+    N = z["masks"].shape[0]
+    ref = np.unpackbits(z["out_bits"], axis=1)[:, :H * W].reshape(N, H, W).astype(bool)
+    return z["masks"], z["boxes"], (H, W), float(z["threshold"]), ref
+
+
+def test_paste_masks_vs_reference_golden():
+    masks, boxes, hw, thr, ref = _golden()
+    got = MO.paste_masks_in_image(torch.from_numpy(masks).to(DEV), torch.from_numpy(boxes).to(DEV), hw, thr)
+    assert got.dtype == torch.bool and tuple(got.shape) == ref.shape
+    assert np.array_equal(got.cpu().numpy(), ref), int((got.cpu().numpy() != ref).sum())      # bit-exact
+
+
+def test_paste_rle_vs_reference_golden():
+    masks, boxes, hw, thr, ref = _golden()
+    H, W = hw
+    counts, nruns = MO.paste_masks_rle_counts(torch.from_numpy(masks).to(DEV), torch.from_numpy(boxes).to(DEV), hw, thr)
+    counts, nruns = counts.cpu().numpy(), nruns.cpu().numpy()
+    for n in range(ref.shape[0]):
+        want = P.rle_counts(ref[n])
+        assert nruns[n] == len(want), (n, nruns[n], len(want))
+        assert np.array_equal(counts[n, :nruns[n]], want), n
+    rles = MO.paste_masks_rle(torch.from_numpy(masks).to(DEV), torch.from_numpy(boxes).to(DEV), hw, thr)
+    for n, r in enumerate(rles):
+        assert r["size"] == [H, W]
+        assert r["counts"] == P.rle_to_string(P.rle_counts(ref[n])), n
+
+
+def _detections(N, H, W, S, seed):
+    g = torch.Generator().manual_seed(seed)
+    low = torch.rand(N, 1, 6, 6, generator=g)
+    masks = torch.nn.functional.interpolate(low, size=(S, S), mode="bicubic", align_corners=False)[:, 0].clamp(0, 1)
+    cx, cy = torch.rand(N, generator=g) * W, torch.rand(N, generator=g) * H
+    bw, bh = torch.rand(N, generator=g) ** 2 * W * 0.8 + 1, torch.rand(N, generator=g) ** 2 * H * 0.8 + 1
+    boxes = torch.stack([(cx - bw / 2).clamp(0, W), (cy - bh / 2).clamp(0, H), (cx + bw / 2).clamp(0, W),
+                         (cy + bh / 2).clamp(0, H)], 1)
+    boxes[0] = torch.tensor([0., 0., float(W), float(H)])
+    masks[0] = 1.0                                  # whole image set: mask starts with a set pixel
+    masks[1] = 0.0
+    return masks, boxes
+
+
+@pytest.mark.parametrize("N,H,W,S", [(7, 64, 48, 28), (40, 333, 500, 28), (3, 50, 70, 14)])
+def test_paste_vs_oracle_small(N, H, W, S):
+    masks, boxes = _detections(N, H, W, S, seed=N)
+    got = MO.paste_masks_in_image(masks.to(DEV), boxes.to(DEV), (H, W), 0.5).cpu().numpy()
+    want = P.paste_masks(masks.numpy(), boxes.numpy(), (H, W), 0.5)
+    assert want.sum() > 0
+    assert np.array_equal(got, want), int((got != want).sum())
+
+
+def test_full_size_round_trip_lvis_scale():
+    """BASELINE-scale evaluation image: 300 detections at 800x1333.  Size-independent properties: decode(RLE) equals the
+    bitmask kernel's output, runs sum to H*W, string round-trips through the oracle's rleFrString."""
+    N, H, W, S = 300, 800, 1333, 28
+    masks, boxes = _detections(N, H, W, S, seed=5)
+    m, b = masks.to(DEV), boxes.to(DEV)
+    bits = MO.paste_masks_in_image(m, b, (H, W), 0.5)
+    counts, nruns = MO.paste_masks_rle_counts(m, b, (H, W), 0.5)
+    assert int(nruns.min()) > 0
+    # device-side decode: run boundaries -> parity of the number of boundaries at or before each pixel
+    ends = counts.long().cumsum(1)
+    assert bool((ends.gather(1, (nruns.long() - 1)[:, None])[:, 0] == H * W).all())
+    cm = bits.transpose(1, 2).reshape(N, -1)        # column-major pixels
+    for n in range(0, N, 13):
+        e = ends[n, :int(nruns[n])]
+        idx = torch.arange(H * W, device=DEV)
+        val = (torch.searchsorted(e, idx, right=True) % 2).bool()
+        assert torch.equal(val, cm[n]), n
+    # area agreement for every detection
+    area_rle = torch.stack([counts[n, 1:int(nruns[n]):2].sum() for n in range(N)])
+    assert torch.equal(area_rle.long(), cm.sum(1))
+    rles = MO.paste_masks_rle(m, b, (H, W), 0.5)
+    cn, nr = counts.cpu().numpy(), nruns.cpu().numpy()
+    for n in range(0, N, 7):
+        assert np.array_equal(P.rle_from_string(rles[n]["counts"]), cn[n, :nr[n]])
+
+
+def test_rle_cap_overflow_is_reported_and_regrown():
+    N, H, W, S = 4, 120, 160, 28
+    g = torch.Generator().manual_seed(3)
+    masks = (torch.rand(N, S, S, generator=g) > 0.5).float()         # checkerboard-like: very many runs
+    boxes = torch.tensor([[0., 0., W, H]] * N)
+    m, b = masks.to(DEV), boxes.to(DEV)
+    counts = torch.empty((N, 16), dtype=torch.int32, device=DEV)
+    nruns = torch.empty((N,), dtype=torch.int32, device=DEV)
+    _lib.check(_lib.lib().dgx_paste_rle(m.data_ptr(), b.data_ptr(), counts.data_ptr(), nruns.data_ptr(), N, S, H, W, 0.5, 16,
+                                        _lib.stream()), "rle")
+    want = [len(P.rle_counts(x)) for x in P.paste_masks(masks.numpy(), boxes.numpy(), (H, W), 0.5)]
+    assert (-nruns.cpu().numpy()).tolist() == want
+    c2, n2 = MO.paste_masks_rle_counts(m, b, (H, W), 0.5, cap=16)    # wrapper regrows
+    assert n2.cpu().numpy().tolist() == want
+
+
+def test_empty_and_bad_args():
+    e = MO.paste_masks_in_image(torch.zeros(0, 28, 28, device=DEV), torch.zeros(0, 4, device=DEV), (10, 12))
+    assert tuple(e.shape) == (0, 10, 12) and e.dtype == torch.bool
+    assert MO.paste_masks_rle(torch.zeros(0, 28, 28, device=DEV), torch.zeros(0, 4, device=DEV), (10, 12)) == []
+    L = _lib.lib()
+    assert L.dgx_paste_masks(None, None, None, 1, 28, 10, 10, 0.5, None) != 0
+    buf = ctypes.create_string_buffer(2)
+    arr = np.array([100, 100, 100, 100], np.int32)
+    assert L.dgx_rle_to_string(arr.ctypes.data, 4, ctypes.cast(buf, ctypes.c_void_p), 2) == -7
+
+
+def test_detector_postprocess_uses_kernel():
+    from divergen_amd.modeling.meta_arch.custom_rcnn import detector_postprocess
+    from divergen_amd.structures import Boxes, Instances
+    masks, boxes = _detections(12, 100, 150, 28, seed=9)
+    inst = Instances((100, 150), pred_boxes=Boxes(boxes.to(DEV)), pred_masks=masks[:, None].to(DEV),
+                     scores=torch.rand(12, device=DEV))
+    out = detector_postprocess(inst, 200, 300)
+    sb = boxes * 2.0
+    want = P.paste_masks(masks.numpy(), sb.numpy(), (200, 300), 0.5)
+    assert np.array_equal(out.pred_masks.cpu().numpy(), want)
+
+
+def test_rle_encode_bitmasks_vs_oracle():
+    rng = np.random.default_rng(4)
+    N, H, W = 6, 77, 53
+    m = rng.random((N, H, W)) < 0.3
+    m[0] = True
+    m[1] = False
+    m[2, :, :] = False
+    m[2, 10:60, 5:40] = True
+    m[3, -1, -1] = True
+    m[3, 0, 0] = True
+    got = MO.rle_encode_bitmasks(torch.from_numpy(m).to(DEV), cap=64)          # cap forces the regrow path
+    for n in range(N):
+        assert got[n]["size"] == [H, W]
+        assert got[n]["counts"] == P.rle_to_string(P.rle_counts(m[n])), n
+
+
+def test_results_writer_matches_reference_layout():
+    """instances_to_coco_json (coco_evaluation.py:380-440): same dicts from the bitmask route and the fused RLE route."""
+    from divergen_amd.evaluation import instances_to_coco_json
+    from divergen_amd.modeling.meta_arch.custom_rcnn import detector_postprocess
+    from divergen_amd.structures import Boxes, Instances
+    masks, boxes = _detections(9, 100, 150, 28, seed=11)
+
+    def make():
+        return Instances((100, 150), pred_boxes=Boxes(boxes.to(DEV)), pred_masks=masks[:, None].to(DEV),
+                         scores=torch.linspace(0.9, 0.1, 9, device=DEV), pred_classes=torch.arange(9, device=DEV))
+    a = instances_to_coco_json(detector_postprocess(make(), 200, 300), 42)
+    b = instances_to_coco_json(detector_postprocess(make(), 200, 300, mask_format="rle"), 42)
+    assert a == b and len(a) == 9
+    want = P.paste_masks(masks.numpy(), (boxes * 2).numpy(), (200, 300), 0.5)
+    for k, r in enumerate(a):
+        assert set(r) == {"image_id", "category_id", "bbox", "score", "segmentation"}
+        assert r["image_id"] == 42 and r["category_id"] == k
+        x0, y0, x1, y1 = (boxes[k] * 2).tolist()
+        assert np.allclose(r["bbox"], [x0, y0, x1 - x0, y1 - y0], atol=1e-4)
+        assert isinstance(r["segmentation"]["counts"], str) and r["segmentation"]["size"] == [200, 300]
+        c = P.rle_from_string(r["segmentation"]["counts"].encode())
+        assert np.array_equal(P.rle_decode(c, 200, 300), want[k])
+    assert instances_to_coco_json(make()[torch.zeros(9, dtype=torch.bool, device=DEV)], 1) == []

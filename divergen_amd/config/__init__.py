@@ -152,7 +152,12 @@ def _merge_node(src, dst, path):
 def get_cfg():
     """Defaults of detectron2 + add_centernet_config + add_divergen_config (already merged)."""
     with open(_DEFAULTS) as f:
-        return CfgNode(json.load(f))
+        cfg = CfgNode(json.load(f))
+    # Keys of THIS build only (not in the reference tree; defaults keep the reference behaviour):
+    #   INPUT.INST_POOL_SHARDS: directory of pool-*.dgxpool shards (divergen_amd/data/pool_store.py, built by
+    #   tools/build_inst_pool.py); when set, pool instances are read from the shards instead of PIL-opened per sample.
+    cfg.INPUT.INST_POOL_SHARDS = ""
+    return cfg
 
 
 def add_centernet_config(cfg):

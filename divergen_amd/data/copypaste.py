@@ -39,7 +39,8 @@ class InstPool:
         for cat, paths in pool.items():
             for p in paths:
                 self.per_cat_pool[int(cat)].append(len(self.dataset))
-                self.data_to_cat[p] = int(cat) - 1      # pool json keys are 1-based category ids
+                self.data_to_cat[p] = int(cat)          # pool json keys ARE the 0-based labels (mapper.py:143-152;
+                                                        # written as `id - 1` by DG/filteration/clean_pool_if.py:173)
                 self.dataset.append(p)
         self.cats = list(self.per_cat_pool.keys())
         self.HWms = json.load(open(area_stats_json)) if area_stats_json and os.path.exists(area_stats_json) else {}
@@ -49,6 +50,28 @@ class InstPool:
         self.shape_jitter, self.mask_threshold = shape_jitter, mask_threshold
         self.filter_min, self.filter_max = instance_filter_min, instance_filter_max
         self.loader = loader or self._pil_loader
+
+    @classmethod
+    def from_config(cls, cfg):
+        """The constructor call of CopyPasteMapper.from_config (mapper.py:726-745) for INST_POOL_FORMAT 'RGBA', including
+        the category filter of InstPool.__init__ (:115-133: keep pool categories whose LVIS frequency is in INST_POOL_FREQ).
+        INPUT.INST_POOL_SHARDS (this build's key) switches the per-sample decode to the shard store."""
+        with open(cfg.INPUT.INST_POOL_PATH) as f:
+            pool = json.load(f)
+        freq_path = cfg.MODEL.ROI_BOX_HEAD.CAT_FREQ_PATH
+        if freq_path and os.path.exists(freq_path):
+            with open(freq_path) as f:
+                infos = json.load(f)
+            select = {info["id"] - 1 for info in infos if info["frequency"] in cfg.INPUT.INST_POOL_FREQ}
+            pool = {k: v for k, v in pool.items() if int(k) in select}
+        loader = None
+        if cfg.INPUT.get("INST_POOL_SHARDS", ""):
+            from .pool_store import PoolStore
+            loader = PoolStore(cfg.INPUT.INST_POOL_SHARDS).loader
+        return cls(pool, cfg.INPUT.TRAIN_SIZE, area_stats_json=cfg.INPUT.MEAN_STD2_PATH,
+                   max_samples=cfg.INPUT.INST_POOL_MAX_SAMPLES, random_scale=cfg.INPUT.RANDOM_SCALE,
+                   random_scale_min=cfg.INPUT.RANDOM_SCALE_MIN, random_scale_max=cfg.INPUT.RANDOM_SCALE_MAX,
+                   random_scale_min_size=cfg.INPUT.RANDOM_SCALE_MIN_SIZE, use_largest_part=cfg.USE_LARGEST_PART, loader=loader)
 
     @staticmethod
     def _pil_loader(path):
@@ -76,7 +99,6 @@ class InstPool:
 
     def load_rgba(self, key, image_hw):
         """_load_RGBA (mapper.py:359-456): returns (rgba (h,w,4) uint8, label) or None when rejected."""
-        from PIL import Image
         H, W = image_hw
         label = self.data_to_cat[key]
         try:
@@ -113,10 +135,16 @@ class InstPool:
             tw, th = int(tw), int(th)
             if tw < 5 or tw >= W or th < 5 or th >= H:
                 return None
-        rgba = np.array(Image.fromarray(rgba, "RGBA").resize((tw, th), Image.BILINEAR))   # cv2.resize role
+        rgba = self._resize(rgba, tw, th)
         if np.random.rand() < 0.5:                                                          # RandomFlip(horizontal)
             rgba = np.ascontiguousarray(rgba[:, ::-1])
         return rgba, label
+
+    @staticmethod
+    def _resize(rgba, tw, th):
+        """cv2.resize(img_RGBA, (target_W, target_H)) role (mapper.py:446); cv2 is not in this image, PIL bilinear is."""
+        from PIL import Image
+        return np.array(Image.fromarray(np.ascontiguousarray(rgba), "RGBA").resize((tw, th), Image.BILINEAR))
 
     @staticmethod
     def random_start_xy(rgba, train_hw):

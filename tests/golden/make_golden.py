@@ -409,7 +409,67 @@ def gen_postprocess():
          out_bits=np.packbits(out.numpy().reshape(N, -1), axis=1), threshold=np.float32(0.5))
 
 
+def gen_pool():
+    """Instance-pool decode: PNG fixtures under tests/golden/pool/ + what the reference's
+    InstPool._load_RGBA (mapper.py:359-444) hands to cv2.resize for each key (array and target size), captured by
+    replacing the stubbed cv2.resize with a recorder.  Keys are stored relative to tests/golden/."""
+    from PIL import Image
+    mp = R.ref("divergen.data.custom_build_copypaste_mapper")
+    pdir = os.path.join(HERE, "pool")
+    os.makedirs(pdir, exist_ok=True)
+    rng = np.random.default_rng(21)
+    names = []
+    for i, (h, w) in enumerate([(40, 56), (33, 21), (64, 64), (17, 90), (48, 30), (6, 7)]):
+        rgb = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        yy, xx = np.mgrid[0:h, 0:w]
+        soft = 255 * np.clip(1.3 - (((xx - w / 2) / (w / 2.4)) ** 2 + ((yy - h / 2) / (h / 2.4)) ** 2), 0, 1)
+        alpha = soft.astype(np.uint8)
+        if i % 2 == 0:          # "path|maskpath" pair: RGB png + single-channel mask png
+            Image.fromarray(rgb, "RGB").save(os.path.join(pdir, "inst%d.png" % i))
+            Image.fromarray(alpha, "L").save(os.path.join(pdir, "inst%d_mask.png" % i))
+            names.append("pool/inst%d.png|pool/inst%d_mask.png" % (i, i))
+        elif i == 1:            # plain RGBA png
+            Image.fromarray(np.dstack([rgb, alpha]), "RGBA").save(os.path.join(pdir, "inst%d.png" % i))
+            names.append("pool/inst%d.png" % i)
+        else:                   # '*' = pre-processed RGBA
+            Image.fromarray(np.dstack([rgb, alpha]), "RGBA").save(os.path.join(pdir, "inst%d.png" % i))
+            names.append("*pool/inst%d.png" % i)
+
+    class _Stop(Exception):
+        pass
+    captured = {}
+
+    def recorder(img, size):
+        captured["img"], captured["size"] = img.copy(), tuple(int(v) for v in size)
+        raise _Stop()
+    mp.cv2.resize = recorder
+    cwd = os.getcwd()
+    os.chdir(HERE)
+    store = {"keys": np.array(names), "labels": np.arange(len(names)) + 3, "train_hw": np.array([256, 320])}
+    try:
+        for mode in ("random_scale", "area_prior"):
+            fake = types.SimpleNamespace(
+                data_to_cat={k: int(3 + i) for i, k in enumerate(names)},
+                HWms={} if mode == "random_scale" else {str(4 + i): [0.12, 0.03] for i in range(len(names))},
+                random_scale=(mode == "random_scale"), random_scale_min=0.5, random_scale_max=2.0, random_scale_min_size=5,
+                scale_min=10, scale_max=0.5, mask_threshold=128, use_largest_part=False, instance_filter_min=0.01,
+                instance_filter_max=1.0, shape_jitter=0.2)
+            for i, k in enumerate(names):
+                np.random.seed(1000 + i)
+                captured.clear()
+                try:
+                    r = mp.InstPool._load_RGBA(fake, k, (256, 320))
+                    assert r is None
+                    store["%s_%d_rejected" % (mode, i)] = np.array(1)
+                except _Stop:
+                    store["%s_%d_img" % (mode, i)] = captured["img"]
+                    store["%s_%d_size" % (mode, i)] = np.array(captured["size"])
+    finally:
+        os.chdir(cwd)
+    save("pool_decode", **store)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["swin", "centernet", "roi", "compositor", "solver", "heads", "postprocess"]
+    which = sys.argv[1:] or ["swin", "centernet", "roi", "compositor", "solver", "heads", "postprocess", "pool"]
     for w in which:
         globals()["gen_" + w]()

@@ -349,6 +349,18 @@ int dgx_rle_encode(const uint8_t* bits, int32_t* counts, int32_t* nruns, int N, 
  * coco_evaluation.py:406 mask_util.encode).  Returns the length written, or -(needed) if cap is too small. */
 int64_t dgx_rle_to_string(const int32_t* counts, int64_t n, char* out, int64_t cap);
 
+/* ---------------------------------------------------------------------------------------------
+ * BSGAL gain scoring on flat gradient arenas (BS/bsgal/modeling/meta_arch/custom_rcnn.py).
+ * dgx_grad_bank_update replaces update_grad_bank (:1046-1062): bank = bank * a + grad * b in that fp32 order
+ *   ("AVERAGE": a = it/(it+1), b = 1/(it+1);  "MOMENTUMm": a = m, b = 1 - m).  bank, grad: f32 (n), 16-byte aligned.
+ * dgx_grad_sim replaces compute_grad_sim (:1074-1086) and the two .norm() passes: one pass over both vectors,
+ *   out3 f64 = {g1.g2, |g1|^2, |g2|^2},  out4 f32 = {g1.g2, |g1|, |g2|, g1.g2 / (|g1||g2| + 1e-8)}.
+ *   workspace: dgx_grad_sim_workspace_bytes(n) bytes.  Deterministic (fixed-order two-stage fp64 reduction). */
+int dgx_grad_bank_update(float* bank, const float* grad, int64_t n, float a, float b, void* stream);
+int64_t dgx_grad_sim_workspace_bytes(int64_t n);
+int dgx_grad_sim(const float* g1, const float* g2, int64_t n, double* out3, float* out4, void* workspace,
+                 void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,6 +7,7 @@ Each fixture stores inputs (or the seed recipe that regenerates them) and the ou
 reference produced.  No reference source text is stored.  The oracle (oracle/*.py) is
 checked against these in tests/test_oracle_*.py; the HIP path is checked against both.
 """
+import importlib
 import os
 import sys
 import types
@@ -469,7 +470,45 @@ def gen_pool():
     save("pool_decode", **store)
 
 
+def gen_bsgal():
+    """BSGAL gradient bank: update_grad_bank / compute_grad_sim of the reference's CustomRCNN
+    (BS/bsgal/modeling/meta_arch/custom_rcnn.py:1046-1086) called unbound on a stand-in `self`."""
+    R.install()
+    BS = R.REF + "/BSGAL/bsgal"
+    R._ns("bsgal", BS)
+    R._ns("bsgal.modeling", BS + "/modeling")
+    R._ns("bsgal.modeling.meta_arch", BS + "/modeling/meta_arch")
+    for nm in ("bsgal.modeling.text", "bsgal.modeling.text.text_encoder", "bsgal.modeling.utils", "torchshow"):
+        sys.modules[nm] = R._Permissive(nm)
+    rc = R._ns("detectron2.modeling.meta_arch.rcnn")
+    rc.GeneralizedRCNN = nn.Module
+    sys.modules["detectron2.utils.comm"].all_gather = lambda x: [x]
+    sys.modules["detectron2.structures"].ROIMasks = R._PermissiveObj("ROIMasks")
+    m = importlib.import_module("bsgal.modeling.meta_arch.custom_rcnn")
+    C = m.CustomRCNN
+    g = torch.Generator().manual_seed(31)
+    n = 2051                                    # not a multiple of 4: exercises the tail
+    store = {}
+    for mode in ("AVERAGE", "MOMENTUM0.9"):
+        bank = nn.Embedding(n, 1)
+        bank.weight.requires_grad = False
+        bank.weight.data.fill_(0)
+        fake = types.SimpleNamespace(active_grad_save=True, active_grad_update=mode, iter=1, grad_bank=bank,
+                                     output_dir="/tmp", rank="0", active_grad_norm=True)
+        grads = [torch.randn(n, generator=g) * (0.1 + 0.3 * i) for i in range(4)]
+        for it, gr in enumerate(grads):
+            fake.iter = it + 1                  # iter % 10000 != 0: no checkpoint write
+            out = C.update_grad_bank(fake, gr)
+            store["%s_bank_%d" % (mode, it)] = out.clone()
+        store["%s_grads" % mode] = torch.stack(grads)
+        probe = torch.randn(n, generator=g)
+        store["%s_probe" % mode] = probe
+        store["%s_sim_norm" % mode] = C.compute_grad_sim(fake, probe, out)
+        store["%s_sim_raw" % mode] = C.compute_grad_sim(fake, probe, out, norm=False)
+    save("bsgal_bank", **store)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["swin", "centernet", "roi", "compositor", "solver", "heads", "postprocess", "pool"]
+    which = sys.argv[1:] or ["swin", "centernet", "roi", "compositor", "solver", "heads", "postprocess", "pool", "bsgal"]
     for w in which:
         globals()["gen_" + w]()

@@ -266,3 +266,179 @@ extern "C" int dgx_layernorm_bwd(const void* dy_bf16, const void* x, const float
     DGX_LAUNCH_CHECK();
     return DGX_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// PatchMerging front half (swintransformer.py:272-298): zero-pad to even H/W, gather the 2x2 neighbourhood
+// [x(2i,2j) | x(2i+1,2j) | x(2i,2j+1) | x(2i+1,2j+1)] into one 4*C0-wide row and LayerNorm it -- in ONE pass over x,
+// bf16 out (the operand of the reduction GEMM).  The reference materialises four strided slices, their concatenation and
+// an fp32 LayerNorm; its backward zero-fills and adds four full-size tensors.  Here every element of x is read once in
+// the forward and every element of dx written once in the backward.
+struct MergeMap { int B, H, W, H2, W2, C0; };
+
+// float4 column i (of 4*C0/4) of merged row (b, i2, j2) -> source float4 pointer index, or -1 in the zero padding
+__device__ __forceinline__ int64_t merge_src4(const MergeMap& m, int b, int i2, int j2, int i, int q0) {
+    const int seg = i / q0, wi = i - seg * q0;
+    const int y = 2 * i2 + (seg & 1), x = 2 * j2 + (seg >> 1);
+    if (y >= m.H || x >= m.W) return -1;
+    return (((int64_t)b * m.H + y) * m.W + x) * q0 + wi;
+}
+template <typename T> __device__ __forceinline__ float4 ld4q(const T* base, int64_t q) {
+    if (q < 0) return make_float4(0.f, 0.f, 0.f, 0.f);
+    return ld4<T>(base + q * 4, 0);
+}
+
+template <typename XT>
+__global__ __launch_bounds__(256) void pm_ln_fwd_kernel(const XT* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, uint16_t* __restrict__ y,
+                                                        float* __restrict__ mean, float* __restrict__ rstd, float eps,
+                                                        MergeMap m) {
+    const int lane = threadIdx.x & 63;
+    const int C = 4 * m.C0, q0 = m.C0 / 4;
+    const int64_t T2 = (int64_t)m.B * m.H2 * m.W2;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t row = wave; row < T2; row += nwaves) {
+        const int j2 = (int)(row % m.W2), i2 = (int)((row / m.W2) % m.H2), b = (int)(row / ((int64_t)m.W2 * m.H2));
+        float s = 0.f;
+        for (int i = lane; i < C / 4; i += 64) {
+            const float4 v = ld4q<XT>(x, merge_src4(m, b, i2, j2, i, q0));
+            s += (v.x + v.y) + (v.z + v.w);
+        }
+        const float mu = wave_sum(s) / (float)C;
+        float q = 0.f;
+        for (int i = lane; i < C / 4; i += 64) {
+            const float4 v = ld4q<XT>(x, merge_src4(m, b, i2, j2, i, q0));
+            const float a = v.x - mu, bb = v.y - mu, c = v.z - mu, d = v.w - mu;
+            q += (a * a + bb * bb) + (c * c + d * d);
+        }
+        const float rs = rsqrtf(wave_sum(q) / (float)C + eps);
+        if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+        const float4* g4 = reinterpret_cast<const float4*>(gamma);
+        const float4* b4 = reinterpret_cast<const float4*>(beta);
+        uint2* yo = reinterpret_cast<uint2*>(y + row * C);
+        for (int i = lane; i < C / 4; i += 64) {
+            const float4 v = ld4q<XT>(x, merge_src4(m, b, i2, j2, i, q0)), g = g4[i], be = b4[i];
+            yo[i] = make_uint2(pack_bf2((v.x - mu) * rs * g.x + be.x, (v.y - mu) * rs * g.y + be.y),
+                               pack_bf2((v.z - mu) * rs * g.z + be.z, (v.w - mu) * rs * g.w + be.w));
+        }
+    }
+}
+
+// NJ = ceil(4*C0/256) float4 columns per lane; same reduction layout as ln_bwd_kernel (part: [block][2][C])
+template <int NJ, typename XT>
+__global__ __launch_bounds__(256) void pm_ln_bwd_kernel(const uint16_t* __restrict__ dy, const XT* __restrict__ x,
+                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                        const float* __restrict__ gamma, XT* __restrict__ dx,
+                                                        float* __restrict__ part, MergeMap m) {
+    __shared__ float red[2][NJ * 256];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int C = 4 * m.C0, q0 = m.C0 / 4;
+    const int64_t T2 = (int64_t)m.B * m.H2 * m.W2;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + w, nwaves = (int64_t)gridDim.x * 4;
+    float dg[NJ][4], db[NJ][4];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dg[j][k] = db[j][k] = 0.f;
+    const float4* g4 = reinterpret_cast<const float4*>(gamma);
+    for (int64_t row = wave; row < T2; row += nwaves) {
+        const int j2 = (int)(row % m.W2), i2 = (int)((row / m.W2) % m.H2), b = (int)(row / ((int64_t)m.W2 * m.H2));
+        const uint2* dyr = reinterpret_cast<const uint2*>(dy + row * C);
+        const float mu = mean[row], rs = rstd[row];
+        float xh[NJ][4], gv[NJ][4];
+        int64_t src[NJ];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int i = lane + 64 * j;
+            src[j] = -1;
+            if (i < C / 4) {
+                src[j] = merge_src4(m, b, i2, j2, i, q0);
+                const float4 v = ld4q<XT>(x, src[j]), g = g4[i];
+                const uint2 d = dyr[i];
+                const float dv[4] = {__uint_as_float(d.x << 16), __uint_as_float(d.x & 0xffff0000u),
+                                     __uint_as_float(d.y << 16), __uint_as_float(d.y & 0xffff0000u)};
+                const float xv[4] = {v.x, v.y, v.z, v.w}, gg[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    xh[j][k] = (xv[k] - mu) * rs;
+                    gv[j][k] = dv[k] * gg[k];
+                    s1 += gv[j][k];
+                    s2 += gv[j][k] * xh[j][k];
+                    dg[j][k] += dv[k] * xh[j][k];
+                    db[j][k] += dv[k];
+                }
+            }
+        }
+        s1 = wave_sum(s1) / (float)C;
+        s2 = wave_sum(s2) / (float)C;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+            if (src[j] >= 0)
+                st4<XT>(dx + src[j] * 4, 0,
+                        make_float4(rs * (gv[j][0] - s1 - xh[j][0] * s2), rs * (gv[j][1] - s1 - xh[j][1] * s2),
+                                    rs * (gv[j][2] - s1 - xh[j][2] * s2), rs * (gv[j][3] - s1 - xh[j][3] * s2)));
+    }
+    for (int turn = 0; turn < 4; ++turn) {
+        if (w == turn) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int c = (lane + 64 * j) * 4 + k;
+                    red[0][c] = turn ? red[0][c] + dg[j][k] : dg[j][k];
+                    red[1][c] = turn ? red[1][c] + db[j][k] : db[j][k];
+                }
+        }
+        __syncthreads();
+    }
+    for (int c = threadIdx.x; c < C; c += 256) {
+        part[((int64_t)blockIdx.x * 2 + 0) * C + c] = red[0][c];
+        part[((int64_t)blockIdx.x * 2 + 1) * C + c] = red[1][c];
+    }
+}
+
+static bool merge_args_ok(int B, int H, int W, int C0) { return B > 0 && H > 0 && W > 0 && C0 > 0 && (C0 & 3) == 0 && 4 * C0 <= 3072; }
+
+extern "C" int dgx_patch_merge_ln_fwd(const void* x, const float* gamma, const float* beta, void* y_bf16, float* mean,
+                                      float* rstd, int B, int H, int W, int C0, float eps, int x_dtype, void* stream) {
+    if (!x || !gamma || !beta || !y_bf16 || !mean || !rstd || !merge_args_ok(B, H, W, C0)) return DGX_ERR_BAD_ARG;
+    const MergeMap m = {B, H, W, (H + 1) / 2, (W + 1) / 2, C0};
+    const int64_t T2 = (int64_t)B * m.H2 * m.W2;
+    const int grid = (int)((T2 + 3) / 4 < 8192 ? (T2 + 3) / 4 : 8192);
+    if (x_dtype == DGX_BF16)
+        hipLaunchKernelGGL(pm_ln_fwd_kernel<uint16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, gamma,
+                           beta, (uint16_t*)y_bf16, mean, rstd, eps, m);
+    else
+        hipLaunchKernelGGL(pm_ln_fwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)x, gamma, beta,
+                           (uint16_t*)y_bf16, mean, rstd, eps, m);
+    DGX_LAUNCH_CHECK();
+    return DGX_OK;
+}
+
+extern "C" int dgx_patch_merge_ln_bwd(const void* dy_bf16, const void* x, const float* mean, const float* rstd,
+                                      const float* gamma, void* dx, float* dgamma, float* dbeta, float* part, int B, int H,
+                                      int W, int C0, int x_dtype, void* stream) {
+    if (!dy_bf16 || !x || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta || !part || !merge_args_ok(B, H, W, C0))
+        return DGX_ERR_BAD_ARG;
+    const MergeMap m = {B, H, W, (H + 1) / 2, (W + 1) / 2, C0};
+    const int64_t T2 = (int64_t)B * m.H2 * m.W2;
+    const int C = 4 * C0, grid = dgx_layernorm_bwd_blocks(T2), nj = (C + 255) / 256;
+    hipStream_t st = (hipStream_t)stream;
+#define PM_BWD(NJ)                                                                                                          \
+    do {                                                                                                                    \
+        if (x_dtype == DGX_BF16)                                                                                            \
+            hipLaunchKernelGGL((pm_ln_bwd_kernel<NJ, uint16_t>), dim3(grid), dim3(256), 0, st, (const uint16_t*)dy_bf16,     \
+                               (const uint16_t*)x, mean, rstd, gamma, (uint16_t*)dx, part, m);                              \
+        else                                                                                                                \
+            hipLaunchKernelGGL((pm_ln_bwd_kernel<NJ, float>), dim3(grid), dim3(256), 0, st, (const uint16_t*)dy_bf16,        \
+                               (const float*)x, mean, rstd, gamma, (float*)dx, part, m);                                    \
+    } while (0)
+    if (nj <= 2) PM_BWD(2);
+    else if (nj <= 3) PM_BWD(3);
+    else if (nj <= 6) PM_BWD(6);
+    else PM_BWD(12);
+#undef PM_BWD
+    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * C / 4 + 63) / 64), dim3(1024), 0, st, part, dgamma, dbeta, grid, C);
+    DGX_LAUNCH_CHECK();
+    return DGX_OK;
+}

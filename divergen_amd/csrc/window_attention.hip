@@ -274,12 +274,12 @@ __global__ __launch_bounds__(WinCfg<WS>::NT * 64) void win_attn_bwd_kernel(
     for (int i = tid; i < NP; i += nthreads) {
         const int yq = i / WS;
         qoff_s[i] = i < N ? yq * (2 * WS - 1) + (i - yq * WS) : 0;
-        if (i >= N) { lse_s[i] = INFINITY; delta_s[i] = 0.f; reg_s[i] = 0; }   // padded queries: p = 0
+        if (i >= N) { lse_s[i] = -INFINITY; delta_s[i] = 0.f; reg_s[i] = 0; }   // padded queries: p = 0
     }
     const int yk = key / WS, xk = key - yk * WS;
     const int kbase = kok ? (WS - 1) * (2 * WS - 1) + (WS - 1) - (yk * (2 * WS - 1) + xk) : 0;
     const float kneg = kok ? 0.0f : -INFINITY;   // padded key columns: p = 0
-    const float scale2 = scale * DGX_LOG2E;
+    const float scale2 = scale * DGX_LOG2E, inv_scale = 1.0f / scale;
     DGX_LDS const float* tbl_k = lds_opaque(tbl + kbase);
     float dbias[NT][4];
 #pragma unroll
@@ -303,7 +303,9 @@ __global__ __launch_bounds__(WinCfg<WS>::NT * 64) void win_attn_bwd_kernel(
             for (int i = 0; i < 8; ++i) d += bf2f((uint16_t)P.d[i]) * bf2f((uint16_t)P.o[i]);
             d += __shfl_xor(d, 1);
             d += __shfl_xor(d, 2);
-            if (sc == 0) { meta_st[NP] = d; meta_st[0] = P.lse * DGX_LOG2E; reinterpret_cast<DGX_LDS int*>(meta_st)[3 * NP] = P.reg; }
+            // stored negated and pre-divided: they are the INITIAL accumulators of the two MFMAs of phase 1, so that
+            // S*scale2 - lse2 and dP - delta cost no VALU instruction (lse_s = -lse/scale, delta_s = -delta)
+            if (sc == 0) { meta_st[NP] = -d; meta_st[0] = -P.lse * inv_scale; reinterpret_cast<DGX_LDS int*>(meta_st)[3 * NP] = P.reg; }
         }
         const bf16x8 vf = P.v;
         CLK(0);
@@ -328,11 +330,10 @@ __global__ __launch_bounds__(WinCfg<WS>::NT * 64) void win_attn_bwd_kernel(
                 if (qt < NT) {
                     const bf16x8 qa = *reinterpret_cast<DGX_LDS const bf16x8*>(q_row + 16 * qt * RR);
                     const bf16x8 da = *reinterpret_cast<DGX_LDS const bf16x8*>(do_row + 16 * qt * RR);
-                    f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                    const f32x4 s = mfma16(qa, kf, z);    // s[r]  = S[q 16qt+4g+r][key]
-                    const f32x4 dp = mfma16(da, vf, z);   // dp[r] = dP[q][key]
-                    const f32x4 lv = *reinterpret_cast<DGX_LDS const f32x4*>(lse_g + 16 * qt);
-                    const f32x4 dl = *reinterpret_cast<DGX_LDS const f32x4*>(delta_g + 16 * qt);
+                    const f32x4 lv = *reinterpret_cast<DGX_LDS const f32x4*>(lse_g + 16 * qt);     // -lse[q] / scale
+                    const f32x4 dl = *reinterpret_cast<DGX_LDS const f32x4*>(delta_g + 16 * qt);   // -delta[q]
+                    const f32x4 s = mfma16(qa, kf, lv);    // s[r]  = S[q 16qt+4g+r][key] - lse[q]/scale
+                    const f32x4 dp = mfma16(da, vf, dl);   // dp[r] = dP[q][key] - delta[q]
                     const i32x4 ov = *reinterpret_cast<DGX_LDS const i32x4*>(qoff_g + 16 * qt);
                     i32x4 rv = {0, 0, 0, 0};
                     if (MASKED) rv = *reinterpret_cast<DGX_LDS const i32x4*>(reg_g + 16 * qt);
@@ -341,8 +342,8 @@ __global__ __launch_bounds__(WinCfg<WS>::NT * 64) void win_attn_bwd_kernel(
                         float sv = __builtin_fmaf(s[r], scale2, tbl_k[ov[r]]);       // log2 domain (bias row, lse pre-scaled)
                         if (N % 16 != 0) sv += kneg;
                         if (MASKED) sv += rv[r] != rk ? -100.0f * DGX_LOG2E : 0.0f;
-                        pv[r] = __builtin_amdgcn_exp2f(sv - lv[r]);
-                        dsv[r] = pv[r] * (dp[r] - dl[r]);
+                        pv[r] = __builtin_amdgcn_exp2f(sv);
+                        dsv[r] = pv[r] * dp[r];
                         dbias[qt < NT ? qt : 0][r] += dsv[r];
                     }
                 }

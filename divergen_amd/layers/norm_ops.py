@@ -49,6 +49,54 @@ class _LayerNormBF16(torch.autograd.Function):
         return dx, dg.to(weight.dtype), db.to(bias.dtype), None, None, None, None, None, None
 
 
+class _PatchMergeLN(torch.autograd.Function):
+    """PatchMerging's pad + 2x2 gather + LayerNorm(4C) (swintransformer.py:272-298) as one kernel each way."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, B, H, W):
+        assert x.dtype in (torch.float32, torch.bfloat16)
+        x = x.contiguous()
+        C0 = x.shape[-1]
+        H2, W2 = (H + 1) // 2, (W + 1) // 2
+        T2 = B * H2 * W2
+        y = torch.empty(B, H2 * W2, 4 * C0, dtype=torch.bfloat16, device=x.device)
+        mean = torch.empty(T2, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(T2, dtype=torch.float32, device=x.device)
+        L.check(L.lib().dgx_patch_merge_ln_fwd(L.ptr(x), L.ptr(weight), L.ptr(bias), L.ptr(y), L.ptr(mean), L.ptr(rstd), B, H, W, C0,
+                                               float(eps), L.dtype_code(x), L.stream()), "dgx_patch_merge_ln_fwd")
+        ctx.save_for_backward(x, mean, rstd)
+        ctx.weight, ctx.bias, ctx.cfg = weight, bias, (B, H, W, C0, T2)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, rstd = ctx.saved_tensors
+        weight, bias = ctx.weight, ctx.bias
+        B, H, W, C0, T2 = ctx.cfg
+        C = 4 * C0
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        nblk = L.lib().dgx_layernorm_bwd_blocks(T2)
+        part = torch.empty(nblk * 2 * C, dtype=torch.float32, device=x.device)
+        in_arena = (weight.is_leaf and bias.is_leaf and weight.grad is not None and bias.grad is not None
+                    and getattr(weight, "_dgx16", None) is not None and getattr(bias, "_dgx16", None) is not None)
+        dg = weight.grad if in_arena else torch.zeros(C, dtype=torch.float32, device=x.device)
+        db = bias.grad if in_arena else torch.zeros(C, dtype=torch.float32, device=x.device)
+        L.check(L.lib().dgx_patch_merge_ln_bwd(L.ptr(dy), L.ptr(x), L.ptr(mean), L.ptr(rstd), L.ptr(weight), L.ptr(dx), L.ptr(dg),
+                                               L.ptr(db), L.ptr(part), B, H, W, C0, L.dtype_code(x), L.stream()),
+                "dgx_patch_merge_ln_bwd")
+        if in_arena:
+            for p in (weight, bias):
+                notify_ready(p)
+            return dx, None, None, None, None, None, None
+        return dx, dg.to(weight.dtype), db.to(bias.dtype), None, None, None, None
+
+
+def patch_merge_layernorm(x, weight, bias, eps, B, H, W):
+    """x (B, H*W, C0) f32|bf16 -> bf16 (B, ceil(H/2)*ceil(W/2), 4*C0): pad, 2x2 gather, LayerNorm."""
+    return _PatchMergeLN.apply(x, weight, bias, eps, B, H, W)
+
+
 def layernorm_bf16(x, weight, bias, eps=1e-5):
     """fp32 (..., C) -> LayerNorm -> bf16 (..., C)."""
     return _LayerNormBF16.apply(x, weight, bias, eps, 0, 0, 0, 0, 0)

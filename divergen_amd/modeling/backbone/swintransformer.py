@@ -20,12 +20,13 @@ import torch.nn.functional as F
 from .. import BACKBONE_REGISTRY, ShapeSpec
 from ...layers.conv_ops import patch_embed4x4
 from ...layers.linear_ops import Linear
-from ...layers.norm_ops import layernorm_bf16, layernorm_window_gather, residual_add
+from ...layers.norm_ops import layernorm_bf16, layernorm_window_gather, patch_merge_layernorm, residual_add
 from ...layers import shift_regions, window_attention_core, window_gather, window_scatter
 from ...layers.swin_block import arena_resident, swin_block
 
 import os
 _FUSED_BLOCK = os.environ.get("DGX_FUSED_BLOCK", "1") == "1"
+_FUSED_MERGE = os.environ.get("DGX_FUSED_MERGE", "1") == "1"      # A/B switch: PatchMerging gather + LayerNorm kernel
 
 
 def trunc_normal_(t, std=0.02):
@@ -153,6 +154,10 @@ class PatchMerging(nn.Module):
 
     def forward(self, x, H, W):
         B, Ltok, C = x.shape
+        if _FUSED_MERGE and torch.is_autocast_enabled() and x.is_cuda and C % 4 == 0 and 4 * C <= 3072 \
+                and x.dtype in (torch.float32, torch.bfloat16):
+            # pad + 2x2 gather + LayerNorm in one pass, bf16 out = what autocast hands the reduction GEMM
+            return self.reduction(patch_merge_layernorm(x, self.norm.weight, self.norm.bias, self.norm.eps, B, H, W))
         x = x.view(B, H, W, C)
         if H % 2 or W % 2:
             x = F.pad(x, (0, 0, 0, W % 2, 0, H % 2))

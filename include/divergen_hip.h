@@ -229,6 +229,15 @@ int dgx_layernorm_bwd_blocks(int64_t T);
 int dgx_layernorm_bwd(const void* dy_bf16, const void* x, const float* mean, const float* rstd,
                       const float* gamma, const void* dres, void* dx, float* dgamma, float* dbeta, float* part,
                       int64_t T, int C, int B, int H, int W, int ws, int shift, int x_dtype, void* stream);
+/* PatchMerging front half (swintransformer.py:272-298: pad to even H/W, x0|x1|x2|x3 concatenation of the 2x2
+ * neighbourhood, LayerNorm(4*C0)) in one pass.  x (B,H,W,C0) f32|bf16 -> y bf16 (B*H2*W2, 4*C0), H2 = ceil(H/2);
+ * mean, rstd f32 (B*H2*W2).  Backward writes dx (B,H,W,C0) in x's dtype, every element once, and ADDS into
+ * dgamma / dbeta (4*C0);  part: f32 scratch of dgx_layernorm_bwd_blocks(B*H2*W2)*2*4*C0.  C0 % 4 == 0, 4*C0 <= 3072. */
+int dgx_patch_merge_ln_fwd(const void* x, const float* gamma, const float* beta, void* y_bf16, float* mean,
+                           float* rstd, int B, int H, int W, int C0, float eps, int x_dtype, void* stream);
+int dgx_patch_merge_ln_bwd(const void* dy_bf16, const void* x, const float* mean, const float* rstd,
+                           const float* gamma, void* dx, float* dgamma, float* dbeta, float* part, int B, int H,
+                           int W, int C0, int x_dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Residual + DropPath epilogue of a Swin block: out = x + scale[b] * y, y bf16 in token order (ws == 0)

@@ -583,3 +583,34 @@ def test_conv3x3_arena_layout_and_in_place_gradients():
     torch.testing.assert_close(conv.weight.grad, 2 * wr.grad, atol=2e-1, rtol=3e-2)      # logical view of the arena gradient
     torch.testing.assert_close(conv.bias.grad, 2 * br.grad, atol=2e-1, rtol=3e-2)
     assert float(arena.g.abs().sum()) > 0
+
+
+# ------------------------------------------------------------------ PatchMerging gather + LayerNorm
+@pytest.mark.parametrize("B,H,W,C0,dt", [(2, 8, 6, 32, torch.float32), (1, 7, 9, 48, torch.bfloat16), (2, 16, 16, 192, torch.bfloat16),
+                                          (1, 5, 4, 384, torch.float32), (1, 4, 4, 768, torch.bfloat16)])
+def test_patch_merge_layernorm_vs_reference_formulation(B, H, W, C0, dt):
+    """swintransformer.py:284-298: pad, x0|x1|x2|x3, LayerNorm(4C) -- fused kernel vs the torch formulation in fp32."""
+    import torch.nn.functional as F
+    from divergen_amd.layers.norm_ops import patch_merge_layernorm
+    g = torch.Generator().manual_seed(B * 100 + H)
+    x = (torch.randn(B, H * W, C0, generator=g) * 1.5 + 0.3).to(dt).to(DEV).requires_grad_()
+    wt = (torch.rand(4 * C0, generator=g) + 0.5).to(DEV).requires_grad_()
+    bs = torch.randn(4 * C0, generator=g).to(DEV).requires_grad_()
+    y = patch_merge_layernorm(x, wt, bs, 1e-5, B, H, W)
+    dy = torch.randn(y.shape, generator=g).to(DEV).bfloat16()
+    y.backward(dy)
+    got = (y.float(), x.grad.float().clone(), wt.grad.clone(), bs.grad.clone())
+    x2 = x.detach().float().requires_grad_()
+    w2, b2 = wt.detach().clone().requires_grad_(), bs.detach().clone().requires_grad_()
+    v = x2.view(B, H, W, C0)
+    if H % 2 or W % 2:
+        v = F.pad(v, (0, 0, 0, W % 2, 0, H % 2))
+    v = torch.cat([v[:, 0::2, 0::2], v[:, 1::2, 0::2], v[:, 0::2, 1::2], v[:, 1::2, 1::2]], -1)
+    ref = F.layer_norm(v.view(B, -1, 4 * C0), (4 * C0,), w2, b2, 1e-5)
+    ref.backward(dy.float())
+    assert got[0].shape == ref.shape
+    assert torch.allclose(got[0], ref, atol=3e-2, rtol=2e-2)                     # bf16 output
+    tol = 3e-2 if dt == torch.bfloat16 else 2e-4
+    assert torch.allclose(got[1], x2.grad, atol=tol, rtol=tol), float((got[1] - x2.grad).abs().max())
+    assert torch.allclose(got[2], w2.grad, atol=2e-3 * max(1.0, float(w2.grad.abs().max())), rtol=1e-3)
+    assert torch.allclose(got[3], b2.grad, atol=1e-3 * max(1.0, float(b2.grad.abs().max())), rtol=1e-3)

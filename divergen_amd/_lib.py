@@ -65,6 +65,8 @@ SIGNATURES = {
     "dgx_grad_bank_update": (c_i, [c_p, c_p, c_i64, c_f, c_f, c_p]),
     "dgx_grad_sim_workspace_bytes": (c_i64, [c_i64]),
     "dgx_grad_sim": (c_i, [c_p, c_p, c_i64, c_p, c_p, c_p, c_p]),
+    "dgx_centernet_losses_blocks": (c_i, [c_i]),
+    "dgx_centernet_losses": (c_i, [c_p] * 6 + [c_i, c_i, c_i, c_i] + [c_f] * 6 + [c_p] * 5 + [c_p]),
     "dgx_detic_losses": (c_i, [c_p] * 7 + [c_i, c_i, c_f, c_f, c_f, c_f, c_p, c_p, c_p, c_p, c_i, c_p]),
     "dgx_gelu_fwd": (c_i, [c_p, c_p, c_i64, c_p]),
     "dgx_gelu_bwd_workspace_bytes": (c_i64, [c_i, c_i]),

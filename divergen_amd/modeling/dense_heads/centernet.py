@@ -7,6 +7,8 @@ normalisers stay on the device (the reference's two `.item()` round trips after 
 centernet.py:259-260,289, become device-side divisions); post-NMS top-k is taken on the GPU
 (no `.cpu()` kthvalue, centernet.py:727-731) with the same ">= k-th score" tie rule.
 """
+import os
+
 import torch
 import torch.distributed as dist
 from torch import nn
@@ -17,6 +19,8 @@ from ...layers import centernet_targets, nms, nms_batched_sorted
 from ...structures import Boxes, Instances
 from ...utils.comm import get_world_size
 from .centernet_head import CenterNetHead
+
+_FUSED_CN_LOSSES = os.environ.get("DGX_FUSED_CN_LOSSES", "1") == "1"      # A/B switch: dgx_centernet_losses
 
 INF = 100000000
 
@@ -167,7 +171,28 @@ class CenterNet(nn.Module):
             return torch.cat(out, dim=0).long(), torch.cat(keep, dim=0)
         return torch.cat(out, dim=0).long()
 
+    def _losses_fused(self, pos_inds, reg_targets, flattened_hms, reg_pred, agn_hm_pred):
+        """`losses` through libdgx's dgx_centernet_losses: raw sums + unscaled gradients from one pass; the normalisers
+        (all-reduced across ranks unless NO_REDUCE) and the three divisions stay here, on device scalars."""
+        world = get_world_size()
+        idx, cared = pos_inds if isinstance(pos_inds, tuple) else (pos_inds, None)
+        alpha = self.hm_focal_alpha
+        loc_num, pos, neg, s, npos = _CenterNetLosses.apply(
+            reg_pred, agn_hm_pred, reg_targets, flattened_hms, idx, cared, bool(self.not_norm_reg), float(self.hm_focal_beta),
+            float(self.loss_gamma), float(self.sigmoid_clamp), float(self.ignore_high_fp),
+            float(alpha) if alpha >= 0 else 1.0, float(1 - alpha) if alpha >= 0 else 1.0)
+        num_pos_local = npos.reshape(1)
+        total_num_pos = num_pos_local * world if self.no_reduce else reduce_sum(num_pos_local)
+        num_pos_avg = torch.clamp(total_num_pos / world, min=1.0)[0]
+        reg_norm = torch.clamp((s if self.no_reduce else reduce_sum(s)) / (1 if self.no_reduce else world), min=1.0)
+        return {"loss_centernet_loc": self.reg_weight * loc_num / reg_norm,
+                "loss_centernet_agn_pos": self.pos_weight * pos / num_pos_avg,
+                "loss_centernet_agn_neg": self.neg_weight * neg / num_pos_avg}
+
     def losses(self, pos_inds, reg_targets, flattened_hms, reg_pred, agn_hm_pred):
+        if (_FUSED_CN_LOSSES and reg_pred.is_cuda and reg_pred.dtype == torch.float32 and agn_hm_pred.dtype == torch.float32
+                and self.with_agn_hm and agn_hm_pred.dim() == 1):      # (__init__ only admits the giou loss)
+            return self._losses_fused(pos_inds, reg_targets, flattened_hms, reg_pred, agn_hm_pred)
         world = get_world_size()
         if isinstance(pos_inds, tuple):      # (indices, cared): fixed length, count stays on the device
             num_pos_local = pos_inds[1].sum().float().reshape(1)
@@ -264,6 +289,40 @@ class _HeadSegment(nn.Module):
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.amp, cache_enabled=False):
             _, reg, hm = self.head(list(feats))
         return tuple(reg) + tuple(hm)
+
+
+class _CenterNetLosses(torch.autograd.Function):
+    """(reg_pred, logit) -> (weighted GIoU sum, pos loss, neg loss | sum of weights, #positives): dgx_centernet_losses."""
+
+    @staticmethod
+    def forward(ctx, reg_pred, logit, reg_targets, hms, idx, cared, not_norm_reg, beta, gamma, clampv, ihf, pos_mul, neg_mul):
+        from ... import _lib as L
+        reg_pred, logit = reg_pred.contiguous(), logit.contiguous()
+        reg_targets, hms = reg_targets.float().contiguous(), hms.float().contiguous()
+        M, C, P = reg_pred.shape[0], hms.shape[1] if hms.dim() > 1 else 1, idx.numel()
+        idx = idx.contiguous()
+        cared_u8 = cared.to(torch.uint8).contiguous() if cared is not None else None
+        dev = reg_pred.device
+        g_reg = torch.empty(M, 4, dtype=torch.float32, device=dev)
+        g_neg = torch.empty(M, dtype=torch.float32, device=dev)
+        g_pos = torch.empty(M, dtype=torch.float32, device=dev)
+        out = torch.empty(8, dtype=torch.float32, device=dev)
+        part = torch.empty(3 * L.lib().dgx_centernet_losses_blocks(M), dtype=torch.float32, device=dev)
+        L.check(L.lib().dgx_centernet_losses(L.ptr(reg_pred), L.ptr(reg_targets), L.ptr(hms), L.ptr(logit), L.ptr(idx) if P else None,
+                                             L.ptr(cared_u8), M, C, P, int(not_norm_reg), beta, gamma, clampv, ihf, pos_mul, neg_mul,
+                                             L.ptr(g_reg), L.ptr(g_neg), L.ptr(g_pos), L.ptr(out), L.ptr(part), L.stream()),
+                "dgx_centernet_losses")
+        ctx.save_for_backward(g_reg, g_neg, g_pos)
+        s_w, n_pos = out[0], out[4]
+        ctx.mark_non_differentiable(s_w, n_pos)
+        return out[1], out[3], out[2], s_w, n_pos
+
+    @staticmethod
+    def backward(ctx, d_loc, d_pos, d_neg, _s, _n):
+        g_reg, g_neg, g_pos = ctx.saved_tensors
+        d_reg = g_reg * d_loc
+        d_logit = torch.addcmul(g_neg * d_neg, g_pos, d_pos)
+        return (d_reg, d_logit) + (None,) * 11
 
 
 def _giou(pred, target):

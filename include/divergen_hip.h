@@ -339,6 +339,21 @@ int dgx_gelu_bwd_colsum(const void* dy, const void* x, void* dx, float* bias_gra
                         void* workspace, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * CenterNet proposal losses (centernet/modeling/dense_heads/centernet.py:237-314 `losses`; layers/iou_loss.py:10-63 'giou';
+ * layers/heatmap_focal_loss.py:51-85).  reg_pred, reg_targets f32 (M,4); hms f32 (M,C) (peak = max over C);
+ * logit f32 (M) agnostic heat-map logits; pos_idx i64 (P) locations of the positives, pos_cared u8 (P) or NULL (all).
+ * Returns RAW sums in out8 = {sum of regression weights, weighted GIoU sum, neg loss, pos loss, #positives, -, -, -}
+ * (pos/neg already multiplied by pos_mul / neg_mul = alpha / 1-alpha) -- the caller all-reduces the normalisers
+ * (:243-262) -- and UNSCALED gradients: g_reg (M,4) = d(weighted GIoU sum)/d reg_pred, g_neg (M) = d neg / d logit,
+ * g_pos (M) = d pos / d logit (scatter-added; cleared by the call).  part: f32 scratch 3*dgx_centernet_losses_blocks(M). */
+int dgx_centernet_losses_blocks(int M);
+int dgx_centernet_losses(const float* reg_pred, const float* reg_targets, const float* hms, const float* logit,
+                         const int64_t* pos_idx, const uint8_t* pos_cared, int M, int C, int P, int not_norm_reg,
+                         float beta, float gamma, float sigmoid_clamp, float ignore_high_fp, float pos_mul,
+                         float neg_mul, float* g_reg, float* g_neg, float* g_pos, float* out8, float* part,
+                         void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Evaluation post-processing.  paste_masks_in_image (D2/layers/mask_ops.py:17-150; called from
  * custom_rcnn.py:265-332 detector_postprocess): the SxS mask probabilities of detection n are sampled bilinearly
  * (F.grid_sample, align_corners=False, zero padding) at every image pixel through its box and thresholded.

@@ -355,3 +355,39 @@ def test_cascade_refine_equals_composed_ops():
         nfg += int(((mlab == 1) & ok).sum())
         r0 += n
     assert int(out["nfg"]) == nfg and int((~out["valid"].bool()).sum()) > 0
+
+
+@pytest.mark.parametrize("not_norm_reg,alpha,ihf,cared_all", [(True, 0.25, 0.85, False), (False, -1.0, 0.0, True), (False, 0.25, 0.85, False)])
+def test_fused_centernet_losses_vs_torch_formulation(not_norm_reg, alpha, ihf, cared_all, monkeypatch):
+    """dgx_centernet_losses vs the elementwise torch formulation of centernet.py:237-314 (values and gradients), incl.
+    rows without a regression target, duplicate positive indices and un-cared positives."""
+    import divergen_amd.modeling.dense_heads.centernet as CM
+    from divergen_amd.utils.events import EventStorage
+    g = torch.Generator().manual_seed(5)
+    M, P = 5000, 37
+    net = CM.CenterNet(in_channels=16, num_classes=7, with_agn_hm=True, only_proposal=True, reg_weight=2.0,
+                       not_norm_reg=not_norm_reg, pos_weight=0.5, neg_weight=0.75, ignore_high_fp=ihf, hm_focal_alpha=alpha,
+                       centernet_head=torch.nn.Identity()).to(DEV).train()
+    reg_t = torch.rand(M, 4, generator=g) * 40
+    reg_t[torch.rand(M, generator=g) < 0.7] = -1e8                       # INF-style "no target" rows
+    reg_t[3] = torch.tensor([5.0, 5.0, 5.0, 5.0])
+    hm = torch.rand(M, 1, generator=g) ** 3
+    rp0 = torch.rand(M, 4, generator=g) * 40
+    rp0[3] = torch.tensor([5.0, 7.0, 5.0, 2.0])                          # ties with the target: split gradient
+    al0 = torch.randn(M, generator=g) * 4                                # includes logits clamped by SIGMOID_CLAMP
+    idx = torch.randint(0, M, (P,), generator=g)
+    idx[1] = idx[0]                                                      # duplicate positive location
+    cared = torch.ones(P, dtype=torch.bool) if cared_all else torch.rand(P, generator=g) < 0.8
+    res = []
+    for fused in (True, False):
+        monkeypatch.setattr(CM, "_FUSED_CN_LOSSES", fused)
+        rp, al = rp0.clone().to(DEV).requires_grad_(), al0.clone().to(DEV).requires_grad_()
+        with EventStorage(0):
+            losses = net.losses((idx.to(DEV), cared.to(DEV)), reg_t.to(DEV), hm.to(DEV), rp, al)
+        (losses["loss_centernet_loc"] * 1.3 + losses["loss_centernet_agn_pos"] * 0.7 + losses["loss_centernet_agn_neg"] * 1.9).backward()
+        res.append(({k: float(v) for k, v in losses.items()}, rp.grad.clone(), al.grad.clone()))
+    (lf, grf, gaf), (lt, grt, gat) = res
+    for k in lt:
+        assert abs(lf[k] - lt[k]) <= 1e-5 * max(1.0, abs(lt[k])), (k, lf[k], lt[k])
+    torch.testing.assert_close(grf, grt, atol=1e-7, rtol=2e-4)
+    torch.testing.assert_close(gaf, gat, atol=1e-7, rtol=2e-4)

@@ -123,6 +123,13 @@ class CenterNet(nn.Module):
         return reg, hm
 
     def compute_grids(self, features):
+        key = tuple((int(f.shape[-2]), int(f.shape[-1]), str(f.device)) for f in features)
+        cache = self.__dict__.setdefault("_grid_cache", {})
+        if key not in cache:       # geometry constants: built once per feature-map signature
+            cache[key] = self._compute_grids(features)
+        return cache[key]
+
+    def _compute_grids(self, features):
         grids = []
         for level, f in enumerate(features):
             h, w = f.shape[-2:]
@@ -223,23 +230,44 @@ class CenterNet(nn.Module):
         pre_topk = self.pre_nms_topk_train if self.training else self.pre_nms_topk_test
         post_topk = self.post_nms_topk_train if self.training else self.post_nms_topk_test
         thr_nms = self.nms_thresh_train if self.training else self.nms_thresh_test
-        per_img = [[] for _ in range(B)]
-        for l in range(len(grids)):
-            hm = hms[l].reshape(B, -1)                                           # (B, HW), C == 1
-            reg = (reg_pred[l] * self.strides[l]).permute(0, 2, 3, 1).reshape(B, -1, 4)
-            k = min(pre_topk, hm.shape[1])
-            vals, idx = torch.where(hm > self.score_thresh, hm, hm.new_full((), -1.0)).topk(k, dim=1)
-            g = grids[l][idx]                                                    # (B,k,2)
-            r = torch.gather(reg, 1, idx[:, :, None].expand(-1, -1, 4))
-            det = torch.stack([g[..., 0] - r[..., 0], g[..., 1] - r[..., 1], g[..., 0] + r[..., 2], g[..., 1] + r[..., 3]], -1)
-            det[..., 2] = torch.max(det[..., 2], det[..., 0] + 0.01)
-            det[..., 3] = torch.max(det[..., 3], det[..., 1] + 0.01)
-            for i in range(B):
-                per_img[i].append((det[i], vals[i]))
-        # Fixed-shape, sync-free from here: every image keeps its K = sum_l k_l candidates; the ones at or below
-        # the score threshold sort to the end and the device-side count tells the NMS kernel where to stop.
-        boxes = torch.stack([torch.cat([d for d, _ in per_img[i]]) for i in range(B)])          # (B,K,4)
-        sc = torch.stack([torch.cat([v for _, v in per_img[i]]) for i in range(B)])             # (B,K)
+        # All levels decoded together (the reference loops over levels, centernet.py:640-688): per-level top-k only where a
+        # level has more locations than PRE_NMS_TOPK (its other levels keep every location), then ONE gather of the grid
+        # centres / strides / regression rows over the concatenated candidate list and ONE box decode.
+        sizes = [int(h.shape[2] * h.shape[3]) for h in hms]
+        key = (tuple(sizes), B, pre_topk, str(hms[0].device))
+        cache = self.__dict__.setdefault("_decode_consts", {})
+        if key not in cache:
+            offs, tot = [], 0
+            for n in sizes:
+                offs.append(tot)
+                tot += n
+            grid_all = torch.cat(grids, 0)                                              # (M,2)
+            stride_all = torch.cat([grids[l].new_full((sizes[l],), float(self.strides[l])) for l in range(len(sizes))])
+            small = [torch.arange(offs[l], offs[l] + sizes[l], device=grid_all.device) for l in range(len(sizes))
+                     if sizes[l] <= pre_topk]
+            small_idx = torch.cat(small)[None].expand(B, -1).contiguous() if small else None
+            cache[key] = (offs, grid_all, stride_all, small_idx)
+        offs, grid_all, stride_all, small_idx = cache[key]
+        hm_all = torch.cat([h.reshape(B, -1) for h in hms], 1)                            # (B,M), C == 1
+        reg_all = torch.cat([r.permute(0, 2, 3, 1).reshape(B, -1, 4) for r in reg_pred], 1)   # (B,M,4)
+        hm_all = torch.where(hm_all > self.score_thresh, hm_all, hm_all.new_full((), -1.0))
+        idx_parts, val_parts = [], []
+        for l, n in enumerate(sizes):
+            if n > pre_topk:
+                v, i = hm_all[:, offs[l]:offs[l] + n].topk(pre_topk, dim=1)
+                idx_parts.append(i + offs[l])
+                val_parts.append(v)
+        if small_idx is not None:
+            idx_parts.append(small_idx)
+            val_parts.append(torch.gather(hm_all, 1, small_idx))
+        idx = torch.cat(idx_parts, 1)                                                     # (B,K)
+        sc = torch.cat(val_parts, 1)
+        g = grid_all[idx]                                                                 # (B,K,2)
+        r = torch.gather(reg_all, 1, idx[:, :, None].expand(-1, -1, 4)) * stride_all[idx][:, :, None]
+        x0, y0 = g[..., 0] - r[..., 0], g[..., 1] - r[..., 1]
+        boxes = torch.stack([x0, y0, torch.max(g[..., 0] + r[..., 2], x0 + 0.01), torch.max(g[..., 1] + r[..., 3], y0 + 0.01)], -1)
+        # Fixed-shape, sync-free from here: every image keeps its K candidates; the ones at or below the score threshold
+        # sort to the end and the device-side count tells the NMS kernel where to stop.
         ok = sc > self.score_thresh
         n_valid = ok.sum(1).to(torch.int32)
         sc = torch.where(ok, torch.sqrt(sc.clamp(min=0)), sc.new_full((), -1.0))

@@ -42,6 +42,9 @@ def get_fed_loss_inds(gt_classes, num_sample_cats, C, weight=None):
     return appeared
 
 
+_FED_CONSTS = {}
+
+
 def fed_loss_class_mask(gt_classes, num_sample_cats, C, weight):
     """get_fed_loss_inds (DG/divergen/modeling/utils.py:16-28) as a (C+1,) 0/1 mask, without reading anything back
     to the host: the classes that appear, plus -- when fewer than num_sample_cats appear -- classes drawn without
@@ -51,15 +54,21 @@ def fed_loss_class_mask(gt_classes, num_sample_cats, C, weight):
     same generator state (when n_appeared >= num_sample_cats the reference draws nothing: the streams then differ)."""
     app = torch.zeros(C + 1, dtype=torch.bool, device=gt_classes.device)
     app.index_fill_(0, gt_classes, True)        # (in-place index ops with Python scalars upload the scalar: avoided)
-    prob = torch.ones(C + 1, dtype=torch.float32, device=gt_classes.device) if weight is None else \
-        torch.cat([weight.float(), weight.new_zeros(1).float()])
-    prob[C:].zero_()
-    prob = prob.masked_fill(app, 0)
-    q = prob / torch.empty_like(prob).exponential_(1)
     k = min(num_sample_cats, C + 1)
+    key = (C, k, str(gt_classes.device), None if weight is None else (weight.data_ptr(), weight._version))
+    if key not in _FED_CONSTS:       # the sampling weights and the rank ramp do not change between calls
+        prob0 = torch.ones(C + 1, dtype=torch.float32, device=gt_classes.device) if weight is None else \
+            torch.cat([weight.float(), weight.new_zeros(1).float()])
+        prob0[C:].zero_()
+        if len(_FED_CONSTS) > 16:
+            _FED_CONSTS.clear()
+        _FED_CONSTS[key] = (prob0, torch.arange(k, device=gt_classes.device))
+    prob0, ramp = _FED_CONSTS[key]
+    prob = prob0.masked_fill(app, 0)
+    q = prob / torch.empty_like(prob).exponential_(1)
     vals, idx = torch.topk(q, k)
     need = num_sample_cats - app.sum()                       # device scalar
-    take = (torch.arange(k, device=q.device) < need) & (vals > 0)
+    take = (ramp < need) & (vals > 0)
     return app.index_put((idx,), app[idx] | take)
 
 

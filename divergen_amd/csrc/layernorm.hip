@@ -61,9 +61,9 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-template <typename XT>
+template <typename XT, typename YT = uint16_t>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const XT* __restrict__ x, const float* __restrict__ gamma,
-                                                     const float* __restrict__ beta, uint16_t* __restrict__ y,
+                                                     const float* __restrict__ beta, YT* __restrict__ y,
                                                      float* __restrict__ mean, float* __restrict__ rstd, int64_t T_out,
                                                      int C, float eps, WinMap m) {
     const int lane = threadIdx.x & 63;
@@ -71,9 +71,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const XT* __restrict__ x, c
     const int64_t nwaves = (int64_t)gridDim.x * 4;
     for (int64_t orow = wave; orow < T_out; orow += nwaves) {
         const int64_t tok = m.ws ? win_src(m, orow) : orow;
-        uint2* yo = reinterpret_cast<uint2*>(y + orow * C);
+        YT* yo = y + orow * C;
         if (tok < 0) {
-            for (int i = lane; i < C / 4; i += 64) yo[i] = make_uint2(0u, 0u);
+            for (int i = lane; i < C / 4; i += 64) st4<YT>(yo, i, make_float4(0.f, 0.f, 0.f, 0.f));
             continue;
         }
         const XT* xr = x + tok * C;
@@ -92,15 +92,15 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const XT* __restrict__ x, c
         const float4* b4 = reinterpret_cast<const float4*>(beta);
         for (int i = lane; i < C / 4; i += 64) {
             const float4 v = ld4<XT>(xr, i), g = g4[i], b = b4[i];
-            yo[i] = make_uint2(pack_bf2((v.x - mu) * rs * g.x + b.x, (v.y - mu) * rs * g.y + b.y),
-                               pack_bf2((v.z - mu) * rs * g.z + b.z, (v.w - mu) * rs * g.w + b.w));
+            st4<YT>(yo, i, make_float4((v.x - mu) * rs * g.x + b.x, (v.y - mu) * rs * g.y + b.y,
+                                       (v.z - mu) * rs * g.z + b.z, (v.w - mu) * rs * g.w + b.w));
         }
     }
 }
 
 // NJ = ceil(C/256): float4 columns per lane
-template <int NJ, typename XT>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const uint16_t* __restrict__ dy, const XT* __restrict__ x,
+template <int NJ, typename XT, typename DT = uint16_t>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const DT* __restrict__ dy, const XT* __restrict__ x,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, const XT* dres, XT* dx,
                                                      float* __restrict__ part, int64_t T, int C, WinMap m) {
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const uint16_t* __restrict_
     const float4* g4 = reinterpret_cast<const float4*>(gamma);
     for (int64_t tok = wave; tok < T; tok += nwaves) {
         const int64_t drow = m.ws ? win_dst(m, tok) : tok;
-        const uint2* dyr = reinterpret_cast<const uint2*>(dy + drow * C);
+        const DT* dyr = dy + drow * C;
         const XT* xr = x + tok * C;
         const float mu = mean[tok], rs = rstd[tok];
         float xh[NJ][4], gv[NJ][4];
@@ -126,9 +126,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const uint16_t* __restrict_
             const int i = lane + 64 * j;
             if (i < C / 4) {
                 const float4 v = ld4<XT>(xr, i), g = g4[i];
-                const uint2 d = dyr[i];
-                const float dv[4] = {__uint_as_float(d.x << 16), __uint_as_float(d.x & 0xffff0000u),
-                                     __uint_as_float(d.y << 16), __uint_as_float(d.y & 0xffff0000u)};
+                const float4 d4 = ld4<DT>(dyr, i);
+                const float dv[4] = {d4.x, d4.y, d4.z, d4.w};
                 const float xv[4] = {v.x, v.y, v.z, v.w}, gg[4] = {g.x, g.y, g.z, g.w};
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -438,6 +437,52 @@ extern "C" int dgx_patch_merge_ln_bwd(const void* dy_bf16, const void* x, const 
     else if (nj <= 6) PM_BWD(6);
     else PM_BWD(12);
 #undef PM_BWD
+    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * C / 4 + 63) / 64), dim3(1024), 0, st, part, dgamma, dbeta, grid, C);
+    DGX_LAUNCH_CHECK();
+    return DGX_OK;
+}
+
+
+// LayerNorm with an fp32 result (PatchEmbed.norm, swintransformer.py:440-442: under autocast the reference's LayerNorm
+// returns fp32 and that tensor IS the stage-0 residual stream).  x f32|bf16 (T,C) -> y f32; backward takes dy f32.
+extern "C" int dgx_layernorm_f32out_fwd(const void* x, const float* gamma, const float* beta, float* y, float* mean,
+                                        float* rstd, int64_t T, int C, float eps, int x_dtype, void* stream) {
+    if (T <= 0) return DGX_OK;
+    if (!x || !gamma || !beta || !y || !mean || !rstd || (C & 3)) return DGX_ERR_BAD_ARG;
+    const WinMap m = make_map(0, 0, 0, 0, 0);
+    const int grid = (int)((T + 3) / 4 < 8192 ? (T + 3) / 4 : 8192);
+    if (x_dtype == DGX_BF16)
+        hipLaunchKernelGGL((ln_fwd_kernel<uint16_t, float>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x,
+                           gamma, beta, y, mean, rstd, T, C, eps, m);
+    else
+        hipLaunchKernelGGL((ln_fwd_kernel<float, float>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)x, gamma,
+                           beta, y, mean, rstd, T, C, eps, m);
+    DGX_LAUNCH_CHECK();
+    return DGX_OK;
+}
+
+extern "C" int dgx_layernorm_f32out_bwd(const float* dy, const void* x, const float* mean, const float* rstd,
+                                        const float* gamma, void* dx, float* dgamma, float* dbeta, float* part, int64_t T,
+                                        int C, int x_dtype, void* stream) {
+    if (T <= 0) return DGX_OK;
+    if (!dy || !x || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta || !part || (C & 3) || C > 768) return DGX_ERR_BAD_ARG;
+    const WinMap m = make_map(0, 0, 0, 0, 0);
+    const int grid = dgx_layernorm_bwd_blocks(T);
+    hipStream_t st = (hipStream_t)stream;
+    const int nj = (C + 255) / 256;
+#define LNF_BWD(NJ)                                                                                                        \
+    do {                                                                                                                   \
+        if (x_dtype == DGX_BF16)                                                                                           \
+            hipLaunchKernelGGL((ln_bwd_kernel<NJ, uint16_t, float>), dim3(grid), dim3(256), 0, st, dy, (const uint16_t*)x,  \
+                               mean, rstd, gamma, (const uint16_t*)nullptr, (uint16_t*)dx, part, T, C, m);                  \
+        else                                                                                                               \
+            hipLaunchKernelGGL((ln_bwd_kernel<NJ, float, float>), dim3(grid), dim3(256), 0, st, dy, (const float*)x, mean,  \
+                               rstd, gamma, (const float*)nullptr, (float*)dx, part, T, C, m);                              \
+    } while (0)
+    if (nj <= 1) LNF_BWD(1);
+    else if (nj <= 2) LNF_BWD(2);
+    else LNF_BWD(3);
+#undef LNF_BWD
     hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * C / 4 + 63) / 64), dim3(1024), 0, st, part, dgamma, dbeta, grid, C);
     DGX_LAUNCH_CHECK();
     return DGX_OK;

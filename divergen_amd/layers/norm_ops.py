@@ -49,6 +49,49 @@ class _LayerNormBF16(torch.autograd.Function):
         return dx, dg.to(weight.dtype), db.to(bias.dtype), None, None, None, None, None, None
 
 
+class _LayerNormF32Out(torch.autograd.Function):
+    """LayerNorm with an fp32 result (PatchEmbed.norm under autocast): x f32|bf16 -> y f32."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        x = x.contiguous()
+        C = x.shape[-1]
+        T = x.numel() // C
+        y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+        mean = torch.empty(T, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(T, dtype=torch.float32, device=x.device)
+        L.check(L.lib().dgx_layernorm_f32out_fwd(L.ptr(x), L.ptr(weight), L.ptr(bias), L.ptr(y), L.ptr(mean), L.ptr(rstd), T, C,
+                                                 float(eps), L.dtype_code(x), L.stream()), "dgx_layernorm_f32out_fwd")
+        ctx.save_for_backward(x, mean, rstd)
+        ctx.weight, ctx.bias, ctx.cfg = weight, bias, (T, C)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, rstd = ctx.saved_tensors
+        weight, bias = ctx.weight, ctx.bias
+        T, C = ctx.cfg
+        dy = dy.float().contiguous()
+        dx = torch.empty_like(x)
+        part = torch.empty(L.lib().dgx_layernorm_bwd_blocks(T) * 2 * C, dtype=torch.float32, device=x.device)
+        in_arena = (weight.is_leaf and bias.is_leaf and weight.grad is not None and bias.grad is not None
+                    and getattr(weight, "_dgx16", None) is not None and getattr(bias, "_dgx16", None) is not None)
+        dg = weight.grad if in_arena else torch.zeros(C, dtype=torch.float32, device=x.device)
+        db = bias.grad if in_arena else torch.zeros(C, dtype=torch.float32, device=x.device)
+        L.check(L.lib().dgx_layernorm_f32out_bwd(L.ptr(dy), L.ptr(x), L.ptr(mean), L.ptr(rstd), L.ptr(weight), L.ptr(dx), L.ptr(dg),
+                                                 L.ptr(db), L.ptr(part), T, C, L.dtype_code(x), L.stream()), "dgx_layernorm_f32out_bwd")
+        if in_arena:
+            for p in (weight, bias):
+                notify_ready(p)
+            return dx, None, None, None
+        return dx, dg.to(weight.dtype), db.to(bias.dtype), None
+
+
+def layernorm_f32out(x, weight, bias, eps=1e-5):
+    """f32|bf16 (..., C) -> LayerNorm -> f32 (..., C)."""
+    return _LayerNormF32Out.apply(x, weight, bias, eps)
+
+
 class _PatchMergeLN(torch.autograd.Function):
     """PatchMerging's pad + 2x2 gather + LayerNorm(4C) (swintransformer.py:272-298) as one kernel each way."""
 

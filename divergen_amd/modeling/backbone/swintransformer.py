@@ -20,7 +20,7 @@ import torch.nn.functional as F
 from .. import BACKBONE_REGISTRY, ShapeSpec
 from ...layers.conv_ops import patch_embed4x4
 from ...layers.linear_ops import Linear
-from ...layers.norm_ops import layernorm_bf16, layernorm_window_gather, patch_merge_layernorm, residual_add
+from ...layers.norm_ops import layernorm_bf16, layernorm_f32out, layernorm_window_gather, patch_merge_layernorm, residual_add
 from ...layers import shift_regions, window_attention_core, window_gather, window_scatter
 from ...layers.swin_block import arena_resident, swin_block
 
@@ -212,7 +212,11 @@ class PatchEmbed(nn.Module):
             x = F.pad(x, (0, 0, 0, p - H % p))
         x, Wh, Ww = patch_embed4x4(x, self.proj.weight, self.proj.bias, p)
         if self.norm is not None:
-            x = self.norm(x)
+            if _FUSED_MERGE and torch.is_autocast_enabled() and x.is_cuda and self.embed_dim % 4 == 0 and self.embed_dim <= 768 \
+                    and x.dtype in (torch.float32, torch.bfloat16):
+                x = layernorm_f32out(x, self.norm.weight, self.norm.bias, self.norm.eps)     # fp32 out, as autocast's LayerNorm
+            else:
+                x = self.norm(x)
         return x, Wh, Ww
 
 

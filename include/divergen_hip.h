@@ -229,6 +229,14 @@ int dgx_layernorm_bwd_blocks(int64_t T);
 int dgx_layernorm_bwd(const void* dy_bf16, const void* x, const float* mean, const float* rstd,
                       const float* gamma, const void* dres, void* dx, float* dgamma, float* dbeta, float* part,
                       int64_t T, int C, int B, int H, int W, int ws, int shift, int x_dtype, void* stream);
+/* LayerNorm with an fp32 result (PatchEmbed.norm, swintransformer.py:440-442; under autocast nn.LayerNorm returns fp32
+ * and that tensor is the stage-0 residual stream).  x f32|bf16 (T,C) -> y f32 (T,C); backward: dy f32, dx in x's dtype,
+ * ADDS into dgamma / dbeta; part as for dgx_layernorm_bwd.  C % 4 == 0, C <= 768 for backward. */
+int dgx_layernorm_f32out_fwd(const void* x, const float* gamma, const float* beta, float* y, float* mean,
+                             float* rstd, int64_t T, int C, float eps, int x_dtype, void* stream);
+int dgx_layernorm_f32out_bwd(const float* dy, const void* x, const float* mean, const float* rstd,
+                             const float* gamma, void* dx, float* dgamma, float* dbeta, float* part, int64_t T,
+                             int C, int x_dtype, void* stream);
 /* PatchMerging front half (swintransformer.py:272-298: pad to even H/W, x0|x1|x2|x3 concatenation of the 2x2
  * neighbourhood, LayerNorm(4*C0)) in one pass.  x (B,H,W,C0) f32|bf16 -> y bf16 (B*H2*W2, 4*C0), H2 = ceil(H/2);
  * mean, rstd f32 (B*H2*W2).  Backward writes dx (B,H,W,C0) in x's dtype, every element once, and ADDS into

@@ -614,3 +614,27 @@ def test_patch_merge_layernorm_vs_reference_formulation(B, H, W, C0, dt):
     assert torch.allclose(got[1], x2.grad, atol=tol, rtol=tol), float((got[1] - x2.grad).abs().max())
     assert torch.allclose(got[2], w2.grad, atol=2e-3 * max(1.0, float(w2.grad.abs().max())), rtol=1e-3)
     assert torch.allclose(got[3], b2.grad, atol=1e-3 * max(1.0, float(b2.grad.abs().max())), rtol=1e-3)
+
+
+@pytest.mark.parametrize("T,C,dt", [(37, 96, torch.bfloat16), (1000, 192, torch.bfloat16), (64, 128, torch.float32), (5, 768, torch.bfloat16)])
+def test_layernorm_f32out_vs_torch(T, C, dt):
+    """PatchEmbed.norm under autocast: LayerNorm of a bf16 (or f32) input with an fp32 result, values and gradients."""
+    import torch.nn.functional as F
+    from divergen_amd.layers.norm_ops import layernorm_f32out
+    g = torch.Generator().manual_seed(T + C)
+    x = (torch.randn(2, T, C, generator=g) * 2 + 0.5).to(dt).to(DEV).requires_grad_()
+    w = (torch.rand(C, generator=g) + 0.5).to(DEV).requires_grad_()
+    b = torch.randn(C, generator=g).to(DEV).requires_grad_()
+    y = layernorm_f32out(x, w, b, 1e-5)
+    assert y.dtype == torch.float32
+    dy = torch.randn(y.shape, generator=g).to(DEV)
+    y.backward(dy)
+    x2 = x.detach().float().requires_grad_()
+    w2, b2 = w.detach().clone().requires_grad_(), b.detach().clone().requires_grad_()
+    ref = F.layer_norm(x2, (C,), w2, b2, 1e-5)
+    ref.backward(dy)
+    torch.testing.assert_close(y, ref, atol=2e-5, rtol=2e-5)
+    tol = 2e-2 if dt == torch.bfloat16 else 2e-4                       # dx is stored in x's dtype
+    torch.testing.assert_close(x.grad.float(), x2.grad, atol=tol, rtol=tol)
+    torch.testing.assert_close(w.grad, w2.grad, atol=2e-3, rtol=1e-3)
+    torch.testing.assert_close(b.grad, b2.grad, atol=2e-3, rtol=1e-3)

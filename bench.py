@@ -252,7 +252,7 @@ def main():
                 by += 2.0 * p.M * (p.Nn + p.Kk) + 8.0 * p.Nn * p.Kk      # dY, X read once (bf16); fp32 gradient read + written
             return fl, by
         if name.endswith("fwd"):
-            B_, nH, ws, mm, io = args[5], args[7], args[8], 2, 4            # QK^T, PV;  q,k,v in + out
+            B_, nH, ws, mm, io = args[7], args[9], args[10], 2, 4            # QK^T, PV;  q,k,v in + out
         else:
             B_, nH, ws, mm, io = args[10], args[12], args[13], 5, 8         # S, dP, dV, dK, dQ;  q,k,v,o,do in + dq,dk,dv out
         N = ws * ws

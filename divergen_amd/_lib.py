@@ -29,7 +29,7 @@ class ColsumProblem(ctypes.Structure):
 SIGNATURES = {
     "dgx_build_arch": (ctypes.c_char_p, []),
     "dgx_abi_version": (c_i, []),
-    "dgx_window_attention_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p]),
+    "dgx_window_attention_fwd": (c_i, [c_p, c_p, c_i64, c_i64, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p]),
     "dgx_window_attention_bwd": (c_i, [c_p] * 8 + [c_i64, c_i64, c_i, c_i, c_i, c_i, c_f, c_p]),
     "dgx_window_gather": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "dgx_window_scatter": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),

@@ -74,7 +74,7 @@ __device__ __forceinline__ void block_to_window_head(int bid, int nH, int& b, in
 template <int WS, bool MASKED>
 __global__ __launch_bounds__(WinCfg<WS>::NT * 64) void win_attn_fwd_kernel(
     const uint16_t* __restrict__ qkv, const float* __restrict__ table, const int8_t* __restrict__ region,
-    uint16_t* __restrict__ out, float* __restrict__ lse, int B_, int nW, int nH, float scale) {
+    uint16_t* __restrict__ out, float* __restrict__ lse, int B_, int nW, int nH, float scale, int64_t t_sh, int64_t t_si) {
     using Cf = WinCfg<WS>;
     constexpr int N = Cf::N, NT = Cf::NT, NTK = Cf::NTK, NP = NTK * 16, RS = Cf::RS, TBL = Cf::TBL;
     constexpr int RR = 40;   // row stride (elements) of the row-major V image
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(WinCfg<WS>::NT * 64) void win_attn_fwd_kernel(
     const int tid = threadIdx.x, nthreads = NT * 64;
 
     const int8_t* reg = region + (int64_t)(b % nW) * N;
-    for (int i = tid; i < TBL; i += nthreads) tbl[i] = table[h * TBL + i] * DGX_LOG2E;
+    for (int i = tid; i < TBL; i += nthreads) tbl[i] = table[h * t_sh + i * t_si] * DGX_LOG2E;
     for (int i = tid; i < NP; i += nthreads) {
         const int yk = i / WS;
         koff_s[i] = i < N ? yk * (2 * WS - 1) + (i - yk * WS) : 0;
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(WinCfg<WS>::NT * 64) void win_attn_bwd_kernel(
     };
 
     // ---- one-time LDS setup: bias row, zero padding rows/columns, rel-pos offsets
-    for (int i = tid; i < TBL; i += nthreads) { tbl[i] = table[h * TBL + i] * DGX_LOG2E; tblacc[i] = 0.f; }   // log2 domain
+    for (int i = tid; i < TBL; i += nthreads) { tbl[i] = table[h * dt_sh + i * dt_si] * DGX_LOG2E; tblacc[i] = 0.f; }   // log2 domain
     for (int i = tid; i < (NP - N) * RR; i += nthreads) { Qs[N * RR + i] = 0; dOs[N * RR + i] = 0; Ks[N * RR + i] = 0; }
     for (int i = tid; i < (NP - N) * RD; i += nthreads) dSt[N * RD + i] = 0;   // padded key rows feed the last K=32 step of dQ
     for (int i = tid; i < NP; i += nthreads) {
@@ -444,8 +444,9 @@ static const int8_t* zero_region() {
     return z;
 }
 
-extern "C" int dgx_window_attention_fwd(const void* qkv, const float* table, const int8_t* region, void* out,
-                                        float* lse, int B_, int nW, int nH, int ws, float scale, void* stream) {
+extern "C" int dgx_window_attention_fwd(const void* qkv, const float* table, int64_t table_stride_head,
+                                        int64_t table_stride_index, const int8_t* region, void* out, float* lse, int B_,
+                                        int nW, int nH, int ws, float scale, void* stream) {
     if (B_ <= 0) return DGX_OK;
     if (!qkv || !table || !out || !lse || nH <= 0 || nW <= 0 || (region && B_ % nW)) return DGX_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
@@ -453,7 +454,8 @@ extern "C" int dgx_window_attention_fwd(const void* qkv, const float* table, con
     if (!region) { region = zero_region(); nW = 1; if (!region) return DGX_ERR_BAD_ARG; }
     const int grid = ((B_ + 7) / 8) * 8 * nH;
 #define FWD_LAUNCH(WSV, MK) hipLaunchKernelGGL((win_attn_fwd_kernel<WSV, MK>), dim3(grid), dim3(WinCfg<WSV>::NT * 64), 0, st, \
-                                              (const uint16_t*)qkv, table, region, (uint16_t*)out, lse, B_, nW, nH, scale)
+                                              (const uint16_t*)qkv, table, region, (uint16_t*)out, lse, B_, nW, nH, scale, \
+                                              table_stride_head, table_stride_index)
     if (ws == 12) { if (masked) FWD_LAUNCH(12, true); else FWD_LAUNCH(12, false); }
     else if (ws == 7) { if (masked) FWD_LAUNCH(7, true); else FWD_LAUNCH(7, false); }
 #undef FWD_LAUNCH

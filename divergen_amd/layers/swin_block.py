@@ -77,11 +77,11 @@ class _SwinBlockFn(torch.autograd.Function):
         # attention
         qw16, pw16, w116, w216 = shadow(qw), shadow(pw), shadow(w1), shadow(w2)
         qkv = torch.addmm(shadow(qb), xw, qw16.t())
-        tableT = table.detach().t().contiguous()
+        tbl = table.detach()                       # ((2ws-1)^2, nH) as stored: the kernels take its strides
         o = torch.empty(Tw, C, dtype=BF16, device=dev)
         lse = torch.empty(B_, nH, N, dtype=f32, device=dev)
-        L.check(lib.dgx_window_attention_fwd(qkv.data_ptr(), tableT.data_ptr(), L.ptr(region), o.data_ptr(), lse.data_ptr(),
-                                             B_, nW, nH, ws, scale, st), "dgx_window_attention_fwd")
+        L.check(lib.dgx_window_attention_fwd(qkv.data_ptr(), tbl.data_ptr(), tbl.stride(1), tbl.stride(0), L.ptr(region),
+                                             o.data_ptr(), lse.data_ptr(), B_, nW, nH, ws, scale, st), "dgx_window_attention_fwd")
         pr = torch.addmm(shadow(pb), o, pw16.t())
         # reverse + roll + crop + DropPath + residual
         x1 = torch.empty_like(x)
@@ -100,7 +100,7 @@ class _SwinBlockFn(torch.autograd.Function):
         out = torch.empty_like(x)
         L.check(lib.dgx_residual_fwd(x1.data_ptr(), f2.data_ptr(), L.ptr(s2), out.data_ptr(), B, H, W, C, 0, 0, code, st),
                 "dgx_residual_fwd")
-        ctx.save_for_backward(x, mean1, rstd1, xw, qkv, tableT, region, o, lse, x1, mean2, rstd2, h2, f1, a, s1, s2,
+        ctx.save_for_backward(x, mean1, rstd1, xw, qkv, region, o, lse, x1, mean2, rstd2, h2, f1, a, s1, s2,
                               qw16, pw16, w116, w216)
         ctx.params = (n1w, n1b, qw, qb, table, pw, pb, n2w, n2b, w1, b1, w2, b2)
         ctx.cfg = cfg
@@ -108,7 +108,7 @@ class _SwinBlockFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        (x, mean1, rstd1, xw, qkv, tableT, region, o, lse, x1, mean2, rstd2, h2, f1, a, s1, s2,
+        (x, mean1, rstd1, xw, qkv, region, o, lse, x1, mean2, rstd2, h2, f1, a, s1, s2,
          qw16, pw16, w116, w216) = ctx.saved_tensors
         n1w, n1b, qw, qb, table, pw, pb, n2w, n2b, w1, b1, w2, b2 = ctx.params
         B, H, W, ws, shift, nH, scale, eps1, eps2 = ctx.cfg
@@ -145,9 +145,10 @@ class _SwinBlockFn(torch.autograd.Function):
                 "dgx_residual_bwd")
         do = _linear_bwd(dpr, o, pw, pb, pw16, wgrads)
         dqkv = torch.empty_like(qkv)
-        L.check(lib.dgx_window_attention_bwd(qkv.data_ptr(), tableT.data_ptr(), L.ptr(region), o.data_ptr(), lse.data_ptr(),
-                                             do.data_ptr(), dqkv.data_ptr(), table.grad.data_ptr(), 1, nH, B_, nW, nH, ws,
-                                             scale, st), "dgx_window_attention_bwd")
+        assert table.grad.stride() == table.stride()          # one pair of strides serves the table and its gradient
+        L.check(lib.dgx_window_attention_bwd(qkv.data_ptr(), table.data_ptr(), L.ptr(region), o.data_ptr(), lse.data_ptr(),
+                                             do.data_ptr(), dqkv.data_ptr(), table.grad.data_ptr(), table.stride(1), table.stride(0),
+                                             B_, nW, nH, ws, scale, st), "dgx_window_attention_bwd")
         _ready(table)
         dxw = _linear_bwd(dqkv, xw, qw, qb, qw16, wgrads)
         # LN1 backward through the window map, accumulated onto dx1 in place

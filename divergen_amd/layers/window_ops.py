@@ -36,7 +36,7 @@ class _WindowAttentionCore(torch.autograd.Function):
         table = table.float().t().contiguous()          # (nH, T): one contiguous row per head
         out = torch.empty(B_, N, nH * 32, dtype=torch.bfloat16, device=qkv.device)
         lse = torch.empty(B_, nH, N, dtype=torch.float32, device=qkv.device)
-        L.check(L.lib().dgx_window_attention_fwd(L.ptr(qkv), L.ptr(table), L.ptr(region), L.ptr(out), L.ptr(lse),
+        L.check(L.lib().dgx_window_attention_fwd(L.ptr(qkv), L.ptr(table), table.shape[1], 1, L.ptr(region), L.ptr(out), L.ptr(lse),
                                                  B_, nW, nH, ws, scale, L.stream()), "dgx_window_attention_fwd")
         ctx.save_for_backward(qkv, table, region, out, lse)
         ctx.cfg = (nW, nH, ws, scale)

@@ -40,7 +40,9 @@ int dgx_abi_version(void);
  * + shift mask, softmax (fp32), @v, head merge.   DG/divergen/modeling/backbone/swintransformer.py:133-154
  *
  *   qkv    bf16 (B_, N, 3, nH, 32)   output of the qkv Linear, N = ws*ws, head_dim fixed at 32
- *   table  f32  (nH, (2ws-1)^2)      relative_position_bias_table TRANSPOSED (one contiguous row per head)
+ *   table  f32                       relative_position_bias_table, entry (index i, head h) at
+ *                                    table[h*table_stride_head + i*table_stride_index]: the parameter itself,
+ *                                    ((2ws-1)^2, nH), is strides (1, nH); a per-head-contiguous copy is (T, 1)
  *   region i8   (nW, N) or NULL      region id of each token of each window position; the additive
  *                                    mask of swintransformer.py:368-387 is (region[i]!=region[j]) ? -100 : 0;
  *                                    B_ % nW == 0, window b uses row b % nW.  NULL = W-MSA (no mask)
@@ -48,14 +50,14 @@ int dgx_abi_version(void);
  *   lse    f32  (B_, nH, N)          log-sum-exp of each score row (saved for backward)
  * ws in {7, 12}.
  */
-int dgx_window_attention_fwd(const void* qkv, const float* table, const int8_t* region,
-                             void* out, float* lse, int B_, int nW, int nH, int ws, float scale,
-                             void* stream);
+int dgx_window_attention_fwd(const void* qkv, const float* table, int64_t table_stride_head,
+                             int64_t table_stride_index, const int8_t* region, void* out, float* lse, int B_,
+                             int nW, int nH, int ws, float scale, void* stream);
 
 /* Backward of the above.  dqkv bf16 (B_,N,3,nH,32) is fully overwritten; the bias-table gradient is
  * ACCUMULATED (atomic fp32 adds) into dtable[h*dtable_stride_head + i*dtable_stride_index], so the
  * caller can point it at the parameter's own (T, nH) gradient (strides 1, nH) or at a zeroed
- * (nH, T) scratch (strides T, 1).  `out`/`lse` are the forward results. */
+ * (nH, T) scratch (strides T, 1).  `table` is read with the SAME two strides.  `out`/`lse` are the forward results. */
 int dgx_window_attention_bwd(const void* qkv, const float* table, const int8_t* region,
                              const void* out, const float* lse, const void* dout,
                              void* dqkv, float* dtable, int64_t dtable_stride_head,

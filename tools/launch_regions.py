@@ -65,7 +65,7 @@ with EventStorage(0):
     for _ in range(3):
         step()
     torch.cuda.synchronize()
-    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
         step()
         torch.cuda.synchronize()
 evs = prof.events()
@@ -90,8 +90,9 @@ if len(sys.argv) > 1:          # op histogram inside one region, e.g.  python to
     for r in want:
         for o in ops:
             if o.thread == r.thread and r.time_range.start <= o.time_range.start <= r.time_range.end:
-                hist[o.name] += len(o.kernels)
-                tim[o.name] += sum(k.duration for k in o.kernels)
+                nm = o.name if len(sys.argv) < 3 or sys.argv[2] != o.name else o.name + " " + str(o.input_shapes)[:90]
+                hist[nm] += len(o.kernels)
+                tim[nm] += sum(k.duration for k in o.kernels)
     for k, v in hist.most_common(40):
         print("   %-40s %5d launches %9.3f ms" % (k, v, tim[k] / 1e3))
 allk = sum(len(o.kernels) for o in ops)

@@ -16,7 +16,7 @@ int main(int argc, char** argv) {
     hipMemset(table, 0, 529 * nH * 4); hipMemset(dtable, 0, 529 * nH * 4);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int it = 0; it < 3; ++it) {
-        dgx_window_attention_fwd(qkv, table, nullptr, out, lse, B_, 1, nH, 12, 0.17677f, nullptr);
+        dgx_window_attention_fwd(qkv, table, 529, 1, nullptr, out, lse, B_, 1, nH, 12, 0.17677f, nullptr);
         dgx_window_attention_bwd(qkv, table, nullptr, out, lse, dout, dqkv, dtable, 529, 1, B_, 1, nH, 12, 0.17677f, nullptr);
     }
     hipDeviceSynchronize();
@@ -25,7 +25,7 @@ int main(int argc, char** argv) {
 #endif
     const int iters = 10; float msf = 0, msb = 0, ms;
     for (int it = 0; it < iters; ++it) {
-        hipEventRecord(e0); dgx_window_attention_fwd(qkv, table, nullptr, out, lse, B_, 1, nH, 12, 0.17677f, nullptr);
+        hipEventRecord(e0); dgx_window_attention_fwd(qkv, table, 529, 1, nullptr, out, lse, B_, 1, nH, 12, 0.17677f, nullptr);
         hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1); msf += ms;
         hipEventRecord(e0); dgx_window_attention_bwd(qkv, table, nullptr, out, lse, dout, dqkv, dtable, 529, 1, B_, 1, nH, 12, 0.17677f, nullptr);
         hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1); msb += ms;

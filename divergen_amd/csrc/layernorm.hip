@@ -99,15 +99,16 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const XT* __restrict__ x, c
 }
 
 // NJ = ceil(C/256): float4 columns per lane
+constexpr int LNB_WAVES = 8;          // waves per backward workgroup: one partial row of (dgamma | dbeta) per workgroup
 template <int NJ, typename XT, typename DT = uint16_t>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const DT* __restrict__ dy, const XT* __restrict__ x,
+__global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const DT* __restrict__ dy, const XT* __restrict__ x,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, const XT* dres, XT* dx,
                                                      float* __restrict__ part, int64_t T, int C, WinMap m) {
     __shared__ float red[2][NJ * 256];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int64_t wave = (int64_t)blockIdx.x * 4 + w;
-    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    const int64_t wave = (int64_t)blockIdx.x * LNB_WAVES + w;
+    const int64_t nwaves = (int64_t)gridDim.x * LNB_WAVES;
     float dg[NJ][4], db[NJ][4];
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const DT* __restrict__ dy, 
         }
     }
     // block partials: the 4 waves fold into one LDS row in turn -> one row of `part` per block: [block][2][C]
-    for (int turn = 0; turn < 4; ++turn) {
+    for (int turn = 0; turn < LNB_WAVES; ++turn) {
         if (w == turn) {
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const DT* __restrict__ dy, 
         }
         __syncthreads();
     }
-    for (int c = threadIdx.x; c < C; c += 256) {
+    for (int c = threadIdx.x; c < C; c += 64 * LNB_WAVES) {
         part[((int64_t)blockIdx.x * 2 + 0) * C + c] = red[0][c];
         part[((int64_t)blockIdx.x * 2 + 1) * C + c] = red[1][c];
     }
@@ -232,8 +233,8 @@ extern "C" int dgx_layernorm_fwd(const void* x, const float* gamma, const float*
 }
 
 extern "C" int dgx_layernorm_bwd_blocks(int64_t T) {
-    int64_t b = (T + 3) / 4;
-    return (int)(b < 1024 ? (b < 1 ? 1 : b) : 1024);
+    int64_t b = (T + LNB_WAVES - 1) / LNB_WAVES;
+    return (int)(b < 512 ? (b < 1 ? 1 : b) : 512);
 }
 
 extern "C" int dgx_layernorm_bwd(const void* dy_bf16, const void* x, const float* mean, const float* rstd,
@@ -250,10 +251,10 @@ extern "C" int dgx_layernorm_bwd(const void* dy_bf16, const void* x, const float
 #define LN_BWD(NJ)                                                                                                         \
     do {                                                                                                                   \
         if (x_dtype == DGX_BF16)                                                                                           \
-            hipLaunchKernelGGL((ln_bwd_kernel<NJ, uint16_t>), dim3(grid), dim3(256), 0, st, (const uint16_t*)dy_bf16,       \
+            hipLaunchKernelGGL((ln_bwd_kernel<NJ, uint16_t>), dim3(grid), dim3(64 * LNB_WAVES), 0, st, (const uint16_t*)dy_bf16,       \
                                (const uint16_t*)x, mean, rstd, gamma, (const uint16_t*)dres, (uint16_t*)dx, part, T, C, m);                        \
         else                                                                                                               \
-            hipLaunchKernelGGL((ln_bwd_kernel<NJ, float>), dim3(grid), dim3(256), 0, st, (const uint16_t*)dy_bf16,          \
+            hipLaunchKernelGGL((ln_bwd_kernel<NJ, float>), dim3(grid), dim3(64 * LNB_WAVES), 0, st, (const uint16_t*)dy_bf16,          \
                                (const float*)x, mean, rstd, gamma, (const float*)dres, (float*)dx, part, T, C, m);                              \
     } while (0)
     if (nj <= 1) LN_BWD(1);
@@ -323,8 +324,9 @@ __global__ __launch_bounds__(256) void pm_ln_fwd_kernel(const XT* __restrict__ x
 }
 
 // NJ = ceil(4*C0/256) float4 columns per lane; same reduction layout as ln_bwd_kernel (part: [block][2][C])
-template <int NJ, typename XT>
-__global__ __launch_bounds__(256) void pm_ln_bwd_kernel(const uint16_t* __restrict__ dy, const XT* __restrict__ x,
+// WAVES: waves per workgroup (4 for the 3072-wide case, whose 200 live registers do not fit an 8-wave workgroup)
+template <int NJ, typename XT, int WAVES = LNB_WAVES>
+__global__ __launch_bounds__(64 * WAVES) void pm_ln_bwd_kernel(const uint16_t* __restrict__ dy, const XT* __restrict__ x,
                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
                                                         const float* __restrict__ gamma, XT* __restrict__ dx,
                                                         float* __restrict__ part, MergeMap m) {
@@ -332,7 +334,7 @@ __global__ __launch_bounds__(256) void pm_ln_bwd_kernel(const uint16_t* __restri
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int C = 4 * m.C0, q0 = m.C0 / 4;
     const int64_t T2 = (int64_t)m.B * m.H2 * m.W2;
-    const int64_t wave = (int64_t)blockIdx.x * 4 + w, nwaves = (int64_t)gridDim.x * 4;
+    const int64_t wave = (int64_t)blockIdx.x * WAVES + w, nwaves = (int64_t)gridDim.x * WAVES;
     float dg[NJ][4], db[NJ][4];
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
@@ -377,7 +379,7 @@ __global__ __launch_bounds__(256) void pm_ln_bwd_kernel(const uint16_t* __restri
                         make_float4(rs * (gv[j][0] - s1 - xh[j][0] * s2), rs * (gv[j][1] - s1 - xh[j][1] * s2),
                                     rs * (gv[j][2] - s1 - xh[j][2] * s2), rs * (gv[j][3] - s1 - xh[j][3] * s2)));
     }
-    for (int turn = 0; turn < 4; ++turn) {
+    for (int turn = 0; turn < WAVES; ++turn) {
         if (w == turn) {
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
@@ -390,7 +392,7 @@ __global__ __launch_bounds__(256) void pm_ln_bwd_kernel(const uint16_t* __restri
         }
         __syncthreads();
     }
-    for (int c = threadIdx.x; c < C; c += 256) {
+    for (int c = threadIdx.x; c < C; c += 64 * WAVES) {
         part[((int64_t)blockIdx.x * 2 + 0) * C + c] = red[0][c];
         part[((int64_t)blockIdx.x * 2 + 1) * C + c] = red[1][c];
     }
@@ -426,16 +428,21 @@ extern "C" int dgx_patch_merge_ln_bwd(const void* dy_bf16, const void* x, const 
 #define PM_BWD(NJ)                                                                                                          \
     do {                                                                                                                    \
         if (x_dtype == DGX_BF16)                                                                                            \
-            hipLaunchKernelGGL((pm_ln_bwd_kernel<NJ, uint16_t>), dim3(grid), dim3(256), 0, st, (const uint16_t*)dy_bf16,     \
+            hipLaunchKernelGGL((pm_ln_bwd_kernel<NJ, uint16_t>), dim3(grid), dim3(64 * LNB_WAVES), 0, st, (const uint16_t*)dy_bf16,     \
                                (const uint16_t*)x, mean, rstd, gamma, (uint16_t*)dx, part, m);                              \
         else                                                                                                                \
-            hipLaunchKernelGGL((pm_ln_bwd_kernel<NJ, float>), dim3(grid), dim3(256), 0, st, (const uint16_t*)dy_bf16,        \
+            hipLaunchKernelGGL((pm_ln_bwd_kernel<NJ, float>), dim3(grid), dim3(64 * LNB_WAVES), 0, st, (const uint16_t*)dy_bf16,        \
                                (const float*)x, mean, rstd, gamma, (float*)dx, part, m);                                    \
     } while (0)
     if (nj <= 2) PM_BWD(2);
     else if (nj <= 3) PM_BWD(3);
     else if (nj <= 6) PM_BWD(6);
-    else PM_BWD(12);
+    else if (x_dtype == DGX_BF16)
+        hipLaunchKernelGGL((pm_ln_bwd_kernel<12, uint16_t, 4>), dim3(grid), dim3(256), 0, st, (const uint16_t*)dy_bf16,
+                           (const uint16_t*)x, mean, rstd, gamma, (uint16_t*)dx, part, m);
+    else
+        hipLaunchKernelGGL((pm_ln_bwd_kernel<12, float, 4>), dim3(grid), dim3(256), 0, st, (const uint16_t*)dy_bf16,
+                           (const float*)x, mean, rstd, gamma, (float*)dx, part, m);
 #undef PM_BWD
     hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * C / 4 + 63) / 64), dim3(1024), 0, st, part, dgamma, dbeta, grid, C);
     DGX_LAUNCH_CHECK();
@@ -473,10 +480,10 @@ extern "C" int dgx_layernorm_f32out_bwd(const float* dy, const void* x, const fl
 #define LNF_BWD(NJ)                                                                                                        \
     do {                                                                                                                   \
         if (x_dtype == DGX_BF16)                                                                                           \
-            hipLaunchKernelGGL((ln_bwd_kernel<NJ, uint16_t, float>), dim3(grid), dim3(256), 0, st, dy, (const uint16_t*)x,  \
+            hipLaunchKernelGGL((ln_bwd_kernel<NJ, uint16_t, float>), dim3(grid), dim3(64 * LNB_WAVES), 0, st, dy, (const uint16_t*)x,  \
                                mean, rstd, gamma, (const uint16_t*)nullptr, (uint16_t*)dx, part, T, C, m);                  \
         else                                                                                                               \
-            hipLaunchKernelGGL((ln_bwd_kernel<NJ, float, float>), dim3(grid), dim3(256), 0, st, dy, (const float*)x, mean,  \
+            hipLaunchKernelGGL((ln_bwd_kernel<NJ, float, float>), dim3(grid), dim3(64 * LNB_WAVES), 0, st, dy, (const float*)x, mean,  \
                                rstd, gamma, (const float*)nullptr, (float*)dx, part, T, C, m);                              \
     } while (0)
     if (nj <= 1) LNF_BWD(1);

@@ -83,7 +83,18 @@ for r in sorted(ranges, key=lambda e: e.time_range.start):
     a[1] += t / 1e3
     a[2] += (r.time_range.end - r.time_range.start) / 1e3
     a[3] += 1
-if len(sys.argv) > 1:          # op histogram inside one region, e.g.  python tools/launch_regions.py "backbone+fpn"
+if len(sys.argv) > 1 and sys.argv[1] == "backward":      # everything that is not inside the forward / optimizer ranges
+    fw = [r for r in ranges if r.name[2:] in ("forward total", "optimizer")]
+    hist, tim = collections.Counter(), collections.Counter()
+    for o in ops:
+        if any(o.thread == r.thread and r.time_range.start <= o.time_range.start <= r.time_range.end for r in fw):
+            continue
+        nm = o.name if len(sys.argv) < 3 or sys.argv[2] != o.name else o.name + " " + str(o.input_shapes)[:90]
+        hist[nm] += len(o.kernels)
+        tim[nm] += sum(k.duration for k in o.kernels)
+    for k, v in hist.most_common(45):
+        print("   %-46s %5d launches %9.3f ms" % (k, v, tim[k] / 1e3))
+elif len(sys.argv) > 1:          # op histogram inside one region, e.g.  python tools/launch_regions.py "backbone+fpn"
     want = [r for r in ranges if r.name[2:] == sys.argv[1]][:1]
     hist = collections.Counter()
     tim = collections.Counter()

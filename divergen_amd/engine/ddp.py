@@ -10,7 +10,15 @@ the rest of backward; buckets whose parameters received no gradient this step (t
 'unused parameter' case, e.g. the mask head on a batch without masks) are flushed zero-filled at
 the end.  Averaging (1/world) is folded into the optimizer kernel's grad_scale.
 xGMI is point-to-point, so a ring all-reduce is bound by one ~153 GB/s link: buckets default to
-64 MiB (fewer, larger collectives) rather than DDP's 25 MiB."""
+64 MiB (fewer, larger collectives) rather than DDP's 25 MiB.
+
+"Ready" means the LAST write of a step into a parameter's gradient.  Autograd's AccumulateGrad hook fires once per
+parameter, but the layers that write their weight gradient straight into the arena signal once per USE, and a weight
+shared by several call sites (the CenterNet tower over five FPN levels) is used several times per step.  The reducer
+therefore learns the number of signals per parameter from the first step (during which nothing is launched early) and
+afterwards counts a parameter as ready at its last expected signal.  Fewer signals than learned (a hipGraph replay
+produces none, a branch not taken) only defer the bucket to `finish()`; MORE signals than learned would mean a bucket
+could have left before its gradients were complete, and `finish()` raises."""
 import os
 
 import torch
@@ -38,6 +46,8 @@ class ArenaReducer:
         self._pending = [b[2] for b in self.buckets]
         self._launched = [False] * len(self.buckets)
         self._works = []
+        self._got = [0] * n            # ready signals of this step, per parameter
+        self._expected = None          # learned from the first step; None = calibrating (no early launches)
         self.active = self.world > 1 or (dist.is_initialized() and os.environ.get("DGX_FORCE_PG") == "1")
         if self.active:
             for i, p in enumerate(arena.params):
@@ -51,9 +61,11 @@ class ArenaReducer:
         b = self.bucket_of[i]
 
         def hook(_param):
-            self._pending[b] -= 1
-            if self._pending[b] == 0:
-                self._launch(b)
+            self._got[i] += 1
+            if self._expected is not None and self._got[i] == self._expected[i]:
+                self._pending[b] -= 1
+                if self._pending[b] == 0:
+                    self._launch(b)
         return hook
 
     def _launch(self, b):
@@ -78,6 +90,15 @@ class ArenaReducer:
             for w in self._works:
                 w.wait()
         self._works = []
+        if self.active:
+            if self._expected is None:
+                self._expected = list(self._got)
+            else:
+                late = [self.arena.names[i] for i, (g, e) in enumerate(zip(self._got, self._expected)) if e > 0 and g > e]
+                if late:
+                    raise RuntimeError("ArenaReducer: parameters signalled 'gradient ready' more often than in the first step "
+                                       "(%s ...): their bucket may have been reduced before the last write" % ", ".join(late[:4]))
+        self._got = [0] * len(self._got)
         self._pending = [b[2] for b in self.buckets]
         self._launched = [False] * len(self.buckets)
         return 1.0 / self.world

@@ -63,7 +63,7 @@ class suspend_ready:
 
 def notify_ready(p):
     r = getattr(p, "_dgx_ready", None)
-    if r is not None and not _READY_SUSPENDED[0] and not torch.cuda.is_current_stream_capturing():
+    if r is not None and not _READY_SUSPENDED[0] and not (p.is_cuda and torch.cuda.is_current_stream_capturing()):
         r()
 
 

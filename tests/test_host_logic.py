@@ -4,6 +4,7 @@ import os
 import sys
 
 import pytest
+import numpy as np
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -109,6 +110,89 @@ def _ddp_worker(rank, world, port, q):
     # not have mapped them yet
     q.put((rank, p0.numpy().copy(), (ar.g.clone() * scale).numpy().copy()))
     dist.destroy_process_group()
+
+
+class _DirectLinearFn(torch.autograd.Function):
+    """The protocol of layers/linear_ops on the CPU: the weight gradient is ADDED straight into the arena view and the
+    reducer is signalled once per use; autograd never sees the weight."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x)
+        ctx.w = w
+        return x @ w.detach().t()
+
+    @staticmethod
+    def backward(ctx, g):
+        from divergen_amd.layers.linear_ops import notify_ready
+        (x,) = ctx.saved_tensors
+        ctx.w.grad.add_(g.t() @ x)
+        notify_ready(ctx.w)
+        return g @ ctx.w.detach(), None          # None: the gradient is already in the arena (no AccumulateGrad)
+
+
+def _direct_linear(x, w):
+    return _DirectLinearFn.apply(x, w)
+
+
+def _ddp_shared_worker(rank, world, port, q):
+    """A weight used TWICE per step through the layers that write gradients straight into the arena (one 'ready' signal
+    per use): the bucket must leave after the last use, not the first."""
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from divergen_amd.engine.ddp import ArenaReducer
+    from divergen_amd.solver import FlatArena
+    torch.manual_seed(7)
+    shared, head = torch.nn.Linear(8, 8, bias=False), torch.nn.Linear(8, 3)
+    model = torch.nn.ModuleList([shared, head])
+    ar = FlatArena(model)
+    red = ArenaReducer(ar, bucket_bytes=16)          # tiny buckets: every parameter its own bucket
+    red.broadcast_parameters()
+    x = torch.full((4, 8), 0.25 * (rank + 1))
+    out = []
+    for it in range(3):                              # step 0 calibrates, steps 1-2 launch from the ready signals
+        ar.zero_grad()
+        y = head(_direct_linear(torch.relu(_direct_linear(x, shared.weight)), shared.weight))
+        y.sum().backward()
+        scale = red.finish()
+        out.append((ar.g.clone() * scale).numpy().copy())
+    q.put((rank, ar.p.numpy().copy(), out, list(red._expected)))
+    dist.destroy_process_group()
+
+
+def test_arena_reducer_shared_weight_world2_gloo():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ddp_shared_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, p_a, g_a, exp_a), (_, p_b, g_b, _) = res
+    # the shared weight signals once per use (+ once more if autograd runs its AccumulateGrad node on the undefined
+    # gradient), the head's two parameters once: the reducer has learned that from step 0
+    assert exp_a[0] >= 2 and exp_a[1] == 1 and exp_a[2] == 1
+    from divergen_amd.solver import FlatArena
+    torch.manual_seed(7)
+    shared, head = torch.nn.Linear(8, 8, bias=False), torch.nn.Linear(8, 3)
+    ar = FlatArena(torch.nn.ModuleList([shared, head]))
+    ar.p.copy_(torch.from_numpy(p_a))
+    tot = torch.zeros_like(ar.g)
+    for r in range(2):          # plain autograd reference with the broadcast weights
+        ar.zero_grad()
+        head(shared(torch.relu(shared(torch.full((4, 8), 0.25 * (r + 1)))))).sum().backward()
+        tot += ar.g
+    for it in range(3):
+        assert np.allclose(g_a[it], g_b[it], atol=1e-6), it
+        assert np.allclose(g_a[it], (tot / 2).numpy(), atol=1e-5), it
 
 
 def test_arena_reducer_world2_gloo():

@@ -239,6 +239,16 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax)
     imgs = a.batch * world * a.steps
+    # After the timed region: every rank applied the same all-reduced gradients with the same deterministic optimizer
+    # kernel, so the weights must still be IDENTICAL across ranks.  A bucket reduced before its last gradient write (or
+    # any rank-local contribution that escaped the all-reduce) shows up here as diverged weights: fail loudly.
+    in_sync = None
+    if world > 1:
+        chk = torch.stack([opt.arena.p.double().sum(), opt.arena.p.double().abs().sum()]).cpu()
+        gathered = [torch.zeros_like(chk) for _ in range(world)]
+        dist.all_gather(gathered, chk.to(dev) if dist.get_backend() == "nccl" else chk)
+        in_sync = all(torch.equal(g.cpu(), gathered[0].cpu()) for g in gathered)
+        assert in_sync, "weights diverged across ranks: %s" % [g.tolist() for g in gathered]
 
     # roofline objects from HIP events recorded (on the launch stream) around every call of the three heaviest
     # libdgx entry points inside the timed region; "roofline" = the one with the largest total time
@@ -290,6 +300,8 @@ def main():
                            "global_batch": a.batch * world, "parallelism": "dp%d" % world, "params_M": nparams / 1e6},
                 "roofline": roof, "roofline_other": objs[1:],
                 "host_issue_ms_per_step": t_issue / a.steps * 1e3}
+        if in_sync is not None:
+            line["weights_identical_across_ranks"] = in_sync
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a.swin)
         print(json.dumps(line))

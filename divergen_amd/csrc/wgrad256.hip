@@ -186,25 +186,34 @@ __global__ __launch_bounds__(256) void wgrad256_partial_kernel(Params256 P) {
     if (st < nst) mfmas(af0, bf0);   // odd stage count: the last stage's fragments are already in registers
     wait_vmcnt<0>();
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // last MFMA -> accumulator read-out hazard
-    // unsplit problems (S == 1) fold straight into the gradient; split ones leave a partial tile for the reduce kernel
+    // unsplit problems (S == 1) fold straight into the gradient; split ones leave a partial tile for the reduce kernel.
+    // The accumulator layout (lane = one column of a 16-wide tile) would store 64-byte runs; each wave passes its
+    // 16 x 128 strips through a private LDS staging area (the pipeline buffers are idle now) and stores / read-modify-
+    // writes 512-byte row segments instead.
     const bool direct = q.S == 1;
     float* out = direct ? q.C : q.ws + (int64_t)s * q.Nn * q.Kk;
     const float beta = direct ? P.beta : 0.f;
+    __syncthreads();                                  // every wave is done reading the operand images
+    constexpr int SR = 132;                           // staging row stride (floats): 4 rows apart = 16 banks apart
+    DGX_LDS float* stg = reinterpret_cast<DGX_LDS float*>((DGX_LDS unsigned char*)lds_raw) + w * (16 * SR);
+    DGX_LDS float* stg_w = stg + (4 * g) * SR + c16;
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < 8; ++i) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int n = n0 + wn + 16 * i + 4 * g + r;
-            if (n >= q.Nn) continue;
+        for (int j = 0; j < 8; ++j)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int k = k0 + wk + 16 * j + c16;
-                if (k < q.Kk) {
-                    float* o = out + (int64_t)n * q.Kk + k;
-                    *o = beta != 0.f ? beta * *o + acc[i][j][r] : acc[i][j][r];
-                }
+            for (int r = 0; r < 4; ++r) stg_w[r * SR + 16 * j] = acc[i][j][r];
+#pragma unroll
+        for (int qd = 0; qd < 8; ++qd) {
+            const int idx = qd * 64 + l, row = idx >> 5, c4 = idx & 31;
+            const f32x4 v = *reinterpret_cast<DGX_LDS const f32x4*>(stg + row * SR + 4 * c4);
+            const int n = n0 + wn + 16 * i + row, k = k0 + wk + 4 * c4;
+            if (n < q.Nn && k < q.Kk) {                // Kk % 8 == 0: a quad never straddles the edge
+                f32x4* o = reinterpret_cast<f32x4*>(out + (int64_t)n * q.Kk + k);
+                *o = beta != 0.f ? beta * *o + v : v;
             }
         }
+    }
 }
 
 __global__ __launch_bounds__(256) void wgrad256_reduce_kernel(Params256 P, int64_t total4) {

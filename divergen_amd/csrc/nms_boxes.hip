@@ -104,7 +104,7 @@ extern "C" int dgx_nms_sorted(const float* boxes, int n, float iou_thr, uint64_t
     hipStream_t st = (hipStream_t)stream;
     if (n < 0 || !num_keep) return DGX_ERR_BAD_ARG;
     if (n == 0) {
-        hipMemsetAsync(num_keep, 0, sizeof(int32_t), st);
+        (void)hipMemsetAsync(num_keep, 0, sizeof(int32_t), st);
         return DGX_OK;
     }
     if (!boxes || !mask || !keep) return DGX_ERR_BAD_ARG;

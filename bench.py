@@ -302,6 +302,7 @@ def main():
                 "host_issue_ms_per_step": t_issue / a.steps * 1e3}
         if in_sync is not None:
             line["weights_identical_across_ranks"] = in_sync
+            line["buckets_reduced_during_backward"] = "%d/%d" % (reducer.last_early, len(reducer.buckets))
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a.swin)
         print(json.dumps(line))

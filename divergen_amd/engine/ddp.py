@@ -46,6 +46,9 @@ class ArenaReducer:
         self._pending = [b[2] for b in self.buckets]
         self._launched = [False] * len(self.buckets)
         self._works = []
+        self._ready = [False] * len(self.buckets)
+        self._next = 0                 # buckets are launched strictly in index order (same order on every rank)
+        self.last_early = 0
         self._got = [0] * n            # ready signals of this step, per parameter
         self._expected = None          # learned from the first step; None = calibrating (no early launches)
         self.active = self.world > 1 or (dist.is_initialized() and os.environ.get("DGX_FORCE_PG") == "1")
@@ -65,8 +68,17 @@ class ArenaReducer:
             if self._expected is not None and self._got[i] == self._expected[i]:
                 self._pending[b] -= 1
                 if self._pending[b] == 0:
-                    self._launch(b)
+                    self._ready[b] = True
+                    self._launch_in_order()
         return hook
+
+    def _launch_in_order(self):
+        """Collectives must be issued in the SAME order on every rank, and which buckets complete early is data dependent
+        (a rank whose batch has no mask targets never completes the mask head's bucket before `finish()`): a bucket is
+        only launched once every bucket before it has been (torch DDP's rule)."""
+        while self._next < len(self.buckets) and self._ready[self._next]:
+            self._launch(self._next)
+            self._next += 1
 
     def _launch(self, b):
         if self._launched[b]:
@@ -85,7 +97,8 @@ class ArenaReducer:
         """Call after backward: flush never-ready buckets, wait for every collective.  Returns the
         factor the optimizer must apply to the summed gradients."""
         if self.active:
-            for b in range(len(self.buckets)):
+            self.last_early = self._next          # buckets that left while backward was still running (diagnostic)
+            for b in range(self._next, len(self.buckets)):
                 self._launch(b)
             for w in self._works:
                 w.wait()
@@ -99,6 +112,8 @@ class ArenaReducer:
                     raise RuntimeError("ArenaReducer: parameters signalled 'gradient ready' more often than in the first step "
                                        "(%s ...): their bucket may have been reduced before the last write" % ", ".join(late[:4]))
         self._got = [0] * len(self._got)
+        self._ready = [False] * len(self.buckets)
+        self._next = 0
         self._pending = [b[2] for b in self.buckets]
         self._launched = [False] * len(self.buckets)
         return 1.0 / self.world

@@ -7,8 +7,10 @@ two graph launches (forward, backward) instead of ~10^3 kernel launches.  The re
 runs these modules eagerly: D2/modeling/backbone/fpn.py:113-154, CN/modeling/dense_heads/centernet_head.py:141-162).
 
 Segments must be free of host syncs, data-dependent shapes and Python-side effects.  Parameter gradients are
-written in place into the gradient arena by the captured kernels; the data-parallel reducer is not signalled
-from inside a replay (its per-parameter callbacks are Python) and flushes those buckets in finish()."""
+written in place into the gradient arena by the captured kernels.  The data-parallel reducer cannot be signalled from
+inside a replay (its per-parameter callbacks are Python), so the segment's inputs pass through an identity autograd node
+whose backward runs right after the replayed backward graph has been enqueued and signals every parameter of the segment
+(without it the reducer, which launches buckets in index order, would hold the whole backbone behind these buckets)."""
 import os
 
 import torch
@@ -16,6 +18,21 @@ import torch
 from ..layers import linear_ops
 
 ENABLED = os.environ.get("DGX_GRAPH_HEADS", "1") == "1"
+
+
+class _SignalAfterBackward(torch.autograd.Function):
+    """Identity on the first input of a graphed segment; its backward = 'the segment's parameter gradients are written'."""
+
+    @staticmethod
+    def forward(ctx, x, params):
+        ctx.params = params
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        for p in ctx.params:
+            linear_ops.notify_ready(p)
+        return g, None
 
 
 class GraphedSegment:
@@ -43,4 +60,10 @@ class GraphedSegment:
                 if p.grad is not None:
                     p.grad.zero_()
             self._fns[key] = fn
+        k = next((i for i, t in enumerate(inputs) if t.requires_grad), None)
+        if k is not None and torch.is_grad_enabled():
+            params = self.__dict__.get("_params")
+            if params is None:
+                params = self.__dict__["_params"] = tuple(p for p in self.module.parameters() if p.requires_grad)
+            inputs = inputs[:k] + (_SignalAfterBackward.apply(inputs[k], params),) + inputs[k + 1:]
         return fn(*inputs)

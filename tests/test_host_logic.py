@@ -161,6 +161,64 @@ def _ddp_shared_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _ddp_uneven_worker(rank, world, port, q):
+    """Rank 1 never uses the LAST-registered layer (first bucket in launch order), rank 0 does: which buckets complete
+    early differs between the ranks, the order of the collectives must not."""
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from divergen_amd.engine.ddp import ArenaReducer
+    from divergen_amd.solver import FlatArena
+    torch.manual_seed(3)
+    a, b, c = torch.nn.Linear(5, 5), torch.nn.Linear(5, 5), torch.nn.Linear(5, 2)
+    ar = FlatArena(torch.nn.ModuleList([a, b, c]))
+    red = ArenaReducer(ar, bucket_bytes=16)
+    red.broadcast_parameters()
+    x = torch.full((3, 5), 0.5 + rank)
+    out = []
+    for it in range(3):
+        ar.zero_grad()
+        h = b(a(x))
+        y = c(h).sum() if rank == 0 else h.sum()      # rank 1: `c` unused -> its buckets only leave at finish()
+        y.backward()
+        scale = red.finish()
+        out.append((ar.g.clone() * scale).numpy().copy())
+    q.put((rank, ar.p.numpy().copy(), out))
+    dist.destroy_process_group()
+
+
+def test_arena_reducer_rank_dependent_unused_branch_world2_gloo():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ddp_uneven_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, p_a, g_a), (_, _, g_b) = res
+    from divergen_amd.solver import FlatArena
+    torch.manual_seed(3)
+    a, b, c = torch.nn.Linear(5, 5), torch.nn.Linear(5, 5), torch.nn.Linear(5, 2)
+    ar = FlatArena(torch.nn.ModuleList([a, b, c]))
+    ar.p.copy_(torch.from_numpy(p_a))
+    tot = torch.zeros_like(ar.g)
+    for r in range(2):
+        ar.zero_grad()
+        h = b(a(torch.full((3, 5), 0.5 + r)))
+        (c(h).sum() if r == 0 else h.sum()).backward()
+        tot += ar.g
+    for it in range(3):
+        assert np.allclose(g_a[it], g_b[it], atol=1e-6), it
+        assert np.allclose(g_a[it], (tot / 2).numpy(), atol=1e-5), it
+
+
 def test_arena_reducer_shared_weight_world2_gloo():
     import socket
     s = socket.socket()

@@ -18,10 +18,11 @@ def enable():
     src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm_gfx950.csv")
     if not os.path.isfile(src):
         return False
-    # TunableOp reads <FILENAME stem><device ordinal>.csv: give this process its own copy under its ordinal
-    ordinal = int(os.environ.get("LOCAL_RANK", "0"))
+    # TunableOp reads <FILENAME stem><device ordinal>.csv: a private copy under EVERY ordinal this process could end up
+    # using (LOCAL_RANK with torchrun, 0 when the launcher narrows the visible devices instead)
     d = tempfile.mkdtemp(prefix="dgx_tunableop_")
-    shutil.copy(src, os.path.join(d, "results%d.csv" % ordinal))
+    for ordinal in range(16):
+        shutil.copy(src, os.path.join(d, "results%d.csv" % ordinal))
     os.environ["PYTORCH_TUNABLEOP_ENABLED"] = "1"
     os.environ["PYTORCH_TUNABLEOP_TUNING"] = "0"
     os.environ["PYTORCH_TUNABLEOP_RECORD_UNTUNED"] = "0"

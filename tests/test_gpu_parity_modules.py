@@ -391,3 +391,22 @@ def test_fused_centernet_losses_vs_torch_formulation(not_norm_reg, alpha, ihf, c
         assert abs(lf[k] - lt[k]) <= 1e-5 * max(1.0, abs(lt[k])), (k, lf[k], lt[k])
     torch.testing.assert_close(grf, grt, atol=1e-7, rtol=2e-4)
     torch.testing.assert_close(gaf, gat, atol=1e-7, rtol=2e-4)
+
+
+def test_predict_instances_candidates_vs_reference_golden(golden):
+    """Product decode (all levels at once, per-level top-k where needed) vs the reference's predict_single_level output
+    (tests/golden/centernet_predict.npz): one level with more locations than the pre-NMS top-k, NMS off so that the
+    candidate list itself is returned (scores are sqrt(heat map), centernet.py:702, in the golden as well)."""
+    from divergen_amd.modeling.dense_heads.centernet import CenterNet
+    g = golden("centernet_predict")
+    hm, reg, grids = T(g["hm"]).to(DEV), T(g["reg"]).to(DEV), T(g["grids"]).to(DEV)
+    net = CenterNet(in_channels=16, num_classes=1, in_features=("p4",), strides=(int(g["stride"]),), with_agn_hm=True,
+                    only_proposal=True, score_thresh=float(g["thresh"]), pre_nms_topk_test=int(g["topk"]), post_nms_topk_test=100,
+                    not_nms=True, sizes_of_interest=((0, 1e8),), centernet_head=torch.nn.Identity()).to(DEV).eval()
+    res = net.predict_instances([grids], [hm], [reg], [(256, 320), (256, 320)])
+    for i, r in enumerate(res):
+        want_b, want_s = T(g["boxes%d" % i]).to(DEV), T(g["scores%d" % i]).to(DEV)
+        assert len(r) == want_s.numel(), (i, len(r), want_s.numel())
+        o = torch.argsort(r.scores, descending=True, stable=True)
+        torch.testing.assert_close(r.scores[o], want_s, atol=0, rtol=0)
+        torch.testing.assert_close(r.pred_boxes.tensor[o], want_b, atol=0, rtol=0)

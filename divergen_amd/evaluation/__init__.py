@@ -34,3 +34,76 @@ def instances_to_coco_json(instances, img_id):
             r["segmentation"] = rles[k]
         out.append(r)
     return out
+
+
+class LVISResultsWriter:
+    """The prediction-collecting half of LVISEvaluator (D2/evaluation/lvis_evaluation.py: reset :76, process :79-97,
+    evaluate :99-125 and the json dump of _eval_predictions :132-160): per-image results in LVIS format, gathered to rank 0
+    and written to `lvis_instances_results.json` with 1-indexed category ids.  The AP computation itself
+    (`_evaluate_predictions_on_lvis`, lvis-api) is not available in this image: `evaluate()` returns {} after writing the
+    file, which is what the reference does when the split has no annotations (:162-164)."""
+
+    def __init__(self, output_dir=None, distributed=True, reverse_id_mapping=None, mask_on_device=True):
+        self._output_dir, self._distributed = output_dir, distributed
+        self._reverse = reverse_id_mapping
+        self._predictions = []
+
+    def reset(self):
+        self._predictions = []
+
+    def process(self, inputs, outputs):
+        for inp, out in zip(inputs, outputs):
+            pred = {"image_id": inp["image_id"]}
+            if "instances" in out:
+                # masks are run-length encoded on the GPU (no bitmask transfer); boxes / scores / classes go to the host
+                pred["instances"] = instances_to_coco_json(out["instances"], inp["image_id"])
+            self._predictions.append(pred)
+
+    def evaluate(self):
+        import itertools
+        import json
+        import os
+        from ..utils import comm
+        preds = self._predictions
+        if self._distributed and comm.get_world_size() > 1:
+            comm.synchronize()
+            gathered = comm.gather(preds, dst=0)
+            if not comm.is_main_process():
+                return
+            preds = list(itertools.chain(*gathered))
+        if len(preds) == 0:
+            return {}
+        results = list(itertools.chain(*[p["instances"] for p in preds if "instances" in p]))
+        for r in results:
+            r["category_id"] = self._reverse[r["category_id"]] if self._reverse is not None else r["category_id"] + 1
+        if self._output_dir:
+            os.makedirs(self._output_dir, exist_ok=True)
+            with open(os.path.join(self._output_dir, "lvis_instances_results.json"), "w") as f:
+                f.write(json.dumps(results))
+        self.results = results
+        return {}
+
+
+def inference_on_dataset(model, data_loader, evaluator, mask_format="rle"):
+    """D2/evaluation/evaluator.py:103-190 without the timing log: model in eval mode under no_grad, evaluator.process per
+    batch, evaluator.evaluate() at the end.  With mask_format="rle" the model's post-processing leaves COCO run-length
+    dicts (`pred_masks_rle`) instead of (N,H,W) bitmasks -- see modeling/meta_arch/custom_rcnn.detector_postprocess."""
+    import torch
+    from ..modeling.meta_arch.custom_rcnn import detector_postprocess
+    was_training = model.training
+    model.eval()
+    evaluator.reset()
+    try:
+        with torch.no_grad():
+            for inputs in data_loader:
+                if mask_format == "rle":
+                    raw = model.inference(inputs, do_postprocess=False)
+                    outputs = [{"instances": detector_postprocess(r, inp.get("height", r.image_size[0]),
+                                                                  inp.get("width", r.image_size[1]), mask_format="rle")}
+                               for r, inp in zip(raw, inputs)]
+                else:
+                    outputs = model(inputs)
+                evaluator.process(inputs, outputs)
+    finally:
+        model.train(was_training)
+    return evaluator.evaluate() or {}

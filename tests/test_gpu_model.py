@@ -274,3 +274,17 @@ def test_inference_path_end_to_end():
         for x, y in zip(a, b):
             assert x["segmentation"] == y["segmentation"] and x["category_id"] == y["category_id"]
             assert abs(x["score"] - y["score"]) < 1e-7 and max(abs(p - q) for p, q in zip(x["bbox"], y["bbox"])) < 1e-4
+    # the evaluator loop: results file in LVIS format (1-indexed category ids), model restored to its mode
+    import json
+    import tempfile
+    from divergen_amd.evaluation import LVISResultsWriter, inference_on_dataset
+    for i, b in enumerate(batch):
+        b["image_id"] = 100 + i
+    with tempfile.TemporaryDirectory() as d:
+        model.train()
+        res = inference_on_dataset(model, [batch], LVISResultsWriter(d, distributed=False))
+        assert res == {} and model.training
+        rows = json.load(open(os.path.join(d, "lvis_instances_results.json")))
+    assert len(rows) == sum(len(o["instances"]) for o in out)
+    assert {r["image_id"] for r in rows} == {100, 101} and min(r["category_id"] for r in rows) >= 1
+    assert all(isinstance(r["segmentation"]["counts"], str) and r["segmentation"]["size"] == [300, 380] for r in rows)

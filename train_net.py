@@ -142,8 +142,10 @@ def main(args):
     model = build_model(cfg)
     if args.eval_only:
         DetectionCheckpointer(model, save_dir=cfg.OUTPUT_DIR).resume_or_load(cfg.MODEL.WEIGHTS, resume=args.resume)
-        raise SystemExit("LVIS evaluation needs the dataset and lvis-api; inference() / postprocess are in "
-                         "divergen_amd.modeling.meta_arch")
+        # do_test (DG/train_net.py:61-118) up to the results file: the loop, the GPU post-processing and the LVIS-format
+        # json are here (divergen_amd/evaluation); AP itself needs the dataset tree and lvis-api, absent from this image
+        raise SystemExit("LVIS evaluation needs the dataset and lvis-api.  Results in LVIS format are produced by "
+                         "divergen_amd.evaluation.inference_on_dataset(model, loader, LVISResultsWriter(out_dir))")
     do_train(cfg, model, resume=args.resume)
 
 

@@ -216,8 +216,13 @@ __global__ __launch_bounds__(256) void wgrad256_partial_kernel(Params256 P) {
     }
 }
 
+// LPQ = lanes per output quad: 1 for large outputs; 16 when the output is small and the split deep (a 192 x 48 patch-embed
+// weight is cut into 256 slabs: one lane per quad would walk them serially, 2 300 lanes for the whole launch)
+template <int LPQ>
 __global__ __launch_bounds__(256) void wgrad256_reduce_kernel(Params256 P, int64_t total4) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total4 * LPQ; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = t / LPQ;
+        const int sub = (int)(t - i * LPQ);
         int pi = 0;
 #pragma unroll
         for (int k = 1; k < MAXP256; ++k)
@@ -226,9 +231,16 @@ __global__ __launch_bounds__(256) void wgrad256_reduce_kernel(Params256 P, int64
         const int64_t e = i - q.red0, n4 = (int64_t)q.Nn * q.Kk / 4;
         const float4* ws = reinterpret_cast<const float4*>(q.ws);
         float4 a = {0.f, 0.f, 0.f, 0.f};
-        for (int s = 0; s < q.S; ++s) {
+        for (int s = sub; s < q.S; s += LPQ) {
             const float4 v = ws[(int64_t)s * n4 + e];
             a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        if (LPQ > 1) {
+#pragma unroll
+            for (int o = LPQ / 2; o > 0; o >>= 1) {
+                a.x += __shfl_xor(a.x, o); a.y += __shfl_xor(a.y, o); a.z += __shfl_xor(a.z, o); a.w += __shfl_xor(a.w, o);
+            }
+            if (sub != 0) continue;
         }
         float4* C = reinterpret_cast<float4*>(q.C);
         if (P.beta != 0.f) {
@@ -323,8 +335,15 @@ extern "C" int dgx_linear_wgrad_grouped(const dgx_wgrad_problem* problems, int n
     P.per_xcd = (wg + 7) / 8;
     hipLaunchKernelGGL(wgrad256_partial_kernel, dim3(8 * P.per_xcd), dim3(256), sm, st, P);
     if (red > 0) {
-        const int grid = (int)((red + 255) / 256 < 8192 ? (red + 255) / 256 : 8192);
-        hipLaunchKernelGGL(wgrad256_reduce_kernel, dim3(grid), dim3(256), 0, st, P, red);
+        int maxS = 1;
+        for (int i = 0; i < n; ++i) maxS = S[i] > maxS ? S[i] : maxS;
+        if (red <= 32768 && maxS >= 16) {          // small output, deep split: 16 lanes share the walk over the slabs
+            // (total4 * 16 is a multiple of 64, so the xor-shuffles never mix lanes of different quads with idle ones)
+            hipLaunchKernelGGL(wgrad256_reduce_kernel<16>, dim3((int)((red * 16 + 255) / 256)), dim3(256), 0, st, P, red);
+        } else {
+            const int grid = (int)((red + 255) / 256 < 8192 ? (red + 255) / 256 : 8192);
+            hipLaunchKernelGGL(wgrad256_reduce_kernel<1>, dim3(grid), dim3(256), 0, st, P, red);
+        }
     }
     DGX_LAUNCH_CHECK();
     return DGX_OK;

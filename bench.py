@@ -299,7 +299,8 @@ def main():
                                        "fused clip/AdamW/EMA; configs/DiverGen_swinL.yaml" % (a.swin, a.size, a.size, a.batch),
                            "global_batch": a.batch * world, "parallelism": "dp%d" % world, "params_M": nparams / 1e6},
                 "roofline": roof, "roofline_other": objs[1:],
-                "host_issue_ms_per_step": t_issue / a.steps * 1e3}
+                "host_issue_ms_per_step": t_issue / a.steps * 1e3,
+                "peak_hbm_gb_rank0": torch.cuda.max_memory_allocated(dev) / 1e9}
         if in_sync is not None:
             line["weights_identical_across_ranks"] = in_sync
             line["buckets_reduced_during_backward"] = "%d/%d" % (reducer.last_early, len(reducer.buckets))

@@ -2,8 +2,8 @@
 // (CN/modeling/dense_heads/centernet_head.py:52-75: Conv3x3 -> GroupNorm(32, 256) -> ReLU, x4 per level).
 // x (N, HW, C) bf16, 8 channels per group (C = 8 G): one 16-byte vector = one group at one pixel, so every
 // pass is a fully coalesced stream.  HBM-bound: forward reads x twice + writes y once; backward reads x, dy twice.
-//   stats   : one workgroup per (n, g): mean / rstd in fp32 (two-pass over the L2-resident group: exact centred variance)
-//   apply   : y = relu?((x - mean) * rstd * gamma + beta)
+//   stats   : slab partial sums per (n, g) in fp32 (shifted sums: no cancellation)
+//   apply   : folds the partials into mean / rstd per workgroup, then y = relu?((x - mean) * rstd * gamma + beta)
 //   bwd red : per (n, g): s1 = sum dyh*gamma, s2 = sum dyh*gamma*xhat and the per-channel sums for dgamma / dbeta
 //   bwd dx  : dx = rstd * (dyh*gamma - (s1 + xhat*s2)/m),  dyh = dy * (y > 0)
 #include "dgx_common.h"
@@ -48,32 +48,36 @@ __global__ __launch_bounds__(256) void gn_stats_partial_kernel(const uint16_t* _
     if (threadIdx.x == 0) { part[((int64_t)blockIdx.x * S + s) * 2] = a; part[((int64_t)blockIdx.x * S + s) * 2 + 1] = q; }
 }
 
-__global__ __launch_bounds__(256) void gn_stats_final_kernel(const uint16_t* __restrict__ x, const float* __restrict__ part,
-                                                             float* __restrict__ mean, float* __restrict__ rstd, int NG, int HW, int C,
-                                                             int G, int S, float eps) {
-    const int ng = blockIdx.x * 256 + threadIdx.x;
-    if (ng >= NG) return;
-    const int n = ng / G, g = ng % G;
-    const float x0 = bf2f(x[(int64_t)n * HW * C + 8 * g]);
-    float a = 0.f, q = 0.f;
-    for (int s = 0; s < S; ++s) { a += part[((int64_t)ng * S + s) * 2]; q += part[((int64_t)ng * S + s) * 2 + 1]; }
-    const float m = (float)HW * 8.0f;
-    const float md = a / m;
-    const float var = fmaxf(q / m - md * md, 0.0f);
-    mean[ng] = x0 + md;
-    rstd[ng] = rsqrtf(var + eps);
-}
-
-__global__ __launch_bounds__(256) void gn_apply_kernel(const uint16_t* __restrict__ x, const float* __restrict__ mean,
-                                                       const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                                       const float* __restrict__ beta, uint16_t* __restrict__ y, int64_t total_vec,
-                                                       int HW, int C, int G, int relu) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total_vec; i += (int64_t)gridDim.x * 256) {
+// grid (blocks per sample, N): every workgroup first folds the slab partials of its sample's G groups into mean / rstd
+// (LDS; workgroup 0 of the sample also stores them for the backward), then normalises its share of the pixels.
+__global__ __launch_bounds__(256) void gn_apply_kernel(const uint16_t* __restrict__ x, const float* __restrict__ part,
+                                                       float* __restrict__ mean, float* __restrict__ rstd,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       uint16_t* __restrict__ y, int HW, int C, int G, int S, float eps, int relu) {
+    __shared__ float mu_s[256], rs_s[256];
+    const int n = blockIdx.y;
+    for (int g = threadIdx.x; g < G; g += 256) {
+        const int ng = n * G + g;
+        const float x0 = bf2f(x[(int64_t)n * HW * C + 8 * g]);
+        float a = 0.f, q = 0.f;
+        for (int s = 0; s < S; ++s) { a += part[((int64_t)ng * S + s) * 2]; q += part[((int64_t)ng * S + s) * 2 + 1]; }
+        const float m = (float)HW * 8.0f;
+        const float md = a / m;
+        const float var = fmaxf(q / m - md * md, 0.0f);
+        const float mu = x0 + md, rs = rsqrtf(var + eps);
+        mu_s[g] = mu;
+        rs_s[g] = rs;
+        if (blockIdx.x == 0) { mean[ng] = mu; rstd[ng] = rs; }
+    }
+    __syncthreads();
+    const int64_t per_n = (int64_t)HW * G;
+    const u32x4* xv = reinterpret_cast<const u32x4*>(x) + (int64_t)n * per_n;
+    u32x4* yv = reinterpret_cast<u32x4*>(y) + (int64_t)n * per_n;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per_n; i += (int64_t)gridDim.x * 256) {
         const int g = (int)(i % G);
-        const int n = (int)(i / ((int64_t)HW * G));
-        const float mu = mean[n * G + g], rs = rstd[n * G + g];
+        const float mu = mu_s[g], rs = rs_s[g];
         float v[8], o[8];
-        unpack8(reinterpret_cast<const u32x4*>(x)[i], v);
+        unpack8(xv[i], v);
         const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + 8 * g), g1 = *reinterpret_cast<const f32x4*>(gamma + 8 * g + 4);
         const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + 8 * g), b1 = *reinterpret_cast<const f32x4*>(beta + 8 * g + 4);
 #pragma unroll
@@ -82,11 +86,11 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const uint16_t* __restric
             const float t = (v[k] - mu) * rs * gm + bt;
             o[k] = relu ? fmaxf(t, 0.f) : t;
         }
-        reinterpret_cast<u32x4*>(y)[i] = pack8(o);
+        yv[i] = pack8(o);
     }
 }
 
-// part2: [N*G][S][18] = s1, s2, dgamma[8], dbeta[8] of slab s; folded into part [N*G][18] by gn_bwd_fold_kernel
+// part2: [N*G][S][18] = s1, s2, dgamma[8], dbeta[8] of slab s (folded by the dx and parameter kernels)
 __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -128,29 +132,36 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const uint16_t* __re
     }
 }
 
-__global__ __launch_bounds__(256) void gn_bwd_fold_kernel(const float* __restrict__ part2, float* __restrict__ part, int NG, int S) {
-    const int i = blockIdx.x * 256 + threadIdx.x;     // over NG*18
-    if (i >= NG * 18) return;
-    const int ng = i / 18, k = i % 18;
-    float a = 0.f;
-    for (int s = 0; s < S; ++s) a += part2[((int64_t)ng * S + s) * 18 + k];
-    part[i] = a;
-}
-
+// grid (blocks per sample, N): s1 / s2 of the sample's groups folded from the slab partials into LDS, then dx
 __global__ __launch_bounds__(256) void gn_bwd_dx_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy,
                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                        const float* __restrict__ part, uint16_t* __restrict__ dx, int64_t total_vec,
-                                                        int HW, int C, int G, int relu) {
+                                                        const float* __restrict__ part2, uint16_t* __restrict__ dx, int HW, int C,
+                                                        int G, int S, int relu) {
+    __shared__ float s1_s[256], s2_s[256];
+    const int n = blockIdx.y;
+    for (int g = threadIdx.x; g < G; g += 256) {
+        float a = 0.f, b = 0.f;
+        for (int s = 0; s < S; ++s) {
+            a += part2[(((int64_t)n * G + g) * S + s) * 18];
+            b += part2[(((int64_t)n * G + g) * S + s) * 18 + 1];
+        }
+        s1_s[g] = a;
+        s2_s[g] = b;
+    }
+    __syncthreads();
     const float inv_m = 1.0f / ((float)HW * 8.0f);
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total_vec; i += (int64_t)gridDim.x * 256) {
+    const int64_t per_n = (int64_t)HW * G;
+    const u32x4* xv = reinterpret_cast<const u32x4*>(x) + (int64_t)n * per_n;
+    const u32x4* dv = reinterpret_cast<const u32x4*>(dy) + (int64_t)n * per_n;
+    u32x4* ov = reinterpret_cast<u32x4*>(dx) + (int64_t)n * per_n;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per_n; i += (int64_t)gridDim.x * 256) {
         const int g = (int)(i % G);
-        const int n = (int)(i / ((int64_t)HW * G));
         const int ng = n * G + g;
-        const float mu = mean[ng], rs = rstd[ng], s1 = part[(int64_t)ng * 18], s2 = part[(int64_t)ng * 18 + 1];
+        const float mu = mean[ng], rs = rstd[ng], s1 = s1_s[g], s2 = s2_s[g];
         float v[8], d[8], o[8];
-        unpack8(reinterpret_cast<const u32x4*>(x)[i], v);
-        unpack8(reinterpret_cast<const u32x4*>(dy)[i], d);
+        unpack8(xv[i], v);
+        unpack8(dv[i], d);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const float gm = gamma[8 * g + k], bt = beta[8 * g + k];
@@ -158,20 +169,25 @@ __global__ __launch_bounds__(256) void gn_bwd_dx_kernel(const uint16_t* __restri
             const float dh = (relu && !(xh * gm + bt > 0.f)) ? 0.f : d[k];
             o[k] = rs * (dh * gm - (s1 + xh * s2) * inv_m);
         }
-        reinterpret_cast<u32x4*>(dx)[i] = pack8(o);
+        ov[i] = pack8(o);
     }
 }
 
-// dgamma[c] += sum_n part[n][g][2 + k], dbeta likewise (c = 8 g + k)
-__global__ __launch_bounds__(256) void gn_bwd_param_kernel(const float* __restrict__ part, float* __restrict__ dgamma,
-                                                           float* __restrict__ dbeta, int N, int C, int G) {
+// dgamma[c] += sum over samples and slabs of part2[n][g][s][2 + k], dbeta likewise (c = 8 g + k); fixed order
+__global__ __launch_bounds__(256) void gn_bwd_param_kernel(const float* __restrict__ part2, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta, int N, int C, int G, int S) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
     const int g = c >> 3, k = c & 7;
     float a = 0.f, b = 0.f;
     for (int n = 0; n < N; ++n) {
-        a += part[((int64_t)n * G + g) * 18 + 2 + k];
-        b += part[((int64_t)n * G + g) * 18 + 10 + k];
+        float an = 0.f, bn = 0.f;
+        for (int s = 0; s < S; ++s) {
+            an += part2[(((int64_t)n * G + g) * S + s) * 18 + 2 + k];
+            bn += part2[(((int64_t)n * G + g) * S + s) * 18 + 10 + k];
+        }
+        a += an;
+        b += bn;
     }
     dgamma[c] += a;
     dbeta[c] += b;
@@ -195,12 +211,13 @@ extern "C" int dgx_groupnorm_fwd(const void* x, const float* gamma, const float*
     const int S = gn_slabs(N * G, HW);
     if (!scratch) return DGX_ERR_BAD_ARG;
     hipLaunchKernelGGL(gn_stats_partial_kernel, dim3(N * G, S), dim3(256), 0, st, (const uint16_t*)x, scratch, HW, C, G, S);
-    hipLaunchKernelGGL(gn_stats_final_kernel, dim3((N * G + 255) / 256), dim3(256), 0, st, (const uint16_t*)x, scratch, mean, rstd, N * G,
-                       HW, C, G, S, eps);
-    const int64_t tv = (int64_t)N * HW * G;
-    const int grid = (int)((tv + 255) / 256 < 4096 ? (tv + 255) / 256 : 4096);
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(grid), dim3(256), 0, st, (const uint16_t*)x, mean, rstd, gamma, beta, (uint16_t*)y, tv, HW,
-                       C, G, relu);
+    if (G > 256) return DGX_ERR_UNSUPPORTED;
+    const int64_t per_n = (int64_t)HW * G;
+    int bpn = (int)((per_n + 255) / 256);
+    const int cap = (4096 + N - 1) / N;
+    if (bpn > cap) bpn = cap;
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(bpn, N), dim3(256), 0, st, (const uint16_t*)x, scratch, mean, rstd, gamma, beta,
+                       (uint16_t*)y, HW, C, G, S, eps, relu);
     DGX_LAUNCH_CHECK();
     return DGX_OK;
 }
@@ -215,12 +232,14 @@ extern "C" int dgx_groupnorm_bwd(const void* x, const void* dy, const float* mea
     float* part2 = part + (int64_t)N * G * 18;      // scratch layout: [N*G][18] folded, then [N*G][S][18]
     hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(N * G, S), dim3(256), 0, st, (const uint16_t*)x, (const uint16_t*)dy, mean, rstd, gamma,
                        beta, part2, HW, C, G, relu, S);
-    hipLaunchKernelGGL(gn_bwd_fold_kernel, dim3((N * G * 18 + 255) / 256), dim3(256), 0, st, part2, part, N * G, S);
-    const int64_t tv = (int64_t)N * HW * G;
-    const int grid = (int)((tv + 255) / 256 < 4096 ? (tv + 255) / 256 : 4096);
-    hipLaunchKernelGGL(gn_bwd_dx_kernel, dim3(grid), dim3(256), 0, st, (const uint16_t*)x, (const uint16_t*)dy, mean, rstd, gamma, beta,
-                       part, (uint16_t*)dx, tv, HW, C, G, relu);
-    hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((C + 255) / 256), dim3(256), 0, st, part, dgamma, dbeta, N, C, G);
+    if (G > 256) return DGX_ERR_UNSUPPORTED;
+    const int64_t per_n = (int64_t)HW * G;
+    int bpn = (int)((per_n + 255) / 256);
+    const int cap = (4096 + N - 1) / N;
+    if (bpn > cap) bpn = cap;
+    hipLaunchKernelGGL(gn_bwd_dx_kernel, dim3(bpn, N), dim3(256), 0, st, (const uint16_t*)x, (const uint16_t*)dy, mean, rstd, gamma, beta,
+                       part2, (uint16_t*)dx, HW, C, G, S, relu);
+    hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((C + 255) / 256), dim3(256), 0, st, part2, dgamma, dbeta, N, C, G, S);
     DGX_LAUNCH_CHECK();
     return DGX_OK;
 }

@@ -306,9 +306,25 @@ def main():
             line["buckets_reduced_during_backward"] = "%d/%d" % (reducer.last_early, len(reducer.buckets))
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a.swin)
-        print(json.dumps(line))
+    # RCCL writes its version banner to the C-level stdout, which is block-buffered when redirected and would otherwise be
+    # flushed at exit, i.e. AFTER the JSON: every rank drains it (and they meet) before rank 0 prints, so that the JSON
+    # line is the last line on the job's stdout.
+    def drain():
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        sys.stdout.flush()
+    drain()
     if dist.is_initialized():
+        if world > 1:
+            dist.barrier()
         dist.destroy_process_group()
+    drain()
+    if rank == 0:
+        sys.stdout.flush()
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

@@ -79,9 +79,12 @@ __global__ __launch_bounds__(WinCfg<WS>::NT * 64) void win_attn_fwd_kernel(
     constexpr int N = Cf::N, NT = Cf::NT, NTK = Cf::NTK, NP = NTK * 16, RS = Cf::RS, TBL = Cf::TBL;
     constexpr int RR = 40;   // row stride (elements) of the row-major V image
     __shared__ __attribute__((aligned(16))) uint16_t Vs[NP * RR];
+    __shared__ __attribute__((aligned(16))) uint16_t Ks[NP * RR];   // K rows too: one coalesced load per workgroup instead of
+                                                                    // nine per-wave passes over K with their global latencies
     __shared__ float tbl[TBL];
     __shared__ __attribute__((aligned(16))) int koff_s[NP];   // rel-pos offset of key k: yk*(2WS-1) + xk
     __shared__ __attribute__((aligned(16))) int kreg_s[NP];   // region id of key k (this window); padded keys: -1
+    static_assert(TBL <= NT * 64 && NP <= NT * 64 && NP * 4 <= 2 * NT * 64, "one prologue load per thread and array");
 
     int b, h;
     block_to_window_head(blockIdx.x, nH, b, h);
@@ -90,22 +93,38 @@ __global__ __launch_bounds__(WinCfg<WS>::NT * 64) void win_attn_fwd_kernel(
     const int64_t rowst = 3 * (int64_t)C;
     const uint16_t* base = qkv + (int64_t)b * N * rowst + h * 32;
     const int tid = threadIdx.x, nthreads = NT * 64;
-
-    const int8_t* reg = region + (int64_t)(b % nW) * N;
-    for (int i = tid; i < TBL; i += nthreads) tbl[i] = table[h * t_sh + i * t_si] * DGX_LOG2E;
-    for (int i = tid; i < NP; i += nthreads) {
-        const int yk = i / WS;
-        koff_s[i] = i < N ? yk * (2 * WS - 1) + (i - yk * WS) : 0;
-        kreg_s[i] = (MASKED && i < N) ? (int)reg[i] : -1;
-    }
-    stage_rows<N, NP, RR>(Vs, base + 2 * C, rowst, tid, nthreads);
-    __syncthreads();
-
     const int w = tid >> 6, l = tid & 63, g = l >> 4, c16 = l & 15;
     const int qi = 16 * w + c16;
     const bool qok = qi < N;
-    const bf16x8 qf = ld_frag_global(base + (int64_t)qi * rowst + 8 * g, qok);
+
+    // ---- every global load of the workgroup is issued here, back to back (ONE memory latency), then parked in LDS
+    const int8_t* reg = region + (int64_t)(b % nW) * N;
+    const float tv = tid < TBL ? table[h * t_sh + tid * t_si] : 0.f;
+    const int kr_in = (MASKED && tid < N) ? (int)reg[tid] : -1;
     const int rq = (MASKED && qok) ? (int)reg[qi] : 0;
+    const int u0 = tid, u1 = tid + nthreads;                       // 16-byte chunks of the K / V images: row u >> 2, chunk u & 3
+    const bf16x8 k0 = ld_frag_global(base + C + (int64_t)(u0 >> 2) * rowst + 8 * (u0 & 3), (u0 >> 2) < N);
+    const bf16x8 v0 = ld_frag_global(base + 2 * C + (int64_t)(u0 >> 2) * rowst + 8 * (u0 & 3), (u0 >> 2) < N);
+    const bool two = u1 < NP * 4;
+    const bf16x8 k1 = ld_frag_global(base + C + (int64_t)(u1 >> 2) * rowst + 8 * (u1 & 3), two && (u1 >> 2) < N);
+    const bf16x8 v1 = ld_frag_global(base + 2 * C + (int64_t)(u1 >> 2) * rowst + 8 * (u1 & 3), two && (u1 >> 2) < N);
+    const bf16x8 qf = ld_frag_global(base + (int64_t)qi * rowst + 8 * g, qok);
+    if (tid < TBL) tbl[tid] = tv * DGX_LOG2E;
+    if (tid < NP) {
+        const int yk = tid / WS;
+        koff_s[tid] = tid < N ? yk * (2 * WS - 1) + (tid - yk * WS) : 0;
+        kreg_s[tid] = kr_in;
+    }
+    if (u0 < NP * 4) {
+        *reinterpret_cast<bf16x8*>(&Ks[(u0 >> 2) * RR + 8 * (u0 & 3)]) = k0;
+        *reinterpret_cast<bf16x8*>(&Vs[(u0 >> 2) * RR + 8 * (u0 & 3)]) = v0;
+    }
+    if (two) {
+        *reinterpret_cast<bf16x8*>(&Ks[(u1 >> 2) * RR + 8 * (u1 & 3)]) = k1;
+        *reinterpret_cast<bf16x8*>(&Vs[(u1 >> 2) * RR + 8 * (u1 & 3)]) = v1;
+    }
+    __syncthreads();
+
     const int yq = qi / WS, xq = qi - yq * WS;
     const int base_q = qok ? (yq + WS - 1) * (2 * WS - 1) + (xq + WS - 1) : (WS - 1) * (2 * WS - 1) + (WS - 1);
     const float scale2 = scale * DGX_LOG2E;
@@ -117,8 +136,7 @@ __global__ __launch_bounds__(WinCfg<WS>::NT * 64) void win_attn_fwd_kernel(
     float mx = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < NTK; ++kt) {
-        const int kr = 16 * kt + c16;
-        const bf16x8 kf = ld_frag_global(base + C + (int64_t)kr * rowst + 8 * g, kr < N);
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(&Ks[(16 * kt + c16) * RR + 8 * g]);   // rows >= N are zero
         f32x4 z = {0.f, 0.f, 0.f, 0.f};
         const f32x4 acc = mfma16(kf, qf, z);  // acc[r] = S^T[key 16kt+4g+r][query c16]
         const i32x4 ko = *reinterpret_cast<DGX_LDS const i32x4*>(koff_g + 16 * kt);

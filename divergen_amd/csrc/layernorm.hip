@@ -61,7 +61,9 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-template <typename XT, typename YT = uint16_t>
+// NJ = ceil(C/256) float4 columns per lane: the row is read ONCE into registers (mean, centred variance and the output all
+// come from them); NJ == 0 is the generic three-pass form for rows wider than 1536.
+template <typename XT, typename YT = uint16_t, int NJ = 0>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const XT* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, YT* __restrict__ y,
                                                      float* __restrict__ mean, float* __restrict__ rstd, int64_t T_out,
@@ -69,6 +71,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const XT* __restrict__ x, c
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * 4;
+    const float4* g4 = reinterpret_cast<const float4*>(gamma);
+    const float4* b4 = reinterpret_cast<const float4*>(beta);
     for (int64_t orow = wave; orow < T_out; orow += nwaves) {
         const int64_t tok = m.ws ? win_src(m, orow) : orow;
         YT* yo = y + orow * C;
@@ -77,6 +81,36 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const XT* __restrict__ x, c
             continue;
         }
         const XT* xr = x + tok * C;
+        if (NJ > 0) {
+            float4 v[NJ > 0 ? NJ : 1];
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int i = lane + 64 * j;
+                v[j] = i < C / 4 ? ld4<XT>(xr, i) : make_float4(0.f, 0.f, 0.f, 0.f);
+                s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+            }
+            const float mu = wave_sum(s) / (float)C;
+            float q = 0.f;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                if (lane + 64 * j < C / 4) {
+                    const float a = v[j].x - mu, b = v[j].y - mu, c = v[j].z - mu, d = v[j].w - mu;
+                    q += (a * a + b * b) + (c * c + d * d);
+                }
+            const float rs = rsqrtf(wave_sum(q) / (float)C + eps);
+            if (lane == 0) { mean[tok] = mu; rstd[tok] = rs; }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int i = lane + 64 * j;
+                if (i < C / 4) {
+                    const float4 g = g4[i], b = b4[i];
+                    st4<YT>(yo, i, make_float4((v[j].x - mu) * rs * g.x + b.x, (v[j].y - mu) * rs * g.y + b.y,
+                                               (v[j].z - mu) * rs * g.z + b.z, (v[j].w - mu) * rs * g.w + b.w));
+                }
+            }
+            continue;
+        }
         float s = 0.f;
         for (int i = lane; i < C / 4; i += 64) { const float4 v = ld4<XT>(xr, i); s += (v.x + v.y) + (v.z + v.w); }
         const float mu = wave_sum(s) / (float)C;
@@ -88,8 +122,6 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const XT* __restrict__ x, c
         }
         const float rs = rsqrtf(wave_sum(q) / (float)C + eps);
         if (lane == 0) { mean[tok] = mu; rstd[tok] = rs; }
-        const float4* g4 = reinterpret_cast<const float4*>(gamma);
-        const float4* b4 = reinterpret_cast<const float4*>(beta);
         for (int i = lane; i < C / 4; i += 64) {
             const float4 v = ld4<XT>(xr, i), g = g4[i], b = b4[i];
             st4<YT>(yo, i, make_float4((v.x - mu) * rs * g.x + b.x, (v.y - mu) * rs * g.y + b.y,
@@ -222,12 +254,19 @@ extern "C" int dgx_layernorm_fwd(const void* x, const float* gamma, const float*
     const WinMap m = make_map(B, H, W, ws, shift);
     const int64_t T_out = ws > 0 ? (int64_t)B * m.nWh * m.nWw * ws * ws : T;
     const int grid = (int)((T_out + 3) / 4 < 8192 ? (T_out + 3) / 4 : 8192);
-    if (x_dtype == DGX_BF16)
-        hipLaunchKernelGGL(ln_fwd_kernel<uint16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, gamma,
-                           beta, (uint16_t*)y_bf16, mean, rstd, T_out, C, eps, m);
-    else
-        hipLaunchKernelGGL(ln_fwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)x, gamma, beta,
-                           (uint16_t*)y_bf16, mean, rstd, T_out, C, eps, m);
+    const int nj = (C + 255) / 256;
+#define LN_FWD(XT, YT, YP, NJ) hipLaunchKernelGGL((ln_fwd_kernel<XT, YT, NJ>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const XT*)x, \
+                                                  gamma, beta, (YT*)YP, mean, rstd, T_out, C, eps, m)
+#define LN_FWD_NJ(XT, YT, YP)                                                                                          \
+    do {                                                                                                               \
+        if (nj <= 1) LN_FWD(XT, YT, YP, 1);                                                                            \
+        else if (nj <= 2) LN_FWD(XT, YT, YP, 2);                                                                       \
+        else if (nj <= 3) LN_FWD(XT, YT, YP, 3);                                                                       \
+        else if (nj <= 6) LN_FWD(XT, YT, YP, 6);                                                                       \
+        else LN_FWD(XT, YT, YP, 0);                                                                                    \
+    } while (0)
+    if (x_dtype == DGX_BF16) LN_FWD_NJ(uint16_t, uint16_t, y_bf16);
+    else LN_FWD_NJ(float, uint16_t, y_bf16);
     DGX_LAUNCH_CHECK();
     return DGX_OK;
 }
@@ -458,12 +497,10 @@ extern "C" int dgx_layernorm_f32out_fwd(const void* x, const float* gamma, const
     if (!x || !gamma || !beta || !y || !mean || !rstd || (C & 3)) return DGX_ERR_BAD_ARG;
     const WinMap m = make_map(0, 0, 0, 0, 0);
     const int grid = (int)((T + 3) / 4 < 8192 ? (T + 3) / 4 : 8192);
-    if (x_dtype == DGX_BF16)
-        hipLaunchKernelGGL((ln_fwd_kernel<uint16_t, float>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x,
-                           gamma, beta, y, mean, rstd, T, C, eps, m);
-    else
-        hipLaunchKernelGGL((ln_fwd_kernel<float, float>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)x, gamma,
-                           beta, y, mean, rstd, T, C, eps, m);
+    const int nj = (C + 255) / 256;
+    const int64_t T_out = T;
+    if (x_dtype == DGX_BF16) LN_FWD_NJ(uint16_t, float, y);
+    else LN_FWD_NJ(float, float, y);
     DGX_LAUNCH_CHECK();
     return DGX_OK;
 }

@@ -1,0 +1,415 @@
+// bf16 GEMM with fused epilogues for gfx950:  C[M][N] = epi( sum_k A[m][k] * B[n][k] ),  A (M,K), B (N,K) row-major
+// (both operands K-contiguous: y = x W^T of nn.Linear as stored; the input gradient dx = dy W runs on the transposed
+// weight image the optimizer step refreshes, so it is the same kernel).  Replaces the hipBLASLt calls behind
+// torch.addmm / torch.mm at the Linear sites of the reference: swintransformer.py:133,155 (qkv / proj), :40-46 (Mlp),
+// :296 (PatchMerging.reduction), fpn.py:126-154 (1x1 laterals), box_head.py:26-98 (FCs).
+//
+// Structure (one workgroup = one BM x BN output tile, 8 waves = 2 (M) x 4 (N), K-step 64):
+//   * both operand tiles go global -> LDS with LDS-direct loads (`buffer_load_dwordx4 ... lds`, no staging registers):
+//     one wave-instruction = 8 tile rows x 128 B = 8 whole cache lines; rows are 128 B in LDS, the 16-byte chunk index
+//     is XOR-swizzled with (row >> 1) & 7 (applied to the per-lane SOURCE address, the LDS image of an instruction is
+//     lane-linear), which makes every ds_read_b128 of an MFMA fragment (16 rows x one chunk column) bank-conflict free;
+//   * two LDS stages; the 8 waves form two groups (waves 0-3 / 4-7 = one wave of each group per SIMD) that run the
+//     same per-K-tile program {read all fragments of the tile into registers | 2*WMF*WNF MFMAs} one phase apart: while
+//     one wave of a SIMD issues MFMAs back to back, its partner reads LDS and issues the loads of the tile after next.
+//     A stage is re-filled as soon as both groups have read it and has ~two phases to land (counted only by vmcnt(0)
+//     at the end of the phase before its first read; raw s_barrier, so LDS-direct loads stay in flight across barriers);
+//   * MFMA operands are swapped (D = W-fragment x X-fragment) so that a lane holds 4 CONSECUTIVE output columns of one
+//     row: the epilogue packs them to bf16, stages the whole tile in LDS (stage buffers are idle by then) and streams
+//     it out as whole rows, 16 B per lane, with the fused tail (bias | bias + exact GELU with both tensors written |
+//     bias + window_reverse/roll/crop + DropPath + residual add | multiply by GELU'(f1)) applied on the way out;
+//   * XCD-aware tile order: workgroups of one XCD (blockIdx % 8) take consecutive tiles = the same A row-panel.
+#include "dgx_common.h"
+
+namespace {
+constexpr int GBK = 64;                 // K-step (elements): 128-byte tile rows
+constexpr uint32_t G_OOB = 0x80000000u; // voffset beyond num_records: the lane's 16 bytes land in LDS as zeros
+
+struct GMap { int B, H, W, ws, shift, nWh, nWw; };   // residual.hip's RMap
+
+struct GemmP {
+    const uint16_t* A;
+    const uint16_t* B;
+    int M, N, K, lda, ldb;
+    int tiles_n, total, per_xcd;
+    int mode;
+    uint16_t* C;            // bf16 (M, ldc): modes 0, 1, 2 (pre-activation), 4
+    int ldc;
+    const uint16_t* bias;   // bf16 (N) or null
+    uint16_t* C2;           // mode 2: GELU(C)
+    const uint16_t* aux;    // mode 4: f1 (M, ldaux)
+    int ldaux;
+    const void* res;        // mode 3: residual stream (tokens, N) fp32 | bf16
+    void* out;              //         out = res + scale[b] * y
+    const float* scale;     //         per-sample DropPath factor or null
+    int res_dtype;
+    GMap map;
+};
+
+__device__ __forceinline__ void g_load_lds16(uint32_t voff, u32x4 rsrc, uint32_t lds_addr, uint32_t soff) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" ::"v"(voff), "s"(rsrc), "s"(lds_addr), "s"(soff)
+                 : "memory");
+}
+__device__ __forceinline__ u32x4 g_rsrc(const void* base, uint32_t bytes) {
+    const uint64_t a = (uint64_t)base;
+    return u32x4{(uint32_t)a, (uint32_t)(a >> 32) & 0xffffu, bytes, 0x00020000u};
+}
+template <int N> __device__ __forceinline__ void g_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void g_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void g_bar() {
+    asm volatile("s_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+constexpr float kGInvSqrt2 = 0.70710678118654752440f;
+constexpr float kGInvSqrt2Pi = 0.39894228040143267794f;
+__device__ __forceinline__ void g_unpack8(const u32x4 r, float (&v)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(r[i] << 16); v[2 * i + 1] = __uint_as_float(r[i] & 0xffff0000u); }
+}
+__device__ __forceinline__ u32x4 g_pack8(const float (&v)[8]) {
+    return u32x4{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+}
+
+// window-order output row -> token index of the (B, H*W) stream, -1 for a padding row (residual.hip: residual_bwd_kernel)
+__device__ __forceinline__ int64_t g_row_token(const GMap& m, int64_t orow, int& b) {
+    if (m.ws == 0) {
+        b = (int)(orow / ((int64_t)m.H * m.W));
+        return orow;
+    }
+    const int Nw = m.ws * m.ws;
+    const int n = (int)(orow % Nw);
+    int64_t t = orow / Nw;
+    const int wc = (int)(t % m.nWw);
+    t /= m.nWw;
+    const int wr = (int)(t % m.nWh);
+    b = (int)(t / m.nWh);
+    int hh = wr * m.ws + n / m.ws + m.shift, ww = wc * m.ws + n % m.ws + m.shift;
+    const int Hp = m.nWh * m.ws, Wp = m.nWw * m.ws;
+    if (hh >= Hp) hh -= Hp;
+    if (ww >= Wp) ww -= Wp;
+    return (hh < m.H && ww < m.W) ? ((int64_t)b * m.H + hh) * m.W + ww : -1;
+}
+
+template <int BM, int BN> struct GemmCfg {
+    static constexpr int WMF = BM / 32;            // 16-row MFMA fragments per wave along M (2 waves)
+    static constexpr int WNF = BN / 64;            // 16-column fragments per wave along N (4 waves)
+    static constexpr int NA = BM / 64;             // LDS-direct loads per wave per K-tile, A rows
+    static constexpr int NB = BN / 64;             //                                      B rows
+    static constexpr int SB = (BM + BN) * 128;     // bytes per stage
+    static constexpr int SROW = BN * 2 + 16;       // epilogue staging row stride (bytes)
+    static constexpr int EPI = BM * SROW + BM * 8; // staged tile + row -> (token, sample) table
+    static constexpr int LDS = (2 * SB > EPI ? 2 * SB : EPI);
+};
+}  // namespace
+
+template <int BM, int BN>
+__global__ __launch_bounds__(512) void gemm_nt_kernel(GemmP P) {
+    using Cfg = GemmCfg<BM, BN>;
+    constexpr int WMF = Cfg::WMF, WNF = Cfg::WNF, NA = Cfg::NA, NB = Cfg::NB, SB = Cfg::SB, SROW = Cfg::SROW;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds_raw[];
+    const int L = (blockIdx.x & 7) * P.per_xcd + (blockIdx.x >> 3);
+    if (L >= P.total) return;
+    const int tm = L / P.tiles_n, tn = L - tm * P.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int tid = threadIdx.x, l = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = w >> 2, wc = w & 3;            // group = M half of the tile (waves 0-3: rows 0 .. BM/2)
+    const int c = l & 15, g = l >> 4;
+    const int NT = (P.K + GBK - 1) / GBK;
+    const int ktail = P.K - (NT - 1) * GBK;        // elements of the last K-tile (64 when K % 64 == 0)
+
+    // ---- loader role: instruction q = w + 8 s of a tile covers tile rows 8q .. 8q+7 (A rows first, then B rows);
+    // lane -> row 8q + (l >> 3), physical chunk l & 7 = logical chunk ^ ((row >> 1) & 7), (q & 1) == (w & 1)
+    const int rsub = l >> 3;
+    const int lc = (l & 7) ^ (((w & 1) << 2) | (rsub >> 1));
+    uint32_t voffA[NA], voffB[NB];
+#pragma unroll
+    for (int s = 0; s < NA; ++s) {
+        const int m = m0 + 8 * (w + 8 * s) + rsub;
+        voffA[s] = m < P.M ? (uint32_t)(((int64_t)m * P.lda + lc * 8) * 2) : G_OOB;
+    }
+#pragma unroll
+    for (int s = 0; s < NB; ++s) {
+        const int n = n0 + 8 * (w + 8 * s) + rsub;
+        voffB[s] = n < P.N ? (uint32_t)(((int64_t)n * P.ldb + lc * 8) * 2) : G_OOB;
+    }
+    const bool kt_ok = lc * 8 < ktail;             // this lane's chunk exists in the last K-tile
+    const u32x4 rA = g_rsrc(P.A, (uint32_t)((int64_t)P.M * P.lda * 2));
+    const u32x4 rB = g_rsrc(P.B, (uint32_t)((int64_t)P.N * P.ldb * 2));
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(DGX_LDS unsigned char*)lds_raw;
+    const uint32_t ldsw = __builtin_amdgcn_readfirstlane(lds0 + 1024u * w);
+    auto issue_tile = [&](int t) {
+        const uint32_t soff = (uint32_t)t * (GBK * 2);
+        const uint32_t dst = ldsw + (uint32_t)(t & 1) * SB;
+        const bool tail = (t == NT - 1) && (ktail != GBK);
+#pragma unroll
+        for (int s = 0; s < NA; ++s) g_load_lds16((tail && !kt_ok) ? G_OOB : voffA[s], rA, dst + 8192u * s, soff);
+#pragma unroll
+        for (int s = 0; s < NB; ++s) g_load_lds16((tail && !kt_ok) ? G_OOB : voffB[s], rB, dst + BM * 128 + 8192u * s, soff);
+    };
+
+    // ---- MFMA role: wave tile = rows grp*BM/2 .. (+16 i + c), columns wc*BN/4 .. (+16 j + c); a fragment (16 rows, k-half kh)
+    // is one ds_read_b128 per lane: row c, logical chunk g + 4 kh -> physical (g ^ swz) ^ 4 kh, swz = (c >> 1) & 7
+    const int swz = (c >> 1) & 7;
+    const uint32_t la = (uint32_t)((grp * (BM / 2) + c) * 128 + ((g ^ swz) << 4));
+    const uint32_t lb = (uint32_t)((BM + wc * (BN / 4) + c) * 128 + ((g ^ swz) << 4));
+    f32x4 acc[WMF][WNF];
+#pragma unroll
+    for (int i = 0; i < WMF; ++i)
+#pragma unroll
+        for (int j = 0; j < WNF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 af[WMF][2], bfr[WNF][2];
+    auto read_frags = [&](int t) {
+        DGX_LDS const unsigned char* sa = lds_opaque((const unsigned char*)lds_raw + (t & 1) * SB + la);
+        DGX_LDS const unsigned char* sa1 = lds_opaque((const unsigned char*)lds_raw + (t & 1) * SB + (la ^ 64u));
+        DGX_LDS const unsigned char* sb = lds_opaque((const unsigned char*)lds_raw + (t & 1) * SB + lb);
+        DGX_LDS const unsigned char* sb1 = lds_opaque((const unsigned char*)lds_raw + (t & 1) * SB + (lb ^ 64u));
+#pragma unroll
+        for (int j = 0; j < WNF; ++j) {
+            bfr[j][0] = *reinterpret_cast<DGX_LDS const bf16x8*>(sb + 2048 * j);
+            bfr[j][1] = *reinterpret_cast<DGX_LDS const bf16x8*>(sb1 + 2048 * j);
+        }
+#pragma unroll
+        for (int i = 0; i < WMF; ++i) {
+            af[i][0] = *reinterpret_cast<DGX_LDS const bf16x8*>(sa + 2048 * i);
+            af[i][1] = *reinterpret_cast<DGX_LDS const bf16x8*>(sa1 + 2048 * i);
+        }
+    };
+    auto mfmas = [&]() {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+            for (int i = 0; i < WMF; ++i)
+#pragma unroll
+                for (int j = 0; j < WNF; ++j) acc[i][j] = mfma16(bfr[j][kh], af[i][kh], acc[i][j]);   // D[n][m]: lane = 4 columns of a row
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // ---- main loop.  Intervals between barriers I_0, I_1, ...: group 0 reads tile t in I_{2t+1} and multiplies in I_{2t+2};
+    // group 1 reads in I_{2t+2} and multiplies in I_{2t+3}.  Tile t+2 replaces tile t in its stage: issued by both groups in
+    // I_{2t+3} (after the barrier that follows group 1's reads of tile t), waited for by every wave before the barrier that
+    // opens I_{2t+5}.
+    issue_tile(0);
+    if (NT > 1) {
+        issue_tile(1);
+        g_vmcnt<NA + NB>();
+    } else {
+        g_vmcnt<0>();
+    }
+    g_bar();                                       // #0: tile 0 visible to everyone
+    if (grp == 0) {
+        for (int t = 0; t < NT; ++t) {
+            if (t >= 1 && t + 1 < NT) issue_tile(t + 1);
+            read_frags(t);
+            g_lgkm0();
+            g_bar();                               // #(2t+1)
+            mfmas();
+            g_vmcnt<0>();                          // tile t+1 landed (own share)
+            g_bar();                               // #(2t+2)
+        }
+        g_bar();                                   // group 1's last phase
+    } else {
+        g_bar();                                   // #1: one phase behind group 0
+        for (int t = 0; t < NT; ++t) {
+            read_frags(t);
+            g_lgkm0();
+            g_vmcnt<0>();                          // tile t+1 landed (own share)
+            g_bar();                               // #(2t+2)
+            if (t + 2 < NT) issue_tile(t + 2);
+            mfmas();
+            g_bar();                               // #(2t+3)
+        }
+    }
+
+    // ---- epilogue: stage the tile as bf16 (bias added) in LDS, then stream whole rows out with the fused tail
+    DGX_LDS unsigned char* stg = (DGX_LDS unsigned char*)lds_raw;
+    {
+        const int colw = wc * (BN / 4) + 4 * g;    // + 16 j: this lane's 4 consecutive columns
+        float bv[WNF][4];
+#pragma unroll
+        for (int j = 0; j < WNF; ++j) {
+            const int n = n0 + colw + 16 * j;
+            uint32_t b01 = 0, b23 = 0;
+            if (P.bias && n < P.N) {
+                const uint2 raw = *reinterpret_cast<const uint2*>(P.bias + n);
+                b01 = raw.x;
+                b23 = raw.y;
+            }
+            bv[j][0] = __uint_as_float(b01 << 16); bv[j][1] = __uint_as_float(b01 & 0xffff0000u);
+            bv[j][2] = __uint_as_float(b23 << 16); bv[j][3] = __uint_as_float(b23 & 0xffff0000u);
+        }
+#pragma unroll
+        for (int i = 0; i < WMF; ++i) {
+            const int row = grp * (BM / 2) + 16 * i + c;
+#pragma unroll
+            for (int j = 0; j < WNF; ++j) {
+                const f32x4 a = acc[i][j];
+                const uint2 pk = {pack_bf2(a[0] + bv[j][0], a[1] + bv[j][1]), pack_bf2(a[2] + bv[j][2], a[3] + bv[j][3])};
+                *reinterpret_cast<DGX_LDS uint2*>(stg + row * SROW + (colw + 16 * j) * 2) = pk;
+            }
+        }
+    }
+    DGX_LDS int64_t* rowtok = reinterpret_cast<DGX_LDS int64_t*>(stg + BM * SROW);   // mode 3: (token << 8 | sample) per tile row
+    if (P.mode == 3 && tid < BM) {
+        int b = 0;
+        const int64_t orow = (int64_t)m0 + tid;
+        const int64_t tok = orow < P.M ? g_row_token(P.map, orow, b) : -1;
+        rowtok[tid] = tok < 0 ? -1 : ((tok << 12) | (int64_t)b);
+    }
+    __syncthreads();
+    constexpr int CPR = BN / 8;                    // 16-byte chunks per tile row
+    for (int idx = tid; idx < BM * CPR; idx += 512) {
+        const int row = idx / CPR, ch = idx - row * CPR;
+        const int gm = m0 + row, gn = n0 + 8 * ch;
+        if (gm >= P.M || gn >= P.N) continue;
+        const u32x4 y = *reinterpret_cast<DGX_LDS const u32x4*>(stg + row * SROW + ch * 16);
+        if (P.mode <= 1) {
+            *reinterpret_cast<u32x4*>(P.C + (int64_t)gm * P.ldc + gn) = y;
+        } else if (P.mode == 2) {
+            *reinterpret_cast<u32x4*>(P.C + (int64_t)gm * P.ldc + gn) = y;
+            float v[8], o[8];
+            g_unpack8(y, v);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = 0.5f * v[k] * (1.0f + erff(v[k] * kGInvSqrt2));
+            *reinterpret_cast<u32x4*>(P.C2 + (int64_t)gm * P.ldc + gn) = g_pack8(o);
+        } else if (P.mode == 4) {
+            float gq[8], v[8], d[8];
+            g_unpack8(y, gq);
+            g_unpack8(*reinterpret_cast<const u32x4*>(P.aux + (int64_t)gm * P.ldaux + gn), v);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float cdf = 0.5f * (1.0f + erff(v[k] * kGInvSqrt2));
+                const float pdf = __expf(-0.5f * v[k] * v[k]) * kGInvSqrt2Pi;
+                d[k] = gq[k] * (cdf + v[k] * pdf);
+            }
+            *reinterpret_cast<u32x4*>(P.C + (int64_t)gm * P.ldc + gn) = g_pack8(d);
+        } else {                                   // mode 3
+            const int64_t rt = rowtok[row];
+            if (rt < 0) continue;
+            const int64_t tok = rt >> 12;
+            const float s = P.scale ? P.scale[(int)(rt & 4095)] : 1.0f;
+            float yv[8], xv[8];
+            g_unpack8(y, yv);
+            const int64_t o = tok * P.N + gn;
+            if (P.res_dtype == DGX_BF16) {
+                g_unpack8(*reinterpret_cast<const u32x4*>((const uint16_t*)P.res + o), xv);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) xv[k] += s * yv[k];
+                *reinterpret_cast<u32x4*>((uint16_t*)P.out + o) = g_pack8(xv);
+            } else {
+                const float4 x0 = reinterpret_cast<const float4*>((const float*)P.res + o)[0];
+                const float4 x1 = reinterpret_cast<const float4*>((const float*)P.res + o)[1];
+                reinterpret_cast<float4*>((float*)P.out + o)[0] = make_float4(x0.x + s * yv[0], x0.y + s * yv[1], x0.z + s * yv[2], x0.w + s * yv[3]);
+                reinterpret_cast<float4*>((float*)P.out + o)[1] = make_float4(x1.x + s * yv[4], x1.y + s * yv[5], x1.z + s * yv[6], x1.w + s * yv[7]);
+            }
+        }
+    }
+}
+
+namespace {
+struct TileChoice { int bm, bn; };
+
+// Tile selection: BN from the divisibility of N (every Swin width is a multiple of 192), BM from how well the tile count
+// fills whole rounds of 256 CUs (one workgroup per CU), weighted by the CU-side efficiency of the smaller tiles.
+TileChoice choose_tile(int M, int N) {
+    const char* env = getenv("DGX_GEMM_TILE");
+    if (env) {
+        int bm = 0, bn = 0;
+        if (sscanf(env, "%dx%d", &bm, &bn) == 2 && (bm == 256 || bm == 192 || bm == 128) && (bn == 192 || bn == 128 || bn == 256) &&
+            !(bm == 256 && bn == 256) && !(bm == 192 && bn != 192))
+            return {bm, bn};
+    }
+    int bn;
+    if (N % 192 == 0) bn = 192;
+    else if (N % 256 == 0 || N > 1024) bn = 256;
+    else bn = 128;
+    const int cand[3] = {256, 192, 128};
+    const double eff[3] = {1.0, 0.97, 0.85};
+    double best = -1.0;
+    int bm = 128;
+    for (int i = 0; i < 3; ++i) {
+        const int b = cand[i];
+        if (bn == 256 && b == 256) continue;       // 256x256 does not fit two waves per SIMD (register file)
+        if (bn != 192 && b == 192) continue;       // instantiated for BN = 192 only
+        const int64_t tiles = (int64_t)((M + b - 1) / b) * ((N + bn - 1) / bn);
+        const int64_t rounds = (tiles + 255) / 256;
+        const double fill = (double)M * N / ((double)rounds * 256 * b * bn);
+        const double sc = fill * eff[i];
+        if (sc > best) { best = sc; bm = b; }
+    }
+    return {bm, bn};
+}
+
+template <int BM, int BN>
+int launch_gemm(GemmP& P, hipStream_t st) {
+    using Cfg = GemmCfg<BM, BN>;
+    const int tiles_m = (P.M + BM - 1) / BM;
+    P.tiles_n = (P.N + BN - 1) / BN;
+    P.total = tiles_m * P.tiles_n;
+    P.per_xcd = (P.total + 7) / 8;
+    static bool once = false;
+    if (!once) {
+        if (hipFuncSetAttribute((const void*)gemm_nt_kernel<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS) != hipSuccess)
+            return DGX_ERR_UNSUPPORTED;
+        once = true;
+    }
+    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN>), dim3(8 * P.per_xcd), dim3(512), Cfg::LDS, st, P);
+    DGX_LAUNCH_CHECK();
+    return DGX_OK;
+}
+}  // namespace
+
+extern "C" int dgx_gemm_bf16_nt(const void* A, const void* B, int M, int N, int K, int64_t lda, int64_t ldb,
+                                const dgx_gemm_epilogue* ep, void* stream) {
+    if (M <= 0 || N <= 0) return DGX_OK;
+    if (!A || !B || !ep || K <= 0 || (K & 7) || (N & 7) || (lda & 7) || (ldb & 7) || lda < K || ldb < K) return DGX_ERR_BAD_ARG;
+    if ((int64_t)M * lda * 2 >= (1ll << 31) || (int64_t)N * ldb * 2 >= (1ll << 31)) return DGX_ERR_UNSUPPORTED;
+    GemmP P;
+    memset(&P, 0, sizeof(P));
+    P.A = (const uint16_t*)A; P.B = (const uint16_t*)B;
+    P.M = M; P.N = N; P.K = K; P.lda = (int)lda; P.ldb = (int)ldb;
+    P.mode = ep->mode;
+    P.C = (uint16_t*)ep->c; P.ldc = (int)ep->ldc;
+    P.bias = (const uint16_t*)ep->bias;
+    P.C2 = (uint16_t*)ep->c2;
+    P.aux = (const uint16_t*)ep->aux; P.ldaux = (int)ep->ldaux;
+    P.res = ep->residual; P.out = ep->out; P.scale = ep->scale; P.res_dtype = ep->residual_dtype;
+    switch (ep->mode) {
+        case DGX_EPI_NONE: case DGX_EPI_BIAS:
+            if (!ep->c || ep->ldc < N || (ep->ldc & 7)) return DGX_ERR_BAD_ARG;
+            if (ep->mode == DGX_EPI_NONE) P.bias = nullptr;
+            break;
+        case DGX_EPI_BIAS_GELU:
+            if (!ep->c || !ep->c2 || ep->ldc < N || (ep->ldc & 7)) return DGX_ERR_BAD_ARG;
+            break;
+        case DGX_EPI_GELU_GRAD:
+            if (!ep->c || !ep->aux || ep->ldc < N || ep->ldaux < N || (ep->ldc & 7) || (ep->ldaux & 7)) return DGX_ERR_BAD_ARG;
+            P.bias = nullptr;
+            break;
+        case DGX_EPI_BIAS_RESIDUAL: {
+            if (!ep->residual || !ep->out || ep->B <= 0 || ep->H <= 0 || ep->W <= 0 || ep->B > 4095 || ep->shift < 0 ||
+                (ep->ws > 0 && ep->shift >= ep->ws) || (ep->residual_dtype != DGX_F32 && ep->residual_dtype != DGX_BF16))
+                return DGX_ERR_BAD_ARG;
+            GMap m = {ep->B, ep->H, ep->W, ep->ws, ep->shift, 0, 0};
+            if (ep->ws > 0) { m.nWh = (ep->H + ep->ws - 1) / ep->ws; m.nWw = (ep->W + ep->ws - 1) / ep->ws; }
+            const int64_t rows = ep->ws > 0 ? (int64_t)ep->B * m.nWh * m.nWw * ep->ws * ep->ws : (int64_t)ep->B * ep->H * ep->W;
+            if (rows != M) return DGX_ERR_BAD_ARG;
+            P.map = m;
+            break;
+        }
+        default: return DGX_ERR_BAD_ARG;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const TileChoice tc = choose_tile(M, N);
+    if (tc.bn == 192) {
+        if (tc.bm == 256) return launch_gemm<256, 192>(P, st);
+        if (tc.bm == 192) return launch_gemm<192, 192>(P, st);
+        return launch_gemm<128, 192>(P, st);
+    }
+    if (tc.bn == 256) return launch_gemm<128, 256>(P, st);
+    if (tc.bm == 256) return launch_gemm<256, 128>(P, st);
+    return launch_gemm<128, 128>(P, st);
+}

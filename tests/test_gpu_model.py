@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _build(graph):
+def _build(graph, swin="T"):
     os.environ["DGX_GRAPH_BACKBONE"] = "1" if graph else "0"
     from divergen_amd.config import get_cfg
     from divergen_amd.modeling import build_model
@@ -17,7 +17,7 @@ def _build(graph):
     from divergen_amd.solver import build_optimizer
     cfg = get_cfg()
     cfg.merge_from_file(os.path.join(ROOT, "tests", "configs", "DiverGen_swinL.yaml"))
-    cfg.merge_from_list(["MODEL.SWIN.SIZE", "T", "MODEL.ROI_BOX_HEAD.CAT_FREQ_PATH",
+    cfg.merge_from_list(["MODEL.SWIN.SIZE", swin, "MODEL.ROI_BOX_HEAD.CAT_FREQ_PATH",
                          os.path.join(ROOT, "tests", "configs", "metadata", "ImageNet2012_filtered04_lvis_v1_train_cat_info_250.json")])
     torch.manual_seed(42)
     model = build_model(cfg).train()
@@ -141,6 +141,10 @@ def test_bf16_product_path_tracks_fp32_path():
 
 
 def test_end_to_end_losses_vs_assembled_oracle(monkeypatch):
+    run_e2e_vs_oracle(monkeypatch, "T", 256)
+
+
+def run_e2e_vs_oracle(monkeypatch, swin, size):
     """Whole training forward against the assembled CPU oracle (oracle/model.py): same weights, same batch, the two
     random draws of the step replaced by the same deterministic rule on both sides, the product's proposals handed to
     the oracle (with near-tied scores the top-k/NMS survivor SET is not stable under fp32 reordering between two
@@ -171,9 +175,9 @@ def test_end_to_end_losses_vs_assembled_oracle(monkeypatch):
 
     monkeypatch.setattr(RH, "subsample_labels", det_sample)
     monkeypatch.setattr(FR, "fed_loss_class_mask", det_fed_mask)
-    cfg, model, opt = _build(False)
+    cfg, model, opt = _build(False, swin)
     model.fp16 = False
-    batch = synthetic_batch(2, 256, cfg.MODEL.ROI_HEADS.NUM_CLASSES, device="cuda")
+    batch = synthetic_batch(2, size, cfg.MODEL.ROI_HEADS.NUM_CLASSES, device="cuda")
     captured = {}
     orig = model.roi_heads.forward
 
@@ -200,7 +204,7 @@ def test_end_to_end_losses_vs_assembled_oracle(monkeypatch):
     def o_fed(k, gtc, K, Cn, weight):
         return det_fed_mask(gtc, K, Cn, weight).nonzero().squeeze(1)
     with torch.no_grad():
-        fp, regs, hms = OM.backbone_and_dense(p, images, "T")
+        fp, regs, hms = OM.backbone_and_dense(p, images, swin)
         want = dict(OM.centernet_losses(regs, hms, [g["boxes"] for g in gts]))
         want.update(OM.roi_head_losses(p, fp, captured["props"], gts, [tuple(b["instances"].image_size) for b in batch], C,
                                        cfg.MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE, cfg.MODEL.ROI_HEADS.POSITIVE_FRACTION, fw,

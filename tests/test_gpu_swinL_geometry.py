@@ -1,0 +1,111 @@
+"""GPU parity at the geometry `bench.py` times (BASELINE configs[2]: Swin-L, window 12, 1024 px, 2 images/GPU).
+
+The kernel tests elsewhere use small window batches; at the benchmarked sizes the attention kernels walk CHUNKS of windows
+per workgroup (register prefetch of the next window, bias-table gradient accumulated across the chunk), which small batches
+never reach.  Here the same C-ABI entry points run on the exact launch shapes of the four Swin-L stages at 1024 px
+(968x6, 242x12, 72x24, 18x48 window-heads of 144 tokens) against the fp32 oracle math on the same bf16 inputs, a Swin-L
+stage-0 BasicLayer pair (W-MSA + SW-MSA on the 264-padded grid) runs against oracle/swin.py, and the registry-built
+Swin-L model runs a whole training forward against the assembled oracle.
+Reference: DG/divergen/modeling/backbone/swintransformer.py:126-157 (WindowAttention), :201-257 (block), :361-400
+(BasicLayer + shift mask)."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+from divergen_amd import layers as la  # noqa: E402
+from oracle import swin as OSW  # noqa: E402
+from tests.test_gpu_kernels import _attn_ref, bf  # noqa: E402
+
+
+# (B_, nH, grid side H of the stage at 1024 px, masked): 2 images, window 12
+@pytest.mark.parametrize("B_,nH,H,masked", [(968, 6, 256, True), (968, 6, 256, False), (242, 12, 128, True),
+                                            (72, 24, 64, True), (18, 48, 32, True), (18, 48, 32, False)])
+def test_window_attention_at_bench_geometry(B_, nH, H, masked):
+    ws, N = 12, 144
+    nW = (-(-H // ws)) ** 2
+    assert B_ == 2 * nW
+    g = torch.Generator().manual_seed(B_ + nH)
+    qkv = bf(torch.randn(B_, N, 3 * nH * 32, generator=g) * 1.5)
+    table = torch.randn((2 * ws - 1) ** 2, nH, generator=g)
+    region = la.shift_regions(H, H, ws) if masked else None           # the ids the model feeds the kernel
+    assert region is None or tuple(region.shape) == (nW, N)
+    scale = 32 ** -0.5
+    go = bf(torch.randn(B_, N, nH * 32, generator=g))
+    qr = qkv.clone().float().requires_grad_(True)
+    tr = table.clone().requires_grad_(True)
+    ref = _attn_ref(qr, tr, region, nH, ws, scale)
+    ref.backward(go.float())
+
+    qd = qkv.to(DEV).requires_grad_(True)
+    td = table.to(DEV).requires_grad_(True)
+    out = la.window_attention_core(qd, td, region.to(DEV) if masked else None, nW if masked else 1, nH, ws, scale)
+    out.backward(go.to(DEV))
+    torch.cuda.synchronize()
+
+    def close(a, b, frac):
+        err, sc = float((a - b).abs().max()), float(b.abs().max())
+        assert err <= frac * sc, (err, sc)
+    # bf16 I/O, bf16 P / dS operands, fp32 accumulation: 1.5 % of the tensor's scale (the bar of the small-batch test)
+    close(out.float().cpu(), ref.detach(), 0.015)
+    close(qd.grad.float().cpu(), qr.grad, 0.015)
+    # the bias-table gradient sums B_/nW * N*N terms per entry in fp32 atomics across workgroup chunks: same 1.5 %
+    close(td.grad.cpu(), tr.grad, 0.015)
+
+
+def test_swinL_stage0_layer_pair_vs_oracle():
+    """BasicLayer of Swin-L stage 0 at 1024 px: 256x256 tokens (padded to 264 for window 12), C = 192, 6 heads, one W-MSA
+    and one SW-MSA block + PatchMerging, one image; product under bf16 autocast (fused block path through the arenas) vs
+    oracle/swin.py fp32 with the same weights: forward, input gradient and two parameter gradients."""
+    from divergen_amd.modeling.backbone.swintransformer import BasicLayer, PatchMerging
+    from divergen_amd.solver import FlatArena
+    torch.manual_seed(3)
+    C, nH, ws, H = 192, 6, 12, 256
+    layer = BasicLayer(dim=C, depth=2, num_heads=nH, window_size=ws, drop_path=0.0, downsample=PatchMerging)
+    for n_, p_ in layer.named_parameters():
+        torch.nn.init.normal_(p_, std=0.04)
+        if "norm" in n_ and n_.endswith("weight"):
+            p_.data.add_(1.0)
+    p = {k: v.detach().clone() for k, v in layer.state_dict().items() if "relative_position_index" not in k}
+    layer = layer.to(DEV).train()
+    arena = FlatArena(layer)
+    g = torch.Generator().manual_seed(9)
+    x0 = torch.randn(1, H * H, C, generator=g)
+    g1 = torch.randn(1, H * H, C, generator=g)
+    g2 = torch.randn(1, (H // 2) ** 2, 2 * C, generator=g)
+
+    xr = x0.clone().requires_grad_(True)
+    pr = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    x_out, x_down, _, _ = OSW.basic_layer(xr, H, H, pr, "", 2, nH, ws, True)
+    ((x_out * g1).sum() + (x_down * g2).sum()).backward()
+
+    arena.zero_grad()
+    x = x0.to(DEV).requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y_out, _, _, y_down, wh, ww = layer(x, H, H)
+    assert (wh, ww) == (H // 2, H // 2)
+    ((y_out.float() * g1.to(DEV)).sum() + (y_down.float() * g2.to(DEV)).sum()).backward()
+    torch.cuda.synchronize()
+
+    def close(a, b, frac):
+        err, sc = float((a - b).abs().max()), float(b.abs().max())
+        assert err <= frac * sc, (err, sc)
+    # same budgets as the reference-golden BasicLayer test (bf16 GEMMs + bf16 attention operands through 2 blocks)
+    close(y_out.float().cpu(), x_out.detach(), 0.03)
+    close(y_down.float().cpu(), x_down.detach(), 0.03)
+    close(x.grad.float().cpu(), xr.grad, 0.05)
+    named = dict(layer.named_parameters())
+    for k in ("blocks.1.attn.qkv.weight", "blocks.0.mlp.fc1.weight", "blocks.1.attn.relative_position_bias_table",
+              "blocks.0.attn.proj.bias", "downsample.reduction.weight"):
+        close(named[k].grad.float().cpu(), pr[k].grad, 0.06)
+
+
+def test_swinL_training_forward_vs_assembled_oracle(monkeypatch):
+    """tests/test_gpu_model.py::test_end_to_end_losses_vs_assembled_oracle on the registry-built Swin-L (L-22k-384,
+    window 12) model at 384 px."""
+    from tests.test_gpu_model import run_e2e_vs_oracle
+    run_e2e_vs_oracle(monkeypatch, "L-22k-384", 384)

@@ -20,6 +20,13 @@ class WgradProblem(ctypes.Structure):
     _fields_ = [("dy", c_p), ("x", c_p), ("gw", c_p), ("M", c_i), ("Nn", c_i), ("Kk", c_i)]
 
 
+class GemmEpilogue(ctypes.Structure):
+    """struct dgx_gemm_epilogue (include/divergen_hip.h)."""
+    _fields_ = [("mode", c_i), ("c", c_p), ("ldc", c_i64), ("bias", c_p), ("c2", c_p), ("aux", c_p), ("ldaux", c_i64),
+                ("residual", c_p), ("out", c_p), ("scale", c_p), ("residual_dtype", c_i),
+                ("B", c_i), ("H", c_i), ("W", c_i), ("ws", c_i), ("shift", c_i)]
+
+
 class ColsumProblem(ctypes.Structure):
     """struct dgx_colsum_problem (include/divergen_hip.h)."""
     _fields_ = [("dy", c_p), ("out", c_p), ("M", c_i), ("N", c_i)]
@@ -82,6 +89,7 @@ SIGNATURES = {
     "dgx_colsum_grouped": (c_i, [ctypes.POINTER(ColsumProblem), c_i, c_f, c_p, c_p]),
     "dgx_residual_fwd": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "dgx_residual_bwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "dgx_gemm_bf16_nt": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i64, c_i64, ctypes.POINTER(GemmEpilogue), c_p]),
     "dgx_adamw_ema_step": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_f,
                                  c_p, c_p, c_i, c_p, c_p]),
 }

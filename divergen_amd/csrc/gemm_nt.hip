@@ -20,6 +20,9 @@
 //     bias + window_reverse/roll/crop + DropPath + residual add | multiply by GELU'(f1)) applied on the way out;
 //   * XCD-aware tile order: workgroups of one XCD (blockIdx % 8) take consecutive tiles = the same A row-panel.
 #include "dgx_common.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
 
 namespace {
 constexpr int GBK = 64;                 // K-step (elements): 128-byte tile rows
@@ -234,9 +237,9 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(GemmP P) {
             const int n = n0 + colw + 16 * j;
             uint32_t b01 = 0, b23 = 0;
             if (P.bias && n < P.N) {
-                const uint2 raw = *reinterpret_cast<const uint2*>(P.bias + n);
-                b01 = raw.x;
-                b23 = raw.y;
+                const u32x2 raw = *reinterpret_cast<const u32x2*>(P.bias + n);
+                b01 = raw[0];
+                b23 = raw[1];
             }
             bv[j][0] = __uint_as_float(b01 << 16); bv[j][1] = __uint_as_float(b01 & 0xffff0000u);
             bv[j][2] = __uint_as_float(b23 << 16); bv[j][3] = __uint_as_float(b23 & 0xffff0000u);
@@ -247,8 +250,8 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(GemmP P) {
 #pragma unroll
             for (int j = 0; j < WNF; ++j) {
                 const f32x4 a = acc[i][j];
-                const uint2 pk = {pack_bf2(a[0] + bv[j][0], a[1] + bv[j][1]), pack_bf2(a[2] + bv[j][2], a[3] + bv[j][3])};
-                *reinterpret_cast<DGX_LDS uint2*>(stg + row * SROW + (colw + 16 * j) * 2) = pk;
+                const u32x2 pk = {pack_bf2(a[0] + bv[j][0], a[1] + bv[j][1]), pack_bf2(a[2] + bv[j][2], a[3] + bv[j][3])};
+                *reinterpret_cast<DGX_LDS u32x2*>(stg + row * SROW + (colw + 16 * j) * 2) = pk;
             }
         }
     }
@@ -368,7 +371,7 @@ extern "C" int dgx_gemm_bf16_nt(const void* A, const void* B, int M, int N, int 
     if (!A || !B || !ep || K <= 0 || (K & 7) || (N & 7) || (lda & 7) || (ldb & 7) || lda < K || ldb < K) return DGX_ERR_BAD_ARG;
     if ((int64_t)M * lda * 2 >= (1ll << 31) || (int64_t)N * ldb * 2 >= (1ll << 31)) return DGX_ERR_UNSUPPORTED;
     GemmP P;
-    memset(&P, 0, sizeof(P));
+    memset((void*)&P, 0, sizeof(P));
     P.A = (const uint16_t*)A; P.B = (const uint16_t*)B;
     P.M = M; P.N = N; P.K = K; P.lda = (int)lda; P.ldb = (int)ldb;
     P.mode = ep->mode;

@@ -395,6 +395,48 @@ int64_t dgx_grad_sim_workspace_bytes(int64_t n);
 int dgx_grad_sim(const float* g1, const float* g2, int64_t n, double* out3, float* out4, void* workspace,
                  void* stream);
 
+
+/* ---------------------------------------------------------------------------------------------
+ * bf16 GEMM with fused epilogues: the forward and input-gradient matrix products of every nn.Linear / 1x1 convolution
+ * on the path (the reference issues them as F.linear -> cuBLAS):  DG/divergen/modeling/backbone/swintransformer.py:133
+ * (qkv), :155 (proj), :40-46 (Mlp fc1 / GELU / fc2), :296 (PatchMerging.reduction); D2/modeling/backbone/fpn.py:126-154
+ * (lateral 1x1); D2/modeling/roi_heads/box_head.py:26-98 and DG/divergen/modeling/roi_heads/detic_fast_rcnn.py:437-466 (FCs).
+ *
+ *   acc[m][n] = sum_k A[m][k] * B[n][k]      A bf16 (M, K) row stride lda, B bf16 (N, K) row stride ldb (elements),
+ *                                             fp32 accumulation on MFMA;  K % 8 == 0, N % 8 == 0, lda/ldb % 8 == 0.
+ *   y = bf16(acc + bias[n])  (bias bf16 (N) or NULL), then by `mode`:
+ *     DGX_EPI_NONE / DGX_EPI_BIAS   c[m][n] = y                                   (ldc)
+ *     DGX_EPI_BIAS_GELU             c[m][n] = y;  c2[m][n] = bf16(GELU_erf(y))    (Mlp.fc1 + act, swintransformer.py:41-42)
+ *     DGX_EPI_GELU_GRAD             c[m][n] = bf16(y * GELU'(aux[m][n]))          (backward of the above; aux = saved c)
+ *     DGX_EPI_BIAS_RESIDUAL         out[tok(m)][n] = residual[tok(m)][n] + scale[b(m)] * y
+ *         rows m are in WINDOW order when ws > 0 (window_reverse + roll(+shift) + crop folded into tok(m), padding rows
+ *         dropped; swintransformer.py:239-255) or token order when ws == 0; residual / out are (B, H*W, N) of
+ *         residual_dtype (DGX_F32 | DGX_BF16); scale f32 (B) = per-sample DropPath factor or NULL.
+ *         M must equal B*nW*ws*ws (ws > 0) or B*H*W.
+ * The input gradient dx = dy W of a Linear is this same call on the TRANSPOSED weight image (K and N swapped).
+ */
+#define DGX_EPI_NONE 0
+#define DGX_EPI_BIAS 1
+#define DGX_EPI_BIAS_GELU 2
+#define DGX_EPI_BIAS_RESIDUAL 3
+#define DGX_EPI_GELU_GRAD 4
+typedef struct dgx_gemm_epilogue {
+    int mode;
+    void* c;              /* bf16 (M, ldc) */
+    int64_t ldc;
+    const void* bias;     /* bf16 (N) or NULL */
+    void* c2;             /* bf16 (M, ldc): DGX_EPI_BIAS_GELU */
+    const void* aux;      /* bf16 (M, ldaux): DGX_EPI_GELU_GRAD */
+    int64_t ldaux;
+    const void* residual; /* DGX_EPI_BIAS_RESIDUAL */
+    void* out;
+    const float* scale;
+    int residual_dtype;
+    int B, H, W, ws, shift;
+} dgx_gemm_epilogue;
+int dgx_gemm_bf16_nt(const void* A, const void* B, int M, int N, int K, int64_t lda, int64_t ldb,
+                     const dgx_gemm_epilogue* epilogue, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -36,6 +36,7 @@ struct GemmP {
     int M, N, K, lda, ldb;
     int tiles_n, total, per_xcd;
     int mode;
+    unsigned long long* dbg; // development: per-workgroup phase timestamps (s_memtime), 8 per workgroup, or null
     uint16_t* C;            // bf16 (M, ldc): modes 0, 1, 2 (pre-activation), 4
     int ldc;
     const uint16_t* bias;   // bf16 (N) or null
@@ -94,7 +95,8 @@ __device__ __forceinline__ int64_t g_row_token(const GMap& m, int64_t orow, int&
     return (hh < m.H && ww < m.W) ? ((int64_t)b * m.H + hh) * m.W + ww : -1;
 }
 
-template <int BM, int BN> struct GemmCfg {
+template <int BM, int BN, int NS_> struct GemmCfg {
+    static constexpr int NS = NS_;                 // LDS stages (K-tiles resident or in flight)
     static constexpr int WMF = BM / 32;            // 16-row MFMA fragments per wave along M (2 waves)
     static constexpr int WNF = BN / 64;            // 16-column fragments per wave along N (4 waves)
     static constexpr int NA = BM / 64;             // LDS-direct loads per wave per K-tile, A rows
@@ -102,17 +104,21 @@ template <int BM, int BN> struct GemmCfg {
     static constexpr int SB = (BM + BN) * 128;     // bytes per stage
     static constexpr int SROW = BN * 2 + 16;       // epilogue staging row stride (bytes)
     static constexpr int EPI = BM * SROW + BM * 8; // staged tile + row -> (token, sample) table
-    static constexpr int LDS = (2 * SB > EPI ? 2 * SB : EPI);
+    static constexpr int LDS = (NS * SB > EPI ? NS * SB : EPI);
 };
 }  // namespace
 
-template <int BM, int BN>
-__global__ __launch_bounds__(512) void gemm_nt_kernel(GemmP P) {
-    using Cfg = GemmCfg<BM, BN>;
+// DIAG (development builds only, -DDGX_GEMM_DEV): ablation bits -- 1 no steady-state loads, 2 no MFMAs, 4 no fragment reads
+template <int BM, int BN, int NS, int MINW, int DIAG = 0>
+__global__ __launch_bounds__(512, MINW) void gemm_nt_kernel(GemmP P) {
+    using Cfg = GemmCfg<BM, BN, NS>;
+    constexpr int NL = Cfg::NA + Cfg::NB;          // LDS-direct loads per wave per K-tile
     constexpr int WMF = Cfg::WMF, WNF = Cfg::WNF, NA = Cfg::NA, NB = Cfg::NB, SB = Cfg::SB, SROW = Cfg::SROW;
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds_raw[];
     const int L = (blockIdx.x & 7) * P.per_xcd + (blockIdx.x >> 3);
     if (L >= P.total) return;
+#define GCLK(i) do { if (P.dbg && threadIdx.x == 0) P.dbg[(size_t)blockIdx.x * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+    GCLK(0);
     const int tm = L / P.tiles_n, tn = L - tm * P.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
     const int tid = threadIdx.x, l = tid & 63;
@@ -142,14 +148,13 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(GemmP P) {
     const u32x4 rB = g_rsrc(P.B, (uint32_t)((int64_t)P.N * P.ldb * 2));
     const uint32_t lds0 = (uint32_t)(uintptr_t)(DGX_LDS unsigned char*)lds_raw;
     const uint32_t ldsw = __builtin_amdgcn_readfirstlane(lds0 + 1024u * w);
-    auto issue_tile = [&](int t) {
+    // one of the NL loads of a tile: k < NA -> A rows, else B rows
+    auto issue_one = [&](int k, int t, int stage) {
         const uint32_t soff = (uint32_t)t * (GBK * 2);
-        const uint32_t dst = ldsw + (uint32_t)(t & 1) * SB;
-        const bool tail = (t == NT - 1) && (ktail != GBK);
-#pragma unroll
-        for (int s = 0; s < NA; ++s) g_load_lds16((tail && !kt_ok) ? G_OOB : voffA[s], rA, dst + 8192u * s, soff);
-#pragma unroll
-        for (int s = 0; s < NB; ++s) g_load_lds16((tail && !kt_ok) ? G_OOB : voffB[s], rB, dst + BM * 128 + 8192u * s, soff);
+        const uint32_t dst = ldsw + (uint32_t)stage * SB;
+        const bool tail = (t == NT - 1) && (ktail != GBK) && !kt_ok;
+        if (k < NA) g_load_lds16(tail ? G_OOB : voffA[k], rA, dst + 8192u * k, soff);
+        else g_load_lds16(tail ? G_OOB : voffB[k - NA], rB, dst + BM * 128 + 8192u * (k - NA), soff);
     };
 
     // ---- MFMA role: wave tile = rows grp*BM/2 .. (+16 i + c), columns wc*BN/4 .. (+16 j + c); a fragment (16 rows, k-half kh)
@@ -163,11 +168,19 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(GemmP P) {
 #pragma unroll
         for (int j = 0; j < WNF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     bf16x8 af[WMF][2], bfr[WNF][2];
-    auto read_frags = [&](int t) {
-        DGX_LDS const unsigned char* sa = lds_opaque((const unsigned char*)lds_raw + (t & 1) * SB + la);
-        DGX_LDS const unsigned char* sa1 = lds_opaque((const unsigned char*)lds_raw + (t & 1) * SB + (la ^ 64u));
-        DGX_LDS const unsigned char* sb = lds_opaque((const unsigned char*)lds_raw + (t & 1) * SB + lb);
-        DGX_LDS const unsigned char* sb1 = lds_opaque((const unsigned char*)lds_raw + (t & 1) * SB + (lb ^ 64u));
+    // LOAD phase of group 0: this wave's NL loads of tile `ti` (if >= 0) into stage `istage`, then the 2 (WMF + WNF) fragment
+    // reads of the tile in `stage`.  Measured (tools/gemm_phase_probe.py): an LDS-direct load costs its wave ~60 cycles of
+    // issue next to MFMAs or plain code and ~80-180 when it sits between ds_reads, so the loads are kept together.
+    auto load_phase = [&](int stage, int ti, int istage) {
+        if (ti >= 0) {
+#pragma unroll
+            for (int k = 0; k < NL; ++k) issue_one(k, ti, istage);
+        }
+        if constexpr ((DIAG & 4) != 0) return;
+        DGX_LDS const unsigned char* sa = lds_opaque((const unsigned char*)lds_raw + stage * SB + la);
+        DGX_LDS const unsigned char* sa1 = lds_opaque((const unsigned char*)lds_raw + stage * SB + (la ^ 64u));
+        DGX_LDS const unsigned char* sb = lds_opaque((const unsigned char*)lds_raw + stage * SB + lb);
+        DGX_LDS const unsigned char* sb1 = lds_opaque((const unsigned char*)lds_raw + stage * SB + (lb ^ 64u));
 #pragma unroll
         for (int j = 0; j < WNF; ++j) {
             bfr[j][0] = *reinterpret_cast<DGX_LDS const bf16x8*>(sb + 2048 * j);
@@ -180,7 +193,8 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(GemmP P) {
         }
     };
     auto mfmas = [&]() {
-        __builtin_amdgcn_s_setprio(1);
+        if constexpr ((DIAG & 2) != 0) return;
+        if constexpr ((DIAG & 8) == 0) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
@@ -192,40 +206,78 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(GemmP P) {
     };
 
     // ---- main loop.  Intervals between barriers I_0, I_1, ...: group 0 reads tile t in I_{2t+1} and multiplies in I_{2t+2};
-    // group 1 reads in I_{2t+2} and multiplies in I_{2t+3}.  Tile t+2 replaces tile t in its stage: issued by both groups in
-    // I_{2t+3} (after the barrier that follows group 1's reads of tile t), waited for by every wave before the barrier that
-    // opens I_{2t+5}.
-    issue_tile(0);
-    if (NT > 1) {
-        issue_tile(1);
-        g_vmcnt<NA + NB>();
-    } else {
-        g_vmcnt<0>();
+    // group 1 reads in I_{2t+2} and multiplies in I_{2t+3}.  Tile tau lives in stage tau % NS: it replaces tile tau - NS, whose
+    // last read (group 1) ends with the barrier that opens I_{2(tau-NS)+3}; both groups issue it in that interval (group 0 in
+    // its read phase of tile tau-NS+1, group 1 in its MFMA phase of tile tau-NS) and every wave has waited for its share
+    // before the barrier that opens I_{2 tau + 1}: 2 (NS - 1) intervals of flight.
+    // wait for this wave's share of tile `tau` with the later tiles it has already issued still in flight
+    auto wait_tile = [&](int tau) {
+        int later = NT - 1 - tau;
+        if (later > NS - 2) later = NS - 2;
+        if (NS >= 4 && later >= 2) g_vmcnt<2 * NL>();
+        else if (NS >= 3 && later >= 1) g_vmcnt<NL>();
+        else g_vmcnt<0>();
+    };
+#pragma unroll
+    for (int t = 0; t < NS; ++t)
+        if (t < NT) {
+#pragma unroll
+            for (int k = 0; k < NL; ++k) issue_one(k, t, t);
+        }
+    {
+        int later = NT - 1;
+        if (later > NS - 1) later = NS - 1;
+        if (NS >= 4 && later >= 3) g_vmcnt<3 * NL>();
+        else if (NS >= 3 && later >= 2) g_vmcnt<2 * NL>();
+        else if (later >= 1) g_vmcnt<NL>();
+        else g_vmcnt<0>();
     }
     g_bar();                                       // #0: tile 0 visible to everyone
-    if (grp == 0) {
+    GCLK(1);
+    int rs = 0;                                    // stage of the tile being read
+    // Group 0 issues in its LOAD phase, group 1 right AFTER its MFMAs (both in I_{2t+3} for tile t + 2 when NS = 2).
+    // Measured per K-tile of a 256x192 tile: loads of group 1 in front of its MFMAs 2525 cycles (their issue time delays the
+    // whole interval), behind them 2106; both groups issuing in their LOAD phases (possible from 3 stages on) is no better.
+    constexpr bool G1_IN_LOAD = false;
+    if (grp == 0 || G1_IN_LOAD) {
+        int is = NS - 1;                           // stage of the next tile to issue (tile t + NS - 1 at t >= 1)
+        if (grp == 1) g_bar();                     // #1: one phase behind group 0
         for (int t = 0; t < NT; ++t) {
-            if (t >= 1 && t + 1 < NT) issue_tile(t + 1);
-            read_frags(t);
+            int ti = -1;
+            if (t >= 1) {
+                is = is + 1 == NS ? 0 : is + 1;
+                if (t + NS - 1 < NT && !(DIAG & 1)) ti = t + NS - 1;
+            }
+            load_phase(rs, ti, is);
+            rs = rs + 1 == NS ? 0 : rs + 1;
             g_lgkm0();
-            g_bar();                               // #(2t+1)
+            if (grp == 1 && t + 1 < NT) wait_tile(t + 1);
+            g_bar();                               // group 0: #(2t+1), group 1: #(2t+2)
             mfmas();
-            g_vmcnt<0>();                          // tile t+1 landed (own share)
-            g_bar();                               // #(2t+2)
+            if (grp == 0 && t + 1 < NT) wait_tile(t + 1);
+            g_bar();                               // group 0: #(2t+2), group 1: #(2t+3)
         }
-        g_bar();                                   // group 1's last phase
+        if (grp == 0) g_bar();                     // group 1's last phase
     } else {
+        int is = 0;                                // tile t + NS goes where tile t was
         g_bar();                                   // #1: one phase behind group 0
         for (int t = 0; t < NT; ++t) {
-            read_frags(t);
+            load_phase(rs, -1, 0);
+            rs = rs + 1 == NS ? 0 : rs + 1;
             g_lgkm0();
-            g_vmcnt<0>();                          // tile t+1 landed (own share)
+            if (t + 1 < NT) wait_tile(t + 1);
             g_bar();                               // #(2t+2)
-            if (t + 2 < NT) issue_tile(t + 2);
             mfmas();
+            if (t + NS < NT && !(DIAG & 1)) {
+#pragma unroll
+                for (int k = 0; k < NL; ++k) issue_one(k, t + NS, is);
+            }
+            is = is + 1 == NS ? 0 : is + 1;
             g_bar();                               // #(2t+3)
         }
     }
+    g_vmcnt<0>();
+    GCLK(2);
 
     // ---- epilogue: stage the tile as bf16 (bias added) in LDS, then stream whole rows out with the fused tail
     DGX_LDS unsigned char* stg = (DGX_LDS unsigned char*)lds_raw;
@@ -263,6 +315,7 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(GemmP P) {
         rowtok[tid] = tok < 0 ? -1 : ((tok << 12) | (int64_t)b);
     }
     __syncthreads();
+    GCLK(3);
     constexpr int CPR = BN / 8;                    // 16-byte chunks per tile row
     for (int idx = tid; idx < BM * CPR; idx += 512) {
         const int row = idx / CPR, ch = idx - row * CPR;
@@ -310,6 +363,7 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(GemmP P) {
             }
         }
     }
+    GCLK(4);
 }
 
 namespace {
@@ -346,24 +400,27 @@ TileChoice choose_tile(int M, int N) {
     return {bm, bn};
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int NS, int MINW = 2, int DIAG = 0>
 int launch_gemm(GemmP& P, hipStream_t st) {
-    using Cfg = GemmCfg<BM, BN>;
+    using Cfg = GemmCfg<BM, BN, NS>;
     const int tiles_m = (P.M + BM - 1) / BM;
     P.tiles_n = (P.N + BN - 1) / BN;
     P.total = tiles_m * P.tiles_n;
     P.per_xcd = (P.total + 7) / 8;
     static bool once = false;
     if (!once) {
-        if (hipFuncSetAttribute((const void*)gemm_nt_kernel<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)gemm_nt_kernel<BM, BN, NS, MINW, DIAG>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS) != hipSuccess)
             return DGX_ERR_UNSUPPORTED;
         once = true;
     }
-    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN>), dim3(8 * P.per_xcd), dim3(512), Cfg::LDS, st, P);
+    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, NS, MINW, DIAG>), dim3(8 * P.per_xcd), dim3(512), Cfg::LDS, st, P);
     DGX_LAUNCH_CHECK();
     return DGX_OK;
 }
 }  // namespace
+
+static void* g_dbg_buffer = nullptr;   // development: set through dgx_dev_gemm_set_debug
+extern "C" void dgx_dev_gemm_set_debug(void* device_buffer) { g_dbg_buffer = device_buffer; }
 
 extern "C" int dgx_gemm_bf16_nt(const void* A, const void* B, int M, int N, int K, int64_t lda, int64_t ldb,
                                 const dgx_gemm_epilogue* ep, void* stream) {
@@ -407,12 +464,59 @@ extern "C" int dgx_gemm_bf16_nt(const void* A, const void* B, int M, int N, int 
     }
     hipStream_t st = (hipStream_t)stream;
     const TileChoice tc = choose_tile(M, N);
-    if (tc.bn == 192) {
-        if (tc.bm == 256) return launch_gemm<256, 192>(P, st);
-        if (tc.bm == 192) return launch_gemm<192, 192>(P, st);
-        return launch_gemm<128, 192>(P, st);
+    P.dbg = (unsigned long long*)g_dbg_buffer;
+    static const char* logp = getenv("DGX_GEMM_LOG");      // development: one line per launch, joined with a kernel trace
+    if (logp) {
+        static FILE* lf = fopen(logp, "w");
+        if (lf) { fprintf(lf, "%d %d %d %d %d %d\n", M, N, K, ep->mode, tc.bm, tc.bn); fflush(lf); }
     }
-    if (tc.bn == 256) return launch_gemm<128, 256>(P, st);
-    if (tc.bm == 256) return launch_gemm<256, 128>(P, st);
-    return launch_gemm<128, 128>(P, st);
+    const char* sg = getenv("DGX_GEMM_STAGES");
+    const int two = sg && atoi(sg) == 2;           // development A/B: every tile with two stages
+#ifdef DGX_GEMM_DEV
+    if (const char* dg = getenv("DGX_GEMM_DIAG")) {
+        switch (atoi(dg)) {
+            case 1: return launch_gemm<256, 192, 2, 2, 1>(P, st);
+            case 2: return launch_gemm<256, 192, 2, 2, 2>(P, st);
+            case 3: return launch_gemm<256, 192, 2, 2, 3>(P, st);
+            case 4: return launch_gemm<256, 192, 2, 2, 4>(P, st);
+            case 5: return launch_gemm<256, 192, 2, 2, 5>(P, st);
+            case 6: return launch_gemm<256, 192, 2, 2, 6>(P, st);
+            case 7: return launch_gemm<256, 192, 2, 2, 7>(P, st);
+            case 200: return launch_gemm<192, 192, 3, 2, 0>(P, st);
+            case 300: return launch_gemm<128, 192, 4, 2, 0>(P, st);
+            case 302: return launch_gemm<128, 192, 3, 2, 0>(P, st);
+            case 400: return launch_gemm<256, 128, 3, 2, 0>(P, st);
+            default: break;
+        }
+    }
+#endif
+    if (tc.bn == 192) {
+        if (tc.bm == 256) return launch_gemm<256, 192, 2>(P, st);
+        if (tc.bm == 192) return two ? launch_gemm<192, 192, 2>(P, st) : launch_gemm<192, 192, 3>(P, st);
+        // 128 x 192 with two stages = 80 KiB and <= 128 registers: two workgroups per CU, one's epilogue under the other's MFMAs
+        return two ? launch_gemm<128, 192, 2, 4>(P, st) : launch_gemm<128, 192, 4>(P, st);
+    }
+    if (tc.bn == 256) return launch_gemm<128, 256, 3>(P, st);
+    if (tc.bm == 256) return launch_gemm<256, 128, 3>(P, st);
+    return launch_gemm<128, 128, 4>(P, st);
+}
+
+// Development timing hook (not part of include/divergen_hip.h): `iters` back-to-back launches of the same GEMM between two
+// HIP events on `stream`; returns the average kernel time in microseconds (host launch cost excluded), < 0 on error.
+extern "C" float dgx_dev_gemm_time_us(const void* A, const void* B, int M, int N, int K, int64_t lda, int64_t ldb,
+                                      const dgx_gemm_epilogue* ep, int iters, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    for (int i = 0; i < 3; ++i)
+        if (dgx_gemm_bf16_nt(A, B, M, N, K, lda, ldb, ep, stream) != DGX_OK) return -1.f;
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return -2.f;
+    (void)hipEventRecord(e0, st);
+    for (int i = 0; i < iters; ++i) (void)dgx_gemm_bf16_nt(A, B, M, N, K, lda, ldb, ep, stream);
+    (void)hipEventRecord(e1, st);
+    (void)hipEventSynchronize(e1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return ms * 1000.f / (float)iters;
 }

@@ -13,6 +13,7 @@ import torch
 import torch.nn.functional as F
 
 from .. import _lib as L
+from .gemm_ops import gemm_nt
 from .linear_ops import accumulate_grad, linear, notify_ready, shadow, wgrad_into
 
 
@@ -47,10 +48,18 @@ class _Conv3x3(torch.autograd.Function):
         wk = _ohwi_matrix(w) if bf else None          # arena weights stored (Cout,kh,kw,Cin): the GEMM operand as is
         wm = wk.t() if wk is not None else w.permute(2, 3, 1, 0).reshape(9 * C, -1)     # (ky,kx,ci) x co
         col, Ho, Wo = _im2col(x, stride)
-        if bias is not None:
+        own = bf and x.is_cuda and w.shape[0] % 8 == 0 and C % 8 == 0       # libdgx MFMA GEMM (bf16 path)
+        if own:
+            if wk is None:
+                wk = wm.t().contiguous()
+            y = gemm_nt(col, wk, shadow(bias) if bias is not None else None)
+            wt = getattr(weight, "_dgx16t", None)      # (9 Cin, Cout): the arena's transposed twin, else a copy
+            wm = wt if (wt is not None and _ohwi_matrix(shadow(weight)) is not None) else wm.contiguous()
+        elif bias is not None:
             y = torch.addmm(shadow(bias) if bf else bias.to(x.dtype), col, wm)
         else:
             y = col @ wm
+        ctx.own = own
         ctx.save_for_backward(col, wm)
         ctx.weight, ctx.bias = weight, bias
         ctx.cfg = (N, H, W, C, Ho, Wo, stride, weight.dtype, bias is not None, weight.shape)
@@ -63,7 +72,7 @@ class _Conv3x3(torch.autograd.Function):
         g2 = gy.reshape(N * Ho * Wo, -1).to(col.dtype)
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            dcol = (g2 @ wm.t()).contiguous()
+            dcol = gemm_nt(g2.contiguous(), wm) if ctx.own else (g2 @ wm.t()).contiguous()
             gx = torch.empty(N, H, W, C, dtype=col.dtype, device=col.device)
             L.check(L.lib().dgx_col2im3x3(L.ptr(dcol), L.ptr(gx), N, H, W, C, stride, L.dtype_code(gx), L.stream()),
                     "dgx_col2im3x3")

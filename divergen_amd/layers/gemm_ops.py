@@ -95,3 +95,21 @@ def gemm_bias_residual(a, b, bias, res, scale, B, H, W, ws, shift):
     ep.B, ep.H, ep.W, ep.ws, ep.shift = B, H, W, ws, shift
     _launch(a, b, ep)
     return out
+
+
+def dev_time_us(a, b, bias=None, iters=30, mode=None):
+    """Development: average KERNEL time (us) of one GEMM over back-to-back launches (HIP events inside libdgx).
+    mode None = bias / plain; EPI_BIAS_GELU and EPI_GELU_GRAD time those epilogues on scratch tensors."""
+    _check2(a, b)
+    M, N = a.shape[0], b.shape[0]
+    c = torch.empty(M, N, dtype=BF16, device=a.device)
+    ep = L.GemmEpilogue()
+    ep.mode = (EPI_BIAS if bias is not None else EPI_NONE) if mode is None else mode
+    ep.c, ep.ldc, ep.bias = c.data_ptr(), N, _dev_ptr(bias)
+    if mode in (EPI_BIAS_GELU, EPI_GELU_GRAD):
+        extra = torch.randn(M, N, device=a.device).to(BF16)
+        ep.c2, ep.aux, ep.ldaux = extra.data_ptr(), extra.data_ptr(), N
+    fn = L.lib().dgx_dev_gemm_time_us
+    fn.restype = ctypes.c_float
+    fn.argtypes = [L.c_p, L.c_p, L.c_i, L.c_i, L.c_i, L.c_i64, L.c_i64, ctypes.POINTER(L.GemmEpilogue), L.c_i, L.c_p]
+    return float(fn(a.data_ptr(), b.data_ptr(), M, N, a.shape[1], a.stride(0), b.stride(0), ctypes.byref(ep), iters, L.stream()))

@@ -73,6 +73,20 @@ def shadow(p):
     return s if s is not None else p.detach().to(BF16)
 
 
+def shadow_t(p):
+    """bf16 TRANSPOSE of a matrix parameter, (numel / shape[0], shape[0]): the arena's transposed twin if present (refreshed
+    after every optimizer step, solver.FlatArena.refresh_transposes), else a transposed copy (pre-arena use)."""
+    s = getattr(p, "_dgx16t", None)
+    if s is not None:
+        return s
+    w = shadow(p)
+    return w.reshape(w.shape[0], -1).t().contiguous()
+
+
+def _own_gemm_ok(x2, n, k):
+    return x2.is_cuda and n % 8 == 0 and k % 8 == 0
+
+
 def accumulate_grad(p, make_grad_fp32, gemm_into=None):
     """Write a gradient into p's arena view.  Returns None if done in place (and signals the
     data-parallel reducer), else the gradient tensor for autograd to accumulate."""
@@ -96,7 +110,10 @@ class _LinearFn(torch.autograd.Function):
         if x2.dtype != BF16:
             x2 = x2.to(BF16)
         x2 = x2.contiguous()
-        if bias is not None:
+        if _own_gemm_ok(x2, w16.shape[0], w16.shape[1]):
+            from .gemm_ops import gemm_nt
+            y = gemm_nt(x2, w16, shadow(bias) if bias is not None else None)
+        elif bias is not None:                       # widths that are not multiples of 8 (cls_score 1454, bbox_pred 4): library
             y = torch.addmm(shadow(bias), x2, w16.t())
         else:
             y = torch.mm(x2, w16.t())
@@ -114,7 +131,11 @@ class _LinearFn(torch.autograd.Function):
         dy2 = dy2.contiguous()
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = torch.mm(dy2, w16).view(ctx.xshape)
+            if _own_gemm_ok(dy2, w16.shape[1], w16.shape[0]):
+                from .gemm_ops import gemm_nt
+                dx = gemm_nt(dy2, shadow_t(weight)).view(ctx.xshape)
+            else:
+                dx = torch.mm(dy2, w16).view(ctx.xshape)
             if ctx.xdtype != BF16:
                 dx = dx.to(ctx.xdtype)
         gw = gb = None

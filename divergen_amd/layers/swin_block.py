@@ -16,7 +16,8 @@ composed path in swintransformer.py, which runs the same kernels in the same ord
 import torch
 
 from .. import _lib as L
-from .linear_ops import BF16, notify_ready, shadow, wgrad_grouped
+from . import gemm_ops as G
+from .linear_ops import BF16, notify_ready, shadow, shadow_t, wgrad_grouped
 
 
 def arena_resident(params):
@@ -48,11 +49,13 @@ def colsum_grouped(problems, beta=1.0):
     L.check(lib.dgx_colsum_grouped(arr, n, float(beta), L.ptr(ws), L.stream()), "dgx_colsum_grouped")
 
 
-def _linear_bwd(dy2, x2, weight, bias, w16, wgrads):
-    """Bias gradient of y = x W^T + b into the arena, weight gradient queued for the block's grouped
-    weight-gradient / bias-gradient launches; returns dx (bf16)."""
+def _linear_bwd(dy2, x2, weight, bias, wgrads, gelu_of=None):
+    """Weight / bias gradient of y = x W^T + b queued for the block's grouped weight-gradient / bias-gradient launches;
+    returns dx = dy W (bf16) from the MFMA GEMM on the transposed weight image -- times GELU'(gelu_of) when given (the
+    input gradient of fc2 carried through the activation in the GEMM's epilogue)."""
     wgrads.append((weight.grad.view(weight.shape[0], -1), dy2, x2, bias))
-    return torch.mm(dy2, w16)
+    wt = shadow_t(weight)
+    return G.gemm_gelu_grad(dy2, wt, gelu_of) if gelu_of is not None else G.gemm_nt(dy2, wt)
 
 
 class _SwinBlockFn(torch.autograd.Function):
@@ -75,41 +78,30 @@ class _SwinBlockFn(torch.autograd.Function):
         L.check(lib.dgx_layernorm_fwd(x.data_ptr(), n1w.data_ptr(), n1b.data_ptr(), xw.data_ptr(), mean1.data_ptr(),
                                       rstd1.data_ptr(), T, C, eps1, B, H, W, ws, shift, code, st), "dgx_layernorm_fwd")
         # attention
-        qw16, pw16, w116, w216 = shadow(qw), shadow(pw), shadow(w1), shadow(w2)
-        qkv = torch.addmm(shadow(qb), xw, qw16.t())
+        qkv = G.gemm_nt(xw, shadow(qw), shadow(qb))
         tbl = table.detach()                       # ((2ws-1)^2, nH) as stored: the kernels take its strides
         o = torch.empty(Tw, C, dtype=BF16, device=dev)
         lse = torch.empty(B_, nH, N, dtype=f32, device=dev)
         L.check(lib.dgx_window_attention_fwd(qkv.data_ptr(), tbl.data_ptr(), tbl.stride(1), tbl.stride(0), L.ptr(region),
                                              o.data_ptr(), lse.data_ptr(), B_, nW, nH, ws, scale, st), "dgx_window_attention_fwd")
-        pr = torch.addmm(shadow(pb), o, pw16.t())
-        # reverse + roll + crop + DropPath + residual
-        x1 = torch.empty_like(x)
-        L.check(lib.dgx_residual_fwd(x.data_ptr(), pr.data_ptr(), L.ptr(s1), x1.data_ptr(), B, H, W, C, ws, shift, code, st),
-                "dgx_residual_fwd")
+        # proj + (reverse + roll + crop + DropPath + residual) in the GEMM's epilogue
+        x1 = G.gemm_bias_residual(o, shadow(pw), shadow(pb), x.view(B, H * W, C), s1, B, H, W, ws, shift).view(x.shape)
         # LN2 + MLP + residual
         h2 = torch.empty(T, C, dtype=BF16, device=dev)
         mean2 = torch.empty(T, dtype=f32, device=dev)
         rstd2 = torch.empty(T, dtype=f32, device=dev)
         L.check(lib.dgx_layernorm_fwd(x1.data_ptr(), n2w.data_ptr(), n2b.data_ptr(), h2.data_ptr(), mean2.data_ptr(),
                                       rstd2.data_ptr(), T, C, eps2, 0, 0, 0, 0, 0, code, st), "dgx_layernorm_fwd")
-        f1 = torch.addmm(shadow(b1), h2, w116.t())
-        a = torch.empty_like(f1)
-        L.check(lib.dgx_gelu_fwd(f1.data_ptr(), a.data_ptr(), f1.numel(), st), "dgx_gelu_fwd")
-        f2 = torch.addmm(shadow(b2), a, w216.t())
-        out = torch.empty_like(x)
-        L.check(lib.dgx_residual_fwd(x1.data_ptr(), f2.data_ptr(), L.ptr(s2), out.data_ptr(), B, H, W, C, 0, 0, code, st),
-                "dgx_residual_fwd")
-        ctx.save_for_backward(x, mean1, rstd1, xw, qkv, region, o, lse, x1, mean2, rstd2, h2, f1, a, s1, s2,
-                              qw16, pw16, w116, w216)
+        f1, a = G.gemm_bias_gelu(h2, shadow(w1), shadow(b1))        # fc1 + exact GELU: both tensors from one epilogue
+        out = G.gemm_bias_residual(a, shadow(w2), shadow(b2), x1.view(B, H * W, C), s2, B, H, W, 0, 0).view(x.shape)
+        ctx.save_for_backward(x, mean1, rstd1, xw, qkv, region, o, lse, x1, mean2, rstd2, h2, f1, a, s1, s2)
         ctx.params = (n1w, n1b, qw, qb, table, pw, pb, n2w, n2b, w1, b1, w2, b2)
         ctx.cfg = cfg
         return out
 
     @staticmethod
     def backward(ctx, g):
-        (x, mean1, rstd1, xw, qkv, region, o, lse, x1, mean2, rstd2, h2, f1, a, s1, s2,
-         qw16, pw16, w116, w216) = ctx.saved_tensors
+        x, mean1, rstd1, xw, qkv, region, o, lse, x1, mean2, rstd2, h2, f1, a, s1, s2 = ctx.saved_tensors
         n1w, n1b, qw, qb, table, pw, pb, n2w, n2b, w1, b1, w2, b2 = ctx.params
         B, H, W, ws, shift, nH, scale, eps1, eps2 = ctx.cfg
         lib, st, dev = L.lib(), L.stream(), g.device
@@ -124,13 +116,8 @@ class _SwinBlockFn(torch.autograd.Function):
         df2 = torch.empty(T, C, dtype=BF16, device=dev)
         L.check(lib.dgx_residual_bwd(g.data_ptr(), L.ptr(s2), df2.data_ptr(), B, H, W, C, 0, 0, code, st), "dgx_residual_bwd")
         wgrads = []
-        da = _linear_bwd(df2, a, w2, b2, w216, wgrads)
-        # GELU backward + the fc1 bias gradient (column sums of df1) in one pass
-        df1 = torch.empty_like(f1)
-        gws = torch.empty(max(int(lib.dgx_gelu_bwd_workspace_bytes(f1.shape[0], f1.shape[1])), 4), dtype=torch.uint8, device=dev)
-        L.check(lib.dgx_gelu_bwd_colsum(da.data_ptr(), f1.data_ptr(), df1.data_ptr(), b1.grad.data_ptr(), f1.shape[0], f1.shape[1], 1.0,
-                                        gws.data_ptr(), st), "dgx_gelu_bwd_colsum")
-        dh2 = _linear_bwd(df1, h2, w1, None, w116, wgrads)
+        df1 = _linear_bwd(df2, a, w2, b2, wgrads, gelu_of=f1)       # (df2 W2) * GELU'(f1)
+        dh2 = _linear_bwd(df1, h2, w1, b1, wgrads)
         # LN2 backward + the residual-branch gradient g -> dx1
         nblk = lib.dgx_layernorm_bwd_blocks(T)
         part = torch.empty(nblk * 2 * C, dtype=torch.float32, device=dev)
@@ -143,14 +130,14 @@ class _SwinBlockFn(torch.autograd.Function):
         dpr = torch.empty(Tw, C, dtype=BF16, device=dev)
         L.check(lib.dgx_residual_bwd(dx1.data_ptr(), L.ptr(s1), dpr.data_ptr(), B, H, W, C, ws, shift, code, st),
                 "dgx_residual_bwd")
-        do = _linear_bwd(dpr, o, pw, pb, pw16, wgrads)
+        do = _linear_bwd(dpr, o, pw, pb, wgrads)
         dqkv = torch.empty_like(qkv)
         assert table.grad.stride() == table.stride()          # one pair of strides serves the table and its gradient
         L.check(lib.dgx_window_attention_bwd(qkv.data_ptr(), table.data_ptr(), L.ptr(region), o.data_ptr(), lse.data_ptr(),
                                              do.data_ptr(), dqkv.data_ptr(), table.grad.data_ptr(), table.stride(1), table.stride(0),
                                              B_, nW, nH, ws, scale, st), "dgx_window_attention_bwd")
         _ready(table)
-        dxw = _linear_bwd(dqkv, xw, qw, qb, qw16, wgrads)
+        dxw = _linear_bwd(dqkv, xw, qw, qb, wgrads)
         # LN1 backward through the window map, accumulated onto dx1 in place
         L.check(lib.dgx_layernorm_bwd(dxw.data_ptr(), x.data_ptr(), mean1.data_ptr(), rstd1.data_ptr(), n1w.data_ptr(),
                                       dx1.data_ptr(), dx1.data_ptr(), n1w.grad.data_ptr(), n1b.grad.data_ptr(), part.data_ptr(),

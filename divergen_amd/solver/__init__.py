@@ -51,12 +51,24 @@ class FlatArena:
         self.p = torch.zeros(n, dtype=torch.float32, device=dev)
         self.g = torch.zeros(n, dtype=torch.float32, device=dev)
         self.p16 = torch.zeros(n, dtype=torch.bfloat16, device=dev)   # bf16 shadow, refreshed by the optimizer kernel
+        # transposed twin of the shadow: every matrix parameter (rows = shape[0] of its STORED layout) transposed in place
+        # of itself -- the B operand of the input-gradient GEMMs (layers/gemm_ops.py); rebuilt by refresh_transposes()
+        self.p16t = torch.zeros(n, dtype=torch.bfloat16, device=dev) if dev.type == "cuda" else None
+        jobs, tiles = [], 0
         for p, o in zip(self.params, offs):
             v = self.view(self.p, p, o)
             v.copy_(p.data)
             p.data = v
             p.grad = self.view(self.g, p, o)
             p._dgx16 = self.view(self.p16, p, o)
+            if self.p16t is not None and p.dim() >= 2:
+                rows = self.stored_rows(p)
+                cols = p.numel() // rows
+                p._dgx16t = self.p16t[o:o + p.numel()].view(cols, rows)
+                jobs.append((o, rows | (cols << 32), tiles))
+                tiles += ((rows + 63) // 64) * ((cols + 63) // 64)
+        self._tjobs = torch.tensor(jobs, dtype=torch.int64, device=dev) if jobs else None
+        self._ttiles = tiles
         self.sync_shadow()
 
     @staticmethod
@@ -71,9 +83,23 @@ class FlatArena:
             return flat.view(co, kh, kw, ci).permute(0, 3, 1, 2)
         return flat.view(p.shape)
 
+    @staticmethod
+    def stored_rows(p):
+        """Leading dimension of the parameter's STORED matrix: shape[0] (also for the (Cout, kh, kw, Cin) conv storage)."""
+        return p.shape[0]
+
     def sync_shadow(self):
         """Re-derive the bf16 shadow from the fp32 weights (after init / broadcast / checkpoint load)."""
         self.p16.copy_(self.p)
+        self.refresh_transposes()
+
+    def refresh_transposes(self):
+        """p16t <- transposes of the matrix parameters of p16: one grouped launch (csrc/transpose.hip)."""
+        if self._tjobs is None:
+            return
+        from .. import _lib as L
+        L.check(L.lib().dgx_transpose_bf16_grouped(self.p16.data_ptr(), self.p16t.data_ptr(), self._tjobs.data_ptr(),
+                                                   self._tjobs.shape[0], self._ttiles, L.stream()), "dgx_transpose_bf16_grouped")
 
     def zero_grad(self):
         self.g.zero_()
@@ -109,6 +135,7 @@ class FusedAdamWEMA:
                        self.betas, self.eps, self.weight_decay, self.clip_value, grad_scale, self.ema_decay,
                        p_bf16=self.arena.p16 if self.arena.p16.is_cuda else None,
                        lr_scale=self.lr_scale, seg_end=self.seg_end, found_inf=found_inf)
+        self.arena.refresh_transposes()
 
     def state_dict(self):
         return {"step": self.step_count, "exp_avg": self.m, "exp_avg_sq": self.v, "lr": self.param_groups[0]["lr"],

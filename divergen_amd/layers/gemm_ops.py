@@ -26,9 +26,23 @@ def _check2(a, b):
         raise L.DgxError("gemm_nt: operands must be K-contiguous")
 
 
+_WS = {}
+WS_BYTES = 64 << 20      # split-K scratch per device (fp32 slabs of skinny, long-K problems), allocated once
+
+
+def _workspace(dev):
+    ws = _WS.get(dev)
+    if ws is None:
+        ws = _WS[dev] = torch.empty(WS_BYTES, dtype=torch.uint8, device=dev)
+    return ws
+
+
 def _launch(a, b, ep):
     M, K = a.shape
     N = b.shape[0]
+    if M * N * 8 <= WS_BYTES:          # at least two slabs fit: let the library decide whether to split K
+        ws = _workspace(a.device)
+        ep.workspace, ep.workspace_bytes = ws.data_ptr(), WS_BYTES
     L.check(L.lib().dgx_gemm_bf16_nt(a.data_ptr(), b.data_ptr(), M, N, K, a.stride(0), b.stride(0), ctypes.byref(ep), L.stream()),
             "dgx_gemm_bf16_nt")
 

@@ -50,6 +50,48 @@ def test_gemm_nt_bias(tile, M, N, K):
     close_bf16(G.gemm_nt(a.to(DEV), b.to(DEV), bias.to(DEV)), ref + bias.float())
 
 
+@pytest.mark.parametrize("M,N,K,S", [(1024, 1024, 12544, 0), (128, 256, 2304, 0), (2048, 1536, 6144, 4), (300, 200, 1096, 3), (512, 384, 640, 2)])
+def test_gemm_split_k(monkeypatch, M, N, K, S):
+    """Few output tiles and a long contraction: K is cut into slabs (fp32 partial sums in the workspace) and folded by a
+    second launch with the same epilogue; S = 0 leaves the split count to the library's plan."""
+    if S:
+        monkeypatch.setenv("DGX_GEMM_SPLITK", str(S))
+    g = torch.Generator().manual_seed(K)
+    a, b = bf(torch.randn(M, K, generator=g)), bf(torch.randn(N, K, generator=g) * 0.1)
+    bias = bf(torch.randn(N, generator=g))
+    ref = a.float() @ b.float().t() + bias.float()
+    close_bf16(G.gemm_nt(a.to(DEV), b.to(DEV), bias.to(DEV)), ref)
+    f1, act = G.gemm_bias_gelu(a.to(DEV), b.to(DEV), bias.to(DEV))
+    close_bf16(f1, ref)
+    close_bf16(act, torch.nn.functional.gelu(f1.float().cpu()), extra=1e-3)
+    if M % 4 == 0:
+        B, H, W = 1, M // 4, 4
+        res = torch.randn(B, H * W, N, generator=g)
+        scale = torch.tensor([0.5])
+        out = G.gemm_bias_residual(a.to(DEV), b.to(DEV), bias.to(DEV), res.to(DEV), scale.to(DEV), B, H, W, 0, 0)
+        want = res + 0.5 * bf(ref).float().reshape(B, H * W, N)
+        assert float((out.cpu() - want).abs().max()) <= 2.0 ** -7 * float(ref.abs().max())
+
+
+def test_gelu_epilogue_accuracy_vs_float64():
+    """The epilogue's erfc-polynomial GELU against float64 erf on the same bf16 pre-activations: the difference must stay
+    inside the single bf16 rounding of the result (plus the stated 1.5e-7 absolute error of the polynomial)."""
+    x = torch.linspace(-9.0, 9.0, 4096 * 8).reshape(4096, 8)
+    a = bf(torch.cat([x, torch.zeros(4096, 8)], 1))                       # (4096, 16): K = 16, picks x via identity columns
+    w = bf(torch.cat([torch.eye(8), torch.zeros(8, 8)], 1))               # (8, 16)
+    f1, act = G.gemm_bias_gelu(a.to(DEV), w.to(DEV), bf(torch.zeros(8)).to(DEV))
+    assert torch.equal(f1.cpu(), a[:, :8])
+    xd = f1.double().cpu()
+    ref = 0.5 * xd * (1.0 + torch.erf(xd / 2 ** 0.5))
+    err = (act.double().cpu() - ref).abs()
+    assert bool((err <= 2.0 ** -8 * ref.abs() + 2e-6).all()), float(err.max())
+    df = G.gemm_gelu_grad(bf(torch.cat([torch.ones(4096, 1), torch.zeros(4096, 15)], 1)).to(DEV),
+                          bf(torch.cat([torch.ones(8, 1), torch.zeros(8, 15)], 1)).to(DEV), f1)
+    gref = 0.5 * (1.0 + torch.erf(xd / 2 ** 0.5)) + xd * torch.exp(-0.5 * xd * xd) / (2 * torch.pi) ** 0.5
+    gerr = (df.double().cpu() - gref).abs()
+    assert bool((gerr <= 2.0 ** -8 * gref.abs() + 2e-6).all()), float(gerr.max())
+
+
 def test_gemm_nt_identity_detects_transposes():
     """A = I against an asymmetric B: the output must be B^T exactly (no rounding: every output is one bf16 value)."""
     n = 448

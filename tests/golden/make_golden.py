@@ -508,7 +508,61 @@ def gen_bsgal():
     save("bsgal_bank", **store)
 
 
+def gen_augment():
+    """EfficientDetResizeCrop (DG/divergen/data/transforms/custom_augmentation_impl.py:24-72) + its transform
+    (custom_transform.py:27-91) run from the reference's own files on seeded np.random streams: the transform parameters,
+    the resized-and-cropped uint8 image, the nearest-neighbour segmentation path and transformed coordinates."""
+    import importlib.util
+    R.install()
+
+    class _T:                                          # fvcore Transform: only the attribute helper is used
+        def _set_attributes(self, params=None):
+            if params:
+                for k, v in params.items():
+                    if k != "self" and not k.startswith("_"):
+                        setattr(self, k, v)
+    ft = types.ModuleType("fvcore.transforms.transform")
+    for nm in ("BlendTransform", "CropTransform", "HFlipTransform", "NoOpTransform", "VFlipTransform", "TransformList"):
+        setattr(ft, nm, type(nm, (_T,), {}))
+    ft.Transform = _T
+    sys.modules["fvcore.transforms"] = types.ModuleType("fvcore.transforms")
+    sys.modules["fvcore.transforms.transform"] = ft
+    am = types.ModuleType("detectron2.data.transforms.augmentation")
+    am.Augmentation = type("Augmentation", (), {"__init__": lambda self: None})
+    for nm in ("detectron2", "detectron2.data", "detectron2.data.transforms"):
+        sys.modules.setdefault(nm, types.ModuleType(nm))
+    sys.modules["detectron2.data.transforms.augmentation"] = am
+
+    def load(name, path):
+        sys.modules.pop(name, None)
+        spec = importlib.util.spec_from_file_location(name, path)
+        m = importlib.util.module_from_spec(spec)
+        sys.modules[name] = m
+        spec.loader.exec_module(m)
+        return m
+    load("divergen.data.transforms.custom_transform", R.DG + "/data/transforms/custom_transform.py")
+    aug = load("divergen.data.transforms.custom_augmentation_impl", R.DG + "/data/transforms/custom_augmentation_impl.py")
+    store = {}
+    rng = np.random.default_rng(5)
+    cases = [((96, 128), 160, (0.1, 2.0), 11), ((85, 128), 160, (0.1, 2.0), 12), ((66, 100), 128, (0.5, 1.5), 13),
+             ((120, 80), 160, (1.0, 1.0), 14), ((64, 48), -1, (0.8, 1.2), 15), ((96, 128), 160, (0.1, 2.0), 16)]
+    for ci, ((h, w), size, scale, seed) in enumerate(cases):
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        seg = (rng.integers(0, 4, (h, w)) * 60).astype(np.uint8)
+        np.random.seed(seed)
+        t = aug.EfficientDetResizeCrop(size, scale).get_transform(img)
+        pts = rng.uniform(0, min(h, w), (7, 2))
+        store["c%d_img" % ci], store["c%d_seg" % ci], store["c%d_pts" % ci] = img, seg, pts
+        store["c%d_cfg" % ci] = np.array([size, scale[0], scale[1], seed], dtype=np.float64)
+        store["c%d_params" % ci] = np.array([t.scaled_h, t.scaled_w, t.offset_y, t.offset_x, t.img_scale,
+                                              t.target_size[0], t.target_size[1]], dtype=np.float64)
+        store["c%d_out" % ci] = t.apply_image(img)
+        store["c%d_seg_out" % ci] = t.apply_segmentation(seg)
+        store["c%d_pts_out" % ci] = t.apply_coords(pts.copy())
+    save("augment", **store)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["swin", "centernet", "roi", "compositor", "solver", "heads", "postprocess", "pool", "bsgal"]
+    which = sys.argv[1:] or ["swin", "centernet", "roi", "compositor", "solver", "heads", "postprocess", "pool", "bsgal", "augment"]
     for w in which:
         globals()["gen_" + w]()

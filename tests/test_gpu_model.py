@@ -294,3 +294,26 @@ def test_inference_path_end_to_end():
     assert len(rows) == sum(len(o["instances"]) for o in out)
     assert {r["image_id"] for r in rows} == {100, 101} and min(r["category_id"] for r in rows) >= 1
     assert all(isinstance(r["segmentation"]["counts"], str) and r["segmentation"]["size"] == [300, 380] for r in rows)
+
+
+def test_eval_only_flow_reports_lvis_ap(tmp_path, monkeypatch):
+    """DG/train_net.py --eval-only -> do_test: test loader over a (tiny, generated) LVIS-format split, inference with GPU
+    post-processing + run-length encoding, results json, box and mask AP from the LVISEval restatement."""
+    import json
+    import sys
+    sys.path.insert(0, ROOT)
+    import train_net
+    from tests.test_host_data import _tiny_lvis
+    root = _tiny_lvis(tmp_path)
+    os.replace(os.path.join(root, "lvis", "lvis_v1_train.json"), os.path.join(root, "lvis", "lvis_v1_val.json"))
+    monkeypatch.setenv("DETECTRON2_DATASETS", root)
+    cfg, model, opt = _build(False)
+    cfg.merge_from_list(["DATASETS.TEST", ("lvis_v1_val",), "OUTPUT_DIR", str(tmp_path / "out"), "DATALOADER.NUM_WORKERS", 0,
+                         "INPUT.MIN_SIZE_TEST", 128, "INPUT.MAX_SIZE_TEST", 192, "MODEL.DEVICE", "cuda"])
+    res = train_net.do_test(cfg, model)
+    assert set(res) == {"bbox", "segm"}
+    for task in ("bbox", "segm"):
+        assert set(res[task]) == {"AP", "AP50", "AP75", "APs", "APm", "APl", "APr", "APc", "APf"}
+        assert -100.0 <= res[task]["AP"] <= 100.0
+    rows = json.load(open(tmp_path / "out" / "inference_lvis_v1_val" / "lvis_instances_results.json"))
+    assert len(rows) > 0 and {r["image_id"] for r in rows} <= {1, 2, 3, 4, 5, 6}

@@ -414,3 +414,23 @@ def test_predict_instances_candidates_vs_reference_golden(golden):
         o = torch.argsort(r.scores, descending=True, stable=True)
         torch.testing.assert_close(r.scores[o], want_s, atol=0, rtol=0)
         torch.testing.assert_close(r.pred_boxes.tensor[o], want_b, atol=0, rtol=0)
+
+
+def test_drop_path_factors_survive_activation_checkpointing():
+    """MODEL.SWIN.USE_CHECKPOINT: the recomputation of a block in backward must use the DropPath factors of the forward
+    pass (drawn once per step for all blocks by SwinTransformer.forward): gradients with and without checkpointing agree."""
+    from divergen_amd.modeling.backbone.swintransformer import SwinTransformer
+    res = {}
+    for ckpt in (False, True):
+        torch.manual_seed(3)
+        net = SwinTransformer(embed_dim=32, depths=[2, 2], num_heads=[1, 2], window_size=7, drop_path_rate=0.5,
+                              out_indices=(0, 1), use_checkpoint=ckpt).to(DEV).train()
+        torch.manual_seed(17)                      # same DropPath draw in both runs
+        x = torch.randn(4, 3, 64, 64, device=DEV)
+        outs = net(x)
+        sum(o.float().square().mean() for o in outs.values()).backward()
+        res[ckpt] = {n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None}
+    assert res[False].keys() == res[True].keys() and len(res[True]) > 10
+    for k in res[False]:
+        a, b = res[False][k], res[True][k]
+        assert float((a - b).abs().max()) <= 1e-4 * float(a.abs().max()) + 1e-7, k

@@ -9,7 +9,8 @@ pre-step weights -> finite check -> zero_grad/backward -> optimizer.step -> lr s
 kernel over flat arenas; the loss dict is reduced and read on the host only when the writers fire
 (no per-iteration device->host sync); gradients are all-reduced by the arena reducer (RCCL), overlapped
 with backward.  `--num-gpus 0` (what launch.sh passes on a box without nvidia-smi) means all GPUs.
-DATASETS.TRAIN ("synthetic",) (or a missing LVIS tree) trains on LVIS-shaped synthetic batches.
+DATASETS.TRAIN ("synthetic",) trains on LVIS-shaped synthetic batches; a registered dataset name goes through
+divergen_amd/data/build.py (json -> dataset dicts -> mapper -> repeat-factor sampler) and fails loudly when its files are absent.
 """
 import datetime
 import logging
@@ -49,16 +50,49 @@ class ModelEma:
         self.optimizer.load_ema_state_dict(sd)
 
 
-def build_train_loader(cfg, device):
-    """Batches with the reference's contract.  Real LVIS loading (json + PIL + EfficientDetResizeCrop +
-    InstPool) lives in divergen_amd/data; without a dataset tree the loop runs on synthetic batches."""
+def base_seed(cfg):
+    """D2 seed_all_rng semantics (D2/utils/env.py:26-43, D2/engine/defaults.py:default_setup): SEED < 0 draws a fresh seed,
+    shared by all ranks here so that rank-derived streams stay distinct and reproducible within a run."""
+    return int(cfg.SEED) if cfg.SEED >= 0 else int(comm.shared_random_seed())
+
+
+def build_train_loader(cfg, device, seed=None):
+    """Batches with the reference's contract (list[dict] with image / instances / height / width).
+    DATASETS.TRAIN ("synthetic",) -> LVIS-shaped random batches; anything else goes through divergen_amd.data.build
+    (dataset dicts from the registered json, DatasetMapper / CopyPasteMapper, RepeatFactorTrainingSampler) and RAISES when
+    the dataset cannot be found -- it never falls back to noise silently."""
     per_gpu = max(cfg.SOLVER.IMS_PER_BATCH // comm.get_world_size(), 1)
+    seed = base_seed(cfg) if seed is None else seed
+    names = tuple(cfg.DATASETS.TRAIN)
+    if names != ("synthetic",):
+        from divergen_amd.data.build import build_detection_train_loader
+        yield from build_detection_train_loader(cfg, per_gpu, device, seed)
+        return
     size = cfg.INPUT.TRAIN_SIZE
     ncls = cfg.MODEL.ROI_HEADS.NUM_CLASSES
     it = 0
     while True:
-        yield synthetic_batch(per_gpu, size, ncls, seed=cfg.SEED * 100003 + comm.get_rank() * 1009 + it, device=device)
+        yield synthetic_batch(per_gpu, size, ncls, seed=(seed * 100003 + comm.get_rank() * 1009 + it) % (2 ** 63), device=device)
         it += 1
+
+
+def do_test(cfg, model):
+    """DG/train_net.py:62-126 for LVIS-type test sets: test loader (one image per batch, sharded over ranks), GPU
+    post-processing + run-length encoding, results json, box / mask AP."""
+    from collections import OrderedDict
+    from divergen_amd.data.build import build_detection_test_loader
+    from divergen_amd.evaluation import LVISEvaluator, inference_on_dataset, print_csv_format
+    results = OrderedDict()
+    device = torch.device(cfg.MODEL.DEVICE)
+    for dataset_name in cfg.DATASETS.TEST:
+        loader = build_detection_test_loader(cfg, dataset_name, device)
+        out_dir = os.path.join(cfg.OUTPUT_DIR, "inference_{}".format(dataset_name))
+        evaluator = LVISEvaluator(dataset_name, cfg, True, out_dir, max_dets_per_image=cfg.TEST.DETECTIONS_PER_IMAGE)
+        results[dataset_name] = inference_on_dataset(model, loader, evaluator)
+        if comm.is_main_process():
+            logger.info("Evaluation results for {} in csv format:".format(dataset_name))
+            print_csv_format(results[dataset_name])
+    return list(results.values())[0] if len(results) == 1 else results
 
 
 def do_train(cfg, model, resume=False):
@@ -68,6 +102,8 @@ def do_train(cfg, model, resume=False):
     reducer = ArenaReducer(optimizer.arena)
     kwargs = {"model_ema": ModelEma(model, optimizer)} if cfg.SOLVER.MODEL_EMA > 0 else {}
     checkpointer = DetectionCheckpointer(model, cfg.OUTPUT_DIR, optimizer=optimizer, scheduler=scheduler, **kwargs)
+    if cfg.MODEL.WEIGHTS and not resume and not os.path.isfile(cfg.MODEL.WEIGHTS):
+        raise FileNotFoundError("Checkpoint {} not found!".format(cfg.MODEL.WEIGHTS))      # as the reference's checkpointer
     start_iter = checkpointer.resume_or_load(cfg.MODEL.WEIGHTS if os.path.isfile(cfg.MODEL.WEIGHTS) else "",
                                              resume=resume).get("iteration", -1) + 1
     if not resume:
@@ -133,7 +169,7 @@ def setup(args):
             f.write(cfg.dump())
         logging.basicConfig(level=logging.INFO, format="[%(asctime)s %(name)s]: %(message)s",
                             handlers=[logging.StreamHandler(), logging.FileHandler(os.path.join(cfg.OUTPUT_DIR, "log.txt"))])
-    torch.manual_seed(cfg.SEED + comm.get_rank())
+    torch.manual_seed(base_seed(cfg) + comm.get_rank())
     return cfg
 
 
@@ -142,10 +178,7 @@ def main(args):
     model = build_model(cfg)
     if args.eval_only:
         DetectionCheckpointer(model, save_dir=cfg.OUTPUT_DIR).resume_or_load(cfg.MODEL.WEIGHTS, resume=args.resume)
-        # do_test (DG/train_net.py:61-118) up to the results file: the loop, the GPU post-processing and the LVIS-format
-        # json are here (divergen_amd/evaluation); AP itself needs the dataset tree and lvis-api, absent from this image
-        raise SystemExit("LVIS evaluation needs the dataset and lvis-api.  Results in LVIS format are produced by "
-                         "divergen_amd.evaluation.inference_on_dataset(model, loader, LVISResultsWriter(out_dir))")
+        return do_test(cfg, model.to(torch.device(cfg.MODEL.DEVICE)))
     do_train(cfg, model, resume=args.resume)
 
 

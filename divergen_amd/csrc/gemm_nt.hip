@@ -50,6 +50,12 @@ struct GemmP {
     const float* scale;     //         per-sample DropPath factor or null
     int res_dtype;
     GMap map;
+    // implicit 3x3 convolution (pad 1, stride 1) over a zero-bordered NHWC image (dgx_conv3x3_*): K-tile kt of the A operand
+    // is tap kt / conv_kc, channels 64 (kt % conv_kc) ..: the SAME rows shifted by (tap / 3) * conv_wp + tap % 3 pixels;
+    // rows are positions of the padded grid, the epilogue keeps the interior ones (cmap: n, h, w of the unpadded output)
+    int conv_kc, conv_wp;
+    int cmap_n, cmap_h, cmap_w;
+    int relu;
 };
 
 __device__ __forceinline__ void g_load_lds16(uint32_t voff, u32x4 rsrc, uint32_t lds_addr, uint32_t soff) {
@@ -148,7 +154,12 @@ __device__ __forceinline__ void g_epi_prefetch(const GemmP& P, int gm, int gn, i
 __device__ __forceinline__ void g_epi_finish(const GemmP& P, int gm, int gn, const u32x4 y, int64_t tok, float sc, const u32x4 xa,
                                              const u32x4 xb) {
     if (P.mode <= 1) {
-        *reinterpret_cast<u32x4*>(P.C + (int64_t)gm * P.ldc + gn) = y;
+        u32x4 o = y;
+        if (P.relu) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = ((o[k] & 0x8000u) ? 0u : (o[k] & 0xffffu)) | ((o[k] & 0x80000000u) ? 0u : (o[k] & 0xffff0000u));
+        }
+        *reinterpret_cast<u32x4*>(P.C + (int64_t)gm * P.ldc + gn) = o;
     } else if (P.mode == 2) {
         *reinterpret_cast<u32x4*>(P.C + (int64_t)gm * P.ldc + gn) = y;
         float v[8], o[8];
@@ -239,16 +250,21 @@ __global__ __launch_bounds__(512, MINW) void gemm_nt_kernel(GemmP P) {
         voffB[s] = n < P.N ? (uint32_t)(((int64_t)n * P.ldb + lc * 8) * 2) : G_OOB;
     }
     const bool kt_ok = lc * 8 < ktail;             // this lane's chunk exists in the last K-tile
-    const u32x4 rA = g_rsrc(P.A, (uint32_t)((int64_t)P.M * P.lda * 2));
+    const u32x4 rA = g_rsrc(P.A, (uint32_t)(((int64_t)P.M + (P.conv_kc ? 2 * P.conv_wp + 2 : 0)) * P.lda * 2));
     const u32x4 rB = g_rsrc(P.B, (uint32_t)((int64_t)P.N * P.ldb * 2));
     const uint32_t lds0 = (uint32_t)(uintptr_t)(DGX_LDS unsigned char*)lds_raw;
     const uint32_t ldsw = __builtin_amdgcn_readfirstlane(lds0 + 1024u * w);
     // one of the NL loads of a tile: k < NA -> A rows, else B rows
     auto issue_one = [&](int k, int t, int stage) {
         const uint32_t soff = (uint32_t)(kt0 + t) * (GBK * 2);
+        uint32_t soffA = soff;
+        if (P.conv_kc) {                           // implicit convolution: tap shift (rows) + channel block of the tap
+            const int tap = (kt0 + t) / P.conv_kc, kc = (kt0 + t) - tap * P.conv_kc;
+            soffA = (uint32_t)((tap / 3) * P.conv_wp + tap % 3) * (uint32_t)(P.lda * 2) + (uint32_t)kc * (GBK * 2);
+        }
         const uint32_t dst = ldsw + (uint32_t)stage * SB;
         const bool tail = (kt0 + t == NTK - 1) && (ktail != GBK) && !kt_ok;
-        if (k < NA) g_load_lds16(tail ? G_OOB : voffA[k], rA, dst + 8192u * k, soff);
+        if (k < NA) g_load_lds16(tail ? G_OOB : voffA[k], rA, dst + 8192u * k, soffA);
         else g_load_lds16(tail ? G_OOB : voffB[k - NA], rB, dst + BM * 128 + 8192u * (k - NA), soff);
     };
 
@@ -424,6 +440,13 @@ __global__ __launch_bounds__(512, MINW) void gemm_nt_kernel(GemmP P) {
         const int64_t tok = orow < P.M ? g_row_token(P.map, orow, b) : -1;
         rowtok[tid] = tok < 0 ? -1 : ((tok << 12) | (int64_t)b);
     }
+    if (P.cmap_h && tid < BM) {                    // padded-grid row -> row of the unpadded (n, h, w) output, -1 on the border
+        const int mp = m0 + tid, hp = P.cmap_h + 2, wp = P.cmap_w + 2;
+        const int n = mp / (hp * wp), r = mp - n * (hp * wp);
+        const int yp = r / wp, xp = r - yp * wp;
+        const bool in = mp < P.M && yp >= 1 && yp <= P.cmap_h && xp >= 1 && xp <= P.cmap_w;
+        rowtok[tid] = in ? (int64_t)(n * P.cmap_h + yp - 1) * P.cmap_w + xp - 1 : -1;
+    }
     __syncthreads();
     GCLK(3);
     constexpr int CPR = BN / 8;                    // 16-byte chunks per tile row
@@ -447,6 +470,11 @@ __global__ __launch_bounds__(512, MINW) void gemm_nt_kernel(GemmP P) {
             q.ok = rt >= 0;
             q.tok = rt >> 12;
             if (q.ok && P.scale) q.sc = P.scale[(int)(rt & 4095)];
+        }
+        if (P.cmap_h && q.ok) {
+            const int64_t rt = rowtok[q.row];
+            q.ok = rt >= 0;
+            q.gm = (int)rt;                        // destination row of the unpadded output
         }
         if (q.ok) g_epi_prefetch(P, q.gm, q.gn, q.tok, q.xa, q.xb);
     };
@@ -660,6 +688,43 @@ extern "C" int dgx_gemm_bf16_nt(const void* A, const void* B, int M, int N, int 
     if (tc.bn == 256) return launch_gemm<128, 256, 3>(P, st);
     if (tc.bm == 256) return launch_gemm<256, 128, 3>(P, st);
     return launch_gemm<128, 128, 4>(P, st);
+}
+
+static int dgx_gemm_dispatch(GemmP& P, hipStream_t st) {
+    const TileChoice tc = choose_tile(P.M, P.N);
+    if (tc.bn == 192) {
+        if (tc.bm == 256) return launch_gemm<256, 192, 2>(P, st);
+        if (tc.bm == 192) return launch_gemm<192, 192, 3>(P, st);
+        return launch_gemm<128, 192, 4>(P, st);
+    }
+    if (tc.bn == 256) return launch_gemm<128, 256, 3>(P, st);
+    if (tc.bm == 256) return launch_gemm<256, 128, 3>(P, st);
+    return launch_gemm<128, 128, 4>(P, st);
+}
+
+extern "C" int64_t dgx_conv3x3_pad_rows(int N, int H, int W) {
+    return (N <= 0 || H <= 0 || W <= 0) ? 0 : (int64_t)N * (H + 2) * (W + 2) + 2 * (int64_t)(W + 3);
+}
+
+extern "C" int dgx_conv3x3_gemm(const void* xpad, const void* w, const void* bias, void* y, int N, int H, int W, int Cin, int Cout,
+                                int relu, void* stream) {
+    if (N <= 0 || H <= 0 || W <= 0) return DGX_OK;
+    if (!xpad || !w || !y || Cin <= 0 || Cout <= 0 || (Cin & 63) || (Cout & 7)) return DGX_ERR_BAD_ARG;
+    const int64_t Mp = (int64_t)N * (H + 2) * (W + 2);
+    if (dgx_conv3x3_pad_rows(N, H, W) * Cin * 2 >= (1ll << 31) || (int64_t)Cout * 9 * Cin * 2 >= (1ll << 31)) return DGX_ERR_UNSUPPORTED;
+    GemmP P;
+    memset((void*)&P, 0, sizeof(P));
+    P.A = (const uint16_t*)xpad;                   // row 0 of the GEMM = padded position 0 minus (Wp + 1): the leading slack
+    P.B = (const uint16_t*)w;
+    P.M = (int)Mp; P.N = Cout; P.K = 9 * Cin; P.lda = Cin; P.ldb = 9 * Cin;
+    P.mode = bias ? DGX_EPI_BIAS : DGX_EPI_NONE;
+    P.C = (uint16_t*)y; P.ldc = Cout;
+    P.bias = (const uint16_t*)bias;
+    P.conv_kc = Cin / GBK; P.conv_wp = W + 2;
+    P.cmap_n = N; P.cmap_h = H; P.cmap_w = W;
+    P.relu = relu;
+    g_ws_bytes_cur = 0;
+    return dgx_gemm_dispatch(P, (hipStream_t)stream);
 }
 
 // Development timing hook (not part of include/divergen_hip.h): `iters` back-to-back launches of the same GEMM between two

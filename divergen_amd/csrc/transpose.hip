@@ -7,7 +7,8 @@
 #include "dgx_common.h"
 
 namespace {
-struct TJob { int64_t off; int rows, cols; int64_t tile0; };    // matrix (rows, cols) at element offset `off` in both arenas
+// matrix (rows, cols) at element offset `off` in both arenas; cin > 0: 3x3 convolution weight, tap-flipped twin
+struct TJob { int64_t off; int rows, cols; int64_t tile0; int64_t cin; };
 
 __global__ __launch_bounds__(256) void transpose_grouped_kernel(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst,
                                                                 const TJob* __restrict__ jobs, int njobs, int64_t total_tiles) {
@@ -26,6 +27,14 @@ __global__ __launch_bounds__(256) void transpose_grouped_kernel(const uint16_t* 
         uint16_t* d = dst + j.off;
         const int t = threadIdx.x;
         const bool vec = ((j.rows | j.cols) & 7) == 0 && (j.off & 7) == 0;
+        // destination of source element (r, c): plain transpose d[c * rows + r]; conv twin (cols = 9 cin, c = tap * cin + ci):
+        // d[ci * 9 rows + (8 - tap) * rows + r] -- a 64-column tile lies inside one tap (cin % 64 == 0)
+        int64_t dbase = (int64_t)c0 * j.rows, dstride = j.rows;
+        if (j.cin > 0) {
+            const int tap = c0 / (int)j.cin, ci0 = c0 - tap * (int)j.cin;
+            dbase = (int64_t)ci0 * 9 * j.rows + (int64_t)(8 - tap) * j.rows;
+            dstride = 9 * (int64_t)j.rows;
+        }
         __syncthreads();
         if (vec) {
 #pragma unroll
@@ -43,7 +52,7 @@ __global__ __launch_bounds__(256) void transpose_grouped_kernel(const uint16_t* 
                     uint32_t w[4];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) w[k] = (uint32_t)tile[orr + 2 * k][oc] | ((uint32_t)tile[orr + 2 * k + 1][oc] << 16);
-                    *reinterpret_cast<u32x4*>(d + (int64_t)(c0 + oc) * j.rows + r0 + orr) = u32x4{w[0], w[1], w[2], w[3]};
+                    *reinterpret_cast<u32x4*>(d + dbase + (int64_t)oc * dstride + r0 + orr) = u32x4{w[0], w[1], w[2], w[3]};
                 }
             }
         } else {
@@ -54,7 +63,7 @@ __global__ __launch_bounds__(256) void transpose_grouped_kernel(const uint16_t* 
             __syncthreads();
             for (int i = t; i < 64 * 64; i += 256) {
                 const int oc = i >> 6, orr = i & 63;
-                if (c0 + oc < j.cols && r0 + orr < j.rows) d[(int64_t)(c0 + oc) * j.rows + r0 + orr] = tile[orr][oc];
+                if (c0 + oc < j.cols && r0 + orr < j.rows) d[dbase + (int64_t)oc * dstride + r0 + orr] = tile[orr][oc];
             }
         }
     }

@@ -17,7 +17,7 @@ constexpr int BM256 = 32;               // m-depth per stage (one K=32 MFMA step
 constexpr int NB256 = 4;                // LDS stage buffers: the stage being computed + 3 in flight
 constexpr int OPB256 = BM256 * T256 * 2;       // bytes of one operand image per stage (16 KiB)
 constexpr int STB256 = 2 * OPB256;             // bytes per stage (A then B)
-constexpr int MAXP256 = 8;
+constexpr int MAXP256 = 9;              // 9 = the taps of a 3x3 convolution (dgx_conv3x3_wgrad)
 
 struct Prob256 {
     const uint16_t* A;
@@ -25,6 +25,7 @@ struct Prob256 {
     float* C;
     float* ws;          // partial tiles [S][Nn][Kk]
     int M, Nn, Kk, tiles_k, tiles, S, slab, wg0;
+    int ldc;            // row stride of C (elements): Kk for a Linear, 9 Cin for one tap block of a convolution weight
     int64_t red0;       // first float4 of this problem in the reduce kernel's index space
 };
 struct Params256 {
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(256) void wgrad256_partial_kernel(Params256 P) {
             const f32x4 v = *reinterpret_cast<DGX_LDS const f32x4*>(stg + row * SR + 4 * c4);
             const int n = n0 + wn + 16 * i + row, k = k0 + wk + 4 * c4;
             if (n < q.Nn && k < q.Kk) {                // Kk % 8 == 0: a quad never straddles the edge
-                f32x4* o = reinterpret_cast<f32x4*>(out + (int64_t)n * q.Kk + k);
+                f32x4* o = reinterpret_cast<f32x4*>(out + (int64_t)n * (direct ? q.ldc : q.Kk) + k);
                 *o = beta != 0.f ? beta * *o + v : v;
             }
         }
@@ -242,12 +243,13 @@ __global__ __launch_bounds__(256) void wgrad256_reduce_kernel(Params256 P, int64
             }
             if (sub != 0) continue;
         }
-        float4* C = reinterpret_cast<float4*>(q.C);
+        const int64_t k4 = q.Kk / 4, rowc = e / k4;
+        float4* C = reinterpret_cast<float4*>(q.C + rowc * q.ldc) + (e - rowc * k4);
         if (P.beta != 0.f) {
-            const float4 c = C[e];
+            const float4 c = *C;
             a.x += P.beta * c.x; a.y += P.beta * c.y; a.z += P.beta * c.z; a.w += P.beta * c.w;
         }
-        C[e] = a;
+        *C = a;
     }
 }
 
@@ -288,8 +290,41 @@ extern "C" int64_t dgx_wgrad_grouped_workspace_bytes(const dgx_wgrad_problem* pr
     return ws_floats256(problems, n, S, nullptr) * 4;
 }
 
+static int wgrad_grouped_impl(const dgx_wgrad_problem* problems, const int* ldc, int n, float beta, void* workspace, void* stream);
+
 extern "C" int dgx_linear_wgrad_grouped(const dgx_wgrad_problem* problems, int n, float beta, void* workspace,
                                         void* stream) {
+    return wgrad_grouped_impl(problems, nullptr, n, beta, workspace, stream);
+}
+
+// Weight gradient of a 3x3 convolution (pad 1, stride 1) without a column matrix: dW[co][tap][ci] = sum over the padded grid of
+// dypad[m][co] * xpad[m + shift(tap)][ci] -- nine Linear-type problems over the SAME two zero-bordered images (dgx_conv3x3_pad:
+// border rows of dypad are zero, so border positions add nothing), the tap being a pointer offset; gw f32 (Cout, 3, 3, Cin).
+extern "C" int64_t dgx_conv3x3_wgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout) {
+    dgx_wgrad_problem pr[9];
+    const int64_t Mp = (int64_t)N * (H + 2) * (W + 2);
+    for (int t = 0; t < 9; ++t) { pr[t].dy = pr[t].x = nullptr; pr[t].gw = nullptr; pr[t].M = (int)Mp; pr[t].Nn = Cout; pr[t].Kk = Cin; }
+    return dgx_wgrad_grouped_workspace_bytes(pr, 9);
+}
+extern "C" int dgx_conv3x3_wgrad(const void* dypad, const void* xpad, float* gw, int N, int H, int W, int Cin, int Cout, float beta,
+                                 void* workspace, void* stream) {
+    if (N <= 0 || H <= 0 || W <= 0) return DGX_OK;
+    if (!dypad || !xpad || !gw || (Cin & 7) || (Cout & 7)) return DGX_ERR_BAD_ARG;
+    const int64_t Mp = (int64_t)N * (H + 2) * (W + 2);
+    const int wp = W + 2;
+    dgx_wgrad_problem pr[9];
+    int ldc[9];
+    for (int t = 0; t < 9; ++t) {
+        pr[t].dy = (const uint16_t*)dypad + (int64_t)(wp + 1) * Cout;                          // grid position 0 (behind the slack)
+        pr[t].x = (const uint16_t*)xpad + (int64_t)((t / 3) * wp + t % 3) * Cin;               // position 0 shifted by tap - (wp + 1)
+        pr[t].gw = gw + (int64_t)t * Cin;
+        pr[t].M = (int)Mp; pr[t].Nn = Cout; pr[t].Kk = Cin;
+        ldc[t] = 9 * Cin;
+    }
+    return wgrad_grouped_impl(pr, ldc, 9, beta, workspace, stream);
+}
+
+static int wgrad_grouped_impl(const dgx_wgrad_problem* problems, const int* ldc, int n, float beta, void* workspace, void* stream) {
     if (n <= 0) return DGX_OK;
     if (!problems || n > MAXP256) return DGX_ERR_BAD_ARG;
     for (int i = 0; i < n; ++i) {
@@ -314,6 +349,7 @@ extern "C" int dgx_linear_wgrad_grouped(const dgx_wgrad_problem* problems, int n
         q.C = p.gw;
         q.ws = (float*)workspace + off[i];
         q.M = p.M; q.Nn = p.Nn; q.Kk = p.Kk;
+        q.ldc = ldc ? ldc[i] : p.Kk;
         q.tiles_k = (p.Kk + T256 - 1) / T256;
         q.S = S[i];
         q.slab = slab[i];

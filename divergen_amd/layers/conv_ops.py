@@ -54,7 +54,8 @@ class _Conv3x3(torch.autograd.Function):
                 wk = wm.t().contiguous()
             y = gemm_nt(col, wk, shadow(bias) if bias is not None else None)
             wt = getattr(weight, "_dgx16t", None)      # (9 Cin, Cout): the arena's transposed twin, else a copy
-            wm = wt if (wt is not None and _ohwi_matrix(shadow(weight)) is not None) else wm.contiguous()
+            plain = wt is not None and not getattr(weight, "_dgx16t_flipped", False) and _ohwi_matrix(shadow(weight)) is not None
+            wm = wt if plain else wm.contiguous()
         elif bias is not None:
             y = torch.addmm(shadow(bias) if bf else bias.to(x.dtype), col, wm)
         else:
@@ -103,6 +104,95 @@ class _Conv3x3(torch.autograd.Function):
         return gx, gw, gb, None
 
 
+def _pad_image(x_nhwc):
+    """Zero-bordered copy for the implicit convolution (dgx_conv3x3_pad): ((W+3) + N (H+2) (W+2) + (W+3), C)."""
+    N, H, W, C = x_nhwc.shape
+    rows = int(L.lib().dgx_conv3x3_pad_rows(N, H, W))
+    xp = torch.empty(rows, C, dtype=x_nhwc.dtype, device=x_nhwc.device)
+    L.check(L.lib().dgx_conv3x3_pad(L.ptr(x_nhwc), L.ptr(xp), N, H, W, C, L.stream()), "dgx_conv3x3_pad")
+    return xp
+
+
+def _flipped_twin(weight, w16):
+    """(Cin, 3, 3, Cout) bf16 with [ci][ey][ex][co] = w[co][ci][2-ey][2-ex]: the arena's twin when it has one, else built here."""
+    if getattr(weight, "_dgx16t_flipped", False):
+        return weight._dgx16t
+    return w16.flip(2, 3).permute(1, 2, 3, 0).reshape(w16.shape[1], -1).contiguous()
+
+
+class _Conv3x3Implicit(torch.autograd.Function):
+    """3x3 / pad 1 / stride 1 convolution on libdgx's implicit GEMM (no column matrix): forward, input gradient and weight
+    gradient all read zero-bordered copies of the NHWC tensors; bf16, Cin % 64 == 0, Cout % 8 == 0."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu):
+        N, H, W, C = x.shape
+        w16 = shadow(weight)
+        wk = _ohwi_matrix(w16)
+        if wk is None:
+            wk = w16.permute(0, 2, 3, 1).reshape(w16.shape[0], -1).contiguous()
+        Co = wk.shape[0]
+        xp = _pad_image(x)
+        y = torch.empty(N, H, W, Co, dtype=torch.bfloat16, device=x.device)
+        b16 = shadow(bias) if bias is not None else None
+        L.check(L.lib().dgx_conv3x3_gemm(L.ptr(xp), wk.data_ptr(), L.ptr(b16), L.ptr(y), N, H, W, C, Co, int(relu), L.stream()),
+                "dgx_conv3x3_gemm")
+        ctx.save_for_backward(xp, y if relu else None)
+        ctx.weight, ctx.bias, ctx.w16 = weight, bias, w16
+        ctx.cfg = (N, H, W, C, Co, relu)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        xp, yact = ctx.saved_tensors
+        N, H, W, C, Co, relu = ctx.cfg
+        weight, bias = ctx.weight, ctx.bias
+        lib = L.lib()
+        g2 = gy.to(torch.bfloat16).contiguous()
+        if relu:
+            g2 = g2 * (yact > 0)
+        gx = gw = gb = None
+        gp = _pad_image(g2)
+        if ctx.needs_input_grad[0]:
+            wf = _flipped_twin(weight, ctx.w16)                       # (Cin, 9 Cout)
+            gsrc = gp
+            if Co % 64:                                                # K-tiles of the input-gradient GEMM hold 64 channels of one tap
+                cp = -(-Co // 64) * 64
+                gsrc = _pad_image(torch.nn.functional.pad(g2, (0, cp - Co)))
+                wf = torch.nn.functional.pad(wf.view(C, 9, Co), (0, cp - Co)).reshape(C, 9 * cp).contiguous()
+                Ck = cp
+            else:
+                Ck = Co
+            gx = torch.empty(N, H, W, C, dtype=torch.bfloat16, device=g2.device)
+            L.check(lib.dgx_conv3x3_gemm(L.ptr(gsrc), wf.data_ptr(), None, L.ptr(gx), N, H, W, Ck, C, 0, L.stream()), "dgx_conv3x3_gemm")
+        if ctx.needs_input_grad[1]:
+            ws = torch.empty(max(int(lib.dgx_conv3x3_wgrad_workspace_bytes(N, H, W, C, Co)), 16), dtype=torch.uint8, device=g2.device)
+            gphys = _ohwi_matrix(weight.grad) if (weight.is_leaf and weight.grad is not None) else None
+            if gphys is not None and gphys.dtype == torch.float32 and getattr(weight, "_dgx16", None) is not None:
+                L.check(lib.dgx_conv3x3_wgrad(L.ptr(gp), L.ptr(xp), gphys.data_ptr(), N, H, W, C, Co, 1.0, L.ptr(ws), L.stream()),
+                        "dgx_conv3x3_wgrad")
+                notify_ready(weight)
+            else:
+                def wgrad():
+                    g = torch.empty(Co, 3, 3, C, dtype=torch.float32, device=g2.device)
+                    L.check(lib.dgx_conv3x3_wgrad(L.ptr(gp), L.ptr(xp), L.ptr(g), N, H, W, C, Co, 0.0, L.ptr(ws), L.stream()),
+                            "dgx_conv3x3_wgrad")
+                    return g.permute(0, 3, 1, 2)
+                gw = accumulate_grad(weight, wgrad)
+        if bias is not None and ctx.needs_input_grad[2]:
+            g2f = g2.view(-1, Co)
+            if (bias.is_leaf and bias.grad is not None and bias.grad.dtype == torch.float32 and getattr(bias, "_dgx16", None) is not None):
+                from .swin_block import colsum_into
+                colsum_into(bias.grad, g2f)
+                notify_ready(bias)
+            else:
+                gb = accumulate_grad(bias, lambda: torch.sum(g2f, 0, dtype=torch.float32))
+        return gx, gw, gb, None
+
+
+_IMPLICIT = os.environ.get("DGX_CONV_IMPLICIT", "1") == "1"      # A/B switch against the im2col path
+
+
 def _compute_dtype(x):
     return torch.bfloat16 if torch.is_autocast_enabled() else x.dtype
 
@@ -122,12 +212,20 @@ def _pad_cout(weight, bias):
     return weight, bias, co
 
 
-def conv3x3(x, weight, bias=None, stride=1):
-    """x logical (N,C,H,W) -> logical (N,Cout,Ho,Wo), NHWC storage both sides."""
+def conv3x3(x, weight, bias=None, stride=1, relu=False):
+    """x logical (N,C,H,W) -> logical (N,Cout,Ho,Wo), NHWC storage both sides.  relu: fused into the implicit-GEMM epilogue
+    where that path applies, applied afterwards otherwise."""
     xh = _nhwc(x).to(_compute_dtype(x))
     weight, bias, co = _pad_cout(weight, bias)
+    implicit = (_IMPLICIT and stride == 1 and xh.is_cuda and xh.dtype == torch.bfloat16 and xh.shape[-1] % 64 == 0
+                and weight.shape[0] % 8 == 0)
     with torch.autocast("cuda", enabled=False):
-        y = _Conv3x3.apply(xh, weight, bias, stride)
+        if implicit:
+            y = _Conv3x3Implicit.apply(xh, weight, bias, relu)
+        else:
+            y = _Conv3x3.apply(xh, weight, bias, stride)
+            if relu:
+                y = torch.relu(y)
     return y[..., :co].permute(0, 3, 1, 2)
 
 
@@ -168,6 +266,7 @@ class Conv2d(torch.nn.Conv2d):
         super().__init__(*a, **k)
         if self.kernel_size == (3, 3) and self.groups == 1 and os.environ.get("DGX_CONV_OHWI", "1") == "1":
             self.weight._dgx_ohwi = True       # FlatArena stores it (Cout, kh, kw, Cin): see solver.FlatArena.view
+            self.weight._dgx_flip = self.stride == (1, 1)      # its bf16 twin: tap-flipped (Cin, kh, kw, Cout), the input-gradient operand
 
     def forward(self, x):
         k, s, p = self.kernel_size, self.stride, self.padding

@@ -64,8 +64,15 @@ class FlatArena:
             if self.p16t is not None and p.dim() >= 2:
                 rows = self.stored_rows(p)
                 cols = p.numel() // rows
-                p._dgx16t = self.p16t[o:o + p.numel()].view(cols, rows)
-                jobs.append((o, rows | (cols << 32), tiles))
+                cin = 0
+                if getattr(p, "_dgx_flip", False) and getattr(p, "_dgx_ohwi", False) and p.dim() == 4 and p.shape[1] % 64 == 0 \
+                        and p.shape[0] % 8 == 0:
+                    cin = p.shape[1]              # stride-1 3x3 convolution: tap-flipped twin (Cin, 3, 3, Cout) for its input gradient
+                    p._dgx16t = self.p16t[o:o + p.numel()].view(cin, 9 * rows)
+                    p._dgx16t_flipped = True
+                else:
+                    p._dgx16t = self.p16t[o:o + p.numel()].view(cols, rows)
+                jobs.append((o, rows | (cols << 32), tiles, cin))
                 tiles += ((rows + 63) // 64) * ((cols + 63) // 64)
         self._tjobs = torch.tensor(jobs, dtype=torch.int64, device=dev) if jobs else None
         self._ttiles = tiles

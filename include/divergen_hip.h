@@ -263,7 +263,7 @@ int dgx_residual_bwd(const void* g, const float* scale, void* dy_bf16, int B, in
 /* ---------------------------------------------------------------------------------------------
  * Grouped form of dgx_linear_wgrad: the weight gradients of several Linear layers (the four of a Swin
  * block: qkv/proj/fc1/fc2, swintransformer.py:101-108,36-46) in ONE launch, so that large output tiles
- * fill the GPU with a small M-split.  n <= 8 problems; for each gw (Nn,Kk) = beta*gw + dy^T x.
+ * fill the GPU with a small M-split.  n <= 9 problems; for each gw (Nn,Kk) = beta*gw + dy^T x.
  * Nn % 8 == 0, Kk % 8 == 0.  workspace: dgx_wgrad_grouped_workspace_bytes(problems, n) bytes. */
 typedef struct dgx_wgrad_problem {
     const void* dy;   /* bf16 (M, Nn) row-major */
@@ -443,8 +443,33 @@ int dgx_gemm_bf16_nt(const void* A, const void* B, int M, int N, int K, int64_t 
 /* Transposed twins of the matrix parameters inside a flat bf16 arena (the operand layout dgx_gemm_bf16_nt needs for the
  * input gradient dx = dy W of F.linear; autograd's mm(dy, W) behind swintransformer.py:40-46,133,155,296): for every job,
  * dst[off + c*rows + r] = src[off + r*cols + c].  jobs = DEVICE array of njobs records {int64 off; int32 rows; int32 cols;
- * int64 tile0} sorted by tile0 = number of 64x64 tiles of all earlier jobs; total_tiles = their total.  One launch. */
+ * int64 tile0; int64 cin} sorted by tile0 = number of 64x64 tiles of all earlier jobs; total_tiles = their total.  cin > 0 marks a
+ * 3x3 convolution weight stored (Cout, 3, 3, Cin) (rows = Cout, cols = 9 cin, cin % 64 == 0): its twin is the tap-flipped
+ * transpose (Cin, 3, 3, Cout) that dgx_conv3x3_gemm takes for the input gradient.  One launch. */
 int dgx_transpose_bf16_grouped(const void* src, void* dst, const void* jobs, int njobs, int64_t total_tiles, void* stream);
+
+
+/* ---------------------------------------------------------------------------------------------
+ * 3x3 convolution (pad 1, stride 1) as an IMPLICIT GEMM over channels-last bf16 images -- the F.conv2d calls of
+ * D2/modeling/backbone/fpn.py:126-154 (output convs), CN/modeling/dense_heads/centernet_head.py:58-77,141-162 (towers and
+ * predictors) and D2/modeling/roi_heads/mask_head.py:209-284 (mask head), forward AND both gradients, with no column matrix.
+ *   dgx_conv3x3_pad    xpad = zero-bordered copy of x (N,H,W,C): rows = (W+3) zero rows, the (N,H+2,W+2) grid, (W+3) zero rows;
+ *                      dgx_conv3x3_pad_rows(N,H,W) rows of C elements.  C % 8 == 0.
+ *   dgx_conv3x3_gemm   y (N,H,W,Cout) = conv(x, w) (+ bias) (ReLU when relu != 0):  w bf16 (Cout, 3, 3, Cin) = (Cout, 9 Cin),
+ *                      Cin % 64 == 0, Cout % 8 == 0.  The MFMA pipeline of dgx_gemm_bf16_nt; K-tile kt of the A operand is tap
+ *                      kt / (Cin/64): the same rows of xpad shifted by a constant, so every tap is a plain strided read.
+ *                      The INPUT gradient is the same call: dx = dgx_conv3x3_gemm(dypad, wflip, NULL, ...) with
+ *                      wflip (Cin, 3, 3, Cout)[ci][ey][ex][co] = w[co][2-ey][2-ex][ci]  (and Cin / Cout exchanged).
+ *   dgx_conv3x3_wgrad  gw f32 (Cout,3,3,Cin) = beta*gw + sum over positions of dypad (x) xpad shifted per tap: nine problems of
+ *                      the grouped weight-gradient kernel over the two padded images.  workspace: ..._workspace_bytes().
+ */
+int64_t dgx_conv3x3_pad_rows(int N, int H, int W);
+int dgx_conv3x3_pad(const void* x, void* xpad, int N, int H, int W, int C, void* stream);
+int dgx_conv3x3_gemm(const void* xpad, const void* w, const void* bias, void* y, int N, int H, int W, int Cin, int Cout,
+                     int relu, void* stream);
+int64_t dgx_conv3x3_wgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout);
+int dgx_conv3x3_wgrad(const void* dypad, const void* xpad, float* gw, int N, int H, int W, int Cin, int Cout, float beta,
+                      void* workspace, void* stream);
 
 #ifdef __cplusplus
 }

@@ -638,3 +638,61 @@ def test_layernorm_f32out_vs_torch(T, C, dt):
     torch.testing.assert_close(x.grad.float(), x2.grad, atol=tol, rtol=tol)
     torch.testing.assert_close(w.grad, w2.grad, atol=2e-3, rtol=1e-3)
     torch.testing.assert_close(b.grad, b2.grad, atol=2e-3, rtol=1e-3)
+
+
+@pytest.mark.parametrize("N,Cin,H,W,Cout,relu", [(2, 64, 13, 18, 24, False), (1, 128, 9, 7, 8, True), (2, 256, 32, 32, 256, False),
+                                                 (1, 64, 1, 1, 64, False)])
+def test_conv3x3_implicit_gemm_vs_torch(N, Cin, H, W, Cout, relu):
+    """Implicit-GEMM 3x3 convolution (dgx_conv3x3_pad / _gemm / _wgrad: forward, input gradient through the tap-flipped
+    weights, weight gradient as nine shifted problems) against torch's fp32 conv2d on the same bf16-rounded operands."""
+    from divergen_amd.layers import conv_ops
+    assert conv_ops._IMPLICIT
+    g = torch.Generator().manual_seed(N * 100 + Cin + Cout)
+    x = bf(torch.randn(N, Cin, H, W, generator=g)).float()
+    w = bf(torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05).float()
+    b = bf(torch.randn(Cout, generator=g)).float()
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = torch.nn.functional.conv2d(xr, wr, br, padding=1)
+    if relu:
+        ref = torch.relu(ref)
+    go = bf(torch.randn(ref.shape, generator=g)).float()
+    ref.backward(go)
+    xd = x.to(DEV).to(torch.bfloat16).requires_grad_(True)
+    wd, bd = w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    got = conv_ops.conv3x3(xd, wd, bd, 1, relu=relu)
+    assert got.dtype == torch.bfloat16
+    got.backward(go.to(DEV).to(torch.bfloat16))
+    sc = float(ref.abs().max())
+    assert float((got.float().cpu() - ref.detach()).abs().max()) <= 2.0 ** -7 * sc + 1e-3
+    assert float((xd.grad.float().cpu() - xr.grad).abs().max()) <= 2.0 ** -6 * float(xr.grad.abs().max()) + 1e-3
+    assert float((wd.grad.cpu() - wr.grad).abs().max()) <= 1e-2 * float(wr.grad.abs().max()) + 1e-3     # dy and x are bf16, sums fp32
+    assert float((bd.grad.cpu() - br.grad).abs().max()) <= 1e-2 * float(br.grad.abs().max()) + 1e-3
+
+
+def test_conv3x3_implicit_arena_twin_and_accumulation():
+    """A stride-1 Conv2d(64 -> 64) in a FlatArena: the input gradient reads the arena's tap-flipped bf16 twin (rebuilt by
+    refresh_transposes), the weight gradient accumulates in place in the (Cout, kh, kw, Cin) storage."""
+    from divergen_amd.layers.conv_ops import Conv2d
+    from divergen_amd.solver import FlatArena
+    torch.manual_seed(4)
+    conv = Conv2d(64, 64, 3, 1, 1).to(DEV)
+    w0, b0 = conv.weight.detach().clone(), conv.bias.detach().clone()
+    arena = FlatArena(conv)
+    assert getattr(conv.weight, "_dgx16t_flipped", False)
+    twin = conv.weight._dgx16t.view(64, 3, 3, 64).float()
+    want = bf(w0).float().flip(2, 3).permute(1, 2, 3, 0)
+    assert torch.equal(twin, want)
+    x = torch.randn(2, 64, 12, 10, device=DEV).to(memory_format=torch.channels_last).requires_grad_(True)
+    go = torch.randn(2, 64, 12, 10, device=DEV)
+    for rep in range(2):
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = conv(x)
+        y.backward(go.to(y.dtype))
+    xr = bf(x.detach()).float().requires_grad_(True)
+    wr, br = bf(w0).float().requires_grad_(True), bf(b0).float().requires_grad_(True)
+    ref = torch.nn.functional.conv2d(xr, wr, br, padding=1)
+    ref.backward(bf(go).float())
+    torch.testing.assert_close(y.float(), ref.detach(), atol=3e-2, rtol=2e-2)
+    torch.testing.assert_close(x.grad, 2 * xr.grad, atol=6e-2, rtol=3e-2)
+    torch.testing.assert_close(conv.weight.grad, 2 * wr.grad, atol=2e-1, rtol=3e-2)
+    torch.testing.assert_close(conv.bias.grad, 2 * br.grad, atol=2e-1, rtol=3e-2)

@@ -24,7 +24,7 @@ class GemmEpilogue(ctypes.Structure):
     """struct dgx_gemm_epilogue (include/divergen_hip.h)."""
     _fields_ = [("mode", c_i), ("c", c_p), ("ldc", c_i64), ("bias", c_p), ("c2", c_p), ("aux", c_p), ("ldaux", c_i64),
                 ("residual", c_p), ("out", c_p), ("scale", c_p), ("residual_dtype", c_i),
-                ("B", c_i), ("H", c_i), ("W", c_i), ("ws", c_i), ("shift", c_i), ("workspace", c_p), ("workspace_bytes", c_i64)]
+                ("B", c_i), ("H", c_i), ("W", c_i), ("ws", c_i), ("shift", c_i), ("workspace", c_p), ("workspace_bytes", c_i64), ("relu", c_i)]
 
 
 class ColsumProblem(ctypes.Structure):

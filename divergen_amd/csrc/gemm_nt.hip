@@ -56,6 +56,7 @@ struct GemmP {
     int conv_kc, conv_wp;
     int cmap_n, cmap_h, cmap_w;
     int relu;
+    int krot;
 };
 
 __device__ __forceinline__ void g_load_lds16(uint32_t voff, u32x4 rsrc, uint32_t lds_addr, uint32_t soff) {
@@ -255,15 +256,20 @@ __global__ __launch_bounds__(512, MINW) void gemm_nt_kernel(GemmP P) {
     const uint32_t lds0 = (uint32_t)(uintptr_t)(DGX_LDS unsigned char*)lds_raw;
     const uint32_t ldsw = __builtin_amdgcn_readfirstlane(lds0 + 1024u * w);
     // one of the NL loads of a tile: k < NA -> A rows, else B rows
+    // K rotation (DGX_GEMM_KROT=1, off by default): workgroups that share an operand panel walk K from different starting
+    // tiles, so a line fetched from HBM for one is in L2 when the others ask.  Measured (tools/gemm_cold_probe2.py): -7..10 %
+    // when every operand is cold in HBM, +5..12 % when they sit in L2 / the memory-side cache, nothing on the training step.
+    const int rot = (P.krot && NT >= 4) ? ((tm + tn) & 3) * (NT >> 2) : 0;
     auto issue_one = [&](int k, int t, int stage) {
-        const uint32_t soff = (uint32_t)(kt0 + t) * (GBK * 2);
+        const int kta = kt0 + (t + rot >= NT ? t + rot - NT : t + rot);
+        const uint32_t soff = (uint32_t)kta * (GBK * 2);
         uint32_t soffA = soff;
         if (P.conv_kc) {                           // implicit convolution: tap shift (rows) + channel block of the tap
-            const int tap = (kt0 + t) / P.conv_kc, kc = (kt0 + t) - tap * P.conv_kc;
+            const int tap = kta / P.conv_kc, kc = kta - tap * P.conv_kc;
             soffA = (uint32_t)((tap / 3) * P.conv_wp + tap % 3) * (uint32_t)(P.lda * 2) + (uint32_t)kc * (GBK * 2);
         }
         const uint32_t dst = ldsw + (uint32_t)stage * SB;
-        const bool tail = (kt0 + t == NTK - 1) && (ktail != GBK) && !kt_ok;
+        const bool tail = (kta == NTK - 1) && (ktail != GBK) && !kt_ok;
         if (k < NA) g_load_lds16(tail ? G_OOB : voffA[k], rA, dst + 8192u * k, soffA);
         else g_load_lds16(tail ? G_OOB : voffB[k - NA], rB, dst + BM * 128 + 8192u * (k - NA), soff);
     };
@@ -629,6 +635,8 @@ extern "C" int dgx_gemm_bf16_nt(const void* A, const void* B, int M, int N, int 
     P.res = ep->residual; P.out = ep->out; P.scale = ep->scale; P.res_dtype = ep->residual_dtype;
     P.ws = (float*)ep->workspace;
     g_ws_bytes_cur = ep->workspace ? ep->workspace_bytes : 0;
+    P.relu = (ep->mode <= DGX_EPI_BIAS) ? ep->relu : 0;
+    if (const char* kr = getenv("DGX_GEMM_KROT")) P.krot = atoi(kr);
     switch (ep->mode) {
         case DGX_EPI_NONE: case DGX_EPI_BIAS:
             if (!ep->c || ep->ldc < N || (ep->ldc & 7)) return DGX_ERR_BAD_ARG;

@@ -248,9 +248,60 @@ def patch_embed4x4(x, weight, bias, patch=4):
     return F.linear(u, weight.reshape(weight.shape[0], -1), bias), Hp, Wp
 
 
-def deconv2x2(x, weight, bias):
+class _Deconv2x2(torch.autograd.Function):
+    """ConvTranspose2d(k 2, s 2) as ONE MFMA GEMM per direction over the weight as stored, (Cin, Cout*2*2):
+    y[pix][(co,dy,dx)] = x[pix] . W[:, (co,dy,dx)] + b[co]  (+ ReLU, which commutes with the pixel shuffle that follows);
+    forward reads the arena's transposed twin (4 Cout, Cin), the input gradient the stored matrix itself, the weight gradient
+    is x^T dy in the stored layout (accumulated in place in the arena)."""
+
+    @staticmethod
+    def forward(ctx, x2, weight, bias, relu):
+        w16 = shadow(weight)
+        Cin = w16.shape[0]
+        wt = getattr(weight, "_dgx16t", None)
+        if wt is None or getattr(weight, "_dgx16t_flipped", False):
+            wt = w16.reshape(Cin, -1).t().contiguous()
+        b4 = shadow(bias).repeat_interleave(4) if bias is not None else None
+        from .gemm_ops import gemm_nt_act
+        y = gemm_nt_act(x2, wt, b4, relu)
+        ctx.save_for_backward(x2, y if relu else None)
+        ctx.weight, ctx.bias, ctx.w16, ctx.relu = weight, bias, w16, relu
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, yact = ctx.saved_tensors
+        weight, bias, w16 = ctx.weight, ctx.bias, ctx.w16
+        g2 = gy.to(torch.bfloat16).contiguous()
+        if ctx.relu:
+            g2 = g2 * (yact > 0)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = gemm_nt(g2, w16.reshape(w16.shape[0], -1))           # (M, 4 Cout) x (Cin, 4 Cout)^T
+        if ctx.needs_input_grad[1]:
+            def into(g):
+                wgrad_into(g.view(g.shape[0], -1), x2, g2)             # (Cin, 4 Cout) = x^T dy
+            gw = accumulate_grad(weight, lambda: torch.mm(x2.t(), g2, out_dtype=torch.float32).view(weight.shape), gemm_into=into)
+        if bias is not None and ctx.needs_input_grad[2]:
+            gb = accumulate_grad(bias, lambda: torch.sum(g2.view(g2.shape[0], -1, 4), (0, 2), dtype=torch.float32))
+        return gx, gw, gb, None
+
+
+def deconv2x2(x, weight, bias, relu=False):
     """ConvTranspose2d(kernel 2, stride 2): weight (Cin,Cout,2,2)."""
     xh = _nhwc(x)
+    N, H, W, Cin = xh.shape
+    Cout = weight.shape[1]
+    if xh.is_cuda and torch.is_autocast_enabled() and Cin % 8 == 0 and Cout % 2 == 0:
+        with torch.autocast("cuda", enabled=False):
+            y = _Deconv2x2.apply(xh.reshape(-1, Cin).to(torch.bfloat16), weight, bias, relu)
+        y = y.view(N, H, W, Cout, 2, 2).permute(0, 1, 4, 2, 5, 3).reshape(N, 2 * H, 2 * W, Cout)
+        return y.permute(0, 3, 1, 2)
+    y = _deconv2x2_ref(xh, weight, bias)
+    return torch.relu(y) if relu else y
+
+
+def _deconv2x2_ref(xh, weight, bias):
     N, H, W, Cin = xh.shape
     Cout = weight.shape[1]
     wm = weight.permute(2, 3, 1, 0).reshape(4 * Cout, Cin)                   # (dy,dx,co) x ci
@@ -268,17 +319,19 @@ class Conv2d(torch.nn.Conv2d):
             self.weight._dgx_ohwi = True       # FlatArena stores it (Cout, kh, kw, Cin): see solver.FlatArena.view
             self.weight._dgx_flip = self.stride == (1, 1)      # its bf16 twin: tap-flipped (Cin, kh, kw, Cout), the input-gradient operand
 
-    def forward(self, x):
+    def forward(self, x, relu=False):
+        """relu=True: the activation that follows the layer, fused into the GEMM epilogue where the path has one."""
         k, s, p = self.kernel_size, self.stride, self.padding
         if k == (1, 1) and s == (1, 1) and p == (0, 0):
-            return conv1x1(x, self.weight, self.bias)
+            y = conv1x1(x, self.weight, self.bias)
+            return torch.relu(y) if relu else y
         if k == (3, 3) and p == (1, 1) and s[0] == s[1] and s[0] in (1, 2) and self.groups == 1:
-            return conv3x3(x, self.weight, self.bias, s[0])
+            return conv3x3(x, self.weight, self.bias, s[0], relu=relu)
         raise L.DgxError("Conv2d %s/%s/%s is not on the hot path and has no HIP implementation" % (k, s, p))
 
 
 class ConvTranspose2d(torch.nn.ConvTranspose2d):
-    def forward(self, x):
+    def forward(self, x, relu=False):
         if self.kernel_size == (2, 2) and self.stride == (2, 2) and self.padding == (0, 0):
-            return deconv2x2(x, self.weight, self.bias)
+            return deconv2x2(x, self.weight, self.bias, relu=relu)
         raise L.DgxError("only ConvTranspose2d(k=2, s=2) is built")

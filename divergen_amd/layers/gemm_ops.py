@@ -68,6 +68,18 @@ def gemm_nt(a, b, bias=None, out=None):
     return c
 
 
+def gemm_nt_act(a, b, bias=None, relu=False):
+    """bf16 (M, N) = relu?(a b^T + bias)."""
+    _check2(a, b)
+    M, N = a.shape[0], b.shape[0]
+    c = torch.empty(M, N, dtype=BF16, device=a.device)
+    ep = L.GemmEpilogue()
+    ep.mode = EPI_BIAS if bias is not None else EPI_NONE
+    ep.c, ep.ldc, ep.bias, ep.relu = c.data_ptr(), N, _dev_ptr(bias), int(bool(relu))
+    _launch(a, b, ep)
+    return c
+
+
 def gemm_bias_gelu(a, b, bias):
     """(f1, act) = (a b^T + bias, GELU_erf(f1)), both bf16 (M, N): Mlp.fc1 + act (swintransformer.py:41-42)."""
     _check2(a, b)

@@ -82,8 +82,17 @@ class MaskRCNNConvUpsampleHead(nn.Sequential):
                     num_classes=1 if m.CLS_AGNOSTIC_MASK else cfg.MODEL.ROI_HEADS.NUM_CLASSES, vis_period=cfg.VIS_PERIOD)
 
     def layers(self, x):
-        for layer in self:
-            x = layer(x)
+        """conv / deconv layers take the ReLU that follows them into their GEMM epilogue."""
+        mods = list(self)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, (Conv2d, ConvTranspose2d)) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU):
+                x = m(x, relu=True)
+                i += 2
+            else:
+                x = m(x)
+                i += 1
         return x
 
     def forward(self, x, instances):

@@ -435,6 +435,7 @@ typedef struct dgx_gemm_epilogue {
     int B, H, W, ws, shift;
     void* workspace;      /* optional fp32 scratch for split-K (few output tiles, long K): S slabs of M*N floats are used when */
     int64_t workspace_bytes; /* they fit, folded by a second launch with the same epilogue; NULL / 0 = never split */
+    int relu;             /* DGX_EPI_NONE / DGX_EPI_BIAS: c = max(y, 0) (Conv2d / ConvTranspose2d followed by ReLU, mask_head.py:209-284) */
 } dgx_gemm_epilogue;
 int dgx_gemm_bf16_nt(const void* A, const void* B, int M, int N, int K, int64_t lda, int64_t ldb,
                      const dgx_gemm_epilogue* epilogue, void* stream);

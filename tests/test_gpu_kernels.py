@@ -696,3 +696,28 @@ def test_conv3x3_implicit_arena_twin_and_accumulation():
     torch.testing.assert_close(x.grad, 2 * xr.grad, atol=6e-2, rtol=3e-2)
     torch.testing.assert_close(conv.weight.grad, 2 * wr.grad, atol=2e-1, rtol=3e-2)
     torch.testing.assert_close(conv.bias.grad, 2 * br.grad, atol=2e-1, rtol=3e-2)
+
+
+@pytest.mark.parametrize("relu", [False, True])
+def test_deconv2x2_mfma_gemm_vs_torch(relu):
+    """ConvTranspose2d(k 2, s 2) of the mask head under autocast: one MFMA GEMM each way over the stored (Cin, Cout*4) weight."""
+    from divergen_amd.layers.conv_ops import deconv2x2
+    g = torch.Generator().manual_seed(8)
+    x = bf(torch.randn(3, 64, 7, 9, generator=g)).float()
+    w = bf(torch.randn(64, 32, 2, 2, generator=g) * 0.1).float()
+    b = bf(torch.randn(32, generator=g)).float()
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = torch.nn.functional.conv_transpose2d(xr, wr, br, stride=2)
+    if relu:
+        ref = torch.relu(ref)
+    go = bf(torch.randn(ref.shape, generator=g)).float()
+    ref.backward(go)
+    xd, wd, bd = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        got = deconv2x2(xd, wd, bd, relu=relu)
+    got.backward(go.to(DEV).to(got.dtype))
+    assert got.dtype == torch.bfloat16 and got.shape == ref.shape
+    torch.testing.assert_close(got.float().cpu(), ref.detach(), atol=3e-2, rtol=2e-2)
+    torch.testing.assert_close(xd.grad.cpu(), xr.grad, atol=3e-2, rtol=2e-2)
+    torch.testing.assert_close(wd.grad.cpu(), wr.grad, atol=1e-1, rtol=3e-2)
+    torch.testing.assert_close(bd.grad.cpu(), br.grad, atol=1e-1, rtol=3e-2)

@@ -31,6 +31,8 @@ struct Prob256 {
 struct Params256 {
     Prob256 p[MAXP256];
     int n, total, per_xcd;
+    int interleave;     // identical problems that share one operand (the 9 taps of a convolution): consecutive workgroups take the
+                        // SAME (slab, tile) of consecutive problems, so the shared dY slab is read from HBM once per XCD, not 9 x
     float beta;
 };
 
@@ -73,11 +75,15 @@ __global__ __launch_bounds__(256) void wgrad256_partial_kernel(Params256 P) {
     const int L = (blockIdx.x & 7) * P.per_xcd + (blockIdx.x >> 3);
     if (L >= P.total) return;
     int pi = 0;
+    if (P.interleave) {
+        pi = L % P.n;
+    } else {
 #pragma unroll
-    for (int i = 1; i < MAXP256; ++i)
-        if (i < P.n && L >= P.p[i].wg0) pi = i;
+        for (int i = 1; i < MAXP256; ++i)
+            if (i < P.n && L >= P.p[i].wg0) pi = i;
+    }
     const Prob256 q = P.p[pi];
-    const int local = L - q.wg0;
+    const int local = P.interleave ? L / P.n : L - q.wg0;
     const int s = local / q.tiles, tile = local - s * q.tiles;
 #ifdef DIAG_SAMEPANEL   // every workgroup streams the same two panels: isolates the CU-side limit from L2 / fabric
     const int n0 = 0, k0 = 0;
@@ -368,6 +374,12 @@ static int wgrad_grouped_impl(const dgx_wgrad_problem* problems, const int* ldc,
         once = true;
     }
     P.total = wg;
+    P.interleave = 0;
+    if (ldc && n > 1) {                            // dgx_conv3x3_wgrad: same M / Nn / Kk for every tap
+        P.interleave = 1;
+        for (int i = 1; i < n; ++i)
+            if (P.p[i].tiles != P.p[0].tiles || P.p[i].S != P.p[0].S || P.p[i].M != P.p[0].M) P.interleave = 0;
+    }
     P.per_xcd = (wg + 7) / 8;
     hipLaunchKernelGGL(wgrad256_partial_kernel, dim3(8 * P.per_xcd), dim3(256), sm, st, P);
     if (red > 0) {

@@ -8,6 +8,7 @@ transposed weight image (`FlatArena.p16t`, refreshed with the bf16 shadow after 
 Reference call sites: swintransformer.py:133,155 (qkv / proj), :40-46 (Mlp), :296 (reduction), fpn.py:126-154, box_head.py:26-98.
 """
 import ctypes
+import os
 
 import torch
 
@@ -55,9 +56,14 @@ def _dev_ptr(t):
     return t.data_ptr()
 
 
+_LIB_AB = os.environ.get("DGX_GEMM_LIB", "")       # development A/B only: route plain GEMMs through the vendor library
+
+
 def gemm_nt(a, b, bias=None, out=None):
     """bf16 (M, N) = a b^T (+ bias)."""
     _check2(a, b)
+    if _LIB_AB and out is None and (_LIB_AB == "all" or (_LIB_AB == "nobias") == (bias is None)):
+        return torch.addmm(bias, a, b.t()) if bias is not None else torch.mm(a, b.t())
     _dev_ptr(a), _dev_ptr(b)
     M, N = a.shape[0], b.shape[0]
     c = out if out is not None else torch.empty(M, N, dtype=BF16, device=a.device)

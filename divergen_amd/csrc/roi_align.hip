@@ -269,6 +269,194 @@ __global__ __launch_bounds__(256) void roi_align_vec_kernel(PoolLevels L, const 
     }
 }
 
+// ---- backward as an output-stationary gather ------------------------------------------------------------------------
+// One workgroup owns a GT_TH x TW pixel tile of one (level, image) gradient map and every lane 8 channels of one tile
+// column: it walks the RoIs in index order, keeps those of its image and level whose sample grid reaches the tile, rebuilds
+// the two 1-D weight tables of each (the float sequence of build_axis_table, restricted to the tile) and accumulates
+//   d feat[y][x][c] = sum_r sum_i WY_r[i][y] * ( sum_j WX_r[j][x] / count_r * d out[r][i][j][c] )
+// in registers.  Every gradient pixel is written exactly once, in the output dtype: no atomics, no zero fill, no fp32
+// staging map, and the summation order is fixed by the RoI order (bit-reproducible from run to run).
+#define GT_TH 8
+#define GT_QB 8
+#define GT_PMAX 16
+#define GT_TWMAX 32
+struct GatherP {
+    void* out[MAX_LEVELS];
+    int H[MAX_LEVELS], W[MAX_LEVELS];
+    float scale[MAX_LEVELS];
+    int tile0[MAX_LEVELS + 1], tiles_x[MAX_LEVELS], tiles_y[MAX_LEVELS];
+    int num_levels, min_level, N, C, R, ph, pw, sampling_ratio, aligned, total;
+};
+struct GatherMeta { int r, i_lo, i_hi; float sw, bin_w; };
+
+__device__ __forceinline__ void gather_axis_rows(float* w, int nw, int i, float start, float bin, int g, int extent, int p0) {
+    for (int k = 0; k < nw; ++k) w[k] = 0.0f;
+    for (int s = 0; s < g; ++s) {
+        float y = start + i * bin + ((float)s + 0.5f) * bin / (float)g;
+        if (y < -1.0f || y > (float)extent) continue;
+        if (y <= 0) y = 0;
+        int lo = (int)y, up;
+        if (lo >= extent - 1) { up = lo = extent - 1; y = (float)lo; } else up = lo + 1;
+        const float l = y - lo, h = 1.0f - l;
+        if ((unsigned)(lo - p0) < (unsigned)nw) w[lo - p0] += h;
+        if ((unsigned)(up - p0) < (unsigned)nw) w[up - p0] += l;
+    }
+}
+
+__device__ __forceinline__ int clamp_bin(float v, int hi) { return (int)fminf(fmaxf(v, 0.0f), (float)hi); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void roi_pool_bwd_gather_kernel(GatherP P, const float* __restrict__ rois, const T* __restrict__ go) {
+    __shared__ __attribute__((aligned(16))) float WY[GT_QB][GT_PMAX][GT_TH];
+    __shared__ float WX[GT_QB][GT_PMAX][GT_TWMAX];
+    __shared__ int list[256];
+    __shared__ int wcount[4];
+    __shared__ GatherMeta meta[GT_QB];
+    const int tid = threadIdx.x;
+    // coarsest level first: its tiles see the most RoIs each
+    int t = P.total - 1 - (int)blockIdx.x, l = 0;
+    while (l + 1 < P.num_levels && t >= P.tile0[l + 1]) ++l;
+    int local = t - P.tile0[l];
+    const int H = P.H[l], W = P.W[l], txn = P.tiles_x[l], tyn = P.tiles_y[l];
+    const int C = P.C, CV = C >> 3, TW = 256 / CV, ph = P.ph, pw = P.pw, bins = ph * pw;
+    const int n = local / (txn * tyn);
+    local -= n * txn * tyn;
+    const int y0 = (local / txn) * GT_TH, x0 = (local % txn) * TW;
+    const int cv = tid % CV, tx = tid / CV;
+    const float scale = P.scale[l];
+    float acc[GT_TH][8];
+#pragma unroll
+    for (int a = 0; a < GT_TH; ++a)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[a][e] = 0.0f;
+
+    for (int base = 0; base < P.R; base += 256) {
+        const int r = base + tid;
+        bool hit = false;
+        if (r < P.R) {
+            const float* roi = rois + 5 * (int64_t)r;
+            const int lvl = P.num_levels > 1 ? assign_level(roi, P.min_level, P.num_levels) : 0;
+            if ((int)roi[0] == n && lvl == l) {
+                const RoiGeom G = roi_geom(roi, scale, ph, pw, P.sampling_ratio, P.aligned != 0);
+                // a sample at y weighs rows floor(y) and floor(y)+1 (after clamping into the map): rows within [y-1, y+1]
+                hit = G.gh > 0 && G.gw > 0 && G.sh - 1.0f <= (float)(y0 + GT_TH - 1) && G.sh + G.bin_h * ph + 1.0f >= (float)y0 &&
+                      G.sw - 1.0f <= (float)(x0 + TW - 1) && G.sw + G.bin_w * pw + 1.0f >= (float)x0;
+            }
+        }
+        const unsigned long long m = __ballot(hit);
+        const int wave = tid >> 6, lane = tid & 63;
+        if (lane == 0) wcount[wave] = __popcll(m);
+        __syncthreads();
+        int off = 0, hits = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { const int cnt = wcount[w]; if (w < wave) off += cnt; hits += cnt; }
+        if (hit) list[off + __popcll(m & ((1ull << lane) - 1ull))] = r;
+        __syncthreads();
+        for (int q0 = 0; q0 < hits; q0 += GT_QB) {
+            const int nq = min(GT_QB, hits - q0);
+            {
+                const int q = tid >> 5, t5 = tid & 31;
+                if (q < nq) {
+                    const int rr = list[q0 + q];
+                    const RoiGeom G = roi_geom(rois + 5 * (int64_t)rr, scale, ph, pw, P.sampling_ratio, P.aligned != 0);
+                    if (t5 < 16) {
+                        if (t5 < ph) gather_axis_rows(&WY[q][t5][0], GT_TH, t5, G.sh, G.bin_h, G.gh, H, y0);
+                    } else if (t5 - 16 < pw) {
+                        float* w = &WX[q][t5 - 16][0];
+                        gather_axis_rows(w, TW, t5 - 16, G.sw, G.bin_w, G.gw, W, x0);
+                        for (int k = 0; k < TW; ++k) w[k] = w[k] / G.count;
+                    }
+                    if (t5 == 0) {
+                        GatherMeta mt;
+                        mt.r = rr; mt.sw = G.sw; mt.bin_w = G.bin_w;
+                        mt.i_lo = 0; mt.i_hi = ph;
+                        if (G.bin_h > 0.0f) {   // bins whose interval meets [y0 - 1, y0 + TH], one bin of slack either side
+                            mt.i_lo = clamp_bin(floorf(((float)(y0 - 1) - G.sh) / G.bin_h) - 1.0f, ph);
+                            mt.i_hi = clamp_bin(floorf(((float)(y0 + GT_TH) - G.sh) / G.bin_h) + 2.0f, ph);
+                        }
+                        meta[q] = mt;
+                    }
+                }
+            }
+            __syncthreads();
+            for (int q = 0; q < nq; ++q) {
+                const GatherMeta mt = meta[q];
+                int j_lo = 0, j_hi = pw;
+                if (mt.bin_w > 0.0f) {
+                    const float xf = (float)(x0 + tx);
+                    j_lo = clamp_bin(floorf((xf - 1.0f - mt.sw) / mt.bin_w) - 1.0f, pw);
+                    j_hi = clamp_bin(floorf((xf + 1.0f - mt.sw) / mt.bin_w) + 2.0f, pw);
+                }
+                const T* gr = go + (int64_t)mt.r * bins * C + 8 * cv;
+                for (int i = mt.i_lo; i < mt.i_hi; ++i) {
+                    const f32x4 wa = *reinterpret_cast<const f32x4*>(&WY[q][i][0]), wb = *reinterpret_cast<const f32x4*>(&WY[q][i][4]);
+                    const float wy[8] = {wa[0], wa[1], wa[2], wa[3], wb[0], wb[1], wb[2], wb[3]};
+                    bool any = false;
+#pragma unroll
+                    for (int a = 0; a < 8; ++a) any = any || wy[a] != 0.0f;
+                    if (!any) continue;
+                    float gx[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    const T* gi = gr + (int64_t)i * pw * C;
+                    for (int j0 = j_lo; j0 < j_hi; j0 += 4) {
+                        float wx[4], v[4][8];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) wx[k] = (j0 + k < j_hi) ? WX[q][j0 + k][tx] : 0.0f;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (wx[k] != 0.0f) Vec8<T>::load(gi + (int64_t)(j0 + k) * C, v[k]);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (wx[k] != 0.0f) {
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) gx[e] += wx[k] * v[k][e];
+                            }
+                    }
+#pragma unroll
+                    for (int a = 0; a < 8; ++a)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) acc[a][e] += wy[a] * gx[e];
+                }
+            }
+            __syncthreads();
+        }
+    }
+    T* ob = (T*)P.out[l] + (int64_t)n * H * W * C + 8 * cv;
+    const int x = x0 + tx;
+    if (x < W) {
+#pragma unroll
+        for (int a = 0; a < GT_TH; ++a)
+            if (y0 + a < H) Vec8<T>::store(ob + ((int64_t)(y0 + a) * W + x) * C, acc[a]);
+    }
+}
+
+static int launch_gather(GatherP& P, const float* rois, const void* go, int dtype, void* stream) {
+    if (P.N <= 0) return DGX_OK;
+    if (!rois && P.R > 0) return DGX_ERR_BAD_ARG;
+    if (!go && P.R > 0) return DGX_ERR_BAD_ARG;
+    const int C = P.C;
+    if (C <= 0 || (C & 7) || 256 % (C >> 3) || 256 / (C >> 3) > GT_TWMAX || P.ph <= 0 || P.pw <= 0 || P.ph > GT_PMAX || P.pw > GT_PMAX)
+        return DGX_ERR_UNSUPPORTED;
+    if (((uintptr_t)go & 15) != 0) return DGX_ERR_UNSUPPORTED;
+    const int TW = 256 / (C >> 3);
+    int total = 0;
+    for (int l = 0; l < P.num_levels; ++l) {
+        if (!P.out[l] || ((uintptr_t)P.out[l] & 15)) return P.out[l] ? DGX_ERR_UNSUPPORTED : DGX_ERR_BAD_ARG;
+        P.tile0[l] = total;
+        P.tiles_x[l] = (P.W[l] + TW - 1) / TW;
+        P.tiles_y[l] = (P.H[l] + GT_TH - 1) / GT_TH;
+        total += P.N * P.tiles_x[l] * P.tiles_y[l];
+    }
+    P.tile0[P.num_levels] = total;
+    P.total = total;
+    if (total <= 0) return DGX_OK;
+    if (dtype == DGX_BF16)
+        hipLaunchKernelGGL((roi_pool_bwd_gather_kernel<uint16_t>), dim3(total), dim3(256), 0, (hipStream_t)stream, P, rois, (const uint16_t*)go);
+    else
+        hipLaunchKernelGGL((roi_pool_bwd_gather_kernel<float>), dim3(total), dim3(256), 0, (hipStream_t)stream, P, rois, (const float*)go);
+    DGX_LAUNCH_CHECK();
+    return DGX_OK;
+}
+
 static int launch_pool(bool fwd, const PoolLevels& L, const float* rois, const void* io, int32_t* levels_out, int C,
                        int R, int ph, int pw, int sampling_ratio, int aligned, int out_nhwc, int dtype, void* stream) {
     if (R <= 0) return DGX_OK;
@@ -380,6 +568,26 @@ extern "C" int dgx_roi_pooler_bwd(const void* grad_out, float* const* grad_feats
     int e = fill_levels(L, nullptr, grad_feats, Hs, Ws, num_levels, min_level);
     if (e) return e;
     return launch_pool(false, L, rois, grad_out, nullptr, C, R, ph, pw, sampling_ratio, 1, out_nhwc, dtype, stream);
+}
+
+// Backward of dgx_roi_pooler_fwd / dgx_roi_align_fwd (channels-last pooled gradient) as a gather: grad_feats[l] is an
+// (N,H_l,W_l,C) map in the dtype of grad_out and is OVERWRITTEN (no zero fill needed, no atomics; deterministic).
+// num_levels == 1: plain ROIAlign with `spatial_scale` / `aligned`; otherwise the ROIPooler level rule with scales
+// 2^-(min_level + l).  DGX_ERR_UNSUPPORTED when C % 8 != 0, 256 % (C/8) != 0, C < 64, the output side exceeds 16 or a
+// pointer is not 16-byte aligned: the caller then uses the scatter forms above.
+extern "C" int dgx_roi_pooler_bwd_gather(const void* grad_out, void* const* grad_feats, const int* Hs, const int* Ws, int num_levels,
+                                         int min_level, float spatial_scale, int aligned, const float* rois, int N, int C, int R,
+                                         int ph, int pw, int sampling_ratio, int dtype, void* stream) {
+    if (!grad_feats || !Hs || !Ws || num_levels < 1 || num_levels > MAX_LEVELS) return DGX_ERR_BAD_ARG;
+    if (dtype != DGX_BF16 && dtype != DGX_F32) return DGX_ERR_BAD_ARG;
+    GatherP P = {};
+    P.num_levels = num_levels; P.min_level = min_level; P.N = N; P.C = C; P.R = R < 0 ? 0 : R; P.ph = ph; P.pw = pw;
+    P.sampling_ratio = sampling_ratio; P.aligned = num_levels > 1 ? 1 : aligned;
+    for (int l = 0; l < num_levels; ++l) {
+        P.out[l] = grad_feats[l]; P.H[l] = Hs[l]; P.W[l] = Ws[l];
+        P.scale[l] = num_levels > 1 ? 1.0f / (float)(1 << (min_level + l)) : spatial_scale;
+    }
+    return launch_gather(P, rois, grad_out, dtype, stream);
 }
 
 // ---- GT mask crop: one workgroup per box, one lane per output pixel, byte taps --------------

@@ -2,10 +2,15 @@
 Reference: D2/layers/roi_align.py:7-65, D2/modeling/poolers.py:22-245, D2/structures/masks.py:189-220."""
 import ctypes
 import math
+import os
 
 import torch
 
 from .. import _lib as L
+
+
+# dev switch: DGX_ROI_GATHER=0 keeps the atomic-scatter backward (A/B runs and the parity test of the two forms)
+_GATHER = os.environ.get("DGX_ROI_GATHER", "1") != "0"
 
 
 def _nhwc(feat):
@@ -58,9 +63,17 @@ class _ROIPooler(torch.autograd.Function):
         nl = len(shapes)
         R = rois.shape[0]
         g_phys = gout.permute(0, 2, 3, 1).contiguous() if out_nhwc else gout.contiguous()
-        grads = [torch.zeros(s[0], s[2], s[3], s[1], dtype=torch.float32, device=gout.device) for s in shapes]
         Hs = (ctypes.c_int * nl)(*[s[2] for s in shapes])
         Ws = (ctypes.c_int * nl)(*[s[3] for s in shapes])
+        if out_nhwc and _GATHER and C % 8 == 0 and C >= 64 and 256 % (C // 8) == 0 and out_size <= 16:
+            # output-stationary gather: every gradient pixel written once, in the feature dtype (no fp32 staging maps)
+            grads = [torch.empty(s[0], s[2], s[3], s[1], dtype=g_phys.dtype, device=gout.device) for s in shapes]
+            ptrs = (ctypes.c_void_p * nl)(*[L.ptr(g) for g in grads])
+            L.check(L.lib().dgx_roi_pooler_bwd_gather(L.ptr(g_phys), ptrs, Hs, Ws, nl, min_level, scale0, int(aligned),
+                                                      L.ptr(rois), N, C, R, out_size, out_size, sampling_ratio,
+                                                      L.dtype_code(g_phys), L.stream()), "dgx_roi_pooler_bwd_gather")
+            return (None,) * 7 + tuple(g.permute(0, 3, 1, 2).to(dt) for g in grads)
+        grads = [torch.zeros(s[0], s[2], s[3], s[1], dtype=torch.float32, device=gout.device) for s in shapes]
         if nl == 1:
             L.check(L.lib().dgx_roi_align_bwd(L.ptr(g_phys), L.ptr(rois), L.ptr(grads[0]), N, Hs[0], Ws[0], C, R,
                                               scale0, out_size, out_size, sampling_ratio, int(aligned), int(out_nhwc),

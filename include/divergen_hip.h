@@ -101,6 +101,18 @@ int dgx_roi_pooler_bwd(const void* grad_out, float* const* grad_feats, const int
                        int num_levels, int min_level, const float* rois, int N, int C, int R, int ph,
                        int pw, int sampling_ratio, int out_nhwc, int dtype, void* stream);
 
+/* Backward of the two pooling entry points above as an output-stationary GATHER (the autograd backward of
+ * torchvision.ops.roi_align reached from D2/modeling/poolers.py:240-245): every pixel of every level's gradient map is
+ * produced by one workgroup that walks the RoIs in index order -- no atomics, no zero fill, deterministic.
+ *   grad_out   (R, ph, pw, C) channels-last, dtype f32 or bf16
+ *   grad_feats (host) array of num_levels device pointers to (N, H_l, W_l, C) maps of the SAME dtype, overwritten
+ *   num_levels == 1: plain ROIAlign with spatial_scale / aligned; > 1: ROIPooler level rule, scales 2^-(min_level + l)
+ * Returns DGX_ERR_UNSUPPORTED for C % 8 != 0, C < 64, 256 % (C/8) != 0, ph or pw > 16 or pointers not 16-byte aligned
+ * (callers then use the scatter forms). */
+int dgx_roi_pooler_bwd_gather(const void* grad_out, void* const* grad_feats, const int* Hs, const int* Ws,
+                              int num_levels, int min_level, float spatial_scale, int aligned, const float* rois,
+                              int N, int C, int R, int ph, int pw, int sampling_ratio, int dtype, void* stream);
+
 /* GT-mask crop for the mask loss: ROIAlign(S x S, scale 1, ratio 0, aligned) on uint8/bool masks
  * and `>= 0.5`, without materialising the fp32 mask.  Replaces BitMasks.crop_and_resize,
  * D2/structures/masks.py:189-220.

@@ -163,6 +163,61 @@ def test_roi_pooler_levels_bf16_and_mask_pool():
     torch.testing.assert_close(got16.float().cpu(), ref16, atol=2e-2, rtol=1e-2)  # bf16 output rounding
 
 
+@pytest.mark.parametrize("C,S,dt", [(256, 7, torch.float32), (256, 14, torch.bfloat16), (64, 7, torch.float32), (512, 3, torch.float32)])
+def test_roi_pooler_backward_gather_vs_oracle_and_scatter(monkeypatch, C, S, dt):
+    """The output-stationary gather backward (one writer per gradient pixel) against the oracle's scatter per level
+    (poolers.py:240-245 -> roi_align backward) on maps whose sides are not tile multiples, with boxes that stick out of the
+    image, empty boxes, boxes smaller than one bin and one box covering the whole image; against the atomic-scatter form of
+    the same library; and twice in a row for bit-reproducibility."""
+    from divergen_amd.layers import roi_ops
+    g = torch.Generator().manual_seed(C + S)
+    sizes = [(37, 50), (19, 25), (10, 13)]
+    feats = [torch.randn(2, C, h, w, generator=g) for h, w in sizes]
+    rois = _rand_rois(g, 300, 2, 37 * 8, 50 * 8)
+    rois[0, 1:] = torch.tensor([-40.0, -30.0, 60.0, 50.0])             # sticks out top-left (samples below -1 are dropped)
+    rois[1, 1:] = torch.tensor([350.0, 250.0, 460.0, 330.0])           # sticks out bottom-right
+    rois[2, 1:] = torch.tensor([100.0, 100.0, 100.0, 100.0])           # empty
+    rois[3, 1:] = torch.tensor([120.0, 80.0, 123.0, 82.5])             # far smaller than one bin per pixel
+    rois[4, 1:] = torch.tensor([0.0, 0.0, 400.0, 296.0])               # whole image -> coarsest level
+    rois[5, 1:] = torch.tensor([200.0, 100.0, 190.0, 90.0])            # inverted
+    order = torch.argsort(rois[:, 0], stable=True)
+    rois = rois[order]
+    scales = (1 / 8, 1 / 16, 1 / 32)
+    boxes = [rois[rois[:, 0] == b][:, 1:] for b in range(2)]
+    go = torch.randn(rois.shape[0], C, S, S, generator=g)
+    if dt == torch.bfloat16:
+        go = bf(go).float()
+    # oracle: scatter per level over the boxes assigned to it
+    lv = OR.assign_boxes_to_levels(boxes, 3, 5)
+    ref = []
+    for l, f in enumerate(feats):
+        sel = lv == l
+        ref.append(OR.roi_align_backward(go[sel], rois[sel], scales[l], tuple(f.shape), 0, True) if bool(sel.any())
+                   else torch.zeros_like(f))
+
+    def run(gather):
+        monkeypatch.setattr(roi_ops, "_GATHER", gather)
+        fd = [f.to(DEV).to(dt).requires_grad_(True) for f in feats]
+        out = la.roi_pooler(fd, rois.to(DEV), S, scales, out_nhwc=True)
+        out.backward(go.to(DEV).to(dt))
+        return [f.grad.float().cpu() for f in fd]
+
+    got, again, scat = run(True), run(True), run(False)
+    for l in range(3):
+        assert torch.equal(got[l], again[l])
+        if dt == torch.float32:
+            torch.testing.assert_close(got[l], ref[l], atol=1e-4, rtol=1e-4)
+            torch.testing.assert_close(got[l], scat[l], atol=1e-4, rtol=1e-4)
+        else:   # one bf16 rounding of the sum
+            tol = 2.0 ** -8 * ref[l].abs() + 1e-4
+            assert not bool(((got[l] - ref[l]).abs() > tol).any())
+    # single level, not aligned (ROIAlign v1 geometry), fixed sampling ratio
+    f1 = feats[0].to(DEV).requires_grad_(True)
+    la.roi_align(f1, rois.to(DEV), 0.125, S, 2, False, True).backward(go.to(DEV))
+    ref1 = OR.roi_align_backward(go, rois, 0.125, tuple(feats[0].shape), 2, False)
+    torch.testing.assert_close(f1.grad.cpu(), ref1, atol=1e-4, rtol=1e-4)
+
+
 def test_mask_crop_bit_exact():
     g = torch.Generator().manual_seed(23)
     H, W, M = 200, 260, 6

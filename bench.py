@@ -27,12 +27,14 @@ import torch.distributed as dist  # noqa: E402
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=12)
-    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--steps", type=int, default=100)
+    p.add_argument("--warmup", type=int, default=5)
     p.add_argument("--size", type=int, default=1024)
     p.add_argument("--swin", default="L-22k-384")
     p.add_argument("--batch", type=int, default=2, help="images per GPU (IMS_PER_BATCH 16 / 8 GPUs)")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-roofline", action="store_true", help="leave the per-launch HIP events off (A/B of their cost)")
+    p.add_argument("--roofline-every", type=int, default=10, help="instrument every n-th timed step with per-launch HIP events")
     p.add_argument("--no-copy-paste", action="store_true")
     return p.parse_args()
 
@@ -49,64 +51,112 @@ def make_pastes(rng, size, k=19):
     return out
 
 
-# HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc, corrected as the
-# MI355X guide prescribes); None where no pass was taken.  Filled from profiles/r01_pmc.json when present.
-PMC_TRAFFIC = {}
-try:
-    with open(os.path.join(ROOT, "profiles", "r01_pmc.json")) as _f:
-        PMC_TRAFFIC = {k: v.get("hbm_bytes_per_launch") for k, v in json.load(_f).items() if isinstance(v, dict)}
-except (OSError, ValueError):
-    pass
+# Evidence committed under profiles/ that the `roofline` object refers to (all optional at run time):
+#   r02_pmc.json                              HBM bytes per launch of each kernel family from rocprofv3 --pmc passes over THIS script
+#   r02_bench_swinL_1024_kernel_stats.csv     rocprofv3 --kernel-trace --stats of THIS script (+ r02_profile_meta.json: steps)
+PROFILE_TAG = "r02"
+FAMILY_KERNELS = {   # family -> substrings of the kernel names rocprof reports for it
+    "gemm_nt": ("gemm_nt_kernel", "gemm_splitk_fold_kernel"),
+    "wgrad": ("wgrad256_partial_kernel", "wgrad256_reduce_kernel", "wgrad_partial_kernel", "wgrad_reduce_kernel"),
+    "attn_fwd": ("win_attn_fwd_kernel",),
+    "attn_bwd": ("win_attn_bwd_kernel",),
+}
+FAMILY_LABEL = {
+    "gemm_nt": "gemm_nt_kernel<BM,BN> (dgx_gemm_bf16_nt + dgx_conv3x3_gemm: every Linear / 3x3-conv forward and input gradient)",
+    "wgrad": "wgrad256_partial/reduce (dgx_linear_wgrad_grouped + dgx_conv3x3_wgrad: every weight gradient)",
+    "attn_fwd": "win_attn_fwd_kernel (dgx_window_attention_fwd)",
+    "attn_bwd": "win_attn_bwd_kernel (dgx_window_attention_bwd)",
+}
 
 
-class KernelTimer:
-    """HIP events around one libdgx entry point, recorded on the stream the kernel is launched on."""
-
-    def __init__(self, lib, name):
-        self.lib, self.name, self.events, self.enabled = lib, name, [], False
-        self.orig = getattr(lib, name)
-
-        def wrapped(*a):
-            if not self.enabled:
-                return self.orig(*a)
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            r = self.orig(*a)
-            e.record()
-            self.events.append((s, e, a))
-            return r
-        wrapped.argtypes, wrapped.restype = self.orig.argtypes, self.orig.restype
-        setattr(lib, name, wrapped)
+def _load_json(name):
+    try:
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return {}
 
 
-def cpu_baseline(swin, budget_s=25.0):
-    """Oracle (CPU restatement of the reference backbone, pinned on the reference's goldens) timed on
-    this box's host cores: Swin fwd+bwd on ONE image, at the largest power-of-two size that fits the
-    time budget; reported as 1024^2-equivalent images/s by token count."""
-    from oracle import swin as OSW
-    from tests._recipes import fill_state, swin_param_shapes
-    c = OSW.SIZE2CONFIG[swin]
+def profile_crosscheck():
+    """Per family: device time and launches per step in the committed rocprofv3 kernel-stats CSV (graph-replayed launches
+    included -- rocprof sees every dispatch)."""
+    import csv
+    meta = _load_json(PROFILE_TAG + "_profile_meta.json")
+    path = os.path.join(ROOT, "profiles", meta.get("kernel_stats_csv", PROFILE_TAG + "_bench_swinL_1024_kernel_stats.csv"))
+    steps = float(meta.get("steps_in_profile", 0) or 0)
+    if not os.path.isfile(path) or steps <= 0:
+        return {}
+    out = {k: {"ns": 0.0, "calls": 0.0} for k in FAMILY_KERNELS}
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            for fam, pats in FAMILY_KERNELS.items():
+                if any(p_ in r["Name"] for p_ in pats):
+                    out[fam]["ns"] += float(r["TotalDurationNs"])
+                    out[fam]["calls"] += float(r["Calls"])
+    return {k: {"csv": os.path.relpath(path, ROOT), "steps_in_profile": steps, "family_ms_per_step": v["ns"] / 1e6 / steps,
+                "launches_per_step": v["calls"] / steps} for k, v in out.items()}
+
+
+def cpu_baseline(swin, model, cfg, budget_s=30.0):
+    """The CPU oracle (restatement of the reference modules, pinned on the reference's goldens) timed on this box's host
+    cores on a BOUNDED sample: one training forward + backward of the ASSEMBLED model (oracle/model.py: Swin + FPN + CenterNet
+    head and losses + proposal decode/NMS + 3-stage cascade + mask head; no optimizer, no copy-paste) on ONE image at the
+    largest power-of-two size that fits the budget, scaled to 1024^2 by pixel count.  `backbone_only` repeats round 1's
+    sample (Swin fwd+bwd alone) for continuity."""
+    from tests._recipes import assembled_oracle_losses
     cores = min(os.cpu_count() or 1, 32)   # more threads than this only adds contention on these GEMM sizes
     torch.set_num_threads(cores)
-    p = fill_state(swin_param_shapes(c["embed_dim"], c["depths"], c["num_heads"], c["ws"]), 7, 0.02)
+    p = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
     for v in p.values():
-        v.requires_grad_(True)
-    size, t = 256, None
-    t_start = time.time()
-    while True:
-        img = torch.randn(1, 3, size, size)
+        if v.is_floating_point():
+            v.requires_grad_(True)
+    fw = model.roi_heads.box_predictor[0].freq_weight.detach().float().cpu()
+    mean = torch.tensor(cfg.MODEL.PIXEL_MEAN).view(1, 3, 1, 1)
+    std = torch.tensor(cfg.MODEL.PIXEL_STD).view(1, 3, 1, 1)
+    from divergen_amd.data import synthetic_batch
+    C = cfg.MODEL.ROI_HEADS.NUM_CLASSES
+    cn = cfg.MODEL.CENTERNET
+
+    def one(size):
+        batch = synthetic_batch(1, size, C, seed=99)
+        images = (torch.stack([b["image"].float() for b in batch]) - mean) / std
+        gts = [dict(boxes=b["instances"].gt_boxes.tensor, classes=b["instances"].gt_classes, masks=b["instances"].gt_masks.tensor)
+               for b in batch]
+        for v in p.values():
+            v.grad = None
         t0 = time.time()
-        outs = OSW.swin_forward(img, p, c["embed_dim"], c["depths"], c["num_heads"], c["ws"])
-        sum(o.square().mean() for o in outs.values()).backward()
-        t = time.time() - t0
-        # next size costs ~4x (token count); stop when it would not fit the budget
-        if t * 4 + (time.time() - t_start) > budget_s or size >= 1024:
+        losses = assembled_oracle_losses(p, images, gts, [(size, size)], swin, C, fw, cfg.MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE,
+                                         cfg.MODEL.ROI_HEADS.POSITIVE_FRACTION, cfg.MODEL.ROI_BOX_HEAD.FED_LOSS_NUM_CAT,
+                                         model.roi_heads.mask_weight, None, cn.INFERENCE_TH, cn.PRE_NMS_TOPK_TRAIN, cn.NMS_TH_TRAIN,
+                                         cn.POST_NMS_TOPK_TRAIN)
+        tf = time.time() - t0
+        sum(losses.values()).backward()
+        return tf, time.time() - t0
+
+    size, t_start = 256, time.time()
+    while True:
+        tf, t = one(size)
+        if t * 4 + (time.time() - t_start) > budget_s or size >= 1024:      # the next size costs ~4x
             break
         size *= 2
     scale = (1024.0 / size) ** 2
-    return {"value": 1.0 / (t * scale), "unit": "images/s (1024^2-equivalent, Swin backbone fwd+bwd only)",
-            "cores": cores, "kind": "port",
-            "sample": "oracle/swin.py Swin-%s fwd+bwd (fp32, %d threads), 1 image %dx%d in %.1f s, x%.0f pixel-count scaling to 1024^2" % (swin, cores, size, size, t, scale)}
+    assembled = {"value": 1.0 / (t * scale), "unit": "images/s (1024^2-equivalent)", "seconds": t, "forward_seconds": tf, "size": size,
+                 "what": "oracle/model.py assembled CenterNet2 Swin-%s training forward + backward, fp32, 1 image" % swin}
+    # round-1 sample: backbone alone
+    from oracle import swin as OSW
+    c = OSW.SIZE2CONFIG[swin]
+    bp = {k[len("backbone.bottom_up."):]: v for k, v in p.items() if k.startswith("backbone.bottom_up.")}
+    img = torch.randn(1, 3, size, size)
+    t0 = time.time()
+    outs = OSW.swin_forward(img, bp, c["embed_dim"], c["depths"], c["num_heads"], c["ws"])
+    sum(o.square().mean() for o in outs.values()).backward()
+    tb = time.time() - t0
+    return {"value": assembled["value"], "unit": "images/s (1024^2-equivalent, whole model fwd+bwd)", "cores": cores, "kind": "port",
+            "sample": "assembled oracle (oracle/model.py) fwd+bwd of 1 image %dx%d in %.1f s on %d threads, x%.0f pixel-count scaling "
+                      "to 1024^2; no optimizer / copy-paste on the CPU side" % (size, size, t, cores, scale),
+            "assembled": assembled,
+            "backbone_only": {"value": 1.0 / (tb * scale), "seconds": tb, "size": size,
+                              "what": "oracle/swin.py Swin-%s fwd+bwd alone (round 1's cpu_baseline sample)" % swin}}
 
 
 def main():
@@ -132,6 +182,18 @@ def main():
         else:
             dist.init_process_group(backend)
     assert world == a.gpus, "launch one process per GPU (WORLD_SIZE=%d, --gpus %d)" % (world, a.gpus)
+    ranks_seen = None
+    if world > 1:
+        # self-check of the launch: every rank contributes 1 and its device index through the collective backend; the sum must
+        # be the world size and the devices pairwise distinct (one process per GPU), otherwise the scaling numbers mean nothing
+        probe = torch.zeros(world + 1, device=dev if dist.get_backend() == "nccl" else "cpu")
+        probe[0] = 1.0
+        probe[1 + rank] = float(local) + 1.0
+        dist.all_reduce(probe)
+        ranks_seen = int(probe[0].item())
+        devs = [int(v) - 1 for v in probe[1:].tolist()]
+        assert ranks_seen == world, "collective saw %d of %d ranks" % (ranks_seen, world)
+        assert "DGX_FORCE_DEVICE" in os.environ or len(set(devs)) == world, "ranks share GPUs: %s" % devs
     # DGX_GRAPH_BACKBONE=1 (opt-in) replays the static-shape backbone fwd+bwd as a hipGraph: -6 % step
     # time at N=1 (the step is CPU-launch-bound), but per-kernel HIP events (the roofline object) and the
     # per-layer gradient readiness the arena reducer overlaps on are only available on the eager path,
@@ -149,9 +211,9 @@ def main():
     from divergen_amd.utils.events import EventStorage
 
     cfg = get_cfg()
-    cfg.merge_from_file(os.path.join(ROOT, "tests", "configs", "DiverGen_swinL.yaml"))
+    cfg.merge_from_file(os.path.join(ROOT, "configs", "DiverGen_swinL.yaml"))
     cfg.merge_from_list(["MODEL.SWIN.SIZE", a.swin, "INPUT.TRAIN_SIZE", a.size, "MODEL.ROI_BOX_HEAD.CAT_FREQ_PATH",
-                         os.path.join(ROOT, "tests", "configs", "metadata",
+                         os.path.join(ROOT, "configs", "metadata",
                                       "ImageNet2012_filtered04_lvis_v1_train_cat_info_250.json")])
     torch.manual_seed(cfg.SEED + rank)
     model = build_model(cfg).train()
@@ -219,20 +281,31 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    L = _lib.lib()
-    timers = {n: KernelTimer(L, n) for n in ("dgx_linear_wgrad_grouped", "dgx_window_attention_fwd", "dgx_window_attention_bwd")}
+    from divergen_amd.utils import prof
+    prof.enable(not a.no_roofline)            # on from the first step: hipGraph captures (warm-up) record what they replay
     with EventStorage(0):
         for _ in range(a.warmup):
             one_step()
         sync()
-        for t in timers.values():
-            t.enabled = True
+        prof.enable(not a.no_roofline)        # restart the tallies: the timed region only
+        prof.pause(True)
+        sampled = 0
         t0 = time.perf_counter()
-        for _ in range(a.steps):
+        for k in range(a.steps):
+            # two event records per heavy launch cost the host ~10 us (measured: +3.5 ms on a 41 ms step when every step is
+            # instrumented, which would make the step host-bound): every `roofline_every`-th step of the timed region carries them
+            on = not a.no_roofline and k % a.roofline_every == 0
+            if on:
+                prof.pause(False)
+                sampled += 1
             total = one_step()
+            if on:
+                prof.pause(True)
         t_issue = time.perf_counter() - t0     # host time to ENQUEUE the steps (diagnostic: CPU- vs GPU-bound)
         sync()
         dt = time.perf_counter() - t0
+    stats = prof.read() if not a.no_roofline else {}
+    prof.enable(False)
     assert bool(torch.isfinite(total)), "non-finite loss"
     tmax = torch.tensor([dt], device=dev)
     if world > 1:
@@ -250,43 +323,41 @@ def main():
         in_sync = all(torch.equal(g.cpu(), gathered[0].cpu()) for g in gathered)
         assert in_sync, "weights diverged across ranks: %s" % [g.tolist() for g in gathered]
 
-    # roofline objects from HIP events recorded (on the launch stream) around every call of the three heaviest
-    # libdgx entry points inside the timed region; "roofline" = the one with the largest total time
-    def work(name, args):
-        """-> (flops, algorithmic bytes) of one call."""
-        if name == "dgx_linear_wgrad_grouped":
-            fl = by = 0.0
-            for i in range(args[1]):
-                p = args[0][i]
-                fl += 2.0 * p.M * p.Nn * p.Kk
-                by += 2.0 * p.M * (p.Nn + p.Kk) + 8.0 * p.Nn * p.Kk      # dY, X read once (bf16); fp32 gradient read + written
-            return fl, by
-        if name.endswith("fwd"):
-            B_, nH, ws, mm, io = args[7], args[9], args[10], 2, 4            # QK^T, PV;  q,k,v in + out
-        else:
-            B_, nH, ws, mm, io = args[10], args[12], args[13], 5, 8         # S, dP, dV, dK, dQ;  q,k,v,o,do in + dq,dk,dv out
-        N = ws * ws
-        return B_ * nH * mm * 2.0 * N * N * 32, B_ * nH * N * (32 * 2 * io + 4)
-
+    # roofline objects: HIP events recorded by libdgx (csrc/prof.hip) on the launch stream around EVERY eager call of a
+    # family inside the timed region, with the algorithmic FLOP / bytes of each call; launches replayed from hipGraphs
+    # (FPN output convs, CenterNet towers) carry no events and are listed next to them with their work.  "roofline" = the
+    # family with the largest device time per step.  `profile` repeats the computation from the rocprofv3 CSV committed
+    # under profiles/ (every dispatch, graphs included): frac_all_launches = flops_per_step / family_ms_per_step / peak.
+    pmc = _load_json(PROFILE_TAG + "_pmc.json")
+    prof_csv = profile_crosscheck()
     objs = []
-    for name, t in timers.items():
-        if not t.events:
+    nsamp = max(sampled, 1)
+    for fam, st in stats.items():
+        if not st["launches"] or st["ms"] <= 0:
             continue
-        tot_ms = sum(s.elapsed_time(e) for s, e, _ in t.events)
-        fl = by = 0.0
-        for _, _, args in t.events:
-            f, b_ = work(name, args)
-            fl += f
-            by += b_
-        tf, gbs = fl / (tot_ms * 1e-3) / 1e12, by / (tot_ms * 1e-3) / 1e9
-        # window attention at head_dim 32 is 72 FLOP/B -- under the ~310 FLOP/B ridge, i.e. HBM-bound; the 256x256
-        # weight-gradient tiles are MFMA-bound
-        mfma = name == "dgx_linear_wgrad_grouped"
-        objs.append({"kernel": name, "bound": "mfma" if mfma else "hbm", "achieved": tf if mfma else gbs,
-                     "peak": 2500.0 if mfma else 8000.0, "unit": "TFLOP/s" if mfma else "GB/s",
-                     "frac": (tf / 2500.0) if mfma else (gbs / 8000.0), "traffic": PMC_TRAFFIC.get(name),
-                     "avg_launch_us": tot_ms * 1e3 / len(t.events), "launches": len(t.events), "total_ms_per_step": tot_ms / a.steps,
-                     "tflops": tf, "algorithmic_gbytes_per_s": gbs})
+        tf, gbs = st["flops"] / (st["ms"] * 1e-3) / 1e12, st["bytes"] / (st["ms"] * 1e-3) / 1e9
+        # window attention at head_dim 32 is 72 FLOP/B -- under the ~310 FLOP/B ridge, i.e. HBM-bound; the GEMM families are
+        # MFMA-bound at their aggregate intensity (reported: flop_per_byte)
+        mfma = fam in ("gemm_nt", "wgrad")
+        o = {"kernel": FAMILY_LABEL[fam], "family": fam, "bound": "mfma" if mfma else "hbm", "achieved": tf if mfma else gbs,
+             "peak": 2500.0 if mfma else 8000.0, "unit": "TFLOP/s" if mfma else "GB/s",
+             "frac": (tf / 2500.0) if mfma else (gbs / 8000.0),
+             "traffic": (pmc.get(fam) or {}).get("hbm_bytes_per_launch"),
+             "algorithmic_bytes_per_launch": st["bytes"] / st["launches"], "flop_per_byte": st["flops"] / max(st["bytes"], 1.0),
+             "avg_launch_us": st["ms"] * 1e3 / st["launches"], "launches_timed_per_step": st["launches"] / nsamp,
+             "total_ms_per_step": st["ms"] / nsamp, "tflops": tf, "algorithmic_gbytes_per_s": gbs,
+             "flops_timed_per_step": st["flops"] / nsamp,
+             "graph_replayed": {"launches_per_step": st["graph_launches"] / nsamp, "flops_per_step": st["graph_flops"] / nsamp,
+                                "bytes_per_step": st["graph_bytes"] / nsamp},
+             "flops_per_step": (st["flops"] + st["graph_flops"]) / nsamp}
+        pc = prof_csv.get(fam)
+        if pc and pc["family_ms_per_step"] > 0:
+            pc = dict(pc)
+            rate = o["flops_per_step"] / (pc["family_ms_per_step"] * 1e-3)
+            byt = (st["bytes"] + st["graph_bytes"]) / nsamp / (pc["family_ms_per_step"] * 1e-3)
+            pc["frac_all_launches"] = rate / 2.5e15 if mfma else byt / 8e12
+            o["profile"] = pc
+        objs.append(o)
     objs.sort(key=lambda o: -o["total_ms_per_step"])
     roof = objs[0] if objs else None
 
@@ -298,14 +369,16 @@ def main():
                 "config": {"workload": "CenterNet2 Swin-%s, %dx%d, %d images/GPU, 1453 classes, GPU copy-paste + fwd + bwd + "
                                        "fused clip/AdamW/EMA; configs/DiverGen_swinL.yaml" % (a.swin, a.size, a.size, a.batch),
                            "global_batch": a.batch * world, "parallelism": "dp%d" % world, "params_M": nparams / 1e6},
-                "roofline": roof, "roofline_other": objs[1:],
+                "roofline": roof, "roofline_other": objs[1:], "roofline_steps_sampled": sampled,
                 "host_issue_ms_per_step": t_issue / a.steps * 1e3,
                 "peak_hbm_gb_rank0": torch.cuda.max_memory_allocated(dev) / 1e9}
         if in_sync is not None:
+            line["ranks_seen_by_collective"] = ranks_seen
+            line["collective_backend"] = "rccl" if dist.get_backend() == "nccl" else dist.get_backend()
             line["weights_identical_across_ranks"] = in_sync
             line["buckets_reduced_during_backward"] = "%d/%d" % (reducer.last_early, len(reducer.buckets))
         if world == 1 and not a.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(a.swin)
+            line["cpu_baseline"] = cpu_baseline(a.swin, model, cfg)
     # RCCL writes its version banner to the C-level stdout, which is block-buffered when redirected and would otherwise be
     # flushed at exit, i.e. AFTER the JSON: every rank drains it (and they meet) before rank 0 prints, so that the JSON
     # line is the last line on the job's stdout.

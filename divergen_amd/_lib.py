@@ -27,6 +27,12 @@ class GemmEpilogue(ctypes.Structure):
                 ("B", c_i), ("H", c_i), ("W", c_i), ("ws", c_i), ("shift", c_i), ("workspace", c_p), ("workspace_bytes", c_i64), ("relu", c_i)]
 
 
+class ProfStats(ctypes.Structure):
+    """struct dgx_prof_stats (include/divergen_hip.h)."""
+    _fields_ = [("ms", ctypes.c_double), ("launches", c_i64), ("flops", ctypes.c_double), ("bytes", ctypes.c_double),
+                ("captured_launches", c_i64), ("captured_flops", ctypes.c_double), ("captured_bytes", ctypes.c_double)]
+
+
 class ColsumProblem(ctypes.Structure):
     """struct dgx_colsum_problem (include/divergen_hip.h)."""
     _fields_ = [("dy", c_p), ("out", c_p), ("M", c_i), ("N", c_i)]
@@ -44,6 +50,9 @@ SIGNATURES = {
     "dgx_roi_align_bwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "dgx_roi_pooler_fwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "dgx_roi_pooler_bwd": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "dgx_prof_enable": (c_i, [c_i]),
+    "dgx_prof_pause": (c_i, [c_i]),
+    "dgx_prof_read": (c_i, [c_i, c_p]),
     "dgx_roi_pooler_bwd_gather": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "dgx_mask_crop": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "dgx_nms_sorted": (c_i, [c_p, c_i, c_f, c_p, c_p, c_p, c_p]),

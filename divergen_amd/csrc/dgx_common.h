@@ -67,3 +67,11 @@ __device__ __forceinline__ bf16x8 tr_frag(DGX_LDS const uint16_t* lane_ptr, int 
     } while (0)
 
 static inline int dgx_ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// Launch accounting (prof.hip): no-op unless dgx_prof_enable(1) was called.
+struct DgxProfScope {
+    DgxProfScope(int family, void* stream, double flops, double bytes);
+    ~DgxProfScope();
+    void *a, *b, *st;
+    int fam;
+};

@@ -665,6 +665,10 @@ extern "C" int dgx_gemm_bf16_nt(const void* A, const void* B, int M, int N, int 
     hipStream_t st = (hipStream_t)stream;
     const TileChoice tc = choose_tile(M, N);
     P.dbg = (unsigned long long*)g_dbg_buffer;
+    // algorithmic traffic: both operands once, every result tensor once (residual mode: residual in, sum out, no C)
+    const double mn = (double)M * N, rsz = ep->residual_dtype == DGX_F32 ? 4.0 : 2.0;
+    const double obytes = ep->mode == DGX_EPI_BIAS_RESIDUAL ? 2.0 * rsz * mn : (ep->mode >= DGX_EPI_BIAS_GELU ? 4.0 * mn : 2.0 * mn);
+    DgxProfScope prof(DGX_PROF_GEMM_NT, stream, 2.0 * mn * K, 2.0 * ((double)M * K + (double)N * K) + obytes);
     static const char* logp = getenv("DGX_GEMM_LOG");      // development: one line per launch, joined with a kernel trace
     if (logp) {
         static FILE* lf = fopen(logp, "w");
@@ -732,6 +736,9 @@ extern "C" int dgx_conv3x3_gemm(const void* xpad, const void* w, const void* bia
     P.cmap_n = N; P.cmap_h = H; P.cmap_w = W;
     P.relu = relu;
     g_ws_bytes_cur = 0;
+    const double pix = (double)N * H * W;       // useful work: the H x W interior (border rows of the padded grid are overhead)
+    DgxProfScope prof(DGX_PROF_GEMM_NT, stream, 2.0 * pix * Cout * 9.0 * Cin,
+                      2.0 * ((double)Mp * Cin + 9.0 * Cin * Cout + pix * Cout));
     return dgx_gemm_dispatch(P, (hipStream_t)stream);
 }
 

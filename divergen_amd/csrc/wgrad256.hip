@@ -300,6 +300,12 @@ static int wgrad_grouped_impl(const dgx_wgrad_problem* problems, const int* ldc,
 
 extern "C" int dgx_linear_wgrad_grouped(const dgx_wgrad_problem* problems, int n, float beta, void* workspace,
                                         void* stream) {
+    double fl = 0.0, by = 0.0;
+    for (int i = 0; problems && i < n && i < MAXP256; ++i) {      // dY, X read once (bf16); fp32 gradient read + written
+        fl += 2.0 * problems[i].M * problems[i].Nn * problems[i].Kk;
+        by += 2.0 * problems[i].M * ((double)problems[i].Nn + problems[i].Kk) + 8.0 * problems[i].Nn * problems[i].Kk;
+    }
+    DgxProfScope prof(DGX_PROF_WGRAD, stream, fl, by);
     return wgrad_grouped_impl(problems, nullptr, n, beta, workspace, stream);
 }
 
@@ -327,6 +333,8 @@ extern "C" int dgx_conv3x3_wgrad(const void* dypad, const void* xpad, float* gw,
         pr[t].M = (int)Mp; pr[t].Nn = Cout; pr[t].Kk = Cin;
         ldc[t] = 9 * Cin;
     }
+    // the nine taps share the two padded images; useful work = the H x W interior
+    DgxProfScope prof(DGX_PROF_WGRAD, stream, 2.0 * N * H * W * 9.0 * Cin * Cout, 2.0 * Mp * ((double)Cin + Cout) + 8.0 * 9.0 * Cin * Cout);
     return wgrad_grouped_impl(pr, ldc, 9, beta, workspace, stream);
 }
 

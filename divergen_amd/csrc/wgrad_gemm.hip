@@ -139,6 +139,7 @@ extern "C" int dgx_linear_wgrad(const void* dy, const void* x, float* gw, int M,
     int slab = (M + S - 1) / S;
     slab = (slab + BM - 1) / BM * BM;
     hipStream_t st = (hipStream_t)stream;
+    DgxProfScope prof(DGX_PROF_WGRAD, stream, 2.0 * M * Nn * Kk, 2.0 * M * ((double)Nn + Kk) + 8.0 * Nn * Kk);
     const size_t sm = (size_t)4 * BM * RSB;
     static bool once = false;
     if (!once) {

@@ -471,6 +471,9 @@ extern "C" int dgx_window_attention_fwd(const void* qkv, const float* table, int
     const bool masked = region != nullptr;
     if (!region) { region = zero_region(); nW = 1; if (!region) return DGX_ERR_BAD_ARG; }
     const int grid = ((B_ + 7) / 8) * 8 * nH;
+    // head_dim 32: QK^T and PV (2 x 2 N^2 32 FLOP per head), q, k, v in + out (bf16) + lse
+    const double heads = (double)B_ * nH, ntok = (double)ws * ws;
+    DgxProfScope prof(DGX_PROF_ATTN_FWD, stream, heads * 2.0 * 2.0 * ntok * ntok * 32.0, heads * ntok * (32.0 * 2.0 * 4.0 + 4.0));
 #define FWD_LAUNCH(WSV, MK) hipLaunchKernelGGL((win_attn_fwd_kernel<WSV, MK>), dim3(grid), dim3(WinCfg<WSV>::NT * 64), 0, st, \
                                               (const uint16_t*)qkv, table, region, (uint16_t*)out, lse, B_, nW, nH, scale, \
                                               table_stride_head, table_stride_index)
@@ -499,6 +502,9 @@ extern "C" int dgx_window_attention_bwd(const void* qkv, const float* table, con
     int chunk = (B_ + nchunks - 1) / nchunks;
     if (chunk < 1) chunk = 1;
     const int grid = ((B_ + chunk - 1) / chunk) * nH;
+    // S, dP, dV, dK, dQ (5 x 2 N^2 32 FLOP per head); q, k, v, out, dout in + dq, dk, dv out (bf16) + lse
+    const double heads = (double)B_ * nH, ntok = (double)ws * ws;
+    DgxProfScope prof(DGX_PROF_ATTN_BWD, stream, heads * 5.0 * 2.0 * ntok * ntok * 32.0, heads * ntok * (32.0 * 2.0 * 8.0 + 4.0));
 #define BWD_ARGS (const uint16_t*)qkv, table, region, (const uint16_t*)out, lse, (const uint16_t*)dout, (uint16_t*)dqkv, dtable, B_, nW, nH, \
                  scale, chunk, dtable_stride_head, dtable_stride_index
     if (ws == 12) {

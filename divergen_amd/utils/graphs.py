@@ -16,6 +16,7 @@ import os
 import torch
 
 from ..layers import linear_ops
+from . import prof
 
 ENABLED = os.environ.get("DGX_GRAPH_HEADS", "1") == "1"
 
@@ -39,6 +40,7 @@ class GraphedSegment:
     def __init__(self, module):
         self.module = module           # nn.Module: forward(*tensors) -> tuple of tensors
         self._fns = {}
+        self._work = {}
 
     def usable(self, inputs):
         return (ENABLED and torch.is_grad_enabled() and all(t.is_cuda for t in inputs)
@@ -52,8 +54,12 @@ class GraphedSegment:
             sample = tuple(t.detach().clone().requires_grad_(t.requires_grad) for t in inputs)
             # capture outside the caller's autocast region (its weight-cast cache cannot be captured); the segment
             # module re-enters autocast itself with the cache off
+            before = prof.captured_snapshot() if prof.ON else None
             with linear_ops.suspend_ready(), torch.autocast("cuda", enabled=False):
                 fn = torch.cuda.make_graphed_callables(self.module, sample, allow_unused_input=True)
+            if before is not None:      # heavy launches recorded into the two graphs (forward + backward): credited per replay
+                after = prof.captured_snapshot()
+                self._work[key] = {k: tuple(x - y for x, y in zip(after[k], before[k])) for k in after}
             # the capture warm-up ran real backward passes whose in-place gradient writes landed in the arena;
             # this step's backward has not started yet, so clearing them is exact
             for p in self.module.parameters():
@@ -66,4 +72,6 @@ class GraphedSegment:
             if params is None:
                 params = self.__dict__["_params"] = tuple(p for p in self.module.parameters() if p.requires_grad)
             inputs = inputs[:k] + (_SignalAfterBackward.apply(inputs[k], params),) + inputs[k + 1:]
+        if prof.ON and key in self._work:
+            prof.add_replay(self._work[key])
         return fn(*inputs)

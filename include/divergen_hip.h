@@ -484,6 +484,32 @@ int64_t dgx_conv3x3_wgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout
 int dgx_conv3x3_wgrad(const void* dypad, const void* xpad, float* gw, int N, int H, int W, int Cin, int Cout, float beta,
                       void* workspace, void* stream);
 
+
+/* ---------------------------------------------------------------------------------------------
+ * Launch accounting for measurement (bench.py's `roofline` objects; no reference counterpart -- the reference has no
+ * device-side instrumentation).  After dgx_prof_enable(1) the entry points of a family bracket each call with HIP events
+ * on the stream they launch on and add the call's algorithmic FLOP and bytes (operands read once, results written once)
+ * to the family's tally.  Calls made while the stream is captured into a hipGraph are tallied in the captured_* fields
+ * instead (no events inside a graph): the caller multiplies them by its replay count.
+ * dgx_prof_read synchronises the events recorded so far; dgx_prof_enable (either value) resets all tallies;
+ * dgx_prof_pause(1) / (0) stops / resumes the accounting without touching them (sampling a subset of steps: two event
+ * records per launch cost the host ~10 us). */
+#define DGX_PROF_GEMM_NT 0   /* dgx_gemm_bf16_nt, dgx_conv3x3_gemm */
+#define DGX_PROF_WGRAD 1     /* dgx_linear_wgrad_grouped, dgx_conv3x3_wgrad, dgx_linear_wgrad */
+#define DGX_PROF_ATTN_FWD 2  /* dgx_window_attention_fwd */
+#define DGX_PROF_ATTN_BWD 3  /* dgx_window_attention_bwd */
+#define DGX_PROF_FAMILIES 4
+typedef struct dgx_prof_stats {
+    double ms;                  /* sum of event-bracketed durations */
+    int64_t launches;           /* calls timed */
+    double flops, bytes;        /* algorithmic work of the timed calls */
+    int64_t captured_launches;  /* calls recorded into hipGraphs (once per capture) */
+    double captured_flops, captured_bytes;
+} dgx_prof_stats;
+int dgx_prof_enable(int on);
+int dgx_prof_pause(int paused);
+int dgx_prof_read(int family, dgx_prof_stats* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -37,3 +37,43 @@ def swin_param_shapes(embed_dim, depths, num_heads, ws, out_indices=(1, 2, 3), m
     for i in out_indices:
         s += [("norm%d.weight" % i, (embed_dim * 2 ** i,)), ("norm%d.bias" % i, (embed_dim * 2 ** i,))]
     return s
+
+
+# ---- the two random draws of a training step replaced by a deterministic rule (shared by the e2e parity test and the
+# cpu_baseline leg of bench.py, which times the assembled oracle)
+def det_sample(labels, num_samples, positive_fraction, bg_label):
+    pos = ((labels != -1) & (labels != bg_label)).nonzero().squeeze(1)
+    neg = (labels == bg_label).nonzero().squeeze(1)
+    npos = min(pos.numel(), int(num_samples * positive_fraction))
+    return pos[:npos], neg[:min(neg.numel(), num_samples - npos)]
+
+
+def det_fed_mask(gt_classes, K, C, weight):
+    app = torch.zeros(C + 1, dtype=torch.bool, device=gt_classes.device)
+    app[gt_classes] = True
+    app[C] = False if not bool((gt_classes == C).any()) else True
+    cand = (~app[:C]) & (weight > 0)
+    extra = cand.nonzero().squeeze(1)[:max(K - int(app.sum()), 0)]
+    m = app.clone()
+    m[extra] = True
+    return m
+
+
+def assembled_oracle_losses(p, images, gts, image_sizes, swin, num_classes, freq_weight, batch_per_image=512, pos_fraction=0.25,
+                            fed_num=50, mask_weight=1.0, proposals=None, score_thresh=0.0001, pre_topk=4000, nms_thresh=0.9,
+                            post_topk=2000):
+    """The whole training forward of oracle/model.py on CPU: Swin + FPN + CenterNet head -> CenterNet losses -> proposals
+    (the oracle's own decode + NMS unless `proposals` are handed in) -> cascade RoI heads + mask head.  Returns the loss
+    dict (differentiable w.r.t. the entries of `p` that require grad)."""
+    from oracle import model as OM
+    fp, regs, hms = OM.backbone_and_dense(p, images, swin)
+    losses = dict(OM.centernet_losses(regs, hms, [g["boxes"] for g in gts]))
+    if proposals is None:
+        with torch.no_grad():
+            proposals = [b for b, _ in (OM.proposals_from_heatmaps([r.detach() for r in regs], [h.detach() for h in hms],
+                                                                   score_thresh, pre_topk, nms_thresh, post_topk))]
+    losses.update(OM.roi_head_losses(p, fp, proposals, gts, image_sizes, num_classes, batch_per_image, pos_fraction, freq_weight,
+                                     fed_num, lambda i, labels, n, frac, bg: det_sample(labels, n, frac, bg),
+                                     lambda k, gtc, K, Cn, w: det_fed_mask(gtc, K, Cn, w).nonzero().squeeze(1),
+                                     mask_weight=mask_weight))
+    return losses

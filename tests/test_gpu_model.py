@@ -16,9 +16,9 @@ def _build(graph, swin="T"):
     from divergen_amd.modeling.backbone.swintransformer import DropPath
     from divergen_amd.solver import build_optimizer
     cfg = get_cfg()
-    cfg.merge_from_file(os.path.join(ROOT, "tests", "configs", "DiverGen_swinL.yaml"))
+    cfg.merge_from_file(os.path.join(ROOT, "configs", "DiverGen_swinL.yaml"))
     cfg.merge_from_list(["MODEL.SWIN.SIZE", swin, "MODEL.ROI_BOX_HEAD.CAT_FREQ_PATH",
-                         os.path.join(ROOT, "tests", "configs", "metadata", "ImageNet2012_filtered04_lvis_v1_train_cat_info_250.json")])
+                         os.path.join(ROOT, "configs", "metadata", "ImageNet2012_filtered04_lvis_v1_train_cat_info_250.json")])
     torch.manual_seed(42)
     model = build_model(cfg).train()
     for m in model.modules():
@@ -161,22 +161,7 @@ def run_e2e_vs_oracle(monkeypatch, swin, size):
     from divergen_amd.utils.events import EventStorage
     from oracle import model as OM
 
-    def det_sample(labels, num_samples, positive_fraction, bg_label):
-        pos = ((labels != -1) & (labels != bg_label)).nonzero().squeeze(1)
-        neg = (labels == bg_label).nonzero().squeeze(1)
-        npos = min(pos.numel(), int(num_samples * positive_fraction))
-        return pos[:npos], neg[:min(neg.numel(), num_samples - npos)]
-
-    def det_fed_mask(gt_classes, K, C, weight):
-        app = torch.zeros(C + 1, dtype=torch.bool, device=gt_classes.device)
-        app[gt_classes] = True
-        app[C] = False if not bool((gt_classes == C).any()) else True
-        cand = (~app[:C]) & (weight > 0)
-        extra = cand.nonzero().squeeze(1)[:max(K - int(app.sum()), 0)]
-        m = app.clone()
-        m[extra] = True
-        return m
-
+    from tests._recipes import assembled_oracle_losses, det_fed_mask, det_sample
     monkeypatch.setattr(RH, "subsample_labels", det_sample)
     monkeypatch.setattr(FR, "fed_loss_class_mask", det_fed_mask)
     cfg, model, opt = _build(False, swin)
@@ -202,18 +187,11 @@ def run_e2e_vs_oracle(monkeypatch, swin, size):
     C = cfg.MODEL.ROI_HEADS.NUM_CLASSES
     fw = model.roi_heads.box_predictor[0].freq_weight.cpu().float()
 
-    def o_sample(i, labels, n, frac, bg):
-        return det_sample(labels, n, frac, bg)
-
-    def o_fed(k, gtc, K, Cn, weight):
-        return det_fed_mask(gtc, K, Cn, weight).nonzero().squeeze(1)
     with torch.no_grad():
-        fp, regs, hms = OM.backbone_and_dense(p, images, swin)
-        want = dict(OM.centernet_losses(regs, hms, [g["boxes"] for g in gts]))
-        want.update(OM.roi_head_losses(p, fp, captured["props"], gts, [tuple(b["instances"].image_size) for b in batch], C,
-                                       cfg.MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE, cfg.MODEL.ROI_HEADS.POSITIVE_FRACTION, fw,
-                                       cfg.MODEL.ROI_BOX_HEAD.FED_LOSS_NUM_CAT, o_sample, o_fed,
-                                       mask_weight=model.roi_heads.mask_weight))
+        want = assembled_oracle_losses(p, images, gts, [tuple(b["instances"].image_size) for b in batch], swin, C, fw,
+                                       cfg.MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE, cfg.MODEL.ROI_HEADS.POSITIVE_FRACTION,
+                                       cfg.MODEL.ROI_BOX_HEAD.FED_LOSS_NUM_CAT, model.roi_heads.mask_weight,
+                                       proposals=captured["props"])
     want = {k: float(v) for k, v in want.items()}
     assert set(got) == set(want), (sorted(got), sorted(want))
     report = {k: (got[k], want[k], abs(got[k] - want[k]) / max(abs(want[k]), 1e-6)) for k in sorted(got)}

@@ -133,7 +133,7 @@ def test_lvis_loader_end_to_end_on_cpu(tmp_path, monkeypatch):
     assert d0["file_name"].endswith("coco/train2017/000000000001.jpg") and d0["neg_category_ids"] == [1]
     assert {a["category_id"] for a in d0["annotations"]} <= {0, 1, 2} and d0["annotations"][0]["bbox_mode"] == "XYWH_ABS"
     cfg = get_cfg()
-    cfg.merge_from_file(os.path.join(os.path.dirname(__file__), "configs", "DiverGen_swinL.yaml"))
+    cfg.merge_from_file(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "configs", "DiverGen_swinL.yaml"))
     cfg.merge_from_list(["INPUT.TRAIN_SIZE", 64, "INPUT.INST_POOL", False, "INPUT.USE_COPY_METHOD", "none", "DATALOADER.NUM_WORKERS", 0,
                          "DATALOADER.SAMPLER_TRAIN", "RepeatFactorTrainingSampler", "DATALOADER.REPEAT_THRESHOLD", 0.5])
     it = B.build_detection_train_loader(cfg, 2, "cpu", seed=7)
@@ -165,7 +165,7 @@ def test_train_loader_default_seed_and_missing_dataset(monkeypatch, tmp_path):
     import train_net
     from divergen_amd.config import get_cfg
     cfg = get_cfg()
-    cfg.merge_from_file(os.path.join(os.path.dirname(__file__), "configs", "baseline_swinL.yaml"))
+    cfg.merge_from_file(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "configs", "baseline_swinL.yaml"))
     assert cfg.SEED < 0
     cfg.merge_from_list(["DATASETS.TRAIN", ("synthetic",), "INPUT.TRAIN_SIZE", 64, "SOLVER.IMS_PER_BATCH", 2])
     batch = next(train_net.build_train_loader(cfg, None))

@@ -10,7 +10,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CFG = os.path.join(ROOT, "tests", "configs")
+CFG = os.path.join(ROOT, "configs")
 FREQ = os.path.join(CFG, "metadata", "ImageNet2012_filtered04_lvis_v1_train_cat_info_250.json")
 
 

@@ -3,8 +3,8 @@ sys.path.insert(0, ".")
 from divergen_amd.config import get_cfg
 from divergen_amd.modeling import build_model
 from divergen_amd.modeling.meta_arch.custom_rcnn import _BackboneForGraph
-cfg = get_cfg(); cfg.merge_from_file("tests/configs/DiverGen_swinL.yaml")
-cfg.merge_from_list(["MODEL.ROI_BOX_HEAD.CAT_FREQ_PATH", "tests/configs/metadata/ImageNet2012_filtered04_lvis_v1_train_cat_info_250.json"])
+cfg = get_cfg(); cfg.merge_from_file("configs/DiverGen_swinL.yaml")
+cfg.merge_from_list(["MODEL.ROI_BOX_HEAD.CAT_FREQ_PATH", "configs/metadata/ImageNet2012_filtered04_lvis_v1_train_cat_info_250.json"])
 model = build_model(cfg).train()
 x = torch.randn(2, 3, 1024, 1024, device="cuda").to(memory_format=torch.channels_last)
 names = list(model.backbone.output_shape().keys())

@@ -12,9 +12,9 @@ from divergen_amd.solver import build_optimizer
 from divergen_amd.utils.events import EventStorage
 
 cfg = get_cfg()
-cfg.merge_from_file("tests/configs/DiverGen_swinL.yaml")
+cfg.merge_from_file("configs/DiverGen_swinL.yaml")
 cfg.merge_from_list(["MODEL.ROI_BOX_HEAD.CAT_FREQ_PATH",
-                     "tests/configs/metadata/ImageNet2012_filtered04_lvis_v1_train_cat_info_250.json"])
+                     "configs/metadata/ImageNet2012_filtered04_lvis_v1_train_cat_info_250.json"])
 torch.manual_seed(42)
 model = build_model(cfg).train()
 opt = build_optimizer(cfg, model)

@@ -43,8 +43,8 @@ wrap(PL.ROIPooler, "forward", "roi pooler")
 wrap(FR.DeticFastRCNNOutputLayers, "losses_from_tensors", "box losses")
 
 cfg = get_cfg()
-cfg.merge_from_file("tests/configs/DiverGen_swinL.yaml")
-cfg.merge_from_list(["MODEL.ROI_BOX_HEAD.CAT_FREQ_PATH", "tests/configs/metadata/ImageNet2012_filtered04_lvis_v1_train_cat_info_250.json"])
+cfg.merge_from_file("configs/DiverGen_swinL.yaml")
+cfg.merge_from_list(["MODEL.ROI_BOX_HEAD.CAT_FREQ_PATH", "configs/metadata/ImageNet2012_filtered04_lvis_v1_train_cat_info_250.json"])
 torch.manual_seed(42)
 model = build_model(cfg).train()
 opt = build_optimizer(cfg, model)

@@ -1,0 +1,67 @@
+"""profiles/rNN_pmc.json from two rocprofv3 --pmc passes over bench.py (FETCH_SIZE and WRITE_SIZE, separate runs):
+
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_f -- python bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-roofline
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_w -- python bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-roofline
+    python tools/pmc_summary.py <fetch counter_collection.csv> <write counter_collection.csv> <steps incl. warm-up> profiles/r02_pmc.json
+
+Per kernel family (bench.FAMILY_KERNELS): dispatches, summed counters, HBM bytes per LAUNCH of the family's entry point
+(a launch of the wgrad entry point = one partial + one reduce dispatch; a split-K GEMM = kernel + fold), with the gfx950
+correction of /opt/skills/guides/MI355X_MICROARCH.md: FETCH_SIZE (KB) counts a 128-byte request of a wide (16 B/lane)
+streaming read as 64 B, so it is doubled for kernels whose reads are 16 B/lane (`wide`); WRITE_SIZE is taken as reported."""
+import csv
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+FAMILY_KERNELS = {
+    "gemm_nt": ("gemm_nt_kernel", "gemm_splitk_fold_kernel"),
+    "wgrad": ("wgrad256_partial_kernel", "wgrad256_reduce_kernel", "wgrad_partial_kernel", "wgrad_reduce_kernel"),
+    "attn_fwd": ("win_attn_fwd_kernel",),
+    "attn_bwd": ("win_attn_bwd_kernel",),
+}
+# entry-point launches are counted on the family's MAIN kernel
+MAIN = {"gemm_nt": "gemm_nt_kernel", "wgrad": "partial_kernel", "attn_fwd": "win_attn_fwd_kernel", "attn_bwd": "win_attn_bwd_kernel"}
+# 16 B/lane streaming reads (LDS-direct tile loads, float4 folds); window attention reads 64-byte head slices (64-B requests)
+WIDE = {"gemm_nt": True, "wgrad": True, "attn_fwd": False, "attn_bwd": False}
+
+
+def collect(path, counter):
+    out = {k: {"kb": 0.0, "dispatches": 0, "main": 0, "per_kernel": {}} for k in FAMILY_KERNELS}
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if r["Counter_Name"] != counter:
+                continue
+            for fam, pats in FAMILY_KERNELS.items():
+                if any(p in r["Kernel_Name"] for p in pats):
+                    out[fam]["kb"] += float(r["Counter_Value"])
+                    out[fam]["dispatches"] += 1
+                    out[fam]["main"] += MAIN[fam] in r["Kernel_Name"]
+                    pk = out[fam]["per_kernel"].setdefault(r["Kernel_Name"].split("(")[0][-60:], [0, 0.0])
+                    pk[0] += 1
+                    pk[1] += float(r["Counter_Value"])
+    return out
+
+
+def main():
+    fcsv, wcsv, steps, dst = sys.argv[1], sys.argv[2], float(sys.argv[3]), sys.argv[4]
+    F, W = collect(fcsv, "FETCH_SIZE"), collect(wcsv, "WRITE_SIZE")
+    res = {"_how": __doc__.strip(), "_steps_in_pass": steps}
+    for fam in FAMILY_KERNELS:
+        if not F[fam]["main"]:
+            continue
+        fetch = F[fam]["kb"] * 1000.0 * (2.0 if WIDE[fam] else 1.0)
+        write = W[fam]["kb"] * 1000.0
+        res[fam] = {"entry_point_launches": F[fam]["main"], "dispatches": F[fam]["dispatches"],
+                    "FETCH_SIZE_KB_raw_sum": F[fam]["kb"], "fetch_doubled": WIDE[fam], "WRITE_SIZE_KB_sum": W[fam]["kb"],
+                    "per_kernel_dispatches_FETCH_KB_WRITE_KB": {k: [v[0], v[1], W[fam]["per_kernel"].get(k, [0, 0.0])[1]]
+                                                                for k, v in F[fam]["per_kernel"].items()},
+                    "hbm_bytes_per_step": (fetch + write) / steps,
+                    "hbm_bytes_per_launch": (fetch + write) / F[fam]["main"]}
+    with open(dst, "w") as f:
+        json.dump(res, f, indent=1)
+    print(json.dumps({k: {kk: vv for kk, vv in v.items() if not kk.startswith("per_kernel")} for k, v in res.items() if not k.startswith("_")}, indent=1))
+
+
+if __name__ == "__main__":
+    main()

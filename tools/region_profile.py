@@ -55,8 +55,8 @@ wrap(RH.DeticCascadeROIHeads, "_create_proposals_from_boxes")
 wrap(RH.DeticCascadeROIHeads, "_forward_mask")
 
 cfg = get_cfg()
-cfg.merge_from_file("tests/configs/DiverGen_swinL.yaml")
-cfg.merge_from_list(["MODEL.ROI_BOX_HEAD.CAT_FREQ_PATH", "tests/configs/metadata/ImageNet2012_filtered04_lvis_v1_train_cat_info_250.json"])
+cfg.merge_from_file("configs/DiverGen_swinL.yaml")
+cfg.merge_from_list(["MODEL.ROI_BOX_HEAD.CAT_FREQ_PATH", "configs/metadata/ImageNet2012_filtered04_lvis_v1_train_cat_info_250.json"])
 torch.manual_seed(42)
 model = build_model(cfg).train()
 opt = build_optimizer(cfg, model)

@@ -13,9 +13,9 @@ from divergen_amd.utils.events import EventStorage
 size = sys.argv[1] if len(sys.argv) > 1 else "T"
 res = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 cfg = get_cfg()
-cfg.merge_from_file("tests/configs/DiverGen_swinL.yaml")
+cfg.merge_from_file("configs/DiverGen_swinL.yaml")
 cfg.merge_from_list(["MODEL.SWIN.SIZE", size, "MODEL.ROI_BOX_HEAD.CAT_FREQ_PATH",
-                     "tests/configs/metadata/ImageNet2012_filtered04_lvis_v1_train_cat_info_250.json"])
+                     "configs/metadata/ImageNet2012_filtered04_lvis_v1_train_cat_info_250.json"])
 torch.manual_seed(42)
 model = build_model(cfg).train()
 batch = synthetic_batch(2, res, cfg.MODEL.ROI_HEADS.NUM_CLASSES, device="cuda")

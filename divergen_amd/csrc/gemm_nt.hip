@@ -532,7 +532,15 @@ __global__ __launch_bounds__(256) void gemm_splitk_fold_kernel(GemmP P) {
             if (tok < 0) continue;
             if (P.scale) sc = P.scale[b];
         }
-        g_epilogue_chunk(P, gm, gn, g_pack8(v), tok, sc);
+        int om = gm;
+        if (P.cmap_h) {                            // implicit convolution: padded-grid row -> unpadded output row, border rows dropped
+            const int hp = P.cmap_h + 2, wp = P.cmap_w + 2;
+            const int n = gm / (hp * wp), r = gm - n * (hp * wp);
+            const int yp = r / wp, xp = r - yp * wp;
+            if (yp < 1 || yp > P.cmap_h || xp < 1 || xp > P.cmap_w) continue;
+            om = (n * P.cmap_h + yp - 1) * P.cmap_w + xp - 1;
+        }
+        g_epilogue_chunk(P, om, gn, g_pack8(v), tok, sc);
     }
 }
 
@@ -615,7 +623,12 @@ int launch_gemm(GemmP& P, hipStream_t st) {
 }
 }  // namespace
 
-static void* g_dbg_buffer = nullptr;   // development: set through dgx_dev_gemm_set_debug
+static void* g_dbg_buffer = nullptr;
+static FILE* gemm_log_file() {     // development: one line per launch (DGX_GEMM_LOG=path), joined with a kernel trace
+    static const char* logp = getenv("DGX_GEMM_LOG");
+    static FILE* lf = logp ? fopen(logp, "w") : nullptr;
+    return lf;
+}   // development: set through dgx_dev_gemm_set_debug
 extern "C" void dgx_dev_gemm_set_debug(void* device_buffer) { g_dbg_buffer = device_buffer; }
 
 extern "C" int dgx_gemm_bf16_nt(const void* A, const void* B, int M, int N, int K, int64_t lda, int64_t ldb,
@@ -669,11 +682,7 @@ extern "C" int dgx_gemm_bf16_nt(const void* A, const void* B, int M, int N, int 
     const double mn = (double)M * N, rsz = ep->residual_dtype == DGX_F32 ? 4.0 : 2.0;
     const double obytes = ep->mode == DGX_EPI_BIAS_RESIDUAL ? 2.0 * rsz * mn : (ep->mode >= DGX_EPI_BIAS_GELU ? 4.0 * mn : 2.0 * mn);
     DgxProfScope prof(DGX_PROF_GEMM_NT, stream, 2.0 * mn * K, 2.0 * ((double)M * K + (double)N * K) + obytes);
-    static const char* logp = getenv("DGX_GEMM_LOG");      // development: one line per launch, joined with a kernel trace
-    if (logp) {
-        static FILE* lf = fopen(logp, "w");
-        if (lf) { fprintf(lf, "%d %d %d %d %d %d\n", M, N, K, ep->mode, tc.bm, tc.bn); fflush(lf); }
-    }
+    if (FILE* lf = gemm_log_file()) { fprintf(lf, "%d %d %d %d %d %d\n", M, N, K, ep->mode, tc.bm, tc.bn); fflush(lf); }
 #ifdef DGX_GEMM_DEV
     if (const char* dg = getenv("DGX_GEMM_DIAG")) {
         switch (atoi(dg)) {
@@ -719,7 +728,7 @@ extern "C" int64_t dgx_conv3x3_pad_rows(int N, int H, int W) {
 }
 
 extern "C" int dgx_conv3x3_gemm(const void* xpad, const void* w, const void* bias, void* y, int N, int H, int W, int Cin, int Cout,
-                                int relu, void* stream) {
+                                int relu, void* workspace, int64_t workspace_bytes, void* stream) {
     if (N <= 0 || H <= 0 || W <= 0) return DGX_OK;
     if (!xpad || !w || !y || Cin <= 0 || Cout <= 0 || (Cin & 63) || (Cout & 7)) return DGX_ERR_BAD_ARG;
     const int64_t Mp = (int64_t)N * (H + 2) * (W + 2);
@@ -735,7 +744,12 @@ extern "C" int dgx_conv3x3_gemm(const void* xpad, const void* w, const void* bia
     P.conv_kc = Cin / GBK; P.conv_wp = W + 2;
     P.cmap_n = N; P.cmap_h = H; P.cmap_w = W;
     P.relu = relu;
-    g_ws_bytes_cur = 0;
+    P.ws = (float*)workspace;                      // small FPN levels: few tiles, 9 Cin / 64 K-tiles -> split-K slabs + fold
+    g_ws_bytes_cur = workspace ? workspace_bytes : 0;
+    if (FILE* lf = gemm_log_file()) {
+        const TileChoice tc = choose_tile(P.M, P.N);
+        fprintf(lf, "%d %d %d %d %d %d\n", P.M, P.N, P.K, 9, tc.bm, tc.bn); fflush(lf);
+    }
     const double pix = (double)N * H * W;       // useful work: the H x W interior (border rows of the padded grid are overhead)
     DgxProfScope prof(DGX_PROF_GEMM_NT, stream, 2.0 * pix * Cout * 9.0 * Cin,
                       2.0 * ((double)Mp * Cin + 9.0 * Cin * Cout + pix * Cout));

@@ -120,6 +120,25 @@ def _flipped_twin(weight, w16):
     return w16.flip(2, 3).permute(1, 2, 3, 0).reshape(w16.shape[1], -1).contiguous()
 
 
+_SPLITK = os.environ.get("DGX_CONV_SPLITK", "1") != "0"      # dev switch for A/B runs
+
+
+class _NoWorkspace:
+    @staticmethod
+    def data_ptr():
+        return None
+
+    @staticmethod
+    def numel():
+        return 0
+
+
+def _splitk_workspace(dev):
+    """The GEMM module's per-device split-K scratch (small FPN levels leave most CUs idle without it)."""
+    from . import gemm_ops
+    return gemm_ops._workspace(dev) if _SPLITK else _NoWorkspace
+
+
 class _Conv3x3Implicit(torch.autograd.Function):
     """3x3 / pad 1 / stride 1 convolution on libdgx's implicit GEMM (no column matrix): forward, input gradient and weight
     gradient all read zero-bordered copies of the NHWC tensors; bf16, Cin % 64 == 0, Cout % 8 == 0."""
@@ -135,8 +154,9 @@ class _Conv3x3Implicit(torch.autograd.Function):
         xp = _pad_image(x)
         y = torch.empty(N, H, W, Co, dtype=torch.bfloat16, device=x.device)
         b16 = shadow(bias) if bias is not None else None
-        L.check(L.lib().dgx_conv3x3_gemm(L.ptr(xp), wk.data_ptr(), L.ptr(b16), L.ptr(y), N, H, W, C, Co, int(relu), L.stream()),
-                "dgx_conv3x3_gemm")
+        ws = _splitk_workspace(x.device)
+        L.check(L.lib().dgx_conv3x3_gemm(L.ptr(xp), wk.data_ptr(), L.ptr(b16), L.ptr(y), N, H, W, C, Co, int(relu),
+                                         ws.data_ptr(), ws.numel(), L.stream()), "dgx_conv3x3_gemm")
         ctx.save_for_backward(xp, y if relu else None)
         ctx.weight, ctx.bias, ctx.w16 = weight, bias, w16
         ctx.cfg = (N, H, W, C, Co, relu)
@@ -164,7 +184,9 @@ class _Conv3x3Implicit(torch.autograd.Function):
             else:
                 Ck = Co
             gx = torch.empty(N, H, W, C, dtype=torch.bfloat16, device=g2.device)
-            L.check(lib.dgx_conv3x3_gemm(L.ptr(gsrc), wf.data_ptr(), None, L.ptr(gx), N, H, W, Ck, C, 0, L.stream()), "dgx_conv3x3_gemm")
+            ws = _splitk_workspace(g2.device)
+            L.check(lib.dgx_conv3x3_gemm(L.ptr(gsrc), wf.data_ptr(), None, L.ptr(gx), N, H, W, Ck, C, 0, ws.data_ptr(), ws.numel(),
+                                         L.stream()), "dgx_conv3x3_gemm")
         if ctx.needs_input_grad[1]:
             ws = torch.empty(max(int(lib.dgx_conv3x3_wgrad_workspace_bytes(N, H, W, C, Co)), 16), dtype=torch.uint8, device=g2.device)
             gphys = _ohwi_matrix(weight.grad) if (weight.is_leaf and weight.grad is not None) else None

@@ -473,13 +473,15 @@ int dgx_transpose_bf16_grouped(const void* src, void* dst, const void* jobs, int
  *                      kt / (Cin/64): the same rows of xpad shifted by a constant, so every tap is a plain strided read.
  *                      The INPUT gradient is the same call: dx = dgx_conv3x3_gemm(dypad, wflip, NULL, ...) with
  *                      wflip (Cin, 3, 3, Cout)[ci][ey][ex][co] = w[co][2-ey][2-ex][ci]  (and Cin / Cout exchanged).
+ *                      workspace (optional, f32): maps with few output tiles cut the 9 Cin contraction into slabs summed by a
+ *                      second launch (split-K) when S * N (H+2) (W+2) * Cout * 4 bytes fit; NULL = never split.
  *   dgx_conv3x3_wgrad  gw f32 (Cout,3,3,Cin) = beta*gw + sum over positions of dypad (x) xpad shifted per tap: nine problems of
  *                      the grouped weight-gradient kernel over the two padded images.  workspace: ..._workspace_bytes().
  */
 int64_t dgx_conv3x3_pad_rows(int N, int H, int W);
 int dgx_conv3x3_pad(const void* x, void* xpad, int N, int H, int W, int C, void* stream);
 int dgx_conv3x3_gemm(const void* xpad, const void* w, const void* bias, void* y, int N, int H, int W, int Cin, int Cout,
-                     int relu, void* stream);
+                     int relu, void* workspace, int64_t workspace_bytes, void* stream);
 int64_t dgx_conv3x3_wgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout);
 int dgx_conv3x3_wgrad(const void* dypad, const void* xpad, float* gw, int N, int H, int W, int Cin, int Cout, float beta,
                       void* workspace, void* stream);

@@ -7,6 +7,7 @@
 
 Weights keep nn.Conv2d / nn.ConvTranspose2d layouts so reference checkpoints load unchanged.
 Inputs and outputs are logical (N,C,H,W) tensors in channels_last memory format (NHWC storage)."""
+import math
 import os
 
 import torch
@@ -258,6 +259,33 @@ def conv1x1(x, weight, bias=None):
     weight, bias, co = _pad_cout(weight, bias)
     y = F.linear(xh, weight.view(weight.shape[0], -1), bias)
     return y[..., :co].permute(0, 3, 1, 2)
+
+
+def preprocess_patch_rows(images, mean, std, size_divisibility=0, patch=4):
+    """list of uint8 (3,h,w) CUDA images -> (PatchRows of the zero-padded, normalised batch, image_sizes): one
+    dgx_preprocess_patches launch per image, no fp32 batch tensor (rcnn.py:220-227 + image_list.py:59-110 + the unfold of
+    the stride-4 PatchEmbed convolution)."""
+    from ..structures import PatchRows
+    sizes = [(int(im.shape[-2]), int(im.shape[-1])) for im in images]
+    H, W = max(s[0] for s in sizes), max(s[1] for s in sizes)
+    st = max(int(size_divisibility), 1)
+    st = st * patch // math.gcd(st, patch)
+    H, W = -(-H // st) * st, -(-W // st) * st
+    Hp, Wp = H // patch, W // patch
+    rows = torch.empty(len(images), Hp * Wp, 3 * patch * patch, dtype=torch.bfloat16, device=images[0].device)
+    m, s_ = mean.reshape(-1).float().contiguous(), std.reshape(-1).float().contiguous()
+    for b, im in enumerate(images):
+        im = im.contiguous()
+        L.check(L.lib().dgx_preprocess_patches(L.ptr(im), sizes[b][0], sizes[b][1], L.ptr(m), L.ptr(s_), rows[b].data_ptr(), Hp, Wp,
+                                               patch, L.stream()), "dgx_preprocess_patches")
+    return PatchRows(rows, Hp, Wp), sizes
+
+
+def patch_embed_rows(pr, weight, bias):
+    """PatchRows -> tokens (B, Hp*Wp, embed): the PatchEmbed projection as a Linear over the prepared rows."""
+    if torch.is_autocast_enabled():
+        return linear(pr.rows, weight, bias), pr.Hp, pr.Wp
+    return F.linear(pr.rows.float(), weight.reshape(weight.shape[0], -1), bias), pr.Hp, pr.Wp
 
 
 def patch_embed4x4(x, weight, bias, patch=4):

@@ -18,7 +18,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import BACKBONE_REGISTRY, ShapeSpec
-from ...layers.conv_ops import patch_embed4x4
+from ...layers.conv_ops import patch_embed4x4, patch_embed_rows
+from ...structures import PatchRows
 from ...layers.linear_ops import Linear
 from ...layers.norm_ops import layernorm_bf16, layernorm_f32out, layernorm_window_gather, patch_merge_layernorm, residual_add
 from ...layers import shift_regions, window_attention_core, window_gather, window_scatter
@@ -207,6 +208,9 @@ class PatchEmbed(nn.Module):
         self.norm = nn.LayerNorm(embed_dim) if patch_norm else None
 
     def forward(self, x):
+        if isinstance(x, PatchRows):       # normalised + padded + unfolded by dgx_preprocess_patches: only the projection is left
+            x, Wh, Ww = patch_embed_rows(x, self.proj.weight, self.proj.bias)
+            return self._norm(x), Wh, Ww
         _, _, H, W = x.shape
         p = self.patch_size[0]
         if W % p:
@@ -214,13 +218,16 @@ class PatchEmbed(nn.Module):
         if H % p:
             x = F.pad(x, (0, 0, 0, p - H % p))
         x, Wh, Ww = patch_embed4x4(x, self.proj.weight, self.proj.bias, p)
+        return self._norm(x), Wh, Ww
+
+    def _norm(self, x):
         if self.norm is not None:
             if _FUSED_MERGE and torch.is_autocast_enabled() and x.is_cuda and self.embed_dim % 4 == 0 and self.embed_dim <= 768 \
                     and x.dtype in (torch.float32, torch.bfloat16):
                 x = layernorm_f32out(x, self.norm.weight, self.norm.bias, self.norm.eps)     # fp32 out, as autocast's LayerNorm
             else:
                 x = self.norm(x)
-        return x, Wh, Ww
+        return x
 
 
 class Backbone(nn.Module):

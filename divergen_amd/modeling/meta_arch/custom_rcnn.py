@@ -12,7 +12,11 @@ from torch import nn
 
 from .. import META_ARCH_REGISTRY, build_backbone, build_proposal_generator, build_roi_heads
 from ...config import configurable
+from ...layers.conv_ops import preprocess_patch_rows
 from ...structures import ImageList
+
+# dev switch: DGX_FUSED_PREPROCESS=0 keeps the torch normalise + pad + unfold path
+_FUSED_PREPROCESS = os.environ.get("DGX_FUSED_PREPROCESS", "1") != "0"
 
 
 @META_ARCH_REGISTRY.register()
@@ -50,8 +54,19 @@ class CustomRCNN(nn.Module):
     def preprocess_image(self, batched_inputs):
         """rcnn.py:220-227: H2D, (x - mean) / std, zero-pad to the backbone's divisibility."""
         images = [x["image"].to(self.device, non_blocking=True) for x in batched_inputs]
+        if self._patch_rows_ok(images):
+            # uint8 images -> PatchEmbed's GEMM operand in one pass (normalise + zero-pad + 4x4 unfold, bf16); the fp32 batch
+            # tensor is only materialised if somebody asks for `.tensor`
+            pr, sizes = preprocess_patch_rows(images, self.pixel_mean, self.pixel_std, self.backbone.size_divisibility)
+            return ImageList(None, sizes, patch_rows=pr)
         images = [(x.float() - self.pixel_mean) / self.pixel_std for x in images]
         return ImageList.from_tensors(images, self.backbone.size_divisibility)
+
+    def _patch_rows_ok(self, images):
+        bu = getattr(self.backbone, "bottom_up", None)
+        pe = getattr(bu, "patch_embed", None)
+        return (_FUSED_PREPROCESS and self.fp16 and self.training and pe is not None and pe.patch_size == (4, 4) and not (self.graph_backbone and self.training)
+                and all(im.is_cuda and im.dtype == torch.uint8 and im.dim() == 3 and im.shape[0] == 3 for im in images))
 
     def _graphed_backbone(self, x):
         key = (tuple(x.shape), self.fp16)
@@ -76,7 +91,10 @@ class CustomRCNN(nn.Module):
             return feats
         if self.fp16:
             with torch.autocast("cuda", dtype=torch.bfloat16):
-                feats = self.backbone(images.tensor.to(memory_format=torch.channels_last))
+                if images.patch_rows is not None:
+                    feats = self.backbone(images.patch_rows)
+                else:
+                    feats = self.backbone(images.tensor.to(memory_format=torch.channels_last))
             if self.heads_fp32:
                 feats = {k: v.float() for k, v in feats.items()}
             return feats

@@ -241,12 +241,35 @@ class Instances:
             ", ".join("{}: {}".format(k, type(v).__name__) for k, v in self._fields.items()))
 
 
-class ImageList:
-    """Batch of images padded to a common, divisible size (image_list.py:59-110)."""
+class PatchRows:
+    """The padded, normalised batch in the layout the Swin PatchEmbed consumes: rows (B, Hp*Wp, 3*4*4) bf16, one row per 4x4
+    patch in (c, dy, dx) order -- written by dgx_preprocess_patches straight from the uint8 images.  `shape` is the (B,3,H,W)
+    the batch tensor would have."""
 
-    def __init__(self, tensor, image_sizes):
-        self.tensor = tensor
+    def __init__(self, rows, Hp, Wp):
+        self.rows, self.Hp, self.Wp = rows, Hp, Wp
+        self.shape = (rows.shape[0], 3, 4 * Hp, 4 * Wp)
+        self.device = rows.device
+
+    def to_tensor(self, dtype=torch.float32):
+        B, _, H, W = self.shape
+        return self.rows.view(B, self.Hp, self.Wp, 3, 4, 4).permute(0, 3, 1, 4, 2, 5).reshape(B, 3, H, W).to(dtype)
+
+
+class ImageList:
+    """Batch of images padded to a common, divisible size (image_list.py:59-110).  With `patch_rows` the batch exists only as
+    PatchEmbed's GEMM operand; `.tensor` is then rebuilt from it on demand (bf16-rounded values)."""
+
+    def __init__(self, tensor, image_sizes, patch_rows=None):
+        self._tensor = tensor
         self.image_sizes = image_sizes
+        self.patch_rows = patch_rows
+
+    @property
+    def tensor(self):
+        if self._tensor is None and self.patch_rows is not None:
+            self._tensor = self.patch_rows.to_tensor()
+        return self._tensor
 
     def __len__(self):
         return len(self.image_sizes)
@@ -257,7 +280,7 @@ class ImageList:
 
     @property
     def device(self):
-        return self.tensor.device
+        return self.patch_rows.device if self._tensor is None and self.patch_rows is not None else self.tensor.device
 
     @staticmethod
     def from_tensors(tensors, size_divisibility=0, pad_value=0.0):

@@ -488,6 +488,17 @@ int dgx_conv3x3_wgrad(const void* dypad, const void* xpad, float* gw, int N, int
 
 
 /* ---------------------------------------------------------------------------------------------
+ * Image normalisation + zero padding + 4x4 patch gather in one pass: the A operand of the PatchEmbed projection straight
+ * from the uint8 image.  Replaces `(x - pixel_mean) / pixel_std` (D2/modeling/meta_arch/rcnn.py:220-227),
+ * ImageList.from_tensors' padded batch (D2/structures/image_list.py:59-110) and the unfold of the stride-4 convolution
+ * (DG/divergen/modeling/backbone/swintransformer.py:317-338).
+ *   img   u8 (3, h, w) one image;  mean, stdv f32 (3) device pointers
+ *   rows  bf16 (Hp*Wp, 48) the rows of THIS image: rows[py*Wp + px][c*16 + dy*4 + dx], zero where 4py+dy >= h or 4px+dx >= w
+ *   patch must be 4 (DGX_ERR_UNSUPPORTED otherwise); h <= 4 Hp, w <= 4 Wp. */
+int dgx_preprocess_patches(const uint8_t* img, int h, int w, const float* mean, const float* stdv, void* rows, int Hp, int Wp,
+                           int patch, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Launch accounting for measurement (bench.py's `roofline` objects; no reference counterpart -- the reference has no
  * device-side instrumentation).  After dgx_prof_enable(1) the entry points of a family bracket each call with HIP events
  * on the stream they launch on and add the call's algorithmic FLOP and bytes (operands read once, results written once)

@@ -111,6 +111,25 @@ def test_window_gather_scatter_exact(B, H, W, C, ws, shift, dt):
     assert torch.equal(la.window_scatter(w.to(DEV), B, H, W, ws, shift).cpu(), back)
 
 
+# ------------------------------------------------------------------ preprocess + patch unfold
+def test_preprocess_patch_rows_matches_normalise_pad_unfold():
+    """dgx_preprocess_patches against the reference's sequence (rcnn.py:220-227 normalise, image_list.py:59-110 zero-pad to
+    the divisibility, swintransformer.py:317-338 stride-4 unfold) on ragged image sizes that are not multiples of 4: the
+    bf16 rows must equal the bf16 rounding of the fp32 path exactly (same subtraction and true division)."""
+    from divergen_amd.layers.conv_ops import preprocess_patch_rows
+    g = torch.Generator().manual_seed(77)
+    imgs = [torch.randint(0, 256, (3, h, w), generator=g, dtype=torch.uint8) for h, w in ((37, 50), (64, 41), (1, 3))]
+    mean, std = torch.tensor([123.675, 116.28, 103.53]).view(3, 1, 1), torch.tensor([58.395, 57.12, 57.375]).view(3, 1, 1)
+    pr, sizes = preprocess_patch_rows([i.to(DEV) for i in imgs], mean.to(DEV), std.to(DEV), 32)
+    assert sizes == [(37, 50), (64, 41), (1, 3)] and pr.shape == (3, 3, 64, 64)
+    ref = torch.zeros(3, 3, 64, 64)
+    for b, im in enumerate(imgs):
+        ref[b, :, :im.shape[1], :im.shape[2]] = (im.float() - mean) / std
+    u = ref.reshape(3, 3, 16, 4, 16, 4).permute(0, 2, 4, 1, 3, 5).reshape(3, 256, 48)
+    assert torch.equal(pr.rows.cpu(), u.to(torch.bfloat16))
+    assert torch.equal(pr.to_tensor(torch.bfloat16).cpu(), ref.to(torch.bfloat16))
+
+
 # ------------------------------------------------------------------ ROIAlign / pooler / mask crop
 def _rand_rois(g, n, B, H, W):
     xy = torch.rand(n, 2, generator=g) * torch.tensor([W * 0.7, H * 0.7])

@@ -51,6 +51,8 @@ SIGNATURES = {
     "dgx_roi_pooler_fwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "dgx_roi_pooler_bwd": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "dgx_preprocess_patches": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
+    "dgx_mask_bce_workspace_floats": (c_i64, [c_i64]),
+    "dgx_mask_bce": (c_i, [c_p, c_i64, c_i64, c_p, c_i64, c_p, c_p, c_p, c_i, c_p]),
     "dgx_prof_enable": (c_i, [c_i]),
     "dgx_prof_pause": (c_i, [c_i]),
     "dgx_prof_read": (c_i, [c_i, c_p]),

@@ -7,6 +7,7 @@ import numpy as np
 import torch
 
 from .. import _lib
+from .. import _lib as L
 
 
 def _prep(masks, boxes):
@@ -86,3 +87,37 @@ def rle_encode_bitmasks(bits, cap=4096):
         lambda c, r, cp: _lib.check(L.dgx_rle_encode(_lib.ptr(b), _lib.ptr(c), _lib.ptr(r), N, H, W, cp, _lib.stream()),
                                     "dgx_rle_encode"), N, cap, b.device)
     return _to_rle_dicts(counts, nruns, H, W)
+
+
+class _MaskBCE(torch.autograd.Function):
+    """mean BCE-with-logits over (R, S, S) mask logits + the three mask statistics, one dgx_mask_bce call
+    (mask_head.py:35-110); the gradient is produced by the same pass."""
+
+    @staticmethod
+    def forward(ctx, pred, gt_u8):
+        R = pred.shape[0]
+        inner = pred[0].numel() if R else 1
+        if pred.dim() > 1 and R and not pred[0].is_contiguous():
+            pred = pred.contiguous()
+        n = pred.numel()
+        row_stride = pred.stride(0) if R else inner
+        out = torch.empty(5, dtype=torch.float32, device=pred.device)
+        ws = torch.empty(max(int(L.lib().dgx_mask_bce_workspace_floats(n)), 8), dtype=torch.float32, device=pred.device)
+        grad = torch.empty(pred.shape, dtype=pred.dtype, device=pred.device) if ctx.needs_input_grad[0] else None
+        L.check(L.lib().dgx_mask_bce(pred.data_ptr() if n else None, row_stride, inner, L.ptr(gt_u8), n, L.ptr(grad), L.ptr(out), L.ptr(ws),
+                                     L.dtype_code(pred), L.stream()), "dgx_mask_bce")
+        ctx.save_for_backward(grad)
+        ctx.mark_non_differentiable(out)
+        return out[0].clone(), out
+
+    @staticmethod
+    def backward(ctx, gloss, _gstats):
+        (grad,) = ctx.saved_tensors
+        return (grad * gloss.to(grad.dtype)) if grad is not None else None, None
+
+
+def mask_bce_with_stats(pred, gt_bool):
+    """pred (R, S, S) f32 / bf16 logits (dim 0 may be strided), gt_bool (R, S, S) bool / uint8 ->
+    (mean BCE loss, stats f32 (5) = [loss, #incorrect, #false positive, #false negative, #positive])."""
+    gt = gt_bool.view(torch.uint8) if gt_bool.dtype == torch.bool else gt_bool
+    return _MaskBCE.apply(pred, gt.contiguous())

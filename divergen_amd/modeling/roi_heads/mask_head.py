@@ -8,6 +8,7 @@ from torch.nn import functional as F
 from .. import ROI_MASK_HEAD_REGISTRY
 from ...config import configurable
 from ...layers.conv_ops import Conv2d, ConvTranspose2d
+from ...layers.mask_ops import mask_bce_with_stats
 from ...utils.events import get_event_storage
 from ..backbone.fpn import c2_msra_fill
 
@@ -30,8 +31,18 @@ def mask_rcnn_loss(pred_mask_logits, instances, vis_period=0):
     else:
         idx = torch.arange(pred_mask_logits.size(0), device=pred_mask_logits.device)
         pred = pred_mask_logits[idx, torch.cat(gt_classes, dim=0)]
+    if pred.is_cuda and pred.dtype in (torch.float32, torch.bfloat16):
+        # loss, gradient and the three statistics in one pass over the logits (dgx_mask_bce)
+        loss, stats = mask_bce_with_stats(pred, gt_masks)
+        with torch.no_grad():  # statistics stay on the device; writers convert lazily
+            n = float(max(gt_masks.numel(), 1))
+            st = get_event_storage()
+            st.put_scalar("mask_rcnn/accuracy", 1 - stats[1] / n)
+            st.put_scalar("mask_rcnn/false_positive", stats[2] / (gt_masks.numel() - stats[4]).clamp(min=1.0))
+            st.put_scalar("mask_rcnn/false_negative", stats[3] / stats[4].clamp(min=1.0))
+        return loss
     gt_bool = gt_masks
-    with torch.no_grad():  # statistics stay on the device; writers convert lazily
+    with torch.no_grad():
         incorrect = (pred > 0.0) != gt_bool
         npos = gt_bool.sum()
         st = get_event_storage()

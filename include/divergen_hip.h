@@ -499,6 +499,18 @@ int dgx_preprocess_patches(const uint8_t* img, int h, int w, const float* mean, 
                            int patch, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Mask loss of mask_rcnn_loss (D2/modeling/roi_heads/mask_head.py:35-110): F.binary_cross_entropy_with_logits(pred, gt,
+ * reduction="mean"), its gradient and the accuracy / false-positive / false-negative counts in one pass.
+ *   logits  (R, inner) f32 or bf16, row r at logits + r*row_stride (the class-specific branch hands a strided gather view)
+ *   gt      u8 (n = R*inner) in {0,1} (dgx_mask_crop's output)
+ *   grad    same dtype as logits, (n) contiguous, = (sigmoid(x) - t) / n; may be NULL
+ *   out     f32 (5): mean loss, #incorrect, #false positive, #false negative, #positive
+ *   workspace f32 (dgx_mask_bce_workspace_floats(n)); sums are two-stage in a fixed order (reproducible). */
+int64_t dgx_mask_bce_workspace_floats(int64_t n);
+int dgx_mask_bce(const void* logits, int64_t row_stride, int64_t inner, const uint8_t* gt, int64_t n, void* grad, float* out,
+                 float* workspace, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Launch accounting for measurement (bench.py's `roofline` objects; no reference counterpart -- the reference has no
  * device-side instrumentation).  After dgx_prof_enable(1) the entry points of a family bracket each call with HIP events
  * on the stream they launch on and add the call's algorithmic FLOP and bytes (operands read once, results written once)

@@ -237,6 +237,33 @@ def test_roi_pooler_backward_gather_vs_oracle_and_scatter(monkeypatch, C, S, dt)
     torch.testing.assert_close(f1.grad.cpu(), ref1, atol=1e-4, rtol=1e-4)
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_mask_bce_matches_torch_formulation(dt):
+    """dgx_mask_bce (loss, gradient, statistics of mask_rcnn_loss, mask_head.py:35-110) against the torch formulation the
+    reference calls, incl. a strided class-gather view, saturated logits and an empty input."""
+    from divergen_amd.layers.mask_ops import mask_bce_with_stats
+    g = torch.Generator().manual_seed(5)
+    R, S = 37, 28
+    full = (torch.randn(R, 3, S, S, generator=g) * 4).to(dt)
+    full[0, 1, 0, :4] = torch.tensor([60.0, -60.0, 0.0, -0.0]).to(dt)
+    gt = torch.rand(R, S, S, generator=g) > 0.6
+    x = full.float()[:, 1].clone().requires_grad_(True)
+    ref = torch.nn.functional.binary_cross_entropy_with_logits(x, gt.float(), reduction="mean")
+    ref.backward()
+    fd = full.to(DEV).requires_grad_(True)
+    loss, stats = mask_bce_with_stats(fd[:, 1], gt.to(DEV))
+    (loss * 2.0).backward()
+    assert abs(float(loss) - float(ref)) <= 2e-6 * abs(float(ref)) + 1e-7
+    gd = fd.grad.float().cpu()
+    assert float(gd[:, 0].abs().max()) == 0.0 and float(gd[:, 2].abs().max()) == 0.0
+    tol = 2.0 ** -8 * (2 * x.grad).abs() + 1e-9 if dt == torch.bfloat16 else 1e-6 * (2 * x.grad).abs() + 1e-10
+    assert not bool(((gd[:, 1] - 2 * x.grad).abs() > tol).any())
+    wrong = (x.detach() > 0) != gt
+    assert stats.cpu().tolist()[1:] == [float(wrong.sum()), float((wrong & ~gt).sum()), float((wrong & gt).sum()), float(gt.sum())]
+    l0, s0 = mask_bce_with_stats(torch.zeros(0, S, S, device=DEV, dtype=dt), torch.zeros(0, S, S, dtype=torch.bool, device=DEV))
+    assert float(l0) == 0.0 and float(s0.abs().sum()) == 0.0
+
+
 def test_mask_crop_bit_exact():
     g = torch.Generator().manual_seed(23)
     H, W, M = 200, 260, 6

@@ -14,27 +14,28 @@ from ..utils import comm
 
 
 def _match_keys(model_keys, ckpt_keys):
-    """Map checkpoint keys to model keys: exact match first, else the model key that has the checkpoint
-    key as its longest '.'-aligned suffix (e.g. 'layers.0...' -> 'backbone.bottom_up.layers.0...')."""
-    mapping, used = {}, set()
-    mk = set(model_keys)
-    for ck in ckpt_keys:
-        if ck in mk:
-            mapping[ck] = ck
-            used.add(ck)
-    for ck in ckpt_keys:
-        if ck in mapping:
-            continue
+    """Map checkpoint keys to model keys (D2/checkpoint/c2_model_loading.py:align_and_update_state_dicts): every MODEL key
+    takes the checkpoint key that is its longest '.'-aligned suffix (e.g. 'backbone.bottom_up.layers.0...' <- 'layers.0...'),
+    independent of the order of either list; an exact match is the longest possible suffix.  A checkpoint key claimed by
+    several model keys is ambiguous and raises, as the reference does."""
+    cset = set(ckpt_keys)
+    mapping = {}
+    for k in model_keys:
         best = None
-        for k in model_keys:
-            if k in used:
-                continue
-            if k.endswith("." + ck) or k == ck:
-                if best is None or len(k) < len(best):
-                    best = k
-        if best is not None:
-            mapping[ck] = best
-            used.add(best)
+        if k in cset:
+            best = k
+        else:
+            parts = k.split(".")
+            for i in range(1, len(parts)):               # longest suffix first
+                suf = ".".join(parts[i:])
+                if suf in cset:
+                    best = suf
+                    break
+        if best is None:
+            continue
+        if best in mapping:
+            raise ValueError("Cannot match one checkpoint key to multiple keys in the model: %s <- %s, %s" % (best, mapping[best], k))
+        mapping[best] = k
     return mapping
 
 

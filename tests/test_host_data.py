@@ -2,6 +2,8 @@
 import math
 import os
 
+import pytest
+
 import torch
 
 
@@ -56,6 +58,14 @@ def test_checkpointer_roundtrip_and_suffix_matching(tmp_path):
                     ["layers.0.blocks.0.attn.qkv.weight", "fpn_lateral3.weight", "head.weight"])
     assert m == {"layers.0.blocks.0.attn.qkv.weight": "backbone.bottom_up.layers.0.blocks.0.attn.qkv.weight",
                  "fpn_lateral3.weight": "backbone.fpn_lateral3.weight"}
+    # a short checkpoint key ('norm.weight') listed FIRST must not claim a model key whose true owner is a longer suffix,
+    # whatever the order of either list (the earlier greedy matcher depended on the checkpoint's key order)
+    mk = ["backbone.bottom_up.patch_embed.norm.weight", "backbone.bottom_up.norm.weight"]
+    for ckeys in (["norm.weight", "patch_embed.norm.weight"], ["patch_embed.norm.weight", "norm.weight"]):
+        for mkeys in (mk, mk[::-1]):
+            assert _match_keys(mkeys, ckeys) == {"patch_embed.norm.weight": mk[0], "norm.weight": mk[1]}
+    with pytest.raises(ValueError):          # one checkpoint key, two owners: ambiguous, as in the reference
+        _match_keys(["a.norm.weight", "b.norm.weight"], ["norm.weight"])
 
 
 # ------------------------------------------------------------------ the real data path (divergen_amd/data/build.py)

@@ -132,14 +132,21 @@ def do_train(cfg, model, resume=False):
             loss_dict = model(data)
             losses = sum(loss_dict.values())
             pending.append((iteration, {k: v.detach() for k, v in loss_dict.items()}))
+            # DG/train_net.py:266 asserts isfinite(losses) before backward; here the flag stays on the device (no sync): a
+            # non-finite loss makes the optimizer kernel skip the weights, moments and EMA of this step (found_inf), and the
+            # deferred host check below runs BEFORE the periodic checkpointer can save
+            bad = (~torch.isfinite(losses.detach())).to(torch.int32)
+            if comm.get_world_size() > 1:
+                torch.distributed.all_reduce(bad, op=torch.distributed.ReduceOp.MAX)
             losses.backward()
             scale = reducer.finish()
-            optimizer.step(grad_scale=scale)          # EMA of the pre-step weights + clip + AdamW, one kernel
+            optimizer.step(grad_scale=scale, found_inf=bad)   # EMA of the pre-step weights + clip + AdamW, one kernel
             storage.put_scalar("lr", optimizer.param_groups[0]["lr"], smoothing_hint=False)
             storage.put_scalars(time=time.perf_counter() - t_step)
             t_data = time.perf_counter()
             scheduler.step()
-            if iteration - start_iter > 5 and (iteration % 20 == 0 or iteration == max_iter):
+            saves_now = cfg.SOLVER.CHECKPOINT_PERIOD > 0 and iteration % cfg.SOLVER.CHECKPOINT_PERIOD == 0
+            if (iteration - start_iter > 5 and (iteration % 20 == 0 or iteration == max_iter)) or saves_now:
                 for it, ld in pending:               # one sync for 20 iterations of losses
                     red = {k: float(v) for k, v in comm.reduce_dict(ld).items()}
                     assert all(v == v and abs(v) != float("inf") for v in red.values()), red

@@ -122,6 +122,39 @@ __device__ __forceinline__ void g_gelu_terms(float x, float& cdf, float& pdf) {
     cdf = x < 0.f ? h : 1.0f - h;
     pdf = e * kGInvSqrt2Pi;
 }
+// The same arithmetic on PAIRS of elements: every plain operation is a packed-fp32 instruction (v_pk_mul_f32 / v_pk_fma_f32 /
+// v_pk_add_f32: two results per issue slot, the same IEEE roundings as the scalar forms, so results are bit-identical); only the
+// reciprocal, the exponential and the sign select stay per element.  Halves the VALU slots of the GELU read-outs; measured
+// in situ the read-out is bound by its loads and stores, not by these (fc1 forward 70.8 -> 69.6 us).
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+__device__ __forceinline__ void g_gelu_terms2(f32x2 x, f32x2& cdf, f32x2& pdf) {
+    const f32x2 ax = {fabsf(x[0]), fabsf(x[1])};
+    const f32x2 z = ax * kGInvSqrt2;
+    const f32x2 d = __builtin_elementwise_fma(f32x2{0.3275911f, 0.3275911f}, z, f32x2{1.0f, 1.0f});
+    const f32x2 t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    const f32x2 nz = -z;
+    const f32x2 zz = nz * z;
+    const f32x2 e = {__expf(zz[0]), __expf(zz[1])};
+    f32x2 p = {1.061405429f, 1.061405429f};
+    p = __builtin_elementwise_fma(p, t, f32x2{-1.453152027f, -1.453152027f});
+    p = __builtin_elementwise_fma(p, t, f32x2{1.421413741f, 1.421413741f});
+    p = __builtin_elementwise_fma(p, t, f32x2{-0.284496736f, -0.284496736f});
+    p = __builtin_elementwise_fma(p, t, f32x2{0.254829592f, 0.254829592f});
+    const f32x2 h = (p * t) * 0.5f * e;           // scalar form: 0.5f * (p * t) * e -- multiplication commutes exactly
+    const f32x2 o = f32x2{1.0f, 1.0f} - h;
+    cdf = f32x2{x[0] < 0.f ? h[0] : o[0], x[1] < 0.f ? h[1] : o[1]};
+    pdf = e * kGInvSqrt2Pi;
+}
+__device__ __forceinline__ f32x2 g_gelu2(f32x2 x) {
+    f32x2 cdf, pdf;
+    g_gelu_terms2(x, cdf, pdf);
+    return x * cdf;
+}
+__device__ __forceinline__ f32x2 g_gelu_grad2(f32x2 x) {
+    f32x2 cdf, pdf;
+    g_gelu_terms2(x, cdf, pdf);
+    return cdf + x * pdf;                          // mul then add, as the scalar form (no contraction)
+}
 __device__ __forceinline__ float g_gelu(float x) {
     float cdf, pdf;
     g_gelu_terms(x, cdf, pdf);
@@ -166,14 +199,20 @@ __device__ __forceinline__ void g_epi_finish(const GemmP& P, int gm, int gn, con
         float v[8], o[8];
         g_unpack8(y, v);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) o[k] = g_gelu(v[k]);
+        for (int k = 0; k < 8; k += 2) {
+            const f32x2 r = g_gelu2(f32x2{v[k], v[k + 1]});
+            o[k] = r[0]; o[k + 1] = r[1];
+        }
         *reinterpret_cast<u32x4*>(P.C2 + (int64_t)gm * P.ldc + gn) = g_pack8(o);
     } else if (P.mode == 4) {
         float gq[8], v[8], d[8];
         g_unpack8(y, gq);
         g_unpack8(xa, v);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) d[k] = gq[k] * g_gelu_grad(v[k]);
+        for (int k = 0; k < 8; k += 2) {
+            const f32x2 r = f32x2{gq[k], gq[k + 1]} * g_gelu_grad2(f32x2{v[k], v[k + 1]});
+            d[k] = r[0]; d[k + 1] = r[1];
+        }
         *reinterpret_cast<u32x4*>(P.C + (int64_t)gm * P.ldc + gn) = g_pack8(d);
     } else {                                       // mode 3
         float yv[8], xv[8];
@@ -223,7 +262,9 @@ __global__ __launch_bounds__(512, MINW) void gemm_nt_kernel(GemmP P) {
     if (L0 >= P.total * P.splits) return;
     const int L = L0 / P.splits, split = L0 - L * P.splits;   // the splits of a tile are neighbours on one XCD
 #define GCLK(i) do { if (P.dbg && threadIdx.x == 0) P.dbg[(size_t)blockIdx.x * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+#define GCLKR(i) do { if (P.dbg && threadIdx.x == 0) P.dbg[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
     GCLK(0);
+    GCLKR(5);                                      // constant 100 MHz counter next to the shader-clock one: the ratio is the clock
     const int tm = L / P.tiles_n, tn = L - tm * P.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
     const int tid = threadIdx.x, l = tid & 63;
@@ -504,6 +545,7 @@ __global__ __launch_bounds__(512, MINW) void gemm_nt_kernel(GemmP P) {
         }
     }
     GCLK(4);
+    GCLKR(6);
 }
 
 // split-K fold: y = bf16(sum_s slab[s] + bias), then the same fused tail; one lane per 8-column chunk
@@ -623,6 +665,7 @@ int launch_gemm(GemmP& P, hipStream_t st) {
 }
 }  // namespace
 
+static int dgx_gemm_dispatch(GemmP& P, hipStream_t st);
 static void* g_dbg_buffer = nullptr;
 static FILE* gemm_log_file() {     // development: one line per launch (DGX_GEMM_LOG=path), joined with a kernel trace
     static const char* logp = getenv("DGX_GEMM_LOG");
@@ -701,18 +744,14 @@ extern "C" int dgx_gemm_bf16_nt(const void* A, const void* B, int M, int N, int 
         }
     }
 #endif
-    if (tc.bn == 192) {
-        if (tc.bm == 256) return launch_gemm<256, 192, 2>(P, st);
-        if (tc.bm == 192) return launch_gemm<192, 192, 3>(P, st);
-        return launch_gemm<128, 192, 4>(P, st);
-    }
-    if (tc.bn == 256) return launch_gemm<128, 256, 3>(P, st);
-    if (tc.bm == 256) return launch_gemm<256, 128, 3>(P, st);
-    return launch_gemm<128, 128, 4>(P, st);
+    return dgx_gemm_dispatch(P, st);
 }
 
 static int dgx_gemm_dispatch(GemmP& P, hipStream_t st) {
     const TileChoice tc = choose_tile(P.M, P.N);
+    // Measured and dropped (round 2): <128, 192, 2 stages, 4 waves / SIMD> = two co-resident workgroups per CU (80 KB of LDS and
+    // 128 registers each) so that one's read-out overlaps the other's main loop: -4 % on the K = 768 shapes, +10..30 % on the
+    // long-K ones, nothing on the step (the two workgroups of a CU start together and stay in phase).
     if (tc.bn == 192) {
         if (tc.bm == 256) return launch_gemm<256, 192, 2>(P, st);
         if (tc.bm == 192) return launch_gemm<192, 192, 3>(P, st);

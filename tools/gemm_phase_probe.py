@@ -10,7 +10,7 @@ import torch  # noqa: E402
 from divergen_amd import _lib as L  # noqa: E402
 from divergen_amd.layers import gemm_ops as G  # noqa: E402
 
-shapes = [("s2.fc1", 8192, 3072, 768), ("s2.fc2", 8192, 768, 3072), ("s2.proj", 10368, 768, 768)]
+shapes = [("s2.fc1", 8192, 3072, 768), ("s2.fc2", 8192, 768, 3072), ("s2.proj", 10368, 768, 768), ("s2.qkv", 10368, 2304, 768)]
 tiles = sys.argv[1].split(",") if len(sys.argv) > 1 else ["256x192", "128x192"]
 diags = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0]
 g = torch.Generator(device="cuda").manual_seed(0)
@@ -43,6 +43,9 @@ for name, M, N, K in shapes:
         def m(v, idx):
             return float(v[idx].mean())
         NT = (K + 63) // 64
+        span = float(d[:, 4].max() - t0)
+        us = G.dev_time_us(x, w, None)
+        print("   span %.0f ticks, %.1f us by HIP events -> %.0f ticks/us; last-starting 256 blocks start at %.0f" % (span, us, span / us, m(st, last)))
         allb = torch.arange(n)
         print("%-8s %-8s diag=%d blocks=%d | prologue %.0f mainloop %.0f (%.0f per K-tile) stage %.0f store %.0f total %.0f" % (
             name, tile, dg, n, m(ph[0], allb), m(ph[1], allb), m(ph[1], allb) / NT, m(ph[2], allb), m(ph[3], allb), m(tot, allb)), flush=True)

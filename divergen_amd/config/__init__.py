@@ -170,6 +170,25 @@ def add_divergen_config(cfg):
     return cfg
 
 
+def add_bsgal_config(cfg):
+    """BS/bsgal/config.py:52-79,176-180: the keys BSGAL adds on top of the Detic / DiverGen tree (the gradient-based active
+    selection of pasted batches); BS/configs/BSGAL/*.yaml load with these in place."""
+    m, i = cfg.MODEL, cfg.INPUT
+    for k, v in (("ACTIVE_MODE", "paste_or_zero"), ("ACTIVE_LOSS", "cls"), ("ACTIVE_LOSS_UPDATE", "all"), ("ACTIVE_SEED", 0),
+                 ("ACTIVE_COMPARE", "default"), ("ACTIVE_TEST", "select"), ("ACTIVE_TEST_INS", "one"), ("ACTIVE_LR", 0.0001),
+                 ("ACTIVE_OPTIMIZER", True), ("ACTIVE_OPTIMIZER_MODE", "sgd"), ("ACTIVE_PRED", False), ("ACTIVE_PRED_CHOOSE", ""),
+                 ("ACTIVE_PRED_SUP", "all"), ("ACTIVE_ONLY_GT_TRAIN", False), ("ACTIVE_ONLY_GT_TEST", False),
+                 ("ACTIVE_GRAD_COMPARE", False), ("ACTIVE_GRAD_NORM", True), ("ACTIVE_GRAD_SAVE", False),
+                 ("ACTIVE_GRAD_UPDATE", "AVERAGE"), ("ONLY_PASTE_SUP", False), ("ACTIVE_FORWARD_ONCE", False),
+                 ("ACTIVE_ONCE_MODE", "only_gt"), ("ACTIVE_EVAL", False), ("ACTIVE_DYNAMIC_THRES", 0.0), ("ACTIVE_TEST_BATCHSIZE", 4)):
+        if k not in m:
+            m[k] = v
+    for k, v in (("ACTIVE_SELECT", False), ("ACTIVE_SELECT_TYPE", "train"), ("SEPARATE_SYN", False), ("SEPERATE_SUP", False)):
+        if k not in i:
+            i[k] = v
+    return cfg
+
+
 def configurable(init_func=None, *, from_config=None):
     """D2/config/config.py `configurable`: allow `Cls(cfg, *args)` to build through
     `Cls.from_config(cfg, *args)` while still accepting explicit keyword construction."""

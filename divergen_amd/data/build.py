@@ -466,8 +466,41 @@ class CopyPasteMapper:
                 raise NotImplementedError("only INST_POOL_FORMAT 'RGBA' with INST_POOL_SAMPLE_TYPE 'cas_random' is built")
             self.inst_pool = InstPool.from_config(cfg)
 
+        # BSGAL (BS/bsgal/data/custom_build_copypaste_mapper.py:237-297, :916-930, :958-963, :1038-1057): keep the un-pasted
+        # sample and add a held-out image that shows one of the pasted classes
+        self.active_select = bool(cfg.INPUT.get("ACTIVE_SELECT", False))
+        self.active_test = cfg.MODEL.get("ACTIVE_TEST", "select")
+        self.active_test_one = cfg.MODEL.get("ACTIVE_TEST_INS", "one") == "one" and "one_class" in cfg.INPUT.INST_POOL_SAMPLE_TYPE
+        self.per_cat_pool_real = None
+
     def set_dataset(self, dataset):
         self.dataset = dataset
+        if self.active_select:
+            pool = {}
+            for i, d in enumerate(dataset):
+                for a in d.get("annotations", []):
+                    pool.setdefault(a["category_id"], set()).add(i)
+            self.per_cat_pool_real = {k: sorted(v) for k, v in pool.items()}
+
+    def _held_out(self, paste_labels, own_labels):
+        """The test image of one sample (:260-284): a class among the pasted ones ('select'), else among the image's own,
+        else any; re-drawn until some training image shows it; then one of those images through the plain mapper."""
+        ncls = 1203
+        if self.active_test == "select":
+            cand = sorted(set(paste_labels)) or sorted(set(own_labels))
+            cls = int(np.random.choice(cand)) if cand else int(np.random.choice(range(ncls)))
+        else:
+            cls = int(np.random.choice(range(ncls)))
+        while not self.per_cat_pool_real.get(cls):
+            cls = int(np.random.choice(range(ncls)))
+        pool = self.per_cat_pool_real[cls]
+        idx = pool[np.random.randint(0, len(pool))]
+        if self.active_test == "random_img":
+            idx = np.random.randint(0, len(self.dataset))
+        test = self.mapper(self.dataset[idx])
+        if self.active_test_one:
+            test["instances"] = test["instances"][test["instances"].gt_classes == cls]
+        return cls, test
 
     def cpu_part(self, dataset_dict):
         """What a loader worker runs: decode + augment + rasterise (and the self-copy index draw of mapper.py:877)."""
@@ -480,7 +513,19 @@ class CopyPasteMapper:
     def gpu_part(self, result):
         if "instances" not in result or not result["instances"].has("gt_masks") or self.inst_pool is None:
             return result
-        return self.inst_pool(result)
+        if not self.active_select:
+            return self.inst_pool(result)
+        import copy
+        origin_image, origin_instances = result["image"].clone(), copy.deepcopy(result["instances"])
+        out = self.inst_pool(result)
+        dev = out["image"].device
+        out["origin_image"], out["origin_instances"] = origin_image.to(dev), origin_instances.to(dev)
+        if not origin_instances.has("instance_source"):
+            out["origin_instances"].instance_source = torch.zeros(len(origin_instances), dtype=torch.int64, device=dev)
+        cls, test = self._held_out(out.get("paste_labels", []), origin_instances.gt_classes.tolist())
+        out["test_image"], out["test_instances"] = test["image"].to(dev), test["instances"].to(dev)
+        out["test_image_class"], out["test_file_name"] = cls, test.get("file_name")
+        return out
 
     def __call__(self, dataset_dict):
         return self.gpu_part(self.cpu_part(dataset_dict))

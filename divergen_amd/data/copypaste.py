@@ -160,7 +160,7 @@ class InstPool:
         inst = data["instances"]
         H, W = image.shape[-2:]
         num = np.random.randint(0, self.max_samples)
-        pastes = []
+        pastes, names = [], []
         for key in [self.dataset[i] for i in self.sample_ids(num)]:
             r = self.load_rgba(key, (H, W))
             if r is None:
@@ -168,6 +168,7 @@ class InstPool:
             rgba, label = r
             x0, y0 = self.random_start_xy(rgba, (H, W))
             pastes.append((rgba, int(x0), int(y0), int(label)))
+            names.append(str(key))
         dev = image.device if image.is_cuda else torch.device("cuda")
         out = copy_paste(image.to(dev), inst.gt_masks.tensor.to(dev).view(torch.uint8), inst.gt_boxes.tensor.to(dev),
                          inst.gt_classes.to(dev), pastes)
@@ -176,4 +177,5 @@ class InstPool:
         ni.gt_masks, ni.instance_source = BitMasks(out["masks"]), out["source"]
         data = dict(data)
         data["image"], data["instances"], data["height"], data["width"] = out["image"], ni, H, W
+        data["paste_labels"], data["paste_filename_list"] = [p[3] for p in pastes], names      # BSGAL's selection reads these
         return data

@@ -80,3 +80,242 @@ class WeightSnapshot:
     def restore(self):
         self.arena.p.copy_(self.saved)
         self.arena.sync_shadow()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The outer loop: "is the pasted batch better than the original one?" decided inside the training forward
+# (BS/bsgal/modeling/meta_arch/custom_rcnn.py:278-780), for the modes the shipped Swin-L configuration and the gradient
+# variant of the paper use.  Everything below is host logic over the model's own forward; the heavy parts are the model's
+# HIP path, the arena copies / axpy of the trial update and the two kernels above.
+class DynamicThreshold:
+    """custom_rcnn.py:29-48: percentile of the last `buffer_size` scores."""
+
+    def __init__(self, buffer_size=100, percentile=0.85):
+        from collections import deque
+        self.queue = deque(maxlen=buffer_size)
+        self.percentile = percentile * 100
+
+    def add_score(self, score):
+        self.queue.append(score)
+
+    def set_percentile(self, percentile):
+        self.percentile = percentile * 100
+
+    def get_threshold(self):
+        import numpy as np
+        return 0 if len(self.queue) == 0 else np.percentile(np.array(self.queue), self.percentile)
+
+
+def fetchloss(losses, str_list):
+    """:1088-1095 -- the entries whose key contains one of the strings."""
+    return {k: v for k, v in losses.items() if any(s in k for s in str_list)}
+
+
+def pop_loss_paste(losses):
+    """:1202-1209 -- split off the entries with 'paste' in their key (per-paste supervision terms)."""
+    paste = {k: v for k, v in losses.items() if "paste" in k}
+    return {k: v for k, v in losses.items() if k not in paste}, paste
+
+
+_LOSS_MODES = {"cls": "cls", "box": "box", "mask": "mask", "cls_stage0": "cls_stage0", "stage0": "stage0"}
+
+
+def loss_sum(losses, mode):
+    """The sums compare_loss / compute_diff_loss take (:1113-1131, :1173-1189)."""
+    if mode == "all":
+        return sum(losses.values())
+    if mode not in _LOSS_MODES:
+        raise NotImplementedError(mode)
+    return sum(v for k, v in losses.items() if _LOSS_MODES[mode] in k)
+
+
+def compare_loss(old_loss, new_loss, active_compare="default", active_loss="cls", it=0, rand=None):
+    """compare_loss (:1097-1169): '<' = keep the old (original) batch, '>' = take the new (pasted) one.  `rand` = a
+    callable returning a uniform [0,1) draw (random.random in the reference)."""
+    import random
+    rand = rand or random.random
+    if active_compare == "all":
+        return ">"
+    if "random" in active_compare:
+        thres = 0.5 if active_compare == "random" else float(active_compare.split("_")[1])
+        return "<" if rand() > thres else ">"
+    old_s, new_s = loss_sum(old_loss, active_loss), loss_sum(new_loss, active_loss)
+    lower = bool(new_s < old_s)
+    if active_compare == "contra":
+        return "<" if lower else ">"
+    if active_compare == "prob":
+        if rand() < 0.8:
+            return ">" if lower else "<"
+        return "<" if lower else ">"
+    if active_compare == "default":
+        return ">" if lower else "<"
+    if active_compare == "schedule":
+        if rand() > it / 90000:
+            return ">" if lower else "<"
+        return ">"
+    raise NotImplementedError(active_compare)
+
+
+def reset_instance_source(gt_instances):
+    """:317-327 -- [0,0,0,1,1,1] per image -> [0,0,0,1,2,3] with ids running over the whole batch (copies)."""
+    import copy
+    total = 1
+    out = copy.deepcopy(gt_instances)
+    for inst in out:
+        n = int(inst.instance_source.sum())
+        if n > 0:
+            assert int(inst.instance_source[-n:].sum()) == n
+            inst.instance_source[-n:] = torch.arange(total, total + n, device=inst.instance_source.device)
+        total += n
+    return out
+
+
+class ActiveSelector:
+    """The decision part of BSGAL's CustomRCNN.forward for ACTIVE_MODE 'paste_or_ori' / 'paste_or_zero'.
+
+    Loss comparison (ACTIVE_GRAD_COMPARE false; BS/configs/BSGAL/BSGAL_SwinL.yaml, :330-470, :560-600): from a snapshot of the
+    weights, take one trial SGD step (lr ACTIVE_LR) on the pasted batch, measure the loss of a held-out 'test' batch, restore;
+    the same for the original batch; train on the batch whose trial step left the lower test loss.
+    Gradient comparison (ACTIVE_GRAD_COMPARE true, :345-355, :447-460): gradient of the held-out batch's ACTIVE_LOSS terms
+    (optionally averaged into the bank), gradients of the pasted and of the original batch's training losses, cosine (or dot)
+    of each with the held-out gradient; the batch that agrees better wins.
+    `loss_fn(batched_inputs) -> loss dict` is the model's plain training forward.  Trial passes run with the backbone in
+    eval mode (no stochastic depth), as `no_grad_loss` (:780-939) does, and never signal the data-parallel reducer (each rank
+    decides for its own batch, like the reference, which calls the module below its DDP wrapper)."""
+
+    def __init__(self, model, arena, loss_fn, *, mode="paste_or_ori", compare="default", loss="cls", loss_update="all", lr=1e-4,
+                 use_optimizer=True, optim_mode="sgd", grad_compare=False, grad_norm=True, grad_save=False, grad_update="AVERAGE",
+                 seed=0, test_batchsize=4, output_dir=None, rank=0):
+        if mode not in ("paste_or_ori", "paste_or_zero"):
+            raise NotImplementedError("ACTIVE_MODE '%s': 'paste_or_ori' / 'paste_or_zero' are built (the forward-once modes of "
+                                      "BSGAL_R50.yaml need the per-paste loss split of BSGAL's box heads)" % mode)
+        if optim_mode != "sgd" or not use_optimizer:
+            raise NotImplementedError("trial update: ACTIVE_OPTIMIZER with ACTIVE_OPTIMIZER_MODE 'sgd' (the default) is built")
+        if grad_compare and mode != "paste_or_ori":
+            raise NotImplementedError("gradient comparison is defined for 'paste_or_ori'")
+        self.model, self.arena, self.loss_fn = model, arena, loss_fn
+        self.mode, self.compare, self.loss, self.loss_update, self.lr = mode, compare, loss, loss_update, lr
+        self.grad_compare, self.grad_save, self.seed, self.test_batchsize = grad_compare, grad_save, seed, test_batchsize
+        self.bank = GradBank(arena, update=grad_update, norm=grad_norm) if grad_compare else None
+        self.iter = self.count = self.paste_count = self.not_paste_count = 0
+        self.output_dir, self.rank = output_dir, str(rank)
+        self.last = {}
+
+    @classmethod
+    def from_config(cls, cfg, model, arena, loss_fn, rank=0):
+        m = cfg.MODEL
+        return cls(model, arena, loss_fn, mode=m.ACTIVE_MODE, compare=m.ACTIVE_COMPARE, loss=m.ACTIVE_LOSS,
+                   loss_update=m.ACTIVE_LOSS_UPDATE, lr=m.ACTIVE_LR, use_optimizer=m.ACTIVE_OPTIMIZER,
+                   optim_mode=m.ACTIVE_OPTIMIZER_MODE, grad_compare=m.ACTIVE_GRAD_COMPARE, grad_norm=m.ACTIVE_GRAD_NORM,
+                   grad_save=m.ACTIVE_GRAD_SAVE, grad_update=m.ACTIVE_GRAD_UPDATE, seed=m.ACTIVE_SEED,
+                   test_batchsize=m.ACTIVE_TEST_BATCHSIZE, output_dir=cfg.OUTPUT_DIR, rank=rank)
+
+    # ---- pieces
+    def _trial_losses(self, inputs, no_grad):
+        """no_grad_loss (:780-939): backbone in eval mode for the pass, the rest of the model as in training."""
+        bb = self.model.backbone
+        was = bb.training
+        bb.eval()
+        try:
+            if no_grad:
+                with torch.no_grad():
+                    return self.loss_fn(inputs)
+            return self.loss_fn(inputs)
+        finally:
+            bb.train(was)
+
+    def _reseed(self):
+        if self.seed != 0:
+            torch.manual_seed(self.seed + self.iter)
+
+    def _update_with_loss(self, losses):
+        """update_with_loss (:941-961) with torch.optim.SGD(lr): p -= lr * grad over the whole arena, shadow refreshed."""
+        total = loss_sum(losses, self.loss_update) if self.loss_update in ("all", "cls") else None
+        if total is None:
+            raise NotImplementedError(self.loss_update)
+        self.arena.zero_grad()
+        total.backward()
+        self.arena.p.add_(self.arena.g, alpha=-self.lr)
+        self.arena.sync_shadow()
+
+    def _split(self, batched_inputs):
+        keep = ("height", "width", "file_name", "image_id")
+        paste = [dict(x) for x in batched_inputs]
+        gt = reset_instance_source([x["instances"] for x in batched_inputs]) \
+            if all(x["instances"].has("instance_source") for x in batched_inputs) else [x["instances"] for x in batched_inputs]
+        for d, g in zip(paste, gt):
+            d["instances"] = g
+        ori = [{**{k: x[k] for k in keep if k in x}, "image": x["origin_image"], "instances": x["origin_instances"]}
+               for x in batched_inputs]
+        test = [{"image": x["test_image"], "instances": x["test_instances"]} for x in batched_inputs]
+        if self.test_batchsize > len(test) and all("test_image2" in x for x in batched_inputs):
+            test += [{"image": x["test_image2"], "instances": x["test_instances2"]} for x in batched_inputs]
+        return paste, ori, test[:self.test_batchsize] if self.test_batchsize < len(test) else test
+
+    # ---- the decision
+    def select(self, batched_inputs):
+        """-> (the batch to train on, paste?).  Leaves weights, shadow and the gradient arena exactly as it found them
+        (weights bit-identical; gradients zeroed, as `self.zero_grad()` does at :399,:468)."""
+        from ..layers.linear_ops import suspend_ready
+        paste_in, ori_in, test_in = self._split(batched_inputs)
+        info = {}
+        with suspend_ready():
+            if self.compare == "all":
+                decision = ">"
+            elif self.grad_compare:
+                ref = self.bank.loss_grad(fetchloss(self._trial_losses(test_in, False), [self.loss])
+                                          if self.loss != "all" else self._trial_losses(test_in, False))
+                self._reseed()
+                g_paste = self.bank.loss_grad(pop_loss_paste(self._trial_losses(paste_in, False))[0])
+                g_ori = self.bank.loss_grad(self._trial_losses(ori_in, False))
+                if self.grad_save:
+                    ref = self.bank.update(ref, self.iter)
+                sim_paste, sim_ori = self.bank.similarity(g_paste, ref), self.bank.similarity(g_ori, ref)
+                info = {"sim_paste_init": sim_paste, "sim_ori_init": sim_ori, "loss_dif": sim_paste - sim_ori}
+                decision = "<" if bool(sim_ori > sim_paste) else ">"          # :592-603
+            else:
+                snap = WeightSnapshot(self.arena)
+                init_test = self._trial_losses(test_in, True) if self.mode == "paste_or_zero" else None
+                self._reseed()
+                paste_train = pop_loss_paste(self._trial_losses(paste_in, False))[0]
+                self._update_with_loss(paste_train)
+                self._reseed()
+                paste_test = self._trial_losses(test_in, True)
+                snap.restore()
+                if self.mode == "paste_or_zero":
+                    old = init_test
+                else:
+                    ori_train = self._trial_losses(ori_in, False)
+                    self._update_with_loss(ori_train)
+                    self._reseed()
+                    old = self._trial_losses(test_in, True)
+                    snap.restore()
+                decision = compare_loss(old, paste_test, self.compare, self.loss, self.iter)
+                info = {"old_test_loss": old, "paste_test_loss": paste_test,
+                        "loss_dif": loss_sum(old, self.loss) - loss_sum(paste_test, self.loss)}
+            self.arena.zero_grad()
+        paste = decision != "<"
+        self.count += 1
+        self.paste_count += int(paste)
+        self.not_paste_count += int(not paste)
+        info["paste"] = paste
+        self.last = info
+        self._log(batched_inputs, paste, info)
+        self.iter += 1
+        return (paste_in if paste else ori_in), paste
+
+    def _log(self, batched_inputs, paste, info):
+        """The per-iteration record under OUTPUT_DIR/paste_source/rank_R/ (:606-641), one line per pasted file."""
+        if not self.output_dir or self.compare == "all":
+            return
+        import os
+        path = os.path.join(self.output_dir, "paste_source", "rank_" + self.rank, str(self.iter // 10000 + 1) + "0000.txt")
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        lists = [x.get("paste_filename_list", []) for x in batched_inputs]
+        n = sum(len(v) for v in lists)
+        dif = round(float(info["loss_dif"]), 4)
+        with open(path, "a") as f:
+            for i, names in enumerate(lists):
+                for name in names:
+                    f.write("%s select_class: %s paste: %d iter: %d loss_dif: %s paste_num: %d\n" % (
+                        name, batched_inputs[i].get("test_image_class"), int(paste), self.iter, dif, n))

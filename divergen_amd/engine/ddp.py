@@ -24,6 +24,8 @@ import os
 import torch
 import torch.distributed as dist
 
+from ..layers import linear_ops
+
 
 class ArenaReducer:
     def __init__(self, arena, bucket_bytes=64 << 20, process_group=None):
@@ -64,6 +66,8 @@ class ArenaReducer:
         b = self.bucket_of[i]
 
         def hook(_param):
+            if linear_ops._READY_SUSPENDED[0]:     # trial backward passes (hipGraph capture warm-ups, BSGAL's selection) are not
+                return                             # part of the training step: nothing to count, nothing to reduce
             self._got[i] += 1
             if self._expected is not None and self._got[i] == self._expected[i]:
                 self._pending[b] -= 1

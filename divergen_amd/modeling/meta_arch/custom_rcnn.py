@@ -103,6 +103,16 @@ class CustomRCNN(nn.Module):
     def forward(self, batched_inputs):
         if not self.training:
             return self.inference(batched_inputs)
+        # BSGAL (BS/bsgal/modeling/meta_arch/custom_rcnn.py:278-780): with INPUT.ACTIVE_SELECT the loader hands the pasted
+        # sample together with its un-pasted original and a held-out image; engine.bsgal.ActiveSelector (attached by the
+        # trainer once the parameter arena exists) decides which of the two batches this step trains on
+        sel = self.__dict__.get("active_selector")
+        if sel is not None and len(batched_inputs) and "origin_image" in batched_inputs[0]:
+            batched_inputs, _ = sel.select(batched_inputs)
+        return self.training_losses(batched_inputs)
+
+    def training_losses(self, batched_inputs):
+        """custom_rcnn.py:118-207 for the box-supervised path: the loss dict of one batch."""
         images = self.preprocess_image(batched_inputs)
         gt_instances = [x["instances"].to(self.device) for x in batched_inputs]
         features = self._features(images)

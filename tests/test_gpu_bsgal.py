@@ -121,3 +121,101 @@ def test_loss_grad_decision_and_weight_snapshot_on_a_model():
     snap.restore()
     for p, q in zip(net.parameters(), before):
         assert torch.equal(p, q)
+
+
+class _TinyModel(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.backbone = torch.nn.Linear(4, 1, bias=False)
+        with torch.no_grad():
+            self.backbone.weight.zero_()
+
+    def training_losses(self, batch):
+        x = torch.stack([d["image"] for d in batch])
+        y = torch.stack([d["instances"].target[0] for d in batch])
+        return {"loss_cls_stage0": ((self.backbone(x).squeeze(1) - y) ** 2).mean()}
+
+
+def test_gradient_comparison_rule_on_known_gradients():
+    """ACTIVE_GRAD_COMPARE (custom_rcnn.py:345-355, :447-460, :592-603) with gradients known in closed form: at w = 0 the
+    gradient of (w.x - y)^2 is -2 y x.  Held-out x = e0; a pasted batch along e0 has cosine 1 with it, an original batch along
+    e1 cosine 0 -> paste; swapped -> original.  The bank (ACTIVE_GRAD_SAVE, AVERAGE) holds the running mean of the held-out
+    gradients, weights untouched, gradients left zeroed."""
+    from divergen_amd.solver import FlatArena
+    from divergen_amd.structures import Instances
+    model = _TinyModel().to(DEV).train()
+    arena = FlatArena(model)
+    sel = BG.ActiveSelector(model, arena, model.training_losses, mode="paste_or_ori", grad_compare=True, grad_save=True,
+                            grad_update="AVERAGE", loss="cls")
+
+    def sample(vec, y=1.0):
+        inst = Instances((1, 1))
+        inst.target = torch.tensor([y], device=DEV)
+        return inst, torch.tensor(vec, device=DEV)
+
+    def batch(p, o):
+        pi, px = sample(p)
+        oi, ox = sample(o)
+        ti, tx = sample([1.0, 0.0, 0.0, 0.0])
+        return [{"image": px, "instances": pi, "origin_image": ox, "origin_instances": oi, "test_image": tx, "test_instances": ti}]
+    e0, e1 = [2.0, 0.0, 0.0, 0.0], [0.0, 3.0, 0.0, 0.0]
+    chosen, paste = sel.select(batch(e0, e1))
+    assert paste and abs(float(sel.last["sim_paste_init"]) - 1.0) < 1e-6 and abs(float(sel.last["sim_ori_init"])) < 1e-6
+    assert torch.equal(sel.bank.bank[:4], torch.tensor([-2.0, 0.0, 0.0, 0.0], device=DEV))       # iter 0: bank = 0*bank + 1*grad, grad = -2 y x
+    chosen, paste = sel.select(batch(e1, e0))
+    assert not paste and torch.equal(chosen[0]["image"], torch.tensor(e0, device=DEV))
+    assert float(arena.p.abs().sum()) == 0.0 and float(arena.g.abs().sum()) == 0.0
+    assert (sel.paste_count, sel.not_paste_count) == (1, 1)
+
+
+@pytest.mark.parametrize("grad_compare", [False, True])
+def test_active_selection_inside_the_training_forward(grad_compare):
+    """BSGAL's outer loop end to end on the registry-built model (Swin-T CenterNet2, 256 px, BS/configs/BSGAL/BSGAL_SwinL.yaml):
+    the forward receives the pasted sample with its original and a held-out image, ActiveSelector runs its trial passes on
+    the HIP path (backbone in eval mode; trial SGD step + restore, or three flattened gradients + bank + cosine), the weights
+    come back bit-identical, the gradient arena is clean, and the step then trains on the chosen batch."""
+    from divergen_amd.config import add_bsgal_config, get_cfg
+    from divergen_amd.data import synthetic_batch
+    from divergen_amd.modeling import build_model
+    from divergen_amd.solver import build_optimizer
+    from divergen_amd.utils.events import EventStorage
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = add_bsgal_config(get_cfg())
+    cfg.merge_from_file(os.path.join(root, "configs", "BSGAL", "BSGAL_SwinL.yaml"))
+    cfg.merge_from_list(["MODEL.SWIN.SIZE", "T", "MODEL.ACTIVE_GRAD_COMPARE", grad_compare, "MODEL.ACTIVE_GRAD_SAVE", grad_compare,
+                         "MODEL.ACTIVE_SEED", 3, "MODEL.ROI_BOX_HEAD.CAT_FREQ_PATH",
+                         os.path.join(root, "configs", "metadata", "lvis_v1_train_cat_info.json"), "OUTPUT_DIR", ""])
+    torch.manual_seed(42)
+    model = build_model(cfg).train()
+    opt = build_optimizer(cfg, model)
+    model.active_selector = BG.ActiveSelector.from_config(cfg, model, opt.arena, model.training_losses)
+    base = synthetic_batch(2, 256, cfg.MODEL.ROI_HEADS.NUM_CLASSES, device=DEV)
+    other = synthetic_batch(2, 256, cfg.MODEL.ROI_HEADS.NUM_CLASSES, seed=7, device=DEV)
+    held = synthetic_batch(2, 256, cfg.MODEL.ROI_HEADS.NUM_CLASSES, seed=99, device=DEV)
+    batch = []
+    for d, o, t in zip(base, other, held):
+        e = dict(d)
+        e["origin_image"], e["origin_instances"] = o["image"], o["instances"]
+        e["test_image"], e["test_instances"], e["test_image_class"] = t["image"], t["instances"], 0
+        e["paste_filename_list"] = []
+        batch.append(e)
+    w0 = opt.arena.p.clone()
+    with EventStorage(0):
+        opt.zero_grad()
+        losses = model(batch)
+        sel = model.active_selector
+        assert torch.equal(opt.arena.p, w0), "trial updates were not undone exactly"
+        assert sel.count == 1 and sel.paste_count + sel.not_paste_count == 1 and sel.iter == 1
+        if grad_compare:
+            sp, so = float(sel.last["sim_paste_init"]), float(sel.last["sim_ori_init"])
+            assert -1.0001 <= sp <= 1.0001 and -1.0001 <= so <= 1.0001 and sel.last["paste"] == (not so > sp)
+            assert float(sel.bank.bank.abs().sum()) > 0          # ACTIVE_GRAD_SAVE: the held-out gradient went into the bank
+        else:
+            old, new = sel.last["old_test_loss"], sel.last["paste_test_loss"]
+            assert set(old) == set(new) and all(np.isfinite(float(v)) for v in list(old.values()) + list(new.values()))
+            assert sel.last["paste"] == bool(BG.loss_sum(new, "cls") < BG.loss_sum(old, "cls"))
+        total = sum(losses.values())
+        total.backward()
+        assert float(opt.arena.g.abs().sum()) > 0
+        opt.step()
+    assert np.isfinite(float(total)) and not torch.equal(opt.arena.p, w0)

@@ -26,7 +26,7 @@ _enable_tuned_gemm()      # library-GEMM algorithm table for this model's shapes
 import torch  # noqa: E402
 
 from divergen_amd.checkpoint import DetectionCheckpointer, PeriodicCheckpointer  # noqa: E402
-from divergen_amd.config import add_centernet_config, add_divergen_config, get_cfg  # noqa: E402
+from divergen_amd.config import add_bsgal_config, add_centernet_config, add_divergen_config, get_cfg  # noqa: E402
 from divergen_amd.data import synthetic_batch  # noqa: E402
 from divergen_amd.engine import ArenaReducer, default_argument_parser, launch  # noqa: E402
 from divergen_amd.modeling import build_model  # noqa: E402
@@ -100,6 +100,11 @@ def do_train(cfg, model, resume=False):
     optimizer = build_optimizer(cfg, model)
     scheduler = build_lr_scheduler(cfg, optimizer)
     reducer = ArenaReducer(optimizer.arena)
+    if cfg.INPUT.get("ACTIVE_SELECT", False):
+        # BSGAL (BS/train_net.py:358-557 + the selection inside its CustomRCNN.forward): the model decides per step whether the
+        # pasted batch or its un-pasted original is trained on; needs the parameter arena, hence attached here
+        from divergen_amd.engine.bsgal import ActiveSelector
+        model.active_selector = ActiveSelector.from_config(cfg, model, optimizer.arena, model.training_losses, rank=comm.get_rank())
     kwargs = {"model_ema": ModelEma(model, optimizer)} if cfg.SOLVER.MODEL_EMA > 0 else {}
     checkpointer = DetectionCheckpointer(model, cfg.OUTPUT_DIR, optimizer=optimizer, scheduler=scheduler, **kwargs)
     if cfg.MODEL.WEIGHTS and not resume and not os.path.isfile(cfg.MODEL.WEIGHTS):
@@ -164,6 +169,7 @@ def setup(args):
     cfg = get_cfg()
     add_centernet_config(cfg)
     add_divergen_config(cfg)
+    add_bsgal_config(cfg)          # BS/configs/BSGAL/*.yaml (MODEL.ACTIVE_*, INPUT.ACTIVE_SELECT) load as well
     cfg.merge_from_file(args.config_file)
     cfg.merge_from_list(args.opts)
     if "/auto" in cfg.OUTPUT_DIR:

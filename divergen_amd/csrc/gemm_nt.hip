@@ -52,7 +52,9 @@ struct GemmP {
     GMap map;
     // implicit 3x3 convolution (pad 1, stride 1) over a zero-bordered NHWC image (dgx_conv3x3_*): K-tile kt of the A operand
     // is tap kt / conv_kc, channels 64 (kt % conv_kc) ..: the SAME rows shifted by (tap / 3) * conv_wp + tap % 3 pixels;
-    // rows are positions of the padded grid, the epilogue keeps the interior ones (cmap: n, h, w of the unpadded output)
+    // GEMM rows are the N*H*W OUTPUT pixels (cmap: n, h, w); row m reads the padded position of its pixel (per-lane offset), so
+    // no border rows are computed and M tiles exactly when N*H*W does (P3 level, 2 x 128 x 128 = 256 tiles of 128 rows: one round
+    // of the chip; over the padded grid it was 265 tiles = two rounds)
     int conv_kc, conv_wp;
     int cmap_n, cmap_h, cmap_w;
     int relu;
@@ -284,7 +286,14 @@ __global__ __launch_bounds__(512, MINW) void gemm_nt_kernel(GemmP P) {
 #pragma unroll
     for (int s = 0; s < NA; ++s) {
         const int m = m0 + 8 * (w + 8 * s) + rsub;
-        voffA[s] = m < P.M ? (uint32_t)(((int64_t)m * P.lda + lc * 8) * 2) : G_OOB;
+        int64_t arow = m;
+        if (P.conv_kc) {                           // output pixel (n, y, x) -> its position in the zero-bordered image
+            const int hw = P.cmap_h * P.cmap_w;
+            const int n = m / hw, r = m - n * hw;
+            const int y = r / P.cmap_w, x = r - y * P.cmap_w;
+            arow = ((int64_t)n * (P.cmap_h + 2) + y + 1) * P.conv_wp + x + 1;
+        }
+        voffA[s] = m < P.M ? (uint32_t)((arow * P.lda + lc * 8) * 2) : G_OOB;
     }
 #pragma unroll
     for (int s = 0; s < NB; ++s) {
@@ -292,7 +301,7 @@ __global__ __launch_bounds__(512, MINW) void gemm_nt_kernel(GemmP P) {
         voffB[s] = n < P.N ? (uint32_t)(((int64_t)n * P.ldb + lc * 8) * 2) : G_OOB;
     }
     const bool kt_ok = lc * 8 < ktail;             // this lane's chunk exists in the last K-tile
-    const u32x4 rA = g_rsrc(P.A, (uint32_t)(((int64_t)P.M + (P.conv_kc ? 2 * P.conv_wp + 2 : 0)) * P.lda * 2));
+    const u32x4 rA = g_rsrc(P.A, (uint32_t)((P.conv_kc ? (int64_t)P.cmap_n * (P.cmap_h + 2) * P.conv_wp + 2 * P.conv_wp + 2 : (int64_t)P.M) * P.lda * 2));
     const u32x4 rB = g_rsrc(P.B, (uint32_t)((int64_t)P.N * P.ldb * 2));
     const uint32_t lds0 = (uint32_t)(uintptr_t)(DGX_LDS unsigned char*)lds_raw;
     const uint32_t ldsw = __builtin_amdgcn_readfirstlane(lds0 + 1024u * w);
@@ -487,13 +496,6 @@ __global__ __launch_bounds__(512, MINW) void gemm_nt_kernel(GemmP P) {
         const int64_t tok = orow < P.M ? g_row_token(P.map, orow, b) : -1;
         rowtok[tid] = tok < 0 ? -1 : ((tok << 12) | (int64_t)b);
     }
-    if (P.cmap_h && tid < BM) {                    // padded-grid row -> row of the unpadded (n, h, w) output, -1 on the border
-        const int mp = m0 + tid, hp = P.cmap_h + 2, wp = P.cmap_w + 2;
-        const int n = mp / (hp * wp), r = mp - n * (hp * wp);
-        const int yp = r / wp, xp = r - yp * wp;
-        const bool in = mp < P.M && yp >= 1 && yp <= P.cmap_h && xp >= 1 && xp <= P.cmap_w;
-        rowtok[tid] = in ? (int64_t)(n * P.cmap_h + yp - 1) * P.cmap_w + xp - 1 : -1;
-    }
     __syncthreads();
     GCLK(3);
     constexpr int CPR = BN / 8;                    // 16-byte chunks per tile row
@@ -517,11 +519,6 @@ __global__ __launch_bounds__(512, MINW) void gemm_nt_kernel(GemmP P) {
             q.ok = rt >= 0;
             q.tok = rt >> 12;
             if (q.ok && P.scale) q.sc = P.scale[(int)(rt & 4095)];
-        }
-        if (P.cmap_h && q.ok) {
-            const int64_t rt = rowtok[q.row];
-            q.ok = rt >= 0;
-            q.gm = (int)rt;                        // destination row of the unpadded output
         }
         if (q.ok) g_epi_prefetch(P, q.gm, q.gn, q.tok, q.xa, q.xb);
     };
@@ -574,15 +571,7 @@ __global__ __launch_bounds__(256) void gemm_splitk_fold_kernel(GemmP P) {
             if (tok < 0) continue;
             if (P.scale) sc = P.scale[b];
         }
-        int om = gm;
-        if (P.cmap_h) {                            // implicit convolution: padded-grid row -> unpadded output row, border rows dropped
-            const int hp = P.cmap_h + 2, wp = P.cmap_w + 2;
-            const int n = gm / (hp * wp), r = gm - n * (hp * wp);
-            const int yp = r / wp, xp = r - yp * wp;
-            if (yp < 1 || yp > P.cmap_h || xp < 1 || xp > P.cmap_w) continue;
-            om = (n * P.cmap_h + yp - 1) * P.cmap_w + xp - 1;
-        }
-        g_epilogue_chunk(P, om, gn, g_pack8(v), tok, sc);
+        g_epilogue_chunk(P, gm, gn, g_pack8(v), tok, sc);
     }
 }
 
@@ -776,7 +765,7 @@ extern "C" int dgx_conv3x3_gemm(const void* xpad, const void* w, const void* bia
     memset((void*)&P, 0, sizeof(P));
     P.A = (const uint16_t*)xpad;                   // row 0 of the GEMM = padded position 0 minus (Wp + 1): the leading slack
     P.B = (const uint16_t*)w;
-    P.M = (int)Mp; P.N = Cout; P.K = 9 * Cin; P.lda = Cin; P.ldb = 9 * Cin;
+    P.M = N * H * W; P.N = Cout; P.K = 9 * Cin; P.lda = Cin; P.ldb = 9 * Cin;
     P.mode = bias ? DGX_EPI_BIAS : DGX_EPI_NONE;
     P.C = (uint16_t*)y; P.ldc = Cout;
     P.bias = (const uint16_t*)bias;

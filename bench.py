@@ -69,6 +69,38 @@ FAMILY_LABEL = {
 }
 
 
+def window_mhsa_object(objs, swin_cfg, size, batch, nsamp):
+    """north_star's window-MHSA figure (forward FLOP per image = sum over stages of depth * nW * (8 N C^2 + 4 N^2 C),
+    nW on the padded grid; x3 for forward + backward): LayerNorm'd windows -> QKV -> attention core -> proj.  The attention
+    kernels are timed as their own families; the QKV / proj GEMMs share the GEMM and weight-gradient families with the MLP
+    and the heads, so their time is ATTRIBUTED by FLOP share of the family (stated in the object) -- an estimate that is
+    exact when a family runs all its shapes at one rate."""
+    fam = {o["family"]: o for o in objs}
+    if not all(k in fam for k in ("gemm_nt", "wgrad", "attn_fwd", "attn_bwd")):
+        return None
+    ws, N = swin_cfg["ws"], swin_cfg["ws"] ** 2
+    gemm_f = core_f = 0.0                          # forward FLOP per image: QKV + proj GEMMs / QK^T + PV
+    for s, (d, nh) in enumerate(zip(swin_cfg["depths"], swin_cfg["num_heads"])):
+        C = swin_cfg["embed_dim"] * 2 ** s
+        H = size // 4 // 2 ** s
+        nW = (-(-H // ws)) ** 2
+        gemm_f += d * nW * 8.0 * N * C * C
+        core_f += d * nW * 4.0 * N * N * C
+    img = batch
+    mhsa_flops = 3.0 * (gemm_f + core_f) * img     # per step
+    t_core = fam["attn_fwd"]["total_ms_per_step"] + fam["attn_bwd"]["total_ms_per_step"]
+    share_g = 2.0 * gemm_f * img / max(fam["gemm_nt"]["flops_timed_per_step"], 1.0)      # forward + input gradient
+    share_w = 1.0 * gemm_f * img / max(fam["wgrad"]["flops_timed_per_step"], 1.0)        # weight gradient
+    t_gemm = share_g * fam["gemm_nt"]["total_ms_per_step"] + share_w * fam["wgrad"]["total_ms_per_step"]
+    t = t_core + t_gemm
+    tf = mhsa_flops / (t * 1e-3) / 1e12 if t > 0 else 0.0
+    return {"kernel": "window-MHSA = QKV GEMM + attention core + proj GEMM, forward + backward (derived)", "family": "window_mhsa",
+            "bound": "mfma", "achieved": tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": tf / 2500.0, "traffic": None,
+            "flops_per_step": mhsa_flops, "gflop_per_image_forward": (gemm_f + core_f) / 1e9, "total_ms_per_step": t,
+            "core_ms_per_step": t_core, "gemm_ms_per_step_attributed": t_gemm,
+            "attribution": "QKV/proj share of the gemm_nt family %.3f and of the wgrad family %.3f, by FLOP" % (share_g, share_w)}
+
+
 def _load_json(name):
     try:
         with open(os.path.join(ROOT, "profiles", name)) as f:
@@ -360,6 +392,13 @@ def main():
         objs.append(o)
     objs.sort(key=lambda o: -o["total_ms_per_step"])
     roof = objs[0] if objs else None
+    if objs:
+        from divergen_amd.modeling.backbone.swintransformer import size2config
+        c = size2config[a.swin]
+        mh = window_mhsa_object(objs, {"ws": c["window_size"], "depths": c["depth"], "num_heads": c["num_heads"], "embed_dim": c["embed_dim"]},
+                                a.size, a.batch, nsamp)
+        if mh is not None:
+            objs.append(mh)
 
     if rank == 0:
         line = {"metric": "images/sec (node) Swin-L CenterNet2 LVIS 1024px", "value": imgs / dt, "unit": "images/s",

@@ -284,3 +284,67 @@ def test_arena_reducer_world2_gloo():
         tot += ar.g
     assert torch.allclose(g_a, tot / 2, atol=1e-6)
     assert (g_a[-12:] == 0).all()           # the unused layer's bucket was flushed zero-filled
+
+
+def _ddp_trial_worker(rank, world, port, q):
+    """BSGAL's selection runs extra backward passes INSIDE a training step (trial passes, rank-local decisions): under
+    linear_ops.suspend_ready() they must neither count as gradient-ready signals nor launch a collective; the step's real
+    backward afterwards reduces exactly as without them."""
+    import os
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from divergen_amd.engine import ArenaReducer
+    from divergen_amd.layers.linear_ops import suspend_ready
+    from divergen_amd.solver import FlatArena
+    torch.manual_seed(11)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 6), torch.nn.ReLU(), torch.nn.Linear(6, 2))
+    ar = FlatArena(net)
+    red = ArenaReducer(ar, bucket_bytes=64)
+    red.broadcast_parameters()
+    x = torch.full((4, 6), 0.5 + rank)
+    out = []
+    for it in range(3):
+        ar.zero_grad()
+        if it >= 1 and rank == 0:                 # only ONE rank runs trial passes: a collective launched from them would hang
+            with suspend_ready():
+                for _ in range(2):
+                    net(x * 3.0).sum().backward()
+            ar.zero_grad()
+        net(x).sum().backward()
+        scale = red.finish()
+        out.append((ar.g.clone() * scale).numpy().copy())
+    q.put((rank, ar.p.numpy().copy(), out))
+    dist.destroy_process_group()
+
+
+def test_arena_reducer_ignores_trial_backward_passes_world2_gloo():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ddp_trial_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, p_a, g_a), (_, _, g_b) = res
+    from divergen_amd.solver import FlatArena
+    torch.manual_seed(11)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 6), torch.nn.ReLU(), torch.nn.Linear(6, 2))
+    ar = FlatArena(net)
+    ar.p.copy_(torch.from_numpy(p_a))
+    tot = torch.zeros_like(ar.g)
+    for r in range(2):
+        ar.zero_grad()
+        net(torch.full((4, 6), 0.5 + r)).sum().backward()
+        tot += ar.g
+    for it in range(3):
+        assert np.allclose(g_a[it], g_b[it], atol=1e-6), it
+        assert np.allclose(g_a[it], (tot / 2).numpy(), atol=1e-5), it

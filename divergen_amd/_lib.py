@@ -51,6 +51,11 @@ SIGNATURES = {
     "dgx_roi_pooler_fwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "dgx_roi_pooler_bwd": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "dgx_preprocess_patches": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
+    "dgx_stem_im2col7x7": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),
+    "dgx_affine_act_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_p]),
+    "dgx_affine_act_bwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_p]),
+    "dgx_maxpool3x3s2_fwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
+    "dgx_maxpool3x3s2_bwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     "dgx_mask_bce_workspace_floats": (c_i64, [c_i64]),
     "dgx_mask_bce": (c_i, [c_p, c_i64, c_i64, c_p, c_i64, c_p, c_p, c_p, c_i, c_p]),
     "dgx_prof_enable": (c_i, [c_i]),

@@ -499,6 +499,26 @@ int dgx_preprocess_patches(const uint8_t* img, int h, int w, const float* mean, 
                            int patch, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * ResNet-50 glue of the R50 configurations (DG/divergen/modeling/backbone/timm.py:27-151 over timm 0.4.9's ResNet /
+ * Bottleneck; DG/configs/Base-C2_L_R5021k_640b64_4x.yaml): everything between the GEMMs, channels-last bf16.
+ *   dgx_stem_im2col7x7   conv1 (7x7, stride 2, pad 3) as GEMM rows: x f32 (N,3,H,W) -> rows bf16 (N*Ho*Wo, 152),
+ *                        rows[r][c*49 + ky*7 + kx] (the order of conv1.weight.view(64, 147)), columns 147..151 zero;
+ *                        Ho = (H-1)/2 + 1.  The contraction runs on dgx_gemm_bf16_nt.
+ *   dgx_affine_act_fwd   FrozenBatchNorm2d (D2/layers/batch_norm.py: y = x*scale + shift with scale = weight*rsqrt(var+eps),
+ *                        shift = bias - mean*scale) + optional residual add + optional ReLU in one pass: x, residual, y bf16
+ *                        (rows, C), scale / shift f32 (C), C % 8 == 0.
+ *   dgx_affine_act_bwd   g = dy*[y > 0] (when relu), dx = g*scale, dres = g (NULL: not wanted; may alias dy).
+ *   dgx_maxpool3x3s2_*   nn.MaxPool2d(3, 2, 1) over (N,H,W,C) bf16; idx u8 (N,Ho,Wo,C) = winning tap (first maximum in scan
+ *                        order, NaN wins: ATen's rule); backward = gather, one writer per input pixel. */
+int dgx_stem_im2col7x7(const float* x_nchw, void* rows_bf16, int N, int H, int W, void* stream);
+int dgx_affine_act_fwd(const void* x, const float* scale, const float* shift, const void* residual, void* y, int64_t rows, int C,
+                       int relu, void* stream);
+int dgx_affine_act_bwd(const void* dy, const void* y, const float* scale, void* dx, void* dres, int64_t rows, int C, int relu,
+                       void* stream);
+int dgx_maxpool3x3s2_fwd(const void* x, void* y, void* idx_u8, int N, int H, int W, int C, void* stream);
+int dgx_maxpool3x3s2_bwd(const void* dy, const void* idx_u8, void* dx, int N, int H, int W, int C, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Mask loss of mask_rcnn_loss (D2/modeling/roi_heads/mask_head.py:35-110): F.binary_cross_entropy_with_logits(pred, gt,
  * reduction="mean"), its gradient and the accuracy / false-positive / false-negative counts in one pass.
  *   logits  (R, inner) f32 or bf16, row r at logits + r*row_stride (the class-specific branch hands a strided gather view)

@@ -129,3 +129,29 @@ def test_solver_trajectory(golden):
     for n in names:
         torch.testing.assert_close(p[n].detach(), T(g["final." + n]), atol=1e-6, rtol=1e-5)
         torch.testing.assert_close(ema[n], T(g["ema." + n]), atol=1e-7, rtol=1e-6)
+
+
+def test_resnet_oracle_frozen_bn_is_eval_batch_norm_and_r50_geometry():
+    """oracle/resnet.py (timm 0.4.9 ResNet-50 + D2 FrozenBatchNorm2d restated; no reference vectors exist for it): the frozen
+    norm equals torch's own batch_norm in eval mode, and the feature pyramid has ResNet-50's channels / strides with the stride
+    carried by the 3x3 convolution of a stage's first block."""
+    import torch
+    import torch.nn.functional as F
+    from oracle import resnet as OR
+    from divergen_amd.modeling.backbone.timm import TIMM
+    g = torch.Generator().manual_seed(1)
+    C = 16
+    sd = {"bn.weight": torch.rand(C, generator=g) + 0.5, "bn.bias": torch.randn(C, generator=g),
+          "bn.running_mean": torch.randn(C, generator=g), "bn.running_var": torch.rand(C, generator=g) + 0.5}
+    x = torch.randn(2, C, 5, 7, generator=g)
+    want = F.batch_norm(x, sd["bn.running_mean"], sd["bn.running_var"], sd["bn.weight"], sd["bn.bias"], False, 0.0, 1e-5)
+    assert torch.allclose(OR.frozen_bn(x, sd, "bn"), want, atol=1e-5, rtol=1e-5)
+    torch.manual_seed(0)
+    m = TIMM("resnet50_in21k", [3, 4, 5])
+    sd = {k[len("base."):]: v.float() for k, v in m.state_dict().items()}
+    assert sd["layer2.0.conv2.weight"].shape == (128, 128, 3, 3) and sd["layer2.0.downsample.0.weight"].shape == (512, 256, 1, 1)
+    assert "layer1.0.downsample.0.weight" in sd and "layer1.1.downsample.0.weight" not in sd
+    feats = OR.resnet50_features(torch.randn(1, 3, 70, 90, generator=g), sd)
+    assert [tuple(f.shape) for f in feats] == [(1, 512, 9, 12), (1, 1024, 5, 6), (1, 2048, 3, 3)]
+    sh = m.output_shape()
+    assert [(sh[k].channels, sh[k].stride) for k in ("layer3", "layer4", "layer5")] == [(512, 8), (1024, 16), (2048, 32)]

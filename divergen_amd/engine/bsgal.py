@@ -191,6 +191,8 @@ class ActiveSelector:
                                       "BSGAL_R50.yaml need the per-paste loss split of BSGAL's box heads)" % mode)
         if optim_mode != "sgd" or not use_optimizer:
             raise NotImplementedError("trial update: ACTIVE_OPTIMIZER with ACTIVE_OPTIMIZER_MODE 'sgd' (the default) is built")
+        if compare == "all":
+            raise NotImplementedError("ACTIVE_COMPARE 'all' (train on the pasted AND the original batch, :772-774) is not built")
         if grad_compare and mode != "paste_or_ori":
             raise NotImplementedError("gradient comparison is defined for 'paste_or_ori'")
         self.model, self.arena, self.loss_fn = model, arena, loss_fn
@@ -260,9 +262,7 @@ class ActiveSelector:
         paste_in, ori_in, test_in = self._split(batched_inputs)
         info = {}
         with suspend_ready():
-            if self.compare == "all":
-                decision = ">"
-            elif self.grad_compare:
+            if self.grad_compare:
                 ref = self.bank.loss_grad(fetchloss(self._trial_losses(test_in, False), [self.loss])
                                           if self.loss != "all" else self._trial_losses(test_in, False))
                 self._reseed()
@@ -306,7 +306,7 @@ class ActiveSelector:
 
     def _log(self, batched_inputs, paste, info):
         """The per-iteration record under OUTPUT_DIR/paste_source/rank_R/ (:606-641), one line per pasted file."""
-        if not self.output_dir or self.compare == "all":
+        if not self.output_dir:
             return
         import os
         path = os.path.join(self.output_dir, "paste_source", "rank_" + self.rank, str(self.iter // 10000 + 1) + "0000.txt")

@@ -108,7 +108,12 @@ class CustomRCNN(nn.Module):
         # trainer once the parameter arena exists) decides which of the two batches this step trains on
         sel = self.__dict__.get("active_selector")
         if sel is not None and len(batched_inputs) and "origin_image" in batched_inputs[0]:
-            batched_inputs, _ = sel.select(batched_inputs)
+            batched_inputs, paste = sel.select(batched_inputs)
+            losses = self.training_losses(batched_inputs)
+            losses = {k: v for k, v in losses.items() if "paste" not in k}          # :767 pop_loss_paste
+            if sel.mode == "paste_or_zero" and not paste:                           # :769-771: the step trains on nothing
+                losses = {k: v * 0.0 for k, v in losses.items()}
+            return losses
         return self.training_losses(batched_inputs)
 
     def training_losses(self, batched_inputs):

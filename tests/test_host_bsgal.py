@@ -124,6 +124,8 @@ def test_unbuilt_modes_say_so():
         BG.ActiveSelector(model, arena, model.training_losses, mode="paste_only")
     with pytest.raises(NotImplementedError):
         BG.ActiveSelector(model, arena, model.training_losses, optim_mode="adam")
+    with pytest.raises(NotImplementedError):
+        BG.ActiveSelector(model, arena, model.training_losses, compare="all")
 
 
 def test_bsgal_configs_load_and_mapper_adds_the_selection_inputs(tmp_path, monkeypatch):

@@ -180,7 +180,8 @@ def add_bsgal_config(cfg):
                  ("ACTIVE_PRED_SUP", "all"), ("ACTIVE_ONLY_GT_TRAIN", False), ("ACTIVE_ONLY_GT_TEST", False),
                  ("ACTIVE_GRAD_COMPARE", False), ("ACTIVE_GRAD_NORM", True), ("ACTIVE_GRAD_SAVE", False),
                  ("ACTIVE_GRAD_UPDATE", "AVERAGE"), ("ONLY_PASTE_SUP", False), ("ACTIVE_FORWARD_ONCE", False),
-                 ("ACTIVE_ONCE_MODE", "only_gt"), ("ACTIVE_EVAL", False), ("ACTIVE_DYNAMIC_THRES", 0.0), ("ACTIVE_TEST_BATCHSIZE", 4)):
+                 ("ACTIVE_ONCE_MODE", "only_gt"), ("ACTIVE_EVAL", False), ("ACTIVE_DYNAMIC_THRES", 0.0), ("ACTIVE_TEST_BATCHSIZE", 4),
+                 ("USE_XPASTE_BOX_LOSS", True), ("USE_XPASTE_MASK_LOSS", True)):
         if k not in m:
             m[k] = v
     for k, v in (("ACTIVE_SELECT", False), ("ACTIVE_SELECT_TYPE", "train"), ("SEPARATE_SYN", False), ("SEPERATE_SUP", False)):

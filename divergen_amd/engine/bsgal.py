@@ -185,16 +185,27 @@ class ActiveSelector:
 
     def __init__(self, model, arena, loss_fn, *, mode="paste_or_ori", compare="default", loss="cls", loss_update="all", lr=1e-4,
                  use_optimizer=True, optim_mode="sgd", grad_compare=False, grad_norm=True, grad_save=False, grad_update="AVERAGE",
-                 seed=0, test_batchsize=4, output_dir=None, rank=0):
-        if mode not in ("paste_or_ori", "paste_or_zero"):
-            raise NotImplementedError("ACTIVE_MODE '%s': 'paste_or_ori' / 'paste_or_zero' are built (the forward-once modes of "
-                                      "BSGAL_R50.yaml need the per-paste loss split of BSGAL's box heads)" % mode)
+                 seed=0, test_batchsize=4, output_dir=None, rank=0, forward_once=False, once_mode="only_gt", only_gt_test=False,
+                 max_iter=90000):
+        once = mode == "paste_only" and forward_once and grad_compare and once_mode.startswith("only_paste")
+        if mode not in ("paste_or_ori", "paste_or_zero") and not once:
+            raise NotImplementedError("ACTIVE_MODE '%s' (forward_once %s, once mode '%s'): built are 'paste_or_ori', 'paste_or_zero' "
+                                      "and 'paste_only' with ACTIVE_GRAD_COMPARE + ACTIVE_FORWARD_ONCE + ACTIVE_ONCE_MODE "
+                                      "'only_paste_*' (BSGAL_R50.yaml)" % (mode, forward_once, once_mode))
+        self.once_mode, self.only_gt_test, self.max_iter = once_mode, only_gt_test, max_iter
+        self.dynamic_queue = None
+        if once and "dynamic" in once_mode:                    # :127-136
+            if "linear" not in once_mode:
+                self.dynamic_queue = DynamicThreshold(buffer_size=1000, percentile=1 - float(once_mode.split("_")[-1]))
+            else:                                              # "only_paste_dynamic_linear_0.3_0.5"
+                self.start_rate, self.end_rate = float(once_mode.split("_")[-2]), float(once_mode.split("_")[-1])
+                self.dynamic_queue = DynamicThreshold(buffer_size=1000, percentile=1 - self.start_rate)
         if optim_mode != "sgd" or not use_optimizer:
             raise NotImplementedError("trial update: ACTIVE_OPTIMIZER with ACTIVE_OPTIMIZER_MODE 'sgd' (the default) is built")
         if compare == "all":
             raise NotImplementedError("ACTIVE_COMPARE 'all' (train on the pasted AND the original batch, :772-774) is not built")
-        if grad_compare and mode != "paste_or_ori":
-            raise NotImplementedError("gradient comparison is defined for 'paste_or_ori'")
+        if grad_compare and mode == "paste_or_zero":
+            raise NotImplementedError("gradient comparison is defined for 'paste_or_ori' / 'paste_only'")
         self.model, self.arena, self.loss_fn = model, arena, loss_fn
         self.mode, self.compare, self.loss, self.loss_update, self.lr = mode, compare, loss, loss_update, lr
         self.grad_compare, self.grad_save, self.seed, self.test_batchsize = grad_compare, grad_save, seed, test_batchsize
@@ -210,21 +221,38 @@ class ActiveSelector:
                    loss_update=m.ACTIVE_LOSS_UPDATE, lr=m.ACTIVE_LR, use_optimizer=m.ACTIVE_OPTIMIZER,
                    optim_mode=m.ACTIVE_OPTIMIZER_MODE, grad_compare=m.ACTIVE_GRAD_COMPARE, grad_norm=m.ACTIVE_GRAD_NORM,
                    grad_save=m.ACTIVE_GRAD_SAVE, grad_update=m.ACTIVE_GRAD_UPDATE, seed=m.ACTIVE_SEED,
-                   test_batchsize=m.ACTIVE_TEST_BATCHSIZE, output_dir=cfg.OUTPUT_DIR, rank=rank)
+                   test_batchsize=m.ACTIVE_TEST_BATCHSIZE, output_dir=cfg.OUTPUT_DIR, rank=rank,
+                   forward_once=m.ACTIVE_FORWARD_ONCE, once_mode=m.ACTIVE_ONCE_MODE, only_gt_test=m.ACTIVE_ONLY_GT_TEST,
+                   max_iter=cfg.SOLVER.MAX_ITER)
 
     # ---- pieces
-    def _trial_losses(self, inputs, no_grad):
-        """no_grad_loss (:780-939): backbone in eval mode for the pass, the rest of the model as in training."""
+    def _trial_losses(self, inputs, no_grad, for_test=False):
+        """no_grad_loss (:780-939): backbone in eval mode for the pass, the rest of the model as in training; the held-out pass
+        (for_test) runs over ground-truth proposals only when ACTIVE_ONLY_GT_TEST is set (:898-905)."""
         bb = self.model.backbone
         was = bb.training
         bb.eval()
+        # :816-829 every no-grad pass, :892-905 the held-out pass with gradients unless an image has no ground truth at all
+        only_gt = self.only_gt_test and (no_grad or (for_test and all(len(d["instances"]) > 0 for d in inputs)))
+        kw = {"only_gt_proposals": True} if only_gt else {}
         try:
             if no_grad:
                 with torch.no_grad():
-                    return self.loss_fn(inputs)
-            return self.loss_fn(inputs)
+                    return self.loss_fn(inputs, **kw)
+            return self.loss_fn(inputs, **kw)
         finally:
             bb.train(was)
+
+    def _once_threshold(self, sim_paste):
+        """:526-541 -- the stand-in for the original batch's similarity in the forward-once modes: a constant taken from the
+        mode string ('only_paste_-0.05'), or a running percentile of the similarities seen so far."""
+        if self.dynamic_queue is None:
+            return float(self.once_mode.split("_")[-1])
+        if "linear" in self.once_mode:
+            self.dynamic_queue.set_percentile(1 - (self.start_rate + (self.end_rate - self.start_rate) * self.iter / self.max_iter))
+        thr = self.dynamic_queue.get_threshold()
+        self.dynamic_queue.add_score(float(sim_paste))
+        return thr
 
     def _reseed(self):
         if self.seed != 0:
@@ -262,9 +290,25 @@ class ActiveSelector:
         paste_in, ori_in, test_in = self._split(batched_inputs)
         info = {}
         with suspend_ready():
-            if self.grad_compare:
-                ref = self.bank.loss_grad(fetchloss(self._trial_losses(test_in, False), [self.loss])
-                                          if self.loss != "all" else self._trial_losses(test_in, False))
+            if self.mode == "paste_only":
+                # forward once (:345-355, :471-541, :592-603): held-out gradient (into the bank), then ONE pass over the pasted
+                # batch whose per-paste classification terms (`loss_paste_ins_stage*`) are differentiated on their own
+                tl = self._trial_losses(test_in, False, for_test=True)
+                ref = self.bank.loss_grad(fetchloss(tl, [self.loss]) if self.loss != "all" else tl)
+                if self.grad_save:
+                    ref = self.bank.update(ref, self.iter)
+                self._reseed()
+                only_paste = fetchloss(self._trial_losses(paste_in, False), ["_paste_"])
+                if not only_paste:
+                    raise RuntimeError("ACTIVE_ONCE_MODE '%s' needs the per-paste loss terms (MODEL.ONLY_PASTE_SUP) and "
+                                       "instance_source on the pasted batch" % self.once_mode)
+                sim_paste = self.bank.similarity(ref, self.bank.loss_grad(only_paste))
+                sim_ori = self._once_threshold(sim_paste)
+                info = {"sim_paste_init": sim_paste, "sim_ori_init": sim_ori, "loss_dif": sim_paste - sim_ori}
+                decision = "<" if bool(sim_ori > sim_paste) else ">"
+            elif self.grad_compare:
+                tl = self._trial_losses(test_in, False, for_test=True)
+                ref = self.bank.loss_grad(fetchloss(tl, [self.loss]) if self.loss != "all" else tl)
                 self._reseed()
                 g_paste = self.bank.loss_grad(pop_loss_paste(self._trial_losses(paste_in, False))[0])
                 g_ori = self.bank.loss_grad(self._trial_losses(ori_in, False))
@@ -275,7 +319,7 @@ class ActiveSelector:
                 decision = "<" if bool(sim_ori > sim_paste) else ">"          # :592-603
             else:
                 snap = WeightSnapshot(self.arena)
-                init_test = self._trial_losses(test_in, True) if self.mode == "paste_or_zero" else None
+                init_test = self._trial_losses(test_in, True, for_test=True) if self.mode == "paste_or_zero" else None
                 self._reseed()
                 paste_train = pop_loss_paste(self._trial_losses(paste_in, False))[0]
                 self._update_with_loss(paste_train)

@@ -116,7 +116,7 @@ class CustomRCNN(nn.Module):
             return losses
         return self.training_losses(batched_inputs)
 
-    def training_losses(self, batched_inputs):
+    def training_losses(self, batched_inputs, only_gt_proposals=False):
         """custom_rcnn.py:118-207 for the box-supervised path: the loss dict of one batch."""
         images = self.preprocess_image(batched_inputs)
         gt_instances = [x["instances"].to(self.device) for x in batched_inputs]
@@ -124,7 +124,8 @@ class CustomRCNN(nn.Module):
         heads_amp = self.fp16 and not self.heads_fp32
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=heads_amp):
             proposals, proposal_losses = self.proposal_generator(images, features, gt_instances)
-            proposals, detector_losses = self.roi_heads(images, features, proposals, gt_instances, ann_type="box")
+            proposals, detector_losses = self.roi_heads(images, features, proposals, gt_instances, ann_type="box",
+                                                        only_gt_proposals=only_gt_proposals)
         losses = {}
         losses.update(detector_losses)
         losses.update(proposal_losses)

@@ -157,7 +157,7 @@ class DeticFastRCNNOutputLayers(nn.Module):
                  test_topk_per_image=100, cls_agnostic_bbox_reg=False, smooth_l1_beta=0.0, box_reg_loss_type="smooth_l1",
                  loss_weight=1.0, mult_proposal_score=False, use_sigmoid_ce=False, use_fed_loss=False,
                  ignore_zero_cats=False, fed_loss_num_cat=50, prior_prob=0.01, cat_freq_path="",
-                 fed_loss_freq_weight=0.5, use_zeroshot_cls=False, divergen_box_loss=True, **unused):
+                 fed_loss_freq_weight=0.5, use_zeroshot_cls=False, divergen_box_loss=True, only_paste_sup=False, **unused):
         super().__init__()
         if use_zeroshot_cls or box_reg_loss_type != "smooth_l1":
             raise NotImplementedError("USE_ZEROSHOT_CLS / non-smooth_l1 box losses are outside the shipped configs")
@@ -173,6 +173,9 @@ class DeticFastRCNNOutputLayers(nn.Module):
         self.test_score_thresh, self.test_nms_thresh, self.test_topk_per_image = test_score_thresh, test_nms_thresh, test_topk_per_image
         self.mult_proposal_score, self.use_sigmoid_ce, self.use_fed_loss = mult_proposal_score, use_sigmoid_ce, use_fed_loss
         self.ignore_zero_cats, self.fed_loss_num_cat, self.divergen_box_loss = ignore_zero_cats, fed_loss_num_cat, divergen_box_loss
+        # BSGAL (BS/bsgal/modeling/roi_heads/detic_fast_rcnn.py:222-247): also report the classification loss of the rows matched
+        # to pasted / to original instances (`loss_paste_ins`, `loss_nopaste_ins`), the terms its gradient comparison differentiates
+        self.only_paste_sup = only_paste_sup
         if use_sigmoid_ce:
             nn.init.constant_(self.cls_score.bias, -math.log((1 - prior_prob) / prior_prob))
         if use_fed_loss or ignore_zero_cats:
@@ -195,7 +198,8 @@ class DeticFastRCNNOutputLayers(nn.Module):
                     use_sigmoid_ce=h.USE_SIGMOID_CE, use_fed_loss=h.USE_FED_LOSS, ignore_zero_cats=h.IGNORE_ZERO_CATS,
                     fed_loss_num_cat=h.FED_LOSS_NUM_CAT, prior_prob=h.PRIOR_PROB, cat_freq_path=h.CAT_FREQ_PATH,
                     fed_loss_freq_weight=h.FED_LOSS_FREQ_WEIGHT, use_zeroshot_cls=h.USE_ZEROSHOT_CLS,
-                    divergen_box_loss=cfg.MODEL.USE_DIVERGEN_BOX_LOSS)
+                    divergen_box_loss=cfg.MODEL.USE_DIVERGEN_BOX_LOSS and cfg.MODEL.get("USE_XPASTE_BOX_LOSS", True),
+                    only_paste_sup=cfg.MODEL.get("ONLY_PASTE_SUP", False))
 
     def forward(self, x, classifier_info=(None, None, None)):
         if x.dim() > 2:
@@ -216,28 +220,51 @@ class DeticFastRCNNOutputLayers(nn.Module):
         gt_classes = torch.cat([p.gt_classes for p in proposals], dim=0)
         prop = torch.cat([p.proposal_boxes.tensor for p in proposals], dim=0)
         gtb = torch.cat([(p.gt_boxes if p.has("gt_boxes") else p.proposal_boxes).tensor for p in proposals], dim=0)
-        src = None if self.divergen_box_loss else torch.cat([p.instance_source for p in proposals if len(p)], dim=0)
+        has_src = all(p.has("instance_source") for p in proposals)
+        src = torch.cat([p.instance_source for p in proposals if len(p)], dim=0) if has_src else None
         return self.losses_from_tensors(scores, deltas, gt_classes, prop, gtb, src)
 
-    def losses_from_tensors(self, scores, deltas, gt_classes, prop, gtb, src):
-        """One kernel pair for loss_cls + loss_box_reg + logging statistics (sigmoid CE, class-agnostic L1);
-        rows with gt_classes < 0 are ignored.  `src` (instance_source) is used only when the DiverGen box loss is off."""
-        if self.divergen_box_loss:
-            src = None
-        C = scores.shape[1] - 1
+    def _class_weight(self, gt_classes, C):
+        """The (C,) weight of the sigmoid CE: federated class sample x zero-frequency mask (None = all ones)."""
         w = None
         if self.use_fed_loss and self.freq_weight is not None:
             w = fed_loss_class_mask(gt_classes, self.fed_loss_num_cat, C, self.freq_weight)[:C].float()
         if self.ignore_zero_cats and self.freq_weight is not None:
             z = (self.freq_weight.view(-1) > 1e-4).float()
             w = z if w is None else w * z
+        return w
+
+    def paste_split(self, scores, gt_classes, w, src):
+        """sigmoid_cross_entropy_loss_with_fed (:431-470): the weighted BCE summed over the rows of pasted (source >= 1) and of
+        original (source == 0) instances, both divided by the number of rows B (rows labelled -1 = padding are not rows)."""
+        C = scores.shape[1] - 1
+        valid = gt_classes >= 0
+        B = valid.sum().clamp(min=1).float()
+        target = torch.nn.functional.one_hot(gt_classes.clamp(min=0), C + 1)[:, :C].to(torch.float32)
+        ce = F.binary_cross_entropy_with_logits(scores[:, :C].float(), target, reduction="none")
+        if w is not None:
+            ce = ce * w.view(1, C)
+        row = ce.sum(1) * valid
+        return (row * (src >= 1)).sum() / B, (row * (src == 0)).sum() / B
+
+    def losses_from_tensors(self, scores, deltas, gt_classes, prop, gtb, src):
+        """One kernel pair for loss_cls + loss_box_reg + logging statistics (sigmoid CE, class-agnostic L1);
+        rows with gt_classes < 0 are ignored.  `src` (instance_source) is used only when the DiverGen box loss is off."""
+        paste_src = src
+        if self.divergen_box_loss:
+            src = None
+        C = scores.shape[1] - 1
+        w = self._class_weight(gt_classes, C)
         with torch.autocast("cuda", enabled=False):
             loss_cls, loss_box, out = _DeticLosses.apply(scores, deltas, gt_classes, w, prop, gtb, src, self.box2box_transform.weights)
         st = get_event_storage()
         st.put_scalar("fast_rcnn/cls_accuracy", out[11])
         st.put_scalar("fast_rcnn/fg_cls_accuracy", out[12])
         st.put_scalar("fast_rcnn/false_negative", out[13])
-        return {"loss_cls": loss_cls, "loss_box_reg": loss_box}
+        losses = {"loss_cls": loss_cls, "loss_box_reg": loss_box}
+        if self.only_paste_sup and paste_src is not None:
+            losses["loss_paste_ins"], losses["loss_nopaste_ins"] = self.paste_split(scores, gt_classes, w, paste_src)
+        return losses
 
     def losses(self, predictions, proposals, classifier_info=(None, None, None)):
         if len(proposals) and self.fused_ok(predictions[0], predictions[1]):
@@ -250,30 +277,56 @@ class DeticFastRCNNOutputLayers(nn.Module):
             gtb = torch.cat([(p.gt_boxes if p.has("gt_boxes") else p.proposal_boxes).tensor for p in proposals], dim=0)
         else:
             prop = gtb = torch.empty((0, 4), device=deltas.device)
-        loss_cls = self.sigmoid_cross_entropy_loss(scores, gt_classes) if self.use_sigmoid_ce else \
+        w = self._class_weight(gt_classes, scores.shape[1] - 1) if (self.use_sigmoid_ce and scores.numel()) else None
+        loss_cls = self.sigmoid_cross_entropy_loss(scores, gt_classes, w) if self.use_sigmoid_ce else \
             F.cross_entropy(scores, gt_classes, reduction="mean")
-        src = None
-        if not self.divergen_box_loss:
-            src = torch.cat([p.instance_source for p in proposals if len(p)], dim=0)
+        has_src = len(proposals) > 0 and all(p.has("instance_source") for p in proposals)
+        paste_src = torch.cat([p.instance_source for p in proposals if len(p)], dim=0) if has_src else None
+        src = None if self.divergen_box_loss else paste_src
+        losses = {"loss_cls": loss_cls, "loss_box_reg": self.box_reg_loss(prop, gtb, deltas, gt_classes, src)}
+        if self.only_paste_sup and paste_src is not None and self.use_sigmoid_ce and scores.numel():
+            losses["loss_paste_ins"], losses["loss_nopaste_ins"] = self.paste_split(scores, gt_classes, w, paste_src)
+        return losses
+
+    def no_grad_losses(self, predictions, proposals, classifier_info=(None, None, None)):
+        """BS detic_fast_rcnn.py:268-352 for the sigmoid-CE recipe: the losses of the held-out pass over ground-truth
+        proposals -- classification WITHOUT the federated / zero-frequency class weights (:393-430), box regression as usual.
+        (The per-paste loss matrix it can also return belongs to ACTIVE_ONLY_GT_TRAIN, which no shipped configuration sets.)"""
+        assert self.use_sigmoid_ce
+        scores, deltas = predictions[0].float(), predictions[1].float()
+        gt_classes = torch.cat([p.gt_classes for p in proposals], dim=0) if len(proposals) else torch.empty(0)
+        _log_classification_stats(scores, gt_classes)
+        prop = torch.cat([p.proposal_boxes.tensor for p in proposals], dim=0)
+        gtb = torch.cat([(p.gt_boxes if p.has("gt_boxes") else p.proposal_boxes).tensor for p in proposals], dim=0)
+        loss_cls = self.sigmoid_cross_entropy_loss(scores, gt_classes, "none")
+        has_src = all(p.has("instance_source") for p in proposals)
+        src = None if (self.divergen_box_loss or not has_src) else torch.cat([p.instance_source for p in proposals if len(p)], dim=0)
         return {"loss_cls": loss_cls, "loss_box_reg": self.box_reg_loss(prop, gtb, deltas, gt_classes, src)}
 
-    def sigmoid_cross_entropy_loss(self, logits, gt_classes):
+    def sigmoid_cross_entropy_loss(self, logits, gt_classes, weight=None):
+        """weight: a (C,) class weight computed by the caller (`_class_weight`), "none" = unweighted (BSGAL's no-fed form),
+        None = draw it here (the reference's own call pattern)."""
         if logits.numel() == 0:
             return logits.new_zeros([1])[0]
         B, C = logits.shape[0], logits.shape[1] - 1
         target = logits.new_zeros(B, C + 1)
         target[torch.arange(B, device=logits.device), gt_classes] = 1
         target = target[:, :C]
-        weight = 1
-        if self.use_fed_loss and self.freq_weight is not None:
-            appeared = get_fed_loss_inds(gt_classes, self.fed_loss_num_cat, C, self.freq_weight)
-            m = appeared.new_zeros(C + 1)
-            m[appeared] = 1
-            weight = weight * m[:C].view(1, C).float()
-        if self.ignore_zero_cats and self.freq_weight is not None:
-            weight = weight * (self.freq_weight.view(-1) > 1e-4).float().view(1, C)
+        if isinstance(weight, str):
+            w = 1
+        elif weight is not None:
+            w = weight.view(1, C)
+        else:
+            w = 1
+            if self.use_fed_loss and self.freq_weight is not None:
+                appeared = get_fed_loss_inds(gt_classes, self.fed_loss_num_cat, C, self.freq_weight)
+                m = appeared.new_zeros(C + 1)
+                m[appeared] = 1
+                w = w * m[:C].view(1, C).float()
+            if self.ignore_zero_cats and self.freq_weight is not None:
+                w = w * (self.freq_weight.view(-1) > 1e-4).float().view(1, C)
         ce = F.binary_cross_entropy_with_logits(logits[:, :-1], target, reduction="none")
-        return torch.sum(ce * weight) / B
+        return torch.sum(ce * w) / B
 
     def box_reg_loss(self, prop, gtb, deltas, gt_classes, instance_source=None):
         fg = ((gt_classes >= 0) & (gt_classes < self.num_classes)).nonzero().squeeze(1)

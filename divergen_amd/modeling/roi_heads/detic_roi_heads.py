@@ -124,7 +124,7 @@ class DeticCascadeROIHeads(nn.Module):
                    box_pooler=ROIPooler(bh.POOLER_RESOLUTION, scales, bh.POOLER_SAMPLING_RATIO, bh.POOLER_TYPE),
                    box_heads=heads, box_predictors=preds, cascade_ious=ch.IOUS,
                    mult_proposal_score=bh.MULT_PROPOSAL_SCORE, mask_weight=rh.MASK_WEIGHT,
-                   divergen_mask_loss=cfg.MODEL.USE_DIVERGEN_MASK_LOSS, one_class_per_proposal=rh.ONE_CLASS_PER_PROPOSAL)
+                   divergen_mask_loss=cfg.MODEL.USE_DIVERGEN_MASK_LOSS and cfg.MODEL.get("USE_XPASTE_MASK_LOSS", True), one_class_per_proposal=rh.ONE_CLASS_PER_PROPOSAL)
         if cfg.MODEL.MASK_ON:
             mh = cfg.MODEL.ROI_MASK_HEAD
             ret.update(mask_in_features=in_features,
@@ -134,12 +134,28 @@ class DeticCascadeROIHeads(nn.Module):
 
     # ------------------------------------------------------------ sampling / matching
     @torch.no_grad()
-    def label_and_sample_proposals(self, proposals, targets):
+    def label_and_sample_proposals(self, proposals, targets, only_gt_proposals=False):
+        """only_gt_proposals (BS/bsgal/modeling/roi_heads/detic_roi_heads.py:334-358, BSGAL's held-out pass): an image WITH
+        ground truth keeps exactly its ground-truth boxes as proposals (the rows appended last), labelled with their own
+        classes; an image without any is sampled as usual."""
         if self.proposal_append_gt:
             proposals = add_ground_truth_to_proposals(targets, proposals)
         out, nfg, nbg = [], [], []
         for p, t in zip(proposals, targets):
             has_gt = len(t) > 0
+            if only_gt_proposals and has_gt:
+                assert self.proposal_append_gt
+                p = p[len(p) - len(t):]
+                if p.has("proposal_valid"):
+                    p.remove("proposal_valid")
+                p.gt_classes = t.gt_classes
+                for name, val in t.get_fields().items():
+                    if (name.startswith("gt_") or name == "instance_source") and not p.has(name):
+                        p.set(name, val)
+                nfg.append(torch.tensor(float(len(t)), device=t.gt_classes.device))
+                nbg.append(torch.zeros((), device=t.gt_classes.device))
+                out.append(p)
+                continue
             midx, mlab = iou_match(t.gt_boxes.tensor, p.proposal_boxes.tensor, self.cascade_ious[0])
             if has_gt:
                 gtc = t.gt_classes[midx]
@@ -271,8 +287,8 @@ class DeticCascadeROIHeads(nn.Module):
             losses.update({n + "_stage{}".format(k): v for n, v in sl.items()})
         return losses
 
-    def _forward_box(self, features, proposals, targets=None):
-        if (self.training and targets is not None and len(proposals) and sum(len(p) for p in proposals) > 0
+    def _forward_box(self, features, proposals, targets=None, only_gt_proposals=False):
+        if (self.training and not only_gt_proposals and targets is not None and len(proposals) and sum(len(p) for p in proposals) > 0
                 and proposals[0].proposal_boxes.tensor.is_cuda and all(bp.fused_supported for bp in self.box_predictor)):
             return self._forward_box_train(features, proposals, targets)
         if (not self.training) and self.mult_proposal_score:
@@ -293,7 +309,7 @@ class DeticCascadeROIHeads(nn.Module):
             st = get_event_storage()
             for stage, (pred, preds, props) in enumerate(outs):
                 with st.name_scope("stage{}".format(stage)):
-                    sl = pred.losses(preds, props)
+                    sl = pred.no_grad_losses(preds, props) if only_gt_proposals else pred.losses(preds, props)
                 losses.update({k + "_stage{}".format(stage): v for k, v in sl.items()})
             return losses
         scores_per_stage = [h[0].predict_probs(h[1], h[2]) for h in outs]
@@ -319,10 +335,15 @@ class DeticCascadeROIHeads(nn.Module):
         boxes = [x.proposal_boxes if self.training else x.pred_boxes for x in instances]
         return self.mask_head(self.mask_pooler(feats, boxes, pad_to=64 if self.training else 0), instances)
 
-    def forward(self, images, features, proposals, targets=None, ann_type="box", **kwargs):
+    def forward(self, images, features, proposals, targets=None, ann_type="box", only_gt_proposals=False, **kwargs):
         if self.training:
             assert ann_type == "box", "image-label / caption co-training is outside the shipped configs"
-            proposals = self.label_and_sample_proposals(proposals, targets)
+            proposals = self.label_and_sample_proposals(proposals, targets, only_gt_proposals)
+            if only_gt_proposals:
+                losses = self._forward_box(features, proposals, targets, only_gt_proposals=True)
+                if targets[0].has("gt_masks"):
+                    losses.update({k: v * self.mask_weight for k, v in self._forward_mask(features, proposals).items()})
+                return proposals, losses
             dev = proposals[0].objectness_logits.device
             if _MASK_SIDE_STREAM and self.mask_on and targets[0].has("gt_masks") and dev.type == "cuda" \
                     and not torch.cuda.is_current_stream_capturing():

@@ -219,3 +219,91 @@ def test_active_selection_inside_the_training_forward(grad_compare):
         assert float(opt.arena.g.abs().sum()) > 0
         opt.step()
     assert np.isfinite(float(total)) and not torch.equal(opt.arena.p, w0)
+
+
+def test_paste_split_and_no_fed_losses_follow_the_reference_formulas():
+    """BS detic_fast_rcnn.py:431-470 (`sigmoid_cross_entropy_loss_with_fed`: weighted BCE summed over pasted / original rows, both
+    over B) and :393-430 (no-fed form) restated with plain torch on the same logits and the same class weights."""
+    from divergen_amd.modeling import ShapeSpec
+    from divergen_amd.modeling.box_regression import Box2BoxTransform
+    from divergen_amd.modeling.roi_heads.detic_fast_rcnn import DeticFastRCNNOutputLayers
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(2)
+    C, R = 37, 64
+    pred = DeticFastRCNNOutputLayers(ShapeSpec(channels=32), box2box_transform=Box2BoxTransform(weights=(10, 10, 5, 5)), num_classes=C,
+                                     cls_agnostic_bbox_reg=True, use_sigmoid_ce=True, only_paste_sup=True).to(DEV)
+    scores = torch.randn(R, C + 1, generator=g).to(DEV)
+    gt = torch.randint(0, C + 1, (R,), generator=g).to(DEV)
+    gt[-5:] = -1                                           # padding rows of a fixed-length proposal list
+    src = torch.randint(0, 4, (R,), generator=g).to(DEV)
+    w = torch.rand(C, generator=g).to(DEV)
+    lp, lo = pred.paste_split(scores, gt, w, src)
+    v = gt >= 0
+    s, t, sr = scores[v], gt[v], src[v]
+    target = torch.zeros(len(t), C + 1, device=DEV)
+    target[torch.arange(len(t)), t] = 1
+    ce = F.binary_cross_entropy_with_logits(s[:, :-1], target[:, :C], reduction="none") * w.view(1, C)
+    B = len(t)
+    assert torch.allclose(lp, ce[sr >= 1].sum() / B, rtol=1e-5) and torch.allclose(lo, ce[sr == 0].sum() / B, rtol=1e-5)
+    assert torch.allclose(lp + lo, ce.sum() / B, rtol=1e-5)          # the two parts make up loss_cls
+    nf = pred.sigmoid_cross_entropy_loss(s, t, "none")
+    assert torch.allclose(nf, F.binary_cross_entropy_with_logits(s[:, :-1], target[:, :C], reduction="none").sum() / B, rtol=1e-5)
+
+
+def test_bsgal_r50_forward_once_selection_end_to_end():
+    """BS/configs/BSGAL/BSGAL_R50.yaml through the registry (R50-timm FPN, ONLY_PASTE_SUP box heads, ACTIVE_MODE paste_only +
+    gradient comparison + forward once + 'only_paste_-0.05', ACTIVE_ONLY_GT_TEST, bank MOMENTUM0.1): the held-out pass runs over
+    ground-truth proposals only, the per-paste terms of the pasted batch are differentiated on their own, the decision is the
+    reference's `threshold > similarity -> original`, weights and gradient arena come back clean, the returned dict has no
+    per-paste keys, and the step trains."""
+    from divergen_amd.config import add_bsgal_config, get_cfg
+    from divergen_amd.data import synthetic_batch
+    from divergen_amd.modeling import build_model
+    from divergen_amd.solver import build_optimizer
+    from divergen_amd.utils.events import EventStorage
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = add_bsgal_config(get_cfg())
+    cfg.merge_from_file(os.path.join(root, "configs", "BSGAL", "BSGAL_R50.yaml"))
+    cfg.merge_from_list(["MODEL.ROI_BOX_HEAD.CAT_FREQ_PATH", os.path.join(root, "configs", "metadata", "lvis_v1_train_cat_info.json"),
+                         "OUTPUT_DIR", ""])
+    assert cfg.MODEL.ONLY_PASTE_SUP and cfg.MODEL.ACTIVE_ONLY_GT_TEST and cfg.MODEL.BACKBONE.NAME == "build_p67_timm_fpn_backbone"
+    torch.manual_seed(42)
+    model = build_model(cfg).train()
+    opt = build_optimizer(cfg, model)
+    sel = model.active_selector = BG.ActiveSelector.from_config(cfg, model, opt.arena, model.training_losses)
+    assert sel.mode == "paste_only" and sel.only_gt_test and sel.bank.update_mode == "MOMENTUM0.1"
+    base = synthetic_batch(2, 256, cfg.MODEL.ROI_HEADS.NUM_CLASSES, device=DEV)           # instance_source = [0]*8 + [1]*4
+    other = synthetic_batch(2, 256, cfg.MODEL.ROI_HEADS.NUM_CLASSES, seed=7, device=DEV)
+    held = synthetic_batch(2, 256, cfg.MODEL.ROI_HEADS.NUM_CLASSES, seed=99, device=DEV)
+    batch = []
+    for d, o, t in zip(base, other, held):
+        assert int(d["instances"].instance_source.sum()) > 0
+        e = dict(d)
+        e["origin_image"], e["origin_instances"] = o["image"], o["instances"]
+        ti = t["instances"]
+        ti.remove("instance_source")
+        e["test_image"], e["test_instances"], e["test_image_class"] = t["image"], ti, 0
+        e["paste_filename_list"] = ["x.png"]
+        batch.append(e)
+    # the plain training forward of this configuration carries the per-paste terms ...
+    with EventStorage(0):
+        plain = model.training_losses([dict(d) for d in base])
+        assert {"loss_paste_ins_stage0", "loss_nopaste_ins_stage2"} <= set(plain)
+        tot = float(plain["loss_paste_ins_stage0"] + plain["loss_nopaste_ins_stage0"])
+        assert abs(tot - float(plain["loss_cls_stage0"])) <= 2e-2 * abs(float(plain["loss_cls_stage0"])) + 1e-3
+        # ... and the held-out pass over ground-truth proposals only has exactly one RoI per ground-truth box
+        held_l = model.training_losses([{"image": e["test_image"], "instances": e["test_instances"]} for e in batch], only_gt_proposals=True)
+        assert all(np.isfinite(float(v)) for v in held_l.values())
+    opt.zero_grad()
+    w0 = opt.arena.p.clone()
+    with EventStorage(0):
+        losses = model(batch)
+        assert torch.equal(opt.arena.p, w0) and sel.count == 1
+        sp, thr = float(sel.last["sim_paste_init"]), float(sel.last["sim_ori_init"])
+        assert thr == -0.05 and (np.isnan(sp) or -1.0001 <= sp <= 1.0001) and sel.last["paste"] == (not thr > sp)
+        assert float(sel.bank.bank.abs().sum()) > 0
+        assert not any("paste" in k for k in losses)
+        total = sum(losses.values())
+        total.backward()
+        opt.step()
+    assert np.isfinite(float(total.detach())) and not torch.equal(opt.arena.p, w0)

@@ -11,7 +11,7 @@
 #include <cstdlib>
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 template <int MODE, int DEPTH>
-__global__ __launch_bounds__(512) void k(const unsigned char* buf, unsigned long long* out, int iters, int ld, int rows_per_wg, uint32_t bytes, int shared) {
+__global__ __launch_bounds__(512) void k(const unsigned char* buf, unsigned long long* out, int iters, int ld, int rows_per_wg, uint32_t bytes, int shared, int seg) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
     const int l = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const uint64_t a = (uint64_t)buf;
@@ -27,9 +27,11 @@ __global__ __launch_bounds__(512) void k(const unsigned char* buf, unsigned long
         for (int d = 0; d < DEPTH; ++d) {
             // instruction q covers rows 8q .. 8q+7 of this workgroup's panel, 128 B per row at K offset (it % kt) * 128
             const uint32_t q = (uint32_t)((it * DEPTH + d) * nw + w);
-            const uint32_t row = row0 + (8 * q + (l >> 3)) % rows_per_wg;
-            const uint32_t koff = ((uint32_t)it % (uint32_t)(ld / 128)) * 128u;
-            const uint32_t voff = row * (uint32_t)ld + koff + (l & 7) * 16u;
+            // seg = bytes per row an instruction covers (128: 8 whole cache lines of 8 rows; 64: half lines of 16 rows)
+            const uint32_t lpr = (uint32_t)seg / 16u, rpi = 64u / lpr;
+            const uint32_t row = row0 + (rpi * q + (uint32_t)l / lpr) % rows_per_wg;
+            const uint32_t koff = ((uint32_t)it % (uint32_t)(ld / seg)) * (uint32_t)seg;
+            const uint32_t voff = row * (uint32_t)ld + koff + ((uint32_t)l % lpr) * 16u;
             const bool lds_path = MODE == 0 || (MODE == 2 && (d & 1) == 0);
             if (lds_path) {
                 asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(voff), "s"(rsrc), "s"(ldsw + 1024u * (d & 7)) : "memory");
@@ -47,19 +49,19 @@ __global__ __launch_bounds__(512) void k(const unsigned char* buf, unsigned long
     if (acc[0] == 0x12345678u && acc[1] == 7u) out[4095] = acc[2];
 }
 template <int MODE, int DEPTH>
-void run(const unsigned char* d, unsigned long long* o, int waves, int ld, int rows_per_wg, size_t bytes, int iters, int shared) {
+void run(const unsigned char* d, unsigned long long* o, int waves, int ld, int rows_per_wg, size_t bytes, int iters, int shared, int seg) {
     hipFuncSetAttribute((const void*)k<MODE, DEPTH>, hipFuncAttributeMaxDynamicSharedMemorySize, 1024 * 8 * 8);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int rep = 0; rep < 2; ++rep) {
         hipEventRecord(e0);
-        hipLaunchKernelGGL((k<MODE, DEPTH>), dim3(256), dim3(64 * waves), 1024 * 8 * 8, 0, d, o, iters, ld, rows_per_wg, (uint32_t)bytes, shared);
+        hipLaunchKernelGGL((k<MODE, DEPTH>), dim3(256), dim3(64 * waves), 1024 * 8 * 8, 0, d, o, iters, ld, rows_per_wg, (uint32_t)bytes, shared, seg);
         hipEventRecord(e1); hipEventSynchronize(e1);
     }
     float ms; hipEventElapsedTime(&ms, e0, e1);
     unsigned long long h[256]; hipMemcpy(h, o, sizeof(h), hipMemcpyDeviceToHost);
     double cyc = 0; for (int i = 0; i < 256; ++i) cyc += (double)h[i]; cyc /= 256;
     const double per_wg = (double)iters * DEPTH * waves * 1024.0;
-    printf("%s mode %d depth %2d waves %d ld %5d: %6.1f B/clk/CU  %7.0f GB/s chip  (%.0f cycles, %.1f us)\n", shared ? "L2 " : "HBM", MODE, DEPTH, waves, ld,
+    printf("%s seg %3d mode %d depth %2d waves %d ld %5d: %6.1f B/clk/CU  %7.0f GB/s chip  (%.0f cycles, %.1f us)\n", shared ? "L2 " : "HBM", seg, MODE, DEPTH, waves, ld,
            per_wg / cyc, per_wg * 256 / (ms * 1e-3) / 1e9, cyc, ms * 1e3);
 }
 int main(int argc, char** argv) {
@@ -70,14 +72,10 @@ int main(int argc, char** argv) {
     hipMalloc(&d, bytes); hipMemset(d, 1, bytes); hipMalloc(&o, 4096 * 8);
     const int iters = 400;
     for (int shared : {1, 0})
-        for (int waves : {8, 4}) {
-            run<0, 7>(d, o, waves, ld, rows_per_wg, bytes, iters, shared);
-            run<1, 7>(d, o, waves, ld, rows_per_wg, bytes, iters, shared);
-            run<0, 14>(d, o, waves, ld, rows_per_wg, bytes, iters, shared);
-            run<1, 14>(d, o, waves, ld, rows_per_wg, bytes, iters, shared);
-            run<0, 28>(d, o, waves, ld, rows_per_wg, bytes, iters, shared);
-            run<1, 28>(d, o, waves, ld, rows_per_wg, bytes, iters, shared);
-            run<2, 28>(d, o, waves, ld, rows_per_wg, bytes, iters, shared);
+        for (int seg : {128, 64}) {
+            run<0, 7>(d, o, 8, ld, rows_per_wg, bytes, iters, shared, seg);
+            run<0, 14>(d, o, 8, ld, rows_per_wg, bytes, iters, shared, seg);
+            run<0, 28>(d, o, 8, ld, rows_per_wg, bytes, iters, shared, seg);
         }
     return 0;
 }

@@ -822,3 +822,38 @@ def test_deconv2x2_mfma_gemm_vs_torch(relu):
     torch.testing.assert_close(xd.grad.cpu(), xr.grad, atol=3e-2, rtol=2e-2)
     torch.testing.assert_close(wd.grad.cpu(), wr.grad, atol=1e-1, rtol=3e-2)
     torch.testing.assert_close(bd.grad.cpu(), br.grad, atol=1e-1, rtol=3e-2)
+
+
+def test_roi_align_and_nms_vs_the_reference_sources_compiled_in_place():
+    """The HIP kernels against the REFERENCE's own C++ (D2/layers/csrc/ROIAlignRotated/ROIAlignRotated_cpu.cpp and
+    nms_rotated/nms_rotated_cpu.cpp at angle 0, compiled where they lie into oracle/_ref/dgref.so by oracle/build.py; the
+    prebuilt binary travels to the GPU box): ROIAlign forward / backward as D2T/modeling/test_roi_pooler.py:14-59 does for the
+    aligned op (atol 1e-4), NMS keep sets equal up to pairs whose IoU sits within float rounding of the threshold (the rotated
+    code clips polygons)."""
+    from oracle.build import load_ref
+    ref = load_ref()
+    if ref is None:
+        pytest.skip("oracle/_ref/dgref.so not present (built in the container from /root/reference)")
+    g = torch.Generator().manual_seed(31)
+    feat = torch.rand(2, 64, 20, 16, generator=g)
+    rois = _rand_rois(g, 48, 2, 20 * 4, 16 * 4)
+    cx, cy = (rois[:, 1] + rois[:, 3]) / 2, (rois[:, 2] + rois[:, 4]) / 2
+    w, h = rois[:, 3] - rois[:, 1], rois[:, 4] - rois[:, 2]
+    rr = torch.stack([rois[:, 0], cx, cy, w, h, torch.zeros_like(w)], 1)
+    want = ref.roi_align_rotated_forward(feat, rr, 0.25, 7, 7, 0)
+    fd = feat.to(DEV).requires_grad_(True)
+    got = la.roi_align(fd, rois.to(DEV), 0.25, 7, 0, True)
+    torch.testing.assert_close(got.cpu(), want, atol=1e-4, rtol=0)
+    go = torch.rand(want.shape, generator=g)
+    got.backward(go.to(DEV))
+    gwant = ref.roi_align_rotated_backward(go, rr, 0.25, 7, 7, 2, 64, 20, 16, 0)
+    torch.testing.assert_close(fd.grad.cpu(), gwant, atol=1e-3, rtol=1e-4)
+    xy = torch.rand(400, 2, generator=g) * 120
+    wh = torch.rand(400, 2, generator=g) * 50 + 2
+    boxes = torch.cat([xy, xy + wh], 1)
+    scores = torch.rand(400, generator=g)
+    r5 = torch.stack([(boxes[:, 0] + boxes[:, 2]) / 2, (boxes[:, 1] + boxes[:, 3]) / 2, wh[:, 0], wh[:, 1], torch.zeros(400)], 1)
+    for thr in (0.3, 0.5, 0.7):
+        mine = set(la.nms(boxes.to(DEV), scores.to(DEV), thr).cpu().tolist())
+        theirs = set(ref.nms_rotated(r5, scores, thr).tolist())
+        assert len(mine ^ theirs) <= 2, (thr, sorted(mine ^ theirs))

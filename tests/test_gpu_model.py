@@ -145,10 +145,10 @@ def test_bf16_product_path_tracks_fp32_path():
 
 
 def test_end_to_end_losses_vs_assembled_oracle(monkeypatch):
-    run_e2e_vs_oracle(monkeypatch, "T", 256)
+    run_e2e_vs_oracle(monkeypatch, "T", 256, bf16_leg=True)
 
 
-def run_e2e_vs_oracle(monkeypatch, swin, size):
+def run_e2e_vs_oracle(monkeypatch, swin, size, bf16_leg=False):
     """Whole training forward against the assembled CPU oracle (oracle/model.py): same weights, same batch, the two
     random draws of the step replaced by the same deterministic rule on both sides, the product's proposals handed to
     the oracle (with near-tied scores the top-k/NMS survivor SET is not stable under fp32 reordering between two
@@ -198,6 +198,28 @@ def run_e2e_vs_oracle(monkeypatch, swin, size):
     print("e2e parity report (product, oracle, rel):", report)
     for k, (a, b, rel) in report.items():
         assert abs(a - b) <= 1e-3 * abs(b) + 1e-6, report
+    if not bf16_leg:
+        return
+    # ---- the bf16 PRODUCT path (what bench.py times) against the fp32 oracle, same weights, same batch, same deterministic
+    # draws, the oracle re-run on THIS pass's proposals: the budget of bf16 activations through the backbone and the heads
+    from divergen_amd.utils import graphs
+    monkeypatch.setattr(graphs, "ENABLED", False)      # graph replay vs eager is test_graphed_head_segments_match_eager's subject
+    model.fp16 = True
+    with EventStorage(0):
+        losses = model(batch)
+    got16 = {k: float(v) for k, v in losses.items()}
+    with torch.no_grad():
+        want16 = assembled_oracle_losses(p, images, gts, [tuple(b["instances"].image_size) for b in batch], swin, C, fw,
+                                         cfg.MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE, cfg.MODEL.ROI_HEADS.POSITIVE_FRACTION,
+                                         cfg.MODEL.ROI_BOX_HEAD.FED_LOSS_NUM_CAT, model.roi_heads.mask_weight,
+                                         proposals=captured["props"])
+    rep16 = {k: (got16[k], float(want16[k]), abs(got16[k] - float(want16[k])) / max(abs(float(want16[k])), 1e-6)) for k in sorted(got16)}
+    print("bf16 product vs fp32 oracle (product, oracle, rel):", rep16)
+    for k, (a, b, rel) in rep16.items():
+        # dense losses 3 %; cascade-stage losses sit behind discrete IoU matching at 0.6 / 0.7 / 0.8 of bf16-refined boxes: 10 %
+        # (15 % for the few-foreground stage-2 box loss), the bounds of test_bf16_product_path_tracks_fp32_path
+        lim = 15e-2 if k == "loss_box_reg_stage2" else (10e-2 if "_stage" in k else 3e-2)
+        assert abs(a - b) <= lim * abs(b) + 1e-6, rep16     # measured: every loss within 0.5 % (most within 1e-3)
 
 
 def test_overfits_a_fixed_batch():

@@ -49,6 +49,40 @@ def colsum_grouped(problems, beta=1.0):
     L.check(lib.dgx_colsum_grouped(arr, n, float(beta), L.ptr(ws), L.stream()), "dgx_colsum_grouped")
 
 
+import os
+# Weight / bias gradients of TWO consecutive blocks share one grouped launch: a Swin-L stage-2 block alone has 108 output tiles
+# of 256x256, so its grouped weight-gradient GEMM is split in two M-slabs (216 workgroups) whose fp32 partial tiles go through a
+# workspace and a reduce kernel; two blocks together are 216 tiles = one round of the chip with NO split: every workgroup runs
+# the whole contraction and folds straight into the gradient arena (no workspace, no reduce launch, half the fp32 tile traffic).
+# The first block's operands simply stay alive until the second block's backward has run; whatever is still pending when the
+# backward pass ends is flushed by an autograd end-of-backward callback.  DGX_WGRAD_PAIR=1 restores one launch per block.
+_PAIR = max(1, int(os.environ.get("DGX_WGRAD_PAIR", "2")))
+_PENDING = []
+_CB_QUEUED = [False]
+
+
+def flush_wgrads():
+    """Launch the pending blocks' weight / bias gradients (<= 8 problems per grouped launch) and signal their parameters."""
+    _CB_QUEUED[0] = False
+    while _PENDING:
+        batch = _PENDING[:2]
+        del _PENDING[:2]
+        probs = [t for wg, _ in batch for t in wg]
+        wgrad_grouped([(g, d, x_) for g, d, x_, _ in probs])
+        colsum_grouped([(b.grad, d) for _, d, _, b in probs if b is not None])
+        for _, params in batch:
+            _ready(*params)
+
+
+def _defer_wgrads(wgrads, params):
+    _PENDING.append((wgrads, params))
+    if len(_PENDING) >= _PAIR:
+        flush_wgrads()
+    elif not _CB_QUEUED[0]:
+        _CB_QUEUED[0] = True
+        torch.autograd.Variable._execution_engine.queue_callback(flush_wgrads)
+
+
 def _linear_bwd(dy2, x2, weight, bias, wgrads, gelu_of=None):
     """Weight / bias gradient of y = x W^T + b queued for the block's grouped weight-gradient / bias-gradient launches;
     returns dx = dy W (bf16) from the MFMA GEMM on the transposed weight image -- times GELU'(gelu_of) when given (the
@@ -144,9 +178,8 @@ class _SwinBlockFn(torch.autograd.Function):
                                       T, C, B, H, W, ws, shift, code, st), "dgx_layernorm_bwd")
         _ready(n1w, n1b)
         # the four weight gradients of the block: one grouped launch (256x256 tiles, small M-split)
-        wgrad_grouped([(g, d, x_) for g, d, x_, _ in wgrads])
-        colsum_grouped([(b.grad, d) for _, d, _, b in wgrads if b is not None])
-        _ready(w2, w1, pw, qw, b2, b1, pb, qb)
+        # the four weight gradients of the block (256x256 tiles): launched together with the next block's (flush_wgrads)
+        _defer_wgrads(wgrads, (w2, w1, pw, qw, b2, b1, pb, qb))
         return (dx1,) + (None,) * 17
 
 

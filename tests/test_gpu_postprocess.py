@@ -175,3 +175,30 @@ def test_results_writer_matches_reference_layout():
         c = P.rle_from_string(r["segmentation"]["counts"].encode())
         assert np.array_equal(P.rle_decode(c, 200, 300), want[k])
     assert instances_to_coco_json(make()[torch.zeros(9, dtype=torch.bool, device=DEV)], 1) == []
+
+
+def test_similarity_filter_matches_torch_cosine_similarity():
+    """DG/filteration/get_image_similarity_from_feature.py:63-78 + filter_image_by_similarity.py:139-212 restated with torch's own
+    cosine_similarity crop by crop (fp32) against the one-GEMM device form (bf16 unit rows): similarities within 4e-3 (bf16
+    rounding of unit vectors), identical keep sets away from the threshold, categories sharded rank::world."""
+    from divergen_amd.data import filtration as FL
+    g = torch.Generator().manual_seed(4)
+    R, G, D = 37, 101, 512
+    base = torch.randn(1, D, generator=g)
+    real = (base + 0.7 * torch.randn(R, D, generator=g)).cuda()
+    gen = (base * torch.rand(G, 1, generator=g) + 0.7 * torch.randn(G, D, generator=g)).cuda()
+    want = torch.stack([torch.cosine_similarity(real[i:i + 1], gen) for i in range(R)])          # the reference's loop
+    got = FL.cosine_similarity_matrix(real, gen)
+    assert got.shape == (R, G) and float((got - want).abs().max()) < 4e-3
+    thr = 0.3
+    keep, sim = FL.filter_category(real, gen, thr)
+    wmean = want.mean(0)
+    safe = (wmean - thr).abs() > 5e-3
+    assert torch.equal(keep[safe], (wmean >= thr)[safe]) and 0 < int(keep.sum()) < G
+    names = ["g%03d.png" % i for i in range(G)]
+    feats_real = {"3": real, "7": real[:5], "9": real}
+    feats_gen = {"3": (names, gen), "7": (names[:8], gen[:8]), "9": ([], gen[:0])}
+    r0 = FL.filter_pool(feats_real, feats_gen, thr, rank=0, world=2)
+    r1 = FL.filter_pool(feats_real, feats_gen, thr, rank=1, world=2)
+    assert set(r0) == {"3", "9"} and set(r1) == {"7"} and r0["9"] == {}
+    assert set(r0["3"]) == {n for n, k in zip(names, keep.cpu().tolist()) if k}

@@ -486,6 +486,8 @@ class CopyPasteMapper:
         """The test image of one sample (:260-284): a class among the pasted ones ('select'), else among the image's own,
         else any; re-drawn until some training image shows it; then one of those images through the plain mapper."""
         ncls = 1203
+        if not any(self.per_cat_pool_real.values()):
+            raise ValueError("INPUT.ACTIVE_SELECT needs a training set with annotations: no category has an image to hold out")
         if self.active_test == "select":
             cand = sorted(set(paste_labels)) or sorted(set(own_labels))
             cls = int(np.random.choice(cand)) if cand else int(np.random.choice(range(ncls)))

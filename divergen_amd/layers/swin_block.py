@@ -74,6 +74,16 @@ def flush_wgrads():
             _ready(*params)
 
 
+def reset_pending():
+    """Drop blocks whose backward pass never completed (an exception unwound it): called when the gradients are cleared for a
+    new step, so that a stale block can never be paired with -- and written into the gradients of -- the next step."""
+    if _PENDING:
+        import warnings
+        warnings.warn("divergen_amd: %d Swin block(s) with pending weight gradients dropped (an earlier backward pass did not finish)" % len(_PENDING))
+        del _PENDING[:]
+    _CB_QUEUED[0] = False
+
+
 def _defer_wgrads(wgrads, params):
     _PENDING.append((wgrads, params))
     if len(_PENDING) >= _PAIR:

@@ -109,6 +109,8 @@ class FlatArena:
                                                    self._tjobs.shape[0], self._ttiles, L.stream()), "dgx_transpose_bf16_grouped")
 
     def zero_grad(self):
+        from ..layers.swin_block import reset_pending
+        reset_pending()
         self.g.zero_()
 
     def segment_ends(self):

@@ -348,3 +348,21 @@ def test_arena_reducer_ignores_trial_backward_passes_world2_gloo():
     for it in range(3):
         assert np.allclose(g_a[it], g_b[it], atol=1e-6), it
         assert np.allclose(g_a[it], (tot / 2).numpy(), atol=1e-5), it
+
+
+def test_pending_weight_gradients_never_leak_into_the_next_step():
+    """layers/swin_block.py defers a block's weight gradients to pair them with the next block's; if a backward pass dies in
+    between, clearing the gradients for the next step must drop the stale block (with a warning) instead of pairing it."""
+    import warnings
+    from divergen_amd.layers import swin_block as SB
+    from divergen_amd.solver import FlatArena
+    SB._PENDING.append(([], ()))
+    arena = FlatArena(torch.nn.Linear(4, 4))
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        arena.zero_grad()
+    assert not SB._PENDING and any("pending weight gradients dropped" in str(x.message) for x in w)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        arena.zero_grad()
+    assert not w

@@ -280,7 +280,7 @@ extern "C" int dgx_layernorm_bwd(const void* dy_bf16, const void* x, const float
                                  const float* gamma, const void* dres, void* dx, float* dgamma, float* dbeta, float* part,
                                  int64_t T, int C, int B, int H, int W, int ws, int shift, int x_dtype, void* stream) {
     if (T <= 0) return DGX_OK;
-    if (!dy_bf16 || !x || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta || !part || (C & 3) || C > 1536 ||
+    if (!dy_bf16 || !x || !mean || !rstd || !gamma || !dx || ((dgamma == nullptr) != (dbeta == nullptr)) || !part || (C & 3) || C > 1536 ||
         (ws > 0 && (int64_t)B * H * W != T))
         return DGX_ERR_BAD_ARG;
     const WinMap m = make_map(B, H, W, ws, shift);
@@ -301,7 +301,50 @@ extern "C" int dgx_layernorm_bwd(const void* dy_bf16, const void* x, const float
     else if (nj <= 3) LN_BWD(3);
     else LN_BWD(6);
 #undef LN_BWD
-    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * C / 4 + 63) / 64), dim3(1024), 0, st, part, dgamma, dbeta, grid, C);
+    // dgamma == dbeta == NULL: the per-block partial rows stay in `part` for dgx_layernorm_param_reduce2 (two norms, one launch)
+    if (dgamma) hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * C / 4 + 63) / 64), dim3(1024), 0, st, part, dgamma, dbeta, grid, C);
+    DGX_LAUNCH_CHECK();
+    return DGX_OK;
+}
+
+struct LnRed2 { const float* part[2]; float* dgamma[2]; float* dbeta[2]; };
+__global__ __launch_bounds__(1024) void ln_param_reduce2_kernel(LnRed2 R, int nblk, int C) {
+    __shared__ float4 red[16][64];
+    const int which = blockIdx.y;
+    const float* part = R.part[which];
+    float* dgamma = R.dgamma[which];
+    float* dbeta = R.dbeta[which];
+    const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int q = blockIdx.x * 64 + lane;
+    const int nq = 2 * C / 4;
+    float4 s = {0.f, 0.f, 0.f, 0.f};
+    if (q < nq) {
+        const float4* p4 = reinterpret_cast<const float4*>(part);
+#pragma unroll 4
+        for (int b = rg; b < nblk; b += 16) {
+            const float4 v = p4[(int64_t)b * nq + q];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    }
+    red[rg][lane] = s;
+    __syncthreads();
+    if (rg == 0 && q < nq) {
+        float4 a = red[0][lane];
+        for (int r = 1; r < 16; ++r) { const float4 v = red[r][lane]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+        float* dst = (4 * q < C) ? dgamma + 4 * q : dbeta + (4 * q - C);
+        dst[0] += a.x; dst[1] += a.y; dst[2] += a.z; dst[3] += a.w;
+    }
+}
+
+// The second stage of TWO dgx_layernorm_bwd calls made with dgamma = dbeta = NULL (same T, hence the same number of partial
+// rows, and the same C): dgamma_x += sum of part_x's rows, in the fixed order of the single-norm kernel (bit-identical).
+extern "C" int dgx_layernorm_param_reduce2(const float* part_a, float* dgamma_a, float* dbeta_a, const float* part_b, float* dgamma_b,
+                                           float* dbeta_b, int64_t T, int C, void* stream) {
+    if (T <= 0) return DGX_OK;
+    if (!part_a || !dgamma_a || !dbeta_a || !part_b || !dgamma_b || !dbeta_b || (C & 3) || C > 1536) return DGX_ERR_BAD_ARG;
+    LnRed2 R = {{part_a, part_b}, {dgamma_a, dgamma_b}, {dbeta_a, dbeta_b}};
+    hipLaunchKernelGGL(ln_param_reduce2_kernel, dim3((2 * C / 4 + 63) / 64, 2), dim3(1024), 0, (hipStream_t)stream, R,
+                       dgx_layernorm_bwd_blocks(T), C);
     DGX_LAUNCH_CHECK();
     return DGX_OK;
 }

@@ -164,12 +164,11 @@ class _SwinBlockFn(torch.autograd.Function):
         dh2 = _linear_bwd(df1, h2, w1, b1, wgrads)
         # LN2 backward + the residual-branch gradient g -> dx1
         nblk = lib.dgx_layernorm_bwd_blocks(T)
-        part = torch.empty(nblk * 2 * C, dtype=torch.float32, device=dev)
+        part = torch.empty(2, nblk * 2 * C, dtype=torch.float32, device=dev)     # partial (dgamma | dbeta) rows of norm2, norm1
         dx1 = torch.empty_like(x)
         L.check(lib.dgx_layernorm_bwd(dh2.data_ptr(), x1.data_ptr(), mean2.data_ptr(), rstd2.data_ptr(), n2w.data_ptr(),
-                                      g.data_ptr(), dx1.data_ptr(), n2w.grad.data_ptr(), n2b.grad.data_ptr(), part.data_ptr(),
+                                      g.data_ptr(), dx1.data_ptr(), None, None, part[0].data_ptr(),
                                       T, C, 0, 0, 0, 0, 0, code, st), "dgx_layernorm_bwd")
-        _ready(n2w, n2b)
         # attention branch
         dpr = torch.empty(Tw, C, dtype=BF16, device=dev)
         L.check(lib.dgx_residual_bwd(dx1.data_ptr(), L.ptr(s1), dpr.data_ptr(), B, H, W, C, ws, shift, code, st),
@@ -184,9 +183,12 @@ class _SwinBlockFn(torch.autograd.Function):
         dxw = _linear_bwd(dqkv, xw, qw, qb, wgrads)
         # LN1 backward through the window map, accumulated onto dx1 in place
         L.check(lib.dgx_layernorm_bwd(dxw.data_ptr(), x.data_ptr(), mean1.data_ptr(), rstd1.data_ptr(), n1w.data_ptr(),
-                                      dx1.data_ptr(), dx1.data_ptr(), n1w.grad.data_ptr(), n1b.grad.data_ptr(), part.data_ptr(),
+                                      dx1.data_ptr(), dx1.data_ptr(), None, None, part[1].data_ptr(),
                                       T, C, B, H, W, ws, shift, code, st), "dgx_layernorm_bwd")
-        _ready(n1w, n1b)
+        # the second stage of both norms' parameter gradients in one launch
+        L.check(lib.dgx_layernorm_param_reduce2(part[0].data_ptr(), n2w.grad.data_ptr(), n2b.grad.data_ptr(), part[1].data_ptr(),
+                                                n1w.grad.data_ptr(), n1b.grad.data_ptr(), T, C, st), "dgx_layernorm_param_reduce2")
+        _ready(n2w, n2b, n1w, n1b)
         # the four weight gradients of the block: one grouped launch (256x256 tiles, small M-split)
         # the four weight gradients of the block (256x256 tiles): launched together with the next block's (flush_wgrads)
         _defer_wgrads(wgrads, (w2, w1, pw, qw, b2, b1, pb, qb))

@@ -243,6 +243,11 @@ int dgx_layernorm_bwd_blocks(int64_t T);
 int dgx_layernorm_bwd(const void* dy_bf16, const void* x, const float* mean, const float* rstd,
                       const float* gamma, const void* dres, void* dx, float* dgamma, float* dbeta, float* part,
                       int64_t T, int C, int B, int H, int W, int ws, int shift, int x_dtype, void* stream);
+/* dgx_layernorm_bwd with dgamma = dbeta = NULL leaves its per-block partial sums in `part`; this folds the partial rows of TWO
+ * such calls (same T and C: norm2 and norm1 of one Swin block) into their parameter gradients in one launch, in the summation
+ * order of the single-norm second stage (bit-identical results). */
+int dgx_layernorm_param_reduce2(const float* part_a, float* dgamma_a, float* dbeta_a, const float* part_b, float* dgamma_b,
+                                float* dbeta_b, int64_t T, int C, void* stream);
 /* LayerNorm with an fp32 result (PatchEmbed.norm, swintransformer.py:440-442; under autocast nn.LayerNorm returns fp32
  * and that tensor is the stage-0 residual stream).  x f32|bf16 (T,C) -> y f32 (T,C); backward: dy f32, dx in x's dtype,
  * ADDS into dgamma / dbeta; part as for dgx_layernorm_bwd.  C % 4 == 0, C <= 768 for backward. */

@@ -857,3 +857,38 @@ def test_roi_align_and_nms_vs_the_reference_sources_compiled_in_place():
         mine = set(la.nms(boxes.to(DEV), scores.to(DEV), thr).cpu().tolist())
         theirs = set(ref.nms_rotated(r5, scores, thr).tolist())
         assert len(mine ^ theirs) <= 2, (thr, sorted(mine ^ theirs))
+
+
+def test_layernorm_param_reduce2_is_bit_identical_to_the_single_norm_second_stage():
+    """dgx_layernorm_bwd with dgamma = dbeta = NULL + dgx_layernorm_param_reduce2 (norm2 and norm1 of a Swin block, one launch)
+    against two ordinary dgx_layernorm_bwd calls: same dx, same parameter gradients, bit for bit (same summation order)."""
+    from divergen_amd import _lib as L
+    lib = L.lib()
+    g = torch.Generator().manual_seed(8)
+    T, C = 3000, 384
+    outs = []
+    for split in (False, True):
+        res = []
+        parts = torch.empty(2, lib.dgx_layernorm_bwd_blocks(T) * 2 * C, device=DEV)
+        grads = [(torch.full((C,), 0.25, device=DEV), torch.full((C,), -0.5, device=DEV)) for _ in range(2)]
+        gg = torch.Generator().manual_seed(8)
+        for k in range(2):
+            x = bf(torch.randn(T, C, generator=gg)).to(DEV)
+            dy = bf(torch.randn(T, C, generator=gg)).to(DEV)
+            gam = torch.randn(C, generator=gg).to(DEV)
+            mean = x.float().mean(1)
+            rstd = (x.float().var(1, unbiased=False) + 1e-5).rsqrt()
+            dx = torch.empty_like(x)
+            dg, db = grads[k]
+            L.check(lib.dgx_layernorm_bwd(L.ptr(dy), L.ptr(x), L.ptr(mean), L.ptr(rstd), L.ptr(gam), None, L.ptr(dx),
+                                          None if split else L.ptr(dg), None if split else L.ptr(db), L.ptr(parts[k]),
+                                          T, C, 0, 0, 0, 0, 0, L.dtype_code(x), L.stream()), "ln_bwd")
+            res.append(dx)
+        if split:
+            L.check(lib.dgx_layernorm_param_reduce2(L.ptr(parts[0]), L.ptr(grads[0][0]), L.ptr(grads[0][1]), L.ptr(parts[1]),
+                                                    L.ptr(grads[1][0]), L.ptr(grads[1][1]), T, C, L.stream()), "reduce2")
+        outs.append((res, grads))
+    for k in range(2):
+        assert torch.equal(outs[0][0][k], outs[1][0][k])
+        assert torch.equal(outs[0][1][k][0], outs[1][1][k][0]) and torch.equal(outs[0][1][k][1], outs[1][1][k][1])
+    assert float((outs[1][1][0][0] - 0.25).abs().max()) > 0

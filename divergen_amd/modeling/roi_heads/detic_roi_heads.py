@@ -46,15 +46,23 @@ def _side_stream(dev):
     return _SIDE_STREAMS[key]
 
 
-def subsample_labels(labels, num_samples, positive_fraction, bg_label):
-    """D2/modeling/sampling.py:9-54 (two torch.randperm draws on the labels' device)."""
-    positive = ((labels != -1) & (labels != bg_label)).nonzero().squeeze(1)
-    negative = (labels == bg_label).nonzero().squeeze(1)
+def _subsample_labels(labels, num_samples, positive_fraction, bg_label, pre=None):
+    """D2/modeling/sampling.py:9-54 (two torch.randperm draws on the labels' device).  pre = (positive, negative) index lists
+    computed by the caller for the whole batch behind ONE device->host read (label_and_sample_proposals); the draws and their
+    order are the reference's either way."""
+    if pre is not None:
+        positive, negative = pre
+    else:
+        positive = ((labels != -1) & (labels != bg_label)).nonzero().squeeze(1)
+        negative = (labels == bg_label).nonzero().squeeze(1)
     num_pos = min(positive.numel(), int(num_samples * positive_fraction))
     num_neg = min(negative.numel(), num_samples - num_pos)
     p1 = torch.randperm(positive.numel(), device=positive.device)[:num_pos]
     p2 = torch.randperm(negative.numel(), device=negative.device)[:num_neg]
     return positive[p1], negative[p2]
+
+
+subsample_labels = _subsample_labels     # tests substitute a deterministic rule here
 
 
 def add_ground_truth_to_proposals(gt, proposals):
@@ -77,10 +85,13 @@ def add_ground_truth_to_proposals(gt, proposals):
 
 
 def select_foreground_proposals(proposals, bg_label):
+    """D2/modeling/roi_heads/roi_heads.py:46-76.  Proposals that come out of label_and_sample_proposals carry their foreground
+    rows FIRST and the count on the host (`_dgx_num_fg`): the selection is then a slice, not a `nonzero` (no device->host read)."""
     fg, masks = [], []
     for p in proposals:
         m = (p.gt_classes != -1) & (p.gt_classes != bg_label)
-        fg.append(p[m.nonzero().squeeze(1)])
+        n = p.__dict__.get("_dgx_num_fg")
+        fg.append(p[:n] if n is not None else p[m.nonzero().squeeze(1)])
         masks.append(m)
     return fg, masks
 
@@ -140,8 +151,33 @@ class DeticCascadeROIHeads(nn.Module):
         classes; an image without any is sampled as usual."""
         if self.proposal_append_gt:
             proposals = add_ground_truth_to_proposals(targets, proposals)
-        out, nfg, nbg = [], [], []
+        # pass 1 (device only): labels of every image and, for the reference's sampler, its positive / negative index lists as
+        # stable argsorts of the two masks; the four list LENGTHS of the batch are read back together -- one device->host read
+        # per step here instead of one `nonzero` per list (the lengths are what torch.randperm(n) needs on the host)
+        labels, pre = [], [None] * len(proposals)
         for p, t in zip(proposals, targets):
+            midx, mlab = iou_match(t.gt_boxes.tensor, p.proposal_boxes.tensor, self.cascade_ious[0])
+            if len(t) > 0:
+                gtc = t.gt_classes[midx]
+                gtc[mlab == 0] = self.num_classes
+            else:
+                gtc = torch.zeros_like(midx) + self.num_classes
+            if p.has("proposal_valid"):
+                # padding rows of a fixed-length proposal list: label -1 = "ignore", never sampled
+                gtc = torch.where(p.proposal_valid, gtc, torch.full_like(gtc, -1))
+                p.remove("proposal_valid")
+            labels.append((midx, gtc))
+        if subsample_labels is _subsample_labels and labels and labels[0][1].is_cuda:
+            orders, counts = [], []
+            for _, gtc in labels:
+                pm, nm = (gtc != -1) & (gtc != self.num_classes), gtc == self.num_classes
+                orders.append((torch.sort(pm.to(torch.int8), descending=True, stable=True)[1],
+                               torch.sort(nm.to(torch.int8), descending=True, stable=True)[1]))
+                counts += [pm.sum(), nm.sum()]
+            counts = torch.stack(counts).tolist()
+            pre = [(o[0][:counts[2 * i]], o[1][:counts[2 * i + 1]]) for i, o in enumerate(orders)]
+        out, nfg, nbg = [], [], []
+        for i, (p, t) in enumerate(zip(proposals, targets)):
             has_gt = len(t) > 0
             if only_gt_proposals and has_gt:
                 assert self.proposal_append_gt
@@ -154,22 +190,18 @@ class DeticCascadeROIHeads(nn.Module):
                         p.set(name, val)
                 nfg.append(torch.tensor(float(len(t)), device=t.gt_classes.device))
                 nbg.append(torch.zeros((), device=t.gt_classes.device))
+                p.__dict__["_dgx_num_fg"] = len(t)
                 out.append(p)
                 continue
-            midx, mlab = iou_match(t.gt_boxes.tensor, p.proposal_boxes.tensor, self.cascade_ious[0])
-            if has_gt:
-                gtc = t.gt_classes[midx]
-                gtc[mlab == 0] = self.num_classes
+            midx, gtc = labels[i]
+            if pre[i] is not None:
+                fg_idx, bg_idx = subsample_labels(gtc, self.batch_size_per_image, self.positive_fraction, self.num_classes, pre=pre[i])
             else:
-                gtc = torch.zeros_like(midx) + self.num_classes
-            if p.has("proposal_valid"):
-                # padding rows of a fixed-length proposal list: label -1 = "ignore", never sampled
-                gtc = torch.where(p.proposal_valid, gtc, torch.full_like(gtc, -1))
-                p.remove("proposal_valid")
-            fg_idx, bg_idx = subsample_labels(gtc, self.batch_size_per_image, self.positive_fraction, self.num_classes)
+                fg_idx, bg_idx = subsample_labels(gtc, self.batch_size_per_image, self.positive_fraction, self.num_classes)
             sidx = torch.cat([fg_idx, bg_idx], dim=0)
             p = p[sidx]
             p.gt_classes = gtc[sidx]
+            p.__dict__["_dgx_num_fg"] = int(fg_idx.numel())       # foreground rows first: select_foreground_proposals slices
             if has_gt:
                 st = midx[sidx]
                 for name, val in t.get_fields().items():

@@ -298,9 +298,12 @@ def main():
             d["image"].record_stream(torch.cuda.current_stream())
             if "instances" in d and d["instances"].has("gt_masks"):
                 d["instances"].gt_masks.tensor.record_stream(torch.cuda.current_stream())
+        # next batch on the side stream, issued BEFORE this step's forward: the host is ahead of the GPU here, whereas after the
+        # forward's one device->host read (proposal sampler) every host microsecond is GPU idle time (measured: -0.55 ms/step
+        # against issuing it between forward and backward)
+        nxt[0] = compose()
         opt.zero_grad()
         losses = model(batch)
-        nxt[0] = compose()                               # next batch, concurrently with this step's backward
         total = sum(losses.values())
         total.backward()
         scale = reducer.finish()

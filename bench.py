@@ -16,8 +16,6 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from divergen_amd.tuning import enable as _enable_tuned_gemm  # noqa: E402  (no torch import inside)
-_enable_tuned_gemm()
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -36,7 +34,24 @@ def parse():
     p.add_argument("--no-roofline", action="store_true", help="leave the per-launch HIP events off (A/B of their cost)")
     p.add_argument("--roofline-every", type=int, default=10, help="instrument every n-th timed step with per-launch HIP events")
     p.add_argument("--no-copy-paste", action="store_true")
+    p.add_argument("--launch-check", action="store_true",
+                   help="bring up the N ranks, run the collective self-check and print its JSON line; no model, no GPU needed "
+                        "(backend from DGX_DIST_BACKEND, default nccl = RCCL)")
     return p.parse_args()
+
+
+def relaunch_under_torchrun(a):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start one process per GPU of this node ourselves
+    (the reference does the same through detectron2's launch(), DG/train_net.py:357-362 -> D2/engine/launch.py:27-126)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
 
 
 def make_pastes(rng, size, k=19):
@@ -193,6 +208,8 @@ def cpu_baseline(swin, model, cfg, budget_s=30.0):
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        relaunch_under_torchrun(a)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -200,15 +217,17 @@ def main():
     # graph capture next to collectives, CenterNet normaliser all-reduces) on a single-GPU box with gloo
     if "DGX_FORCE_DEVICE" in os.environ:
         local = int(os.environ["DGX_FORCE_DEVICE"])
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    backend = os.environ.get("DGX_DIST_BACKEND", "nccl")
+    on_gpu = not (a.launch_check and backend != "nccl")      # the launch check over gloo runs without a GPU (CPU-container test)
+    if on_gpu:
+        torch.cuda.set_device(local)
+    dev = torch.device("cuda", local) if on_gpu else torch.device("cpu")
     if world > 1 or os.environ.get("DGX_FORCE_PG") == "1":      # DGX_FORCE_PG: a 1-rank RCCL group, to test RCCL next to graph capture
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        backend = os.environ.get("DGX_DIST_BACKEND", "nccl")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -225,7 +244,18 @@ def main():
         ranks_seen = int(probe[0].item())
         devs = [int(v) - 1 for v in probe[1:].tolist()]
         assert ranks_seen == world, "collective saw %d of %d ranks" % (ranks_seen, world)
-        assert "DGX_FORCE_DEVICE" in os.environ or len(set(devs)) == world, "ranks share GPUs: %s" % devs
+        assert "DGX_FORCE_DEVICE" in os.environ or not on_gpu or len(set(devs)) == world, "ranks share GPUs: %s" % devs
+    if a.launch_check:
+        if world > 1:
+            dist.barrier()
+        line = {"launch_check": True, "n_gpus": world, "ranks_seen_by_collective": ranks_seen if ranks_seen is not None else 1,
+                "collective_backend": ("rccl" if dist.get_backend() == "nccl" else dist.get_backend()) if dist.is_initialized() else None,
+                "launched_by": "torchrun" if "TORCHELASTIC_RUN_ID" in os.environ else "direct"}
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps(line), flush=True)
+        return
     # DGX_GRAPH_BACKBONE=1 (opt-in) replays the static-shape backbone fwd+bwd as a hipGraph: -6 % step
     # time at N=1 (the step is CPU-launch-bound), but per-kernel HIP events (the roofline object) and the
     # per-layer gradient readiness the arena reducer overlaps on are only available on the eager path,

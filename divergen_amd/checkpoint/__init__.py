@@ -70,10 +70,12 @@ class DetectionCheckpointer:
         with open(os.path.join(self.save_dir, "last_checkpoint")) as f:
             return os.path.join(self.save_dir, f.read().strip())
 
-    def resume_or_load(self, path, *, resume=True):
+    def resume_or_load(self, path, *, resume=True, model_key="model"):
+        """model_key="model_ema": the weights evaluated by `--eval-only` when SOLVER.MODEL_EMA > 0 (DG/train_net.py:340-350
+        copies ckpt['model_ema'] over ckpt['model'] through a temporary file before loading)."""
         if resume and self.has_checkpoint():
-            return self.load(self.get_checkpoint_file())
-        return self.load(path, checkpointables=[])
+            return self.load(self.get_checkpoint_file(), model_key=model_key)
+        return self.load(path, checkpointables=[], model_key=model_key)
 
     def _load_file(self, filename):
         if filename.endswith(".pkl"):
@@ -90,13 +92,17 @@ class DetectionCheckpointer:
             loaded = {"model": loaded}
         return loaded
 
-    def load(self, path, checkpointables=None):
+    def load(self, path, checkpointables=None, model_key="model"):
         if not path:
             self.logger.info("No checkpoint found. Initializing model from scratch")
             return {}
         if not os.path.isfile(path):
             raise FileNotFoundError("Checkpoint {} not found!".format(path))
         ckpt = self._load_file(path)
+        if model_key != "model":
+            if model_key not in ckpt:
+                raise KeyError("checkpoint %s has no '%s' entry (keys: %s)" % (path, model_key, sorted(ckpt)))
+            ckpt["model"] = ckpt[model_key]
         sd = ckpt.pop("model")
         sd = {k[7:] if k.startswith("module.") else k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v)
               for k, v in sd.items()}

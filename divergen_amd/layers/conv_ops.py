@@ -1,6 +1,7 @@
-"""Convolutions of the dense / RoI heads as GEMMs over channels-last tensors.
+"""Convolutions of the dense / RoI heads as libdgx GEMMs over channels-last bf16 tensors (no library route, no fp32 mode).
 
-  conv3x3      im2col (HIP) + library GEMM; backward = GEMM + col2im (HIP) and col^T @ dy
+  conv3x3      stride 1: implicit GEMM over a zero-bordered NHWC image (no column matrix), forward, input and weight gradient;
+               stride 2 (P6 / P7, R50 down-sampling): im2col (HIP) + the same MFMA GEMM; backward = GEMM + col2im (HIP)
   conv1x1      a Linear over NHWC pixels
   patch_embed  4x4 stride-4 conv = Linear over unfolded 4x4x3 patches (a pure view)
   deconv2x2    ConvTranspose2d(k=2,s=2) = Linear C -> 4*Cout per pixel + pixel shuffle (a view)
@@ -11,7 +12,6 @@ import math
 import os
 
 import torch
-import torch.nn.functional as F
 
 from .. import _lib as L
 from .gemm_ops import gemm_nt
@@ -49,18 +49,16 @@ class _Conv3x3(torch.autograd.Function):
         wk = _ohwi_matrix(w) if bf else None          # arena weights stored (Cout,kh,kw,Cin): the GEMM operand as is
         wm = wk.t() if wk is not None else w.permute(2, 3, 1, 0).reshape(9 * C, -1)     # (ky,kx,ci) x co
         col, Ho, Wo = _im2col(x, stride)
-        own = bf and x.is_cuda and w.shape[0] % 8 == 0 and C % 8 == 0       # libdgx MFMA GEMM (bf16 path)
-        if own:
-            if wk is None:
-                wk = wm.t().contiguous()
-            y = gemm_nt(col, wk, shadow(bias) if bias is not None else None)
-            wt = getattr(weight, "_dgx16t", None)      # (9 Cin, Cout): the arena's transposed twin, else a copy
-            plain = wt is not None and not getattr(weight, "_dgx16t_flipped", False) and _ohwi_matrix(shadow(weight)) is not None
-            wm = wt if plain else wm.contiguous()
-        elif bias is not None:
-            y = torch.addmm(shadow(bias) if bf else bias.to(x.dtype), col, wm)
-        else:
-            y = col @ wm
+        if not (bf and x.is_cuda and w.shape[0] % 8 == 0 and C % 8 == 0):
+            raise L.DgxError("conv3x3: bf16 GPU input with Cin, Cout multiples of 8 required (got %s %s, Cin %d, Cout %d)"
+                             % (x.dtype, x.device, C, w.shape[0]))
+        own = True
+        if wk is None:
+            wk = wm.t().contiguous()
+        y = gemm_nt(col, wk, shadow(bias) if bias is not None else None)
+        wt = getattr(weight, "_dgx16t", None)      # (9 Cin, Cout): the arena's transposed twin, else a copy
+        plain = wt is not None and not getattr(weight, "_dgx16t_flipped", False) and _ohwi_matrix(shadow(weight)) is not None
+        wm = wt if plain else wm.contiguous()
         ctx.own = own
         ctx.save_for_backward(col, wm)
         ctx.weight, ctx.bias = weight, bias
@@ -74,7 +72,7 @@ class _Conv3x3(torch.autograd.Function):
         g2 = gy.reshape(N * Ho * Wo, -1).to(col.dtype)
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            dcol = gemm_nt(g2.contiguous(), wm) if ctx.own else (g2 @ wm.t()).contiguous()
+            dcol = gemm_nt(g2.contiguous(), wm)
             gx = torch.empty(N, H, W, C, dtype=col.dtype, device=col.device)
             L.check(L.lib().dgx_col2im3x3(L.ptr(dcol), L.ptr(gx), N, H, W, C, stride, L.dtype_code(gx), L.stream()),
                     "dgx_col2im3x3")
@@ -216,12 +214,7 @@ class _Conv3x3Implicit(torch.autograd.Function):
 _IMPLICIT = os.environ.get("DGX_CONV_IMPLICIT", "1") == "1"      # A/B switch against the im2col path
 
 
-def _compute_dtype(x):
-    return torch.bfloat16 if torch.is_autocast_enabled() else x.dtype
-
-
-MIN_COUT = 8  # GEMMs with 1..4 output columns hit a GEMV path in the BLAS library whose host-side
-              # setup costs ~10 ms per call; zero-padded output channels keep them on the GEMM path
+MIN_COUT = 8  # the MFMA GEMM writes 8-column chunks: 1- and 4-channel predictors run with zero-padded output channels
 
 
 def _pad_cout(weight, bias):
@@ -238,10 +231,9 @@ def _pad_cout(weight, bias):
 def conv3x3(x, weight, bias=None, stride=1, relu=False):
     """x logical (N,C,H,W) -> logical (N,Cout,Ho,Wo), NHWC storage both sides.  relu: fused into the implicit-GEMM epilogue
     where that path applies, applied afterwards otherwise."""
-    xh = _nhwc(x).to(_compute_dtype(x))
+    xh = _nhwc(x).to(torch.bfloat16)
     weight, bias, co = _pad_cout(weight, bias)
-    implicit = (_IMPLICIT and stride == 1 and xh.is_cuda and xh.dtype == torch.bfloat16 and xh.shape[-1] % 64 == 0
-                and weight.shape[0] % 8 == 0)
+    implicit = _IMPLICIT and stride == 1 and xh.is_cuda and xh.shape[-1] % 64 == 0 and weight.shape[0] % 8 == 0
     with torch.autocast("cuda", enabled=False):
         if implicit:
             y = _Conv3x3Implicit.apply(xh, weight, bias, relu)
@@ -253,12 +245,7 @@ def conv3x3(x, weight, bias=None, stride=1, relu=False):
 
 
 def conv1x1(x, weight, bias=None):
-    xh = _nhwc(x)
-    if weight.shape[0] >= MIN_COUT and torch.is_autocast_enabled():
-        return linear(xh, weight, bias).permute(0, 3, 1, 2)     # arena path: no casts, fp32 wgrad in place
-    weight, bias, co = _pad_cout(weight, bias)
-    y = F.linear(xh, weight.view(weight.shape[0], -1), bias)
-    return y[..., :co].permute(0, 3, 1, 2)
+    return linear(_nhwc(x), weight, bias).permute(0, 3, 1, 2)     # arena path: no casts, fp32 wgrad in place
 
 
 def preprocess_patch_rows(images, mean, std, size_divisibility=0, patch=4):
@@ -283,9 +270,7 @@ def preprocess_patch_rows(images, mean, std, size_divisibility=0, patch=4):
 
 def patch_embed_rows(pr, weight, bias):
     """PatchRows -> tokens (B, Hp*Wp, embed): the PatchEmbed projection as a Linear over the prepared rows."""
-    if torch.is_autocast_enabled():
-        return linear(pr.rows, weight, bias), pr.Hp, pr.Wp
-    return F.linear(pr.rows.float(), weight.reshape(weight.shape[0], -1), bias), pr.Hp, pr.Wp
+    return linear(pr.rows, weight, bias), pr.Hp, pr.Wp
 
 
 def patch_embed4x4(x, weight, bias, patch=4):
@@ -293,9 +278,7 @@ def patch_embed4x4(x, weight, bias, patch=4):
     B, Cin, H, W = x.shape
     Hp, Wp = H // patch, W // patch
     u = x.reshape(B, Cin, Hp, patch, Wp, patch).permute(0, 2, 4, 1, 3, 5).reshape(B, Hp * Wp, Cin * patch * patch)
-    if torch.is_autocast_enabled():
-        return linear(u, weight, bias), Hp, Wp          # arena path: (embed, 3,4,4) is a (embed, 48) Linear weight
-    return F.linear(u, weight.reshape(weight.shape[0], -1), bias), Hp, Wp
+    return linear(u, weight, bias), Hp, Wp          # arena path: (embed, 3,4,4) is a (embed, 48) Linear weight
 
 
 class _Deconv2x2(torch.autograd.Function):
@@ -342,21 +325,11 @@ def deconv2x2(x, weight, bias, relu=False):
     xh = _nhwc(x)
     N, H, W, Cin = xh.shape
     Cout = weight.shape[1]
-    if xh.is_cuda and torch.is_autocast_enabled() and Cin % 8 == 0 and Cout % 2 == 0:
-        with torch.autocast("cuda", enabled=False):
-            y = _Deconv2x2.apply(xh.reshape(-1, Cin).to(torch.bfloat16), weight, bias, relu)
-        y = y.view(N, H, W, Cout, 2, 2).permute(0, 1, 4, 2, 5, 3).reshape(N, 2 * H, 2 * W, Cout)
-        return y.permute(0, 3, 1, 2)
-    y = _deconv2x2_ref(xh, weight, bias)
-    return torch.relu(y) if relu else y
-
-
-def _deconv2x2_ref(xh, weight, bias):
-    N, H, W, Cin = xh.shape
-    Cout = weight.shape[1]
-    wm = weight.permute(2, 3, 1, 0).reshape(4 * Cout, Cin)                   # (dy,dx,co) x ci
-    y = F.linear(xh, wm, bias.repeat(4) if bias is not None else None)        # (N,H,W,4*Cout)
-    y = y.view(N, H, W, 2, 2, Cout).permute(0, 1, 3, 2, 4, 5).reshape(N, 2 * H, 2 * W, Cout)
+    if not (xh.is_cuda and Cin % 8 == 0 and Cout % 2 == 0):
+        raise L.DgxError("deconv2x2: GPU input with Cin %% 8 == 0 and even Cout required (Cin %d, Cout %d, %s)" % (Cin, Cout, xh.device))
+    with torch.autocast("cuda", enabled=False):
+        y = _Deconv2x2.apply(xh.reshape(-1, Cin).to(torch.bfloat16), weight, bias, relu)
+    y = y.view(N, H, W, Cout, 2, 2).permute(0, 1, 4, 2, 5, 3).reshape(N, 2 * H, 2 * W, Cout)
     return y.permute(0, 3, 1, 2)
 
 
@@ -368,6 +341,13 @@ class Conv2d(torch.nn.Conv2d):
         if self.kernel_size == (3, 3) and self.groups == 1 and os.environ.get("DGX_CONV_OHWI", "1") == "1":
             self.weight._dgx_ohwi = True       # FlatArena stores it (Cout, kh, kw, Cin): see solver.FlatArena.view
             self.weight._dgx_flip = self.stride == (1, 1)      # its bf16 twin: tap-flipped (Cin, kh, kw, Cout), the input-gradient operand
+        if self.kernel_size == (1, 1) and self.groups == 1 and self.out_channels % 8:
+            # a 1x1 convolution is a Linear over pixels: widths that are not multiples of 8 (the 1-channel mask predictor) get
+            # zero rows up to 8 inside the arena (layers.linear_ops.shadow_padded)
+            from .linear_ops import pad8
+            self.weight._dgx_pad_rows = pad8(self.out_channels)
+            if self.bias is not None:
+                self.bias._dgx_pad_rows = pad8(self.out_channels)
 
     def forward(self, x, relu=False):
         """relu=True: the activation that follows the layer, fused into the GEMM epilogue where the path has one."""

@@ -8,7 +8,6 @@ transposed weight image (`FlatArena.p16t`, refreshed with the bf16 shadow after 
 Reference call sites: swintransformer.py:133,155 (qkv / proj), :40-46 (Mlp), :296 (reduction), fpn.py:126-154, box_head.py:26-98.
 """
 import ctypes
-import os
 
 import torch
 
@@ -28,13 +27,16 @@ def _check2(a, b):
 
 
 _WS = {}
-WS_BYTES = 64 << 20      # split-K scratch per device (fp32 slabs of skinny, long-K problems), allocated once
+WS_BYTES = 64 << 20      # split-K scratch (fp32 slabs of skinny, long-K problems), allocated once per (device, stream)
 
 
 def _workspace(dev):
-    ws = _WS.get(dev)
+    """One scratch buffer per (device, stream): two streams that run split-K GEMMs at the same time (the opt-in mask-branch
+    side stream next to the box cascade) must not fold their fp32 slabs in the same buffer."""
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _WS.get(key)
     if ws is None:
-        ws = _WS[dev] = torch.empty(WS_BYTES, dtype=torch.uint8, device=dev)
+        ws = _WS[key] = torch.empty(WS_BYTES, dtype=torch.uint8, device=dev)
     return ws
 
 
@@ -56,14 +58,9 @@ def _dev_ptr(t):
     return t.data_ptr()
 
 
-_LIB_AB = os.environ.get("DGX_GEMM_LIB", "")       # development A/B only: route plain GEMMs through the vendor library
-
-
 def gemm_nt(a, b, bias=None, out=None):
     """bf16 (M, N) = a b^T (+ bias)."""
     _check2(a, b)
-    if _LIB_AB and out is None and (_LIB_AB == "all" or (_LIB_AB == "nobias") == (bias is None)):
-        return torch.addmm(bias, a, b.t()) if bias is not None else torch.mm(a, b.t())
     _dev_ptr(a), _dev_ptr(b)
     M, N = a.shape[0], b.shape[0]
     c = out if out is not None else torch.empty(M, N, dtype=BF16, device=a.device)

@@ -12,22 +12,22 @@ import torch.nn as nn
 from .. import _lib as L
 
 BF16 = torch.bfloat16
-import os
-WGRAD_MIN_M = int(os.environ.get("DGX_WGRAD_MIN_M", 4096))   # measured crossover vs the library GEMM (tools/wgrad_probe2.py): long-M shapes only
+
+
+def pad8(n):
+    return (n + 7) // 8 * 8
 
 
 def wgrad_into(g2, dy2, x2, beta=1.0):
-    """g2 fp32 (Nn,Kk) = beta*g2 + dy2^T x2: the 256x256 split-M MFMA kernel (dgx_linear_wgrad_grouped, here a group
-    of one) for the long contractions of this model, the library GEMM for short ones."""
+    """g2 fp32 (Nn,Kk) = beta*g2 + dy2^T x2 on the 256x256 split-M MFMA kernel (dgx_linear_wgrad_grouped, a group of
+    one).  There is no library route: shapes the kernel does not take raise."""
     M, Nn = dy2.shape
     Kk = x2.shape[1]
-    if (dy2.is_cuda and M >= WGRAD_MIN_M and Nn % 8 == 0 and Kk % 8 == 0 and g2.is_contiguous() and dy2.is_contiguous()
-            and x2.is_contiguous() and dy2.dtype == BF16 and x2.dtype == BF16 and M * max(Nn, Kk) * 2 < (1 << 31)):
-        wgrad_grouped([(g2, dy2, x2)], beta)
-    elif beta == 0.0:
-        torch.mm(dy2.t(), x2, out_dtype=torch.float32, out=g2)
-    else:
-        torch.addmm(g2, dy2.t(), x2, out_dtype=torch.float32, out=g2)
+    if not (dy2.is_cuda and Nn % 8 == 0 and Kk % 8 == 0 and g2.is_contiguous() and dy2.dtype == BF16 and x2.dtype == BF16
+            and M * max(Nn, Kk) * 2 < (1 << 31)):
+        raise L.DgxError("wgrad_into: dy %s %s x %s %s -- libdgx takes bf16 GPU operands with widths that are multiples of 8"
+                         % (tuple(dy2.shape), dy2.dtype, tuple(x2.shape), x2.dtype))
+    wgrad_grouped([(g2, dy2.contiguous(), x2.contiguous())], beta)
 
 
 def wgrad_grouped(problems, beta=1.0):
@@ -83,8 +83,34 @@ def shadow_t(p):
     return w.reshape(w.shape[0], -1).t().contiguous()
 
 
-def _own_gemm_ok(x2, n, k):
-    return x2.is_cuda and n % 8 == 0 and k % 8 == 0
+def shadow_padded(p):
+    """bf16 operand of a Linear weight (N, K) / bias (N,) whose width N is not a multiple of 8 (cls_score 1454, bbox_pred 4,
+    the 1- and 4-channel CenterNet predictors as Linears): N rounded up to 8 with zero rows.  Inside a FlatArena the padding
+    lives in the arena itself (`_dgx16p`: the rows behind the parameter's own are part of its segment and stay zero under
+    AdamW / EMA because their gradient is zero), so the GEMMs read it without a per-step copy; before that a padded copy."""
+    s = getattr(p, "_dgx16p", None)
+    if s is not None:
+        return s
+    w = shadow(p)
+    w = w.reshape(w.shape[0], -1) if w.dim() > 1 else w
+    n = w.shape[0]
+    if n % 8 == 0:
+        return w
+    pad = pad8(n) - n
+    return torch.cat([w, w.new_zeros((pad,) + tuple(w.shape[1:]))], 0)
+
+
+def shadow_t_padded(p):
+    """(K, pad8(N)) twin of `shadow_padded(weight)`: the B operand of the input-gradient GEMM."""
+    s = getattr(p, "_dgx16t", None)
+    if s is not None and s.shape[1] % 8 == 0 and not getattr(p, "_dgx16t_flipped", False):
+        return s
+    return shadow_padded(p).t().contiguous()
+
+
+def grad_padded(p):
+    """fp32 gradient view with the padded leading dimension (arena), else None."""
+    return getattr(p, "_dgxgp", None)
 
 
 def accumulate_grad(p, make_grad_fp32, gemm_into=None):
@@ -102,62 +128,124 @@ def accumulate_grad(p, make_grad_fp32, gemm_into=None):
 
 
 class _LinearFn(torch.autograd.Function):
+    """y_pad (M, pad8(N)) = x W^T + b on libdgx's MFMA GEMM; callers slice [..., :N].  The slice's backward hands this
+    node a zero-padded gradient, which is exactly the K-padded operand the input- and weight-gradient GEMMs need."""
+
     @staticmethod
     def forward(ctx, x, weight, bias):
-        w16 = shadow(weight)
-        w16 = w16.reshape(w16.shape[0], -1)          # conv 1x1 weights (Cout,Cin,1,1) are Linear weights
+        from .gemm_ops import gemm_nt
+        w16 = shadow_padded(weight)                  # conv 1x1 weights (Cout,Cin,1,1) are Linear weights
+        w16 = w16.reshape(w16.shape[0], -1)
         x2 = x.reshape(-1, x.shape[-1])
         if x2.dtype != BF16:
             x2 = x2.to(BF16)
         x2 = x2.contiguous()
-        if _own_gemm_ok(x2, w16.shape[0], w16.shape[1]):
-            from .gemm_ops import gemm_nt
-            y = gemm_nt(x2, w16, shadow(bias) if bias is not None else None)
-        elif bias is not None:                       # widths that are not multiples of 8 (cls_score 1454, bbox_pred 4): library
-            y = torch.addmm(shadow(bias), x2, w16.t())
-        else:
-            y = torch.mm(x2, w16.t())
-        ctx.save_for_backward(x2, w16)
+        if w16.shape[1] % 8:
+            raise L.DgxError("Linear: in_features %d is not a multiple of 8 (no such layer on the path)" % w16.shape[1])
+        y = gemm_nt(x2, w16, shadow_padded(bias) if bias is not None else None)
+        ctx.save_for_backward(x2)
         ctx.weight, ctx.bias, ctx.xshape, ctx.xdtype = weight, bias, x.shape, x.dtype
         return y.view(*x.shape[:-1], w16.shape[0])
 
     @staticmethod
     def backward(ctx, dy):
-        x2, w16 = ctx.saved_tensors
+        from .gemm_ops import gemm_nt
+        x2, = ctx.saved_tensors
         weight, bias = ctx.weight, ctx.bias
         dy2 = dy.reshape(-1, dy.shape[-1])
         if dy2.dtype != BF16:
             dy2 = dy2.to(BF16)
         dy2 = dy2.contiguous()
+        n = weight.shape[0]
         dx = None
         if ctx.needs_input_grad[0]:
-            if _own_gemm_ok(dy2, w16.shape[1], w16.shape[0]):
-                from .gemm_ops import gemm_nt
-                dx = gemm_nt(dy2, shadow_t(weight)).view(ctx.xshape)
-            else:
-                dx = torch.mm(dy2, w16).view(ctx.xshape)
+            dx = gemm_nt(dy2, shadow_t_padded(weight)).view(ctx.xshape)
             if ctx.xdtype != BF16:
                 dx = dx.to(ctx.xdtype)
         gw = gb = None
         if ctx.needs_input_grad[1]:
-            def into(g):
-                wgrad_into(g.view(g.shape[0], -1), dy2, x2)
-            gw = accumulate_grad(weight, lambda: torch.mm(dy2.t(), x2, out_dtype=torch.float32).view(weight.shape),
-                                 gemm_into=into)
+            gp = grad_padded(weight)
+
+            def into(g):       # the arena's (padded) gradient rows: accumulated in place, fp32
+                wgrad_into(gp if gp is not None else g.view(g.shape[0], -1), dy2, x2)
+
+            def fresh():       # not arena resident: a gradient tensor for autograd to accumulate
+                g = torch.empty(dy2.shape[1], x2.shape[1], dtype=torch.float32, device=x2.device)
+                wgrad_into(g, dy2, x2, beta=0.0)
+                return g[:n].view(weight.shape)
+            gw = accumulate_grad(weight, fresh, gemm_into=into if (n % 8 == 0 or gp is not None) else None)
         if bias is not None and ctx.needs_input_grad[2]:
-            gb = accumulate_grad(bias, lambda: torch.sum(dy2, 0, dtype=torch.float32))
+            bp = grad_padded(bias)
+            if bias.is_leaf and bias.grad is not None and bias.grad.dtype == torch.float32 and getattr(bias, "_dgx16", None) is not None \
+                    and (n % 8 == 0 or bp is not None):
+                from .swin_block import colsum_into
+                colsum_into(bp if bp is not None else bias.grad, dy2)      # bias gradient summed straight into the arena
+                notify_ready(bias)
+            else:
+                gb = accumulate_grad(bias, lambda: torch.sum(dy2[:, :n], 0, dtype=torch.float32))
         return dx, gw, gb
 
 
-def linear(x, weight, bias=None):
+def linear_padded(x, weight, bias=None):
+    """(.., pad8(N)): the GEMM's own output; columns >= N come from zero weight rows and zero bias padding."""
+    if not x.is_cuda:
+        raise L.DgxError("libdgx ops need GPU (ROCm) tensors; got a %s tensor -- no CPU fallback exists" % x.device)
     with torch.autocast("cuda", enabled=False):
         return _LinearFn.apply(x, weight, bias)
 
 
+def linear(x, weight, bias=None):
+    y = linear_padded(x, weight, bias)
+    n = weight.shape[0]
+    return y if y.shape[-1] == n else y[..., :n]
+
+
 class Linear(nn.Linear):
-    """nn.Linear parameters (checkpoint-compatible); bf16 GEMMs over the arena shadow."""
+    """nn.Linear parameters (checkpoint-compatible); every forward is libdgx's bf16 MFMA GEMM over the arena shadow (fp32
+    accumulation, bf16 result) -- there is no second precision mode and no library route."""
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        if self.out_features % 8:
+            self.weight._dgx_pad_rows = pad8(self.out_features)
+            if self.bias is not None:
+                self.bias._dgx_pad_rows = pad8(self.out_features)
 
     def forward(self, x):
-        if x.dtype == torch.float32 and not torch.is_autocast_enabled():
-            return torch.nn.functional.linear(x, self.weight, self.bias)   # fp32 parity mode (cfg.FP16 off)
         return linear(x, self.weight, self.bias)
+
+
+class _GeluFn(torch.autograd.Function):
+    """Exact (erf) GELU on bf16 activations: dgx_gelu_fwd / dgx_gelu_bwd_colsum (nn.GELU of the Swin MLP on the composed path;
+    the one-node Swin block has it inside the fc1 GEMM's read-out)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.to(BF16).contiguous()
+        if x.numel() % 8:
+            raise L.DgxError("gelu: element count must be a multiple of 8")
+        y = torch.empty_like(x)
+        L.check(L.lib().dgx_gelu_fwd(L.ptr(x), L.ptr(y), x.numel(), L.stream()), "dgx_gelu_fwd")
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, = ctx.saved_tensors
+        N = x.shape[-1]
+        M = x.numel() // N
+        dy = dy.to(BF16).contiguous()
+        dx = torch.empty_like(x)
+        lib = L.lib()
+        ws = torch.empty(max(int(lib.dgx_gelu_bwd_workspace_bytes(M, N)), 16), dtype=torch.uint8, device=x.device)
+        L.check(lib.dgx_gelu_bwd_colsum(L.ptr(dy), L.ptr(x), L.ptr(dx), None, M, N, 0.0, L.ptr(ws), L.stream()), "dgx_gelu_bwd_colsum")
+        return dx
+
+
+def gelu(x):
+    return _GeluFn.apply(x)
+
+
+class GELU(nn.Module):
+    def forward(self, x):
+        return gelu(x)

@@ -222,12 +222,11 @@ class _GroupNormReLU(torch.autograd.Function):
 
 
 def groupnorm_relu(x, weight, bias, num_groups, eps=1e-5, relu=True):
-    """x logical (N, C, H, W) with channels-last storage, bf16 -> same.  Falls back to torch for other layouts."""
+    """x logical (N, C, H, W) with channels-last storage -> same, bf16 (the only form built: 8 channels per group)."""
     N, C, H, W = x.shape
-    if not (x.is_cuda and x.dtype == torch.bfloat16 and C == 8 * num_groups):
-        y = torch.nn.functional.group_norm(x, num_groups, weight, bias, eps)
-        return torch.relu(y) if relu else y
-    xp = x.permute(0, 2, 3, 1).contiguous()
+    if not (x.is_cuda and C == 8 * num_groups):
+        raise L.DgxError("groupnorm_relu: GPU input with 8 channels per group required (C %d, groups %d, %s)" % (C, num_groups, x.device))
+    xp = x.permute(0, 2, 3, 1).to(torch.bfloat16).contiguous()
     with torch.autocast("cuda", enabled=False):
         y = _GroupNormReLU.apply(xp, weight, bias, num_groups, eps, relu)
     return y.permute(0, 3, 1, 2)

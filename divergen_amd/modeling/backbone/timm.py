@@ -47,13 +47,10 @@ class FrozenBatchNorm2d(nn.Module):
         """x logical (N,C,H,W) over NHWC storage -> same; optional residual (same layout) and ReLU in the same pass."""
         scale, shift = self.scale_shift()
         xh = _nhwc(x)
-        if xh.is_cuda and xh.dtype == BF16 and xh.shape[-1] % 8 == 0:
-            rh = _nhwc(residual).to(BF16).contiguous() if residual is not None else None
-            return _AffineAct.apply(xh.contiguous(), scale, shift, rh, relu).permute(0, 3, 1, 2)
-        y = xh.float() * scale + shift                     # fp32 parity mode (cfg.FP16 off)
-        if residual is not None:
-            y = y + _nhwc(residual).float()
-        return (torch.relu(y) if relu else y).to(xh.dtype).permute(0, 3, 1, 2)
+        if not (xh.is_cuda and xh.shape[-1] % 8 == 0):
+            raise L.DgxError("FrozenBatchNorm2d: GPU input with C %% 8 == 0 required (%s, C %d)" % (xh.device, xh.shape[-1]))
+        rh = _nhwc(residual).to(BF16).contiguous() if residual is not None else None
+        return _AffineAct.apply(xh.to(BF16).contiguous(), scale, shift, rh, relu).permute(0, 3, 1, 2)
 
 
 class _AffineAct(torch.autograd.Function):
@@ -103,9 +100,9 @@ class _MaxPool(torch.autograd.Function):
 def maxpool3x3s2(x):
     """nn.MaxPool2d(kernel_size=3, stride=2, padding=1) on a logical (N,C,H,W) tensor over NHWC storage."""
     xh = _nhwc(x)
-    if xh.is_cuda and xh.dtype == BF16 and xh.shape[-1] % 8 == 0:
-        return _MaxPool.apply(xh.contiguous()).permute(0, 3, 1, 2)
-    return torch.nn.functional.max_pool2d(x, 3, 2, 1)
+    if not (xh.is_cuda and xh.shape[-1] % 8 == 0):
+        raise L.DgxError("maxpool3x3s2: GPU input with C %% 8 == 0 required (%s, C %d)" % (xh.device, xh.shape[-1]))
+    return _MaxPool.apply(xh.to(BF16).contiguous()).permute(0, 3, 1, 2)
 
 
 class _StemConv(torch.autograd.Function):
@@ -142,11 +139,11 @@ class _StemConv(torch.autograd.Function):
 
 class StemConv(nn.Conv2d):
     def forward(self, x):
-        if x.is_cuda and torch.is_autocast_enabled() and self.kernel_size == (7, 7) and self.stride == (2, 2) and self.padding == (3, 3) \
-                and self.in_channels == 3 and self.bias is None and self.out_channels % 8 == 0:
-            with torch.autocast("cuda", enabled=False):
-                return _StemConv.apply(x, self.weight).permute(0, 3, 1, 2)
-        return super().forward(x)
+        if not (x.is_cuda and self.kernel_size == (7, 7) and self.stride == (2, 2) and self.padding == (3, 3)
+                and self.in_channels == 3 and self.bias is None and self.out_channels % 8 == 0):
+            raise L.DgxError("StemConv: only the ResNet stem (7x7 / 2 / pad 3, 3 -> 8k channels, no bias) on a GPU tensor is built")
+        with torch.autocast("cuda", enabled=False):
+            return _StemConv.apply(x, self.weight).permute(0, 3, 1, 2)
 
 
 class Bottleneck(nn.Module):

@@ -73,10 +73,10 @@ class CenterNetHead(nn.Module):
         i = 0
         while i < len(mods):
             m = mods[i]
-            if (isinstance(m, nn.GroupNorm) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
-                    and x.is_cuda and x.dtype == torch.bfloat16 and m.num_channels == 8 * m.num_groups):
-                x = groupnorm_relu(x, m.weight, m.bias, m.num_groups, m.eps, relu=True)
-                i += 2
+            if isinstance(m, nn.GroupNorm):
+                relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+                x = groupnorm_relu(x, m.weight, m.bias, m.num_groups, m.eps, relu=relu)
+                i += 2 if relu else 1
             else:
                 x = m(x)
                 i += 1

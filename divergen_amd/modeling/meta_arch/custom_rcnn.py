@@ -2,9 +2,9 @@
 D2/modeling/meta_arch/rcnn.py:24-243 for the box-supervised path the shipped configs train.
 
 Precision: the reference runs the backbone under fp16 autocast + GradScaler and the heads in fp32
-(custom_rcnn.py:141-146).  Here cfg.FP16 selects bf16 autocast (no loss scaling needed) and, by
-default, keeps the dense/RoI head GEMMs and convolutions in bf16 as well (DGX_HEADS_FP32=1 restores
-fp32 heads); losses, box decoding and targets are always fp32."""
+(custom_rcnn.py:141-146).  This build has ONE precision: bf16 operands, fp32 accumulation in every GEMM / convolution /
+attention kernel of backbone and heads (no loss scaling needed); losses, box decoding, targets and the optimizer state are
+fp32.  cfg.FP16 False (no shipped configuration) is refused: there is no fp32-activation path and no eager fallback."""
 import os
 
 import torch
@@ -32,7 +32,9 @@ class CustomRCNN(nn.Module):
         self.input_format, self.vis_period, self.fp16, self.roi_head_name = input_format, vis_period, fp16, roi_head_name
         self.register_buffer("pixel_mean", torch.tensor(pixel_mean).view(-1, 1, 1), False)
         self.register_buffer("pixel_std", torch.tensor(pixel_std).view(-1, 1, 1), False)
-        self.heads_fp32 = os.environ.get("DGX_HEADS_FP32", "0") == "1"
+        if not fp16:
+            raise NotImplementedError("cfg.FP16 False: this build computes in bf16 with fp32 accumulation on its own HIP kernels; "
+                                      "an fp32-activation mode does not exist (every shipped configuration sets FP16: True)")
         # hipGraph capture of the static-shape backbone fwd+bwd (launch-bound otherwise: ~3.5k launches)
         self.graph_backbone = os.environ.get("DGX_GRAPH_BACKBONE", "0") == "1"
         self._graphed = {}
@@ -65,7 +67,7 @@ class CustomRCNN(nn.Module):
     def _patch_rows_ok(self, images):
         bu = getattr(self.backbone, "bottom_up", None)
         pe = getattr(bu, "patch_embed", None)
-        return (_FUSED_PREPROCESS and self.fp16 and self.training and pe is not None and pe.patch_size == (4, 4) and not (self.graph_backbone and self.training)
+        return (_FUSED_PREPROCESS and pe is not None and pe.patch_size == (4, 4) and not (self.graph_backbone and self.training)
                 and all(im.is_cuda and im.dtype == torch.uint8 and im.dim() == 3 and im.shape[0] == 3 for im in images))
 
     def _graphed_backbone(self, x):
@@ -84,21 +86,11 @@ class CustomRCNN(nn.Module):
 
     def _features(self, images):
         if self.graph_backbone and self.training:
-            x = images.tensor.to(memory_format=torch.channels_last) if self.fp16 else images.tensor
-            feats = self._graphed_backbone(x)
-            if self.heads_fp32:
-                feats = {k: v.float() for k, v in feats.items()}
-            return feats
-        if self.fp16:
-            with torch.autocast("cuda", dtype=torch.bfloat16):
-                if images.patch_rows is not None:
-                    feats = self.backbone(images.patch_rows)
-                else:
-                    feats = self.backbone(images.tensor.to(memory_format=torch.channels_last))
-            if self.heads_fp32:
-                feats = {k: v.float() for k, v in feats.items()}
-            return feats
-        return self.backbone(images.tensor)
+            return self._graphed_backbone(images.tensor.to(memory_format=torch.channels_last))
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            if images.patch_rows is not None:
+                return self.backbone(images.patch_rows)
+            return self.backbone(images.tensor.to(memory_format=torch.channels_last))
 
     def forward(self, batched_inputs):
         if not self.training:
@@ -121,8 +113,7 @@ class CustomRCNN(nn.Module):
         images = self.preprocess_image(batched_inputs)
         gt_instances = [x["instances"].to(self.device) for x in batched_inputs]
         features = self._features(images)
-        heads_amp = self.fp16 and not self.heads_fp32
-        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=heads_amp):
+        with torch.autocast("cuda", dtype=torch.bfloat16):
             proposals, proposal_losses = self.proposal_generator(images, features, gt_instances)
             proposals, detector_losses = self.roi_heads(images, features, proposals, gt_instances, ann_type="box",
                                                         only_gt_proposals=only_gt_proposals)
@@ -135,9 +126,10 @@ class CustomRCNN(nn.Module):
     def inference(self, batched_inputs, do_postprocess=True):
         assert not self.training
         images = self.preprocess_image(batched_inputs)
-        features = self.backbone(images.tensor)
-        proposals, _ = self.proposal_generator(images, features, None)
-        results, _ = self.roi_heads(images, features, proposals)
+        features = self._features(images)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            proposals, _ = self.proposal_generator(images, features, None)
+            results, _ = self.roi_heads(images, features, proposals)
         if not do_postprocess:
             return results
         out = []

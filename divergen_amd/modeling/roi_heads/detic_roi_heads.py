@@ -309,6 +309,9 @@ class DeticCascadeROIHeads(nn.Module):
                 f = nfg[0].float()
                 st.put_scalar("stage{}/roi_head/num_fg_samples".format(k), f / B)
                 st.put_scalar("stage{}/roi_head/num_bg_samples".format(k), (R - f) / B)
+            obs = self.__dict__.get("stage_observer")
+            if obs is not None:      # tests: the labels this stage trains on (hand-over to the CPU oracle)
+                obs(k, dict(boxes=prop, valid=valid, gt_classes=gtc, gt_boxes=gtb, counts=counts))
             boxes = [Boxes(b) for b in prop.split(counts)]
             x = self.box_pooler(feats, boxes, pad_to=256)
             x = _ScaleGradient.apply(x, 1.0 / self.num_cascade_stages)

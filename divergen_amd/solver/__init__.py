@@ -43,11 +43,12 @@ class FlatArena:
         self.names = [n for n, _ in params]
         self.params = [p for _, p in params]
         dev = self.params[0].device
-        offs, n = [], 0
+        offs, sizes, n = [], [], 0
         for p in self.params:
             offs.append(n)
-            n += (p.numel() + 3) // 4 * 4
-        self.offsets, self.numel = offs, n
+            sizes.append((self.padded_numel(p) + 3) // 4 * 4)
+            n += sizes[-1]
+        self.offsets, self.sizes, self.numel = offs, sizes, n
         self.p = torch.zeros(n, dtype=torch.float32, device=dev)
         self.g = torch.zeros(n, dtype=torch.float32, device=dev)
         self.p16 = torch.zeros(n, dtype=torch.bfloat16, device=dev)   # bf16 shadow, refreshed by the optimizer kernel
@@ -61,9 +62,17 @@ class FlatArena:
             p.data = v
             p.grad = self.view(self.g, p, o)
             p._dgx16 = self.view(self.p16, p, o)
+            pr = getattr(p, "_dgx_pad_rows", 0)
+            if pr:
+                # a Linear whose width is not a multiple of 8 (cls_score 1454, bbox_pred 4): the segment holds pad8(rows) rows,
+                # the extra ones zero for ever (zero gradient -> AdamW / EMA leave them at zero); the GEMMs take these views
+                cols = p.numel() // p.shape[0]
+                shape = (pr, cols) if p.dim() >= 2 else (pr,)
+                p._dgx16p = self.p16[o:o + pr * cols].view(shape)
+                p._dgxgp = self.g[o:o + pr * cols].view(shape)
             if self.p16t is not None and p.dim() >= 2:
-                rows = self.stored_rows(p)
-                cols = p.numel() // rows
+                rows = pr or self.stored_rows(p)
+                cols = p.numel() // self.stored_rows(p)
                 cin = 0
                 if getattr(p, "_dgx_flip", False) and getattr(p, "_dgx_ohwi", False) and p.dim() == 4 and p.shape[1] % 64 == 0 \
                         and p.shape[0] % 8 == 0:
@@ -71,7 +80,7 @@ class FlatArena:
                     p._dgx16t = self.p16t[o:o + p.numel()].view(cin, 9 * rows)
                     p._dgx16t_flipped = True
                 else:
-                    p._dgx16t = self.p16t[o:o + p.numel()].view(cols, rows)
+                    p._dgx16t = self.p16t[o:o + rows * cols].view(cols, rows)
                 jobs.append((o, rows | (cols << 32), tiles, cin))
                 tiles += ((rows + 63) // 64) * ((cols + 63) // 64)
         self._tjobs = torch.tensor(jobs, dtype=torch.int64, device=dev) if jobs else None
@@ -89,6 +98,12 @@ class FlatArena:
             co, ci, kh, kw = p.shape
             return flat.view(co, kh, kw, ci).permute(0, 3, 1, 2)
         return flat.view(p.shape)
+
+    @staticmethod
+    def padded_numel(p):
+        """Elements of the parameter's arena segment: pad8(rows) x columns for a Linear tagged `_dgx_pad_rows`."""
+        pr = getattr(p, "_dgx_pad_rows", 0)
+        return pr * (p.numel() // p.shape[0]) if pr else p.numel()
 
     @staticmethod
     def stored_rows(p):
@@ -114,7 +129,7 @@ class FlatArena:
         self.g.zero_()
 
     def segment_ends(self):
-        return [o + (p.numel() + 3) // 4 * 4 for o, p in zip(self.offsets, self.params)]
+        return [o + n for o, n in zip(self.offsets, self.sizes)]
 
 
 class FusedAdamWEMA:

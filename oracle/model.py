@@ -66,8 +66,12 @@ def _match(gt_boxes, gt_classes, boxes, thr, num_classes):
 
 
 def roi_head_losses(p, fp, proposals, gts, image_sizes, num_classes, batch_per_image, pos_fraction, freq_weight, fed_num,
-                    sample_fn, fed_fn, mask_weight=1.0, prefix="roi_heads."):
-    """proposals: per image (boxes (n,4)).  gts: per image dict(boxes, classes, masks (n,H,W) bool)."""
+                    sample_fn, fed_fn, mask_weight=1.0, prefix="roi_heads.", stage_labels=None):
+    """proposals: per image (boxes (n,4)).  gts: per image dict(boxes, classes, masks (n,H,W) bool).
+    stage_labels (tests): {k: per image (keep mask (n,), classes (n_kept,), matched gt index (n_kept,))} for cascade stages
+    k >= 1 -- the discrete outcome of `_match_and_label_boxes` handed in by the implementation under test, so that a refined
+    box that sits within rounding of an IoU threshold cannot flip a label between the two sides; the boxes, features, logits
+    and losses are still the oracle's own."""
     feats = [fp[k] for k in ("p3", "p4", "p5")]
     scales = (1 / 8, 1 / 16, 1 / 32)
     # label_and_sample_proposals (+ add_ground_truth_to_proposals)
@@ -90,8 +94,12 @@ def roi_head_losses(p, fp, proposals, gts, image_sizes, num_classes, batch_per_i
                 H_, W_ = image_sizes[i]
                 b = torch.stack([b[:, 0].clamp(0, W_), b[:, 1].clamp(0, H_), b[:, 2].clamp(0, W_), b[:, 3].clamp(0, H_)], 1)
                 keep = ((b[:, 2] - b[:, 0]) > 0) & ((b[:, 3] - b[:, 1]) > 0)
-                b = b[keep]
-                idx, c = _match(g["boxes"], g["classes"], b, IOUS[k], num_classes)
+                if stage_labels is not None and k in stage_labels:
+                    keep, c, idx = stage_labels[k][i]
+                    b = b[keep]
+                else:
+                    b = b[keep]
+                    idx, c = _match(g["boxes"], g["classes"], b, IOUS[k], num_classes)
                 nb.append(b)
                 nc.append(c)
                 midx[i] = idx

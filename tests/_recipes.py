@@ -16,6 +16,18 @@ def fill_state(shapes, seed, scale=0.05):
     return out
 
 
+def fill_by_name(module, seed, scale):
+    """Mirrors tests/golden/make_golden.py:fill_by_name: parameters from a per-NAME seeded stream, bf16-exact values."""
+    import zlib
+    with torch.no_grad():
+        for name, p in module.named_parameters():
+            g = torch.Generator().manual_seed(seed + (zlib.crc32(name.encode()) & 0xFFFFFF))
+            v = torch.randn(p.shape, generator=g) * scale
+            if p.dim() == 1 and name.endswith("weight"):
+                v = v + 1.0
+            p.copy_(v.to(torch.bfloat16).float())
+
+
 def swin_param_shapes(embed_dim, depths, num_heads, ws, out_indices=(1, 2, 3), mlp_ratio=4):
     """named_parameters() order of the reference SwinTransformer (swintransformer.py:473-557)."""
     s = [("patch_embed.proj.weight", (embed_dim, 3, 4, 4)), ("patch_embed.proj.bias", (embed_dim,)),
@@ -61,7 +73,7 @@ def det_fed_mask(gt_classes, K, C, weight):
 
 def assembled_oracle_losses(p, images, gts, image_sizes, swin, num_classes, freq_weight, batch_per_image=512, pos_fraction=0.25,
                             fed_num=50, mask_weight=1.0, proposals=None, score_thresh=0.0001, pre_topk=4000, nms_thresh=0.9,
-                            post_topk=2000):
+                            post_topk=2000, stage_labels=None):
     """The whole training forward of oracle/model.py on CPU: Swin + FPN + CenterNet head -> CenterNet losses -> proposals
     (the oracle's own decode + NMS unless `proposals` are handed in) -> cascade RoI heads + mask head.  Returns the loss
     dict (differentiable w.r.t. the entries of `p` that require grad)."""
@@ -75,5 +87,5 @@ def assembled_oracle_losses(p, images, gts, image_sizes, swin, num_classes, freq
     losses.update(OM.roi_head_losses(p, fp, proposals, gts, image_sizes, num_classes, batch_per_image, pos_fraction, freq_weight,
                                      fed_num, lambda i, labels, n, frac, bg: det_sample(labels, n, frac, bg),
                                      lambda k, gtc, K, Cn, w: det_fed_mask(gtc, K, Cn, w).nonzero().squeeze(1),
-                                     mask_weight=mask_weight))
+                                     mask_weight=mask_weight, stage_labels=stage_labels))
     return losses

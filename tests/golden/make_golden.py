@@ -387,6 +387,96 @@ def gen_heads():
          **{("p." + k): v for k, v in head.state_dict().items()})
 
 
+def fill_by_name(module, seed, scale):
+    """Parameters from a per-NAME seeded stream, rounded to bf16 (so the product's bf16 shadow weights ARE these weights):
+    independent of registration order; mirrored by tests/_recipes.py:fill_by_name."""
+    import zlib
+    with torch.no_grad():
+        for name, p in module.named_parameters():
+            g = torch.Generator().manual_seed(seed + (zlib.crc32(name.encode()) & 0xFFFFFF))
+            v = torch.randn(p.shape, generator=g) * scale
+            if p.dim() == 1 and name.endswith("weight"):          # norm scales
+                v = v + 1.0
+            p.copy_(v.to(torch.bfloat16).float())
+
+
+def bf16r(t):
+    return t.to(torch.bfloat16).float()
+
+
+def gen_heads_wide():
+    """FPN, CenterNetHead, mask head and box head of the reference at the widths the product's HIP path is built for
+    (256 channels: implicit-GEMM convolutions, 8-channel GroupNorm groups), fp32 on bf16-exact weights and inputs: values and
+    gradients.  Fixtures hold inputs / outputs only; the parameters are regenerated from their names (fill_by_name)."""
+    fpn_m = sys.modules.get("detectron2.modeling.backbone.fpn") or R.ref("detectron2.modeling.backbone.fpn")
+    f5 = R.ref("centernet.modeling.backbone.fpn_p5")
+    ch = R.ref("centernet.modeling.dense_heads.centernet_head")
+    mh = R.ref("detectron2.modeling.roi_heads.mask_head")
+    bh = R.ref("detectron2.modeling.roi_heads.box_head")
+    ss = sys.modules["detectron2.layers"].ShapeSpec
+    Backbone = sys.modules["detectron2.modeling.backbone"].Backbone
+
+    class Dummy(Backbone):
+        _out_features = ["swin1", "swin2", "swin3"]
+        _out_feature_channels = {"swin1": 64, "swin2": 128, "swin3": 256}
+        _out_feature_strides = {"swin1": 8, "swin2": 16, "swin3": 32}
+
+        def forward(self, x):
+            return x
+
+    torch.manual_seed(2000)
+    fpn = fpn_m.FPN(Dummy(), ["swin1", "swin2", "swin3"], 256, norm="", top_block=f5.LastLevelP6P7_P5(256, 256), fuse_type="sum")
+    fill_by_name(fpn, 71, 0.03)
+    feats = {"swin1": bf16r(torch.randn(1, 64, 16, 12)).requires_grad_(True), "swin2": bf16r(torch.randn(1, 128, 8, 6)).requires_grad_(True),
+             "swin3": bf16r(torch.randn(1, 256, 4, 3)).requires_grad_(True)}
+    out = fpn(feats)
+    gos = {k: bf16r(torch.randn(v.shape)) for k, v in out.items()}
+    sum((out[k] * gos[k]).sum() for k in out).backward()
+    sd = dict(fpn.named_parameters())
+    save("fpn_wide", **{("in." + k): v for k, v in feats.items()}, **{("out." + k): v for k, v in out.items()},
+         **{("go." + k): v for k, v in gos.items()}, **{("din." + k): v.grad for k, v in feats.items()},
+         **{"g.fpn_lateral5.weight": sd["fpn_lateral5.weight"].grad, "g.fpn_output3.bias": sd["fpn_output3.bias"].grad,
+            "g.fpn_output4.weight.rows8": sd["fpn_output4.weight"].grad[:8], "g.top_block.p6.weight.rows8": sd["top_block.p6.weight"].grad[:8]})
+
+    head = ch.CenterNetHead(in_channels=256, num_levels=2, num_classes=5, with_agn_hm=True, only_proposal=True, norm="GN",
+                            num_cls_convs=4, num_box_convs=4, num_share_convs=0, use_deformable=False, prior_prob=0.01)
+    fill_by_name(head, 72, 0.02)
+    with torch.no_grad():
+        head.bbox_pred.bias.fill_(2.0)          # keep the ReLU of the regression maps away from zero, as the trained bias (8.0) does
+    xs = [bf16r(torch.randn(1, 256, 12, 10)).requires_grad_(True), bf16r(torch.randn(1, 256, 6, 5)).requires_grad_(True)]
+    clss, regs, hms = head(xs)
+    gr = [bf16r(torch.randn(r.shape)) for r in regs]
+    gh = [bf16r(torch.randn(h.shape)) for h in hms]
+    (sum((r * g).sum() for r, g in zip(regs, gr)) + sum((h * g).sum() for h, g in zip(hms, gh))).backward()
+    hp = dict(head.named_parameters())
+    save("centernet_head_wide", x0=xs[0], x1=xs[1], reg0=regs[0], reg1=regs[1], hm0=hms[0], hm1=hms[1], gr0=gr[0], gr1=gr[1],
+         gh0=gh[0], gh1=gh[1], dx0=xs[0].grad, dx1=xs[1].grad,
+         **{"g.bbox_tower.0.weight.rows8": hp["bbox_tower.0.weight"].grad[:8], "g.bbox_tower.1.weight": hp["bbox_tower.1.weight"].grad,
+            "g.bbox_tower.1.bias": hp["bbox_tower.1.bias"].grad, "g.bbox_pred.weight": hp["bbox_pred.weight"].grad,
+            "g.agn_hm.bias": hp["agn_hm.bias"].grad, "g.scales.1.scale": hp["scales.1.scale"].grad})
+
+    mask = mh.MaskRCNNConvUpsampleHead(ss(channels=256, height=14, width=14), num_classes=1, conv_dims=[256] * 5, conv_norm="")
+    fill_by_name(mask, 73, 0.02)
+    xm = bf16r(torch.randn(3, 256, 14, 14)).requires_grad_(True)
+    logits = mask.layers(xm)
+    gm = bf16r(torch.randn(logits.shape))
+    (logits * gm).sum().backward()
+    mp = dict(mask.named_parameters())
+    save("mask_head_wide", x=xm, logits=logits, go=gm, dx=xm.grad,
+         **{"g.mask_fcn1.weight.rows8": mp["mask_fcn1.weight"].grad[:8], "g.deconv.weight.rows8": mp["deconv.weight"].grad[:8],
+            "g.deconv.bias": mp["deconv.bias"].grad, "g.predictor.weight": mp["predictor.weight"].grad, "g.predictor.bias": mp["predictor.bias"].grad})
+
+    box = bh.FastRCNNConvFCHead(ss(channels=256, height=7, width=7), conv_dims=[], fc_dims=[1024, 1024])
+    fill_by_name(box, 74, 0.01)
+    xb = bf16r(torch.randn(8, 256, 7, 7)).requires_grad_(True)
+    yb = box(xb)
+    gb = bf16r(torch.randn(yb.shape))
+    (yb * gb).sum().backward()
+    bp = dict(box.named_parameters())
+    save("box_head_wide", x=xb, y=yb, go=gb, dx=xb.grad,
+         **{"g.fc1.weight.rows4": bp["fc1.weight"].grad[:4], "g.fc2.weight.rows16": bp["fc2.weight"].grad[:16], "g.fc2.bias": bp["fc2.bias"].grad})
+
+
 def gen_postprocess():
     """paste_masks_in_image (D2/layers/mask_ops.py:73) on seeded detections; output stored bit-packed."""
     mo = R.ref("detectron2.layers.mask_ops")
@@ -563,6 +653,6 @@ def gen_augment():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["swin", "centernet", "roi", "compositor", "solver", "heads", "postprocess", "pool", "bsgal", "augment"]
+    which = sys.argv[1:] or ["swin", "centernet", "roi", "compositor", "solver", "heads", "heads_wide", "postprocess", "pool", "bsgal", "augment"]
     for w in which:
         globals()["gen_" + w]()

@@ -408,36 +408,44 @@ def test_adamw_ema_step_vs_oracle():
 
 
 # ------------------------------------------------------------------ conv path (im2col + GEMM)
-@pytest.mark.parametrize("stride,dt", [(1, torch.float32), (2, torch.float32), (1, torch.bfloat16)])
-def test_conv3x3_matches_torch_cpu(stride, dt):
+def _close(got, ref, frac, what=""):
+    """|got - ref| <= frac * max|ref|: the tolerance of a bf16-operand / fp32-accumulate kernel against fp32 math on the SAME
+    bf16-rounded operands is stated relative to the tensor's scale (bf16 results carry 2^-9 relative rounding)."""
+    err = float((got.float().cpu() - ref.float()).abs().max())
+    assert err <= frac * float(ref.abs().max()) + 1e-6, (what, err, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("stride", [1, 2])
+def test_conv3x3_matches_torch_cpu(stride):
+    """3x3 convolutions (im2col + MFMA GEMM; Cin 16 is below the implicit-GEMM path's 64), ConvTranspose2d(2, 2) and the 4x4
+    patch embedding against torch-CPU fp32 on the same bf16-rounded operands: values and all gradients."""
     from divergen_amd.layers.conv_ops import conv3x3, deconv2x2, patch_embed4x4
     g = torch.Generator().manual_seed(51)
-    x = torch.randn(2, 16, 13, 18, generator=g)
-    w = torch.randn(24, 16, 3, 3, generator=g) * 0.1
-    b = torch.randn(24, generator=g)
+    x = bf(torch.randn(2, 16, 13, 18, generator=g))
+    w = bf(torch.randn(24, 16, 3, 3, generator=g) * 0.1)
+    b = bf(torch.randn(24, generator=g))
     xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
     ref = torch.nn.functional.conv2d(xr, wr, br, stride=stride, padding=1)
-    go = torch.randn(ref.shape, generator=g)
+    go = bf(torch.randn(ref.shape, generator=g))
     ref.backward(go)
     xd, wd, bd = [t.to(DEV).requires_grad_(True) for t in (x, w, b)]
-    got = conv3x3(xd.to(dt), wd, bd, stride)
-    got.backward(go.to(DEV).to(dt))
-    tol = dict(atol=1e-4, rtol=1e-4) if dt == torch.float32 else dict(atol=8e-2, rtol=5e-2)  # bf16 operands
-    torch.testing.assert_close(got.float().cpu(), ref.detach(), **tol)
-    torch.testing.assert_close(xd.grad.cpu(), xr.grad, **tol)
-    torch.testing.assert_close(wd.grad.cpu(), wr.grad, **(tol if dt == torch.float32 else dict(atol=0.3, rtol=5e-2)))
-    torch.testing.assert_close(bd.grad.cpu(), br.grad, **(tol if dt == torch.float32 else dict(atol=0.3, rtol=5e-2)))
-    if dt == torch.float32 and stride == 1:
-        wt = torch.randn(16, 8, 2, 2, generator=g)
-        bt = torch.randn(8, generator=g)
-        torch.testing.assert_close(deconv2x2(x.to(DEV), wt.to(DEV), bt.to(DEV)).cpu(),
-                                   torch.nn.functional.conv_transpose2d(x, wt, bt, stride=2), atol=1e-4, rtol=1e-4)
-        img = torch.randn(2, 3, 16, 24, generator=g)
-        wp = torch.randn(32, 3, 4, 4, generator=g)
-        bp = torch.randn(32, generator=g)
+    got = conv3x3(xd, wd, bd, stride)
+    assert got.dtype == torch.bfloat16
+    got.backward(go.to(DEV).to(torch.bfloat16))
+    _close(got, ref.detach(), 8e-3, "y")
+    _close(xd.grad, xr.grad, 8e-3, "dx")
+    _close(wd.grad, wr.grad, 8e-3, "dw")
+    _close(bd.grad, br.grad, 8e-3, "db")
+    if stride == 1:
+        xt = bf(torch.randn(2, 16, 13, 18, generator=g))
+        wt = bf(torch.randn(16, 8, 2, 2, generator=g))
+        bt = bf(torch.randn(8, generator=g))
+        _close(deconv2x2(xt.to(DEV), wt.to(DEV), bt.to(DEV)), torch.nn.functional.conv_transpose2d(xt, wt, bt, stride=2), 8e-3, "deconv")
+        img = bf(torch.randn(2, 3, 16, 24, generator=g))
+        wp = bf(torch.randn(32, 3, 4, 4, generator=g))
+        bp = bf(torch.randn(32, generator=g))
         tok, hp, wp_ = patch_embed4x4(img.to(DEV), wp.to(DEV), bp.to(DEV))
-        refp = torch.nn.functional.conv2d(img, wp, bp, stride=4).flatten(2).transpose(1, 2)
-        torch.testing.assert_close(tok.cpu(), refp, atol=1e-4, rtol=1e-4)
+        _close(tok, torch.nn.functional.conv2d(img, wp, bp, stride=4).flatten(2).transpose(1, 2), 8e-3, "patch_embed")
 
 
 @pytest.mark.parametrize("M,Nn,Kk", [(16384, 576, 192), (20000, 192, 768), (16384 + 17, 1152, 384), (17000, 64, 72)])

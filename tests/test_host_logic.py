@@ -366,3 +366,20 @@ def test_pending_weight_gradients_never_leak_into_the_next_step():
         warnings.simplefilter("always")
         arena.zero_grad()
     assert not w
+
+
+def test_bench_launches_its_own_ranks_gloo():
+    """`python bench.py --gpus 2` without a launcher around it must start one process per rank itself (re-exec under
+    torch.distributed.run, as DG/train_net.py:357-362 does through detectron2's launch()) and reach the collective self-check:
+    run here over gloo without a GPU (--launch-check: rendezvous + all-reduce probe + the JSON line, no model)."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, DGX_DIST_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--launch-check"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["ranks_seen_by_collective"] == 2 and line["n_gpus"] == 2 and line["launched_by"] == "torchrun"

@@ -1,7 +1,6 @@
 """Dev helper: kernel-level profile of the FPN top-down + CenterNet tower (eager, fwd+bwd) on bench shapes."""
 import sys
 sys.path.insert(0, ".")
-from divergen_amd.tuning import enable as _e; _e()
 import torch
 from torch.profiler import ProfilerActivity, profile
 from divergen_amd.config import get_cfg

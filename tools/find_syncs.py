@@ -1,7 +1,6 @@
 """Dev helper: list the source lines that force a device->host synchronisation in one training step."""
 import sys, warnings, collections, traceback
 sys.path.insert(0, ".")
-from divergen_amd.tuning import enable as _e; _e()
 import torch
 import numpy as np
 from divergen_amd.config import get_cfg

@@ -1,7 +1,6 @@
 """Dev helper: per-shape GEMM time in one training step (torch profiler, record_shapes)."""
 import os, sys, time
 sys.path.insert(0, ".")
-from divergen_amd.tuning import enable as _e; _e()
 import torch
 sys.path.insert(0, ".")
 from torch.profiler import ProfilerActivity, profile

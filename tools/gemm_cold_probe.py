@@ -5,8 +5,6 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from divergen_amd.tuning import enable as _enable  # noqa: E402
-_enable()
 import torch  # noqa: E402
 from divergen_amd.layers import gemm_ops as G  # noqa: E402
 

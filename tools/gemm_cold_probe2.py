@@ -2,8 +2,6 @@
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from divergen_amd.tuning import enable as _enable
-_enable()
 import torch
 from divergen_amd.layers import gemm_ops as G
 from tools.gemm_cold_probe import run

@@ -11,8 +11,6 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from divergen_amd.tuning import enable as _enable  # noqa: E402
-_enable()
 import torch  # noqa: E402
 
 

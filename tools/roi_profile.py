@@ -1,7 +1,6 @@
 """Dev helper: op-level profile (host + device) of the RoI heads' forward only."""
 import sys
 sys.path.insert(0, ".")
-from divergen_amd.tuning import enable as _e; _e()
 import torch
 from torch.profiler import ProfilerActivity, profile
 from divergen_amd.config import get_cfg

@@ -20,8 +20,6 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-from divergen_amd.tuning import enable as _enable_tuned_gemm  # noqa: E402
-_enable_tuned_gemm()      # library-GEMM algorithm table for this model's shapes (before the first GEMM)
 
 import torch  # noqa: E402
 
@@ -76,9 +74,42 @@ def build_train_loader(cfg, device, seed=None):
         it += 1
 
 
-def do_test(cfg, model):
+class ema_weights:
+    """Context: the model computes with the optimizer's EMA weights (DG/train_net.py:62-64 evaluates `model_ema.ema`, a second
+    module; here the EMA is an arena, swapped with the live weights for the duration and swapped back, bf16 shadows included)."""
+
+    def __init__(self, optimizer):
+        self.opt = optimizer if (optimizer is not None and getattr(optimizer, "ema", None) is not None) else None
+
+    def _swap(self):
+        a = self.opt.arena
+        tmp = a.p.clone()
+        a.p.copy_(self.opt.ema)
+        self.opt.ema.copy_(tmp)
+        a.sync_shadow()
+
+    def __enter__(self):
+        if self.opt is not None:
+            self._swap()
+
+    def __exit__(self, *exc):
+        if self.opt is not None:
+            self._swap()
+
+
+def do_test(cfg, model, optimizer=None):
     """DG/train_net.py:62-126 for LVIS-type test sets: test loader (one image per batch, sharded over ranks), GPU
-    post-processing + run-length encoding, results json, box / mask AP."""
+    post-processing + run-length encoding, results json, box / mask AP.  `optimizer` with an EMA arena: the EMA weights are
+    the ones evaluated (:63-64)."""
+    with ema_weights(optimizer):
+        was_training = model.training
+        try:
+            return _do_test(cfg, model)
+        finally:
+            model.train(was_training)
+
+
+def _do_test(cfg, model):
     from collections import OrderedDict
     from divergen_amd.data.build import build_detection_test_loader
     from divergen_amd.evaluation import LVISEvaluator, inference_on_dataset, print_csv_format
@@ -150,7 +181,12 @@ def do_train(cfg, model, resume=False):
             storage.put_scalars(time=time.perf_counter() - t_step)
             t_data = time.perf_counter()
             scheduler.step()
-            saves_now = cfg.SOLVER.CHECKPOINT_PERIOD > 0 and iteration % cfg.SOLVER.CHECKPOINT_PERIOD == 0
+            if cfg.TEST.EVAL_PERIOD > 0 and iteration % cfg.TEST.EVAL_PERIOD == 0 and iteration != max_iter:      # DG/train_net.py:294-298
+                do_test(cfg, model, optimizer)
+                comm.synchronize()
+            # the checkpointer's own predicate (PeriodicCheckpointer.step): the deferred finite-loss check runs before it can save
+            saves_now = (cfg.SOLVER.CHECKPOINT_PERIOD > 0 and (iteration + 1) % cfg.SOLVER.CHECKPOINT_PERIOD == 0) \
+                or iteration >= max_iter - 1
             if (iteration - start_iter > 5 and (iteration % 20 == 0 or iteration == max_iter)) or saves_now:
                 for it, ld in pending:               # one sync for 20 iterations of losses
                     red = {k: float(v) for k, v in comm.reduce_dict(ld).items()}
@@ -163,6 +199,7 @@ def do_train(cfg, model, resume=False):
             extra = {"model_ema": kwargs["model_ema"].state_dict()} if kwargs else {}
             periodic.step(iteration, **extra)
         logger.info("Total training time: {}".format(str(datetime.timedelta(seconds=int(time.perf_counter() - t_start)))))
+    return optimizer
 
 
 def setup(args):
@@ -190,9 +227,14 @@ def main(args):
     cfg = setup(args)
     model = build_model(cfg)
     if args.eval_only:
-        DetectionCheckpointer(model, save_dir=cfg.OUTPUT_DIR).resume_or_load(cfg.MODEL.WEIGHTS, resume=args.resume)
+        # DG/train_net.py:340-354: with SOLVER.MODEL_EMA > 0 the checkpoint's EMA weights are the model that is evaluated
+        key = "model_ema" if cfg.SOLVER.MODEL_EMA > 0 else "model"
+        DetectionCheckpointer(model, save_dir=cfg.OUTPUT_DIR).resume_or_load(cfg.MODEL.WEIGHTS, resume=args.resume, model_key=key)
         return do_test(cfg, model.to(torch.device(cfg.MODEL.DEVICE)))
-    do_train(cfg, model, resume=args.resume)
+    optimizer = do_train(cfg, model, resume=args.resume)
+    res = do_test(cfg, model, optimizer)        # DG/train_net.py:368: the EMA weights when there are any
+    comm.synchronize()
+    return res
 
 
 if __name__ == "__main__":

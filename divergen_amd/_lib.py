@@ -17,7 +17,7 @@ c_p, c_i, c_f, c_i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_i
 
 class WgradProblem(ctypes.Structure):
     """struct dgx_wgrad_problem (include/divergen_hip.h)."""
-    _fields_ = [("dy", c_p), ("x", c_p), ("gw", c_p), ("M", c_i), ("Nn", c_i), ("Kk", c_i)]
+    _fields_ = [("dy", c_p), ("x", c_p), ("gw", c_p), ("M", c_i), ("Nn", c_i), ("Kk", c_i), ("gb", c_p)]
 
 
 class GemmEpilogue(ctypes.Structure):
@@ -69,6 +69,9 @@ SIGNATURES = {
     "dgx_nms_batched": (c_i, [c_p, c_p, c_p, c_i, c_i, c_f, c_i, c_p, c_p, c_i, c_p, c_p]),
     "dgx_iou_match": (c_i, [c_p, c_i, c_p, c_i, c_f, c_p, c_p, c_p, c_p]),
     "dgx_centernet_targets": (c_i, [c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_f, c_f, c_p, c_p, c_p]),
+    "dgx_roi_label": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_i, c_f, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "dgx_roi_gather": (c_i, [c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f] + [c_p] * 10 + [c_p]),
+    "dgx_centernet_label_inds": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_p]),
     "dgx_copy_paste": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p]),
     "dgx_im2col3x3": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "dgx_col2im3x3": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
@@ -96,6 +99,9 @@ SIGNATURES = {
     "dgx_centernet_losses_blocks": (c_i, [c_i]),
     "dgx_centernet_losses": (c_i, [c_p] * 6 + [c_i, c_i, c_i, c_i] + [c_f] * 6 + [c_p] * 5 + [c_p]),
     "dgx_detic_losses": (c_i, [c_p] * 7 + [c_i, c_i, c_f, c_f, c_f, c_f, c_p, c_p, c_p, c_p, c_i, c_p]),
+    "dgx_detic_losses_strided": (c_i, [c_p, c_i64, c_p, c_i64] + [c_p] * 5 + [c_i, c_i, c_f, c_f, c_f, c_f, c_p, c_i64, c_i, c_p, c_p, c_p, c_i, c_p]),
+    "dgx_detic_grad_scale": (c_i, [c_p, c_i64, c_i, c_i, c_p, c_p, c_p, c_i, c_p]),
+    "dgx_fed_class_mask": (c_i, [c_p, c_i, c_p, c_p, c_i, c_i, c_p, c_p]),
     "dgx_gelu_fwd": (c_i, [c_p, c_p, c_i64, c_p]),
     "dgx_gelu_bwd_workspace_bytes": (c_i64, [c_i, c_i]),
     "dgx_gelu_bwd_colsum": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_p, c_p]),

@@ -103,3 +103,42 @@ extern "C" int dgx_centernet_targets(const float* gt_boxes, const int32_t* gt_of
     DGX_LAUNCH_CHECK();
     return DGX_OK;
 }
+
+
+// Positive-location indices of the CenterNet losses (CN/modeling/dense_heads/centernet.py:439-483 `_get_label_inds`): for
+// every ground-truth box and every FPN level the flat index (level-major layout: level, image, y, x) of the location that
+// holds the box centre, and whether the box's size falls into the level's size-of-interest range.  One thread per
+// (box, level); the float sequence is the reference's (centre = (x0 + x1) / 2, / stride, truncation; half diagonal).
+__global__ __launch_bounds__(256) void centernet_label_inds_kernel(const float* __restrict__ gt, const int32_t* __restrict__ offs, CtLevels P,
+                                                                   int total, int64_t* __restrict__ ind, uint8_t* __restrict__ cared) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= total * P.L) return;
+    const int n = t / P.L, l = t - n * P.L;
+    int img = 0;
+    while (img + 1 < P.B && n >= offs[img + 1]) ++img;
+    const float x0 = gt[4 * n], y0 = gt[4 * n + 1], x1 = gt[4 * n + 2], y1 = gt[4 * n + 3];
+    const float st = (float)P.stride[l];
+    const int64_t cx = (int64_t)(((x0 + x1) / 2.0f) / st), cy = (int64_t)(((y0 + y1) / 2.0f) / st);
+    ind[t] = P.out_base[l] + (int64_t)img * P.h[l] * P.w[l] + cy * P.w[l] + cx;
+    const float dx = x1 - x0, dy = y1 - y0;
+    const float crit = sqrtf(dx * dx + dy * dy) / 2.0f;
+    cared[t] = (crit >= P.lo[l] && crit <= P.hi[l]) ? 1 : 0;
+}
+extern "C" int dgx_centernet_label_inds(const float* gt_boxes, const int32_t* gt_offsets, int B, int total, const int32_t* level_hw,
+                                        const int32_t* strides, const float* soi, int L, int64_t* ind, uint8_t* cared, void* stream) {
+    if (B <= 0 || total <= 0) return DGX_OK;
+    if (!gt_boxes || !gt_offsets || !level_hw || !strides || !soi || !ind || !cared || L < 1 || L > CT_MAX_LEVELS) return DGX_ERR_BAD_ARG;
+    CtLevels P = {};
+    P.L = L; P.B = B;
+    int64_t ob = 0;
+    for (int l = 0; l < L; ++l) {
+        P.h[l] = level_hw[2 * l]; P.w[l] = level_hw[2 * l + 1]; P.stride[l] = strides[l];
+        P.lo[l] = soi[2 * l]; P.hi[l] = soi[2 * l + 1];
+        P.out_base[l] = ob;
+        ob += (int64_t)B * P.h[l] * P.w[l];
+    }
+    hipLaunchKernelGGL(centernet_label_inds_kernel, dim3((total * L + 255) / 256), dim3(256), 0, (hipStream_t)stream, gt_boxes, gt_offsets, P,
+                       total, ind, cared);
+    DGX_LAUNCH_CHECK();
+    return DGX_OK;
+}

@@ -25,14 +25,15 @@ __global__ __launch_bounds__(256) void detic_rows_kernel(const T* __restrict__ l
                                                          const float* __restrict__ prop, const float* __restrict__ gtb,
                                                          const int64_t* __restrict__ src, int R, int C, float wx, float wy,
                                                          float ww, float wh, T* __restrict__ dlogits, float* __restrict__ dsign,
-                                                         float* __restrict__ part) {
+                                                         float* __restrict__ part, int64_t ldx, int64_t ldd, int64_t ldg,
+                                                         int gcols) {
     __shared__ float red_l[4];
     __shared__ float red_v[4];
     __shared__ int red_i[4];
     const int r = blockIdx.x;
     const int64_t g = gt[r];
-    const T* x = logits + (int64_t)r * (C + 1);
-    T* dx = dlogits + (int64_t)r * (C + 1);
+    const T* x = logits + (int64_t)r * ldx;
+    T* dx = dlogits + (int64_t)r * ldg;
     const bool row_on = g >= 0;      // gt < 0: "ignore" row (dropped by the reference before the loss): no loss, no gradient
     float loss = 0.f, best = -INFINITY;
     int besti = 0x7fffffff;
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(256) void detic_rows_kernel(const T* __restrict__ l
             const float tg[4] = {wx * (tx - sx) / sw, wy * (ty - sy) / sh, ww * logf(tw / sw), wh * logf(th / sh)};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const float d = ld1<T>(deltas + 4 * (int64_t)r + k) - tg[k];
+                const float d = ld1<T>(deltas + ldd * (int64_t)r + k) - tg[k];
                 lb += fabsf(d);
                 sg[k] = d > 0.f ? 1.0f : (d < 0.f ? -1.0f : 0.0f);
             }
@@ -89,6 +90,9 @@ __global__ __launch_bounds__(256) void detic_rows_kernel(const T* __restrict__ l
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) dsign[4 * (int64_t)r + k] = sg[k];
+        // joint layout (gcols > C + 1): the gradient row also carries the box-delta signs behind the logits and zero columns
+        // up to gcols -- the K-padded operand of the predictor's input- and weight-gradient GEMMs (scaled later in place)
+        for (int k = C + 1; k < gcols; ++k) st1<T>(dx + k, k < C + 5 ? sg[k - C - 1] : 0.0f);
         float* o = part + (int64_t)r * NPART;
         o[0] = L;
         o[1] = lb;
@@ -137,24 +141,113 @@ __global__ __launch_bounds__(256) void detic_fold_kernel(const float* __restrict
     }
 }
 
-extern "C" int dgx_detic_losses(const void* logits, const void* deltas, const int64_t* gt_classes, const float* class_w,
-                                const float* prop, const float* gtb, const int64_t* src, int R, int C, float wx, float wy,
-                                float ww, float wh, void* dlogits, float* dsign, float* out16, float* part, int dtype,
-                                void* stream) {
+extern "C" int dgx_detic_losses_strided(const void* logits, int64_t ld_logits, const void* deltas, int64_t ld_deltas,
+                                        const int64_t* gt_classes, const float* class_w, const float* prop, const float* gtb,
+                                        const int64_t* src, int R, int C, float wx, float wy, float ww, float wh, void* dlogits,
+                                        int64_t ld_dlogits, int grad_cols, float* dsign, float* out16, float* part, int dtype,
+                                        void* stream) {
     if (!out16) return DGX_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (R <= 0) {
         (void)hipMemsetAsync(out16, 0, 16 * sizeof(float), st);
         return DGX_OK;
     }
-    if (!logits || !deltas || !gt_classes || !prop || !gtb || !dlogits || !dsign || !part || C <= 0) return DGX_ERR_BAD_ARG;
+    if (!logits || !deltas || !gt_classes || !prop || !gtb || !dlogits || !dsign || !part || C <= 0 || ld_logits < C + 1 ||
+        ld_deltas < 4 || ld_dlogits < C + 1 || (grad_cols > C + 1 && (grad_cols < C + 5 || grad_cols > ld_dlogits)))
+        return DGX_ERR_BAD_ARG;
     if (dtype == DGX_BF16)
         hipLaunchKernelGGL(detic_rows_kernel<uint16_t>, dim3(R), dim3(256), 0, st, (const uint16_t*)logits, (const uint16_t*)deltas,
-                           gt_classes, class_w, prop, gtb, src, R, C, wx, wy, ww, wh, (uint16_t*)dlogits, dsign, part);
+                           gt_classes, class_w, prop, gtb, src, R, C, wx, wy, ww, wh, (uint16_t*)dlogits, dsign, part, ld_logits,
+                           ld_deltas, ld_dlogits, grad_cols);
     else
         hipLaunchKernelGGL(detic_rows_kernel<float>, dim3(R), dim3(256), 0, st, (const float*)logits, (const float*)deltas, gt_classes,
-                           class_w, prop, gtb, src, R, C, wx, wy, ww, wh, (float*)dlogits, dsign, part);
+                           class_w, prop, gtb, src, R, C, wx, wy, ww, wh, (float*)dlogits, dsign, part, ld_logits, ld_deltas,
+                           ld_dlogits, grad_cols);
     hipLaunchKernelGGL(detic_fold_kernel, dim3(1), dim3(256), 0, st, part, R, out16);
+    DGX_LAUNCH_CHECK();
+    return DGX_OK;
+}
+
+extern "C" int dgx_detic_losses(const void* logits, const void* deltas, const int64_t* gt_classes, const float* class_w,
+                                const float* prop, const float* gtb, const int64_t* src, int R, int C, float wx, float wy,
+                                float ww, float wh, void* dlogits, float* dsign, float* out16, float* part, int dtype,
+                                void* stream) {
+    return dgx_detic_losses_strided(logits, C + 1, deltas, 4, gt_classes, class_w, prop, gtb, src, R, C, wx, wy, ww, wh, dlogits,
+                                    C + 1, 0, dsign, out16, part, dtype, stream);
+}
+
+// In-place scaling of a joint gradient buffer (rows, ld) written by dgx_detic_losses_strided: columns [0, C + 1) by
+// g_cls * out16[14], columns [C + 1, C + 5) by g_box * out16[10] -- the two loss terms' backward scales, all on the device.
+template <typename T>
+__global__ __launch_bounds__(256) void detic_grad_scale_kernel(T* __restrict__ dy, int64_t ld, int rows, int C1, const float* __restrict__ out16,
+                                                               const float* __restrict__ g_cls, const float* __restrict__ g_box) {
+    const float sc = g_cls[0] * out16[14], sb = g_box[0] * out16[10];
+    const int cols = C1 + 4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)rows * cols; i += (int64_t)gridDim.x * 256) {
+        const int r = (int)(i / cols), c = (int)(i - (int64_t)r * cols);
+        T* p = dy + (int64_t)r * ld + c;
+        st1<T>(p, ld1<T>(p) * (c < C1 ? sc : sb));
+    }
+}
+extern "C" int dgx_detic_grad_scale(void* dy, int64_t ld, int rows, int C, const float* out16, const float* g_cls, const float* g_box,
+                                    int dtype, void* stream) {
+    if (rows <= 0) return DGX_OK;
+    if (!dy || !out16 || !g_cls || !g_box || C <= 0 || ld < C + 5) return DGX_ERR_BAD_ARG;
+    const int64_t n = (int64_t)rows * (C + 5);
+    const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    if (dtype == DGX_BF16)
+        hipLaunchKernelGGL(detic_grad_scale_kernel<uint16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (uint16_t*)dy, ld, rows, C + 1,
+                           out16, g_cls, g_box);
+    else
+        hipLaunchKernelGGL(detic_grad_scale_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (float*)dy, ld, rows, C + 1, out16,
+                           g_cls, g_box);
+    DGX_LAUNCH_CHECK();
+    return DGX_OK;
+}
+
+// Federated-loss class set (DG/divergen/modeling/utils.py:16-28 get_fed_loss_inds) as a 0/1 mask over C + 1 classes, one
+// workgroup: the classes that appear among gt_classes, plus -- when fewer than K appear -- the (K - #appeared) classes with
+// the largest  prob[c] / expo[c]  among the others (prob > 0).  torch.multinomial(prob, n, replacement=False) IS the top-n of
+// prob / Exponential(1); the caller draws `expo` with torch's generator (one exponential_ call of C + 1 values, the reference's
+// position in the random stream), so the class SET is the reference's for the same generator state.
+__global__ __launch_bounds__(1024) void fed_class_mask_kernel(const int64_t* __restrict__ gt, int R, const float* __restrict__ prob,
+                                                              const float* __restrict__ expo, int C, int K, uint8_t* __restrict__ mask) {
+    extern __shared__ float q[];                    // C + 1 keys, then C + 1 appearance flags (as ints)
+    int* app = reinterpret_cast<int*>(q + C + 1);
+    __shared__ int n_app;
+    for (int c = threadIdx.x; c <= C; c += blockDim.x) app[c] = 0;
+    if (threadIdx.x == 0) n_app = 0;
+    __syncthreads();
+    for (int r = threadIdx.x; r < R; r += blockDim.x) {
+        const int64_t g = gt[r];
+        if (g >= 0 && g <= C) app[(int)g] = 1;      // benign race: every writer stores 1
+    }
+    __syncthreads();
+    int cnt = 0;
+    for (int c = threadIdx.x; c <= C; c += blockDim.x) {
+        cnt += app[c];
+        q[c] = (app[c] || c == C) ? 0.0f : prob[c] / expo[c];
+    }
+    atomicAdd(&n_app, cnt);
+    __syncthreads();
+    const int need = K - n_app;
+    for (int c = threadIdx.x; c <= C; c += blockDim.x) {
+        int take = 0;
+        const float v = q[c];
+        if (need > 0 && v > 0.0f) {
+            int rank = 0;                           // keys that sort in front of this one (value descending, index ascending)
+            for (int o = 0; o <= C; ++o) rank += (q[o] > v || (q[o] == v && o < c)) ? 1 : 0;
+            take = rank < need;
+        }
+        mask[c] = (uint8_t)(app[c] | take);
+    }
+}
+extern "C" int dgx_fed_class_mask(const int64_t* gt_classes, int R, const float* prob, const float* expo, int C, int K, uint8_t* mask,
+                                  void* stream) {
+    if (!prob || !expo || !mask || C <= 0 || R < 0 || (R > 0 && !gt_classes)) return DGX_ERR_BAD_ARG;
+    const size_t sm = (size_t)(C + 1) * 8;
+    if (sm > 64 * 1024) return DGX_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(fed_class_mask_kernel, dim3(1), dim3(1024), sm, (hipStream_t)stream, gt_classes, R, prob, expo, C, K, mask);
     DGX_LAUNCH_CHECK();
     return DGX_OK;
 }

@@ -19,6 +19,7 @@
 //   * read-out: each wave passes its 16-row strips through a private LDS staging area (bf16, bias added) and streams whole
 //     row segments (256 / 192 B) out with the fused tails of gemm_common.h.
 #include "gemm_common.h"
+#include <stdlib.h>
 #include <type_traits>
 
 namespace {
@@ -28,7 +29,9 @@ __device__ __forceinline__ void mfma16_acc(f32x4& c, bf16x8 a, bf16x8 b) {      
 template <int V> using IC = std::integral_constant<int, V>;
 }  // namespace
 
-template <int BN>
+// DIAG (development builds, -DDGX_GEMM_DEV): ablation bits -- 1 no A register loads, 2 no ds_write of A, 4 no LDS-direct B loads,
+// 8 no fragment reads (results are then wrong; only the timing stamps are read)
+template <int BN, int DIAG = 0>
 __global__ __launch_bounds__(256) void gemm256_kernel(GemmP P) {
     constexpr int BM = 256;
     constexpr int WNF = BN / 32;                   // 16-column fragments per wave along N (2 waves): 8 | 6
@@ -44,6 +47,8 @@ __global__ __launch_bounds__(256) void gemm256_kernel(GemmP P) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds_raw[];
     const int L = (blockIdx.x & 7) * P.per_xcd + (blockIdx.x >> 3);      // XCD-aware order: an XCD's workgroups share A row panels
     if (L >= P.total) return;
+#define G2CLK(i) do { if (P.dbg && threadIdx.x == 0) P.dbg[(size_t)blockIdx.x * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+    G2CLK(0);
     const int tm = L / P.tiles_n, tn = L - tm * P.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
     const int tid = threadIdx.x, l = tid & 63;
@@ -81,7 +86,11 @@ __global__ __launch_bounds__(256) void gemm256_kernel(GemmP P) {
     const uint32_t ldsw = __builtin_amdgcn_readfirstlane(lds0 + 1024u * w);
     DGX_LDS unsigned char* const lane_wr = (DGX_LDS unsigned char*)lds_raw + 1024 * w + 16 * l;     // this lane's slot in a row group
 
-    auto tail_mask = [&](int kt, uint32_t v) __attribute__((always_inline)) { return ((kt == NT - 1) && (ktail != GBK) && !kt_ok) ? G_OOB : v; };
+    // K-tiles beyond the problem (the look-ahead of the last tiles) and chunks beyond K in the last tile read as zeros: every load
+    // of the main loop is issued unconditionally, so there is ONE loop body and no branch around a load
+    auto tail_mask = [&](int kt, uint32_t v) __attribute__((always_inline)) {
+        return (kt >= NT || ((kt == NT - 1) && (ktail != GBK) && !kt_ok)) ? G_OOB : v;
+    };
     auto sgpr = [](uint32_t v) __attribute__((always_inline)) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };     // wave-uniform values, pinned scalar
     auto issue_b = [&](int s, int kt, int stage) __attribute__((always_inline)) {       // LDS-direct: B row group w + 4 s of K-tile kt
         g_load_lds16(tail_mask(kt, voffB[s]), rB, sgpr(ldsw + (uint32_t)stage * SB + BOFF + 4096u * s), sgpr((uint32_t)kt * (GBK * 2)));
@@ -114,8 +123,13 @@ __global__ __launch_bounds__(256) void gemm256_kernel(GemmP P) {
     // one sub-step: MFMAs of `cur`, fragment reads into `nxt` (if RD), one memory op per group chosen by MODE -- all compile-time,
     // so that no load sits behind a branch (the compiler's vmcnt bookkeeping turns conservative -- vmcnt(0) -- across branches):
     //   MODE 1: A register loads of K-tile `kt` into `ra` (8 groups);  MODE 2: ds_write of `ra` + LDS-direct B of K-tile kt
+    // PH (0 | 1, by the wave's N half): the two wave classes place their memory operations in DIFFERENT issue groups -- all four
+    // waves run in lock-step behind the barrier, and a memory instruction whose issue waits for the address path behind three
+    // others idles this SIMD's matrix pipe (one wave per SIMD: nothing else can issue).  Measured (tools/gemm_phase_probe.py,
+    // ablations): the 22-24 memory instructions of a K-tile cost ~700 cycles of issue on top of ~1 840 (BN 192) / ~2 350 (BN 256).
     auto substep = [&](const bf16x8 (&cur)[NFR], bf16x8 (&nxt)[NFR], auto rdc, auto rstagec, auto rkhc, auto modec, int kt, auto stagec,
-                       u32x4 (&ra)[8]) __attribute__((always_inline)) {
+                       u32x4 (&ra)[8], auto phc) __attribute__((always_inline)) {
+        constexpr int PH = decltype(phc)::value;
         constexpr bool RD = decltype(rdc)::value != 0;
         constexpr int RSTAGE = decltype(rstagec)::value, RKH = decltype(rkhc)::value, MODE = decltype(modec)::value;
         constexpr int STAGE = decltype(stagec)::value;
@@ -124,17 +138,29 @@ __global__ __launch_bounds__(256) void gemm256_kernel(GemmP P) {
         DGX_LDS const unsigned char* pb = lds_opaque((const unsigned char*)lds_raw + RSTAGE * SB + (lb ^ (RKH ? 64u : 0u)));
 #pragma unroll
         for (int gq = 0; gq < NG; ++gq) {
-            if constexpr (MODE == 1) {
-                if (gq < 8) ra[gq] = load_a_reg(gq, kt);
+            // slot of this group in the wave class's schedule: 16 groups (BN 256): class 0 uses the even groups for its first
+            // kind of operation and the odd ones for the second, class 1 the other way round; 12 groups (BN 192): one kind from the
+            // front, the other from the back, swapped between the classes
+            if constexpr (MODE == 1 && !(DIAG & 1)) {
+                if constexpr (NG == 16) {
+                    if ((gq & 1) == PH) ra[gq >> 1] = load_a_reg(gq >> 1, kt);
+                } else {
+                    if (gq >= 4 * PH && gq < 4 * PH + 8) ra[gq - 4 * PH] = load_a_reg(gq - 4 * PH, kt);
+                }
             }
             if constexpr (MODE == 2) {
-                // every ds_write before the first LDS-direct load: the compiler counts only the register loads it knows (16 in
-                // flight: vmcnt(15 - s) before write s), so an LDS-direct load issued earlier would make those waits reach
-                // into the YOUNGER register loads of A(t + 3)
-                if (gq < 8) store_a(gq, STAGE, ra[gq]);
-                if (gq >= NG - NBL) issue_b(gq - (NG - NBL), kt, STAGE);
+                if constexpr (NG == 16) {
+                    if ((gq & 1) == PH && !(DIAG & 2)) store_a(gq >> 1, STAGE, ra[gq >> 1]);
+                    if ((gq & 1) != PH && !(DIAG & 4)) issue_b(gq >> 1, kt, STAGE);
+                } else if constexpr (PH == 0) {
+                    if (gq < 8 && !(DIAG & 2)) store_a(gq, STAGE, ra[gq]);
+                    if (gq >= NG - NBL && !(DIAG & 4)) issue_b(gq - (NG - NBL), kt, STAGE);
+                } else {
+                    if (gq < NBL && !(DIAG & 4)) issue_b(gq, kt, STAGE);
+                    if (gq >= NG - 8 && !(DIAG & 2)) store_a(gq - (NG - 8), STAGE, ra[gq - (NG - 8)]);
+                }
             }
-            if constexpr (RD) {
+            if constexpr (RD && !(DIAG & 8)) {
                 read_frag(pa, pb, gq, nxt);
                 if (gq + NG < NFR) read_frag(pa, pb, gq + NG, nxt);
             }
@@ -152,17 +178,16 @@ __global__ __launch_bounds__(256) void gemm256_kernel(GemmP P) {
     for (int s = 0; s < 8; ++s) issue_a_lds(s, 0, 0);
 #pragma unroll
     for (int s = 0; s < NBL; ++s) issue_b(s, 0, 0);
-    if (NT > 1) {
 #pragma unroll
-        for (int s = 0; s < 8; ++s) issue_a_lds(s, 1, 1);
+    for (int s = 0; s < 8; ++s) issue_a_lds(s, 1, 1);
 #pragma unroll
-        for (int s = 0; s < NBL; ++s) issue_b(s, 1, 1);
-    }
+    for (int s = 0; s < NBL; ++s) issue_b(s, 1, 1);
     // (always issued: a K-tile beyond the problem reads as zeros and is never written to LDS -- keeps the loads branch-free)
 #pragma unroll
-    for (int s = 0; s < 8; ++s) ra0[s] = load_a_reg(s, NT > 2 ? 2 : NT);
+    for (int s = 0; s < 8; ++s) ra0[s] = load_a_reg(s, 2);
     g_vmcnt<8>();
     g_bar();
+    G2CLK(1);
     {
         DGX_LDS const unsigned char* pa = lds_opaque((const unsigned char*)lds_raw + la);
         DGX_LDS const unsigned char* pb = lds_opaque((const unsigned char*)lds_raw + lb);
@@ -175,31 +200,33 @@ __global__ __launch_bounds__(256) void gemm256_kernel(GemmP P) {
     //   boundary: own B(t + 1) landed (only the A(t + 3) loads are younger), own LDS ops retired, barrier:
     //             every wave has read tile t, and A(t + 1) / B(t + 1) are visible
     //   (t, 1): read fx <- (t + 1, kh 0); A(t + 2): ra[t & 1] -> stage t & 1 (ds_write), then B(t + 2) LDS-direct -> stage t & 1
-    // REM = K-tiles left including this one (4 = "four or more"): which of the look-ahead operations still exist
-    auto ktile = [&](int t, auto parc, auto remc) __attribute__((always_inline)) {
-        constexpr int PAR = decltype(parc)::value, REM = decltype(remc)::value;
-        constexpr bool L3 = REM >= 4, L2 = REM >= 3, N1 = REM >= 2;
-        if constexpr (PAR == 0) substep(fx, fy, IC<1>{}, IC<PAR>{}, IC<1>{}, IC<(L3 ? 1 : 0)>{}, t + 3, IC<0>{}, ra1);
-        else substep(fx, fy, IC<1>{}, IC<PAR>{}, IC<1>{}, IC<(L3 ? 1 : 0)>{}, t + 3, IC<0>{}, ra0);
-        g_lgkm0();
-        if constexpr (L3) g_vmcnt<8>(); else g_vmcnt<0>();
+    auto ktile = [&](int t, auto parc, auto phc) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(parc)::value;
+        if constexpr (PAR == 0) substep(fx, fy, IC<1>{}, IC<PAR>{}, IC<1>{}, IC<1>{}, t + 3, IC<0>{}, ra1, phc);
+        else substep(fx, fy, IC<1>{}, IC<PAR>{}, IC<1>{}, IC<1>{}, t + 3, IC<0>{}, ra0, phc);
+        // s_waitcnt through the builtin: the compiler's own counter model then knows that every LDS read is back and that at
+        // most the 8 register loads just issued are in flight (it would otherwise re-wait in front of the first MFMA / ds_write)
+        __builtin_amdgcn_s_waitcnt(0xC07F);        // lgkmcnt(0)
+        __builtin_amdgcn_s_waitcnt(0x0F78);        // vmcnt(8)
         g_bar();
-        if constexpr (PAR == 0) substep(fy, fx, IC<(N1 ? 1 : 0)>{}, IC<(PAR ^ 1)>{}, IC<0>{}, IC<(L2 ? 2 : 0)>{}, t + 2, IC<PAR>{}, ra0);
-        else substep(fy, fx, IC<(N1 ? 1 : 0)>{}, IC<(PAR ^ 1)>{}, IC<0>{}, IC<(L2 ? 2 : 0)>{}, t + 2, IC<PAR>{}, ra1);
+        if constexpr (DIAG & 16) {                 // dev: the waves of one N half start each K-tile ~64 cycles late (de-correlated issue)
+            if (wn) __builtin_amdgcn_s_sleep(1);
+        }
+        if constexpr (PAR == 0) substep(fy, fx, IC<1>{}, IC<(PAR ^ 1)>{}, IC<0>{}, IC<2>{}, t + 2, IC<PAR>{}, ra0, phc);
+        else substep(fy, fx, IC<1>{}, IC<(PAR ^ 1)>{}, IC<0>{}, IC<2>{}, t + 2, IC<PAR>{}, ra1, phc);
     };
-    int t = 0;
-    for (; NT - t >= 5; t += 2) {                  // steady state: every look-ahead exists for both tiles of the pair
-        ktile(t, IC<0>{}, IC<4>{});
-        ktile(t + 1, IC<1>{}, IC<4>{});
-    }
-    switch (NT - t) {                              // 1 .. 4 tiles left, the first one at even parity
-        case 4: ktile(t, IC<0>{}, IC<4>{}); ktile(t + 1, IC<1>{}, IC<3>{}); ktile(t + 2, IC<0>{}, IC<2>{}); ktile(t + 3, IC<1>{}, IC<1>{}); break;
-        case 3: ktile(t, IC<0>{}, IC<3>{}); ktile(t + 1, IC<1>{}, IC<2>{}); ktile(t + 2, IC<0>{}, IC<1>{}); break;
-        case 2: ktile(t, IC<0>{}, IC<2>{}); ktile(t + 1, IC<1>{}, IC<1>{}); break;
-        default: ktile(t, IC<0>{}, IC<1>{}); break;
-    }
+    auto mainloop = [&](auto phc) __attribute__((always_inline)) {
+        int t = 0;
+        for (; t + 2 <= NT; t += 2) {
+            ktile(t, IC<0>{}, phc);
+            ktile(t + 1, IC<1>{}, phc);
+        }
+        if (t < NT) ktile(t, IC<0>{}, phc);
+    };
+    mainloop(IC<0>{});
     g_vmcnt<0>();
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // last MFMA -> accumulator read-out hazard
+    G2CLK(2);
 
     // ---- read-out.  Mode 3: row -> (token, sample) table for the whole tile first (one thread per row)
     DGX_LDS int64_t* rowtok = reinterpret_cast<DGX_LDS int64_t*>((DGX_LDS unsigned char*)lds_raw + TOK0);
@@ -269,19 +296,22 @@ __global__ __launch_bounds__(256) void gemm256_kernel(GemmP P) {
                 if (ok[k]) g_epi_finish(Q, gm[k], gn[k], y[k], tok[k], sc[k], xa[k], xb[k]);
         }
     };
+    G2CLK(3);
     switch (P.mode) {
         case 2: readout(IC<2>{}); break;
         case 3: readout(IC<3>{}); break;
         case 4: readout(IC<4>{}); break;
+        case 5: readout(IC<5>{}); break;
         default: readout(IC<1>{}); break;          // plain / bias (+ ReLU): bias already added to the staged tile
     }
+    G2CLK(4);
 }
 
 bool gemm256_supported(const GemmP& P) {
     return P.conv_kc == 0 && P.M >= 256 && P.N >= 192 && P.K >= 64;
 }
 
-template <int BN>
+template <int BN, int DIAG = 0>
 static int launch256(GemmP& P, hipStream_t st) {
     constexpr int LDS = 2 * (256 + BN) * 128 + 4 * 16 * (BN + 16) + 256 * 8;
     const int tiles_m = (P.M + 255) / 256;
@@ -291,15 +321,28 @@ static int launch256(GemmP& P, hipStream_t st) {
     P.per_xcd = (P.total + 7) / 8;
     static bool once = false;
     if (!once) {
-        if (hipFuncSetAttribute((const void*)gemm256_kernel<BN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)gemm256_kernel<BN, DIAG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
             return DGX_ERR_UNSUPPORTED;
         once = true;
     }
-    hipLaunchKernelGGL((gemm256_kernel<BN>), dim3(8 * P.per_xcd), dim3(256), LDS, st, P);
+    hipLaunchKernelGGL((gemm256_kernel<BN, DIAG>), dim3(8 * P.per_xcd), dim3(256), LDS, st, P);
     DGX_LAUNCH_CHECK();
     return DGX_OK;
 }
 
 int gemm256_launch(GemmP& P, int bn, hipStream_t st) {
+#ifdef DGX_GEMM_DEV
+    if (const char* dg = getenv("DGX_GEMM_DIAG")) {
+        switch (atoi(dg)) {
+            case 1: return bn == 256 ? launch256<256, 1>(P, st) : launch256<192, 1>(P, st);
+            case 3: return bn == 256 ? launch256<256, 3>(P, st) : launch256<192, 3>(P, st);
+            case 4: return bn == 256 ? launch256<256, 4>(P, st) : launch256<192, 4>(P, st);
+            case 7: return bn == 256 ? launch256<256, 7>(P, st) : launch256<192, 7>(P, st);
+            case 15: return bn == 256 ? launch256<256, 15>(P, st) : launch256<192, 15>(P, st);
+            case 16: return bn == 256 ? launch256<256, 16>(P, st) : launch256<192, 16>(P, st);
+            default: break;
+        }
+    }
+#endif
     return bn == 256 ? launch256<256>(P, st) : launch256<192>(P, st);
 }

@@ -163,7 +163,7 @@ __device__ __forceinline__ float g_gelu_grad(float x) {
 // g_epi_prefetch issues the loads, g_epi_finish does the arithmetic and the stores.  tok / sc: mode 3 token index (>= 0)
 // and DropPath factor of the row.
 __device__ __forceinline__ void g_epi_prefetch(const GemmP& P, int gm, int gn, int64_t tok, u32x4& xa, u32x4& xb) {
-    if (P.mode == 4) {
+    if (P.mode == 4 || P.mode == 5) {
         xa = *reinterpret_cast<const u32x4*>(P.aux + (int64_t)gm * P.ldaux + gn);
     } else if (P.mode == 3) {
         const int64_t o = tok * P.N + gn;
@@ -204,6 +204,16 @@ __device__ __forceinline__ void g_epi_finish(const GemmP& P, int gm, int gn, con
             d[k] = r[0]; d[k + 1] = r[1];
         }
         *reinterpret_cast<u32x4*>(P.C + (int64_t)gm * P.ldc + gn) = g_pack8(d);
+    } else if (P.mode == 5) {                      // ReLU': pass y where the saved activation is positive
+        u32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t a = xa[k];
+            const uint32_t lo = ((a & 0x8000u) || !(a & 0x7fffu)) ? 0u : 0xffffu;
+            const uint32_t hi = ((a & 0x80000000u) || !(a & 0x7fff0000u)) ? 0u : 0xffff0000u;
+            o[k] = y[k] & (lo | hi);
+        }
+        *reinterpret_cast<u32x4*>(P.C + (int64_t)gm * P.ldc + gn) = o;
     } else {                                       // mode 3
         float yv[8], xv[8];
         g_unpack8(y, yv);

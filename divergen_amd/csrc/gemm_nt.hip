@@ -475,7 +475,7 @@ extern "C" int dgx_gemm_bf16_nt(const void* A, const void* B, int M, int N, int 
         case DGX_EPI_BIAS_GELU:
             if (!ep->c || !ep->c2 || ep->ldc < N || (ep->ldc & 7)) return DGX_ERR_BAD_ARG;
             break;
-        case DGX_EPI_GELU_GRAD:
+        case DGX_EPI_GELU_GRAD: case DGX_EPI_RELU_GRAD:
             if (!ep->c || !ep->aux || ep->ldc < N || ep->ldaux < N || (ep->ldc & 7) || (ep->ldaux & 7)) return DGX_ERR_BAD_ARG;
             P.bias = nullptr;
             break;
@@ -497,11 +497,11 @@ extern "C" int dgx_gemm_bf16_nt(const void* A, const void* B, int M, int N, int 
     P.dbg = (unsigned long long*)g_dbg_buffer;
     // algorithmic traffic: both operands once, every result tensor once (residual mode: residual in, sum out, no C)
     const double mn = (double)M * N, rsz = ep->residual_dtype == DGX_F32 ? 4.0 : 2.0;
-    const double obytes = ep->mode == DGX_EPI_BIAS_RESIDUAL ? 2.0 * rsz * mn : (ep->mode >= DGX_EPI_BIAS_GELU ? 4.0 * mn : 2.0 * mn);
+    const double obytes = ep->mode == DGX_EPI_BIAS_RESIDUAL ? 2.0 * rsz * mn : (ep->mode >= DGX_EPI_BIAS_GELU ? 4.0 * mn : 2.0 * mn);   // GELU / GELU' / ReLU': two tensors
     DgxProfScope prof(DGX_PROF_GEMM_NT, stream, 2.0 * mn * K, 2.0 * ((double)M * K + (double)N * K) + obytes);
     if (FILE* lf = gemm_log_file()) { fprintf(lf, "%d %d %d %d %d %d\n", M, N, K, ep->mode, tc.bm, tc.bn); fflush(lf); }
 #ifdef DGX_GEMM_DEV
-    if (const char* dg = getenv("DGX_GEMM_DIAG")) {
+    if (const char* dg = getenv("DGX_GEMM256") ? nullptr : getenv("DGX_GEMM_DIAG")) {
         switch (atoi(dg)) {
             case 1: return launch_gemm<256, 192, 2, 2, 1>(P, st);
             case 2: return launch_gemm<256, 192, 2, 2, 2>(P, st);
@@ -523,12 +523,18 @@ extern "C" int dgx_gemm_bf16_nt(const void* A, const void* B, int M, int N, int 
 
 static int dgx_gemm_dispatch(GemmP& P, hipStream_t st) {
     const TileChoice tc = choose_tile(P.M, P.N);
-    if (const char* e = getenv("DGX_GEMM256")) {          // development: force the 256 x BN kernel where it applies
-        const int bn = atoi(e);
-        if ((bn == 256 || bn == 192) && gemm256_supported(P)) {
-            const int64_t tiles = (int64_t)((P.M + 255) / 256) * ((P.N + bn - 1) / bn);
+    // The 4-wave 256 x BN kernel (gemm256.hip) is NOT dispatched by default.  Measured in round 3 (profiles/r03_gemm256_*.txt):
+    // back to back on hot operands with the bias tail it is 5-18 % faster than the tiles below on the problems that fill the
+    // chip for >= ~1.75 rounds (stage-0 / stage-1 fc1, fc2 input gradient, qkv; stage-2 qkv / fc1), but inside the training step
+    // -- GELU / GELU' / residual tails, operands written by the previous kernel -- the GEMM family came out 0.2-0.3 ms per step
+    // SLOWER with it (13.7 vs 13.4 ms), so the 8-wave kernel stays the product path.  DGX_GEMM256 = 256 | 192 forces the new
+    // kernel wherever it is supported (development, tools/gemm_shapes_probe.py / gemm_phase_probe.py).
+    if (const char* e = getenv("DGX_GEMM256")) {
+        const int force = atoi(e);
+        if ((force == 256 || force == 192) && gemm256_supported(P)) {
             const int nt = (P.K + GBK - 1) / GBK;
-            if (choose_splits(tiles, P.K, P.M, P.N, P.ws ? g_ws_bytes_cur : 0) == 1 || nt < 8 || tiles > 128) return gemm256_launch(P, bn, st);
+            const int64_t tiles = (int64_t)((P.M + 255) / 256) * ((P.N + force - 1) / force);
+            if (choose_splits(tiles, P.K, P.M, P.N, P.ws ? g_ws_bytes_cur : 0) == 1 || nt < 8 || tiles > 128) return gemm256_launch(P, force, st);
         }
     }
     // Measured and dropped (round 2): <128, 192, 2 stages, 4 waves / SIMD> = two co-resident workgroups per CU (80 KB of LDS and

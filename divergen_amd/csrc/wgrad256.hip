@@ -23,6 +23,8 @@ struct Prob256 {
     const uint16_t* A;
     const uint16_t* B;
     float* C;
+    float* gb;          // bias gradient (Nn) = beta*gb + column sums of A, or null
+    float* wsb;         // split problems: partial column sums [S][Nn]
     float* ws;          // partial tiles [S][Nn][Kk]
     int M, Nn, Kk, tiles_k, tiles, S, slab, wg0;
     int ldc;            // row stride of C (elements): Kk for a Linear, 9 Cin for one tap block of a convolution weight
@@ -138,6 +140,25 @@ __global__ __launch_bounds__(256) void wgrad256_partial_kernel(Params256 P) {
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // Bias gradient = column sums of dY = the product of the A fragments with a vector of ones: the workgroups of the first tile
+    // column of a problem run 4 extra MFMAs per wave and stage (+6 %) on fragments they hold anyway -- no second pass over dY,
+    // no extra launch.  The two waves that share an n-half split its 8 fragments (w & 1 selects fragments 4 (w & 1) ..).
+    const bool do_bias = q.gb != nullptr && (tile % q.tiles_k) == 0;
+    f32x4 bacc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bf16x8 ones = {(short)0x3F80, (short)0x3F80, (short)0x3F80, (short)0x3F80, (short)0x3F80, (short)0x3F80, (short)0x3F80, (short)0x3F80};
+    auto bias_mfmas = [&](const bf16x8 (&af)[8]) {
+        if (do_bias) {
+            if (w & 1) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bacc[i] = mfma16(af[4 + i], ones, bacc[i]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bacc[i] = mfma16(af[i], ones, bacc[i]);
+            }
+        }
+    };
 
     // Software pipeline: while the MFMAs of stage st run out of registers, the transpose reads of stage st+1
     // fill the other fragment set and the LDS-direct loads of stages st+2 .. st+4 are in flight.
@@ -156,6 +177,7 @@ __global__ __launch_bounds__(256) void wgrad256_partial_kernel(Params256 P) {
         for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int j = 0; j < 8; ++j) mfma16_agpr(acc[i][j], af[i], bfr[j]);
+        bias_mfmas(af);
     };
     // One pipeline step.  Stage st+1 must have landed for everyone; then, in 16 groups pinned by scheduling
     // barriers, the wave issues {a global->LDS load of stage st+4 (every other group), the two transpose reads of
@@ -176,6 +198,7 @@ __global__ __launch_bounds__(256) void wgrad256_partial_kernel(Params256 P) {
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        bias_mfmas(caf);
     };
     bf16x8 af0[8], bf0[8], af1[8], bf1[8];
     issue(0);
@@ -198,6 +221,17 @@ __global__ __launch_bounds__(256) void wgrad256_partial_kernel(Params256 P) {
     // 16 x 128 strips through a private LDS staging area (the pipeline buffers are idle now) and stores / read-modify-
     // writes 512-byte row segments instead.
     const bool direct = q.S == 1;
+    if (do_bias && c16 == 0) {
+        // D[n][.] layout: lane group g holds rows 4g .. 4g + 3 of the 16-row fragment (replicated over the 16 columns)
+        float* bo = direct ? q.gb : q.wsb + (int64_t)s * q.Nn;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + wn + 16 * (4 * (w & 1) + i) + 4 * g + r;
+                if (n < q.Nn) bo[n] = (direct && P.beta != 0.f) ? P.beta * bo[n] + bacc[i][r] : bacc[i][r];
+            }
+    }
     float* out = direct ? q.C : q.ws + (int64_t)s * q.Nn * q.Kk;
     const float beta = direct ? P.beta : 0.f;
     __syncthreads();                                  // every wave is done reading the operand images
@@ -259,6 +293,17 @@ __global__ __launch_bounds__(256) void wgrad256_reduce_kernel(Params256 P, int64
     }
 }
 
+// split problems: gb[n] = beta*gb[n] + sum_s wsb[s][n], one thread per column, fixed order
+__global__ __launch_bounds__(256) void wgrad256_bias_reduce_kernel(Params256 P) {
+    const Prob256& q = P.p[blockIdx.y];
+    if (blockIdx.y >= P.n || q.S <= 1 || !q.gb) return;
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= q.Nn) return;
+    float a = 0.f;
+    for (int s = 0; s < q.S; ++s) a += q.wsb[(int64_t)s * q.Nn + n];
+    q.gb[n] = P.beta != 0.f ? P.beta * q.gb[n] + a : a;
+}
+
 // rows per workgroup R (multiple of BM256) such that sum_p tiles_p * ceil(M_p / R) fits one round of 256 workgroups
 static void plan256(const dgx_wgrad_problem* pr, int n, int* S, int* slab) {
     int tiles[MAXP256], maxM = 0;
@@ -280,11 +325,15 @@ static void plan256(const dgx_wgrad_problem* pr, int n, int* S, int* slab) {
     }
 }
 
-static int64_t ws_floats256(const dgx_wgrad_problem* pr, int n, const int* S, int64_t* off) {
+static int64_t ws_floats256(const dgx_wgrad_problem* pr, int n, const int* S, int64_t* off, int64_t* offb = nullptr) {
     int64_t tot = 0;
     for (int i = 0; i < n; ++i) {
         if (off) off[i] = tot;
         if (S[i] > 1) tot += (int64_t)S[i] * pr[i].Nn * pr[i].Kk;
+    }
+    for (int i = 0; i < n; ++i) {                  // partial column sums of the split problems that carry a bias gradient
+        if (offb) offb[i] = tot;
+        if (S[i] > 1 && pr[i].gb) tot += ((int64_t)S[i] * pr[i].Nn + 3) / 4 * 4;
     }
     return tot;
 }
@@ -301,7 +350,7 @@ static int wgrad_grouped_impl(const dgx_wgrad_problem* problems, const int* ldc,
 extern "C" int dgx_linear_wgrad_grouped(const dgx_wgrad_problem* problems, int n, float beta, void* workspace,
                                         void* stream) {
     double fl = 0.0, by = 0.0;
-    for (int i = 0; problems && i < n && i < MAXP256; ++i) {      // dY, X read once (bf16); fp32 gradient read + written
+    for (int i = 0; problems && i < n && i < MAXP256; ++i) {      // dY, X read once (bf16); fp32 gradient read + written (bias: free)
         fl += 2.0 * problems[i].M * problems[i].Nn * problems[i].Kk;
         by += 2.0 * problems[i].M * ((double)problems[i].Nn + problems[i].Kk) + 8.0 * problems[i].Nn * problems[i].Kk;
     }
@@ -315,7 +364,7 @@ extern "C" int dgx_linear_wgrad_grouped(const dgx_wgrad_problem* problems, int n
 extern "C" int64_t dgx_conv3x3_wgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout) {
     dgx_wgrad_problem pr[9];
     const int64_t Mp = (int64_t)N * (H + 2) * (W + 2);
-    for (int t = 0; t < 9; ++t) { pr[t].dy = pr[t].x = nullptr; pr[t].gw = nullptr; pr[t].M = (int)Mp; pr[t].Nn = Cout; pr[t].Kk = Cin; }
+    for (int t = 0; t < 9; ++t) { pr[t].dy = pr[t].x = nullptr; pr[t].gw = nullptr; pr[t].gb = nullptr; pr[t].M = (int)Mp; pr[t].Nn = Cout; pr[t].Kk = Cin; }
     return dgx_wgrad_grouped_workspace_bytes(pr, 9);
 }
 extern "C" int dgx_conv3x3_wgrad(const void* dypad, const void* xpad, float* gw, int N, int H, int W, int Cin, int Cout, float beta,
@@ -330,6 +379,7 @@ extern "C" int dgx_conv3x3_wgrad(const void* dypad, const void* xpad, float* gw,
         pr[t].dy = (const uint16_t*)dypad + (int64_t)(wp + 1) * Cout;                          // grid position 0 (behind the slack)
         pr[t].x = (const uint16_t*)xpad + (int64_t)((t / 3) * wp + t % 3) * Cin;               // position 0 shifted by tap - (wp + 1)
         pr[t].gw = gw + (int64_t)t * Cin;
+        pr[t].gb = nullptr;
         pr[t].M = (int)Mp; pr[t].Nn = Cout; pr[t].Kk = Cin;
         ldc[t] = 9 * Cin;
     }
@@ -347,9 +397,9 @@ static int wgrad_grouped_impl(const dgx_wgrad_problem* problems, const int* ldc,
         if ((int64_t)p.M * p.Nn * 2 >= (1ll << 31) || (int64_t)p.M * p.Kk * 2 >= (1ll << 31)) return DGX_ERR_UNSUPPORTED;
     }
     int S[MAXP256], slab[MAXP256];
-    int64_t off[MAXP256];
+    int64_t off[MAXP256], offb[MAXP256];
     plan256(problems, n, S, slab);
-    ws_floats256(problems, n, S, off);
+    ws_floats256(problems, n, S, off, offb);
     Params256 P;
     P.n = n;
     P.beta = beta;
@@ -361,6 +411,8 @@ static int wgrad_grouped_impl(const dgx_wgrad_problem* problems, const int* ldc,
         q.A = (const uint16_t*)p.dy;
         q.B = (const uint16_t*)p.x;
         q.C = p.gw;
+        q.gb = p.gb;
+        q.wsb = (float*)workspace + offb[i];
         q.ws = (float*)workspace + off[i];
         q.M = p.M; q.Nn = p.Nn; q.Kk = p.Kk;
         q.ldc = ldc ? ldc[i] : p.Kk;
@@ -400,6 +452,13 @@ static int wgrad_grouped_impl(const dgx_wgrad_problem* problems, const int* ldc,
             const int grid = (int)((red + 255) / 256 < 8192 ? (red + 255) / 256 : 8192);
             hipLaunchKernelGGL(wgrad256_reduce_kernel<1>, dim3(grid), dim3(256), 0, st, P, red);
         }
+    }
+    {
+        int maxNn = 0;
+        bool any = false;
+        for (int i = 0; i < n; ++i)
+            if (S[i] > 1 && problems[i].gb) { any = true; maxNn = problems[i].Nn > maxNn ? problems[i].Nn : maxNn; }
+        if (any) hipLaunchKernelGGL(wgrad256_bias_reduce_kernel, dim3((maxNn + 255) / 256, n), dim3(256), 0, st, P);
     }
     DGX_LAUNCH_CHECK();
     return DGX_OK;

@@ -14,7 +14,7 @@ import torch
 from .. import _lib as L
 
 BF16 = torch.bfloat16
-EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL, EPI_GELU_GRAD = 0, 1, 2, 3, 4
+EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL, EPI_GELU_GRAD, EPI_RELU_GRAD = 0, 1, 2, 3, 4, 5
 
 
 def _check2(a, b):
@@ -105,6 +105,19 @@ def gemm_gelu_grad(a, b, f1):
     ep = L.GemmEpilogue()
     ep.mode = EPI_GELU_GRAD
     ep.c, ep.ldc, ep.aux, ep.ldaux = c.data_ptr(), N, f1.data_ptr(), N
+    _launch(a, b, ep)
+    return c
+
+
+def gemm_relu_grad(a, b, act):
+    """bf16 (M, N) = (a b^T) where act > 0 else 0: the input gradient of the layer that follows a ReLU, carried through it."""
+    _check2(a, b)
+    M, N = a.shape[0], b.shape[0]
+    assert act.shape == (M, N) and act.dtype == BF16 and act.is_contiguous()
+    c = torch.empty(M, N, dtype=BF16, device=a.device)
+    ep = L.GemmEpilogue()
+    ep.mode = EPI_RELU_GRAD
+    ep.c, ep.ldc, ep.aux, ep.ldaux = c.data_ptr(), N, act.data_ptr(), N
     _launch(a, b, ep)
     return c
 

@@ -18,7 +18,7 @@ def pad8(n):
     return (n + 7) // 8 * 8
 
 
-def wgrad_into(g2, dy2, x2, beta=1.0):
+def wgrad_into(g2, dy2, x2, beta=1.0, gb=None):
     """g2 fp32 (Nn,Kk) = beta*g2 + dy2^T x2 on the 256x256 split-M MFMA kernel (dgx_linear_wgrad_grouped, a group of
     one).  There is no library route: shapes the kernel does not take raise."""
     M, Nn = dy2.shape
@@ -27,18 +27,23 @@ def wgrad_into(g2, dy2, x2, beta=1.0):
             and M * max(Nn, Kk) * 2 < (1 << 31)):
         raise L.DgxError("wgrad_into: dy %s %s x %s %s -- libdgx takes bf16 GPU operands with widths that are multiples of 8"
                          % (tuple(dy2.shape), dy2.dtype, tuple(x2.shape), x2.dtype))
-    wgrad_grouped([(g2, dy2.contiguous(), x2.contiguous())], beta)
+    wgrad_grouped([(g2, dy2.contiguous(), x2.contiguous(), gb)], beta)
 
 
 def wgrad_grouped(problems, beta=1.0):
-    """[(g2 fp32 (Nn,Kk), dy2 bf16 (M,Nn), x2 bf16 (M,Kk)), ...] (<= 8): g2 = beta*g2 + dy2^T x2, ONE launch
-    (dgx_linear_wgrad_grouped: 256x256 MFMA tiles, M-split sized for the whole group)."""
+    """[(g2 fp32 (Nn,Kk), dy2 bf16 (M,Nn), x2 bf16 (M,Kk)[, gb fp32 (Nn) | None]), ...] (<= 9): g2 = beta*g2 + dy2^T x2 and, with
+    gb, the bias gradient gb = beta*gb + dy2.sum(0) from the same pass -- ONE launch (dgx_linear_wgrad_grouped: 256x256 MFMA
+    tiles, M-split sized for the whole group)."""
     n = len(problems)
     arr = (L.WgradProblem * n)()
-    for i, (g2, dy2, x2) in enumerate(problems):
+    for i, pr in enumerate(problems):
+        g2, dy2, x2 = pr[:3]
+        gb = pr[3] if len(pr) > 3 else None
         assert g2.is_contiguous() and dy2.is_contiguous() and x2.is_contiguous()
         assert dy2.dtype == BF16 and x2.dtype == BF16 and g2.dtype == torch.float32
+        assert gb is None or (gb.dtype == torch.float32 and gb.is_contiguous() and gb.numel() == dy2.shape[1])
         arr[i].dy, arr[i].x, arr[i].gw = dy2.data_ptr(), x2.data_ptr(), g2.data_ptr()
+        arr[i].gb = gb.data_ptr() if gb is not None else None
         arr[i].M, arr[i].Nn, arr[i].Kk = dy2.shape[0], dy2.shape[1], x2.shape[1]
     lib = L.lib()
     nbytes = int(lib.dgx_wgrad_grouped_workspace_bytes(arr, n))
@@ -88,7 +93,9 @@ def shadow_padded(p):
     the 1- and 4-channel CenterNet predictors as Linears): N rounded up to 8 with zero rows.  Inside a FlatArena the padding
     lives in the arena itself (`_dgx16p`: the rows behind the parameter's own are part of its segment and stay zero under
     AdamW / EMA because their gradient is zero), so the GEMMs read it without a per-step copy; before that a padded copy."""
-    s = getattr(p, "_dgx16p", None)
+    s = getattr(p, "_dgx16g", None)            # member of an arena parameter group: the whole group's rows
+    if s is None:
+        s = getattr(p, "_dgx16p", None)
     if s is not None:
         return s
     w = shadow(p)
@@ -102,7 +109,9 @@ def shadow_padded(p):
 
 def shadow_t_padded(p):
     """(K, pad8(N)) twin of `shadow_padded(weight)`: the B operand of the input-gradient GEMM."""
-    s = getattr(p, "_dgx16t", None)
+    s = getattr(p, "_dgx16tg", None)
+    if s is None:
+        s = getattr(p, "_dgx16t", None)
     if s is not None and s.shape[1] % 8 == 0 and not getattr(p, "_dgx16t_flipped", False):
         return s
     return shadow_padded(p).t().contiguous()
@@ -110,7 +119,20 @@ def shadow_t_padded(p):
 
 def grad_padded(p):
     """fp32 gradient view with the padded leading dimension (arena), else None."""
-    return getattr(p, "_dgxgp", None)
+    g = getattr(p, "_dgxgg", None)
+    return g if g is not None else getattr(p, "_dgxgp", None)
+
+
+def group_parameters(first_weight_or_bias, *others, pad_to=8):
+    """Tag parameters that always run together on the same input (rows of ONE GEMM operand) as an arena group: see
+    solver.FlatArena.  The first argument is the group's handle (its `_dgx16g` / `_dgx16tg` / `_dgxgg` views span the group)."""
+    members = (first_weight_or_bias,) + others
+    key = ("group", id(first_weight_or_bias))
+    for i, q in enumerate(members):
+        if hasattr(q, "_dgx_pad_rows"):
+            del q._dgx_pad_rows
+        q._dgx_group = (key, i, pad_to)
+        q._dgx_group_members = members
 
 
 def accumulate_grad(p, make_grad_fp32, gemm_into=None):
@@ -123,6 +145,10 @@ def accumulate_grad(p, make_grad_fp32, gemm_into=None):
         else:
             g.add_(make_grad_fp32())
         notify_ready(p)
+        if gemm_into is not None:             # a group's gradient rows are written by its handle's call: signal every member
+            for q in getattr(p, "_dgx_group_members", ()):
+                if q is not p:
+                    notify_ready(q)
         return None
     return make_grad_fp32().to(p.dtype)
 
@@ -163,24 +189,34 @@ class _LinearFn(torch.autograd.Function):
             if ctx.xdtype != BF16:
                 dx = dx.to(ctx.xdtype)
         gw = gb = None
+        bp = grad_padded(bias) if bias is not None else None
+        bias_in_arena = (bias is not None and ctx.needs_input_grad[2] and bias.is_leaf and bias.grad is not None
+                         and bias.grad.dtype == torch.float32 and getattr(bias, "_dgx16", None) is not None and (n % 8 == 0 or bp is not None))
+        bias_done = False
         if ctx.needs_input_grad[1]:
             gp = grad_padded(weight)
+            fuse_bias = bias_in_arena and weight.is_leaf and weight.grad is not None and getattr(weight, "_dgx16", None) is not None \
+                and (n % 8 == 0 or gp is not None)
 
-            def into(g):       # the arena's (padded) gradient rows: accumulated in place, fp32
-                wgrad_into(gp if gp is not None else g.view(g.shape[0], -1), dy2, x2)
+            def into(g):       # the arena's (padded) gradient rows: accumulated in place, fp32; the bias gradient rides along
+                wgrad_into(gp if gp is not None else g.view(g.shape[0], -1), dy2, x2,
+                           gb=(bp if bp is not None else bias.grad) if fuse_bias else None)
 
             def fresh():       # not arena resident: a gradient tensor for autograd to accumulate
                 g = torch.empty(dy2.shape[1], x2.shape[1], dtype=torch.float32, device=x2.device)
                 wgrad_into(g, dy2, x2, beta=0.0)
                 return g[:n].view(weight.shape)
             gw = accumulate_grad(weight, fresh, gemm_into=into if (n % 8 == 0 or gp is not None) else None)
-        if bias is not None and ctx.needs_input_grad[2]:
-            bp = grad_padded(bias)
-            if bias.is_leaf and bias.grad is not None and bias.grad.dtype == torch.float32 and getattr(bias, "_dgx16", None) is not None \
-                    and (n % 8 == 0 or bp is not None):
+            if fuse_bias:
+                bias_done = True
+                for q in getattr(bias, "_dgx_group_members", (bias,)):
+                    notify_ready(q)
+        if bias is not None and ctx.needs_input_grad[2] and not bias_done:
+            if bias_in_arena:
                 from .swin_block import colsum_into
                 colsum_into(bp if bp is not None else bias.grad, dy2)      # bias gradient summed straight into the arena
-                notify_ready(bias)
+                for q in getattr(bias, "_dgx_group_members", (bias,)):
+                    notify_ready(q)
             else:
                 gb = accumulate_grad(bias, lambda: torch.sum(dy2[:, :n], 0, dtype=torch.float32))
         return dx, gw, gb

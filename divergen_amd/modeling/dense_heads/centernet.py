@@ -143,6 +143,11 @@ class CenterNet(nn.Module):
     @torch.no_grad()
     def _get_ground_truth(self, shapes, gt_instances):
         boxes = [g.gt_boxes.tensor for g in gt_instances]
+        if boxes[0].is_cuda and boxes[0].dtype == torch.float32:
+            # dense targets + the fixed-length (index, cared) list of the positives: two launches over the same box list
+            reg, hm, inds = centernet_targets(boxes, shapes, self.strides, self.sizes_of_interest, self.hm_min_overlap,
+                                              self.min_radius, label_inds=True)
+            return inds, reg, hm
         reg, hm = centernet_targets(boxes, shapes, self.strides, self.sizes_of_interest, self.hm_min_overlap,
                                     self.min_radius)
         return self._get_label_inds(boxes, shapes, masked=boxes[0].is_cuda), reg, hm

@@ -11,7 +11,7 @@ from torch.nn import functional as F
 
 from ...config import configurable
 from ...layers import batched_nms
-from ...layers.linear_ops import Linear
+from ...layers.linear_ops import Linear, group_parameters, linear_padded
 from ...structures import Boxes, Instances
 from ...utils.events import get_event_storage
 from ..box_regression import Box2BoxTransform
@@ -52,24 +52,30 @@ def fed_loss_class_mask(gt_classes, num_sample_cats, C, weight):
     `topk(prob / Exponential(1), k)`; the same draw is made here with k = num_sample_cats and only the first
     num_sample_cats - n_appeared of it kept, so the class SET is the one the reference code would obtain from the
     same generator state (when n_appeared >= num_sample_cats the reference draws nothing: the streams then differ)."""
-    app = torch.zeros(C + 1, dtype=torch.bool, device=gt_classes.device)
-    app.index_fill_(0, gt_classes, True)        # (in-place index ops with Python scalars upload the scalar: avoided)
-    k = min(num_sample_cats, C + 1)
-    key = (C, k, str(gt_classes.device), None if weight is None else (weight.data_ptr(), weight._version))
-    if key not in _FED_CONSTS:       # the sampling weights and the rank ramp do not change between calls
-        prob0 = torch.ones(C + 1, dtype=torch.float32, device=gt_classes.device) if weight is None else \
+    dev = gt_classes.device
+    key = (C, str(dev), None if weight is None else (weight.data_ptr(), weight._version))
+    if key not in _FED_CONSTS:       # the sampling weights do not change between calls
+        prob0 = torch.ones(C + 1, dtype=torch.float32, device=dev) if weight is None else \
             torch.cat([weight.float(), weight.new_zeros(1).float()])
         prob0[C:].zero_()
         if len(_FED_CONSTS) > 16:
             _FED_CONSTS.clear()
-        _FED_CONSTS[key] = (prob0, torch.arange(k, device=gt_classes.device))
-    prob0, ramp = _FED_CONSTS[key]
-    prob = prob0.masked_fill(app, 0)
-    q = prob / torch.empty_like(prob).exponential_(1)
-    vals, idx = torch.topk(q, k)
-    need = num_sample_cats - app.sum()                       # device scalar
-    take = (ramp < need) & (vals > 0)
-    return app.index_put((idx,), app[idx] | take)
+        _FED_CONSTS[key] = prob0.contiguous()
+    prob0 = _FED_CONSTS[key]
+    expo = torch.empty_like(prob0).exponential_(1)          # torch's generator: the reference's position in the random stream
+    if not gt_classes.is_cuda:
+        app = torch.zeros(C + 1, dtype=torch.bool, device=dev)
+        app[gt_classes.clamp(min=0)] = True
+        q = prob0.masked_fill(app, 0) / expo
+        vals, idx = torch.topk(q, min(num_sample_cats, C + 1))
+        take = (torch.arange(idx.numel(), device=dev) < num_sample_cats - app.sum()) & (vals > 0)
+        return app.index_put((idx,), app[idx] | take)
+    from ... import _lib as L
+    mask = torch.empty(C + 1, dtype=torch.uint8, device=dev)
+    gt = gt_classes.contiguous()
+    L.check(L.lib().dgx_fed_class_mask(L.ptr(gt) if gt.numel() else None, gt.numel(), L.ptr(prob0), L.ptr(expo), C, int(num_sample_cats),
+                                       L.ptr(mask), L.stream()), "dgx_fed_class_mask")
+    return mask.view(torch.bool)
 
 
 class _DeticLosses(torch.autograd.Function):
@@ -165,6 +171,10 @@ class DeticFastRCNNOutputLayers(nn.Module):
         input_size = input_shape.channels * (input_shape.width or 1) * (input_shape.height or 1)
         self.cls_score = Linear(input_size, num_classes + 1)
         self.bbox_pred = Linear(input_size, (1 if cls_agnostic_bbox_reg else num_classes) * 4)
+        # cls_score and bbox_pred read the same features: their rows sit back to back in the parameter arena (1454 + 4 -> 1464
+        # rows), one GEMM each way serves both (forward, input gradient, weight gradient)
+        group_parameters(self.cls_score.weight, self.bbox_pred.weight)
+        group_parameters(self.cls_score.bias, self.bbox_pred.bias)
         nn.init.normal_(self.cls_score.weight, std=0.01)
         nn.init.normal_(self.bbox_pred.weight, std=0.001)
         for l in (self.cls_score, self.bbox_pred):
@@ -204,7 +214,19 @@ class DeticFastRCNNOutputLayers(nn.Module):
     def forward(self, x, classifier_info=(None, None, None)):
         if x.dim() > 2:
             x = torch.flatten(x, start_dim=1)
+        y = self.forward_joint(x)
+        if y is not None:
+            c1, nb = self.cls_score.out_features, self.bbox_pred.out_features
+            return y[:, :c1], y[:, c1:c1 + nb]
         return self.cls_score(x), self.bbox_pred(x)
+
+    def forward_joint(self, x):
+        """(R, pad8(C + 1 + 4)) logits | box deltas | zero columns from ONE GEMM over the arena group, or None when the parameters
+        are not arena resident (module used on its own)."""
+        w = self.cls_score.weight
+        if getattr(w, "_dgx16g", None) is None:
+            return None
+        return linear_padded(x, w, self.cls_score.bias)
 
     @property
     def fused_supported(self):

@@ -13,6 +13,7 @@ from torch import nn
 from .. import ROI_HEADS_REGISTRY, ShapeSpec
 from ...config import configurable
 from ...layers import iou_match
+from ...layers.box_stage import box_stage, box_stage_supported
 from ...structures import Boxes, Instances
 from ...utils.events import get_event_storage
 from ..box_regression import Box2BoxTransform
@@ -312,13 +313,25 @@ class DeticCascadeROIHeads(nn.Module):
             obs = self.__dict__.get("stage_observer")
             if obs is not None:      # tests: the labels this stage trains on (hand-over to the CPU oracle)
                 obs(k, dict(boxes=prop, valid=valid, gt_classes=gtc, gt_boxes=gtb, counts=counts))
-            boxes = [Boxes(b) for b in prop.split(counts)]
-            x = self.box_pooler(feats, boxes, pad_to=256)
+            x = self.box_pooler.forward_rows(feats, prop, counts, pad_to=256)
+            pred = self.box_predictor[k]
+            if box_stage_supported(self.box_head[k], pred):
+                # flatten -> fc1 -> ReLU -> fc2 -> ReLU -> cls_score | bbox_pred -> losses: one autograd node (layers/box_stage.py)
+                C = pred.num_classes
+                w = pred._class_weight(gtc, C)
+                loss_cls, loss_box, out, deltas = box_stage(x, self.box_head[k], pred, gtc, w, prop, gtb,
+                                                            None if pred.divergen_box_loss else src, R, 1.0 / self.num_cascade_stages)
+                with st.name_scope("stage{}".format(k)):
+                    st.put_scalar("fast_rcnn/cls_accuracy", out[11])
+                    st.put_scalar("fast_rcnn/fg_cls_accuracy", out[12])
+                    st.put_scalar("fast_rcnn/false_negative", out[13])
+                losses["loss_cls_stage{}".format(k)], losses["loss_box_reg_stage{}".format(k)] = loss_cls, loss_box
+                continue
             x = _ScaleGradient.apply(x, 1.0 / self.num_cascade_stages)
-            scores, deltas = self.box_predictor[k](self.box_head[k](x))
+            scores, deltas = pred(self.box_head[k](x))
             scores, deltas = scores[:R], deltas[:R]
             with st.name_scope("stage{}".format(k)):
-                sl = self.box_predictor[k].losses_from_tensors(scores, deltas, gtc, prop, gtb, src)
+                sl = pred.losses_from_tensors(scores, deltas, gtc, prop, gtb, src)
             losses.update({n + "_stage{}".format(k): v for n, v in sl.items()})
         return losses
 

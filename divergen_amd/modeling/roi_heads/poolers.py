@@ -21,6 +21,24 @@ class ROIPooler(nn.Module):
         self.min_level, self.max_level = int(mn), int(mx)
         assert len(scales) == self.max_level - self.min_level + 1
 
+    def forward_rows(self, x, boxes, counts, pad_to=0):
+        """`forward` for RoIs that already sit in ONE (R, 4) tensor with `counts` rows per image (the cascade keeps them that way):
+        the image-index column and the shape-padding rows are constants of (counts, pad_to), built once."""
+        R = int(boxes.shape[0])
+        Rp = R if pad_to <= 0 else -(-R // pad_to) * pad_to
+        key = (tuple(counts), Rp, str(boxes.device))
+        cache = self.__dict__.setdefault("_rows_cache", {})
+        idx = cache.get(key)
+        if idx is None:
+            if len(cache) > 64:
+                cache.clear()
+            col = torch.cat([torch.full((n,), float(i)) for i, n in enumerate(counts)] + [torch.zeros(Rp - R)])
+            idx = cache[key] = col.to(boxes.device).view(Rp, 1)
+        rois = torch.zeros(Rp, 5, dtype=torch.float32, device=boxes.device) if Rp > R else torch.empty(Rp, 5, dtype=torch.float32, device=boxes.device)
+        rois[:, :1] = idx
+        rois[:R, 1:] = boxes
+        return roi_pooler(list(x), rois, self.output_size, self.scales, self.sampling_ratio, self.out_nhwc)
+
     def forward(self, x, box_lists, pad_to=0):
         """x: list of (N,C,H,W); box_lists: list[Boxes] per image -> (R, C, S, S).
         pad_to > 0 rounds R up to a multiple of pad_to with empty boxes (their output rows are zeros):

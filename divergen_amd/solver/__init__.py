@@ -40,14 +40,50 @@ class FlatArena:
             if p.requires_grad and id(p) not in seen:
                 seen.add(id(p))
                 params.append((name, p))
-        self.names = [n for n, _ in params]
-        self.params = [p for _, p in params]
+        # Parameter GROUPS (`p._dgx_group = (key, position, pad_to)`): layers that always run together on the same input (cls_score
+        # + bbox_pred of a box predictor; the 1- and 4-channel CenterNet predictors) are laid out back to back, the group's row
+        # count rounded up to `pad_to` with zero rows, so that ONE GEMM (forward, input gradient, weight gradient) serves the
+        # group through the views `_dgx16g` / `_dgx16tg` / `_dgxgg`.  The parameters themselves stay separate (state-dict keys,
+        # shapes and checkpoints are the reference's); only the allocation order changes.
+        groups = {}
+        for name, p in params:
+            g = getattr(p, "_dgx_group", None)
+            if g is not None:
+                groups.setdefault(g[0], []).append((g[1], name, p))
+        units, placed = [], set()
+        for name, p in params:
+            if id(p) in placed:
+                continue
+            g = getattr(p, "_dgx_group", None)
+            members = [(name, p)] if g is None else [(n_, q) for _, n_, q in sorted(groups[g[0]], key=lambda t: t[0])]
+            units.append(members)
+            placed.update(id(q) for _, q in members)
+        self.names = [n_ for u in units for n_, _ in u]
+        self.params = [q for u in units for _, q in u]
         dev = self.params[0].device
         offs, sizes, n = [], [], 0
-        for p in self.params:
-            offs.append(n)
-            sizes.append((self.padded_numel(p) + 3) // 4 * 4)
-            n += sizes[-1]
+        self._groups = []                      # (offset, padded rows, columns, members)
+        for u in units:
+            if len(u) == 1:
+                offs.append(n)
+                sizes.append((self.padded_numel(u[0][1]) + 3) // 4 * 4)
+                n += sizes[-1]
+                continue
+            cols = u[0][1].numel() // u[0][1].shape[0]
+            assert all(q.numel() // q.shape[0] == cols and getattr(q, "_dgx_pad_rows", 0) == 0 for _, q in u), \
+                "grouped parameters must share their column count"
+            rows = sum(q.shape[0] for _, q in u)
+            pad_to = max(q._dgx_group[2] for _, q in u)
+            rows_pad = (rows + pad_to - 1) // pad_to * pad_to
+            g0 = n
+            for _, q in u:
+                offs.append(n)
+                sizes.append(q.numel())
+                n += q.numel()
+            tail = (g0 + rows_pad * cols + 3) // 4 * 4 - n          # zero rows behind the last member belong to its segment
+            sizes[-1] += tail
+            n += tail
+            self._groups.append((g0, rows_pad, cols, [q for _, q in u]))
         self.offsets, self.sizes, self.numel = offs, sizes, n
         self.p = torch.zeros(n, dtype=torch.float32, device=dev)
         self.g = torch.zeros(n, dtype=torch.float32, device=dev)
@@ -70,7 +106,7 @@ class FlatArena:
                 shape = (pr, cols) if p.dim() >= 2 else (pr,)
                 p._dgx16p = self.p16[o:o + pr * cols].view(shape)
                 p._dgxgp = self.g[o:o + pr * cols].view(shape)
-            if self.p16t is not None and p.dim() >= 2:
+            if self.p16t is not None and p.dim() >= 2 and getattr(p, "_dgx_group", None) is None:
                 rows = pr or self.stored_rows(p)
                 cols = p.numel() // self.stored_rows(p)
                 cin = 0
@@ -83,6 +119,19 @@ class FlatArena:
                     p._dgx16t = self.p16t[o:o + rows * cols].view(cols, rows)
                 jobs.append((o, rows | (cols << 32), tiles, cin))
                 tiles += ((rows + 63) // 64) * ((cols + 63) // 64)
+        for g0, rows_pad, cols, members in self._groups:
+            one_d = members[0].dim() == 1
+            shape = (rows_pad,) if one_d else (rows_pad, cols)
+            v16, vg = self.p16[g0:g0 + rows_pad * cols].view(shape), self.g[g0:g0 + rows_pad * cols].view(shape)
+            vt = None
+            if self.p16t is not None and not one_d:
+                vt = self.p16t[g0:g0 + rows_pad * cols].view(cols, rows_pad)
+                jobs.append((g0, rows_pad | (cols << 32), tiles, 0))
+                tiles += ((rows_pad + 63) // 64) * ((cols + 63) // 64)
+            r0 = 0
+            for q in members:
+                q._dgx16g, q._dgxgg, q._dgx16tg, q._dgx_group_row0 = v16, vg, vt, r0
+                r0 += q.shape[0]
         self._tjobs = torch.tensor(jobs, dtype=torch.int64, device=dev) if jobs else None
         self._ttiles = tiles
         self.sync_shadow()

@@ -157,6 +157,32 @@ int dgx_iou_match(const float* gt, int M, const float* props, int N, float thr,
                   int64_t* matched_idx, int8_t* matched_label, float* max_iou, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Proposal labelling and sampling of the RoI heads for the whole batch (detic_roi_heads.py:273-307
+ * `label_and_sample_proposals`; D2 proposal_utils.py:126-196, boxes.py:334-357, matcher.py:62-104, sampling.py:9-54).
+ * dgx_roi_label: one workgroup per image.  Rows of image b = its K fixed-length proposals (prop f32 (B,K,4), valid u8 (B,K)
+ *   or NULL) followed, when append_gt, by its n_b ground-truth boxes (gt_boxes f32 (G,4), gt_classes i64 (G), gt_offsets i32
+ *   (B+1) on the device; max_gt = max n_b).  Per row: matched_idx i32 (B,Nmax) = best ground-truth box of the image (first
+ *   maximum; 0 without ground truth) and labels i64 (B,Nmax) = its class when IoU >= iou_thr, num_classes (background)
+ *   otherwise, -1 for invalid proposals and for the padding up to Nmax >= K + max_gt.  pos_idx / neg_idx i32 (B,Nmax): the rows
+ *   with a foreground / background label in index order (what `nonzero` of the two masks returns), counts i32 (B,2) their
+ *   lengths.  IoU float sequence = dgx_iou_match.
+ * dgx_roi_gather: the sampled rows of the batch, image after image, foreground first: row t of image b comes from
+ *   pos_idx[b][perm_pos[b][t]] (t < num_pos[b]) or neg_idx[b][perm_neg[b][t - num_pos[b]]]; perm_* (HOST arrays of B device
+ *   pointers, i64) are the leading entries of the caller's random permutations (torch.randperm: the reference's generator).
+ *   Outputs (R = sum num_pos + num_neg rows): boxes f32 (R,4), classes i64, matched ground-truth box f32 (R,4) (the row's own
+ *   box for an image without ground truth) and index-within-image i64, instance_source i64 (0 without ground truth / gt_src
+ *   NULL; out_src may be NULL), objectness logit f32 (logits (B,K) for proposals, gt_logit for ground-truth rows; may be NULL).
+ *   B <= 16. */
+int dgx_roi_label(const float* prop, const uint8_t* valid, int B, int K, const float* gt_boxes, const int64_t* gt_classes,
+                  const int32_t* gt_offsets, int max_gt, float iou_thr, int num_classes, int append_gt, int Nmax,
+                  int32_t* matched_idx, int64_t* labels, int32_t* pos_idx, int32_t* neg_idx, int32_t* counts, void* stream);
+int dgx_roi_gather(int B, int K, int Nmax, const int64_t* const* perm_pos, const int64_t* const* perm_neg, const int* num_pos,
+                   const int* num_neg, const float* prop, const float* logits, const float* gt_boxes, const int64_t* gt_src,
+                   const int32_t* gt_offsets, float gt_logit, const int32_t* matched_idx, const int64_t* labels,
+                   const int32_t* pos_idx, const int32_t* neg_idx, float* out_boxes, int64_t* out_classes, float* out_gt_boxes,
+                   int64_t* out_gt_index, int64_t* out_src, float* out_logits, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * CenterNet dense target assignment for one batch, no M x N temporaries.
  * CN/modeling/dense_heads/centernet.py:338-436 (+ :505-530, :551-562, :576-592).
  *   gt_boxes f32 (sum n_i, 4); gt_offsets i32 (B+1) prefix offsets per image
@@ -168,6 +194,12 @@ int dgx_centernet_targets(const float* gt_boxes, const int32_t* gt_offsets, int 
                           const int32_t* level_hw, const int32_t* strides, const float* soi, int L,
                           float delta, float min_radius, float* reg_targets, float* heatmap,
                           void* stream);
+/* The positive-location list of the CenterNet losses (centernet.py:439-483 `_get_label_inds`), fixed length: for every box n
+ * (of `total` = sum n_i, images concatenated) and level l:  ind[n * L + l] = flat index of the location holding the box centre in
+ * the level-major layout above, cared[n * L + l] = 1 when the box's half diagonal lies in the level's size range (the
+ * reference's list is ind[cared]; the loss kernel takes both, so no shape depends on the data). */
+int dgx_centernet_label_inds(const float* gt_boxes, const int32_t* gt_offsets, int B, int total, const int32_t* level_hw,
+                             const int32_t* strides, const float* soi, int L, int64_t* ind, uint8_t* cared, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Instance copy-paste compositor ('basic' blend).  Replaces the per-paste numpy passes of
@@ -280,13 +312,16 @@ int dgx_residual_bwd(const void* g, const float* scale, void* dy_bf16, int B, in
 /* ---------------------------------------------------------------------------------------------
  * Grouped form of dgx_linear_wgrad: the weight gradients of several Linear layers (the four of a Swin
  * block: qkv/proj/fc1/fc2, swintransformer.py:101-108,36-46) in ONE launch, so that large output tiles
- * fill the GPU with a small M-split.  n <= 9 problems; for each gw (Nn,Kk) = beta*gw + dy^T x.
+ * fill the GPU with a small M-split.  n <= 9 problems; for each gw (Nn,Kk) = beta*gw + dy^T x  and, when gb != NULL, the
+ * layer's BIAS gradient gb (Nn) = beta*gb + column sums of dy from the same pass (the sum over rows autograd performs for the
+ * bias; computed as dy^T 1 on fragments the kernel holds anyway -- ABI version 3 added the field).
  * Nn % 8 == 0, Kk % 8 == 0.  workspace: dgx_wgrad_grouped_workspace_bytes(problems, n) bytes. */
 typedef struct dgx_wgrad_problem {
     const void* dy;   /* bf16 (M, Nn) row-major */
     const void* x;    /* bf16 (M, Kk) row-major */
     float* gw;        /* f32 (Nn, Kk) */
     int M, Nn, Kk;
+    float* gb;        /* f32 (Nn) or NULL */
 } dgx_wgrad_problem;
 int64_t dgx_wgrad_grouped_workspace_bytes(const dgx_wgrad_problem* problems, int n);
 int dgx_linear_wgrad_grouped(const dgx_wgrad_problem* problems, int n, float beta, void* workspace,
@@ -337,6 +372,28 @@ int dgx_detic_losses(const void* logits, const void* deltas, const int64_t* gt_c
                      const float* prop, const float* gtb, const int64_t* src, int R, int C, float wx, float wy,
                      float ww, float wh, void* dlogits, float* dsign, float* out16, float* part, int dtype,
                      void* stream);
+/* The same with row strides (elements), for the JOINT output of the predictor pair cls_score | bbox_pred
+ * (detic_fast_rcnn.py:437-466 runs two Linears on the same features; here their rows are one GEMM operand):
+ *   logits = y, ld_logits = ld;  deltas = y + (C+1), ld_deltas = ld   with y (R, ld), ld >= C + 5
+ *   grad_cols > C + 1: row r of dlogits (ld_dlogits) additionally gets dsign[r] in columns [C+1, C+5) and zeros in
+ *   [C+5, grad_cols) -- the K-padded operand of the pair's input- and weight-gradient GEMMs, still unscaled;
+ *   dgx_detic_grad_scale then multiplies columns [0, C+1) by g_cls * out16[14] and [C+1, C+5) by g_box * out16[10]
+ *   (g_cls, g_box: device scalars = the gradients of the two loss values), in place. */
+int dgx_detic_losses_strided(const void* logits, int64_t ld_logits, const void* deltas, int64_t ld_deltas,
+                             const int64_t* gt_classes, const float* class_w, const float* prop, const float* gtb,
+                             const int64_t* src, int R, int C, float wx, float wy, float ww, float wh, void* dlogits,
+                             int64_t ld_dlogits, int grad_cols, float* dsign, float* out16, float* part, int dtype,
+                             void* stream);
+int dgx_detic_grad_scale(void* dy, int64_t ld, int rows, int C, const float* out16, const float* g_cls, const float* g_box,
+                         int dtype, void* stream);
+
+/* Federated-loss class set of one cascade stage (DG/divergen/modeling/utils.py:16-28 get_fed_loss_inds, used by
+ * detic_fast_rcnn.py:271-304) as a 0/1 mask u8 (C+1): the classes present in gt_classes i64 (R), plus -- when fewer than K are
+ * present -- the K - #present classes with the largest prob[c] / expo[c] among the others (prob f32 (C+1) >= 0, the sampling
+ * weights with 0 for the background; expo f32 (C+1) = Exponential(1) draws made by the caller's generator: multinomial without
+ * replacement IS this top-k, so the set is the reference's for the same generator state).  One workgroup; C + 1 <= 8192. */
+int dgx_fed_class_mask(const int64_t* gt_classes, int R, const float* prob, const float* expo, int C, int K, uint8_t* mask,
+                       void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Hand-over between two cascade stages for all images of the batch in one launch
@@ -425,6 +482,9 @@ int dgx_grad_sim(const float* g1, const float* g2, int64_t n, double* out3, floa
  *     DGX_EPI_NONE / DGX_EPI_BIAS   c[m][n] = y                                   (ldc)
  *     DGX_EPI_BIAS_GELU             c[m][n] = y;  c2[m][n] = bf16(GELU_erf(y))    (Mlp.fc1 + act, swintransformer.py:41-42)
  *     DGX_EPI_GELU_GRAD             c[m][n] = bf16(y * GELU'(aux[m][n]))          (backward of the above; aux = saved c)
+ *     DGX_EPI_RELU_GRAD             c[m][n] = aux[m][n] > 0 ? y : 0               (input gradient carried through the ReLU that
+ *                                   follows a Linear / convolution: box_head.py:26-98 fc_relu, mask_head.py:209-284; aux = the
+ *                                   saved activation)
  *     DGX_EPI_BIAS_RESIDUAL         out[tok(m)][n] = residual[tok(m)][n] + scale[b(m)] * y
  *         rows m are in WINDOW order when ws > 0 (window_reverse + roll(+shift) + crop folded into tok(m), padding rows
  *         dropped; swintransformer.py:239-255) or token order when ws == 0; residual / out are (B, H*W, N) of
@@ -437,13 +497,14 @@ int dgx_grad_sim(const float* g1, const float* g2, int64_t n, double* out3, floa
 #define DGX_EPI_BIAS_GELU 2
 #define DGX_EPI_BIAS_RESIDUAL 3
 #define DGX_EPI_GELU_GRAD 4
+#define DGX_EPI_RELU_GRAD 5
 typedef struct dgx_gemm_epilogue {
     int mode;
     void* c;              /* bf16 (M, ldc) */
     int64_t ldc;
     const void* bias;     /* bf16 (N) or NULL */
     void* c2;             /* bf16 (M, ldc): DGX_EPI_BIAS_GELU */
-    const void* aux;      /* bf16 (M, ldaux): DGX_EPI_GELU_GRAD */
+    const void* aux;      /* bf16 (M, ldaux): DGX_EPI_GELU_GRAD, DGX_EPI_RELU_GRAD */
     int64_t ldaux;
     const void* residual; /* DGX_EPI_BIAS_RESIDUAL */
     void* out;

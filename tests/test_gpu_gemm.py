@@ -174,3 +174,16 @@ def test_gemm_rejects_bad_arguments():
         G.gemm_nt(a, b)
     with pytest.raises(DgxError):
         G.gemm_nt(torch.zeros(16, 16), torch.zeros(8, 16))        # not bf16 / not on the GPU
+
+
+@pytest.mark.parametrize("M,N,K", [(1024, 1024, 1024), (1024, 12544, 1024), (300, 200, 136), (2048, 1536, 6144)])
+def test_gemm_relu_grad(M, N, K):
+    """DGX_EPI_RELU_GRAD: (a b^T) masked by the saved activation (box-head FCs: box_head.py:26-98) -- exact masking of the
+    bf16-rounded product, split-K and plain paths."""
+    g = torch.Generator().manual_seed(M + K)
+    a, b = bf(torch.randn(M, K, generator=g)), bf(torch.randn(N, K, generator=g) * 0.1)
+    act = bf(torch.relu(torch.randn(M, N, generator=g)))
+    ref = (a.float() @ b.float().t()) * (act.float() > 0)
+    got = G.gemm_relu_grad(a.to(DEV), b.to(DEV), act.to(DEV))
+    close_bf16(got, ref)
+    assert bool((got.float().cpu()[act.float() <= 0] == 0).all())

@@ -900,3 +900,22 @@ def test_layernorm_param_reduce2_is_bit_identical_to_the_single_norm_second_stag
         assert torch.equal(outs[0][0][k], outs[1][0][k])
         assert torch.equal(outs[0][1][k][0], outs[1][1][k][0]) and torch.equal(outs[0][1][k][1], outs[1][1][k][1])
     assert float((outs[1][1][0][0] - 0.25).abs().max()) > 0
+
+
+@pytest.mark.parametrize("shapes", [[(16384, 576, 192)], [(1024, 1464, 1024)], [(8192, 768, 3072), (8192, 3072, 768), (10368, 768, 768), (10368, 2304, 768)],
+                                    [(1024, 1024, 12544), (1024, 1024, 1024), (1024, 1464, 1024)], [(20000, 192, 768), (17000, 64, 72)]])
+def test_wgrad_grouped_with_bias_gradients(shapes):
+    """dgx_linear_wgrad_grouped with gb: weight gradients dY^T X and bias gradients dY^T 1 of a group in one launch (split and
+    unsplit plans, beta = 1 accumulation) against fp32 math on the same bf16 operands."""
+    from divergen_amd.layers.linear_ops import wgrad_grouped
+    g = torch.Generator().manual_seed(97)
+    probs, refs = [], []
+    for M, Nn, Kk in shapes:
+        dy, x = bf(torch.randn(M, Nn, generator=g)), bf(torch.randn(M, Kk, generator=g))
+        w0, b0 = torch.randn(Nn, Kk, generator=g), torch.randn(Nn, generator=g)
+        probs.append((w0.to(DEV).clone(), dy.to(DEV), x.to(DEV), b0.to(DEV).clone()))
+        refs.append((w0 + dy.float().t() @ x.float(), b0 + dy.float().sum(0)))
+    wgrad_grouped(probs, 1.0)
+    for (gw, _, _, gb), (rw, rb) in zip(probs, refs):
+        torch.testing.assert_close(gw.cpu(), rw, atol=2e-2, rtol=2e-4)
+        torch.testing.assert_close(gb.cpu(), rb, atol=2e-2, rtol=2e-4)

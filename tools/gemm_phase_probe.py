@@ -21,7 +21,11 @@ for name, M, N, K in shapes:
     x = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
     w = (torch.randn(N, K, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
     for tile, dg in [(t_, d_) for t_ in tiles for d_ in diags]:
-        os.environ["DGX_GEMM_TILE"] = tile
+        if tile.startswith("g"):                       # g256 / g192: the 4-wave 256 x BN kernel (gemm256.hip)
+            os.environ["DGX_GEMM256"] = tile[1:]
+        else:
+            os.environ.pop("DGX_GEMM256", None)
+            os.environ["DGX_GEMM_TILE"] = tile
         os.environ["DGX_GEMM_DIAG"] = str(dg)
         for _ in range(3):
             G.gemm_nt(x, w)

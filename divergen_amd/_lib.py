@@ -69,6 +69,9 @@ SIGNATURES = {
     "dgx_nms_batched": (c_i, [c_p, c_p, c_p, c_i, c_i, c_f, c_i, c_p, c_p, c_i, c_p, c_p]),
     "dgx_iou_match": (c_i, [c_p, c_i, c_p, c_i, c_f, c_p, c_p, c_p, c_p]),
     "dgx_centernet_targets": (c_i, [c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_f, c_f, c_p, c_p, c_p]),
+    "dgx_centernet_scores": (c_i, [c_p, c_i, c_i, c_p, c_p, c_i, c_i, c_f, c_p, c_p, c_i, c_p]),
+    "dgx_centernet_decode": (c_i, [c_p, c_i, c_i, c_p, c_p, c_i, c_i, c_p, c_i, c_p, c_f, c_p, c_p, c_p, c_i, c_p]),
+    "dgx_centernet_finalize": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p]),
     "dgx_roi_label": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_i, c_f, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
     "dgx_roi_gather": (c_i, [c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f] + [c_p] * 10 + [c_p]),
     "dgx_centernet_label_inds": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_p]),
@@ -120,6 +123,8 @@ SIGNATURES = {
     "dgx_conv3x3_gemm": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_i64, c_p]),
     "dgx_conv3x3_wgrad_workspace_bytes": (c_i64, [c_i, c_i, c_i, c_i, c_i]),
     "dgx_conv3x3_wgrad": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_p]),
+    "dgx_conv3x3_wgrad_bias_workspace_bytes": (c_i64, [c_i, c_i, c_i, c_i, c_i]),
+    "dgx_conv3x3_wgrad_bias": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_p]),
     "dgx_transpose_bf16_grouped": (c_i, [c_p, c_p, c_p, c_i, c_i64, c_p]),
     "dgx_adamw_ema_step": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_f,
                                  c_p, c_p, c_i, c_p, c_p]),

@@ -367,8 +367,21 @@ extern "C" int64_t dgx_conv3x3_wgrad_workspace_bytes(int N, int H, int W, int Ci
     for (int t = 0; t < 9; ++t) { pr[t].dy = pr[t].x = nullptr; pr[t].gw = nullptr; pr[t].gb = nullptr; pr[t].M = (int)Mp; pr[t].Nn = Cout; pr[t].Kk = Cin; }
     return dgx_wgrad_grouped_workspace_bytes(pr, 9);
 }
+extern "C" int dgx_conv3x3_wgrad_bias(const void* dypad, const void* xpad, float* gw, float* gb, int N, int H, int W, int Cin, int Cout,
+                                      float beta, void* workspace, void* stream);
 extern "C" int dgx_conv3x3_wgrad(const void* dypad, const void* xpad, float* gw, int N, int H, int W, int Cin, int Cout, float beta,
                                  void* workspace, void* stream) {
+    return dgx_conv3x3_wgrad_bias(dypad, xpad, gw, nullptr, N, H, W, Cin, Cout, beta, workspace, stream);
+}
+extern "C" int64_t dgx_conv3x3_wgrad_bias_workspace_bytes(int N, int H, int W, int Cin, int Cout) {
+    dgx_wgrad_problem pr[9];
+    const int64_t Mp = (int64_t)N * (H + 2) * (W + 2);
+    float dummy;
+    for (int t = 0; t < 9; ++t) { pr[t].dy = pr[t].x = nullptr; pr[t].gw = nullptr; pr[t].gb = t == 0 ? &dummy : nullptr; pr[t].M = (int)Mp; pr[t].Nn = Cout; pr[t].Kk = Cin; }
+    return dgx_wgrad_grouped_workspace_bytes(pr, 9);
+}
+extern "C" int dgx_conv3x3_wgrad_bias(const void* dypad, const void* xpad, float* gw, float* gb, int N, int H, int W, int Cin, int Cout,
+                                      float beta, void* workspace, void* stream) {
     if (N <= 0 || H <= 0 || W <= 0) return DGX_OK;
     if (!dypad || !xpad || !gw || (Cin & 7) || (Cout & 7)) return DGX_ERR_BAD_ARG;
     const int64_t Mp = (int64_t)N * (H + 2) * (W + 2);
@@ -379,7 +392,7 @@ extern "C" int dgx_conv3x3_wgrad(const void* dypad, const void* xpad, float* gw,
         pr[t].dy = (const uint16_t*)dypad + (int64_t)(wp + 1) * Cout;                          // grid position 0 (behind the slack)
         pr[t].x = (const uint16_t*)xpad + (int64_t)((t / 3) * wp + t % 3) * Cin;               // position 0 shifted by tap - (wp + 1)
         pr[t].gw = gw + (int64_t)t * Cin;
-        pr[t].gb = nullptr;
+        pr[t].gb = t == 0 ? gb : nullptr;        // the bias gradient = column sums of dypad (its border rows are zero): once
         pr[t].M = (int)Mp; pr[t].Nn = Cout; pr[t].Kk = Cin;
         ldc[t] = 9 * Cin;
     }

@@ -186,23 +186,33 @@ class _Conv3x3Implicit(torch.autograd.Function):
             ws = _splitk_workspace(g2.device)
             L.check(lib.dgx_conv3x3_gemm(L.ptr(gsrc), wf.data_ptr(), None, L.ptr(gx), N, H, W, Ck, C, 0, ws.data_ptr(), ws.numel(),
                                          L.stream()), "dgx_conv3x3_gemm")
+        bias_arena = (bias is not None and ctx.needs_input_grad[2] and bias.is_leaf and bias.grad is not None
+                      and bias.grad.dtype == torch.float32 and getattr(bias, "_dgx16", None) is not None)
+        bias_done = False
         if ctx.needs_input_grad[1]:
-            ws = torch.empty(max(int(lib.dgx_conv3x3_wgrad_workspace_bytes(N, H, W, C, Co)), 16), dtype=torch.uint8, device=g2.device)
             gphys = _ohwi_matrix(weight.grad) if (weight.is_leaf and weight.grad is not None) else None
             if gphys is not None and gphys.dtype == torch.float32 and getattr(weight, "_dgx16", None) is not None:
-                L.check(lib.dgx_conv3x3_wgrad(L.ptr(gp), L.ptr(xp), gphys.data_ptr(), N, H, W, C, Co, 1.0, L.ptr(ws), L.stream()),
-                        "dgx_conv3x3_wgrad")
+                # weight gradient (nine tap problems over the two padded images) AND the bias gradient (dy^T 1) in one launch
+                gbp = bias.grad if bias_arena else None
+                ws = torch.empty(max(int(lib.dgx_conv3x3_wgrad_bias_workspace_bytes(N, H, W, C, Co)), 16), dtype=torch.uint8, device=g2.device)
+                L.check(lib.dgx_conv3x3_wgrad_bias(L.ptr(gp), L.ptr(xp), gphys.data_ptr(), L.ptr(gbp), N, H, W, C, Co, 1.0, L.ptr(ws),
+                                                   L.stream()), "dgx_conv3x3_wgrad_bias")
                 notify_ready(weight)
+                if bias_arena:
+                    bias_done = True
+                    notify_ready(bias)
             else:
+                ws = torch.empty(max(int(lib.dgx_conv3x3_wgrad_workspace_bytes(N, H, W, C, Co)), 16), dtype=torch.uint8, device=g2.device)
+
                 def wgrad():
                     g = torch.empty(Co, 3, 3, C, dtype=torch.float32, device=g2.device)
                     L.check(lib.dgx_conv3x3_wgrad(L.ptr(gp), L.ptr(xp), L.ptr(g), N, H, W, C, Co, 0.0, L.ptr(ws), L.stream()),
                             "dgx_conv3x3_wgrad")
                     return g.permute(0, 3, 1, 2)
                 gw = accumulate_grad(weight, wgrad)
-        if bias is not None and ctx.needs_input_grad[2]:
+        if bias is not None and ctx.needs_input_grad[2] and not bias_done:
             g2f = g2.view(-1, Co)
-            if (bias.is_leaf and bias.grad is not None and bias.grad.dtype == torch.float32 and getattr(bias, "_dgx16", None) is not None):
+            if bias_arena:
                 from .swin_block import colsum_into
                 colsum_into(bias.grad, g2f)
                 notify_ready(bias)

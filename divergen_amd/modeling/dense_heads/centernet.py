@@ -16,7 +16,7 @@ from torch import nn
 from .. import PROPOSAL_GENERATOR_REGISTRY
 from ...config import configurable
 from ...layers import centernet_targets, nms, nms_batched_sorted
-from ...structures import Boxes, Instances
+from ...structures import Boxes, Instances, ProposalBatch
 from ...utils.comm import get_world_size
 from .centernet_head import CenterNetHead
 
@@ -82,6 +82,9 @@ class CenterNet(nn.Module):
     def forward(self, images, features_dict, gt_instances):
         features = [features_dict[f] for f in self.in_features]
         reg_pred_per_level, agn_hm_pred_per_level = self._run_head(features)
+        raw_hm = raw_reg = None
+        if self.training and reg_pred_per_level[0].is_cuda and not self.not_nms:
+            raw_hm, raw_reg = [a.detach() for a in agn_hm_pred_per_level], [r.detach() for r in reg_pred_per_level]
         reg_pred_per_level = [r.float() for r in reg_pred_per_level]
         agn_hm_pred_per_level = [a.float() for a in agn_hm_pred_per_level]
         grids = self.compute_grids(features)
@@ -99,14 +102,17 @@ class CenterNet(nn.Module):
         agn_hm_pred = torch.cat([x.permute(0, 2, 3, 1).reshape(-1) for x in agn_hm_pred_per_level], dim=0)
         losses = self.losses(pos_inds, reg_targets, flattened_hms, reg_pred, agn_hm_pred)
         with torch.no_grad():
-            hms = [x.detach().sigmoid() for x in agn_hm_pred_per_level]
-            proposals = self.predict_instances(grids, hms, [r.detach() for r in reg_pred_per_level], images.image_sizes)
+            proposals = self._predict_instances_fused(raw_hm, raw_reg, images.image_sizes) if raw_hm is not None else None
+            if proposals is None:
+                hms = [x.detach().sigmoid() for x in agn_hm_pred_per_level]
+                proposals = self.predict_instances(grids, hms, [r.detach() for r in reg_pred_per_level], images.image_sizes)
         for p in proposals:
             p.proposal_boxes = p.get("pred_boxes")
             p.objectness_logits = p.get("scores")
             p.remove("pred_boxes")
             p.remove("scores")
-            p.remove("pred_classes")
+            if p.has("pred_classes"):
+                p.remove("pred_classes")
         return proposals, losses
 
     def _run_head(self, features):
@@ -229,6 +235,81 @@ class CenterNet(nn.Module):
         return losses
 
     # ---------------------------------------------------------------- decoding
+    @staticmethod
+    def _nhwc_layout(t):
+        """(pixel stride, ok): a logical (B, C, h, w) tensor whose channels of a pixel sit `stride(1) == 1` apart in a dense
+        (B, h, w, pixel_stride) image -- what the channels-last head produces, including channel slices of it."""
+        B, C, h, w = t.shape
+        ps = t.stride(3) if w > 1 else (t.stride(2) if h > 1 else max(C, 1))
+        ok = (C == 1 or t.stride(1) == 1) and (w == 1 or t.stride(3) == ps) and (h == 1 or t.stride(2) == w * ps) \
+            and (B == 1 or t.stride(0) == h * w * ps) and ps >= C
+        return ps, ok
+
+    @torch.no_grad()
+    def _predict_instances_fused(self, hm_logits, reg_maps, image_sizes):
+        """predict_instances for training on the GPU: libdgx kernels around torch's top-k / sort (dgx_centernet_scores / _decode /
+        dgx_nms_batched / _finalize); fixed-length lists + validity flags, no host round trip.  None = layouts it does not take."""
+        import ctypes
+        from ... import _lib as L
+        Lv, B = len(hm_logits), int(hm_logits[0].shape[0])
+        lay_h = [self._nhwc_layout(t) for t in hm_logits]
+        lay_r = [self._nhwc_layout(t) for t in reg_maps]
+        if (not all(ok for _, ok in lay_h + lay_r) or len({ps for ps, _ in lay_h}) != 1 or len({ps for ps, _ in lay_r}) != 1
+                or len({t.dtype for t in hm_logits + reg_maps}) != 1 or hm_logits[0].dtype not in (torch.float32, torch.bfloat16)):
+            return None
+        dev = hm_logits[0].device
+        pre_topk, post_topk, thr_nms = self.pre_nms_topk_train, self.post_nms_topk_train, self.nms_thresh_train
+        sizes = [int(t.shape[2] * t.shape[3]) for t in hm_logits]
+        M = sum(sizes)
+        hw = (ctypes.c_int32 * (2 * Lv))(*[v for t in hm_logits for v in (int(t.shape[2]), int(t.shape[3]))])
+        st = (ctypes.c_int32 * Lv)(*self.strides[:Lv])
+        hp = (ctypes.c_void_p * Lv)(*[t.data_ptr() for t in hm_logits])
+        rp = (ctypes.c_void_p * Lv)(*[t.data_ptr() for t in reg_maps])
+        code = L.dtype_code(hm_logits[0])
+        scores = torch.empty(B, M, dtype=torch.float32, device=dev)
+        n_valid = torch.empty(B, dtype=torch.int32, device=dev)
+        lib = L.lib()
+        L.check(lib.dgx_centernet_scores(hp, lay_h[0][0], 0, hw, st, Lv, B, float(self.score_thresh), L.ptr(scores), L.ptr(n_valid), code,
+                                         L.stream()), "dgx_centernet_scores")
+        key = (tuple(sizes), B, pre_topk, str(dev), "fused")
+        cache = self.__dict__.setdefault("_decode_consts", {})
+        if key not in cache:
+            offs, tot = [], 0
+            for n in sizes:
+                offs.append(tot)
+                tot += n
+            small = [torch.arange(offs[l], offs[l] + sizes[l], device=dev) for l in range(Lv) if sizes[l] <= pre_topk]
+            cache[key] = (offs, torch.cat(small)[None].expand(B, -1).contiguous() if small else None)
+        offs, small_idx = cache[key]
+        parts = [scores[:, offs[l]:offs[l] + n].topk(pre_topk, dim=1)[1] + offs[l] for l, n in enumerate(sizes) if n > pre_topk]
+        if small_idx is not None:
+            parts.append(small_idx)
+        idx = torch.cat(parts, 1).contiguous() if len(parts) > 1 else parts[0].contiguous()
+        Kc = int(idx.shape[1])
+        boxes = torch.empty(B, Kc, 4, dtype=torch.float32, device=dev)
+        sc = torch.empty(B, Kc, dtype=torch.float32, device=dev)
+        L.check(lib.dgx_centernet_decode(rp, lay_r[0][0], 0, hw, st, Lv, B, L.ptr(idx), Kc, L.ptr(scores), float(self.score_thresh),
+                                         L.ptr(boxes), L.ptr(sc), L.ptr(n_valid), code, L.stream()), "dgx_centernet_decode")
+        sc, order = torch.sort(sc, dim=1, descending=True, stable=True)
+        boxes = torch.gather(boxes, 1, order[:, :, None].expand(-1, -1, 4))
+        cap = min(Kc, post_topk + 64)
+        keep_idx, num_keep = nms_batched_sorted(boxes, sc, n_valid, thr_nms, max_keep=post_topk, cap=cap)
+        o_box = torch.empty(B, cap, 4, dtype=torch.float32, device=dev)
+        o_sc = torch.empty(B, cap, dtype=torch.float32, device=dev)
+        o_valid = torch.empty(B, cap, dtype=torch.uint8, device=dev)
+        L.check(lib.dgx_centernet_finalize(L.ptr(boxes), L.ptr(sc), L.ptr(keep_idx.contiguous()), L.ptr(num_keep.contiguous()), B, Kc, cap,
+                                           L.ptr(o_box), L.ptr(o_sc), L.ptr(o_valid), L.stream()), "dgx_centernet_finalize")
+        valid = o_valid.view(torch.bool)
+        results = ProposalBatch()
+        for i in range(B):
+            inst = Instances(image_sizes[i])
+            inst.pred_boxes = Boxes(o_box[i])
+            inst.scores = o_sc[i]
+            inst.proposal_valid = valid[i]
+            results.append(inst)
+        results.batch = (o_box, o_sc, valid)
+        return results
+
     @torch.no_grad()
     def predict_instances(self, grids, hms, reg_pred, image_sizes):
         B = hms[0].shape[0]
@@ -307,6 +388,9 @@ class CenterNet(nn.Module):
                 inst.scores = sc[i, :counts[i]]
             inst.pred_classes = torch.zeros_like(inst.scores, dtype=torch.int64)
             results.append(inst)
+        if counts is None:      # training: the batch-level tensors travel with the list (the RoI heads label / sample them in one go)
+            results = ProposalBatch(results)
+            results.batch = (boxes, sc, valid)
         return results
 
 

@@ -14,7 +14,7 @@ from .. import ROI_HEADS_REGISTRY, ShapeSpec
 from ...config import configurable
 from ...layers import iou_match
 from ...layers.box_stage import box_stage, box_stage_supported
-from ...structures import Boxes, Instances
+from ...structures import Boxes, Instances, ProposalBatch
 from ...utils.events import get_event_storage
 from ..box_regression import Box2BoxTransform
 from .box_head import build_box_head
@@ -66,6 +66,13 @@ def _subsample_labels(labels, num_samples, positive_fraction, bg_label, pre=None
 subsample_labels = _subsample_labels     # tests substitute a deterministic rule here
 
 
+def draw_permutation(n, k, device):
+    """The first k entries of a random permutation of n (sampling.py:42-47: `torch.randperm(n)[:k]`, torch's generator).  The
+    batch-level sampler below calls it in the reference's order (image by image, positives then negatives); tests substitute
+    `arange(k)` here (= "the first k in index order", the rule the CPU oracle applies)."""
+    return torch.randperm(n, device=device)[:k]
+
+
 def add_ground_truth_to_proposals(gt, proposals):
     """D2/modeling/proposal_generator/proposal_utils.py:126-196."""
     out = []
@@ -90,9 +97,13 @@ def select_foreground_proposals(proposals, bg_label):
     rows FIRST and the count on the host (`_dgx_num_fg`): the selection is then a slice, not a `nonzero` (no device->host read)."""
     fg, masks = [], []
     for p in proposals:
-        m = (p.gt_classes != -1) & (p.gt_classes != bg_label)
         n = p.__dict__.get("_dgx_num_fg")
-        fg.append(p[:n] if n is not None else p[m.nonzero().squeeze(1)])
+        if n is not None:
+            fg.append(p[:n])
+            masks.append(None)               # (the selection mask is only computed where somebody needs it)
+            continue
+        m = (p.gt_classes != -1) & (p.gt_classes != bg_label)
+        fg.append(p[m.nonzero().squeeze(1)])
         masks.append(m)
     return fg, masks
 
@@ -150,6 +161,9 @@ class DeticCascadeROIHeads(nn.Module):
         """only_gt_proposals (BS/bsgal/modeling/roi_heads/detic_roi_heads.py:334-358, BSGAL's held-out pass): an image WITH
         ground truth keeps exactly its ground-truth boxes as proposals (the rows appended last), labelled with their own
         classes; an image without any is sampled as usual."""
+        fused = self._label_and_sample_fused(proposals, targets) if not only_gt_proposals else None
+        if fused is not None:
+            return fused
         if self.proposal_append_gt:
             proposals = add_ground_truth_to_proposals(targets, proposals)
         # pass 1 (device only): labels of every image and, for the reference's sampler, its positive / negative index lists as
@@ -216,6 +230,92 @@ class DeticCascadeROIHeads(nn.Module):
         st.put_scalar("roi_head/num_bg_samples", torch.stack([x.float() for x in nbg]).mean())
         return out
 
+    def _label_and_sample_fused(self, proposals, targets):
+        """label_and_sample_proposals for the whole batch in two launches around the step's one device->host read
+        (dgx_roi_label -> counts -> torch.randperm draws in the reference's order -> dgx_roi_gather); None when the inputs do
+        not come as a batch (no fixed-length proposal tensors, CPU tensors, a substituted `subsample_labels`)."""
+        import ctypes
+        from ... import _lib as L
+        from ...structures import BitMasks
+        from ...utils.h2d import upload_i32
+        batch = getattr(proposals, "batch", None)
+        if (batch is None or subsample_labels is not _subsample_labels or not self.proposal_append_gt or not len(targets)
+                or not batch[0].is_cuda or len(targets) > 16):
+            return None
+        boxes, scores, valid = batch                                  # (B, K, 4) f32, (B, K) f32, (B, K) bool
+        B, K = int(boxes.shape[0]), int(boxes.shape[1])
+        dev = boxes.device
+        gts = [len(t) for t in targets]
+        offs = [0]
+        for n in gts:
+            offs.append(offs[-1] + n)
+        G = offs[-1]
+        has_src = all(t.has("instance_source") for t in targets)
+        if G:
+            gt_boxes = torch.cat([t.gt_boxes.tensor for t in targets]).float().contiguous()
+            gt_classes = torch.cat([t.gt_classes for t in targets]).contiguous()
+            gt_src = torch.cat([t.instance_source for t in targets]).contiguous() if has_src else None
+        else:
+            gt_boxes, gt_classes, gt_src = boxes.new_zeros(1, 4), torch.zeros(1, dtype=torch.int64, device=dev), None
+        offs_t = upload_i32(offs, dev)
+        Nmax = K + max(gts)
+        midx = torch.empty(B, Nmax, dtype=torch.int32, device=dev)
+        labels = torch.empty(B, Nmax, dtype=torch.int64, device=dev)
+        pos_idx = torch.empty(B, Nmax, dtype=torch.int32, device=dev)
+        neg_idx = torch.empty(B, Nmax, dtype=torch.int32, device=dev)
+        counts = torch.empty(2 * B, dtype=torch.int32, device=dev)
+        boxes, scores = boxes.float().contiguous(), scores.float().contiguous()
+        valid_u8 = valid.view(torch.uint8).contiguous() if valid is not None else None
+        lib = L.lib()
+        L.check(lib.dgx_roi_label(L.ptr(boxes), L.ptr(valid_u8), B, K, L.ptr(gt_boxes), L.ptr(gt_classes), L.ptr(offs_t), max(gts),
+                                  float(self.cascade_ious[0]), self.num_classes, 1, Nmax, L.ptr(midx), L.ptr(labels), L.ptr(pos_idx),
+                                  L.ptr(neg_idx), L.ptr(counts), L.stream()), "dgx_roi_label")
+        c = counts.tolist()                                           # THE device->host read of the step
+        perms, npos, nneg = [], [], []
+        for i in range(B):
+            k_pos = min(c[2 * i], int(self.batch_size_per_image * self.positive_fraction))
+            k_neg = min(c[2 * i + 1], self.batch_size_per_image - k_pos)
+            perms.append((draw_permutation(c[2 * i], k_pos, dev), draw_permutation(c[2 * i + 1], k_neg, dev)))
+            npos.append(k_pos)
+            nneg.append(k_neg)
+        R = sum(npos) + sum(nneg)
+        o_box = torch.empty(R, 4, dtype=torch.float32, device=dev)
+        o_cls = torch.empty(R, dtype=torch.int64, device=dev)
+        o_gtb = torch.empty(R, 4, dtype=torch.float32, device=dev)
+        o_gti = torch.empty(R, dtype=torch.int64, device=dev)
+        o_src = torch.empty(R, dtype=torch.int64, device=dev) if has_src else None
+        o_log = torch.empty(R, dtype=torch.float32, device=dev)
+        pp = (ctypes.c_void_p * B)(*[p1.data_ptr() if p1.numel() else None for p1, _ in perms])
+        pn = (ctypes.c_void_p * B)(*[p2.data_ptr() if p2.numel() else None for _, p2 in perms])
+        gt_logit = math.log((1.0 - 1e-10) / (1 - (1.0 - 1e-10)))
+        L.check(lib.dgx_roi_gather(B, K, Nmax, pp, pn, (ctypes.c_int * B)(*npos), (ctypes.c_int * B)(*nneg), L.ptr(boxes), L.ptr(scores),
+                                   L.ptr(gt_boxes), L.ptr(gt_src), L.ptr(offs_t), gt_logit, L.ptr(midx), L.ptr(labels), L.ptr(pos_idx),
+                                   L.ptr(neg_idx), L.ptr(o_box), L.ptr(o_cls), L.ptr(o_gtb), L.ptr(o_gti), L.ptr(o_src), L.ptr(o_log),
+                                   L.stream()), "dgx_roi_gather")
+        out, r0 = ProposalBatch(), 0
+        for i, (p, t) in enumerate(zip(proposals, targets)):
+            n = npos[i] + nneg[i]
+            inst = Instances(p.image_size, proposal_boxes=Boxes(o_box[r0:r0 + n]), objectness_logits=o_log[r0:r0 + n],
+                             gt_classes=o_cls[r0:r0 + n])
+            if gts[i] > 0:
+                inst.gt_boxes = Boxes(o_gtb[r0:r0 + n])
+                if has_src:
+                    inst.instance_source = o_src[r0:r0 + n]
+                if t.has("gt_masks"):
+                    inst.gt_masks = t.gt_masks[o_gti[r0:r0 + n]]      # lazy: an index into the image's mask stack
+                for name, val in t.get_fields().items():
+                    if name.startswith("gt_") and name not in ("gt_boxes", "gt_masks", "gt_classes") and not inst.has(name):
+                        inst.set(name, val[o_gti[r0:r0 + n]])
+            inst.__dict__["_dgx_num_fg"] = npos[i]
+            out.append(inst)
+            r0 += n
+        out.train = dict(prop=o_box, gt_classes=o_cls, gt_boxes=o_gtb, src=o_src, counts=[a + b for a, b in zip(npos, nneg)],
+                         t_boxes=gt_boxes, t_classes=gt_classes, t_src=gt_src, gts=gts)
+        st = get_event_storage()
+        st.put_scalar("roi_head/num_fg_samples", sum(npos) / float(B))
+        st.put_scalar("roi_head/num_bg_samples", sum(nneg) / float(B))
+        return out
+
     @torch.no_grad()
     def _match_and_label_boxes(self, proposals, stage, targets):
         nfg, nbg = [], []
@@ -272,21 +372,26 @@ class DeticCascadeROIHeads(nn.Module):
         from ... import _lib as L
         dev = proposals[0].proposal_boxes.tensor.device
         B = len(proposals)
-        counts = [len(p) for p in proposals]
-        row0 = (ctypes.c_int * (B + 1))(*([0] + list(torch.tensor(counts).cumsum(0).tolist())))
-        gts = [len(t) for t in targets]
-        gt0 = (ctypes.c_int * (B + 1))(*([0] + list(torch.tensor(gts).cumsum(0).tolist())))
+        tr = getattr(proposals, "train", None)
+        counts = tr["counts"] if tr is not None else [len(p) for p in proposals]
+        gts = tr["gts"] if tr is not None else [len(t) for t in targets]
+        row0 = (ctypes.c_int * (B + 1))(*([0] + [sum(counts[:i + 1]) for i in range(B)]))
+        gt0 = (ctypes.c_int * (B + 1))(*([0] + [sum(gts[:i + 1]) for i in range(B)]))
         img_h = (ctypes.c_float * B)(*[float(p.image_size[0]) for p in proposals])
         img_w = (ctypes.c_float * B)(*[float(p.image_size[1]) for p in proposals])
         R = sum(counts)
-        gt_boxes = torch.cat([t.gt_boxes.tensor for t in targets]).float().contiguous()
-        gt_classes = torch.cat([t.gt_classes for t in targets]).contiguous()
         has_src = all(t.has("instance_source") for t in targets)
-        gt_src = torch.cat([t.instance_source for t in targets]).contiguous() if has_src else None
-        prop = torch.cat([p.proposal_boxes.tensor for p in proposals]).float().contiguous()
-        gtc = torch.cat([p.gt_classes for p in proposals])
-        gtb = torch.cat([(p.gt_boxes if p.has("gt_boxes") else p.proposal_boxes).tensor for p in proposals]).float()
-        src = torch.cat([p.instance_source for p in proposals]) if all(p.has("instance_source") for p in proposals) else None
+        if tr is not None:      # the sampler's batch-level tensors: no re-concatenation
+            gt_boxes, gt_classes, gt_src = tr["t_boxes"], tr["t_classes"], tr["t_src"]
+            prop, gtc, gtb, src = tr["prop"], tr["gt_classes"], tr["gt_boxes"], tr["src"]
+        else:
+            gt_boxes = torch.cat([t.gt_boxes.tensor for t in targets]).float().contiguous()
+            gt_classes = torch.cat([t.gt_classes for t in targets]).contiguous()
+            gt_src = torch.cat([t.instance_source for t in targets]).contiguous() if has_src else None
+            prop = torch.cat([p.proposal_boxes.tensor for p in proposals]).float().contiguous()
+            gtc = torch.cat([p.gt_classes for p in proposals])
+            gtb = torch.cat([(p.gt_boxes if p.has("gt_boxes") else p.proposal_boxes).tensor for p in proposals]).float()
+            src = torch.cat([p.instance_source for p in proposals]) if all(p.has("instance_source") for p in proposals) else None
         feats = [features[f] for f in self.box_in_features]
         st = get_event_storage()
         losses, valid, deltas = {}, None, None
@@ -381,7 +486,12 @@ class DeticCascadeROIHeads(nn.Module):
                 instances = [i[i.instance_source == 0] for i in instances]
         feats = [features[f] for f in self.mask_in_features]
         boxes = [x.proposal_boxes if self.training else x.pred_boxes for x in instances]
-        return self.mask_head(self.mask_pooler(feats, boxes, pad_to=64 if self.training else 0), instances)
+        if self.training and boxes and boxes[0].tensor.is_cuda:
+            rows = torch.cat([b.tensor for b in boxes]) if len(boxes) > 1 else boxes[0].tensor
+            x = self.mask_pooler.forward_rows(feats, rows.float(), [len(b) for b in boxes], pad_to=64)
+        else:
+            x = self.mask_pooler(feats, boxes, pad_to=64 if self.training else 0)
+        return self.mask_head(x, instances)
 
     def forward(self, images, features, proposals, targets=None, ann_type="box", only_gt_proposals=False, **kwargs):
         if self.training:

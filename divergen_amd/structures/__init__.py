@@ -114,6 +114,10 @@ class BitMasks:
         if isinstance(item, torch.Tensor) and item.dim() == 1 and item.dtype in (torch.int64, torch.int32, torch.bool):
             cur = self._index if self._index is not None else torch.arange(self._base.shape[0], device=self._base.device)
             return BitMasks(self._base, cur[item.to(cur.device)])
+        if isinstance(item, slice):          # stays lazy: slicing a sampled proposal list must not gather full-resolution masks
+            if self._index is None:
+                return BitMasks(self._base[item])
+            return BitMasks(self._base, self._index[item])
         m = self.tensor[item]
         assert m.dim() == 3
         return BitMasks(m)
@@ -301,3 +305,10 @@ class ImageList:
             for img, pad_img in zip(tensors, batched):
                 pad_img[..., : img.shape[-2], : img.shape[-1]].copy_(img)
         return ImageList(batched.contiguous(), image_sizes)
+
+
+class ProposalBatch(list):
+    """list[Instances] that also carries its batch-level tensors (`batch`: fixed-length proposals of the whole batch from the
+    proposal generator; `train`: the sampled rows of the whole batch from label_and_sample_proposals)."""
+    batch = None
+    train = None

@@ -157,6 +157,26 @@ int dgx_iou_match(const float* gt, int M, const float* props, int N, float thr,
                   int64_t* matched_idx, int8_t* matched_label, float* max_iou, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * CenterNet proposal decoding around torch's top-k / sort and dgx_nms_batched (centernet.py:627-737 `predict_instances`,
+ * `predict_single_level`, `nms_and_topK`).  Level geometry as for dgx_centernet_targets (HOST arrays level_hw (L,2), strides (L));
+ * per-level maps are channels-last (B, h, w, pixel_stride) of dtype f32 | bf16, HOST arrays of L device pointers; M = sum h*w.
+ *   dgx_centernet_scores:   scores f32 (B, M) (levels concatenated per image) = sigmoid(logit[channel]) where > thr, else -1;
+ *                           n_valid i32 (B) cleared.
+ *   dgx_centernet_decode:   cand_idx i64 (B, Kc) locations in [0, M) -> boxes f32 (B, Kc, 4) = (gx - s r0, gy - s r1,
+ *                           max(gx + s r2, x0 + .01), max(gy + s r3, y0 + .01)), (gx, gy) = (x s + s/2, y s + s/2), r = the 4
+ *                           regression channels from `reg_channel`; out_scores = sqrt(score) where score > thr else -1;
+ *                           n_valid[b] += number of candidates above thr.
+ *   dgx_centernet_finalize: keep_idx i32 (B, cap) / num_keep i32 (B) from dgx_nms_batched over the score-sorted candidates
+ *                           (B, K) -> out_boxes (B, cap, 4), out_scores (B, cap), out_valid u8 (B, cap); rows >= num_keep zeroed. */
+int dgx_centernet_scores(const void* const* hm_levels, int hm_pixel_stride, int hm_channel, const int32_t* level_hw,
+                         const int32_t* strides, int L, int B, float thr, float* scores, int32_t* n_valid, int dtype, void* stream);
+int dgx_centernet_decode(const void* const* reg_levels, int reg_pixel_stride, int reg_channel, const int32_t* level_hw,
+                         const int32_t* strides, int L, int B, const int64_t* cand_idx, int Kc, const float* scores, float thr,
+                         float* boxes, float* out_scores, int32_t* n_valid, int dtype, void* stream);
+int dgx_centernet_finalize(const float* sorted_boxes, const float* sorted_scores, const int32_t* keep_idx, const int32_t* num_keep,
+                           int B, int K, int cap, float* out_boxes, float* out_scores, uint8_t* out_valid, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Proposal labelling and sampling of the RoI heads for the whole batch (detic_roi_heads.py:273-307
  * `label_and_sample_proposals`; D2 proposal_utils.py:126-196, boxes.py:334-357, matcher.py:62-104, sampling.py:9-54).
  * dgx_roi_label: one workgroup per image.  Rows of image b = its K fixed-length proposals (prop f32 (B,K,4), valid u8 (B,K)
@@ -551,6 +571,11 @@ int dgx_conv3x3_gemm(const void* xpad, const void* w, const void* bias, void* y,
 int64_t dgx_conv3x3_wgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout);
 int dgx_conv3x3_wgrad(const void* dypad, const void* xpad, float* gw, int N, int H, int W, int Cin, int Cout, float beta,
                       void* workspace, void* stream);
+/* the same, also producing the convolution's bias gradient gb f32 (Cout) = beta*gb + sum over pixels of dy (NULL = none) from the
+ * same pass; workspace: dgx_conv3x3_wgrad_bias_workspace_bytes */
+int64_t dgx_conv3x3_wgrad_bias_workspace_bytes(int N, int H, int W, int Cin, int Cout);
+int dgx_conv3x3_wgrad_bias(const void* dypad, const void* xpad, float* gw, float* gb, int N, int H, int W, int Cin, int Cout,
+                           float beta, void* workspace, void* stream);
 
 
 /* ---------------------------------------------------------------------------------------------

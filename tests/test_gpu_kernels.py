@@ -1,6 +1,8 @@
 """GPU parity tests proper: every libdgx kernel through the C ABI vs the CPU oracle and the golden
 fixtures generated from the reference's own files.  Integer / index / byte outputs are compared
 bit-exactly; floating point with the tolerance stated at each assert."""
+import types
+
 import numpy as np
 import pytest
 import torch
@@ -919,3 +921,58 @@ def test_wgrad_grouped_with_bias_gradients(shapes):
     for (gw, _, _, gb), (rw, rb) in zip(probs, refs):
         torch.testing.assert_close(gw.cpu(), rw, atol=2e-2, rtol=2e-4)
         torch.testing.assert_close(gb.cpu(), rb, atol=2e-2, rtol=2e-4)
+
+
+def test_roi_label_and_gather_vs_reference_golden(golden, monkeypatch):
+    """The batch-level sampler of the RoI heads (dgx_roi_label + dgx_roi_gather behind
+    DeticCascadeROIHeads._label_and_sample_fused) against the reference's own Matcher + subsample_labels outputs
+    (tests/golden/roi_match.npz: labels at IoU 0.6 and the positive / negative index lists drawn under torch seed 777):
+    labels, index lists and the sampled rows bit-exact.  The golden's permutations were drawn by the CPU generator, so the test
+    draws them the same way and hands them in through `draw_permutation`."""
+    import divergen_amd.modeling.roi_heads.detic_roi_heads as RH
+    from divergen_amd.structures import BitMasks, Boxes, Instances, ProposalBatch
+    from divergen_amd.utils.events import EventStorage
+    g = golden("roi_match")
+    gt, pr, cls = T(g["gt"]), T(g["proposals"]), T(g["cls"])
+    K = pr.shape[0] - gt.shape[0]                      # the golden's proposal list ends with the ground-truth boxes themselves
+    gtc = T(g["gt_classes"])
+    heads = types.SimpleNamespace(proposal_append_gt=True, cascade_ious=[0.6], num_classes=20, batch_size_per_image=64,
+                                  positive_fraction=0.25)
+    # two images: the golden's, and the same boxes with a THIRD of the proposals flagged invalid and no ground truth at all
+    valid = torch.ones(2, K, dtype=torch.bool)
+    valid[1, ::3] = False
+    props = ProposalBatch([Instances((400, 400)), Instances((400, 400))])
+    props.batch = (torch.stack([pr[:K], pr[:K]]).to(DEV), torch.rand(2, K).to(DEV), valid.to(DEV))
+    t0 = Instances((400, 400), gt_boxes=Boxes(gt.to(DEV)), gt_classes=gtc.to(DEV), instance_source=(torch.arange(9) % 2).to(DEV),
+                   gt_masks=BitMasks(torch.zeros(9, 8, 8, dtype=torch.bool, device=DEV)))
+    t1 = Instances((400, 400), gt_boxes=Boxes(torch.zeros(0, 4, device=DEV)), gt_classes=torch.zeros(0, dtype=torch.int64, device=DEV),
+                   instance_source=torch.zeros(0, dtype=torch.int64, device=DEV))
+    torch.manual_seed(int(g["seed"]))
+    cpu_draws = []
+
+    def draw(n, k, device):
+        p = torch.randperm(n)[:k]                     # CPU generator, the reference's call (sampling.py:42-47)
+        cpu_draws.append((n, k))
+        return p.to(device)
+    monkeypatch.setattr(RH, "draw_permutation", draw)
+    with EventStorage(0):
+        out = RH.DeticCascadeROIHeads._label_and_sample_fused(heads, props, [t0, t1])
+    assert out is not None and len(out) == 2
+    pos, neg = T(g["pos_idx"]), T(g["neg_idx"])
+    assert cpu_draws[0] == (int((cls != 20).sum()), len(pos)) and cpu_draws[1] == (int((cls == 20).sum()), len(neg))
+    a = out[0]
+    sel = torch.cat([pos, neg])
+    assert a.__dict__["_dgx_num_fg"] == len(pos)
+    assert torch.equal(a.proposal_boxes.tensor.cpu(), pr[sel])
+    assert torch.equal(a.gt_classes.cpu(), cls[sel])
+    midx = T(g["match_idx_6"])[sel]
+    assert torch.equal(a.gt_boxes.tensor.cpu(), gt[midx])
+    assert torch.equal(a.instance_source.cpu(), (torch.arange(9) % 2)[midx])
+    assert torch.equal(a.gt_masks._index.cpu(), midx)
+    # image without ground truth: every valid proposal is background, invalid ones are never sampled
+    b = out[1]
+    assert b.__dict__["_dgx_num_fg"] == 0 and len(b) == 64 and bool((b.gt_classes == 20).all())
+    bad = pr[:K][::3]
+    assert not any(bool((bad == row).all(1).any()) for row in b.proposal_boxes.tensor.cpu())
+    tr = out.train
+    assert tr["counts"] == [64, 64] and tr["prop"].shape == (128, 4) and torch.equal(tr["gt_boxes"][64:].cpu(), tr["prop"][64:].cpu())

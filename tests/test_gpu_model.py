@@ -152,7 +152,9 @@ def run_e2e_vs_oracle(monkeypatch, swin, size):
     from torch.profiler import ProfilerActivity, profile
 
     from tests._recipes import assembled_oracle_losses, det_fed_mask, det_sample
-    monkeypatch.setattr(RH, "subsample_labels", det_sample)
+    # the product's batch-level sampler with "the first k in index order" in place of the random permutation = det_sample on the
+    # oracle side (tests/_recipes.py)
+    monkeypatch.setattr(RH, "draw_permutation", lambda n, k, device: torch.arange(k, device=device))
     monkeypatch.setattr(FR, "fed_loss_class_mask", det_fed_mask)
     monkeypatch.setattr(graphs, "ENABLED", False)      # graph replay vs eager is test_graphed_head_segments_match_eager's subject
     cfg, model, opt = _build(False, swin)
@@ -319,3 +321,32 @@ def test_eval_only_flow_reports_lvis_ap(tmp_path, monkeypatch):
         assert -100.0 <= res[task]["AP"] <= 100.0
     rows = json.load(open(tmp_path / "out" / "inference_lvis_v1_val" / "lvis_instances_results.json"))
     assert len(rows) > 0 and {r["image_id"] for r in rows} <= {1, 2, 3, 4, 5, 6}
+
+
+def test_fused_sampler_equals_composed_sampler(monkeypatch):
+    """label_and_sample_proposals as two batch-level kernels around the step's one device->host read (dgx_roi_label /
+    dgx_roi_gather) against the composed per-image path (IoU match, masks, stable sorts, index gathers): the same
+    torch.randperm draws in the same order, hence the same sampled rows -- every loss of the step bit-identical."""
+    import divergen_amd.modeling.roi_heads.detic_roi_heads as RH
+    from divergen_amd.data import synthetic_batch
+    from divergen_amd.utils import graphs
+    from divergen_amd.utils.events import EventStorage
+    monkeypatch.setattr(graphs, "ENABLED", False)
+    cfg, model, opt = _build(False)
+    batch = synthetic_batch(2, 256, cfg.MODEL.ROI_HEADS.NUM_CLASSES, device="cuda")
+    res = []
+    used = []
+    orig = RH.DeticCascadeROIHeads._label_and_sample_fused
+    for fused in (True, False):
+        def spy(self, proposals, targets, _f=fused):
+            out = orig(self, proposals, targets) if _f else None
+            used.append(out is not None)
+            return out
+        monkeypatch.setattr(RH.DeticCascadeROIHeads, "_label_and_sample_fused", spy)
+        with EventStorage(0) as st:
+            torch.manual_seed(123)
+            losses = model(batch)
+            torch.cuda.synchronize()
+            res.append(({k: float(v) for k, v in losses.items()}, float(st.latest()["roi_head/num_fg_samples"][0])))
+    assert used == [True, False]
+    assert res[0] == res[1], res

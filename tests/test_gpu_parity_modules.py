@@ -499,6 +499,32 @@ def test_predict_instances_candidates_vs_reference_golden(golden):
         torch.testing.assert_close(r.pred_boxes.tensor[o], want_b, atol=0, rtol=0)
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+def test_fused_proposal_decode_equals_composed_decode(dt):
+    """CenterNet._predict_instances_fused (dgx_centernet_scores / _decode / _finalize around torch's top-k, sort and the NMS
+    kernel) against predict_instances (the composed torch form, itself pinned on the reference's predict_single_level golden
+    above): the same fixed-length boxes / scores / validity rows, bit for bit -- five levels, two of them larger than the pre-NMS
+    top-k, channel-sliced channels-last maps as the head produces them, invalid tail included."""
+    from divergen_amd.modeling.dense_heads.centernet import CenterNet
+    g = torch.Generator().manual_seed(23)
+    net = CenterNet(in_channels=16, num_classes=1, with_agn_hm=True, only_proposal=True, score_thresh=0.3, pre_nms_topk_train=300,
+                    post_nms_topk_train=100, nms_thresh_train=0.9, centernet_head=torch.nn.Identity()).to(DEV).train()
+    B, shapes = 2, [(32, 40), (16, 20), (8, 10), (4, 5), (2, 3)]
+    both = [(torch.randn(B, h, w, 8, generator=g) * 2).to(DEV).to(dt) for h, w in shapes]          # NHWC storage, 8 channels
+    hm_logits = [t.permute(0, 3, 1, 2)[:, :1] for t in both]
+    regs = [torch.relu(t.permute(0, 3, 1, 2)[:, 1:5].float() * 1.5 + 1.0).to(dt) for t in both]     # elementwise result: dense NHWC, C = 4
+    sizes = [(256, 320), (250, 300)]
+    fused = net._predict_instances_fused(hm_logits, regs, sizes)
+    assert fused is not None
+    grids = net.compute_grids(regs)
+    ref = net.predict_instances(grids, [x.float().sigmoid() for x in hm_logits], [r.float() for r in regs], sizes)
+    for a, b in zip(fused, ref):
+        assert torch.equal(a.proposal_valid, b.proposal_valid) and 0 < int(a.proposal_valid.sum()) < a.proposal_valid.numel()
+        assert torch.equal(a.pred_boxes.tensor, b.pred_boxes.tensor)
+        assert torch.equal(a.scores, b.scores)
+    assert fused.batch[0].shape == (B, 164, 4)
+
+
 def test_drop_path_factors_survive_activation_checkpointing():
     """MODEL.SWIN.USE_CHECKPOINT: the recomputation of a block in backward must use the DropPath factors of the forward
     pass (drawn once per step for all blocks by SwinTransformer.forward): gradients with and without checkpointing agree."""

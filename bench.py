@@ -34,6 +34,9 @@ def parse():
     p.add_argument("--no-roofline", action="store_true", help="leave the per-launch HIP events off (A/B of their cost)")
     p.add_argument("--roofline-every", type=int, default=10, help="instrument every n-th timed step with per-launch HIP events")
     p.add_argument("--no-copy-paste", action="store_true")
+    p.add_argument("--distinct-batches", type=int, default=8,
+                   help="synthetic (images, ground truth, paste sets) in rotation: proposal / foreground / paste-survivor counts then "
+                        "differ from step to step, so the data-dependent paths are inside the timed region")
     p.add_argument("--launch-check", action="store_true",
                    help="bring up the N ranks, run the collective self-check and print its JSON line; no model, no GPU needed "
                         "(backend from DGX_DIST_BACKEND, default nccl = RCCL)")
@@ -67,12 +70,13 @@ def make_pastes(rng, size, k=19):
 
 
 # Evidence committed under profiles/ that the `roofline` object refers to (all optional at run time):
-#   r02_pmc.json                              HBM bytes per launch of each kernel family from rocprofv3 --pmc passes over THIS script
-#   r02_bench_swinL_1024_kernel_stats.csv     rocprofv3 --kernel-trace --stats of THIS script (+ r02_profile_meta.json: steps)
-PROFILE_TAG = "r02"
+#   r03_pmc.json                              HBM bytes per launch / per step of each kernel family from rocprofv3 --pmc passes over
+#                                             THIS script, timed steps only (tools/pmc_summary.py)
+#   r03_bench_swinL_1024_kernel_stats.csv     rocprofv3 --kernel-trace --stats of THIS script (+ r03_profile_meta.json: steps)
+PROFILE_TAG = "r03"
 FAMILY_KERNELS = {   # family -> substrings of the kernel names rocprof reports for it
     "gemm_nt": ("gemm_nt_kernel", "gemm_splitk_fold_kernel"),
-    "wgrad": ("wgrad256_partial_kernel", "wgrad256_reduce_kernel", "wgrad_partial_kernel", "wgrad_reduce_kernel"),
+    "wgrad": ("wgrad256_partial_kernel", "wgrad256_reduce_kernel", "wgrad256_bias_reduce_kernel", "wgrad_partial_kernel", "wgrad_reduce_kernel"),
     "attn_fwd": ("win_attn_fwd_kernel",),
     "attn_bwd": ("win_attn_bwd_kernel",),
 }
@@ -287,11 +291,16 @@ def main():
         opt.ema.copy_(opt.arena.p)
     nparams = sum(p.numel() for p in model.parameters())
 
-    base = synthetic_batch(a.batch, a.size, cfg.MODEL.ROI_HEADS.NUM_CLASSES, seed=1234 + rank, device=dev)
+    nd = max(1, a.distinct_batches)
     rng = np.random.default_rng(7 + rank)
-    pastes = [make_pastes(rng, a.size) for _ in range(a.batch)]
-    # pre-stage paste patches as device tensors so the timed region starts with inputs resident in HBM
-    pastes = [[(torch.from_numpy(r).to(dev), x, y, l) for r, x, y, l in ps] for ps in pastes]
+    bases, paste_sets = [], []
+    for j in range(nd):
+        n_gt = (12, 10, 14, 12, 8, 16, 11, 13)[j % 8]          # 12 objects per image on average, not the same every step
+        bases.append(synthetic_batch(a.batch, a.size, cfg.MODEL.ROI_HEADS.NUM_CLASSES, seed=1234 + rank + 1000 * j, n_gt=n_gt, device=dev))
+        ps = [make_pastes(rng, a.size) for _ in range(a.batch)]
+        # pre-stage paste patches as device tensors so the timed region starts with inputs resident in HBM
+        paste_sets.append([[(torch.from_numpy(r).to(dev), x, y, l) for r, x, y, l in p_] for p_ in ps])
+    turn = [0]
 
     # The copy-paste compositor is the data-loading side of the step (the reference runs it in loader workers,
     # DG/divergen/data/custom_build_copypaste_mapper.py): it depends on nothing the optimizer produces, so the batch of
@@ -302,6 +311,8 @@ def main():
 
     def compose():
         batch = []
+        base, pastes = bases[turn[0] % nd], paste_sets[turn[0] % nd]
+        turn[0] += 1
         with torch.cuda.stream(side):
             for d, ps in zip(base, pastes):
                 inst = d["instances"]
@@ -404,11 +415,19 @@ def main():
         # window attention at head_dim 32 is 72 FLOP/B -- under the ~310 FLOP/B ridge, i.e. HBM-bound; the GEMM families are
         # MFMA-bound at their aggregate intensity (reported: flop_per_byte)
         mfma = fam in ("gemm_nt", "wgrad")
+        # launch population of the byte figures: EVERY dispatch of the family's entry point in a timed step, eager and
+        # hipGraph-replayed alike -- the population the PMC pass counts (tools/pmc_summary.py cuts the same timed steps)
+        n_all = (st["launches"] + st["graph_launches"]) / nsamp
+        b_all = (st["bytes"] + st["graph_bytes"]) / nsamp
+        pm = pmc.get(fam) or {}
         o = {"kernel": FAMILY_LABEL[fam], "family": fam, "bound": "mfma" if mfma else "hbm", "achieved": tf if mfma else gbs,
              "peak": 2500.0 if mfma else 8000.0, "unit": "TFLOP/s" if mfma else "GB/s",
              "frac": (tf / 2500.0) if mfma else (gbs / 8000.0),
-             "traffic": (pmc.get(fam) or {}).get("hbm_bytes_per_launch"),
-             "algorithmic_bytes_per_launch": st["bytes"] / st["launches"], "flop_per_byte": st["flops"] / max(st["bytes"], 1.0),
+             "traffic": pm.get("hbm_bytes_per_launch"), "traffic_per_step": pm.get("hbm_bytes_per_step"),
+             "traffic_launches_per_step": pm.get("launches_per_step"),
+             "algorithmic_bytes_per_launch": b_all / max(n_all, 1e-9), "algorithmic_bytes_per_step": b_all, "launches_per_step": n_all,
+             "traffic_over_algorithmic": (pm["hbm_bytes_per_step"] / b_all) if pm.get("hbm_bytes_per_step") and b_all > 0 else None,
+             "flop_per_byte": st["flops"] / max(st["bytes"], 1.0),
              "avg_launch_us": st["ms"] * 1e3 / st["launches"], "launches_timed_per_step": st["launches"] / nsamp,
              "total_ms_per_step": st["ms"] / nsamp, "tflops": tf, "algorithmic_gbytes_per_s": gbs,
              "flops_timed_per_step": st["flops"] / nsamp,
@@ -437,7 +456,7 @@ def main():
         line = {"metric": "images/sec (node) Swin-L CenterNet2 LVIS 1024px", "value": imgs / dt, "unit": "images/s",
                 "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
-                "data": "synthetic (random-init weights, LVIS-shaped boxes/masks, 19 RGBA pastes per image)",
+                "data": "synthetic (random-init weights, LVIS-shaped boxes/masks, 19 RGBA pastes per image; %d distinct batches in rotation)" % nd,
                 "config": {"workload": "CenterNet2 Swin-%s, %dx%d, %d images/GPU, 1453 classes, GPU copy-paste + fwd + bwd + "
                                        "fused clip/AdamW/EMA; configs/DiverGen_swinL.yaml" % (a.swin, a.size, a.size, a.batch),
                            "global_batch": a.batch * world, "parallelism": "dp%d" % world, "params_M": nparams / 1e6},

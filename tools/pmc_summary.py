@@ -2,10 +2,14 @@
 
     rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_f -- python bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-roofline
     rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_w -- python bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-roofline
-    python tools/pmc_summary.py <fetch counter_collection.csv> <write counter_collection.csv> <steps incl. warm-up> profiles/r02_pmc.json
+    python tools/pmc_summary.py <fetch counter_collection.csv> <write counter_collection.csv> <warm-up steps> <timed steps> profiles/r03_pmc.json
 
-Per kernel family (bench.FAMILY_KERNELS): dispatches, summed counters, HBM bytes per LAUNCH of the family's entry point
-(a launch of the wgrad entry point = one partial + one reduce dispatch; a split-K GEMM = kernel + fold), with the gfx950
+Only the TIMED steps are counted: the dispatches are walked in dispatch order and cut at the fused optimizer kernel
+(`adamw_ema_kernel`, exactly one dispatch per step), so the hipGraph capture warm-ups and the warm-up steps drop out while the
+graph-replayed launches of the timed steps stay in -- the same launch population bench.py's `algorithmic_bytes_per_launch`
+covers (round 2 divided by different populations on the two sides).
+Per kernel family (bench.FAMILY_KERNELS): dispatches, summed counters, HBM bytes per STEP and per LAUNCH of the family's entry
+point (a launch of the wgrad entry point = one partial + its reduce dispatches; a split-K GEMM = kernel + fold), with the gfx950
 correction of /opt/skills/guides/MI355X_MICROARCH.md: FETCH_SIZE (KB) counts a 128-byte request of a wide (16 B/lane)
 streaming read as 64 B, so it is doubled for kernels whose reads are 16 B/lane (`wide`); WRITE_SIZE is taken as reported."""
 import csv
@@ -16,7 +20,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 FAMILY_KERNELS = {
     "gemm_nt": ("gemm_nt_kernel", "gemm_splitk_fold_kernel"),
-    "wgrad": ("wgrad256_partial_kernel", "wgrad256_reduce_kernel", "wgrad_partial_kernel", "wgrad_reduce_kernel"),
+    "wgrad": ("wgrad256_partial_kernel", "wgrad256_reduce_kernel", "wgrad256_bias_reduce_kernel", "wgrad_partial_kernel", "wgrad_reduce_kernel"),
     "attn_fwd": ("win_attn_fwd_kernel",),
     "attn_bwd": ("win_attn_bwd_kernel",),
 }
@@ -26,12 +30,17 @@ MAIN = {"gemm_nt": "gemm_nt_kernel", "wgrad": "partial_kernel", "attn_fwd": "win
 WIDE = {"gemm_nt": True, "wgrad": True, "attn_fwd": False, "attn_bwd": False}
 
 
-def collect(path, counter):
+def collect(path, counter, warm, timed):
     out = {k: {"kb": 0.0, "dispatches": 0, "main": 0, "per_kernel": {}} for k in FAMILY_KERNELS}
     with open(path) as f:
-        for r in csv.DictReader(f):
-            if r["Counter_Name"] != counter:
-                continue
+        rows = [r for r in csv.DictReader(f) if r["Counter_Name"] == counter]
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    step = 0                                   # index of the training step a dispatch belongs to
+    for r in rows:
+        in_timed = warm <= step < warm + timed
+        if "adamw_ema_kernel" in r["Kernel_Name"]:
+            step += 1
+        if in_timed:
             for fam, pats in FAMILY_KERNELS.items():
                 if any(p in r["Kernel_Name"] for p in pats):
                     out[fam]["kb"] += float(r["Counter_Value"])
@@ -40,13 +49,14 @@ def collect(path, counter):
                     pk = out[fam]["per_kernel"].setdefault(r["Kernel_Name"].split("(")[0][-60:], [0, 0.0])
                     pk[0] += 1
                     pk[1] += float(r["Counter_Value"])
+    assert step >= warm + timed, "fewer optimizer dispatches (%d) than warm-up + timed steps (%d)" % (step, warm + timed)
     return out
 
 
 def main():
-    fcsv, wcsv, steps, dst = sys.argv[1], sys.argv[2], float(sys.argv[3]), sys.argv[4]
-    F, W = collect(fcsv, "FETCH_SIZE"), collect(wcsv, "WRITE_SIZE")
-    res = {"_how": __doc__.strip(), "_steps_in_pass": steps}
+    fcsv, wcsv, warm, steps, dst = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+    F, W = collect(fcsv, "FETCH_SIZE", warm, steps), collect(wcsv, "WRITE_SIZE", warm, steps)
+    res = {"_how": __doc__.strip(), "_timed_steps_counted": steps, "_warmup_steps_skipped": warm}
     for fam in FAMILY_KERNELS:
         if not F[fam]["main"]:
             continue
@@ -56,6 +66,7 @@ def main():
                     "FETCH_SIZE_KB_raw_sum": F[fam]["kb"], "fetch_doubled": WIDE[fam], "WRITE_SIZE_KB_sum": W[fam]["kb"],
                     "per_kernel_dispatches_FETCH_KB_WRITE_KB": {k: [v[0], v[1], W[fam]["per_kernel"].get(k, [0, 0.0])[1]]
                                                                 for k, v in F[fam]["per_kernel"].items()},
+                    "launches_per_step": F[fam]["main"] / float(steps),
                     "hbm_bytes_per_step": (fetch + write) / steps,
                     "hbm_bytes_per_launch": (fetch + write) / F[fam]["main"]}
     with open(dst, "w") as f:

@@ -1,0 +1,18 @@
+#!/bin/bash
+# Round-3 evidence run on the GPU box: kernel stats + PMC passes over bench.py, summaries into gpurun_out/r03/.
+set -x
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/r03
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_stats -o p -- python $R/bench.py --steps 8 --warmup 3 --no-roofline --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/stats.err
+f=$(find /tmp/p_stats -name "*kernel_stats.csv" | head -1)
+cp $f $O/r03_bench_swinL_1024_kernel_stats.csv
+python $R/tools/prof_summary.py $f 11 > $O/r03_bench_swinL_1024_summary.txt
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/p_f -o p -- python $R/bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-roofline > /dev/null 2> $O/pmc_f.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/p_w -o p -- python $R/bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-roofline > /dev/null 2> $O/pmc_w.err
+ff=$(find /tmp/p_f -name "*counter_collection.csv" | head -1)
+fw=$(find /tmp/p_w -name "*counter_collection.csv" | head -1)
+python $R/tools/pmc_summary.py $ff $fw 2 2 $O/r03_pmc.json > $O/pmc_summary.txt 2>&1
+cd $R && python bench.py > $O/r03_bench_line.json 2> $O/bench.err
+tail -c 1500 $O/r03_bench_line.json

@@ -1,8 +1,8 @@
 """Build recipe for the oracle's native pieces (TEST INFRASTRUCTURE, see oracle/__init__.py).
 
   build_oracle()  gcc  oracle/roi_nms.c           -> oracle/_build/liboracle.so   (always)
-  build_ref()     g++  reference in-tree CPU sources, compiled where they lie under
-                  /root/reference, + oracle/ref_shim.cpp -> oracle/_ref/dgref.so
+  build_ref()     g++  reference in-tree CPU sources (ROIAlignRotated_cpu.cpp, nms_rotated_cpu.cpp, cocoeval.cpp),
+                  compiled where they lie under /root/reference, + oracle/ref_shim.cpp -> oracle/_ref/dgref.so
                   (only when /root/reference exists, i.e. in the authoring container;
                   the GPU box uses the prebuilt file that travels with the snapshot)
 
@@ -43,7 +43,8 @@ def build_ref(verbose=False):
     os.makedirs(out_dir, exist_ok=True)
     srcs = [os.path.join(HERE, "ref_shim.cpp"),
             os.path.join(REF_CSRC, "ROIAlignRotated", "ROIAlignRotated_cpu.cpp"),
-            os.path.join(REF_CSRC, "nms_rotated", "nms_rotated_cpu.cpp")]
+            os.path.join(REF_CSRC, "nms_rotated", "nms_rotated_cpu.cpp"),
+            os.path.join(REF_CSRC, "cocoeval", "cocoeval.cpp")]
     if not _stale(out, srcs):
         return out
     import torch

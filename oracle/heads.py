@@ -11,6 +11,7 @@ TEST INFRASTRUCTURE (see oracle/__init__.py).  Functional over reference-keyed s
   box_reg_loss                     detic_fast_rcnn.py:271-304 (smooth_l1, beta 0 => L1)
   MaskRCNNConvUpsampleHead.layers  D2/modeling/roi_heads/mask_head.py:209-284
   mask_rcnn_loss                   D2/modeling/roi_heads/mask_head.py:31-111
+  fast_rcnn_inference_single_image D2/modeling/roi_heads/fast_rcnn.py:117-170 (pinned by tests/golden/fast_rcnn_inference.npz)
 """
 import torch
 import torch.nn.functional as F
@@ -118,3 +119,26 @@ def mask_loss(mask_logits, gt_masks_list, prop_boxes_list):
         return mask_logits.sum() * 0
     tg = torch.cat(tg).to(torch.float32)
     return F.binary_cross_entropy_with_logits(mask_logits[:, 0], tg, reduction="mean")
+
+
+def fast_rcnn_inference_single_image(boxes, scores, image_shape, score_thresh, nms_thresh, topk_per_image):
+    """D2/modeling/roi_heads/fast_rcnn.py:117-170: rows with a non-finite box or score are dropped, the background column is cut,
+    boxes are clipped to the image (structures/boxes.py:200-214: x to [0, w], y to [0, h]), (row, class) pairs above the score
+    threshold go through per-class greedy NMS (kept in descending score order, stable), the best `topk_per_image` stay.
+    Returns boxes (n, 4), scores (n,), classes (n,), proposal rows (n,) -- rows index the FILTERED (finite) proposal list, as
+    in the reference."""
+    valid = torch.isfinite(boxes).all(dim=1) & torch.isfinite(scores).all(dim=1)
+    boxes, scores = boxes[valid], scores[valid][:, :-1]
+    nreg = boxes.shape[1] // 4
+    h, w = image_shape
+    b = boxes.reshape(-1, 4).clone()
+    b[:, 0].clamp_(min=0, max=w); b[:, 2].clamp_(min=0, max=w)
+    b[:, 1].clamp_(min=0, max=h); b[:, 3].clamp_(min=0, max=h)
+    b = b.view(-1, nreg, 4)
+    rows, cls = torch.nonzero(scores > score_thresh, as_tuple=True)          # row-major order = the reference's nonzero()
+    cand = b[rows, 0] if nreg == 1 else b[rows, cls]
+    sc = scores[rows, cls]
+    keep = roi.batched_nms(cand, sc, cls, nms_thresh)
+    if topk_per_image >= 0:
+        keep = keep[:topk_per_image]
+    return cand[keep], sc[keep], cls[keep], rows[keep]

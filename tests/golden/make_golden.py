@@ -500,6 +500,45 @@ def gen_postprocess():
          out_bits=np.packbits(out.numpy().reshape(N, -1), axis=1), threshold=np.float32(0.5))
 
 
+def gen_inference():
+    """fast_rcnn_inference_single_image (D2/modeling/roi_heads/fast_rcnn.py:117-170) on seeded box / score tensors.  The file is
+    torch-only except for `batched_nms` (torchvision, not vendored): the reference function runs with the oracle's per-class
+    greedy NMS in that slot (oracle/roi.py, itself cross-checked against the reference's nms_rotated_cpu.cpp), so what this
+    fixture pins is everything around it -- the finite-row filter, clipping, score threshold, the (row, class) index pairs,
+    per-class suppression, top-k, output order."""
+    fr = R.ref("detectron2.modeling.roi_heads.fast_rcnn")
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import roi as OR
+    fr.batched_nms = OR.batched_nms
+    g = torch.Generator().manual_seed(4242)
+    store = {}
+    # (name, R proposals, K classes, class-specific regression?, image (h, w), score threshold, NMS threshold, top-k)
+    cases = [("agnostic", 400, 23, False, (333, 500), 0.02, 0.5, 100), ("perclass", 160, 7, True, (240, 200), 0.05, 0.6, 50),
+             ("nonfinite", 120, 11, False, (128, 160), 0.0001, 0.5, 300), ("empty", 40, 5, False, (64, 64), 1.5, 0.5, 10),
+             ("swinL", 256, 1203, False, (800, 1216), 0.0001, 0.5, 300)]
+    for name, Rn, K, per_class, (h, w), st, nt, topk in cases:
+        # clustered boxes (so that suppression happens), some reaching outside the image (so that clipping matters)
+        ctr = torch.rand(Rn // 8 + 1, 2, generator=g) * torch.tensor([w, h])
+        c = ctr[torch.randint(0, len(ctr), (Rn,), generator=g)] + torch.randn(Rn, 2, generator=g) * 6.0
+        wh = (torch.rand(Rn, 2, generator=g) * 0.5 + 0.08) * torch.tensor([w, h])
+        nreg = K if per_class else 1
+        base = torch.cat([c - wh / 2, c + wh / 2], 1)
+        boxes = (base[:, None, :] + torch.randn(Rn, nreg, 4, generator=g) * 3.0).reshape(Rn, nreg * 4)
+        if name == "swinL":                                    # sigmoid scores of a federated classifier: most classes near 0
+            scores = torch.sigmoid(torch.randn(Rn, K + 1, generator=g) * 2.5 - 6.0)
+        else:
+            scores = torch.rand(Rn, K + 1, generator=g) ** 3
+        if name == "nonfinite":
+            boxes[5, 2] = float("inf"); boxes[17, 0] = float("nan"); scores[33, 4] = float("nan")
+        res, kept = fr.fast_rcnn_inference_single_image(boxes.clone(), scores.clone(), (h, w), st, nt, topk)
+        store[name + "_boxes"], store[name + "_scores"] = boxes, scores
+        store[name + "_cfg"] = np.array([h, w, st, nt, topk], dtype=np.float64)
+        store[name + "_out_boxes"], store[name + "_out_scores"] = res.pred_boxes.tensor, res.scores
+        store[name + "_out_classes"], store[name + "_out_rows"] = res.pred_classes, kept
+        print("  %-10s %4d x %4d classes -> %3d detections" % (name, Rn, K, len(kept)))
+    save("fast_rcnn_inference", **store)
+
+
 def gen_pool():
     """Instance-pool decode: PNG fixtures under tests/golden/pool/ + what the reference's
     InstPool._load_RGBA (mapper.py:359-444) hands to cv2.resize for each key (array and target size), captured by
@@ -653,6 +692,6 @@ def gen_augment():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["swin", "centernet", "roi", "compositor", "solver", "heads", "heads_wide", "postprocess", "pool", "bsgal", "augment"]
+    which = sys.argv[1:] or ["swin", "centernet", "roi", "compositor", "solver", "heads", "heads_wide", "postprocess", "inference", "pool", "bsgal", "augment"]
     for w in which:
         globals()["gen_" + w]()

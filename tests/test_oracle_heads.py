@@ -1,5 +1,8 @@
 """Oracle CenterNet / heads / compositor / solver vs outputs of the reference's own files."""
+import os
+
 import numpy as np
+import pytest
 import torch
 
 from oracle import centernet as C
@@ -155,3 +158,22 @@ def test_resnet_oracle_frozen_bn_is_eval_batch_norm_and_r50_geometry():
     assert [tuple(f.shape) for f in feats] == [(1, 512, 9, 12), (1, 1024, 5, 6), (1, 2048, 3, 3)]
     sh = m.output_shape()
     assert [(sh[k].channels, sh[k].stride) for k in ("layer3", "layer4", "layer5")] == [(512, 8), (1024, 16), (2048, 32)]
+
+
+INFERENCE_CASES = ("agnostic", "perclass", "nonfinite", "empty", "swinL")
+
+
+@pytest.mark.parametrize("name", INFERENCE_CASES)
+def test_fast_rcnn_inference_matches_reference_output(name):
+    """oracle/heads.py fast_rcnn_inference_single_image vs the reference's own function run on the same tensors
+    (tests/golden/make_golden.py gen_inference): kept (row, class) pairs and their order bit-exact, boxes / scores equal."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fast_rcnn_inference.npz"))
+    h, w, st, nt, topk = g[name + "_cfg"]
+    boxes, scores, classes, rows = Hd.fast_rcnn_inference_single_image(
+        torch.from_numpy(g[name + "_boxes"]), torch.from_numpy(g[name + "_scores"]), (int(h), int(w)), float(st), float(nt), int(topk))
+    assert np.array_equal(rows.numpy(), g[name + "_out_rows"]) and np.array_equal(classes.numpy(), g[name + "_out_classes"])
+    assert np.array_equal(boxes.numpy(), g[name + "_out_boxes"]) and np.array_equal(scores.numpy(), g[name + "_out_scores"])
+    if name == "empty":
+        assert len(rows) == 0
+    else:
+        assert len(rows) > 0 and bool((scores[:-1] >= scores[1:]).all())

@@ -31,8 +31,13 @@ def warmup_cosine_lr(base_lr, it, max_iters, warmup_iters, warmup_factor, warmup
 
 
 class FlatArena:
-    """Re-homes every trainable parameter of `model` into one contiguous fp32 buffer (16-byte
-    aligned segments) and gives each a persistent .grad view into a second buffer."""
+    """Re-homes every trainable parameter of `model` into one contiguous fp32 buffer and gives each a persistent .grad view
+    into a second buffer.  Segments start on multiples of ALIGN = 64 elements: 128 bytes in the bf16 shadow / transposed twin
+    (the GEMMs' B operand: a 128-byte row chunk of an LDS-direct load is then ONE cache line; with the 4-element alignment of
+    rounds 1-2 every weight behind a 529 x nH bias table sat 48 bytes off and each chunk cost two L2 requests -- measured in
+    situ, profiles/r03_gemm_insitu_pmc.txt: +27..46 % requests per launch against the same shapes on aligned operands) and
+    256 bytes in the fp32 weight / gradient arenas (the weight-gradient read-outs)."""
+    ALIGN = 64
 
     def __init__(self, model):
         params, seen = [], set()
@@ -66,7 +71,7 @@ class FlatArena:
         for u in units:
             if len(u) == 1:
                 offs.append(n)
-                sizes.append((self.padded_numel(u[0][1]) + 3) // 4 * 4)
+                sizes.append((self.padded_numel(u[0][1]) + self.ALIGN - 1) // self.ALIGN * self.ALIGN)
                 n += sizes[-1]
                 continue
             cols = u[0][1].numel() // u[0][1].shape[0]
@@ -80,7 +85,7 @@ class FlatArena:
                 offs.append(n)
                 sizes.append(q.numel())
                 n += q.numel()
-            tail = (g0 + rows_pad * cols + 3) // 4 * 4 - n          # zero rows behind the last member belong to its segment
+            tail = (g0 + rows_pad * cols + self.ALIGN - 1) // self.ALIGN * self.ALIGN - n          # zero rows behind the last member belong to its segment
             sizes[-1] += tail
             n += tail
             self._groups.append((g0, rows_pad, cols, [q for _, q in u]))

@@ -38,5 +38,5 @@ for key, (c, us, cyc, hit, miss) in sorted(agg.items(), key=lambda kv: -kv[1][1]
     tot += us
     print("%8d %6d %6d %4d %3dx%-3d   %8.1f %8.1f %9.3f %6.0f %5.2f %6.3f %10.0f" % (
         M, N, K, mode, bm, bn, c / steps, us / c, us / 1e3 / steps, 2.0 * M * N * K / (us / c) / 1e6,
-        cyc / us / 1e3 if us else 0.0, hit / (hit + miss) if hit + miss else 0.0, (hit + miss) / c))
+        cyc / us / 1e4 if us else 0.0, hit / (hit + miss) if hit + miss else 0.0, (hit + miss) / c))
 print("total %.2f ms/step" % (tot / 1e3 / steps))

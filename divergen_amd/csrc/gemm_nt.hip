@@ -246,8 +246,74 @@ __global__ __launch_bounds__(512, MINW) void gemm_nt_kernel(GemmP P) {
         }
         return;
     }
-    // ---- epilogue: stage the tile as bf16 (bias added) in LDS, then stream whole rows out with the fused tail
+    // ---- epilogue: stage the tile as bf16 (bias added) in LDS, then stream whole rows out with the fused tail.  The extra
+    // operands of the tail (mode 4 / 5: the saved pre-activation tile; mode 3: the residual rows -- cold in HBM) are requested
+    // for the WHOLE tile before the accumulators are staged (ITERS 16-byte loads per lane in flight, hidden behind the staging
+    // pass and its barrier); round 2 fetched them in batches of four behind the barrier and the read-out waited on each batch.
     DGX_LDS unsigned char* stg = (DGX_LDS unsigned char*)lds_raw;
+    DGX_LDS int64_t* rowtok = reinterpret_cast<DGX_LDS int64_t*>(stg + BM * SROW);   // mode 3: (token << 12 | sample) per tile row
+    constexpr int CPR = BN / 8;                    // 16-byte chunks per tile row
+    constexpr int ITERS = (BM * CPR + 511) / 512;
+    if (P.mode == 3) {
+        if (tid < BM) {
+            int b = 0;
+            const int64_t orow = (int64_t)m0 + tid;
+            const int64_t tok = orow < P.M ? g_row_token(P.map, orow, b) : -1;
+            rowtok[tid] = tok < 0 ? -1 : ((tok << 12) | (int64_t)b);
+        }
+        __syncthreads();
+    }
+    u32x4 xa[ITERS], xb[ITERS];
+    int tid_e = tid;
+    asm volatile("" : "+v"(tid_e));               // opaque: keeps the chunk addresses of the tail from being formed above the main loop
+    // chunk `it` of this lane: tile row / 16-byte column, global row / column, token and DropPath factor (mode 3)
+    auto locate = [&](int it, int& row, int& ch, int& gm, int& gn, int64_t& tok, float& sc) -> bool {
+        const int idx = tid_e + it * 512;
+        row = idx / CPR;
+        ch = idx - row * CPR;
+        gm = m0 + row;
+        gn = n0 + 8 * ch;
+        tok = 0;
+        sc = 1.0f;
+        bool ok = idx < BM * CPR && gm < P.M && gn < P.N;
+        if (P.mode == 3 && ok) {
+            const int64_t rt = rowtok[row];
+            ok = rt >= 0;
+            tok = rt >> 12;
+            if (ok && P.scale) sc = P.scale[(int)(rt & 4095)];
+        }
+        return ok;
+    };
+    // branch-free per lane (a chunk outside the problem reads element 0 of the operand and is dropped in the finish loop): with
+    // the loads under per-lane conditions the compiler carries both arrays through every join and spills them
+    static_assert((BM * CPR) % 512 == 0, "every lane owns exactly ITERS chunks");
+    if (P.mode == 4 || P.mode == 5) {
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int idx = tid_e + it * 512, row = idx / CPR, gm = m0 + row, gn = n0 + 8 * (idx - row * CPR);
+            const int64_t off = (gm < P.M && gn < P.N) ? (int64_t)gm * P.ldaux + gn : 0;
+            xa[it] = *reinterpret_cast<const u32x4*>(P.aux + off);
+        }
+    } else if (P.mode == 3) {
+        if (P.res_dtype == DGX_BF16) {
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it) {
+                const int idx = tid_e + it * 512, row = idx / CPR, gm = m0 + row, gn = n0 + 8 * (idx - row * CPR);
+                const int64_t rt = rowtok[row];
+                const int64_t off = (gm < P.M && gn < P.N && rt >= 0) ? (rt >> 12) * P.N + gn : 0;
+                xa[it] = *reinterpret_cast<const u32x4*>((const uint16_t*)P.res + off);
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it) {
+                const int idx = tid_e + it * 512, row = idx / CPR, gm = m0 + row, gn = n0 + 8 * (idx - row * CPR);
+                const int64_t rt = rowtok[row];
+                const int64_t off = (gm < P.M && gn < P.N && rt >= 0) ? (rt >> 12) * P.N + gn : 0;
+                xa[it] = reinterpret_cast<const u32x4*>((const float*)P.res + off)[0];
+                xb[it] = reinterpret_cast<const u32x4*>((const float*)P.res + off)[1];
+            }
+        }
+    }
     {
         const int colw = wc * (BN / 4) + 4 * g;    // + 16 j: this lane's 4 consecutive columns
         float bv[WNF][4];
@@ -274,57 +340,15 @@ __global__ __launch_bounds__(512, MINW) void gemm_nt_kernel(GemmP P) {
             }
         }
     }
-    DGX_LDS int64_t* rowtok = reinterpret_cast<DGX_LDS int64_t*>(stg + BM * SROW);   // mode 3: (token << 12 | sample) per tile row
-    if (P.mode == 3 && tid < BM) {
-        int b = 0;
-        const int64_t orow = (int64_t)m0 + tid;
-        const int64_t tok = orow < P.M ? g_row_token(P.map, orow, b) : -1;
-        rowtok[tid] = tok < 0 ? -1 : ((tok << 12) | (int64_t)b);
-    }
     __syncthreads();
     GCLK(3);
-    constexpr int CPR = BN / 8;                    // 16-byte chunks per tile row
-    constexpr int ITERS = (BM * CPR + 511) / 512;
-    // read-out in batches of EB chunks per lane: the extra operands of batch b + 1 (saved pre-activation / residual rows,
-    // cold in HBM) are requested before batch b is finished, so a lane has EB loads in flight instead of one
-    constexpr int EB = 4, NBATCH = (ITERS + EB - 1) / EB;
-    struct Chunk { int row, ch, gm, gn; bool ok; int64_t tok; float sc; u32x4 xa, xb; };
-    auto locate = [&](int it, Chunk& q) {
-        const int idx = tid + it * 512;
-        q.row = idx / CPR;
-        q.ch = idx - q.row * CPR;
-        q.gm = m0 + q.row;
-        q.gn = n0 + 8 * q.ch;
-        q.ok = it < ITERS && idx < BM * CPR && q.gm < P.M && q.gn < P.N;
-        q.tok = 0;
-        q.sc = 1.0f;
-        q.xa = q.xb = u32x4{0u, 0u, 0u, 0u};
-        if (P.mode == 3 && q.ok) {
-            const int64_t rt = rowtok[q.row];
-            q.ok = rt >= 0;
-            q.tok = rt >> 12;
-            if (q.ok && P.scale) q.sc = P.scale[(int)(rt & 4095)];
-        }
-        if (q.ok) g_epi_prefetch(P, q.gm, q.gn, q.tok, q.xa, q.xb);
-    };
-    Chunk cur[EB], nxt[EB];
 #pragma unroll
-    for (int k = 0; k < EB; ++k) locate(k, cur[k]);
-#pragma unroll
-    for (int b = 0; b < NBATCH; ++b) {
-        if (b + 1 < NBATCH) {
-#pragma unroll
-            for (int k = 0; k < EB; ++k) locate((b + 1) * EB + k, nxt[k]);
-        }
-#pragma unroll
-        for (int k = 0; k < EB; ++k)
-            if (cur[k].ok)
-                g_epi_finish(P, cur[k].gm, cur[k].gn, *reinterpret_cast<DGX_LDS const u32x4*>(stg + cur[k].row * SROW + cur[k].ch * 16),
-                             cur[k].tok, cur[k].sc, cur[k].xa, cur[k].xb);
-        if (b + 1 < NBATCH) {
-#pragma unroll
-            for (int k = 0; k < EB; ++k) cur[k] = nxt[k];
-        }
+    for (int it = 0; it < ITERS; ++it) {
+        int row, ch, gm, gn;
+        int64_t tok;
+        float sc;
+        if (locate(it, row, ch, gm, gn, tok, sc))
+            g_epi_finish(P, gm, gn, *reinterpret_cast<DGX_LDS const u32x4*>(stg + row * SROW + ch * 16), tok, sc, xa[it], xb[it]);
     }
     GCLK(4);
     GCLKR(6);

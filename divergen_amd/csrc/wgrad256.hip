@@ -258,10 +258,31 @@ __global__ __launch_bounds__(256) void wgrad256_partial_kernel(Params256 P) {
 }
 
 // LPQ = lanes per output quad: 1 for large outputs; 16 when the output is small and the split deep (a 192 x 48 patch-embed
-// weight is cut into 256 slabs: one lane per quad would walk them serially, 2 300 lanes for the whole launch)
+// weight is cut into 256 slabs: one lane per quad would walk them serially, 2 300 lanes for the whole launch).
+// The last `bias_blocks` workgroups of the launch fold the bias-gradient slabs of the split problems instead
+// (gb[n] = beta * gb[n] + sum_s wsb[s][n], one lane per column, fixed order; block = (problem, 256 columns)): round 2 ran a
+// third launch for them (41 launches and 0.4 ms per step of one-wave-deep latency).
 template <int LPQ>
-__global__ __launch_bounds__(256) void wgrad256_reduce_kernel(Params256 P, int64_t total4) {
-    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total4 * LPQ; t += (int64_t)gridDim.x * blockDim.x) {
+__global__ __launch_bounds__(256) void wgrad256_reduce_kernel(Params256 P, int64_t total4, int bias_blocks, int bias_cb) {
+    const int main_blocks = (int)gridDim.x - bias_blocks;
+    if ((int)blockIdx.x >= main_blocks) {
+        const int j = (int)blockIdx.x - main_blocks, pi = j / bias_cb;
+        const Prob256& q = P.p[pi];
+        if (pi >= P.n || q.S <= 1 || !q.gb) return;
+        const int n = (j - pi * bias_cb) * 256 + threadIdx.x;
+        if (n >= q.Nn) return;
+        const float* w = q.wsb + n;
+        float a = 0.f;
+        int s = 0;
+        for (; s + 4 <= q.S; s += 4) {             // four slabs in flight; the additions keep the slab order
+            const float v0 = w[(int64_t)s * q.Nn], v1 = w[(int64_t)(s + 1) * q.Nn], v2 = w[(int64_t)(s + 2) * q.Nn], v3 = w[(int64_t)(s + 3) * q.Nn];
+            a += v0; a += v1; a += v2; a += v3;
+        }
+        for (; s < q.S; ++s) a += w[(int64_t)s * q.Nn];
+        q.gb[n] = P.beta != 0.f ? P.beta * q.gb[n] + a : a;
+        return;
+    }
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total4 * LPQ; t += (int64_t)main_blocks * blockDim.x) {
         const int64_t i = t / LPQ;
         const int sub = (int)(t - i * LPQ);
         int pi = 0;
@@ -291,17 +312,6 @@ __global__ __launch_bounds__(256) void wgrad256_reduce_kernel(Params256 P, int64
         }
         *C = a;
     }
-}
-
-// split problems: gb[n] = beta*gb[n] + sum_s wsb[s][n], one thread per column, fixed order
-__global__ __launch_bounds__(256) void wgrad256_bias_reduce_kernel(Params256 P) {
-    const Prob256& q = P.p[blockIdx.y];
-    if (blockIdx.y >= P.n || q.S <= 1 || !q.gb) return;
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= q.Nn) return;
-    float a = 0.f;
-    for (int s = 0; s < q.S; ++s) a += q.wsb[(int64_t)s * q.Nn + n];
-    q.gb[n] = P.beta != 0.f ? P.beta * q.gb[n] + a : a;
 }
 
 // rows per workgroup R (multiple of BM256) such that sum_p tiles_p * ceil(M_p / R) fits one round of 256 workgroups
@@ -455,23 +465,24 @@ static int wgrad_grouped_impl(const dgx_wgrad_problem* problems, const int* ldc,
     }
     P.per_xcd = (wg + 7) / 8;
     hipLaunchKernelGGL(wgrad256_partial_kernel, dim3(8 * P.per_xcd), dim3(256), sm, st, P);
-    if (red > 0) {
-        int maxS = 1;
-        for (int i = 0; i < n; ++i) maxS = S[i] > maxS ? S[i] : maxS;
-        if (red <= 32768 && maxS >= 16) {          // small output, deep split: 16 lanes share the walk over the slabs
-            // (total4 * 16 is a multiple of 64, so the xor-shuffles never mix lanes of different quads with idle ones)
-            hipLaunchKernelGGL(wgrad256_reduce_kernel<16>, dim3((int)((red * 16 + 255) / 256)), dim3(256), 0, st, P, red);
-        } else {
-            const int grid = (int)((red + 255) / 256 < 8192 ? (red + 255) / 256 : 8192);
-            hipLaunchKernelGGL(wgrad256_reduce_kernel<1>, dim3(grid), dim3(256), 0, st, P, red);
-        }
-    }
+    int bias_cb = 1, bias_blocks = 0;              // bias-gradient folds of the split problems ride in the reduce launch
     {
         int maxNn = 0;
-        bool any = false;
         for (int i = 0; i < n; ++i)
-            if (S[i] > 1 && problems[i].gb) { any = true; maxNn = problems[i].Nn > maxNn ? problems[i].Nn : maxNn; }
-        if (any) hipLaunchKernelGGL(wgrad256_bias_reduce_kernel, dim3((maxNn + 255) / 256, n), dim3(256), 0, st, P);
+            if (S[i] > 1 && problems[i].gb) maxNn = problems[i].Nn > maxNn ? problems[i].Nn : maxNn;
+        if (maxNn > 0) { bias_cb = (maxNn + 255) / 256; bias_blocks = bias_cb * n; }
+    }
+    if (red > 0 || bias_blocks > 0) {
+        int maxS = 1;
+        for (int i = 0; i < n; ++i) maxS = S[i] > maxS ? S[i] : maxS;
+        if (red > 0 && red <= 32768 && maxS >= 16) {   // small output, deep split: 16 lanes share the walk over the slabs
+            // (total4 * 16 is a multiple of 64, so the xor-shuffles never mix lanes of different quads with idle ones)
+            hipLaunchKernelGGL(wgrad256_reduce_kernel<16>, dim3((int)((red * 16 + 255) / 256) + bias_blocks), dim3(256), 0, st, P, red,
+                               bias_blocks, bias_cb);
+        } else {
+            const int grid = (int)((red + 255) / 256 < 8192 ? (red + 255) / 256 : 8192);
+            hipLaunchKernelGGL(wgrad256_reduce_kernel<1>, dim3(grid + bias_blocks), dim3(256), 0, st, P, red, bias_blocks, bias_cb);
+        }
     }
     DGX_LAUNCH_CHECK();
     return DGX_OK;

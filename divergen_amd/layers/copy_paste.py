@@ -37,7 +37,7 @@ def copy_paste(image, masks, boxes, labels, pastes):
     out_masks = torch.empty(nobj, H, W, dtype=torch.uint8, device=dev)
     out_boxes = torch.empty(nobj, 4, dtype=torch.float32, device=dev)
     out_valid = torch.empty(nobj, dtype=torch.uint8, device=dev)
-    stats = torch.empty(nobj * (K + 1) * 5 + H * W, dtype=torch.int32, device=dev)
+    stats = torch.empty(nobj * (K + 1) * 5 + 3 + H * W, dtype=torch.int32, device=dev)
     L.check(L.lib().dgx_copy_paste(L.ptr(image), L.ptr(masks) if n0 else None, L.ptr(boxes0) if n0 else None, n0, H, W,
                                    L.ptr(flat), L.ptr(desc_t), K, L.ptr(out_masks), L.ptr(out_boxes), L.ptr(out_valid),
                                    L.ptr(stats), L.stream()), "dgx_copy_paste")

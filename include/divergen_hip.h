@@ -235,7 +235,8 @@ int dgx_centernet_label_inds(const float* gt_boxes, const int32_t* gt_offsets, i
  *   out_boxes f32 (n0+K, 4), out_valid u8 (n0+K): 1 if the object survives the reference's
  *   occlusion filter (|box delta| <= 10 in all coords, or area > 300) at every step and, for
  *   pastes, has a non-empty footprint.  The host compacts by out_valid (order preserved).
- *   stats i32 workspace of (n0+K)*(K+1)*5 + H*W words (per-object histograms + per-pixel cover bits).
+ *   stats i32 workspace of (n0+K)*(K+1)*5 + 3 + H*W words, 16-byte aligned (per-object histograms, then -- on the next
+ *   16-byte boundary -- the per-pixel cover words).
  *   K <= 31. */
 int dgx_copy_paste(uint8_t* image, const uint8_t* masks, const float* boxes0, int n0, int H, int W,
                    const uint8_t* src_rgba, const int32_t* src_desc, int K, uint8_t* out_masks,

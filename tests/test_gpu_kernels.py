@@ -392,6 +392,33 @@ def test_copy_paste_random_vs_oracle_full_size():
         assert np.array_equal(out[k].cpu().numpy(), ref[k]), k
 
 
+@pytest.mark.parametrize("H,W,n,K", [(77, 101, 3, 7), (30, 24, 2, 5), (64, 80, 0, 3), (50, 37, 4, 31), (128, 256, 70, 2)])
+def test_copy_paste_ragged_sizes_vs_oracle(H, W, n, K):
+    """Row lengths / plane sizes that are not multiples of the 16-pixel groups of cp_stats / cp_masks (byte path), planes that are
+    (vector path with W % 16 != 0 handled per row), no original objects, the maximum number of pastes, and more objects than
+    one resolve workgroup holds (64)."""
+    rng = np.random.default_rng(H * 1000 + W + K)
+    yy, xx = np.mgrid[0:H, 0:W]
+    masks = np.zeros((n, H, W), np.uint8)
+    for i in range(n):
+        cx, cy, rx, ry = rng.uniform(0, W), rng.uniform(0, H), rng.uniform(3, W / 3), rng.uniform(3, H / 3)
+        masks[i] = (((xx - cx) / rx) ** 2 + ((yy - cy) / ry) ** 2) <= 1
+    img = rng.integers(0, 256, (3, H, W), dtype=np.uint8)
+    boxes = OK.get_bboxes(masks) if n else np.zeros((0, 4), np.float32)
+    labels = rng.integers(0, 1203, n).astype(np.int64)
+    pastes = []
+    for k in range(K):
+        sh, sw = int(rng.uniform(4, H * 0.7)), int(rng.uniform(4, W * 0.7))
+        rgba = rng.integers(0, 256, (sh, sw, 4), dtype=np.uint8)
+        y2, x2 = np.mgrid[0:sh, 0:sw]
+        rgba[..., 3] *= ((((x2 - sw / 2) / (sw / 2)) ** 2 + ((y2 - sh / 2) / (sh / 2)) ** 2) <= 1).astype(np.uint8)
+        pastes.append((rgba, int(rng.integers(-sw // 2, W - sw // 2)), int(rng.integers(-sh // 2, H - sh // 2)), 2000 + k))
+    ref = OK.composite(img, masks, boxes, labels, pastes)
+    out = la.copy_paste(T(img).to(DEV), T(masks).to(DEV), T(boxes).to(DEV), T(labels).to(DEV), pastes)
+    for k in ("image", "masks", "boxes", "labels", "source"):
+        assert np.array_equal(out[k].cpu().numpy(), ref[k]), k
+
+
 # ------------------------------------------------------------------ optimizer
 def test_adamw_ema_step_vs_oracle():
     g = torch.Generator().manual_seed(41)

@@ -260,7 +260,7 @@ __global__ __launch_bounds__(WinCfg<WS>::NT * 64) void win_attn_bwd_kernel(
     const uint32_t st_qk_c = (uint32_t)(srow * (int)rowst + 8 * sc);     // staging chunk inside this window's qkv rows
     const uint32_t st_o_c = (uint32_t)(srow * C + 8 * sc);               // ... inside out / dout rows
     const uint32_t v_off_c = (uint32_t)((kok ? key : 0) * (int)rowst + 8 * g);
-    const uint32_t row4_c = (uint32_t)((16 * w + 4 * g) * (int)rowst + c16);   // output rows 16w + 4g (+ r via the base)
+    const uint32_t row4_c = (uint32_t)((kok ? key : 0) * (int)rowst + 4 * g);   // output row = this lane's key / query, entries 4g ..
     auto issue = [&](int b, BwdPrefetch& P) {
         const uint16_t* base = qkv + (int64_t)b * N * rowst + h * 32;
         const uint16_t* dob = dout + (int64_t)b * N * C + h * 32;
@@ -381,26 +381,24 @@ __global__ __launch_bounds__(WinCfg<WS>::NT * 64) void win_attn_bwd_kernel(
             const bf16x8 pf = __builtin_bit_cast(bf16x8, a);   // A = P^T : row = key, slots = queries
             const bf16x8 df = __builtin_bit_cast(bf16x8, d);   // A = dS^T
             // B operands = dO / Q rows {32t+4g+j, 32t+16+4g+j} (the k-slot order of P^T / dS^T), by transpose reads
-            dV[0] = mfma16(pf, tr_frag(do_l4, 32 * t * RR, (32 * t + 16) * RR), dV[0]);
-            dV[1] = mfma16(pf, tr_frag(do_l4, 32 * t * RR + 16, (32 * t + 16) * RR + 16), dV[1]);
-            dK[0] = mfma16(df, tr_frag(q_l4, 32 * t * RR, (32 * t + 16) * RR), dK[0]);
-            dK[1] = mfma16(df, tr_frag(q_l4, 32 * t * RR + 16, (32 * t + 16) * RR + 16), dK[1]);
+            // swapped operands: D = (dO^T) (P) = dV^T, so a lane ends up with 4 CONSECUTIVE head-dim entries of ONE key
+            // (8-byte stores; with P^T as the A operand it held one entry of 4 keys: 2-byte stores, 4 x 32-byte pieces each)
+            dV[0] = mfma16(tr_frag(do_l4, 32 * t * RR, (32 * t + 16) * RR), pf, dV[0]);
+            dV[1] = mfma16(tr_frag(do_l4, 32 * t * RR + 16, (32 * t + 16) * RR + 16), pf, dV[1]);
+            dK[0] = mfma16(tr_frag(q_l4, 32 * t * RR, (32 * t + 16) * RR), df, dK[0]);
+            dK[1] = mfma16(tr_frag(q_l4, 32 * t * RR + 16, (32 * t + 16) * RR + 16), df, dK[1]);
             __builtin_amdgcn_sched_barrier(0);   // keep the t-steps apart: shorter live ranges, no spills
         }
         CLK(2);
         uint16_t* dqb = dqkv + (int64_t)b * N * rowst + h * 32;
         uint32_t row4 = row4_c;
         asm volatile("" : "+v"(row4));   // same: store addresses are per-window temporaries
+        if (kok) {                       // this lane: key 16w + c16, head-dim entries 16 dt + 4g .. + 3
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            if (16 * w + 4 * g + r < N) {
-                uint16_t* dkr = dqb + r * rowst + C;      // uniform
-                uint16_t* dvr = dqb + r * rowst + 2 * C;
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt) {
-                    dkr[row4 + 16 * dt] = f2bf(dK[dt][r] * scale);
-                    dvr[row4 + 16 * dt] = f2bf(dV[dt][r]);
-                }
+            for (int dt = 0; dt < 2; ++dt) {
+                *reinterpret_cast<u32x2*>(dqb + C + row4 + 16 * dt) =
+                    u32x2{pack_bf2(dK[dt][0] * scale, dK[dt][1] * scale), pack_bf2(dK[dt][2] * scale, dK[dt][3] * scale)};
+                *reinterpret_cast<u32x2*>(dqb + 2 * C + row4 + 16 * dt) = u32x2{pack_bf2(dV[dt][0], dV[dt][1]), pack_bf2(dV[dt][2], dV[dt][3])};
             }
         }
         CLK(3);
@@ -414,17 +412,15 @@ __global__ __launch_bounds__(WinCfg<WS>::NT * 64) void win_attn_bwd_kernel(
 #pragma unroll
         for (int t = 0; t < NTK / 2; ++t) {
             const bf16x8 sa = tr_frag(ds_l8, 32 * t * RD, (32 * t + 4) * RD);   // k-slots = keys 32t+8g .. +7 for A and B
-            dQ[0] = mfma16(sa, tr_frag(k_l8, 32 * t * RR, (32 * t + 4) * RR), dQ[0]);
-            dQ[1] = mfma16(sa, tr_frag(k_l8, 32 * t * RR + 16, (32 * t + 4) * RR + 16), dQ[1]);
+            dQ[0] = mfma16(tr_frag(k_l8, 32 * t * RR, (32 * t + 4) * RR), sa, dQ[0]);            // swapped: dQ^T, see dV / dK
+            dQ[1] = mfma16(tr_frag(k_l8, 32 * t * RR + 16, (32 * t + 4) * RR + 16), sa, dQ[1]);
         }
         CLK(5);
+        if (kok) {                       // query 16w + c16
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            if (16 * w + 4 * g + r < N) {
-                uint16_t* dqr = dqb + r * rowst;          // uniform
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt) dqr[row4 + 16 * dt] = f2bf(dQ[dt][r] * scale);
-            }
+            for (int dt = 0; dt < 2; ++dt)
+                *reinterpret_cast<u32x2*>(dqb + row4 + 16 * dt) =
+                    u32x2{pack_bf2(dQ[dt][0] * scale, dQ[dt][1] * scale), pack_bf2(dQ[dt][2] * scale, dQ[dt][3] * scale)};
         }
         CLK(6);
     }

@@ -224,6 +224,68 @@ class _Conv3x3Implicit(torch.autograd.Function):
 _IMPLICIT = os.environ.get("DGX_CONV_IMPLICIT", "1") == "1"      # A/B switch against the im2col path
 
 
+class _Conv3x3Group(torch.autograd.Function):
+    """3x3 / pad 1 / stride 1 convolution whose output channels are the rows of an ARENA PARAMETER GROUP (solver.FlatArena:
+    the group's weights sit back to back, rounded up to `pad_to` zero rows; CenterNetHead's agn_hm (1) | bbox_pred (4) | zeros):
+    forward, input gradient and weight / bias gradient read and write the group's views (`_dgx16g`, the tap-flipped
+    `_dgx16tg`, `_dgxgg`) -- ONE implicit GEMM each, no torch.cat of weights, no padded copies, no per-call flipped twin,
+    gradients accumulated in place (round 2 rebuilt all of those per FPN level: ~20 small launches per level and direction)."""
+
+    @staticmethod
+    def forward(ctx, x, w_handle, b_handle):
+        N, H, W, C = x.shape
+        wk = w_handle._dgx16g                        # (rows_pad, 9 Cin) bf16, K-order (kh, kw, ci)
+        Co = wk.shape[0]
+        xp = _pad_image(x)
+        y = torch.empty(N, H, W, Co, dtype=torch.bfloat16, device=x.device)
+        ws = _splitk_workspace(x.device)
+        L.check(L.lib().dgx_conv3x3_gemm(L.ptr(xp), wk.data_ptr(), b_handle._dgx16g.data_ptr(), L.ptr(y), N, H, W, C, Co, 0,
+                                         ws.data_ptr(), ws.numel(), L.stream()), "dgx_conv3x3_gemm")
+        ctx.save_for_backward(xp)
+        ctx.w_handle, ctx.b_handle = w_handle, b_handle
+        ctx.cfg = (N, H, W, C, Co)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (xp,) = ctx.saved_tensors
+        N, H, W, C, Co = ctx.cfg
+        w_handle, b_handle = ctx.w_handle, ctx.b_handle
+        lib = L.lib()
+        g2 = gy.to(torch.bfloat16).contiguous()
+        gp = _pad_image(g2)
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty(N, H, W, C, dtype=torch.bfloat16, device=g2.device)
+            ws = _splitk_workspace(g2.device)
+            L.check(lib.dgx_conv3x3_gemm(L.ptr(gp), w_handle._dgx16tg.data_ptr(), None, L.ptr(gx), N, H, W, Co, C, 0, ws.data_ptr(),
+                                         ws.numel(), L.stream()), "dgx_conv3x3_gemm")
+        ws = torch.empty(max(int(lib.dgx_conv3x3_wgrad_bias_workspace_bytes(N, H, W, C, Co)), 16), dtype=torch.uint8, device=g2.device)
+        L.check(lib.dgx_conv3x3_wgrad_bias(L.ptr(gp), L.ptr(xp), w_handle._dgxgg.data_ptr(), b_handle._dgxgg.data_ptr(), N, H, W, C, Co, 1.0,
+                                           L.ptr(ws), L.stream()), "dgx_conv3x3_wgrad_bias")
+        for q in tuple(w_handle._dgx_group_members) + tuple(b_handle._dgx_group_members):
+            notify_ready(q)
+        return gx, None, None
+
+
+def conv3x3_group_usable(x, w_handle, b_handle):
+    """The grouped predictor convolution needs the arena (group views with a tap-flipped twin, fp32 gradient rows), a GPU
+    bf16-able input with Cin % 64 == 0 and a group padded to 64 rows (whole K-tiles for the input-gradient convolution)."""
+    wg, wt, gg = (getattr(w_handle, n, None) for n in ("_dgx16g", "_dgx16tg", "_dgxgg"))
+    bg, bgg = getattr(b_handle, "_dgx16g", None), getattr(b_handle, "_dgxgg", None)
+    return (_IMPLICIT and x.is_cuda and torch.is_grad_enabled() and wg is not None and wt is not None and gg is not None and bg is not None
+            and bgg is not None and getattr(w_handle, "_dgx16tg_flipped", False) and wg.shape[0] % 64 == 0 and x.shape[1] % 64 == 0
+            and gg.dtype == torch.float32)
+
+
+def conv3x3_group(x, w_handle, b_handle):
+    """x logical (N, C, H, W) -> logical (N, rows_pad, H, W) (NHWC storage): rows of the group in member order, then zeros."""
+    xh = _nhwc(x).to(torch.bfloat16)
+    with torch.autocast("cuda", enabled=False):
+        y = _Conv3x3Group.apply(xh, w_handle, b_handle)
+    return y.permute(0, 3, 1, 2)
+
+
 MIN_COUT = 8  # the MFMA GEMM writes 8-column chunks: 1- and 4-channel predictors run with zero-padded output channels
 
 

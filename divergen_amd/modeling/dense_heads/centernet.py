@@ -81,29 +81,50 @@ class CenterNet(nn.Module):
     # ---------------------------------------------------------------- forward
     def forward(self, images, features_dict, gt_instances):
         features = [features_dict[f] for f in self.in_features]
-        reg_pred_per_level, agn_hm_pred_per_level = self._run_head(features)
-        raw_hm = raw_reg = None
-        if self.training and reg_pred_per_level[0].is_cuda and not self.not_nms:
-            raw_hm, raw_reg = [a.detach() for a in agn_hm_pred_per_level], [r.detach() for r in reg_pred_per_level]
-        reg_pred_per_level = [r.float() for r in reg_pred_per_level]
-        agn_hm_pred_per_level = [a.float() for a in agn_hm_pred_per_level]
-        grids = self.compute_grids(features)
-        shapes = [(int(x.shape[2]), int(x.shape[3])) for x in reg_pred_per_level]
-        if not self.training:
-            hms = [x.sigmoid() for x in agn_hm_pred_per_level]
-            proposals = self.predict_instances(grids, hms, reg_pred_per_level, images.image_sizes)
-            for p in proposals:
-                p.proposal_boxes = p.get("pred_boxes")
-                p.objectness_logits = p.get("scores")
-                p.remove("pred_boxes")
-            return proposals, {}
-        pos_inds, reg_targets, flattened_hms = self._get_ground_truth(shapes, gt_instances)
-        reg_pred = torch.cat([x.permute(0, 2, 3, 1).reshape(-1, 4) for x in reg_pred_per_level], dim=0)
-        agn_hm_pred = torch.cat([x.permute(0, 2, 3, 1).reshape(-1) for x in agn_hm_pred_per_level], dim=0)
+        flat = self._run_head_flat(features) if self.training and not self.not_nms else None
+        if flat is not None:
+            # graphed training path: the captured segment ends in the flattened (sum_l B h_l w_l, 4) / (sum_l B h_l w_l) fp32
+            # tensors the losses take (the per-level float() / permute / reshape / cat of centernet.py:179-235 run inside the
+            # graph), so the replayed backward receives TWO contiguous gradients instead of ten strided per-level ones (round 2:
+            # 83 copy / fill launches per step inside torch's GraphedBackward); the proposal decode reads per-level NHWC views
+            reg_pred, agn_hm_pred = flat
+            shapes = [(int(x.shape[2]), int(x.shape[3])) for x in features]
+            B = int(features[0].shape[0])
+            raw_hm, raw_reg, off = [], [], 0
+            for h, w in shapes:
+                n = B * h * w
+                raw_reg.append(reg_pred.detach()[off:off + n].view(B, h, w, 4).permute(0, 3, 1, 2))
+                raw_hm.append(agn_hm_pred.detach()[off:off + n].view(B, h, w, 1).permute(0, 3, 1, 2))
+                off += n
+            pos_inds, reg_targets, flattened_hms = self._get_ground_truth(shapes, gt_instances)
+            reg_pred_per_level = agn_hm_pred_per_level = grids = None
+        else:
+            reg_pred_per_level, agn_hm_pred_per_level = self._run_head(features)
+            raw_hm = raw_reg = None
+            if self.training and reg_pred_per_level[0].is_cuda and not self.not_nms:
+                raw_hm, raw_reg = [a.detach() for a in agn_hm_pred_per_level], [r.detach() for r in reg_pred_per_level]
+            reg_pred_per_level = [r.float() for r in reg_pred_per_level]
+            agn_hm_pred_per_level = [a.float() for a in agn_hm_pred_per_level]
+            grids = self.compute_grids(features)
+            shapes = [(int(x.shape[2]), int(x.shape[3])) for x in reg_pred_per_level]
+            if not self.training:
+                hms = [x.sigmoid() for x in agn_hm_pred_per_level]
+                proposals = self.predict_instances(grids, hms, reg_pred_per_level, images.image_sizes)
+                for p in proposals:
+                    p.proposal_boxes = p.get("pred_boxes")
+                    p.objectness_logits = p.get("scores")
+                    p.remove("pred_boxes")
+                return proposals, {}
+            pos_inds, reg_targets, flattened_hms = self._get_ground_truth(shapes, gt_instances)
+            reg_pred = torch.cat([x.permute(0, 2, 3, 1).reshape(-1, 4) for x in reg_pred_per_level], dim=0)
+            agn_hm_pred = torch.cat([x.permute(0, 2, 3, 1).reshape(-1) for x in agn_hm_pred_per_level], dim=0)
         losses = self.losses(pos_inds, reg_targets, flattened_hms, reg_pred, agn_hm_pred)
         with torch.no_grad():
             proposals = self._predict_instances_fused(raw_hm, raw_reg, images.image_sizes) if raw_hm is not None else None
             if proposals is None:
+                if agn_hm_pred_per_level is None:      # flattened path whose layout the fused decode refused: per-level copies
+                    agn_hm_pred_per_level, reg_pred_per_level = [t.contiguous() for t in raw_hm], [t.contiguous() for t in raw_reg]
+                    grids = self.compute_grids(features)
                 hms = [x.detach().sigmoid() for x in agn_hm_pred_per_level]
                 proposals = self.predict_instances(grids, hms, [r.detach() for r in reg_pred_per_level], images.image_sizes)
         for p in proposals:
@@ -115,16 +136,19 @@ class CenterNet(nn.Module):
                 p.remove("pred_classes")
         return proposals, losses
 
-    def _run_head(self, features):
-        """Tower + predictors on every level; in training the whole thing is one captured hipGraph pair."""
+    def _run_head_flat(self, features):
+        """Tower + predictors on every level as one captured hipGraph pair ending in the flattened loss operands
+        (reg_pred (M, 4) fp32, agn_hm_pred (M,) fp32); None when the segment cannot be replayed (eval, capture in progress,
+        graphs switched off, CPU tensors)."""
         seg = self.__dict__.get("_segment")
         if seg is None:
             from ...utils.graphs import GraphedSegment
             seg = self.__dict__["_segment"] = GraphedSegment(_HeadSegment(self.centernet_head))
-        if self.training and self.with_agn_hm and seg.usable(features):
-            out = seg(*features)
-            n = len(features)
-            return list(out[:n]), list(out[n:])
+        if self.with_agn_hm and seg.usable(features):
+            return seg(*features)
+        return None
+
+    def _run_head(self, features):
         _, reg, hm = self.centernet_head(features)
         return reg, hm
 
@@ -395,7 +419,7 @@ class CenterNet(nn.Module):
 
 
 class _HeadSegment(nn.Module):
-    """CenterNetHead with tensors in / tuple out (regression maps then heat maps): the unit captured as a hipGraph."""
+    """CenterNetHead with tensors in / (flattened regression rows, flattened heat-map logits) out: the unit captured as a hipGraph."""
 
     def __init__(self, head):
         super().__init__()
@@ -405,7 +429,11 @@ class _HeadSegment(nn.Module):
     def forward(self, *feats):
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.amp, cache_enabled=False):
             _, reg, hm = self.head(list(feats))
-        return tuple(reg) + tuple(hm)
+        # centernet.py:179-235: per level (B, C, h, w) -> (B h w, C), levels stacked; float(bf16) is exact, so casting after the cat
+        # gives the values of the reference's order (cast, then cat)
+        reg_flat = torch.cat([x.permute(0, 2, 3, 1).reshape(-1, 4) for x in reg], dim=0).float()
+        hm_flat = torch.cat([x.permute(0, 2, 3, 1).reshape(-1) for x in hm], dim=0).float()
+        return reg_flat, hm_flat
 
 
 class _CenterNetLosses(torch.autograd.Function):

@@ -9,7 +9,8 @@ from torch.nn import functional as F
 
 from ...config import configurable
 from ...layers.norm_ops import groupnorm_relu
-from ...layers.conv_ops import Conv2d, conv3x3
+from ...layers.conv_ops import Conv2d, conv3x3, conv3x3_group, conv3x3_group_usable
+from ...layers.linear_ops import group_parameters
 
 
 class Scale(nn.Module):
@@ -52,6 +53,9 @@ class CenterNetHead(nn.Module):
             self.agn_hm = Conv2d(in_channels, 1, 3, 1, 1)
             nn.init.constant_(self.agn_hm.bias, bias_value)
             nn.init.normal_(self.agn_hm.weight, std=0.01)
+            # heat-map row first, the four regression rows behind it, zero rows up to 64 (one whole K-tile of the input gradient)
+            group_parameters(self.agn_hm.weight, self.bbox_pred.weight, pad_to=64)
+            group_parameters(self.agn_hm.bias, self.bbox_pred.bias, pad_to=64)
         if not only_proposal:
             self.cls_logits = Conv2d(in_channels, num_classes, 3, 1, 1)
             nn.init.constant_(self.cls_logits.bias, bias_value)
@@ -89,8 +93,14 @@ class CenterNetHead(nn.Module):
             cls_tower = self._run_tower(self.cls_tower, feature)
             bbox_tower = self._run_tower(self.bbox_tower, feature)
             clss.append(None if self.only_proposal else self.cls_logits(cls_tower))
-            if self.with_agn_hm:
-                # agn_hm (1 ch) and bbox_pred (4 ch) read the same tower output: one im2col + one GEMM
+            if self.with_agn_hm and conv3x3_group_usable(bbox_tower, self.agn_hm.weight, self.agn_hm.bias):
+                # agn_hm (1 ch) and bbox_pred (4 ch) read the same tower output and are one arena parameter group (5 rows + zero
+                # rows up to 64): ONE implicit GEMM each way on the group's views
+                both = conv3x3_group(bbox_tower, self.agn_hm.weight, self.agn_hm.bias)
+                agn_hms.append(both[:, :1])
+                reg = both[:, 1:5]
+            elif self.with_agn_hm:
+                # outside the arena (no optimizer built yet, eval): one GEMM over the concatenated weights
                 both = conv3x3(bbox_tower, torch.cat([self.agn_hm.weight, self.bbox_pred.weight], 0),
                                torch.cat([self.agn_hm.bias, self.bbox_pred.bias], 0))
                 agn_hms.append(both[:, :1])

@@ -129,13 +129,19 @@ class FlatArena:
             shape = (rows_pad,) if one_d else (rows_pad, cols)
             v16, vg = self.p16[g0:g0 + rows_pad * cols].view(shape), self.g[g0:g0 + rows_pad * cols].view(shape)
             vt = None
+            # a group of stride-1 3x3 convolutions stored (Cout, kh, kw, Cin) (the 1- and 4-channel CenterNet predictors): the
+            # twin is the tap-flipped (Cin, 3, 3, rows_pad) image their input-gradient convolution reads, as for single weights
+            conv = (not one_d and all(q.dim() == 4 and getattr(q, "_dgx_ohwi", False) and getattr(q, "_dgx_flip", False) for q in members)
+                    and members[0].shape[1] % 64 == 0 and rows_pad % 8 == 0)
             if self.p16t is not None and not one_d:
-                vt = self.p16t[g0:g0 + rows_pad * cols].view(cols, rows_pad)
-                jobs.append((g0, rows_pad | (cols << 32), tiles, 0))
+                cin = members[0].shape[1] if conv else 0
+                vt = self.p16t[g0:g0 + rows_pad * cols].view((cin, 9 * rows_pad) if conv else (cols, rows_pad))
+                jobs.append((g0, rows_pad | (cols << 32), tiles, cin))
                 tiles += ((rows_pad + 63) // 64) * ((cols + 63) // 64)
             r0 = 0
             for q in members:
                 q._dgx16g, q._dgxgg, q._dgx16tg, q._dgx_group_row0 = v16, vg, vt, r0
+                q._dgx16tg_flipped = bool(conv and vt is not None)
                 r0 += q.shape[0]
         self._tjobs = torch.tensor(jobs, dtype=torch.int64, device=dev) if jobs else None
         self._ttiles = tiles

@@ -33,7 +33,7 @@ WS_BYTES = 64 << 20      # split-K scratch (fp32 slabs of skinny, long-K problem
 def _workspace(dev):
     """One scratch buffer per (device, stream): two streams that run split-K GEMMs at the same time (the opt-in mask-branch
     side stream next to the box cascade) must not fold their fp32 slabs in the same buffer."""
-    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    key = (dev, L.stream())
     ws = _WS.get(key)
     if ws is None:
         ws = _WS[key] = torch.empty(WS_BYTES, dtype=torch.uint8, device=dev)

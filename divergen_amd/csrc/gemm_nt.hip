@@ -263,7 +263,11 @@ __global__ __launch_bounds__(512, MINW) void gemm_nt_kernel(GemmP P) {
         }
         __syncthreads();
     }
-    u32x4 xa[ITERS], xb[ITERS];
+    // PFN chunks of the tail operands per lane are requested at a time: the whole tile for the one-workgroup-per-CU instantiations,
+    // half of it where two workgroups share a CU (128 registers per lane; the partner workgroup covers the second half's latency)
+    constexpr int PFN = MINW >= 4 ? ITERS / 2 : ITERS;
+    static_assert(PFN > 0 && ITERS % PFN == 0 && ITERS / PFN <= 2, "one or two whole chunks");
+    u32x4 xa[PFN], xb[PFN];
     int tid_e = tid;
     asm volatile("" : "+v"(tid_e));               // opaque: keeps the chunk addresses of the tail from being formed above the main loop
     // chunk `it` of this lane: tile row / 16-byte column, global row / column, token and DropPath factor (mode 3)
@@ -287,33 +291,32 @@ __global__ __launch_bounds__(512, MINW) void gemm_nt_kernel(GemmP P) {
     // branch-free per lane (a chunk outside the problem reads element 0 of the operand and is dropped in the finish loop): with
     // the loads under per-lane conditions the compiler carries both arrays through every join and spills them
     static_assert((BM * CPR) % 512 == 0, "every lane owns exactly ITERS chunks");
-    if (P.mode == 4 || P.mode == 5) {
-#pragma unroll
-        for (int it = 0; it < ITERS; ++it) {
-            const int idx = tid_e + it * 512, row = idx / CPR, gm = m0 + row, gn = n0 + 8 * (idx - row * CPR);
-            const int64_t off = (gm < P.M && gn < P.N) ? (int64_t)gm * P.ldaux + gn : 0;
-            xa[it] = *reinterpret_cast<const u32x4*>(P.aux + off);
-        }
-    } else if (P.mode == 3) {
-        if (P.res_dtype == DGX_BF16) {
-#pragma unroll
-            for (int it = 0; it < ITERS; ++it) {
-                const int idx = tid_e + it * 512, row = idx / CPR, gm = m0 + row, gn = n0 + 8 * (idx - row * CPR);
-                const int64_t rt = rowtok[row];
-                const int64_t off = (gm < P.M && gn < P.N && rt >= 0) ? (rt >> 12) * P.N + gn : 0;
-                xa[it] = *reinterpret_cast<const u32x4*>((const uint16_t*)P.res + off);
-            }
-        } else {
-#pragma unroll
-            for (int it = 0; it < ITERS; ++it) {
-                const int idx = tid_e + it * 512, row = idx / CPR, gm = m0 + row, gn = n0 + 8 * (idx - row * CPR);
-                const int64_t rt = rowtok[row];
-                const int64_t off = (gm < P.M && gn < P.N && rt >= 0) ? (rt >> 12) * P.N + gn : 0;
-                xa[it] = reinterpret_cast<const u32x4*>((const float*)P.res + off)[0];
-                xb[it] = reinterpret_cast<const u32x4*>((const float*)P.res + off)[1];
-            }
-        }
+#define DGX_EPI_PREFETCH(IT0)                                                                                                     \
+    if (P.mode == 4 || P.mode == 5) {                                                                                             \
+        _Pragma("unroll") for (int it = 0; it < PFN; ++it) {                                                                      \
+            const int idx = tid_e + ((IT0) + it) * 512, row = idx / CPR, gm = m0 + row, gn = n0 + 8 * (idx - row * CPR);          \
+            const int64_t off = (gm < P.M && gn < P.N) ? (int64_t)gm * P.ldaux + gn : 0;                                          \
+            xa[it] = *reinterpret_cast<const u32x4*>(P.aux + off);                                                                \
+        }                                                                                                                         \
+    } else if (P.mode == 3) {                                                                                                     \
+        if (P.res_dtype == DGX_BF16) {                                                                                            \
+            _Pragma("unroll") for (int it = 0; it < PFN; ++it) {                                                                  \
+                const int idx = tid_e + ((IT0) + it) * 512, row = idx / CPR, gm = m0 + row, gn = n0 + 8 * (idx - row * CPR);      \
+                const int64_t rt = rowtok[row];                                                                                   \
+                const int64_t off = (gm < P.M && gn < P.N && rt >= 0) ? (rt >> 12) * P.N + gn : 0;                                \
+                xa[it] = *reinterpret_cast<const u32x4*>((const uint16_t*)P.res + off);                                           \
+            }                                                                                                                     \
+        } else {                                                                                                                  \
+            _Pragma("unroll") for (int it = 0; it < PFN; ++it) {                                                                  \
+                const int idx = tid_e + ((IT0) + it) * 512, row = idx / CPR, gm = m0 + row, gn = n0 + 8 * (idx - row * CPR);      \
+                const int64_t rt = rowtok[row];                                                                                   \
+                const int64_t off = (gm < P.M && gn < P.N && rt >= 0) ? (rt >> 12) * P.N + gn : 0;                                \
+                xa[it] = reinterpret_cast<const u32x4*>((const float*)P.res + off)[0];                                            \
+                xb[it] = reinterpret_cast<const u32x4*>((const float*)P.res + off)[1];                                            \
+            }                                                                                                                     \
+        }                                                                                                                         \
     }
+    DGX_EPI_PREFETCH(0)
     {
         const int colw = wc * (BN / 4) + 4 * g;    // + 16 j: this lane's 4 consecutive columns
         float bv[WNF][4];
@@ -343,13 +346,25 @@ __global__ __launch_bounds__(512, MINW) void gemm_nt_kernel(GemmP P) {
     __syncthreads();
     GCLK(3);
 #pragma unroll
-    for (int it = 0; it < ITERS; ++it) {
+    for (int it = 0; it < PFN; ++it) {
         int row, ch, gm, gn;
         int64_t tok;
         float sc;
         if (locate(it, row, ch, gm, gn, tok, sc))
             g_epi_finish(P, gm, gn, *reinterpret_cast<DGX_LDS const u32x4*>(stg + row * SROW + ch * 16), tok, sc, xa[it], xb[it]);
     }
+    if constexpr (PFN < ITERS) {
+        DGX_EPI_PREFETCH(PFN)
+#pragma unroll
+        for (int it = 0; it < PFN; ++it) {
+            int row, ch, gm, gn;
+            int64_t tok;
+            float sc;
+            if (locate(PFN + it, row, ch, gm, gn, tok, sc))
+                g_epi_finish(P, gm, gn, *reinterpret_cast<DGX_LDS const u32x4*>(stg + row * SROW + ch * 16), tok, sc, xa[it], xb[it]);
+        }
+    }
+#undef DGX_EPI_PREFETCH
     GCLK(4);
     GCLKR(6);
 }
@@ -561,10 +576,16 @@ static int dgx_gemm_dispatch(GemmP& P, hipStream_t st) {
             if (choose_splits(tiles, P.K, P.M, P.N, P.ws ? g_ws_bytes_cur : 0) == 1 || nt < 8 || tiles > 128) return gemm256_launch(P, force, st);
         }
     }
-    // Measured and dropped (round 2): <128, 192, 2 stages, 4 waves / SIMD> = two co-resident workgroups per CU (80 KB of LDS and
-    // 128 registers each) so that one's read-out overlaps the other's main loop: -4 % on the K = 768 shapes, +10..30 % on the
-    // long-K ones, nothing on the step (the two workgroups of a CU start together and stay in phase).
     if (tc.bn == 192) {
+        // contractions of up to 12 K-tiles (K <= 768: every qkv / proj / fc1 / fc2-input-gradient GEMM of the backbone) spend a third of
+        // a tile's time in prologue and read-out: TWO workgroups share a CU there (128 x 192 tiles, 2 stages = 80 KB of LDS, 128
+        // registers per lane), so one's read-out -- with its GELU / GELU' / residual tail -- runs beside the other's main loop.
+        // Round 2 measured this geometry back to back with the bias tail only (-4 % at K = 768, +10..30 % at long K) and dropped it;
+        // inside the step, where the tails are the real ones, it wins wherever K <= 768 (round 3, same call: GEMM family
+        // 11.80 -> 11.18 ms/step; K <= 384 only: 11.58; every K: 11.70) and loses on the long contractions, which keep the deeper rings.
+        // DGX_GEMM_2WG=0 switches it off (A/B).
+        static const int two_wg = getenv("DGX_GEMM_2WG") ? atoi(getenv("DGX_GEMM_2WG")) : 1;
+        if (two_wg && P.K <= 768 && P.M >= 8192 && !P.conv_kc) return launch_gemm<128, 192, 2, 4>(P, st);
         if (tc.bm == 256) return launch_gemm<256, 192, 2>(P, st);
         if (tc.bm == 192) return launch_gemm<192, 192, 3>(P, st);
         return launch_gemm<128, 192, 4>(P, st);

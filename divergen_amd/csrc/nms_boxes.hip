@@ -75,8 +75,8 @@ __global__ __launch_bounds__(1024) void nms_sweep_kernel(const uint64_t* __restr
         // split over G row-groups so all 1024 threads have independent loads in flight
         const int ncols = nb - b - 1;
         if (ncols > 0 && kn > 0) {
-            int G = blockDim.x / ncols;
-            G = G < 1 ? 1 : (G > 8 ? 8 : G);
+            int G = blockDim.x / ncols;                 // lanes per column: each walks every G-th kept row, four loads in flight
+            G = G < 1 ? 1 : (G > 16 ? 16 : G);
             for (int idx = tid; idx < ncols * G; idx += blockDim.x) {
                 const int grp = idx / ncols, cb = b + 1 + (idx - grp * ncols);
                 uint64_t acc = 0;
@@ -185,10 +185,16 @@ __global__ __launch_bounds__(1024) void nms_sweep_batched_kernel(const uint64_t*
     for (int i = tid; i < cap; i += blockDim.x) keep_idx[i] = -1;
     if (tid == 0) { total = 0; done = 0; tie_score = 0.f; }
     __syncthreads();
+    // the diagonal word of a row does not depend on the sweep: the next block's words are requested while this block's kept
+    // rows are OR-ed into the removed vector (one global-memory latency less on the serial path per 64-box block)
+    uint64_t mine_next = (tid < 64 && tid < min(64, n)) ? mask[(int64_t)tid * nb] : 0ull;
     for (int blk = 0; blk < nbv; ++blk) {
+        const uint64_t mine_cur = mine_next;
+        if (tid < 64 && blk + 1 < nbv)
+            mine_next = tid < min(64, n - 64 * (blk + 1)) ? mask[(int64_t)(64 * (blk + 1) + tid) * nb + blk + 1] : 0ull;
         if (tid < 64) {
             const int cnt = min(64, n - 64 * blk);
-            const uint64_t mine = tid < cnt ? mask[(int64_t)(64 * blk + tid) * nb + blk] : 0ull;
+            const uint64_t mine = mine_cur;
             const uint64_t vbits = cnt == 64 ? ~0ull : ((1ull << cnt) - 1ull);
             uint64_t alive = uniform64(~remv[blk] & vbits);
             const int tot = __builtin_amdgcn_readfirstlane(total);
@@ -218,8 +224,8 @@ __global__ __launch_bounds__(1024) void nms_sweep_batched_kernel(const uint64_t*
         if (done) break;
         const int ncols = nbv - blk - 1;
         if (ncols > 0 && kn > 0) {
-            int G = blockDim.x / ncols;
-            G = G < 1 ? 1 : (G > 8 ? 8 : G);
+            int G = blockDim.x / ncols;                 // lanes per column: each walks every G-th kept row, four loads in flight
+            G = G < 1 ? 1 : (G > 16 ? 16 : G);
             for (int idx = tid; idx < ncols * G; idx += blockDim.x) {
                 const int grp = idx / ncols, cb = blk + 1 + (idx - grp * ncols);
                 uint64_t acc = 0;

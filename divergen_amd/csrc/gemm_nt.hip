@@ -479,6 +479,10 @@ int launch_gemm(GemmP& P, hipStream_t st) {
 }  // namespace
 
 static int dgx_gemm_dispatch(GemmP& P, hipStream_t st);
+static bool use_two_wg(const GemmP& P) {          // see dgx_gemm_dispatch
+    static const int two_wg = getenv("DGX_GEMM_2WG") ? atoi(getenv("DGX_GEMM_2WG")) : 1;
+    return two_wg && P.N % 192 == 0 && P.K <= 768 && P.M >= 8192 && !P.conv_kc;
+}
 static void* g_dbg_buffer = nullptr;
 static FILE* gemm_log_file() {     // development: one line per launch (DGX_GEMM_LOG=path), joined with a kernel trace
     static const char* logp = getenv("DGX_GEMM_LOG");
@@ -538,7 +542,7 @@ extern "C" int dgx_gemm_bf16_nt(const void* A, const void* B, int M, int N, int 
     const double mn = (double)M * N, rsz = ep->residual_dtype == DGX_F32 ? 4.0 : 2.0;
     const double obytes = ep->mode == DGX_EPI_BIAS_RESIDUAL ? 2.0 * rsz * mn : (ep->mode >= DGX_EPI_BIAS_GELU ? 4.0 * mn : 2.0 * mn);   // GELU / GELU' / ReLU': two tensors
     DgxProfScope prof(DGX_PROF_GEMM_NT, stream, 2.0 * mn * K, 2.0 * ((double)M * K + (double)N * K) + obytes);
-    if (FILE* lf = gemm_log_file()) { fprintf(lf, "%d %d %d %d %d %d\n", M, N, K, ep->mode, tc.bm, tc.bn); fflush(lf); }
+    if (FILE* lf = gemm_log_file()) { fprintf(lf, "%d %d %d %d %d %d\n", M, N, K, ep->mode, use_two_wg(P) ? 128 : tc.bm, tc.bn); fflush(lf); }
 #ifdef DGX_GEMM_DEV
     if (const char* dg = getenv("DGX_GEMM256") ? nullptr : getenv("DGX_GEMM_DIAG")) {
         switch (atoi(dg)) {
@@ -584,8 +588,7 @@ static int dgx_gemm_dispatch(GemmP& P, hipStream_t st) {
         // inside the step, where the tails are the real ones, it wins wherever K <= 768 (round 3, same call: GEMM family
         // 11.80 -> 11.18 ms/step; K <= 384 only: 11.58; every K: 11.70) and loses on the long contractions, which keep the deeper rings.
         // DGX_GEMM_2WG=0 switches it off (A/B).
-        static const int two_wg = getenv("DGX_GEMM_2WG") ? atoi(getenv("DGX_GEMM_2WG")) : 1;
-        if (two_wg && P.K <= 768 && P.M >= 8192 && !P.conv_kc) return launch_gemm<128, 192, 2, 4>(P, st);
+        if (use_two_wg(P)) return launch_gemm<128, 192, 2, 4>(P, st);
         if (tc.bm == 256) return launch_gemm<256, 192, 2>(P, st);
         if (tc.bm == 192) return launch_gemm<192, 192, 3>(P, st);
         return launch_gemm<128, 192, 4>(P, st);

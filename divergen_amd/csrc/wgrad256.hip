@@ -17,7 +17,7 @@ constexpr int BM256 = 32;               // m-depth per stage (one K=32 MFMA step
 constexpr int NB256 = 4;                // LDS stage buffers: the stage being computed + 3 in flight
 constexpr int OPB256 = BM256 * T256 * 2;       // bytes of one operand image per stage (16 KiB)
 constexpr int STB256 = 2 * OPB256;             // bytes per stage (A then B)
-constexpr int MAXP256 = 9;              // 9 = the taps of a 3x3 convolution (dgx_conv3x3_wgrad)
+constexpr int MAXP256 = 12;             // >= 9 (the taps of a 3x3 convolution, dgx_conv3x3_wgrad); 12: two Swin blocks and a part of a third (252 of 256 tiles)
 
 struct Prob256 {
     const uint16_t* A;

@@ -31,7 +31,7 @@ def wgrad_into(g2, dy2, x2, beta=1.0, gb=None):
 
 
 def wgrad_grouped(problems, beta=1.0):
-    """[(g2 fp32 (Nn,Kk), dy2 bf16 (M,Nn), x2 bf16 (M,Kk)[, gb fp32 (Nn) | None]), ...] (<= 9): g2 = beta*g2 + dy2^T x2 and, with
+    """[(g2 fp32 (Nn,Kk), dy2 bf16 (M,Nn), x2 bf16 (M,Kk)[, gb fp32 (Nn) | None]), ...] (<= 12): g2 = beta*g2 + dy2^T x2 and, with
     gb, the bias gradient gb = beta*gb + dy2.sum(0) from the same pass -- ONE launch (dgx_linear_wgrad_grouped: 256x256 MFMA
     tiles, M-split sized for the whole group)."""
     n = len(problems)

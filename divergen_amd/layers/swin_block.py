@@ -50,55 +50,90 @@ def colsum_grouped(problems, beta=1.0):
 
 
 import os
-# Weight / bias gradients of TWO consecutive blocks share one grouped launch: a Swin-L stage-2 block alone has 108 output tiles
-# of 256x256, so its grouped weight-gradient GEMM is split in two M-slabs (216 workgroups) whose fp32 partial tiles go through a
-# workspace and a reduce kernel; two blocks together are 216 tiles = one round of the chip with NO split: every workgroup runs
-# the whole contraction and folds straight into the gradient arena (no workspace, no reduce launch, half the fp32 tile traffic).
-# The first block's operands simply stay alive until the second block's backward has run; whatever is still pending when the
-# backward pass ends is flushed by an autograd end-of-backward callback.  DGX_WGRAD_PAIR=1 restores one launch per block.
-_PAIR = max(1, int(os.environ.get("DGX_WGRAD_PAIR", "2")))
-_PENDING = []
+# Weight / bias gradients of consecutive blocks share grouped launches: a Swin-L stage-2 block alone has 108 output tiles of
+# 256x256, so its grouped weight-gradient GEMM would be split in two M-slabs (216 workgroups) whose fp32 partial tiles go through
+# a workspace and a reduce kernel; two blocks together are 216 tiles = one round of the chip with NO split: every workgroup runs
+# the whole contraction and folds straight into the gradient arena (round 2).  Round 3 packs by PROBLEM instead of by block: a
+# launch takes queued problems in order while they fit 256 tiles, i.e. two blocks and the fc1 (or qkv + proj) of a third = 252
+# tiles instead of 216 on the 256 CUs, and 18 stage-2 blocks need 8 launches instead of 9 (a launch lasts one tile's contraction
+# whatever its tile count).  Operands stay alive until their problem has been launched; whatever is still pending when the backward
+# pass ends is flushed by an autograd end-of-backward callback.  DGX_WGRAD_PAIR=1 restores one launch per block, =2 block pairs.
+_PAIR = max(1, int(os.environ.get("DGX_WGRAD_PAIR", "3")))
+_PENDING = []          # [problem (g, dy, x, bias, weight), tiles] in arrival order
 _CB_QUEUED = [False]
+_ROUND, _MAXP = 256, 12
 
 
-def flush_wgrads():
-    """Launch the pending blocks' weight / bias gradients (<= 8 problems per grouped launch) and signal their parameters."""
-    _CB_QUEUED[0] = False
+def _tiles(g):
+    return (-(-g.shape[0] // 256)) * (-(-g.shape[1] // 256))
+
+
+def _launch(items):
+    # weight AND bias gradients in one grouped launch: the bias gradient is dY^T 1 on the fragments the weight-gradient kernel
+    # holds anyway (round 3; the separate column-sum kernels cost 95 launches / 1.1 ms per step)
+    wgrad_grouped([(g, d, x_, b.grad if b is not None else None) for (g, d, x_, b, w), _ in items])
+    for (g, d, x_, b, w), _ in items:
+        _ready(w) if b is None else _ready(w, b)
+
+
+def flush_wgrads(final=True):
+    """Launch pending weight / bias gradients (<= 12 problems and, when several fit, <= 256 tiles per grouped launch) and signal
+    their parameters.  final=False (called when a block's problems arrive) keeps the tail that does not yet fill a round."""
+    if final:
+        _CB_QUEUED[0] = False
     while _PENDING:
-        batch = _PENDING[:2]
-        del _PENDING[:2]
-        probs = [t for wg, _ in batch for t in wg]
-        # weight AND bias gradients of the (two) blocks in one grouped launch: the bias gradient is dY^T 1 on the fragments the
-        # weight-gradient kernel holds anyway (round 3; the separate column-sum kernels cost 95 launches / 1.1 ms per step)
-        wgrad_grouped([(g, d, x_, b.grad if b is not None else None) for g, d, x_, b in probs])
-        for _, params in batch:
-            _ready(*params)
+        if not final and sum(t for _, t in _PENDING) < _ROUND:      # not enough queued to choose a full round from
+            break
+        pick, rest, s = [], [], 0
+        for it in _PENDING:                          # first fit in arrival order (the order of the launches is free)
+            if len(pick) < _MAXP and (s + it[1] <= _ROUND or not pick):
+                pick.append(it)
+                s += it[1]
+            else:
+                rest.append(it)
+        _PENDING[:] = rest
+        _launch(pick)
 
 
 def reset_pending():
-    """Drop blocks whose backward pass never completed (an exception unwound it): called when the gradients are cleared for a
-    new step, so that a stale block can never be paired with -- and written into the gradients of -- the next step."""
+    """Drop problems whose backward pass never completed (an exception unwound it): called when the gradients are cleared for a
+    new step, so that a stale problem can never be launched into the gradients of the next step."""
     if _PENDING:
         import warnings
-        warnings.warn("divergen_amd: %d Swin block(s) with pending weight gradients dropped (an earlier backward pass did not finish)" % len(_PENDING))
+        warnings.warn("divergen_amd: %d pending weight gradients dropped (an earlier backward pass did not finish)" % len(_PENDING))
         del _PENDING[:]
     _CB_QUEUED[0] = False
 
 
 def _defer_wgrads(wgrads, params):
-    _PENDING.append((wgrads, params))
-    if len(_PENDING) >= _PAIR:
-        flush_wgrads()
-    elif not _CB_QUEUED[0]:
+    blk = sum(_tiles(p[0]) for p in wgrads)
+    M = wgrads[0][1].shape[0]
+    if _PENDING and _PENDING[0][0][1].shape[0] != M:      # a new stage (other token count): its problems do not share launches
+        _flush_all()
+    if _PAIR >= 3 and 2 * blk <= _ROUND:                  # at least two blocks fit a round: pack by problem
+        _PENDING.extend([p, _tiles(p[0])] for p in wgrads)
+        flush_wgrads(final=False)
+    else:                                                 # one launch per block / per pair of blocks
+        _PENDING.extend([p, 0] for p in wgrads)
+        if len(_PENDING) // 4 >= min(_PAIR, 2):
+            _flush_all()
+    if _PENDING and not _CB_QUEUED[0]:
         _CB_QUEUED[0] = True
         torch.autograd.Variable._execution_engine.queue_callback(flush_wgrads)
+
+
+def _flush_all():
+    while _PENDING:
+        items = _PENDING[:_MAXP]
+        del _PENDING[:_MAXP]
+        _launch(items)
 
 
 def _linear_bwd(dy2, x2, weight, bias, wgrads, gelu_of=None):
     """Weight / bias gradient of y = x W^T + b queued for the block's grouped weight-gradient / bias-gradient launches;
     returns dx = dy W (bf16) from the MFMA GEMM on the transposed weight image -- times GELU'(gelu_of) when given (the
     input gradient of fc2 carried through the activation in the GEMM's epilogue)."""
-    wgrads.append((weight.grad.view(weight.shape[0], -1), dy2, x2, bias))
+    wgrads.append((weight.grad.view(weight.shape[0], -1), dy2, x2, bias, weight))
     wt = shadow_t(weight)
     return G.gemm_gelu_grad(dy2, wt, gelu_of) if gelu_of is not None else G.gemm_nt(dy2, wt)
 

@@ -333,7 +333,7 @@ int dgx_residual_bwd(const void* g, const float* scale, void* dy_bf16, int B, in
 /* ---------------------------------------------------------------------------------------------
  * Grouped form of dgx_linear_wgrad: the weight gradients of several Linear layers (the four of a Swin
  * block: qkv/proj/fc1/fc2, swintransformer.py:101-108,36-46) in ONE launch, so that large output tiles
- * fill the GPU with a small M-split.  n <= 9 problems; for each gw (Nn,Kk) = beta*gw + dy^T x  and, when gb != NULL, the
+ * fill the GPU with a small M-split.  n <= 12 problems; for each gw (Nn,Kk) = beta*gw + dy^T x  and, when gb != NULL, the
  * layer's BIAS gradient gb (Nn) = beta*gb + column sums of dy from the same pass (the sum over rows autograd performs for the
  * bias; computed as dy^T 1 on fragments the kernel holds anyway -- ABI version 3 added the field).
  * Nn % 8 == 0, Kk % 8 == 0.  workspace: dgx_wgrad_grouped_workspace_bytes(problems, n) bytes. */

@@ -120,6 +120,34 @@ def window_mhsa_object(objs, swin_cfg, size, batch, nsamp):
             "attribution": "QKV/proj share of the gemm_nt family %.3f and of the wgrad family %.3f, by FLOP" % (share_g, share_w)}
 
 
+def _copy_sources(step):
+    """Development (DGX_BENCH_COPY_SOURCES=1): one bench step under the torch profiler with stacks; device copies / fills grouped by
+    the innermost repo frame (or autograd node) that issued them, to stderr."""
+    import collections
+    from torch.profiler import ProfilerActivity, profile
+    pats = ("copyBuffer", "fillBuffer", "Memcpy", "Memset")
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as pr:
+        step()
+        torch.cuda.synchronize()
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for e in pr.events():
+        ks = [k for k in (e.kernels or []) if any(p in k.name for p in pats)]
+        if not ks:
+            continue
+        where = next((fr for fr in (e.stack or []) if ("divergen_amd" in fr or "bench.py" in fr) and "site-packages" not in fr), None)
+        if where is None:
+            q = e
+            while q is not None and "Backward" not in q.name and "evaluate_function" not in q.name:
+                q = q.cpu_parent
+            where = "[bwd] " + q.name if q is not None else "[?] " + e.name
+        a_ = agg[(where[-70:], e.name, str(e.input_shapes)[:60])]
+        a_[0] += len(ks)
+        a_[1] += sum(k.duration for k in ks)
+    print("device copies / fills in one bench step: %d" % sum(v[0] for v in agg.values()), file=sys.stderr)
+    for k, (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:40]:
+        print("%4d %8.1f us  %-70s %-18s %s" % (n, t, k[0], k[1][:18], k[2]), file=sys.stderr)
+
+
 def _load_json(name):
     try:
         with open(os.path.join(ROOT, "profiles", name)) as f:
@@ -298,8 +326,10 @@ def main():
         n_gt = (12, 10, 14, 12, 8, 16, 11, 13)[j % 8]          # 12 objects per image on average, not the same every step
         bases.append(synthetic_batch(a.batch, a.size, cfg.MODEL.ROI_HEADS.NUM_CLASSES, seed=1234 + rank + 1000 * j, n_gt=n_gt, device=dev))
         ps = [make_pastes(rng, a.size) for _ in range(a.batch)]
-        # pre-stage paste patches as device tensors so the timed region starts with inputs resident in HBM
-        paste_sets.append([[(torch.from_numpy(r).to(dev), x, y, l) for r, x, y, l in p_] for p_ in ps])
+        # pre-stage the paste patches of each image in the form the compositor takes them (one flat device buffer + descriptors,
+        # layers.pack_pastes: what a loader worker hands over after its single host->device copy), so that the timed region starts
+        # with inputs resident in HBM
+        paste_sets.append([la.pack_pastes(p_, dev) for p_ in ps])
     turn = [0]
 
     # The copy-paste compositor is the data-loading side of the step (the reference runs it in loader workers,
@@ -363,6 +393,9 @@ def main():
         for _ in range(a.warmup):
             one_step()
         sync()
+        if os.environ.get("DGX_BENCH_COPY_SOURCES"):      # development: which ops of ONE bench step end in device copies / fills
+            _copy_sources(one_step)
+            sync()
         prof.enable(not a.no_roofline)        # restart the tallies: the timed region only
         prof.pause(True)
         sampled = 0

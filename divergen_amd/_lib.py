@@ -120,6 +120,7 @@ SIGNATURES = {
     "dgx_gemm_bf16_nt": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i64, c_i64, ctypes.POINTER(GemmEpilogue), c_p]),
     "dgx_conv3x3_pad_rows": (c_i64, [c_i, c_i, c_i]),
     "dgx_conv3x3_pad": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
+    "dgx_conv3x3_pad_relu_grad": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     "dgx_conv3x3_gemm": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_i64, c_p]),
     "dgx_conv3x3_wgrad_workspace_bytes": (c_i64, [c_i, c_i, c_i, c_i, c_i]),
     "dgx_conv3x3_wgrad": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_p]),

@@ -147,6 +147,51 @@ __global__ __launch_bounds__(256) void pad_nhwc_kernel(const uint4* __restrict__
     }
 }
 
+// The same copy with ReLU' folded in: element e of the copy = g[e] where the saved activation y[e] (bf16, the convolution's own
+// ReLU-ed output) is positive, else 0 -- the output gradient of a convolution with a fused ReLU, masked on its way into the padded
+// image that its input- and weight-gradient kernels read (round 2: a compare and a multiply launch in front of the copy).
+__global__ __launch_bounds__(256) void pad_nhwc_relu_kernel(const uint4* __restrict__ g, const uint4* __restrict__ y, uint4* __restrict__ out,
+                                                            int N, int H, int W, int vecC, int64_t total_rows) {
+    const int wp = W + 2, hp = H + 2, slack = W + 3;
+    const int64_t total = total_rows * vecC;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int v = (int)(i % vecC);
+        const int64_t row = i / vecC - slack;
+        uint4 val = {0u, 0u, 0u, 0u};
+        if (row >= 0 && row < (int64_t)N * hp * wp) {
+            const int n = (int)(row / (hp * wp)), r = (int)(row - (int64_t)n * hp * wp);
+            const int yp = r / wp, xp = r - yp * wp;
+            if (yp >= 1 && yp <= H && xp >= 1 && xp <= W) {
+                const int64_t src = (((int64_t)n * H + yp - 1) * W + xp - 1) * vecC + v;
+                const uint4 gv = g[src], yv = y[src];
+                const uint32_t gw[4] = {gv.x, gv.y, gv.z, gv.w}, yw[4] = {yv.x, yv.y, yv.z, yv.w};
+                uint32_t o[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {      // bf16 > 0: sign bit clear and not (+)zero
+                    const uint32_t a = yw[k];
+                    const uint32_t lo = ((a & 0x8000u) || !(a & 0x7fffu)) ? 0u : 0xffffu;
+                    const uint32_t hi = ((a & 0x80000000u) || !(a & 0x7fff0000u)) ? 0u : 0xffff0000u;
+                    o[k] = gw[k] & (lo | hi);
+                }
+                val = make_uint4(o[0], o[1], o[2], o[3]);
+            }
+        }
+        out[i] = val;
+    }
+}
+
+extern "C" int dgx_conv3x3_pad_relu_grad(const void* g, const void* y, void* gpad, int N, int H, int W, int C, void* stream) {
+    if (N <= 0 || H <= 0 || W <= 0) return DGX_OK;
+    if (!g || !y || !gpad || C <= 0 || (C & 7)) return DGX_ERR_BAD_ARG;
+    const int64_t rows = (int64_t)N * (H + 2) * (W + 2) + 2 * (int64_t)(W + 3);
+    const int64_t total = rows * (C / 8);
+    const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(pad_nhwc_relu_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint4*)g, (const uint4*)y, (uint4*)gpad, N, H,
+                       W, C / 8, rows);
+    DGX_LAUNCH_CHECK();
+    return DGX_OK;
+}
+
 extern "C" int dgx_conv3x3_pad(const void* x, void* xpad, int N, int H, int W, int C, void* stream) {
     if (N <= 0 || H <= 0 || W <= 0) return DGX_OK;
     if (!x || !xpad || C <= 0 || (C & 7)) return DGX_ERR_BAD_ARG;

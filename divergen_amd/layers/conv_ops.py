@@ -112,6 +112,15 @@ def _pad_image(x_nhwc):
     return xp
 
 
+def _pad_image_relu_grad(g_nhwc, y_nhwc):
+    """Zero-bordered copy of g masked by ReLU'(y) (y = the layer's ReLU-ed output): dgx_conv3x3_pad_relu_grad."""
+    N, H, W, C = g_nhwc.shape
+    rows = int(L.lib().dgx_conv3x3_pad_rows(N, H, W))
+    gp = torch.empty(rows, C, dtype=g_nhwc.dtype, device=g_nhwc.device)
+    L.check(L.lib().dgx_conv3x3_pad_relu_grad(L.ptr(g_nhwc), L.ptr(y_nhwc), L.ptr(gp), N, H, W, C, L.stream()), "dgx_conv3x3_pad_relu_grad")
+    return gp
+
+
 def _flipped_twin(weight, w16):
     """(Cin, 3, 3, Cout) bf16 with [ci][ey][ex][co] = w[co][ci][2-ey][2-ex]: the arena's twin when it has one, else built here."""
     if getattr(weight, "_dgx16t_flipped", False):
@@ -168,10 +177,12 @@ class _Conv3x3Implicit(torch.autograd.Function):
         weight, bias = ctx.weight, ctx.bias
         lib = L.lib()
         g2 = gy.to(torch.bfloat16).contiguous()
-        if relu:
-            g2 = g2 * (yact > 0)
         gx = gw = gb = None
-        gp = _pad_image(g2)
+        masked_in_pad = relu and Co % 64 == 0 and yact.is_contiguous()
+        if relu and not masked_in_pad:
+            g2 = g2 * (yact > 0)
+        # ReLU' rides in the zero-bordered copy (one launch instead of compare + multiply + copy); everything behind reads gp
+        gp = _pad_image_relu_grad(g2, yact) if masked_in_pad else _pad_image(g2)
         if ctx.needs_input_grad[0]:
             wf = _flipped_twin(weight, ctx.w16)                       # (Cin, 9 Cout)
             gsrc = gp
@@ -211,7 +222,7 @@ class _Conv3x3Implicit(torch.autograd.Function):
                     return g.permute(0, 3, 1, 2)
                 gw = accumulate_grad(weight, wgrad)
         if bias is not None and ctx.needs_input_grad[2] and not bias_done:
-            g2f = g2.view(-1, Co)
+            g2f = (g2 * (yact > 0) if masked_in_pad else g2).view(-1, Co)      # (outside the arena: the masked gradient is needed unpadded)
             if bias_arena:
                 from .swin_block import colsum_into
                 colsum_into(bias.grad, g2f)

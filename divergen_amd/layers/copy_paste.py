@@ -7,9 +7,53 @@ from .. import _lib as L
 from ..utils.h2d import upload_i32
 
 
+class PackedPastes:
+    """The K paste patches of one image as the kernel takes them: ONE flat uint8 buffer (each RGBA patch padded to 4 bytes) + the
+    (K, 5) int32 descriptors (byte offset, h, w, x0, y0) + the K labels, all on the device."""
+
+    def __init__(self, flat, desc, labels, K):
+        self.flat, self.desc, self.labels, self.K = flat, desc, labels, K
+
+    def __len__(self):
+        return self.K
+
+
+def pack_pastes(pastes, device):
+    """list of (rgba uint8 (h, w, 4) numpy | tensor, x0, y0, label) -> PackedPastes.  Host arrays (the loader's case: patches come
+    out of the instance pool in host memory) are laid out in one host buffer and go up in ONE copy; patches that already live on
+    the device are gathered with one concatenation.  Round 2 concatenated 2 K device chunks per image inside every step, which
+    torch executes as one hipMemcpyAsync per chunk: 38 blit launches of ~10 us per image (0.8 ms per step on the loader stream)."""
+    K = len(pastes)
+    desc, off = [], 0
+    on_dev = [isinstance(r, torch.Tensor) and r.is_cuda for r, _, _, _ in pastes]
+    sizes = []
+    for rgba, x0, y0, _ in pastes:
+        h, w = int(rgba.shape[0]), int(rgba.shape[1])
+        n = h * w * 4
+        desc.append([off, h, w, int(x0), int(y0)])
+        sizes.append(n)
+        off += n + ((-n) % 4)
+    if K and all(on_dev):
+        chunks = []
+        for (rgba, _, _, _), n in zip(pastes, sizes):
+            chunks.append(rgba.reshape(-1))
+            if (-n) % 4:
+                chunks.append(torch.zeros((-n) % 4, dtype=torch.uint8, device=device))
+        flat = torch.cat(chunks)
+    else:
+        host = np.zeros(max(off, 4), dtype=np.uint8)
+        for (rgba, _, _, _), d, n in zip(pastes, desc, sizes):
+            a = rgba.detach().cpu().numpy() if isinstance(rgba, torch.Tensor) else np.asarray(rgba)
+            host[d[0]:d[0] + n] = np.ascontiguousarray(a, dtype=np.uint8).reshape(-1)
+        flat = torch.from_numpy(host).pin_memory().to(device, non_blocking=True) if torch.device(device).type == "cuda" else torch.from_numpy(host)
+    desc_t = upload_i32(desc, device).view(-1, 5) if K else torch.zeros(0, 5, dtype=torch.int32, device=device)
+    labels = upload_i32([int(np.asarray(p[3]).reshape(-1)[0]) for p in pastes], device).long() if K else torch.zeros(0, dtype=torch.int64, device=device)
+    return PackedPastes(flat, desc_t, labels, K)
+
+
 def copy_paste(image, masks, boxes, labels, pastes):
     """image uint8 (3,H,W), masks uint8 (n,H,W), boxes f32 (n,4), labels i64 (n) -- GPU tensors.
-    pastes: list of (rgba uint8 numpy/tensor (h,w,4), x0, y0, label) applied in order.
+    pastes: list of (rgba uint8 numpy/tensor (h,w,4), x0, y0, label) applied in order, or a PackedPastes (pack_pastes).
     Returns dict(image, masks, boxes, labels, source) exactly like the sequential reference."""
     K = len(pastes)
     dev = image.device
@@ -17,19 +61,8 @@ def copy_paste(image, masks, boxes, labels, pastes):
     if K == 0:
         return dict(image=image, masks=masks, boxes=boxes, labels=labels,
                     source=torch.zeros(n0, dtype=torch.int64, device=dev))
-    desc, chunks, off = [], [], 0
-    for rgba, x0, y0, _ in pastes:
-        a = rgba if isinstance(rgba, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(rgba))
-        h, w = int(a.shape[0]), int(a.shape[1])
-        a = a.to(dev, non_blocking=True).reshape(-1)
-        desc.append([off, h, w, int(x0), int(y0)])
-        chunks.append(a)
-        pad = (-a.numel()) % 4
-        if pad:
-            chunks.append(torch.zeros(pad, dtype=torch.uint8, device=dev))
-        off += a.numel() + pad
-    flat = torch.cat(chunks)
-    desc_t = upload_i32(desc, dev).view(-1, 5)
+    pk = pastes if isinstance(pastes, PackedPastes) else pack_pastes(pastes, dev)
+    flat, desc_t = pk.flat, pk.desc
     image = image.contiguous().clone()
     masks = masks.contiguous()
     boxes0 = boxes.float().contiguous()
@@ -41,8 +74,8 @@ def copy_paste(image, masks, boxes, labels, pastes):
     L.check(L.lib().dgx_copy_paste(L.ptr(image), L.ptr(masks) if n0 else None, L.ptr(boxes0) if n0 else None, n0, H, W,
                                    L.ptr(flat), L.ptr(desc_t), K, L.ptr(out_masks), L.ptr(out_boxes), L.ptr(out_valid),
                                    L.ptr(stats), L.stream()), "dgx_copy_paste")
-    valid = out_valid.bool()
-    all_labels = torch.cat([labels.to(torch.int64), upload_i32([int(np.asarray(p[3]).reshape(-1)[0]) for p in pastes], dev).long()])
+    keep = out_valid.nonzero().squeeze(1)          # ONE compaction (and one device->host count) for the four per-object tensors
+    all_labels = torch.cat([labels.to(torch.int64), pk.labels])
     source = torch.cat([torch.zeros(n0, dtype=torch.int64, device=dev), torch.ones(K, dtype=torch.int64, device=dev)])
-    return dict(image=image, masks=out_masks[valid], boxes=out_boxes[valid], labels=all_labels[valid],
-                source=source[valid])
+    return dict(image=image, masks=out_masks.index_select(0, keep), boxes=out_boxes.index_select(0, keep),
+                labels=all_labels.index_select(0, keep), source=source.index_select(0, keep))

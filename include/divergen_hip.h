@@ -567,6 +567,10 @@ int dgx_transpose_bf16_grouped(const void* src, void* dst, const void* jobs, int
  */
 int64_t dgx_conv3x3_pad_rows(int N, int H, int W);
 int dgx_conv3x3_pad(const void* x, void* xpad, int N, int H, int W, int C, void* stream);
+/* gpad = the zero-bordered copy of the output gradient g (N,H,W,C bf16) masked by ReLU': element kept where the saved activation
+ * y (same shape, bf16: the convolution's ReLU-ed output) is > 0.  Replaces `g * (y > 0)` in front of dgx_conv3x3_pad in the backward
+ * of a convolution with a fused ReLU (D2/layers/wrappers.py Conv2d with activation = relu: mask_head.py:209-284, fpn.py). */
+int dgx_conv3x3_pad_relu_grad(const void* g, const void* y, void* gpad, int N, int H, int W, int C, void* stream);
 int dgx_conv3x3_gemm(const void* xpad, const void* w, const void* bias, void* y, int N, int H, int W, int Cin, int Cout,
                      int relu, void* workspace, int64_t workspace_bytes, void* stream);
 int64_t dgx_conv3x3_wgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout);

@@ -1003,3 +1003,25 @@ def test_roi_label_and_gather_vs_reference_golden(golden, monkeypatch):
     assert not any(bool((bad == row).all(1).any()) for row in b.proposal_boxes.tensor.cpu())
     tr = out.train
     assert tr["counts"] == [64, 64] and tr["prop"].shape == (128, 4) and torch.equal(tr["gt_boxes"][64:].cpu(), tr["prop"][64:].cpu())
+
+
+@pytest.mark.parametrize("N,H,W,C", [(2, 14, 14, 256), (1, 5, 9, 64), (3, 8, 8, 128)])
+def test_conv3x3_pad_relu_grad_bit_exact(N, H, W, C):
+    """dgx_conv3x3_pad_relu_grad (ReLU' folded into the zero-bordered copy of a convolution's output gradient) = dgx_conv3x3_pad of
+    g * (y > 0), bit for bit -- including y = +0 / -0 / negative / NaN-free denormal bf16 activations."""
+    from divergen_amd import _lib as L
+    g = torch.Generator(device=DEV).manual_seed(N * 100 + H)
+    gy = torch.randn(N, H, W, C, device=DEV, generator=g).to(torch.bfloat16)
+    y = torch.relu(torch.randn(N, H, W, C, device=DEV, generator=g)).to(torch.bfloat16)
+    y.view(-1)[::7] = 0.0
+    y.view(-1)[3::11] = -0.0
+    y.view(-1)[5::13] = 1e-40                      # flushes to a bf16 zero / denormal
+    rows = int(L.lib().dgx_conv3x3_pad_rows(N, H, W))
+    ref = torch.empty(rows, C, dtype=torch.bfloat16, device=DEV)
+    masked = (gy * (y > 0)).contiguous()
+    L.check(L.lib().dgx_conv3x3_pad(L.ptr(masked), L.ptr(ref), N, H, W, C, L.stream()), "dgx_conv3x3_pad")
+    got = torch.full((rows, C), float("nan"), dtype=torch.bfloat16, device=DEV)
+    L.check(L.lib().dgx_conv3x3_pad_relu_grad(L.ptr(gy), L.ptr(y), L.ptr(got), N, H, W, C, L.stream()), "dgx_conv3x3_pad_relu_grad")
+    # -0.0 * False = -0.0 in torch (sign kept) but a masked element is +0 in the kernel: compare as numbers and require exact zeros
+    assert torch.equal(got.float(), ref.float())
+    assert not torch.isnan(got.float()).any()

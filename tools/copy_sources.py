@@ -73,4 +73,4 @@ tot_n = sum(a[0] for a in agg.values())
 tot_t = sum(a[1] for a in agg.values())
 print("matching device kernels in one step: %d, %.3f ms" % (tot_n, tot_t / 1e3))
 for key, (n, t, names) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:70]:
-    print("%3d  %7.1f us  %-58s %-22s %s  {%s}" % (n, t, key[0][:58], key[1][:22], key[2], ", ".join("%s x%d" % kv for kv in names.most_common(2))))
+    print("%3d  %7.1f us  %-58s %-22s %s  {%s}" % (n, t, key[0][:58], key[1][:22], key[2], ", ".join("%s x%d" % kv for kv in names.most_common(8 if "Graphed" in key[0] or "Graphed" in key[1] else 2))))

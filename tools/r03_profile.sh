@@ -5,10 +5,13 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r03
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_stats -o p -- python $R/bench.py --steps 8 --warmup 3 --no-roofline --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/stats.err
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_stats -o p -- python $R/bench.py --steps 8 --warmup 4 --no-roofline --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/stats.err
 f=$(find /tmp/p_stats -name "*kernel_stats.csv" | head -1)
-cp $f $O/r03_bench_swinL_1024_kernel_stats.csv
-python $R/tools/prof_summary.py $f 11 > $O/r03_bench_swinL_1024_summary.txt
+cp $f $O/r03_bench_swinL_1024_kernel_stats_all_steps.csv          # rocprofv3's own totals: 12 steps incl. warm-up and graph captures
+# steady-state steps only (cut at the optimizer kernel, first 4 steps dropped): what the family summary and bench.py's cross-check read
+n=$(python $R/tools/trace_stats.py $(find /tmp/p_stats -name "*kernel_trace.csv" | head -1) 4 $O/r03_bench_swinL_1024_kernel_stats.csv)
+echo "{\"kernel_stats_csv\": \"r03_bench_swinL_1024_kernel_stats.csv\", \"steps_in_profile\": $n, \"command\": \"bash tools/r03_profile.sh (rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 8 --warmup 4 --no-cpu-baseline --no-roofline; tools/trace_stats.py keeps the $n steady-state steps behind the 4th optimizer launch; r03_bench_swinL_1024_kernel_stats_all_steps.csv = rocprofv3's own --stats over all 12 steps incl. the hipGraph capture passes)\"}" > $O/r03_profile_meta.json
+python $R/tools/prof_summary.py $O/r03_bench_swinL_1024_kernel_stats.csv $n > $O/r03_bench_swinL_1024_summary.txt
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/p_f -o p -- python $R/bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-roofline > /dev/null 2> $O/pmc_f.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/p_w -o p -- python $R/bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-roofline > /dev/null 2> $O/pmc_w.err
 ff=$(find /tmp/p_f -name "*counter_collection.csv" | head -1)

@@ -33,6 +33,11 @@ class ProfStats(ctypes.Structure):
                 ("captured_launches", c_i64), ("captured_flops", ctypes.c_double), ("captured_bytes", ctypes.c_double)]
 
 
+class GnItem(ctypes.Structure):
+    """struct dgx_gn_item (include/divergen_hip.h)."""
+    _fields_ = [("x", c_p), ("dy", c_p), ("out", c_p), ("mean", c_p), ("rstd", c_p), ("scratch", c_p), ("N", c_i), ("HW", c_i)]
+
+
 class ColsumProblem(ctypes.Structure):
     """struct dgx_colsum_problem (include/divergen_hip.h)."""
     _fields_ = [("dy", c_p), ("out", c_p), ("M", c_i), ("N", c_i)]
@@ -111,6 +116,8 @@ SIGNATURES = {
     "dgx_groupnorm_scratch_floats": (c_i64, [c_i, c_i, c_i]),
     "dgx_groupnorm_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_p]),
     "dgx_groupnorm_bwd": (c_i, [c_p] * 10 + [c_i, c_i, c_i, c_i, c_i, c_p]),
+    "dgx_groupnorm_fwd_multi": (c_i, [c_p, c_i, c_p, c_p, c_i, c_i, c_f, c_i, c_p]),
+    "dgx_groupnorm_bwd_multi": (c_i, [c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
     "dgx_colsum_workspace_bytes": (c_i64, [c_i, c_i]),
     "dgx_colsum_bf16": (c_i, [c_p, c_p, c_i, c_i, c_f, c_p, c_p]),
     "dgx_colsum_grouped_workspace_bytes": (c_i64, [ctypes.POINTER(ColsumProblem), c_i]),

@@ -29,10 +29,10 @@ __device__ __forceinline__ float block_sum(float v, float* red) {   // 256 threa
 
 // grid (N*G, S): slab s of the pixels of one (n, g).  Sums are taken of x - x0 (x0 = the group's first element) so that
 // var = E[d^2] - E[d]^2 does not cancel when the mean is large against the spread.  part[(ng*S + s)*2 + {0,1}].
-__global__ __launch_bounds__(256) void gn_stats_partial_kernel(const uint16_t* __restrict__ x, float* __restrict__ part, int HW, int C,
-                                                               int G, int S) {
+__device__ __forceinline__ void gn_stats_partial_body(const uint16_t* __restrict__ x, float* __restrict__ part, int HW, int C,
+                                                               int G, int S, int bx, int by) {
     __shared__ float red[4];
-    const int n = blockIdx.x / G, g = blockIdx.x % G, s = blockIdx.y;
+    const int n = bx / G, g = bx % G, s = by;
     const uint16_t* base = x + (int64_t)n * HW * C + 8 * g;
     const float x0 = bf2f(base[0]);
     const int per = (HW + S - 1) / S, p0 = s * per, p1 = min(HW, p0 + per);
@@ -45,17 +45,17 @@ __global__ __launch_bounds__(256) void gn_stats_partial_kernel(const uint16_t* _
     }
     a = block_sum(a, red);
     q = block_sum(q, red);
-    if (threadIdx.x == 0) { part[((int64_t)blockIdx.x * S + s) * 2] = a; part[((int64_t)blockIdx.x * S + s) * 2 + 1] = q; }
+    if (threadIdx.x == 0) { part[((int64_t)bx * S + s) * 2] = a; part[((int64_t)bx * S + s) * 2 + 1] = q; }
 }
 
 // grid (blocks per sample, N): every workgroup first folds the slab partials of its sample's G groups into mean / rstd
 // (LDS; workgroup 0 of the sample also stores them for the backward), then normalises its share of the pixels.
-__global__ __launch_bounds__(256) void gn_apply_kernel(const uint16_t* __restrict__ x, const float* __restrict__ part,
+__device__ __forceinline__ void gn_apply_body(const uint16_t* __restrict__ x, const float* __restrict__ part,
                                                        float* __restrict__ mean, float* __restrict__ rstd,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       uint16_t* __restrict__ y, int HW, int C, int G, int S, float eps, int relu) {
+                                                       uint16_t* __restrict__ y, int HW, int C, int G, int S, float eps, int relu, int bx, int by, int gdx) {
     __shared__ float mu_s[256], rs_s[256];
-    const int n = blockIdx.y;
+    const int n = by;
     for (int g = threadIdx.x; g < G; g += 256) {
         const int ng = n * G + g;
         const float x0 = bf2f(x[(int64_t)n * HW * C + 8 * g]);
@@ -67,13 +67,13 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const uint16_t* __restric
         const float mu = x0 + md, rs = rsqrtf(var + eps);
         mu_s[g] = mu;
         rs_s[g] = rs;
-        if (blockIdx.x == 0) { mean[ng] = mu; rstd[ng] = rs; }
+        if (bx == 0) { mean[ng] = mu; rstd[ng] = rs; }
     }
     __syncthreads();
     const int64_t per_n = (int64_t)HW * G;
     const u32x4* xv = reinterpret_cast<const u32x4*>(x) + (int64_t)n * per_n;
     u32x4* yv = reinterpret_cast<u32x4*>(y) + (int64_t)n * per_n;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per_n; i += (int64_t)gridDim.x * 256) {
+    for (int64_t i = (int64_t)bx * 256 + threadIdx.x; i < per_n; i += (int64_t)gdx * 256) {
         const int g = (int)(i % G);
         const float mu = mu_s[g], rs = rs_s[g];
         float v[8], o[8];
@@ -91,19 +91,19 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const uint16_t* __restric
 }
 
 // part2: [N*G][S][18] = s1, s2, dgamma[8], dbeta[8] of slab s (folded by the dx and parameter kernels)
-__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy,
+__device__ __forceinline__ void gn_bwd_reduce_body(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                            float* __restrict__ part2, int HW, int C, int G, int relu, int S) {
+                                                            float* __restrict__ part2, int HW, int C, int G, int relu, int S, int bx, int by) {
     __shared__ float red[4];
-    const int n = blockIdx.x / G, g = blockIdx.x % G;
+    const int n = bx / G, g = bx % G;
     const int64_t off = (int64_t)n * HW * C + 8 * g;
-    const float mu = mean[blockIdx.x], rs = rstd[blockIdx.x];
+    const float mu = mean[bx], rs = rstd[bx];
     float gm[8], bt[8], dg[8], db[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) { gm[k] = gamma[8 * g + k]; bt[k] = beta[8 * g + k]; dg[k] = db[k] = 0.f; }
     float s1 = 0.f, s2 = 0.f;
-    const int per = (HW + S - 1) / S, p0 = blockIdx.y * per, p1 = min(HW, p0 + per);
+    const int per = (HW + S - 1) / S, p0 = by * per, p1 = min(HW, p0 + per);
     for (int p = p0 + threadIdx.x; p < p1; p += 256) {
         float v[8], d[8];
         unpack8(*reinterpret_cast<const u32x4*>(x + off + (int64_t)p * C), v);
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const uint16_t* __re
             s2 += dh * gm[k] * xh;
         }
     }
-    float* out = part2 + ((int64_t)blockIdx.x * S + blockIdx.y) * 18;
+    float* out = part2 + ((int64_t)bx * S + by) * 18;
     float r = block_sum(s1, red);
     if (threadIdx.x == 0) out[0] = r;
     r = block_sum(s2, red);
@@ -133,13 +133,13 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const uint16_t* __re
 }
 
 // grid (blocks per sample, N): s1 / s2 of the sample's groups folded from the slab partials into LDS, then dx
-__global__ __launch_bounds__(256) void gn_bwd_dx_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy,
+__device__ __forceinline__ void gn_bwd_dx_body(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy,
                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         const float* __restrict__ part2, uint16_t* __restrict__ dx, int HW, int C,
-                                                        int G, int S, int relu) {
+                                                        int G, int S, int relu, int bx, int by, int gdx) {
     __shared__ float s1_s[256], s2_s[256];
-    const int n = blockIdx.y;
+    const int n = by;
     for (int g = threadIdx.x; g < G; g += 256) {
         float a = 0.f, b = 0.f;
         for (int s = 0; s < S; ++s) {
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void gn_bwd_dx_kernel(const uint16_t* __restri
     const u32x4* xv = reinterpret_cast<const u32x4*>(x) + (int64_t)n * per_n;
     const u32x4* dv = reinterpret_cast<const u32x4*>(dy) + (int64_t)n * per_n;
     u32x4* ov = reinterpret_cast<u32x4*>(dx) + (int64_t)n * per_n;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per_n; i += (int64_t)gridDim.x * 256) {
+    for (int64_t i = (int64_t)bx * 256 + threadIdx.x; i < per_n; i += (int64_t)gdx * 256) {
         const int g = (int)(i % G);
         const int ng = n * G + g;
         const float mu = mean[ng], rs = rstd[ng], s1 = s1_s[g], s2 = s2_s[g];
@@ -188,6 +188,82 @@ __global__ __launch_bounds__(256) void gn_bwd_param_kernel(const float* __restri
         }
         a += an;
         b += bn;
+    }
+    dgamma[c] += a;
+    dbeta[c] += b;
+}
+
+// ---- launchable forms: one tensor, or up to GN_MAXI tensors (the FPN levels of one tower layer: same weights, same C / G, different
+// N / HW) in ONE launch, blockIdx.z = the tensor -- the small levels' workgroups then run beside the large level's instead of
+// in latency-bound launches of their own
+constexpr int GN_MAXI = 8;
+struct GnItem {
+    const uint16_t* x; const uint16_t* dy; uint16_t* out; float* mean; float* rstd; float* scratch;
+    int N, HW, S, bpn;
+};
+struct GnMulti { GnItem it[GN_MAXI]; int n; };
+
+__global__ __launch_bounds__(256) void gn_stats_partial_kernel(const uint16_t* x, float* part, int HW, int C, int G, int S) {
+    gn_stats_partial_body(x, part, HW, C, G, S, blockIdx.x, blockIdx.y);
+}
+__global__ __launch_bounds__(256) void gn_apply_kernel(const uint16_t* x, const float* part, float* mean, float* rstd, const float* gamma,
+                                                       const float* beta, uint16_t* y, int HW, int C, int G, int S, float eps, int relu) {
+    gn_apply_body(x, part, mean, rstd, gamma, beta, y, HW, C, G, S, eps, relu, blockIdx.x, blockIdx.y, gridDim.x);
+}
+__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const uint16_t* x, const uint16_t* dy, const float* mean, const float* rstd,
+                                                            const float* gamma, const float* beta, float* part2, int HW, int C, int G, int relu,
+                                                            int S) {
+    gn_bwd_reduce_body(x, dy, mean, rstd, gamma, beta, part2, HW, C, G, relu, S, blockIdx.x, blockIdx.y);
+}
+__global__ __launch_bounds__(256) void gn_bwd_dx_kernel(const uint16_t* x, const uint16_t* dy, const float* mean, const float* rstd,
+                                                        const float* gamma, const float* beta, const float* part2, uint16_t* dx, int HW, int C,
+                                                        int G, int S, int relu) {
+    gn_bwd_dx_body(x, dy, mean, rstd, gamma, beta, part2, dx, HW, C, G, S, relu, blockIdx.x, blockIdx.y, gridDim.x);
+}
+
+__global__ __launch_bounds__(256) void gn_stats_partial_multi_kernel(GnMulti M, int C, int G) {
+    const GnItem& t = M.it[blockIdx.z];
+    if ((int)blockIdx.x >= t.N * G || (int)blockIdx.y >= t.S) return;
+    gn_stats_partial_body(t.x, t.scratch, t.HW, C, G, t.S, blockIdx.x, blockIdx.y);
+}
+__global__ __launch_bounds__(256) void gn_apply_multi_kernel(GnMulti M, const float* gamma, const float* beta, int C, int G, float eps,
+                                                             int relu) {
+    const GnItem& t = M.it[blockIdx.z];
+    if ((int)blockIdx.y >= t.N || (int)blockIdx.x >= t.bpn) return;
+    gn_apply_body(t.x, t.scratch, t.mean, t.rstd, gamma, beta, t.out, t.HW, C, G, t.S, eps, relu, blockIdx.x, blockIdx.y, t.bpn);
+}
+__global__ __launch_bounds__(256) void gn_bwd_reduce_multi_kernel(GnMulti M, const float* gamma, const float* beta, int C, int G, int relu) {
+    const GnItem& t = M.it[blockIdx.z];
+    if ((int)blockIdx.x >= t.N * G || (int)blockIdx.y >= t.S) return;
+    gn_bwd_reduce_body(t.x, t.dy, t.mean, t.rstd, gamma, beta, t.scratch + (int64_t)t.N * G * 18, t.HW, C, G, relu, t.S, blockIdx.x, blockIdx.y);
+}
+__global__ __launch_bounds__(256) void gn_bwd_dx_multi_kernel(GnMulti M, const float* gamma, const float* beta, int C, int G, int relu) {
+    const GnItem& t = M.it[blockIdx.z];
+    if ((int)blockIdx.y >= t.N || (int)blockIdx.x >= t.bpn) return;
+    gn_bwd_dx_body(t.x, t.dy, t.mean, t.rstd, gamma, beta, t.scratch + (int64_t)t.N * G * 18, t.out, t.HW, C, G, t.S, relu, blockIdx.x, blockIdx.y,
+                   t.bpn);
+}
+// dgamma[c] += sum over the tensors (in list order), their samples and slabs -- one lane per channel, fixed order
+__global__ __launch_bounds__(256) void gn_bwd_param_multi_kernel(GnMulti M, float* __restrict__ dgamma, float* __restrict__ dbeta, int C, int G) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const int g = c >> 3, k = c & 7;
+    float a = 0.f, b = 0.f;
+    for (int i = 0; i < M.n; ++i) {
+        const GnItem& t = M.it[i];
+        const float* part2 = t.scratch + (int64_t)t.N * G * 18;
+        float ai = 0.f, bi = 0.f;
+        for (int n = 0; n < t.N; ++n) {
+            float an = 0.f, bn = 0.f;
+            for (int s = 0; s < t.S; ++s) {
+                an += part2[(((int64_t)n * G + g) * t.S + s) * 18 + 2 + k];
+                bn += part2[(((int64_t)n * G + g) * t.S + s) * 18 + 10 + k];
+            }
+            ai += an;
+            bi += bn;
+        }
+        a += ai;
+        b += bi;
     }
     dgamma[c] += a;
     dbeta[c] += b;
@@ -240,6 +316,62 @@ extern "C" int dgx_groupnorm_bwd(const void* x, const void* dy, const float* mea
     hipLaunchKernelGGL(gn_bwd_dx_kernel, dim3(bpn, N), dim3(256), 0, st, (const uint16_t*)x, (const uint16_t*)dy, mean, rstd, gamma, beta,
                        part2, (uint16_t*)dx, HW, C, G, S, relu);
     hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((C + 255) / 256), dim3(256), 0, st, part2, dgamma, dbeta, N, C, G, S);
+    DGX_LAUNCH_CHECK();
+    return DGX_OK;
+}
+
+// Several tensors through the same GroupNorm (+ ReLU) in one launch per pass (see GnMulti): items[i] = {x, y, mean, rstd, scratch,
+// N, HW}; scratch as for the single form (dgx_groupnorm_scratch_floats(N, HW, G) floats each).
+static int gn_fill(GnMulti& M, const dgx_gn_item* items, int n, int G, bool bwd, int& maxNG, int& maxS, int& maxN, int& maxbpn) {
+    M.n = n;
+    maxNG = maxS = maxN = maxbpn = 0;
+    for (int i = 0; i < n; ++i) {
+        const dgx_gn_item& a = items[i];
+        if (a.N <= 0 || a.HW <= 0 || !a.x || !a.out || !a.mean || !a.rstd || !a.scratch || (bwd && !a.dy)) return DGX_ERR_BAD_ARG;
+        GnItem& t = M.it[i];
+        t.x = (const uint16_t*)a.x; t.dy = (const uint16_t*)a.dy; t.out = (uint16_t*)a.out;
+        t.mean = a.mean; t.rstd = a.rstd; t.scratch = a.scratch;
+        t.N = a.N; t.HW = a.HW; t.S = gn_slabs(a.N * G, a.HW);
+        const int64_t per_n = (int64_t)a.HW * G;
+        int bpn = (int)((per_n + 255) / 256);
+        const int cap = (4096 + a.N - 1) / a.N;
+        t.bpn = bpn > cap ? cap : bpn;
+        maxNG = a.N * G > maxNG ? a.N * G : maxNG;
+        maxS = t.S > maxS ? t.S : maxS;
+        maxN = a.N > maxN ? a.N : maxN;
+        maxbpn = t.bpn > maxbpn ? t.bpn : maxbpn;
+    }
+    for (int i = n; i < GN_MAXI; ++i) M.it[i] = M.it[0];
+    return DGX_OK;
+}
+
+extern "C" int dgx_groupnorm_fwd_multi(const dgx_gn_item* items, int n, const float* gamma, const float* beta, int C, int G, float eps, int relu,
+                                       void* stream) {
+    if (n <= 0) return DGX_OK;
+    if (!items || n > GN_MAXI || !gamma || !beta || C != 8 * G || G > 256) return n > GN_MAXI ? DGX_ERR_UNSUPPORTED : DGX_ERR_BAD_ARG;
+    GnMulti M;
+    int maxNG, maxS, maxN, maxbpn;
+    const int rc = gn_fill(M, items, n, G, false, maxNG, maxS, maxN, maxbpn);
+    if (rc != DGX_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(gn_stats_partial_multi_kernel, dim3(maxNG, maxS, n), dim3(256), 0, st, M, C, G);
+    hipLaunchKernelGGL(gn_apply_multi_kernel, dim3(maxbpn, maxN, n), dim3(256), 0, st, M, gamma, beta, C, G, eps, relu);
+    DGX_LAUNCH_CHECK();
+    return DGX_OK;
+}
+
+extern "C" int dgx_groupnorm_bwd_multi(const dgx_gn_item* items, int n, const float* gamma, const float* beta, float* dgamma, float* dbeta, int C,
+                                       int G, int relu, void* stream) {
+    if (n <= 0) return DGX_OK;
+    if (!items || n > GN_MAXI || !gamma || !beta || !dgamma || !dbeta || C != 8 * G || G > 256) return n > GN_MAXI ? DGX_ERR_UNSUPPORTED : DGX_ERR_BAD_ARG;
+    GnMulti M;
+    int maxNG, maxS, maxN, maxbpn;
+    const int rc = gn_fill(M, items, n, G, true, maxNG, maxS, maxN, maxbpn);
+    if (rc != DGX_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(gn_bwd_reduce_multi_kernel, dim3(maxNG, maxS, n), dim3(256), 0, st, M, gamma, beta, C, G, relu);
+    hipLaunchKernelGGL(gn_bwd_dx_multi_kernel, dim3(maxbpn, maxN, n), dim3(256), 0, st, M, gamma, beta, C, G, relu);
+    hipLaunchKernelGGL(gn_bwd_param_multi_kernel, dim3((C + 255) / 256), dim3(256), 0, st, M, dgamma, dbeta, C, G);
     DGX_LAUNCH_CHECK();
     return DGX_OK;
 }

@@ -221,6 +221,87 @@ class _GroupNormReLU(torch.autograd.Function):
         return dx, dg.to(weight.dtype), db.to(bias.dtype), None, None, None
 
 
+class _GroupNormReLUMulti(torch.autograd.Function):
+    """The same GroupNorm (+ ReLU) over several channels-last bf16 tensors -- the FPN levels of one CenterNet tower layer, which
+    share its weights -- in ONE launch per pass (dgx_groupnorm_fwd_multi / _bwd_multi; <= 8 tensors).  xs: (N, H, W, C) bf16."""
+
+    @staticmethod
+    def forward(ctx, weight, bias, G, eps, relu, *xs):
+        n = len(xs)
+        C = xs[0].shape[-1]
+        w32, b32 = weight.detach().float().contiguous(), bias.detach().float().contiguous()
+        items = (L.GnItem * n)()
+        ys, saved, keep = [], [], []
+        lib = L.lib()
+        for i, x in enumerate(xs):
+            N, H, W, _ = x.shape
+            y = torch.empty_like(x)
+            mean = torch.empty(N * G, dtype=torch.float32, device=x.device)
+            rstd = torch.empty(N * G, dtype=torch.float32, device=x.device)
+            scratch = torch.empty(int(lib.dgx_groupnorm_scratch_floats(N, H * W, G)), dtype=torch.float32, device=x.device)
+            it = items[i]
+            it.x, it.dy, it.out, it.mean, it.rstd, it.scratch = L.ptr(x), None, L.ptr(y), L.ptr(mean), L.ptr(rstd), L.ptr(scratch)
+            it.N, it.HW = N, H * W
+            ys.append(y)
+            saved += [x, mean, rstd]
+            keep.append(scratch)                       # alive until the launches below are enqueued
+        L.check(lib.dgx_groupnorm_fwd_multi(items, n, L.ptr(w32), L.ptr(b32), C, G, float(eps), int(relu), L.stream()), "dgx_groupnorm_fwd_multi")
+        ctx.save_for_backward(w32, b32, *saved)
+        ctx.weight, ctx.bias, ctx.cfg = weight, bias, (G, relu, n, C)
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        w32, b32 = ctx.saved_tensors[:2]
+        saved = ctx.saved_tensors[2:]
+        weight, bias = ctx.weight, ctx.bias
+        G, relu, n, C = ctx.cfg
+        dev = w32.device
+        in_arena = (weight.is_leaf and bias.is_leaf and weight.grad is not None and bias.grad is not None
+                    and weight.grad.dtype == torch.float32 and getattr(weight, "_dgx16", None) is not None
+                    and getattr(bias, "_dgx16", None) is not None)
+        dg = weight.grad if in_arena else torch.zeros(C, dtype=torch.float32, device=dev)
+        db = bias.grad if in_arena else torch.zeros(C, dtype=torch.float32, device=dev)
+        items = (L.GnItem * n)()
+        dxs, keep = [], []
+        lib = L.lib()
+        for i in range(n):
+            x, mean, rstd = saved[3 * i:3 * i + 3]
+            N, H, W, _ = x.shape
+            dy = dys[i]
+            if dy is None:
+                dy = torch.zeros_like(x)
+            dy = dy.contiguous()
+            if dy.dtype != torch.bfloat16:
+                dy = dy.to(torch.bfloat16)
+            dx = torch.empty_like(x)
+            part = torch.empty(int(lib.dgx_groupnorm_scratch_floats(N, H * W, G)), dtype=torch.float32, device=dev)
+            it = items[i]
+            it.x, it.dy, it.out, it.mean, it.rstd, it.scratch = L.ptr(x), L.ptr(dy), L.ptr(dx), L.ptr(mean), L.ptr(rstd), L.ptr(part)
+            it.N, it.HW = N, H * W
+            dxs.append(dx)
+            keep += [dy, part]
+        L.check(lib.dgx_groupnorm_bwd_multi(items, n, L.ptr(w32), L.ptr(b32), L.ptr(dg), L.ptr(db), C, G, int(relu), L.stream()),
+                "dgx_groupnorm_bwd_multi")
+        if in_arena:
+            notify_ready(weight)
+            notify_ready(bias)
+            return (None, None, None, None, None) + tuple(dxs)
+        return (dg.to(weight.dtype), db.to(bias.dtype), None, None, None) + tuple(dxs)
+
+
+def groupnorm_relu_multi(xs, weight, bias, num_groups, eps=1e-5, relu=True):
+    """list of logical (N, C, H, W) tensors with channels-last storage -> list of the same, bf16: one GroupNorm (+ ReLU) over all
+    of them in one launch per pass (the levels of one tower layer)."""
+    C = xs[0].shape[1]
+    if not (all(x.is_cuda and x.shape[1] == C for x in xs) and C == 8 * num_groups and len(xs) <= 8):
+        raise L.DgxError("groupnorm_relu_multi: <= 8 GPU inputs with the same C = 8 * groups required")
+    xps = [x.permute(0, 2, 3, 1).to(torch.bfloat16).contiguous() for x in xs]
+    with torch.autocast("cuda", enabled=False):
+        ys = _GroupNormReLUMulti.apply(weight, bias, num_groups, eps, relu, *xps)
+    return [y.permute(0, 3, 1, 2) for y in ys]
+
+
 def groupnorm_relu(x, weight, bias, num_groups, eps=1e-5, relu=True):
     """x logical (N, C, H, W) with channels-last storage -> same, bf16 (the only form built: 8 channels per group)."""
     N, C, H, W = x.shape

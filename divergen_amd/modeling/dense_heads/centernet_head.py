@@ -8,7 +8,7 @@ from torch import nn
 from torch.nn import functional as F
 
 from ...config import configurable
-from ...layers.norm_ops import groupnorm_relu
+from ...layers.norm_ops import groupnorm_relu, groupnorm_relu_multi
 from ...layers.conv_ops import Conv2d, conv3x3, conv3x3_group, conv3x3_group_usable
 from ...layers.linear_ops import group_parameters
 
@@ -20,6 +20,9 @@ class Scale(nn.Module):
 
     def forward(self, x):
         return x * self.scale
+
+
+_GN_MULTI = __import__("os").environ.get("DGX_GN_MULTI", "1") == "1"      # A/B switch: GroupNorm of a tower layer over all levels at once
 
 
 class CenterNetHead(nn.Module):
@@ -86,12 +89,36 @@ class CenterNetHead(nn.Module):
                 i += 1
         return x
 
+    @staticmethod
+    def _run_tower_levels(tower, xs):
+        """The tower over ALL levels, layer by layer: the convolutions stay one (implicit-GEMM) call per level, the GroupNorm + ReLU
+        of a layer -- shared weights, one small latency-bound launch per level and pass in the level-by-level order -- runs over
+        the levels together (layers.norm_ops.groupnorm_relu_multi: one launch per pass instead of five)."""
+        mods = list(tower)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, nn.GroupNorm):
+                relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+                xs = groupnorm_relu_multi(xs, m.weight, m.bias, m.num_groups, m.eps, relu=relu)
+                i += 2 if relu else 1
+            else:
+                xs = [m(x) for x in xs]
+                i += 1
+        return xs
+
     def forward(self, x):
         clss, bbox_reg, agn_hms = [], [], []
+        multi = (_GN_MULTI and len(x) > 1 and len(x) <= 8 and all(f.is_cuda for f in x) and len(self.share_tower) == 0 and len(self.cls_tower) == 0
+                 and all(not isinstance(m, nn.GroupNorm) or self.bbox_tower[0].out_channels == 8 * m.num_groups for m in self.bbox_tower))
+        towers = self._run_tower_levels(self.bbox_tower, list(x)) if multi else None
         for l, feature in enumerate(x):
-            feature = self._run_tower(self.share_tower, feature)
-            cls_tower = self._run_tower(self.cls_tower, feature)
-            bbox_tower = self._run_tower(self.bbox_tower, feature)
+            if multi:
+                cls_tower, bbox_tower = feature, towers[l]
+            else:
+                feature = self._run_tower(self.share_tower, feature)
+                cls_tower = self._run_tower(self.cls_tower, feature)
+                bbox_tower = self._run_tower(self.bbox_tower, feature)
             clss.append(None if self.only_proposal else self.cls_logits(cls_tower))
             if self.with_agn_hm and conv3x3_group_usable(bbox_tower, self.agn_hm.weight, self.agn_hm.bias):
                 # agn_hm (1 ch) and bbox_pred (4 ch) read the same tower output and are one arena parameter group (5 rows + zero

@@ -375,6 +375,23 @@ int dgx_groupnorm_fwd(const void* x, const float* gamma, const float* beta, void
 int dgx_groupnorm_bwd(const void* x, const void* dy, const float* mean, const float* rstd, const float* gamma,
                       const float* beta, void* dx, float* dgamma, float* dbeta, float* part, int N, int HW,
                       int C, int G, int relu, void* stream);
+/* The same GroupNorm (+ ReLU) over SEVERAL tensors at once -- the FPN levels of one CenterNet tower layer share its weights
+ * (centernet_head.py:141-162 runs the tower level by level): n <= 8 items, one launch per pass for all of them, the bias / weight
+ * gradients accumulated over the items in list order.  `out` = y (forward) | dx (backward); `dy` unused in the forward;
+ * `scratch` = dgx_groupnorm_scratch_floats(N, HW, G) floats per item, the forward's for the forward, a fresh one for the backward. */
+typedef struct dgx_gn_item {
+    const void* x;      /* (N, HW, C) bf16 */
+    const void* dy;     /* (N, HW, C) bf16, backward only */
+    void* out;          /* (N, HW, C) bf16 */
+    float* mean;        /* (N * G) */
+    float* rstd;        /* (N * G) */
+    float* scratch;
+    int N, HW;
+} dgx_gn_item;
+int dgx_groupnorm_fwd_multi(const dgx_gn_item* items, int n, const float* gamma, const float* beta, int C, int G, float eps, int relu,
+                            void* stream);
+int dgx_groupnorm_bwd_multi(const dgx_gn_item* items, int n, const float* gamma, const float* beta, float* dgamma, float* dbeta, int C,
+                            int G, int relu, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Detic box-head losses of one cascade stage in one pass: sigmoid cross-entropy with per-class weights

@@ -1025,3 +1025,33 @@ def test_conv3x3_pad_relu_grad_bit_exact(N, H, W, C):
     # -0.0 * False = -0.0 in torch (sign kept) but a masked element is +0 in the kernel: compare as numbers and require exact zeros
     assert torch.equal(got.float(), ref.float())
     assert not torch.isnan(got.float()).any()
+
+
+def test_groupnorm_relu_multi_matches_per_tensor():
+    """groupnorm_relu_multi (one launch per pass over the FPN levels of a tower layer) = groupnorm_relu tensor by tensor: outputs and
+    input gradients bit-identical (same per-tensor arithmetic), weight / bias gradients equal up to the order of the fp32 sums."""
+    from divergen_amd.layers.norm_ops import groupnorm_relu, groupnorm_relu_multi
+    g = torch.Generator(device=DEV).manual_seed(5)
+    C, G = 256, 32
+    shapes = [(2, 32, 32), (2, 16, 16), (2, 8, 8), (2, 4, 4), (2, 2, 2)]
+    for relu in (True, False):
+        xs = [torch.randn(n, C, h, w, device=DEV, generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last) for n, h, w in shapes]
+        gos = [torch.randn(n, C, h, w, device=DEV, generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last) for n, h, w in shapes]
+        res = {}
+        for mode in ("single", "multi"):
+            w = (torch.randn(C, device=DEV, generator=torch.Generator(device=DEV).manual_seed(9)) * 0.2 + 1.0).requires_grad_(True)
+            b = (torch.randn(C, device=DEV, generator=torch.Generator(device=DEV).manual_seed(10)) * 0.2).requires_grad_(True)
+            ins = [x.clone().requires_grad_(True) for x in xs]
+            if mode == "single":
+                ys = [groupnorm_relu(x, w, b, G, 1e-5, relu=relu) for x in ins]
+            else:
+                ys = groupnorm_relu_multi(ins, w, b, G, 1e-5, relu=relu)
+            torch.autograd.backward(ys, gos)
+            res[mode] = ([y.detach().float() for y in ys], [x.grad.float() for x in ins], w.grad.clone(), b.grad.clone())
+        for a, c in zip(res["single"][0], res["multi"][0]):
+            assert torch.equal(a, c)
+        for a, c in zip(res["single"][1], res["multi"][1]):
+            assert torch.equal(a, c)
+        for k in (2, 3):
+            a, c = res["single"][k], res["multi"][k]
+            assert float((a - c).abs().max()) <= 1e-4 * float(a.abs().max()) + 1e-6

@@ -33,6 +33,11 @@ class ProfStats(ctypes.Structure):
                 ("captured_launches", c_i64), ("captured_flops", ctypes.c_double), ("captured_bytes", ctypes.c_double)]
 
 
+class PadItem(ctypes.Structure):
+    """struct dgx_pad_item (include/divergen_hip.h)."""
+    _fields_ = [("x", c_p), ("xpad", c_p), ("N", c_i), ("H", c_i), ("W", c_i)]
+
+
 class GnItem(ctypes.Structure):
     """struct dgx_gn_item (include/divergen_hip.h)."""
     _fields_ = [("x", c_p), ("dy", c_p), ("out", c_p), ("mean", c_p), ("rstd", c_p), ("scratch", c_p), ("N", c_i), ("HW", c_i)]
@@ -128,6 +133,7 @@ SIGNATURES = {
     "dgx_conv3x3_pad_rows": (c_i64, [c_i, c_i, c_i]),
     "dgx_conv3x3_pad": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     "dgx_conv3x3_pad_relu_grad": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
+    "dgx_conv3x3_pad_multi": (c_i, [c_p, c_i, c_i, c_p]),
     "dgx_conv3x3_gemm": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_i64, c_p]),
     "dgx_conv3x3_wgrad_workspace_bytes": (c_i64, [c_i, c_i, c_i, c_i, c_i]),
     "dgx_conv3x3_wgrad": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_p]),

@@ -192,6 +192,49 @@ extern "C" int dgx_conv3x3_pad_relu_grad(const void* g, const void* y, void* gpa
     return DGX_OK;
 }
 
+// Several images (the FPN levels of one tower layer) in one launch: blockIdx.y = the image set
+constexpr int PAD_MAXI = 8;
+struct PadMulti { const uint4* x[PAD_MAXI]; uint4* out[PAD_MAXI]; int N[PAD_MAXI], H[PAD_MAXI], W[PAD_MAXI]; int64_t rows[PAD_MAXI]; };
+__global__ __launch_bounds__(256) void pad_nhwc_multi_kernel(PadMulti M, int vecC) {
+    const int k = blockIdx.y;
+    const uint4* __restrict__ x = M.x[k];
+    uint4* __restrict__ out = M.out[k];
+    const int N = M.N[k], H = M.H[k], W = M.W[k];
+    const int wp = W + 2, hp = H + 2, slack = W + 3;
+    const int64_t total = M.rows[k] * vecC;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int v = (int)(i % vecC);
+        const int64_t row = i / vecC - slack;
+        uint4 val = {0u, 0u, 0u, 0u};
+        if (row >= 0 && row < (int64_t)N * hp * wp) {
+            const int n = (int)(row / (hp * wp)), r = (int)(row - (int64_t)n * hp * wp);
+            const int yp = r / wp, xp = r - yp * wp;
+            if (yp >= 1 && yp <= H && xp >= 1 && xp <= W) val = x[(((int64_t)n * H + yp - 1) * W + xp - 1) * vecC + v];
+        }
+        out[i] = val;
+    }
+}
+
+extern "C" int dgx_conv3x3_pad_multi(const dgx_pad_item* items, int n, int C, void* stream) {
+    if (n <= 0) return DGX_OK;
+    if (!items || n > PAD_MAXI || C <= 0 || (C & 7)) return n > PAD_MAXI ? DGX_ERR_UNSUPPORTED : DGX_ERR_BAD_ARG;
+    PadMulti M;
+    int64_t mx = 0;
+    for (int i = 0; i < n; ++i) {
+        const dgx_pad_item& a = items[i];
+        if (!a.x || !a.xpad || a.N <= 0 || a.H <= 0 || a.W <= 0) return DGX_ERR_BAD_ARG;
+        M.x[i] = (const uint4*)a.x; M.out[i] = (uint4*)a.xpad; M.N[i] = a.N; M.H[i] = a.H; M.W[i] = a.W;
+        M.rows[i] = (int64_t)a.N * (a.H + 2) * (a.W + 2) + 2 * (int64_t)(a.W + 3);
+        const int64_t t = M.rows[i] * (C / 8);
+        mx = t > mx ? t : mx;
+    }
+    for (int i = n; i < PAD_MAXI; ++i) { M.x[i] = M.x[0]; M.out[i] = M.out[0]; M.N[i] = M.N[0]; M.H[i] = M.H[0]; M.W[i] = M.W[0]; M.rows[i] = 0; }
+    const int grid = (int)((mx + 255) / 256 < 4096 ? (mx + 255) / 256 : 4096);
+    hipLaunchKernelGGL(pad_nhwc_multi_kernel, dim3(grid, n), dim3(256), 0, (hipStream_t)stream, M, C / 8);
+    DGX_LAUNCH_CHECK();
+    return DGX_OK;
+}
+
 extern "C" int dgx_conv3x3_pad(const void* x, void* xpad, int N, int H, int W, int C, void* stream) {
     if (N <= 0 || H <= 0 || W <= 0) return DGX_OK;
     if (!x || !xpad || C <= 0 || (C & 7)) return DGX_ERR_BAD_ARG;

@@ -297,6 +297,119 @@ def conv3x3_group(x, w_handle, b_handle):
     return y.permute(0, 3, 1, 2)
 
 
+_CONV_MULTI = os.environ.get("DGX_CONV_MULTI", "1") == "1"      # A/B switch: a tower layer's convolution over all levels with shared padded-copy launches
+
+
+def _pad_images(xs):
+    """Zero-bordered copies of several NHWC images with the same channel count in ONE launch (dgx_conv3x3_pad_multi)."""
+    n = len(xs)
+    items = (L.PadItem * n)()
+    outs = []
+    lib = L.lib()
+    for i, x in enumerate(xs):
+        N, H, W, C = x.shape
+        xp = torch.empty(int(lib.dgx_conv3x3_pad_rows(N, H, W)), C, dtype=x.dtype, device=x.device)
+        items[i].x, items[i].xpad, items[i].N, items[i].H, items[i].W = L.ptr(x), L.ptr(xp), N, H, W
+        outs.append(xp)
+    L.check(lib.dgx_conv3x3_pad_multi(items, n, xs[0].shape[-1], L.stream()), "dgx_conv3x3_pad_multi")
+    return outs
+
+
+class _ConvOperands:
+    """The arena views one 3x3 convolution needs in all three passes: wk (Cout, 9 Cin) bf16 in K-order (kh, kw, ci), wf its tap-flipped
+    twin (Cin, 9 Cout), gw the fp32 gradient rows (Cout, 9 Cin), bias / bias gradient, and the parameters to signal."""
+
+    def __init__(self, wk, wf, gw, b16, gb, params):
+        self.wk, self.wf, self.gw, self.b16, self.gb, self.params = wk, wf, gw, b16, gb, params
+
+
+def conv_operands(weight, bias):
+    """_ConvOperands of an arena-resident stride-1 3x3 convolution (a Conv2d weight or the handle of a parameter group), else None."""
+    if getattr(weight, "_dgx16g", None) is not None:          # parameter group (CenterNet predictors)
+        if not conv3x3_group_usable_w(weight, bias):
+            return None
+        return _ConvOperands(weight._dgx16g, weight._dgx16tg, weight._dgxgg, bias._dgx16g, bias._dgxgg,
+                             tuple(weight._dgx_group_members) + tuple(bias._dgx_group_members))
+    if bias is None or not (weight.is_leaf and bias.is_leaf and weight.grad is not None and bias.grad is not None
+                            and getattr(weight, "_dgx16", None) is not None and getattr(bias, "_dgx16", None) is not None
+                            and getattr(weight, "_dgx16t_flipped", False) and weight.grad.dtype == torch.float32
+                            and bias.grad.dtype == torch.float32):
+        return None
+    wk, gw = _ohwi_matrix(shadow(weight)), _ohwi_matrix(weight.grad)
+    if wk is None or gw is None or wk.shape[0] % 64 or weight.shape[1] % 64:
+        return None
+    return _ConvOperands(wk, weight._dgx16t, gw, shadow(bias), bias.grad, (weight, bias))
+
+
+def conv3x3_group_usable_w(w_handle, b_handle):
+    wg, wt, gg = (getattr(w_handle, n, None) for n in ("_dgx16g", "_dgx16tg", "_dgxgg"))
+    bg, bgg = getattr(b_handle, "_dgx16g", None), getattr(b_handle, "_dgxgg", None)
+    return (wg is not None and wt is not None and gg is not None and bg is not None and bgg is not None
+            and getattr(w_handle, "_dgx16tg_flipped", False) and wg.shape[0] % 64 == 0 and gg.dtype == torch.float32)
+
+
+class _Conv3x3Multi(torch.autograd.Function):
+    """One 3x3 / pad 1 / stride 1 convolution (shared weights) over SEVERAL NHWC bf16 images -- a CenterNet tower layer over the FPN
+    levels: the zero-bordered copies of all inputs (forward) / output gradients (backward) are one launch each; the implicit GEMMs
+    and the weight-gradient launches stay per image.  Gradients accumulate in place in the arena (beta = 1), in level order."""
+
+    @staticmethod
+    def forward(ctx, ops, *xs):
+        lib = L.lib()
+        xps = _pad_images(xs)
+        Co = ops.wk.shape[0]
+        ys = []
+        for x, xp in zip(xs, xps):
+            N, H, W, C = x.shape
+            y = torch.empty(N, H, W, Co, dtype=torch.bfloat16, device=x.device)
+            ws = _splitk_workspace(x.device)
+            L.check(lib.dgx_conv3x3_gemm(L.ptr(xp), ops.wk.data_ptr(), ops.b16.data_ptr(), L.ptr(y), N, H, W, C, Co, 0, ws.data_ptr(), ws.numel(),
+                                         L.stream()), "dgx_conv3x3_gemm")
+            ys.append(y)
+        ctx.save_for_backward(*xps)
+        ctx.ops, ctx.shapes = ops, [tuple(x.shape) for x in xs]
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *gys):
+        xps, ops = ctx.saved_tensors, ctx.ops
+        lib = L.lib()
+        Co = ops.wk.shape[0]
+        g2s = []
+        for gy, (N, H, W, C) in zip(gys, ctx.shapes):
+            g2s.append(gy.to(torch.bfloat16).contiguous() if gy is not None else torch.zeros(N, H, W, Co, dtype=torch.bfloat16, device=xps[0].device))
+        gps = _pad_images(g2s)
+        gxs = []
+        for i, (gp, xp, (N, H, W, C)) in enumerate(zip(gps, xps, ctx.shapes)):
+            gx = None
+            if ctx.needs_input_grad[1 + i]:
+                gx = torch.empty(N, H, W, C, dtype=torch.bfloat16, device=gp.device)
+                ws = _splitk_workspace(gp.device)
+                L.check(lib.dgx_conv3x3_gemm(L.ptr(gp), ops.wf.data_ptr(), None, L.ptr(gx), N, H, W, Co, C, 0, ws.data_ptr(), ws.numel(),
+                                             L.stream()), "dgx_conv3x3_gemm")
+            gxs.append(gx)
+            ws = torch.empty(max(int(lib.dgx_conv3x3_wgrad_bias_workspace_bytes(N, H, W, C, Co)), 16), dtype=torch.uint8, device=gp.device)
+            L.check(lib.dgx_conv3x3_wgrad_bias(L.ptr(gp), L.ptr(xp), ops.gw.data_ptr(), ops.gb.data_ptr(), N, H, W, C, Co, 1.0, L.ptr(ws),
+                                               L.stream()), "dgx_conv3x3_wgrad_bias")
+        for q in ops.params:
+            notify_ready(q)
+        return (None,) + tuple(gxs)
+
+
+def conv3x3_multi(xs, weight, bias):
+    """list of logical (N, C, H, W) tensors (channels-last storage) through the SAME stride-1 3x3 convolution -> list of logical
+    (N, Cout, H, W); None when the layer is not arena-resident / the inputs do not qualify (callers then go level by level)."""
+    if not (_IMPLICIT and _CONV_MULTI and torch.is_grad_enabled() and 1 < len(xs) <= 8 and all(x.is_cuda and x.shape[1] % 64 == 0 for x in xs)):
+        return None
+    ops = conv_operands(weight, bias)
+    if ops is None:
+        return None
+    xhs = [_nhwc(x).to(torch.bfloat16) for x in xs]
+    with torch.autocast("cuda", enabled=False):
+        ys = _Conv3x3Multi.apply(ops, *xhs)
+    return [y.permute(0, 3, 1, 2) for y in ys]
+
+
 MIN_COUT = 8  # the MFMA GEMM writes 8-column chunks: 1- and 4-channel predictors run with zero-padded output channels
 
 

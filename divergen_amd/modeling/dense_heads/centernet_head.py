@@ -9,7 +9,7 @@ from torch.nn import functional as F
 
 from ...config import configurable
 from ...layers.norm_ops import groupnorm_relu, groupnorm_relu_multi
-from ...layers.conv_ops import Conv2d, conv3x3, conv3x3_group, conv3x3_group_usable
+from ...layers.conv_ops import Conv2d, conv3x3, conv3x3_group, conv3x3_group_usable, conv3x3_multi
 from ...layers.linear_ops import group_parameters
 
 
@@ -103,7 +103,8 @@ class CenterNetHead(nn.Module):
                 xs = groupnorm_relu_multi(xs, m.weight, m.bias, m.num_groups, m.eps, relu=relu)
                 i += 2 if relu else 1
             else:
-                xs = [m(x) for x in xs]
+                ys = conv3x3_multi(xs, m.weight, m.bias) if isinstance(m, Conv2d) and m.kernel_size == (3, 3) and m.stride == (1, 1) else None
+                xs = ys if ys is not None else [m(x) for x in xs]
                 i += 1
         return xs
 
@@ -112,6 +113,8 @@ class CenterNetHead(nn.Module):
         multi = (_GN_MULTI and len(x) > 1 and len(x) <= 8 and all(f.is_cuda for f in x) and len(self.share_tower) == 0 and len(self.cls_tower) == 0
                  and all(not isinstance(m, nn.GroupNorm) or self.bbox_tower[0].out_channels == 8 * m.num_groups for m in self.bbox_tower))
         towers = self._run_tower_levels(self.bbox_tower, list(x)) if multi else None
+        # the grouped predictor convolution (agn_hm | bbox_pred) over all levels with one padded-copy launch per pass
+        boths = conv3x3_multi(towers, self.agn_hm.weight, self.agn_hm.bias) if multi and self.with_agn_hm else None
         for l, feature in enumerate(x):
             if multi:
                 cls_tower, bbox_tower = feature, towers[l]
@@ -120,7 +123,10 @@ class CenterNetHead(nn.Module):
                 cls_tower = self._run_tower(self.cls_tower, feature)
                 bbox_tower = self._run_tower(self.bbox_tower, feature)
             clss.append(None if self.only_proposal else self.cls_logits(cls_tower))
-            if self.with_agn_hm and conv3x3_group_usable(bbox_tower, self.agn_hm.weight, self.agn_hm.bias):
+            if boths is not None:
+                agn_hms.append(boths[l][:, :1])
+                reg = boths[l][:, 1:5]
+            elif self.with_agn_hm and conv3x3_group_usable(bbox_tower, self.agn_hm.weight, self.agn_hm.bias):
                 # agn_hm (1 ch) and bbox_pred (4 ch) read the same tower output and are one arena parameter group (5 rows + zero
                 # rows up to 64): ONE implicit GEMM each way on the group's views
                 both = conv3x3_group(bbox_tower, self.agn_hm.weight, self.agn_hm.bias)

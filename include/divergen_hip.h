@@ -584,6 +584,9 @@ int dgx_transpose_bf16_grouped(const void* src, void* dst, const void* jobs, int
  */
 int64_t dgx_conv3x3_pad_rows(int N, int H, int W);
 int dgx_conv3x3_pad(const void* x, void* xpad, int N, int H, int W, int C, void* stream);
+/* dgx_conv3x3_pad over n <= 8 images of the same channel count in one launch (the FPN levels a shared tower layer reads). */
+typedef struct dgx_pad_item { const void* x; void* xpad; int N, H, W; } dgx_pad_item;
+int dgx_conv3x3_pad_multi(const dgx_pad_item* items, int n, int C, void* stream);
 /* gpad = the zero-bordered copy of the output gradient g (N,H,W,C bf16) masked by ReLU': element kept where the saved activation
  * y (same shape, bf16: the convolution's ReLU-ed output) is > 0.  Replaces `g * (y > 0)` in front of dgx_conv3x3_pad in the backward
  * of a convolution with a fused ReLU (D2/layers/wrappers.py Conv2d with activation = relu: mask_head.py:209-284, fpn.py). */

@@ -39,7 +39,13 @@ struct GemmP {
     int cmap_n, cmap_h, cmap_w;
     int relu;
     int krot;
+    // grouped implicit convolution (dgx_conv3x3_gemm_multi): ngrp > 0 images that share B / bias / N / K / the epilogue -- the FPN
+    // levels under one tower layer -- in ONE launch: tile L belongs to group g = the last one with tile0 <= L; the kernel patches
+    // A / C / M and the image geometry from the group's record and goes on as for a single image (no split-K in this form)
+    int ngrp;
+    struct Grp { const uint16_t* A; uint16_t* C; int M, cn, ch, cw, wp, tile0; } grp[6];
 };
+constexpr int GEMM_MAXG = 6;
 }  // namespace dgxgemm
 using dgxgemm::GMap;
 using dgxgemm::GemmP;

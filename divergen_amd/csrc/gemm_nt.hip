@@ -47,7 +47,19 @@ __global__ __launch_bounds__(512, MINW) void gemm_nt_kernel(GemmP P) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds_raw[];
     const int L0 = (blockIdx.x & 7) * P.per_xcd + (blockIdx.x >> 3);
     if (L0 >= P.total * P.splits) return;
-    const int L = L0 / P.splits, split = L0 - L * P.splits;   // the splits of a tile are neighbours on one XCD
+    int L = L0 / P.splits;
+    const int split = L0 - L * P.splits;           // the splits of a tile are neighbours on one XCD
+    if (P.ngrp > 0) {                              // grouped convolution: this tile's image (P is this kernel's own copy of the descriptor)
+        L = __builtin_amdgcn_readfirstlane(L);    // (the division above runs on the vector unit: tell the compiler the value is uniform)
+        // constant indices only (a dynamic index into the by-value descriptor would go through private memory and lose uniformity)
+        dgxgemm::GemmP::Grp q = P.grp[0];
+#pragma unroll
+        for (int k = 1; k < dgxgemm::GEMM_MAXG; ++k)
+            if (k < P.ngrp && L >= P.grp[k].tile0) q = P.grp[k];
+        P.A = q.A; P.C = q.C; P.M = q.M;
+        P.cmap_n = q.cn; P.cmap_h = q.ch; P.cmap_w = q.cw; P.conv_wp = q.wp;
+        L -= q.tile0;
+    }
 #define GCLK(i) do { if (P.dbg && threadIdx.x == 0) P.dbg[(size_t)blockIdx.x * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
 #define GCLKR(i) do { if (P.dbg && threadIdx.x == 0) P.dbg[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
     GCLK(0);
@@ -596,6 +608,78 @@ static int dgx_gemm_dispatch(GemmP& P, hipStream_t st) {
     if (tc.bn == 256) return launch_gemm<128, 256, 3>(P, st);
     if (tc.bm == 256) return launch_gemm<256, 128, 3>(P, st);
     return launch_gemm<128, 128, 4>(P, st);
+}
+
+extern "C" int64_t dgx_conv3x3_pad_rows(int N, int H, int W);
+namespace {
+template <int BM, int BN, int NS, int MINW = 2>
+int launch_gemm_grouped(GemmP& P, const int* Ms, int n, hipStream_t st) {
+    using Cfg = GemmCfg<BM, BN, NS>;
+    P.tiles_n = (P.N + BN - 1) / BN;
+    int tot = 0;
+    for (int i = 0; i < n; ++i) {
+        P.grp[i].tile0 = tot;
+        tot += ((Ms[i] + BM - 1) / BM) * P.tiles_n;
+    }
+    P.total = tot;
+    P.splits = 1;
+    P.kt_per_split = (P.K + GBK - 1) / GBK;
+    P.per_xcd = (P.total + 7) / 8;
+    static bool once = false;
+    if (!once) {
+        if (hipFuncSetAttribute((const void*)gemm_nt_kernel<BM, BN, NS, MINW, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS) != hipSuccess)
+            return DGX_ERR_UNSUPPORTED;
+        once = true;
+    }
+    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, NS, MINW, 0>), dim3(8 * P.per_xcd), dim3(512), Cfg::LDS, st, P);
+    DGX_LAUNCH_CHECK();
+    return DGX_OK;
+}
+}  // namespace
+
+// y_i = conv3x3(x_i, w) (+ bias) for n <= 6 zero-bordered images that share the weights, in ONE launch (see GemmP::grp): the levels of
+// a CenterNet tower layer.  Cout <= 256 (one column tile of the instantiations used here).
+extern "C" int dgx_conv3x3_gemm_multi(const dgx_conv_item* items, int n, const void* w, const void* bias, int Cin, int Cout, int relu,
+                                      void* stream) {
+    if (n <= 0) return DGX_OK;
+    if (!items || !w || Cin <= 0 || Cout <= 0 || (Cin & 63) || (Cout & 7)) return DGX_ERR_BAD_ARG;
+    if (n > dgxgemm::GEMM_MAXG || (int64_t)Cout * 9 * Cin * 2 >= (1ll << 31)) return DGX_ERR_UNSUPPORTED;
+    GemmP P;
+    memset((void*)&P, 0, sizeof(P));
+    P.B = (const uint16_t*)w;
+    P.N = Cout; P.K = 9 * Cin; P.lda = Cin; P.ldb = 9 * Cin;
+    P.mode = bias ? DGX_EPI_BIAS : DGX_EPI_NONE;
+    P.ldc = Cout;
+    P.bias = (const uint16_t*)bias;
+    P.conv_kc = Cin / GBK;
+    P.relu = relu;
+    P.ngrp = n;
+    int Ms[dgxgemm::GEMM_MAXG];
+    double fl = 0.0, by = 2.0 * 9.0 * Cin * Cout;
+    for (int i = 0; i < n; ++i) {
+        const dgx_conv_item& a = items[i];
+        if (!a.xpad || !a.y || a.N <= 0 || a.H <= 0 || a.W <= 0) return DGX_ERR_BAD_ARG;
+        if (dgx_conv3x3_pad_rows(a.N, a.H, a.W) * Cin * 2 >= (1ll << 31)) return DGX_ERR_UNSUPPORTED;
+        Ms[i] = a.N * a.H * a.W;
+        P.grp[i].A = (const uint16_t*)a.xpad; P.grp[i].C = (uint16_t*)a.y; P.grp[i].M = Ms[i];
+        P.grp[i].cn = a.N; P.grp[i].ch = a.H; P.grp[i].cw = a.W; P.grp[i].wp = a.W + 2;
+        const double pix = (double)a.N * a.H * a.W;
+        fl += 2.0 * pix * Cout * 9.0 * Cin;
+        by += 2.0 * ((double)a.N * (a.H + 2) * (a.W + 2) * Cin + pix * Cout);
+    }
+    for (int i = n; i < dgxgemm::GEMM_MAXG; ++i) P.grp[i] = P.grp[0];
+    // first group's fields also in the single-image slots (the kernel overwrites them per tile)
+    P.A = P.grp[0].A; P.C = P.grp[0].C; P.M = Ms[0];
+    P.cmap_n = P.grp[0].cn; P.cmap_h = P.grp[0].ch; P.cmap_w = P.grp[0].cw; P.conv_wp = P.grp[0].wp;
+    if (FILE* lf = gemm_log_file()) {
+        for (int i = 0; i < n; ++i) fprintf(lf, "%d %d %d %d %d %d\n", Ms[i], P.N, P.K, 9, 128, Cout > 128 ? 256 : 128);
+        fflush(lf);
+    }
+    DgxProfScope prof(DGX_PROF_GEMM_NT, stream, fl, by);
+    hipStream_t st = (hipStream_t)stream;
+    if (Cout > 256) return DGX_ERR_UNSUPPORTED;
+    if (Cout > 128) return launch_gemm_grouped<128, 256, 3>(P, Ms, n, st);
+    return launch_gemm_grouped<128, 128, 4>(P, Ms, n, st);
 }
 
 extern "C" int64_t dgx_conv3x3_pad_rows(int N, int H, int W) {

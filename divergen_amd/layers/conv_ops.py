@@ -348,6 +348,28 @@ def conv3x3_group_usable_w(w_handle, b_handle):
             and getattr(w_handle, "_dgx16tg_flipped", False) and wg.shape[0] % 64 == 0 and gg.dtype == torch.float32)
 
 
+_CONV_GEMM_MULTI = os.environ.get("DGX_CONV_GEMM_MULTI", "1") == "1"      # A/B switch: one grouped implicit-GEMM launch for the levels
+
+
+def _conv_gemms(xps, ys, nhw, w, b16, Cin, Cout):
+    """y_i = conv3x3(zero-bordered x_i, w) (+ bias) for the images of a tower layer: ONE grouped launch (dgx_conv3x3_gemm_multi: <= 6
+    images, Cout <= 256; the small levels' tiles run beside the large level's instead of in split-K launches of their own), else one
+    implicit GEMM per image."""
+    lib = L.lib()
+    n = len(xps)
+    if _CONV_GEMM_MULTI and 1 < n <= 6 and Cout <= 256:
+        items = (L.ConvItem * n)()
+        for i, (xp, y, (N, H, W)) in enumerate(zip(xps, ys, nhw)):
+            items[i].xpad, items[i].y, items[i].N, items[i].H, items[i].W = L.ptr(xp), L.ptr(y), N, H, W
+        L.check(lib.dgx_conv3x3_gemm_multi(items, n, w.data_ptr(), b16.data_ptr() if b16 is not None else None, Cin, Cout, 0, L.stream()),
+                "dgx_conv3x3_gemm_multi")
+        return
+    for xp, y, (N, H, W) in zip(xps, ys, nhw):
+        ws = _splitk_workspace(xp.device)
+        L.check(lib.dgx_conv3x3_gemm(L.ptr(xp), w.data_ptr(), b16.data_ptr() if b16 is not None else None, L.ptr(y), N, H, W, Cin, Cout, 0,
+                                     ws.data_ptr(), ws.numel(), L.stream()), "dgx_conv3x3_gemm")
+
+
 class _Conv3x3Multi(torch.autograd.Function):
     """One 3x3 / pad 1 / stride 1 convolution (shared weights) over SEVERAL NHWC bf16 images -- a CenterNet tower layer over the FPN
     levels: the zero-bordered copies of all inputs (forward) / output gradients (backward) are one launch each; the implicit GEMMs
@@ -358,14 +380,8 @@ class _Conv3x3Multi(torch.autograd.Function):
         lib = L.lib()
         xps = _pad_images(xs)
         Co = ops.wk.shape[0]
-        ys = []
-        for x, xp in zip(xs, xps):
-            N, H, W, C = x.shape
-            y = torch.empty(N, H, W, Co, dtype=torch.bfloat16, device=x.device)
-            ws = _splitk_workspace(x.device)
-            L.check(lib.dgx_conv3x3_gemm(L.ptr(xp), ops.wk.data_ptr(), ops.b16.data_ptr(), L.ptr(y), N, H, W, C, Co, 0, ws.data_ptr(), ws.numel(),
-                                         L.stream()), "dgx_conv3x3_gemm")
-            ys.append(y)
+        ys = [torch.empty(x.shape[0], x.shape[1], x.shape[2], Co, dtype=torch.bfloat16, device=x.device) for x in xs]
+        _conv_gemms(xps, ys, [tuple(x.shape[:3]) for x in xs], ops.wk, ops.b16, xs[0].shape[3], Co)
         ctx.save_for_backward(*xps)
         ctx.ops, ctx.shapes = ops, [tuple(x.shape) for x in xs]
         return tuple(ys)
@@ -379,15 +395,12 @@ class _Conv3x3Multi(torch.autograd.Function):
         for gy, (N, H, W, C) in zip(gys, ctx.shapes):
             g2s.append(gy.to(torch.bfloat16).contiguous() if gy is not None else torch.zeros(N, H, W, Co, dtype=torch.bfloat16, device=xps[0].device))
         gps = _pad_images(g2s)
-        gxs = []
+        need = [i for i in range(len(gps)) if ctx.needs_input_grad[1 + i]]
+        gxs = [torch.empty(N, H, W, C, dtype=torch.bfloat16, device=gps[0].device) if i in need else None
+               for i, (N, H, W, C) in enumerate(ctx.shapes)]
+        if need:
+            _conv_gemms([gps[i] for i in need], [gxs[i] for i in need], [ctx.shapes[i][:3] for i in need], ops.wf, None, Co, ctx.shapes[0][3])
         for i, (gp, xp, (N, H, W, C)) in enumerate(zip(gps, xps, ctx.shapes)):
-            gx = None
-            if ctx.needs_input_grad[1 + i]:
-                gx = torch.empty(N, H, W, C, dtype=torch.bfloat16, device=gp.device)
-                ws = _splitk_workspace(gp.device)
-                L.check(lib.dgx_conv3x3_gemm(L.ptr(gp), ops.wf.data_ptr(), None, L.ptr(gx), N, H, W, Co, C, 0, ws.data_ptr(), ws.numel(),
-                                             L.stream()), "dgx_conv3x3_gemm")
-            gxs.append(gx)
             ws = torch.empty(max(int(lib.dgx_conv3x3_wgrad_bias_workspace_bytes(N, H, W, C, Co)), 16), dtype=torch.uint8, device=gp.device)
             L.check(lib.dgx_conv3x3_wgrad_bias(L.ptr(gp), L.ptr(xp), ops.gw.data_ptr(), ops.gb.data_ptr(), N, H, W, C, Co, 1.0, L.ptr(ws),
                                                L.stream()), "dgx_conv3x3_wgrad_bias")

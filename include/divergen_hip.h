@@ -587,6 +587,10 @@ int dgx_conv3x3_pad(const void* x, void* xpad, int N, int H, int W, int C, void*
 /* dgx_conv3x3_pad over n <= 8 images of the same channel count in one launch (the FPN levels a shared tower layer reads). */
 typedef struct dgx_pad_item { const void* x; void* xpad; int N, H, W; } dgx_pad_item;
 int dgx_conv3x3_pad_multi(const dgx_pad_item* items, int n, int C, void* stream);
+/* dgx_conv3x3_gemm over n <= 6 zero-bordered images that share the weights (and bias / ReLU) in ONE launch: the FPN levels under a
+ * CenterNet tower layer (centernet_head.py:141-162).  Cout <= 256.  The input gradient is the same call on the tap-flipped twin. */
+typedef struct dgx_conv_item { const void* xpad; void* y; int N, H, W; } dgx_conv_item;
+int dgx_conv3x3_gemm_multi(const dgx_conv_item* items, int n, const void* w, const void* bias, int Cin, int Cout, int relu, void* stream);
 /* gpad = the zero-bordered copy of the output gradient g (N,H,W,C bf16) masked by ReLU': element kept where the saved activation
  * y (same shape, bf16: the convolution's ReLU-ed output) is > 0.  Replaces `g * (y > 0)` in front of dgx_conv3x3_pad in the backward
  * of a convolution with a fused ReLU (D2/layers/wrappers.py Conv2d with activation = relu: mask_head.py:209-284, fpn.py). */

@@ -1055,3 +1055,42 @@ def test_groupnorm_relu_multi_matches_per_tensor():
         for k in (2, 3):
             a, c = res["single"][k], res["multi"][k]
             assert float((a - c).abs().max()) <= 1e-4 * float(a.abs().max()) + 1e-6
+
+
+@pytest.mark.parametrize("Cin,Cout", [(256, 256), (256, 64), (64, 256)])
+def test_conv3x3_gemm_multi_equals_per_image(Cin, Cout):
+    """dgx_conv3x3_gemm_multi (the FPN levels of a tower layer in ONE grouped implicit-GEMM launch) against dgx_conv3x3_gemm image by
+    image WITHOUT split-K (same tiles, same K order): bit-identical outputs, including the levels of 1-2 tiles and ragged M."""
+    import ctypes
+    from divergen_amd import _lib as L
+    lib = L.lib()
+    g = torch.Generator(device=DEV).manual_seed(Cin + Cout)
+    shapes = [(2, 32, 32), (2, 16, 16), (2, 8, 8), (2, 5, 3), (1, 2, 2)]
+    w = (torch.randn(Cout, 9 * Cin, device=DEV, generator=g) * 0.05).to(torch.bfloat16)
+    b = torch.randn(Cout, device=DEV, generator=g).to(torch.bfloat16)
+    xs = [torch.randn(n, h, w_, Cin, device=DEV, generator=g).to(torch.bfloat16) for n, h, w_ in shapes]
+    xps = []
+    for x in xs:
+        n, h, w_, _ = x.shape
+        xp = torch.empty(int(lib.dgx_conv3x3_pad_rows(n, h, w_)), Cin, dtype=torch.bfloat16, device=DEV)
+        L.check(lib.dgx_conv3x3_pad(L.ptr(x), L.ptr(xp), n, h, w_, Cin, L.stream()), "pad")
+        xps.append(xp)
+    ref = []
+    for (n, h, w_), xp in zip(shapes, xps):
+        y = torch.empty(n, h, w_, Cout, dtype=torch.bfloat16, device=DEV)
+        L.check(lib.dgx_conv3x3_gemm(L.ptr(xp), L.ptr(w), L.ptr(b), L.ptr(y), n, h, w_, Cin, Cout, 0, None, 0, L.stream()), "conv")   # no workspace: no split-K
+        ref.append(y)
+    items = (L.ConvItem * len(xs))()
+    got = []
+    for i, ((n, h, w_), xp) in enumerate(zip(shapes, xps)):
+        y = torch.full((n, h, w_, Cout), float("nan"), dtype=torch.bfloat16, device=DEV)
+        items[i].xpad, items[i].y, items[i].N, items[i].H, items[i].W = L.ptr(xp), L.ptr(y), n, h, w_
+        got.append(y)
+    L.check(lib.dgx_conv3x3_gemm_multi(items, len(xs), L.ptr(w), L.ptr(b), Cin, Cout, 0, L.stream()), "conv multi")
+    for a, c in zip(ref, got):
+        assert torch.equal(a.float(), c.float())
+    # and against torch's convolution on the first level (fp32 accumulate both sides, bf16 output)
+    x0 = xs[0].float().permute(0, 3, 1, 2)
+    w4 = w.float().view(Cout, 3, 3, Cin).permute(0, 3, 1, 2)
+    t = torch.nn.functional.conv2d(x0, w4, b.float(), padding=1).permute(0, 2, 3, 1)
+    assert float((got[0].float() - t).abs().max()) <= 2e-2 * float(t.abs().max())

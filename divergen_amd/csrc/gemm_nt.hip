@@ -671,8 +671,10 @@ extern "C" int dgx_conv3x3_gemm_multi(const dgx_conv_item* items, int n, const v
     // first group's fields also in the single-image slots (the kernel overwrites them per tile)
     P.A = P.grp[0].A; P.C = P.grp[0].C; P.M = Ms[0];
     P.cmap_n = P.grp[0].cn; P.cmap_h = P.grp[0].ch; P.cmap_w = P.grp[0].cw; P.conv_wp = P.grp[0].wp;
-    if (FILE* lf = gemm_log_file()) {
-        for (int i = 0; i < n; ++i) fprintf(lf, "%d %d %d %d %d %d\n", Ms[i], P.N, P.K, 9, 128, Cout > 128 ? 256 : 128);
+    if (FILE* lf = gemm_log_file()) {              // one line per LAUNCH (tools/gemm_insitu.py joins lines with dispatches): M = all images' rows
+        int msum = 0;
+        for (int i = 0; i < n; ++i) msum += Ms[i];
+        fprintf(lf, "%d %d %d %d %d %d\n", msum, P.N, P.K, 9, 128, Cout > 128 ? 256 : 128);
         fflush(lf);
     }
     DgxProfScope prof(DGX_PROF_GEMM_NT, stream, fl, by);

@@ -43,6 +43,11 @@ class ConvItem(ctypes.Structure):
     _fields_ = [("xpad", c_p), ("y", c_p), ("N", c_i), ("H", c_i), ("W", c_i)]
 
 
+class ConvWgradItem(ctypes.Structure):
+    """struct dgx_conv_wgrad_item (include/divergen_hip.h)."""
+    _fields_ = [("dypad", c_p), ("xpad", c_p), ("N", c_i), ("H", c_i), ("W", c_i)]
+
+
 class GnItem(ctypes.Structure):
     """struct dgx_gn_item (include/divergen_hip.h)."""
     _fields_ = [("x", c_p), ("dy", c_p), ("out", c_p), ("mean", c_p), ("rstd", c_p), ("scratch", c_p), ("N", c_i), ("HW", c_i)]
@@ -140,6 +145,8 @@ SIGNATURES = {
     "dgx_conv3x3_pad_relu_grad": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     "dgx_conv3x3_pad_multi": (c_i, [c_p, c_i, c_i, c_p]),
     "dgx_conv3x3_gemm_multi": (c_i, [c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_p]),
+    "dgx_conv3x3_wgrad_bias_multi_workspace_bytes": (c_i64, [c_p, c_i, c_i, c_i]),
+    "dgx_conv3x3_wgrad_bias_multi": (c_i, [c_p, c_i, c_p, c_p, c_i, c_i, c_f, c_p, c_p]),
     "dgx_conv3x3_gemm": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_i64, c_p]),
     "dgx_conv3x3_wgrad_workspace_bytes": (c_i64, [c_i, c_i, c_i, c_i, c_i]),
     "dgx_conv3x3_wgrad": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_p]),

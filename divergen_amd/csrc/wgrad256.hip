@@ -36,6 +36,10 @@ struct Params256 {
     int interleave;     // identical problems that share one operand (the 9 taps of a convolution): consecutive workgroups take the
                         // SAME (slab, tile) of consecutive problems, so the shared dY slab is read from HBM once per XCD, not 9 x
     float beta;
+    // multi-image convolution (dgx_conv3x3_wgrad_bias_multi): the M dimension of the nine tap problems runs over nimg zero-bordered
+    // image pairs; slab s belongs to the last image with slab0 <= s and carries ITS pointers and tap shift
+    int nimg;
+    struct Img { const uint16_t* dy; const uint16_t* x; int wp, M, slab0; } img[6];
 };
 
 // 16 bytes per lane from a raw buffer straight into LDS (no staging registers): lane i of the wave lands at
@@ -84,15 +88,27 @@ __global__ __launch_bounds__(256) void wgrad256_partial_kernel(Params256 P) {
         for (int i = 1; i < MAXP256; ++i)
             if (i < P.n && L >= P.p[i].wg0) pi = i;
     }
-    const Prob256 q = P.p[pi];
+    Prob256 q = P.p[pi];
     const int local = P.interleave ? L / P.n : L - q.wg0;
     const int s = local / q.tiles, tile = local - s * q.tiles;
+    int s_in = s;                                  // slab index inside its image
+    if (P.nimg > 0) {                              // multi-image convolution: this slab's image (constant indices: see gemm_nt.hip)
+        const int su = __builtin_amdgcn_readfirstlane(s), tap = __builtin_amdgcn_readfirstlane(pi);
+        Params256::Img im = P.img[0];
+#pragma unroll
+        for (int k = 1; k < 6; ++k)
+            if (k < P.nimg && su >= P.img[k].slab0) im = P.img[k];
+        q.A = im.dy + (int64_t)(im.wp + 1) * q.Nn;                           // grid position 0 (behind the slack)
+        q.B = im.x + (int64_t)((tap / 3) * im.wp + tap % 3) * q.Kk;          // position 0 shifted by tap - (wp + 1)
+        q.M = im.M;
+        s_in = su - im.slab0;
+    }
 #ifdef DIAG_SAMEPANEL   // every workgroup streams the same two panels: isolates the CU-side limit from L2 / fabric
     const int n0 = 0, k0 = 0;
     const int m_begin = 0, m_end = min(q.M, q.slab);
 #else
     const int n0 = (tile / q.tiles_k) * T256, k0 = (tile % q.tiles_k) * T256;
-    const int m_begin = s * q.slab, m_end = min(q.M, m_begin + q.slab);
+    const int m_begin = s_in * q.slab, m_end = min(q.M, m_begin + q.slab);
 #endif
     const int nst = (m_end - m_begin + BM256 - 1) / BM256;
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, g = l >> 4, c16 = l & 15;
@@ -426,6 +442,7 @@ static int wgrad_grouped_impl(const dgx_wgrad_problem* problems, const int* ldc,
     Params256 P;
     P.n = n;
     P.beta = beta;
+    P.nimg = 0;
     int wg = 0;
     int64_t red = 0;
     for (int i = 0; i < n; ++i) {
@@ -483,6 +500,115 @@ static int wgrad_grouped_impl(const dgx_wgrad_problem* problems, const int* ldc,
             const int grid = (int)((red + 255) / 256 < 8192 ? (red + 255) / 256 : 8192);
             hipLaunchKernelGGL(wgrad256_reduce_kernel<1>, dim3(grid + bias_blocks), dim3(256), 0, st, P, red, bias_blocks, bias_cb);
         }
+    }
+    DGX_LAUNCH_CHECK();
+    return DGX_OK;
+}
+
+// dW += sum over SEVERAL zero-bordered image pairs (dypad_i, xpad_i) of the same convolution -- the FPN levels under one CenterNet tower
+// layer, whose weights are shared -- in ONE partial launch + ONE reduce launch: the nine tap problems run over all images' rows, cut
+// into slabs of R rows that never straddle an image (R = the smallest multiple of 32 for which 9 x sum_i ceil(M_i / R) workgroups fit
+// one round of 256).  Round 2 / early round 3: one partial + one reduce launch PER image (the P5 - P7 levels: ~30 us of launches for
+// microseconds of work each).
+static int conv_multi_plan(const dgx_conv_wgrad_item* items, int n, int tiles, int* R_out, int* nsl, int* M) {
+    int maxM = 0;
+    for (int i = 0; i < n; ++i) {
+        M[i] = items[i].N * (items[i].H + 2) * (items[i].W + 2);
+        maxM = M[i] > maxM ? M[i] : maxM;
+    }
+    int R = BM256;
+    for (;; R += BM256) {
+        int64_t wgs = 0;
+        for (int i = 0; i < n; ++i) wgs += (int64_t)9 * tiles * ((M[i] + R - 1) / R);
+        if (wgs <= 256 || R >= maxM) break;
+    }
+    int S = 0;
+    for (int i = 0; i < n; ++i) { nsl[i] = (M[i] + R - 1) / R; S += nsl[i]; }
+    *R_out = R;
+    return S;
+}
+
+extern "C" int64_t dgx_conv3x3_wgrad_bias_multi_workspace_bytes(const dgx_conv_wgrad_item* items, int n, int Cin, int Cout) {
+    if (!items || n <= 0 || n > 6) return 0;
+    if (n == 1) return dgx_conv3x3_wgrad_bias_workspace_bytes(items[0].N, items[0].H, items[0].W, Cin, Cout);
+    int R, nsl[6], M[6];
+    const int tiles = ((Cout + T256 - 1) / T256) * ((Cin + T256 - 1) / T256);
+    const int S = conv_multi_plan(items, n, tiles, &R, nsl, M);
+    return ((int64_t)9 * S * Cout * Cin + ((int64_t)S * Cout + 3) / 4 * 4) * 4;
+}
+
+extern "C" int dgx_conv3x3_wgrad_bias_multi(const dgx_conv_wgrad_item* items, int n, float* gw, float* gb, int Cin, int Cout, float beta,
+                                            void* workspace, void* stream) {
+    if (n <= 0) return DGX_OK;
+    if (!items || !gw || !workspace || (Cin & 7) || (Cout & 7) || Cin <= 0 || Cout <= 0) return DGX_ERR_BAD_ARG;
+    if (n > 6) return DGX_ERR_UNSUPPORTED;
+    if (n == 1)                                    // (a single slab would be finished by the partial kernel itself: the per-image plan)
+        return dgx_conv3x3_wgrad_bias(items[0].dypad, items[0].xpad, gw, gb, items[0].N, items[0].H, items[0].W, Cin, Cout, beta, workspace,
+                                      stream);
+    int R, nsl[6], M[6];
+    const int tiles_k = (Cin + T256 - 1) / T256, tiles = ((Cout + T256 - 1) / T256) * tiles_k;
+    for (int i = 0; i < n; ++i) {
+        if (!items[i].dypad || !items[i].xpad || items[i].N <= 0 || items[i].H <= 0 || items[i].W <= 0) return DGX_ERR_BAD_ARG;
+        const int64_t rows = (int64_t)items[i].N * (items[i].H + 2) * (items[i].W + 2) + 2 * (int64_t)(items[i].W + 3);
+        if (rows * Cout * 2 >= (1ll << 31) || rows * Cin * 2 >= (1ll << 31)) return DGX_ERR_UNSUPPORTED;
+    }
+    const int S = conv_multi_plan(items, n, tiles, &R, nsl, M);
+    Params256 P;
+    P.n = 9;
+    P.beta = beta;
+    P.nimg = n;
+    int s0 = 0;
+    double fl = 0.0, by = 8.0 * 9.0 * Cin * Cout;
+    for (int i = 0; i < n; ++i) {
+        P.img[i].dy = (const uint16_t*)items[i].dypad; P.img[i].x = (const uint16_t*)items[i].xpad;
+        P.img[i].wp = items[i].W + 2; P.img[i].M = M[i]; P.img[i].slab0 = s0;
+        s0 += nsl[i];
+        fl += 2.0 * items[i].N * items[i].H * items[i].W * 9.0 * Cin * Cout;
+        by += 2.0 * M[i] * ((double)Cin + Cout);
+    }
+    for (int i = n; i < 6; ++i) P.img[i] = P.img[0];
+    float* ws = (float*)workspace;
+    const int64_t per = (int64_t)S * Cout * Cin;
+    int wg = 0;
+    int64_t red = 0;
+    for (int t = 0; t < 9; ++t) {
+        Prob256& q = P.p[t];
+        q.A = P.img[0].dy; q.B = P.img[0].x;       // patched per slab in the kernel
+        q.C = gw + (int64_t)t * Cin;
+        q.gb = t == 0 ? gb : nullptr;              // the bias gradient = column sums of dypad (its border rows are zero): once
+        q.wsb = ws + 9 * per;
+        q.ws = ws + (int64_t)t * per;
+        q.M = M[0]; q.Nn = Cout; q.Kk = Cin;
+        q.ldc = 9 * Cin;
+        q.tiles_k = tiles_k;
+        q.S = S;
+        q.slab = R;
+        q.tiles = tiles;
+        q.wg0 = wg;
+        q.red0 = red;
+        wg += tiles * S;
+        red += (int64_t)Cout * Cin / 4;
+    }
+    for (int i = 9; i < MAXP256; ++i) P.p[i] = P.p[0];
+    hipStream_t st = (hipStream_t)stream;
+    const size_t sm = (size_t)NB256 * STB256;
+    static bool once = false;
+    if (!once) {
+        (void)hipFuncSetAttribute((const void*)wgrad256_partial_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+        once = true;
+    }
+    P.total = wg;
+    P.interleave = 1;
+    P.per_xcd = (wg + 7) / 8;
+    DgxProfScope prof(DGX_PROF_WGRAD, stream, fl, by);
+    hipLaunchKernelGGL(wgrad256_partial_kernel, dim3(8 * P.per_xcd), dim3(256), sm, st, P);
+    const int bias_cb = (Cout + 255) / 256, bias_blocks = gb ? bias_cb * 9 : 0;
+    if (red <= 32768 && S >= 16) {
+        hipLaunchKernelGGL(wgrad256_reduce_kernel<16>, dim3((int)((red * 16 + 255) / 256) + bias_blocks), dim3(256), 0, st, P, red, bias_blocks,
+                           bias_cb);
+    } else {
+        const int grid = (int)((red + 255) / 256 < 8192 ? (red + 255) / 256 : 8192);
+        hipLaunchKernelGGL(wgrad256_reduce_kernel<1>, dim3(grid + bias_blocks), dim3(256), 0, st, P, red, bias_blocks, bias_cb);
     }
     DGX_LAUNCH_CHECK();
     return DGX_OK;

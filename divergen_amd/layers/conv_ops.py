@@ -298,6 +298,7 @@ def conv3x3_group(x, w_handle, b_handle):
 
 
 _CONV_MULTI = os.environ.get("DGX_CONV_MULTI", "1") == "1"      # A/B switch: a tower layer's convolution over all levels with shared padded-copy launches
+_WGRAD_MULTI = os.environ.get("DGX_CONV_WGRAD_MULTI", "1") == "1"   # A/B switch: that layer's weight gradient over all levels in one partial + one reduce launch
 
 
 def _pad_images(xs):
@@ -400,10 +401,20 @@ class _Conv3x3Multi(torch.autograd.Function):
                for i, (N, H, W, C) in enumerate(ctx.shapes)]
         if need:
             _conv_gemms([gps[i] for i in need], [gxs[i] for i in need], [ctx.shapes[i][:3] for i in need], ops.wf, None, Co, ctx.shapes[0][3])
-        for i, (gp, xp, (N, H, W, C)) in enumerate(zip(gps, xps, ctx.shapes)):
-            ws = torch.empty(max(int(lib.dgx_conv3x3_wgrad_bias_workspace_bytes(N, H, W, C, Co)), 16), dtype=torch.uint8, device=gp.device)
-            L.check(lib.dgx_conv3x3_wgrad_bias(L.ptr(gp), L.ptr(xp), ops.gw.data_ptr(), ops.gb.data_ptr(), N, H, W, C, Co, 1.0, L.ptr(ws),
-                                               L.stream()), "dgx_conv3x3_wgrad_bias")
+        C = ctx.shapes[0][3]
+        if _WGRAD_MULTI and len(gps) <= 6:
+            items = (L.ConvWgradItem * len(gps))()
+            for i, (gp, xp, (N, H, W, _)) in enumerate(zip(gps, xps, ctx.shapes)):
+                items[i].dypad, items[i].xpad, items[i].N, items[i].H, items[i].W = L.ptr(gp), L.ptr(xp), N, H, W
+            ws = torch.empty(max(int(lib.dgx_conv3x3_wgrad_bias_multi_workspace_bytes(items, len(gps), C, Co)), 16), dtype=torch.uint8,
+                             device=gps[0].device)
+            L.check(lib.dgx_conv3x3_wgrad_bias_multi(items, len(gps), ops.gw.data_ptr(), ops.gb.data_ptr(), C, Co, 1.0, L.ptr(ws), L.stream()),
+                    "dgx_conv3x3_wgrad_bias_multi")
+        else:
+            for i, (gp, xp, (N, H, W, _)) in enumerate(zip(gps, xps, ctx.shapes)):
+                ws = torch.empty(max(int(lib.dgx_conv3x3_wgrad_bias_workspace_bytes(N, H, W, C, Co)), 16), dtype=torch.uint8, device=gp.device)
+                L.check(lib.dgx_conv3x3_wgrad_bias(L.ptr(gp), L.ptr(xp), ops.gw.data_ptr(), ops.gb.data_ptr(), N, H, W, C, Co, 1.0, L.ptr(ws),
+                                                   L.stream()), "dgx_conv3x3_wgrad_bias")
         for q in ops.params:
             notify_ready(q)
         return (None,) + tuple(gxs)

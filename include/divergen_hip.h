@@ -591,6 +591,13 @@ int dgx_conv3x3_pad_multi(const dgx_pad_item* items, int n, int C, void* stream)
  * CenterNet tower layer (centernet_head.py:141-162).  Cout <= 256.  The input gradient is the same call on the tap-flipped twin. */
 typedef struct dgx_conv_item { const void* xpad; void* y; int N, H, W; } dgx_conv_item;
 int dgx_conv3x3_gemm_multi(const dgx_conv_item* items, int n, const void* w, const void* bias, int Cin, int Cout, int relu, void* stream);
+/* The weight (+ bias) gradient of ONE convolution accumulated over n <= 6 zero-bordered image pairs (output gradient, input) -- the FPN
+ * levels under a shared tower layer -- in one partial + one reduce launch: gw (Cout, 3, 3, Cin) f32 = beta*gw + sum_i dW_i, gb likewise.
+ * workspace: dgx_conv3x3_wgrad_bias_multi_workspace_bytes(...) bytes. */
+typedef struct dgx_conv_wgrad_item { const void* dypad; const void* xpad; int N, H, W; } dgx_conv_wgrad_item;
+int64_t dgx_conv3x3_wgrad_bias_multi_workspace_bytes(const dgx_conv_wgrad_item* items, int n, int Cin, int Cout);
+int dgx_conv3x3_wgrad_bias_multi(const dgx_conv_wgrad_item* items, int n, float* gw, float* gb, int Cin, int Cout, float beta,
+                                 void* workspace, void* stream);
 /* gpad = the zero-bordered copy of the output gradient g (N,H,W,C bf16) masked by ReLU': element kept where the saved activation
  * y (same shape, bf16: the convolution's ReLU-ed output) is > 0.  Replaces `g * (y > 0)` in front of dgx_conv3x3_pad in the backward
  * of a convolution with a fused ReLU (D2/layers/wrappers.py Conv2d with activation = relu: mask_head.py:209-284, fpn.py). */

@@ -1094,3 +1094,56 @@ def test_conv3x3_gemm_multi_equals_per_image(Cin, Cout):
     w4 = w.float().view(Cout, 3, 3, Cin).permute(0, 3, 1, 2)
     t = torch.nn.functional.conv2d(x0, w4, b.float(), padding=1).permute(0, 2, 3, 1)
     assert float((got[0].float() - t).abs().max()) <= 2e-2 * float(t.abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Cin,Cout,beta", [(256, 256, 1.0), (256, 8, 0.0), (64, 256, 1.0)])
+def test_conv3x3_wgrad_bias_multi_equals_sum_over_images(Cin, Cout, beta):
+    """dgx_conv3x3_wgrad_bias_multi (the weight + bias gradient of a tower layer over all FPN levels, one partial + one reduce launch)
+    against torch's fp32 convolution weight gradient summed over the images (bf16 operands, fp32 accumulation both sides; the slab
+    partition differs from the per-image launches, so the sums are compared to fp32 reassociation tolerance), and against the
+    per-image entry point dgx_conv3x3_wgrad_bias accumulated with beta = 1."""
+    from divergen_amd import _lib as L
+    lib = L.lib()
+    g = torch.Generator(device=DEV).manual_seed(Cin * 3 + Cout)
+    shapes = [(2, 32, 32), (2, 16, 16), (2, 8, 8), (2, 5, 3), (1, 2, 2)]
+    xs = [torch.randn(n, h, w_, Cin, device=DEV, generator=g).to(torch.bfloat16) for n, h, w_ in shapes]
+    gs = [(torch.randn(n, h, w_, Cout, device=DEV, generator=g) * 0.1).to(torch.bfloat16) for n, h, w_ in shapes]
+
+    def pad(x):
+        n, h, w_, c = x.shape
+        xp = torch.empty(int(lib.dgx_conv3x3_pad_rows(n, h, w_)), c, dtype=torch.bfloat16, device=DEV)
+        L.check(lib.dgx_conv3x3_pad(L.ptr(x), L.ptr(xp), n, h, w_, c, L.stream()), "pad")
+        return xp
+    xps, gps = [pad(x) for x in xs], [pad(x) for x in gs]
+    gw0 = torch.randn(Cout, 3, 3, Cin, device=DEV, generator=g)
+    gb0 = torch.randn(Cout, device=DEV, generator=g)
+    # per-image launches (the path this replaces)
+    gw_a, gb_a = gw0.clone() * beta, gb0.clone() * beta
+    for (n, h, w_), gp, xp in zip(shapes, gps, xps):
+        ws = torch.empty(max(int(lib.dgx_conv3x3_wgrad_bias_workspace_bytes(n, h, w_, Cin, Cout)), 16), dtype=torch.uint8, device=DEV)
+        L.check(lib.dgx_conv3x3_wgrad_bias(L.ptr(gp), L.ptr(xp), gw_a.data_ptr(), gb_a.data_ptr(), n, h, w_, Cin, Cout, 1.0, L.ptr(ws),
+                                           L.stream()), "wgrad")
+    items = (L.ConvWgradItem * len(xs))()
+    for i, ((n, h, w_), gp, xp) in enumerate(zip(shapes, gps, xps)):
+        items[i].dypad, items[i].xpad, items[i].N, items[i].H, items[i].W = L.ptr(gp), L.ptr(xp), n, h, w_
+    ws = torch.empty(max(int(lib.dgx_conv3x3_wgrad_bias_multi_workspace_bytes(items, len(xs), Cin, Cout)), 16), dtype=torch.uint8, device=DEV)
+    gw_b, gb_b = gw0.clone(), gb0.clone()
+    L.check(lib.dgx_conv3x3_wgrad_bias_multi(items, len(xs), gw_b.data_ptr(), gb_b.data_ptr(), Cin, Cout, beta, L.ptr(ws), L.stream()), "multi")
+    # torch fp32 reference
+    ref_w, ref_b = gw0.double() * beta, gb0.double() * beta
+    for x, gy in zip(xs, gs):
+        xi = x.double().permute(0, 3, 1, 2)
+        gi = gy.double().permute(0, 3, 1, 2)
+        dw = torch.nn.grad.conv2d_weight(xi, (Cout, Cin, 3, 3), gi, padding=1)            # (Cout, Cin, 3, 3)
+        ref_w += dw.permute(0, 2, 3, 1)
+        ref_b += gi.sum((0, 2, 3))
+    tol_w = 2e-5 * float(ref_w.abs().max()) + 1e-5
+    assert float((gw_b.double() - ref_w).abs().max()) <= tol_w
+    assert float((gb_b.double() - ref_b).abs().max()) <= 2e-5 * float(ref_b.abs().max()) + 1e-5
+    assert float((gw_b - gw_a).abs().max()) <= tol_w
+    assert float((gb_b - gb_a).abs().max()) <= 2e-5 * float(ref_b.abs().max()) + 1e-5
+    # a second call with the same operands is deterministic (fixed slab order in the reduce)
+    gw_c, gb_c = gw0.clone(), gb0.clone()
+    L.check(lib.dgx_conv3x3_wgrad_bias_multi(items, len(xs), gw_c.data_ptr(), gb_c.data_ptr(), Cin, Cout, beta, L.ptr(ws), L.stream()), "multi")
+    assert torch.equal(gw_b, gw_c) and torch.equal(gb_b, gb_c)

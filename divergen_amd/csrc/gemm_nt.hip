@@ -433,12 +433,16 @@ int choose_splits(int64_t tiles, int K, int64_t M, int64_t N, int64_t ws_bytes) 
 
 // Tile selection: BN from the divisibility of N (every Swin width is a multiple of 192), BM from how well the tile count
 // fills whole rounds of 256 CUs (one workgroup per CU), weighted by the CU-side efficiency of the smaller tiles.
+static bool tile_192x256() {        // DGX_GEMM_192x256=0: A/B switch for the 192 x 256 tile (2 stages) where it saves a round
+    static const int on = getenv("DGX_GEMM_192x256") ? atoi(getenv("DGX_GEMM_192x256")) : 1;
+    return on != 0;
+}
 TileChoice choose_tile(int M, int N) {
     const char* env = getenv("DGX_GEMM_TILE");
     if (env) {
         int bm = 0, bn = 0;
         if (sscanf(env, "%dx%d", &bm, &bn) == 2 && (bm == 256 || bm == 192 || bm == 128) && (bn == 192 || bn == 128 || bn == 256) &&
-            !(bm == 256 && bn == 256) && !(bm == 192 && bn != 192))
+            !(bm == 256 && bn == 256) && !(bm == 192 && bn == 128))
             return {bm, bn};
     }
     int bn;
@@ -452,7 +456,8 @@ TileChoice choose_tile(int M, int N) {
     for (int i = 0; i < 3; ++i) {
         const int b = cand[i];
         if (bn == 256 && b == 256) continue;       // 256x256 does not fit two waves per SIMD (register file)
-        if (bn != 192 && b == 192) continue;       // instantiated for BN = 192 only
+        if (bn == 128 && b == 192) continue;       // 192-row tiles: instantiated for BN = 192 and 256
+        if (bn == 256 && b == 192 && !tile_192x256()) continue;
         const int64_t tiles = (int64_t)((M + b - 1) / b) * ((N + bn - 1) / bn);
         const int64_t rounds = (tiles + 255) / 256;
         const double fill = (double)M * N / ((double)rounds * 256 * b * bn);
@@ -605,6 +610,7 @@ static int dgx_gemm_dispatch(GemmP& P, hipStream_t st) {
         if (tc.bm == 192) return launch_gemm<192, 192, 3>(P, st);
         return launch_gemm<128, 192, 4>(P, st);
     }
+    if (tc.bn == 256 && tc.bm == 192) return launch_gemm<192, 256, 2>(P, st);
     if (tc.bn == 256) return launch_gemm<128, 256, 3>(P, st);
     if (tc.bm == 256) return launch_gemm<256, 128, 3>(P, st);
     return launch_gemm<128, 128, 4>(P, st);
@@ -680,7 +686,14 @@ extern "C" int dgx_conv3x3_gemm_multi(const dgx_conv_item* items, int n, const v
     DgxProfScope prof(DGX_PROF_GEMM_NT, stream, fl, by);
     hipStream_t st = (hipStream_t)stream;
     if (Cout > 256) return DGX_ERR_UNSUPPORTED;
-    if (Cout > 128) return launch_gemm_grouped<128, 256, 3>(P, Ms, n, st);
+    if (Cout > 128) {
+        // 192-row tiles when they save a round of the chip (the five tower levels at 1024^2 x 2 images: 341 tiles of 128 rows =
+        // two rounds, 229 tiles of 192 rows = one)
+        int t128 = 0, t192 = 0;
+        for (int i = 0; i < n; ++i) { t128 += (Ms[i] + 127) / 128; t192 += (Ms[i] + 191) / 192; }
+        if (tile_192x256() && ((t192 + 255) / 256) * 192 < ((t128 + 255) / 256) * 128) return launch_gemm_grouped<192, 256, 2>(P, Ms, n, st);
+        return launch_gemm_grouped<128, 256, 3>(P, Ms, n, st);
+    }
     return launch_gemm_grouped<128, 128, 4>(P, Ms, n, st);
 }
 

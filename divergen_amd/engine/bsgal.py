@@ -200,10 +200,14 @@ class ActiveSelector:
             else:                                              # "only_paste_dynamic_linear_0.3_0.5"
                 self.start_rate, self.end_rate = float(once_mode.split("_")[-2]), float(once_mode.split("_")[-1])
                 self.dynamic_queue = DynamicThreshold(buffer_size=1000, percentile=1 - self.start_rate)
-        if optim_mode != "sgd" or not use_optimizer:
-            raise NotImplementedError("trial update: ACTIVE_OPTIMIZER with ACTIVE_OPTIMIZER_MODE 'sgd' (the default) is built")
-        if compare == "all":
-            raise NotImplementedError("ACTIVE_COMPARE 'all' (train on the pasted AND the original batch, :772-774) is not built")
+        # the trial update (:146-158, :941-971): ACTIVE_OPTIMIZER false = the manual `p -= lr * g`, which is what SGD(lr) does too;
+        # 'adam' = torch.optim.Adam(lr, betas=(0, 0)) -- stateless, p -= lr * g / (|g| + 1e-8); 'adamw' = torch.optim.AdamW(lr) whose
+        # moments persist across trials (the reference never restores them with the weights)
+        self.optim_mode = optim_mode if use_optimizer else "sgd"
+        if self.optim_mode not in ("sgd", "adam", "adamw"):
+            raise NotImplementedError("ACTIVE_OPTIMIZER_MODE '%s' (:150-158 knows 'sgd', 'adam', 'adamw')" % optim_mode)
+        self._m = self._v = None
+        self._trial_steps = 0
         if grad_compare and mode == "paste_or_zero":
             raise NotImplementedError("gradient comparison is defined for 'paste_or_ori' / 'paste_only'")
         self.model, self.arena, self.loss_fn = model, arena, loss_fn
@@ -265,8 +269,24 @@ class ActiveSelector:
             raise NotImplementedError(self.loss_update)
         self.arena.zero_grad()
         total.backward()
-        self.arena.p.add_(self.arena.g, alpha=-self.lr)
-        self.arena.sync_shadow()
+        if self.optim_mode == "sgd":
+            self.arena.p.add_(self.arena.g, alpha=-self.lr)
+            self.arena.sync_shadow()
+            return
+        from ..layers.optim_ops import adamw_ema_step
+        if self._m is None:
+            self._m, self._v = torch.zeros_like(self.arena.p), torch.zeros_like(self.arena.p)
+        p16 = self.arena.p16 if self.arena.p16.is_cuda else None
+        if self.optim_mode == "adam":      # betas (0, 0): exp_avg = g, exp_avg_sq = g^2, both bias corrections 1 at every step
+            adamw_ema_step(self.arena.p, self.arena.g, self._m, self._v, None, 1, self.lr, (0.0, 0.0), 1e-8, 0.0, 0.0, 1.0, 0.0, p_bf16=p16)
+        else:                              # torch.optim.AdamW defaults: betas (0.9, 0.999), eps 1e-8, weight decay 0.01
+            self._trial_steps += 1
+            adamw_ema_step(self.arena.p, self.arena.g, self._m, self._v, None, self._trial_steps, self.lr, (0.9, 0.999), 1e-8, 0.01, 0.0,
+                           1.0, 0.0, p_bf16=p16)
+        if p16 is None:
+            self.arena.sync_shadow()
+        else:
+            self.arena.refresh_transposes()
 
     def _split(self, batched_inputs):
         keep = ("height", "width", "file_name", "image_id")
@@ -289,6 +309,14 @@ class ActiveSelector:
         from ..layers.linear_ops import suspend_ready
         paste_in, ori_in, test_in = self._split(batched_inputs)
         info = {}
+        if self.compare == "all":
+            # :339, :556-557, :772-774 -- no trial passes: the step trains on the pasted batch AND on the original one (whose losses
+            # custom_rcnn.forward adds term by term: `extra_losses`); recorded as "paste"
+            self.count += 1
+            self.paste_count += 1
+            self.last = {"paste": True, "extra": ori_in}
+            self.iter += 1
+            return paste_in, True
         with suspend_ready():
             if self.mode == "paste_only":
                 # forward once (:345-355, :471-541, :592-603): held-out gradient (into the bank), then ONE pass over the pasted
@@ -347,6 +375,12 @@ class ActiveSelector:
         self._log(batched_inputs, paste, info)
         self.iter += 1
         return (paste_in if paste else ori_in), paste
+
+    def extra_losses(self):
+        """ACTIVE_COMPARE 'all': the training losses of the original batch (:556-557 `no_grad_loss(ori..., no_grad=False)`: backbone in
+        eval mode, gradients on), which the caller adds to the pasted batch's losses (:772-774); None otherwise."""
+        extra = self.last.pop("extra", None) if self.compare == "all" else None
+        return None if extra is None else self._trial_losses(extra, False)
 
     def _log(self, batched_inputs, paste, info):
         """The per-iteration record under OUTPUT_DIR/paste_source/rank_R/ (:606-641), one line per pasted file."""

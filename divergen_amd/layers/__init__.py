@@ -8,4 +8,4 @@ from .roi_ops import roi_align, roi_pooler, mask_crop  # noqa
 from .box_ops import nms, batched_nms, iou_match, nms_batched_sorted  # noqa
 from .dense_ops import centernet_targets  # noqa
 from .copy_paste import PackedPastes, copy_paste, pack_pastes  # noqa
-from .optim_ops import adamw_ema_step  # noqa
+from .optim_ops import adamw_ema_step, clip_coef, sgd_ema_step  # noqa

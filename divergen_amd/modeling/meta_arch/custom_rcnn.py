@@ -101,8 +101,11 @@ class CustomRCNN(nn.Module):
         sel = self.__dict__.get("active_selector")
         if sel is not None and len(batched_inputs) and "origin_image" in batched_inputs[0]:
             batched_inputs, paste = sel.select(batched_inputs)
+            extra = sel.extra_losses()                                              # ACTIVE_COMPARE 'all': the original batch as well
             losses = self.training_losses(batched_inputs)
             losses = {k: v for k, v in losses.items() if "paste" not in k}          # :767 pop_loss_paste
+            if extra is not None:                                                   # :772-774
+                losses = {k: v + extra[k] for k, v in losses.items()}
             if sel.mode == "paste_or_zero" and not paste:                           # :769-771: the step trains on nothing
                 losses = {k: v * 0.0 for k, v in losses.items()}
             return losses

@@ -245,12 +245,55 @@ class FusedAdamWEMA:
                 self.arena.view(self.ema, p, o).copy_(sd[key])
 
 
+class FusedSGDEMA(FusedAdamWEMA):
+    """The 'SGD' branch of build_custom_optimizer (custom_solver.py:64-68): torch.optim.SGD(momentum, nesterov, one weight decay for
+    every parameter) + EMA as ONE pass over the arena (csrc/optim.hip: dgx_sgd_ema_step).  clip_norm > 0 = the reference's
+    FullModelGradientClippingOptimizer (:46-60): the whole-arena gradient norm and its clip coefficient stay on the device."""
+
+    def __init__(self, arena, lr, momentum=0.9, nesterov=False, weight_decay=1e-4, clip_value=0.0, clip_norm=0.0, ema_decay=0.0,
+                 lr_multipliers=None):
+        self.arena, self.lr, self.momentum, self.nesterov = arena, lr, momentum, nesterov
+        self.weight_decay, self.clip_value, self.clip_norm, self.ema_decay = weight_decay, clip_value, clip_norm, ema_decay
+        self.buf = torch.zeros_like(arena.p) if momentum != 0 else None
+        self.ema = arena.p.clone() if ema_decay > 0 else None
+        self.step_count = 0
+        self.lr_scale = self.seg_end = None
+        if lr_multipliers is not None and any(abs(x - 1.0) > 0 for x in lr_multipliers):
+            self.lr_scale = torch.tensor(lr_multipliers, dtype=torch.float32, device=arena.p.device)
+            self.seg_end = torch.tensor(arena.segment_ends(), dtype=torch.int64, device=arena.p.device)
+        self.param_groups = [{"lr": lr}]
+        self.last_clip = None                 # device (2,): [coefficient, gradient norm] of the last step with clip_norm
+
+    def step(self, grad_scale=1.0, found_inf=None):
+        from ..layers.optim_ops import clip_coef, sgd_ema_step
+        self.step_count += 1
+        self.last_clip = clip_coef(self.arena.g, self.clip_norm, grad_scale) if self.clip_norm > 0 else None
+        sgd_ema_step(self.arena.p, self.arena.g, self.buf, self.ema, self.step_count, self.param_groups[0]["lr"], self.momentum,
+                     self.nesterov, self.weight_decay, self.clip_value, grad_scale, self.last_clip, self.ema_decay,
+                     p_bf16=self.arena.p16 if self.arena.p16.is_cuda else None, lr_scale=self.lr_scale, seg_end=self.seg_end,
+                     found_inf=found_inf)
+        self.arena.refresh_transposes()
+
+    def state_dict(self):
+        return {"step": self.step_count, "momentum_buffer": self.buf, "lr": self.param_groups[0]["lr"], "names": self.arena.names,
+                "offsets": self.arena.offsets}
+
+    def load_state_dict(self, sd):
+        self.step_count = int(sd["step"])
+        if self.buf is not None and sd.get("momentum_buffer") is not None:
+            self.buf.copy_(sd["momentum_buffer"])
+
+
 def build_optimizer(cfg, model):
-    """build_custom_optimizer (custom_solver.py:19-77) for OPTIMIZER == 'ADAMW' with value clipping."""
+    """build_custom_optimizer (custom_solver.py:19-77): OPTIMIZER 'ADAMW' (the shipped configs; value clipping) or 'SGD'
+    (value clipping or the full-model norm clipping of :46-60)."""
     s = cfg.SOLVER
-    if not (s.USE_CUSTOM_SOLVER and s.OPTIMIZER == "ADAMW"):
-        raise NotImplementedError("only SOLVER.USE_CUSTOM_SOLVER with OPTIMIZER ADAMW (the shipped configs) is built")
-    assert s.CLIP_GRADIENTS.CLIP_TYPE == "value", "shipped configs clip by value"
+    if not (s.USE_CUSTOM_SOLVER and s.OPTIMIZER in ("ADAMW", "SGD")):
+        raise NotImplementedError("no optimizer type %s (custom_solver.py:74-75); SOLVER.USE_CUSTOM_SOLVER is what the shipped configs set"
+                                  % s.OPTIMIZER)
+    ctype = s.CLIP_GRADIENTS.CLIP_TYPE
+    if s.CLIP_GRADIENTS.ENABLED and not (ctype == "value" or (ctype == "full_model" and s.OPTIMIZER == "SGD")):
+        raise NotImplementedError("CLIP_GRADIENTS.CLIP_TYPE '%s' with %s: built are 'value' (both) and 'full_model' (SGD)" % (ctype, s.OPTIMIZER))
     arena = FlatArena(model)
     mult = []
     for name in arena.names:
@@ -261,6 +304,10 @@ def build_optimizer(cfg, model):
             m *= s.CUSTOM_MULTIPLIER
         mult.append(m)
     clip = s.CLIP_GRADIENTS.CLIP_VALUE if s.CLIP_GRADIENTS.ENABLED else 0.0
+    if s.OPTIMIZER == "SGD":
+        return FusedSGDEMA(arena, s.BASE_LR, momentum=s.MOMENTUM, nesterov=s.NESTEROV, weight_decay=s.WEIGHT_DECAY,
+                           clip_value=clip if ctype == "value" else 0.0, clip_norm=clip if ctype == "full_model" else 0.0,
+                           ema_decay=s.MODEL_EMA, lr_multipliers=mult)
     return FusedAdamWEMA(arena, s.BASE_LR, weight_decay=s.WEIGHT_DECAY, clip_value=clip, ema_decay=s.MODEL_EMA,
                          lr_multipliers=mult)
 

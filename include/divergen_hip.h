@@ -257,6 +257,20 @@ int dgx_adamw_ema_step(float* p, const float* g, float* m, float* v, float* ema,
                        const float* lr_scale, const int64_t* seg_end, int n_seg,
                        const int32_t* found_inf, void* stream);
 
+/* The 'SGD' branch of build_custom_optimizer (DG/divergen/custom_solver.py:64-68 = torch.optim.SGD with momentum / nesterov and one
+ * weight decay for every group) over the same arena, with the EMA lerp, bf16 shadow, per-segment lr multipliers and found_inf of
+ * the AdamW step:  d = clip(g * grad_scale [* *grad_scale_dev]) + wd * p;  buf = (step == 1) ? d : momentum * buf + d;
+ * d = nesterov ? d + momentum * buf : buf;  p -= lr * d.   buf f32 (n), may be NULL when momentum == 0. */
+int dgx_sgd_ema_step(float* p, const float* g, float* buf, float* ema, void* p_bf16, int64_t n, float lr, float momentum,
+                     int nesterov, float weight_decay, float clip_value, float grad_scale, const float* grad_scale_dev,
+                     int step, float ema_decay, const float* lr_scale, const int64_t* seg_end, int n_seg,
+                     const int32_t* found_inf, void* stream);
+/* FullModelGradientClippingOptimizer (custom_solver.py:46-60: torch.nn.utils.clip_grad_norm_ over all parameters) without a host
+ * read: out2[0] = min(1, max_norm / (||g * grad_scale||_2 + 1e-6)), out2[1] = the norm; out2 is what dgx_sgd_ema_step takes as
+ * grad_scale_dev.  workspace: dgx_clip_coef_workspace_floats() floats.  Deterministic (fixed partial order, double fold). */
+int64_t dgx_clip_coef_workspace_floats(void);
+int dgx_clip_coef_f32(const float* g, int64_t n, float grad_scale, float max_norm, float* workspace, float* out2, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * 3x3 / pad 1 / stride 1|2 convolution as im2col + library GEMM on channels-last tensors.
  * Replaces the cuDNN (here: MIOpen) calls behind nn.Conv2d at D2/modeling/backbone/fpn.py:126-154,

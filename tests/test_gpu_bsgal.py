@@ -307,3 +307,61 @@ def test_bsgal_r50_forward_once_selection_end_to_end():
         total.backward()
         opt.step()
     assert np.isfinite(float(total.detach())) and not torch.equal(opt.arena.p, w0)
+
+
+@pytest.mark.parametrize("optim_mode,use_optimizer", [("sgd", True), ("adam", True), ("adamw", True), ("sgd", False), ("adam", False)])
+def test_trial_update_matches_the_reference_optimizers(optim_mode, use_optimizer):
+    """update_with_loss (custom_rcnn.py:941-971) for every ACTIVE_OPTIMIZER_MODE the reference constructs (:146-158): SGD(lr),
+    Adam(lr, betas=(0, 0)), AdamW(lr) -- whose moments survive the weight restore between trials -- and the manual
+    `p -= lr * g` of ACTIVE_OPTIMIZER false, against torch.optim on a CPU copy over three consecutive trial updates."""
+    from divergen_amd.solver import FlatArena
+    torch.manual_seed(3)
+    net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Tanh(), torch.nn.Linear(16, 4)).to(DEV)
+    ref = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Tanh(), torch.nn.Linear(16, 4))
+    ref.load_state_dict({k: v.cpu() for k, v in net.state_dict().items()})
+    arena = FlatArena(net)
+    lr = 0.05
+    sel = BG.ActiveSelector(net, arena, None, lr=lr, optim_mode=optim_mode, use_optimizer=use_optimizer, loss_update="all")
+    mode = optim_mode if use_optimizer else "sgd"
+    opt = {"sgd": lambda: torch.optim.SGD(ref.parameters(), lr=lr), "adam": lambda: torch.optim.Adam(ref.parameters(), lr=lr, betas=(0.0, 0.0)),
+           "adamw": lambda: torch.optim.AdamW(ref.parameters(), lr=lr)}[mode]()
+    for it in range(3):
+        x, y = torch.randn(32, 8), torch.randn(32, 4)
+        opt.zero_grad()
+        ((ref(x) - y) ** 2).mean().backward()
+        opt.step()
+        sel._update_with_loss({"loss_a": ((net(x.to(DEV)) - y.to(DEV)) ** 2).mean()})
+        for p, q in zip(net.parameters(), ref.parameters()):
+            torch.testing.assert_close(p.detach().cpu(), q.detach(), atol=2e-6, rtol=2e-5)
+
+
+def test_active_compare_all_trains_on_both_batches():
+    """ACTIVE_COMPARE 'all' (custom_rcnn.py:339, :556-557, :772-774, :1099-1100): no trial passes; the step's losses are the pasted
+    batch's plus the original batch's, term by term; counted as 'paste'."""
+    from divergen_amd.solver import FlatArena
+    from divergen_amd.structures import Instances
+    model = _TinyModel().to(DEV).train()
+    with torch.no_grad():
+        model.backbone.weight.copy_(torch.tensor([[0.5, -1.0, 0.25, 2.0]]))
+    arena = FlatArena(model)
+    sel = BG.ActiveSelector(model, arena, model.training_losses, mode="paste_or_ori", compare="all", loss="cls")
+
+    def sample(vec, y):
+        inst = Instances((1, 1))
+        inst.target = torch.tensor([y], device=DEV)
+        return inst, torch.tensor(vec, device=DEV)
+    pi, px = sample([1.0, 2.0, 0.0, 0.0], 1.0)
+    oi, ox = sample([0.0, 0.0, 3.0, 1.0], -2.0)
+    ti, tx = sample([1.0, 0.0, 0.0, 0.0], 0.0)
+    batch = [{"image": px, "instances": pi, "origin_image": ox, "origin_instances": oi, "test_image": tx, "test_instances": ti}]
+    before = arena.p.clone()
+    chosen, paste = sel.select(batch)
+    assert paste and torch.equal(chosen[0]["image"], px) and torch.equal(arena.p, before)
+    extra = sel.extra_losses()
+    lp = model.training_losses(chosen)
+    total = {k: v + extra[k] for k, v in lp.items()}
+    w = torch.tensor([0.5, -1.0, 0.25, 2.0])
+    want = float((w @ torch.tensor([1.0, 2.0, 0.0, 0.0]) - 1.0) ** 2 + (w @ torch.tensor([0.0, 0.0, 3.0, 1.0]) + 2.0) ** 2)
+    assert abs(float(total["loss_cls_stage0"]) - want) < 1e-5
+    assert sel.extra_losses() is None                       # consumed: one original-batch pass per step
+    assert (sel.paste_count, sel.not_paste_count, sel.iter) == (1, 0, 1)

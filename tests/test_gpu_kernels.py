@@ -436,6 +436,47 @@ def test_adamw_ema_step_vs_oracle():
     torch.testing.assert_close(vd.cpu(), v, atol=1e-7, rtol=1e-5)
 
 
+@pytest.mark.parametrize("momentum,nesterov,clip_norm", [(0.9, False, 0.0), (0.9, True, 0.0), (0.0, False, 0.0), (0.9, False, 2.5)])
+def test_sgd_ema_step_vs_torch_sgd(momentum, nesterov, clip_norm):
+    """dgx_sgd_ema_step / dgx_clip_coef_f32 against what the 'SGD' branch of build_custom_optimizer constructs (custom_solver.py:46-68):
+    torch.optim.SGD on the CPU with two parameter groups of different lr (the backbone multiplier), the same weight decay in both,
+    per-element value clipping (maybe_add_gradient_clipping, CLIP_TYPE 'value') or clip_grad_norm_ over all parameters
+    (FullModelGradientClippingOptimizer), EMA of the pre-step weights (train_net.py:262-284)."""
+    g = torch.Generator().manual_seed(43)
+    n0, n1 = 4 * 300, 4 * 700
+    n = n0 + n1
+    a0, a1 = torch.nn.Parameter(torch.randn(n0, generator=g)), torch.nn.Parameter(torch.randn(n1, generator=g))
+    lr, wd, clip_value = 0.02, 1e-3, (0.0 if clip_norm else 1.0)
+    opt = torch.optim.SGD([{"params": [a0], "lr": lr * 0.1, "weight_decay": wd}, {"params": [a1], "lr": lr, "weight_decay": wd}], lr,
+                          momentum=momentum, nesterov=nesterov)
+    pd = torch.cat([a0.detach(), a1.detach()]).to(DEV)
+    ema, ed = pd.cpu().clone(), pd.clone()
+    buf = torch.zeros(n, device=DEV) if momentum else None
+    lr_scale = torch.tensor([0.1, 1.0], device=DEV)
+    seg_end = torch.tensor([n0, n], dtype=torch.int64, device=DEV)
+    for step in range(1, 6):
+        gr = torch.randn(n, generator=g) * 3
+        ema.mul_(0.999).add_(torch.cat([a0.detach(), a1.detach()]), alpha=1 - 0.999)
+        a0.grad, a1.grad = gr[:n0].clone(), gr[n0:].clone()
+        if clip_norm:
+            total = torch.nn.utils.clip_grad_norm_([a0, a1], clip_norm)
+        else:
+            torch.nn.utils.clip_grad_value_([a0, a1], clip_value)
+        opt.step()
+        gd = gr.to(DEV)
+        coef = la.clip_coef(gd, clip_norm) if clip_norm else None
+        if clip_norm:
+            assert abs(float(coef[1]) - float(total)) <= 1e-5 * float(total)
+            assert abs(float(coef[0]) - min(1.0, clip_norm / (float(total) + 1e-6))) <= 1e-6
+        la.sgd_ema_step(pd, gd, buf, ed, step, lr, momentum, nesterov, wd, clip_value, 1.0, coef, 0.999, lr_scale=lr_scale, seg_end=seg_end)
+    ref = torch.cat([a0.detach(), a1.detach()])
+    torch.testing.assert_close(pd.cpu(), ref, atol=2e-6, rtol=1e-5)
+    torch.testing.assert_close(ed.cpu(), ema, atol=1e-6, rtol=1e-6)
+    if momentum:
+        rb = torch.cat([opt.state[a0]["momentum_buffer"], opt.state[a1]["momentum_buffer"]])
+        torch.testing.assert_close(buf.cpu(), rb, atol=2e-6, rtol=1e-5)
+
+
 # ------------------------------------------------------------------ conv path (im2col + GEMM)
 def _close(got, ref, frac, what=""):
     """|got - ref| <= frac * max|ref|: the tolerance of a bf16-operand / fp32-accumulate kernel against fp32 math on the SAME
@@ -1057,15 +1098,16 @@ def test_groupnorm_relu_multi_matches_per_tensor():
             assert float((a - c).abs().max()) <= 1e-4 * float(a.abs().max()) + 1e-6
 
 
-@pytest.mark.parametrize("Cin,Cout", [(256, 256), (256, 64), (64, 256)])
-def test_conv3x3_gemm_multi_equals_per_image(Cin, Cout):
+@pytest.mark.parametrize("Cin,Cout,top", [(256, 256, 32), (256, 64, 32), (64, 256, 32), (256, 256, 128)])
+def test_conv3x3_gemm_multi_equals_per_image(Cin, Cout, top):
     """dgx_conv3x3_gemm_multi (the FPN levels of a tower layer in ONE grouped implicit-GEMM launch) against dgx_conv3x3_gemm image by
-    image WITHOUT split-K (same tiles, same K order): bit-identical outputs, including the levels of 1-2 tiles and ragged M."""
+    image WITHOUT split-K (same K order per output element): bit-identical outputs, including the levels of 1-2 tiles and ragged M.
+    top = 128: the 1024^2 geometry, where the grouped launch takes 192-row tiles (one round instead of two)."""
     import ctypes
     from divergen_amd import _lib as L
     lib = L.lib()
     g = torch.Generator(device=DEV).manual_seed(Cin + Cout)
-    shapes = [(2, 32, 32), (2, 16, 16), (2, 8, 8), (2, 5, 3), (1, 2, 2)]
+    shapes = [(2, top, top), (2, top // 2, top // 2), (2, top // 4, top // 4), (2, 5, 3), (1, 2, 2)]
     w = (torch.randn(Cout, 9 * Cin, device=DEV, generator=g) * 0.05).to(torch.bfloat16)
     b = torch.randn(Cout, device=DEV, generator=g).to(torch.bfloat16)
     xs = [torch.randn(n, h, w_, Cin, device=DEV, generator=g).to(torch.bfloat16) for n, h, w_ in shapes]

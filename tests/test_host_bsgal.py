@@ -123,9 +123,10 @@ def test_unbuilt_modes_say_so():
     with pytest.raises(NotImplementedError):
         BG.ActiveSelector(model, arena, model.training_losses, mode="paste_only")
     with pytest.raises(NotImplementedError):
-        BG.ActiveSelector(model, arena, model.training_losses, optim_mode="adam")
-    with pytest.raises(NotImplementedError):
-        BG.ActiveSelector(model, arena, model.training_losses, compare="all")
+        BG.ActiveSelector(model, arena, model.training_losses, optim_mode="rmsprop")      # :150-158 knows sgd / adam / adamw
+    assert BG.ActiveSelector(model, arena, model.training_losses, optim_mode="adam").optim_mode == "adam"
+    assert BG.ActiveSelector(model, arena, model.training_losses, optim_mode="adam", use_optimizer=False).optim_mode == "sgd"
+    assert BG.ActiveSelector(model, arena, model.training_losses, compare="all").compare == "all"
 
 
 def test_bsgal_configs_load_and_mapper_adds_the_selection_inputs(tmp_path, monkeypatch):

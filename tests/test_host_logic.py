@@ -383,3 +383,39 @@ def test_bench_launches_its_own_ranks_gloo():
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["ranks_seen_by_collective"] == 2 and line["n_gpus"] == 2 and line["launched_by"] == "torchrun"
+
+
+def test_build_optimizer_branches_follow_build_custom_optimizer():
+    """custom_solver.py:19-77: OPTIMIZER 'ADAMW' | 'SGD' (momentum / nesterov from the config, lr multipliers for backbone and
+    CUSTOM_MULTIPLIER_NAME, one weight decay), CLIP_TYPE 'value' or 'full_model'; anything else raises like :74-75."""
+    import pytest
+    import torch
+    from divergen_amd.config import get_cfg
+    from divergen_amd.solver import FusedAdamWEMA, FusedSGDEMA, build_optimizer
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.backbone = torch.nn.Linear(4, 4)
+            self.head = torch.nn.Linear(4, 2)
+    cfg = get_cfg()
+    cfg.SOLVER.USE_CUSTOM_SOLVER = True
+    cfg.SOLVER.OPTIMIZER = "ADAMW"
+    assert type(build_optimizer(cfg, Net())) is FusedAdamWEMA
+    cfg.SOLVER.OPTIMIZER = "SGD"
+    cfg.SOLVER.MOMENTUM, cfg.SOLVER.NESTEROV, cfg.SOLVER.BACKBONE_MULTIPLIER = 0.8, True, 0.1
+    cfg.SOLVER.CLIP_GRADIENTS.ENABLED, cfg.SOLVER.CLIP_GRADIENTS.CLIP_TYPE, cfg.SOLVER.CLIP_GRADIENTS.CLIP_VALUE = True, "full_model", 0.5
+    opt = build_optimizer(cfg, Net())
+    assert type(opt) is FusedSGDEMA and (opt.momentum, opt.nesterov, opt.clip_norm, opt.clip_value) == (0.8, True, 0.5, 0.0)
+    assert opt.buf is not None and opt.buf.shape == opt.arena.p.shape
+    by_name = dict(zip(opt.arena.names, opt.lr_scale.tolist()))
+    assert by_name["backbone.weight"] == pytest.approx(0.1) and by_name["head.weight"] == 1.0
+    cfg.SOLVER.CLIP_GRADIENTS.CLIP_TYPE = "value"
+    opt = build_optimizer(cfg, Net())
+    assert (opt.clip_norm, opt.clip_value) == (0.0, 0.5)
+    cfg.SOLVER.CLIP_GRADIENTS.CLIP_TYPE = "norm"
+    with pytest.raises(NotImplementedError):
+        build_optimizer(cfg, Net())
+    cfg.SOLVER.CLIP_GRADIENTS.CLIP_TYPE, cfg.SOLVER.OPTIMIZER = "value", "LAMB"
+    with pytest.raises(NotImplementedError):
+        build_optimizer(cfg, Net())

@@ -48,6 +48,11 @@ class ConvWgradItem(ctypes.Structure):
     _fields_ = [("dypad", c_p), ("xpad", c_p), ("N", c_i), ("H", c_i), ("W", c_i)]
 
 
+class HeadLevel(ctypes.Structure):
+    """struct dgx_head_level (include/divergen_hip.h)."""
+    _fields_ = [("x", c_p), ("dx", c_p), ("scale", c_p), ("rows", c_i)]
+
+
 class GnItem(ctypes.Structure):
     """struct dgx_gn_item (include/divergen_hip.h)."""
     _fields_ = [("x", c_p), ("dy", c_p), ("out", c_p), ("mean", c_p), ("rstd", c_p), ("scratch", c_p), ("N", c_i), ("HW", c_i)]
@@ -91,6 +96,9 @@ SIGNATURES = {
     "dgx_centernet_targets": (c_i, [c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_f, c_f, c_p, c_p, c_p]),
     "dgx_centernet_scores": (c_i, [c_p, c_i, c_i, c_p, c_p, c_i, c_i, c_f, c_p, c_p, c_i, c_p]),
     "dgx_centernet_decode": (c_i, [c_p, c_i, c_i, c_p, c_p, c_i, c_i, c_p, c_i, c_p, c_f, c_p, c_p, c_p, c_i, c_p]),
+    "dgx_centernet_head_outputs": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p]),
+    "dgx_centernet_head_outputs_bwd_workspace_floats": (c_i64, [c_p, c_i, c_i]),
+    "dgx_centernet_head_outputs_bwd": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
     "dgx_centernet_finalize": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p]),
     "dgx_roi_label": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_i, c_f, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
     "dgx_roi_gather": (c_i, [c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f] + [c_p] * 10 + [c_p]),

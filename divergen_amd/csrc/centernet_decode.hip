@@ -144,3 +144,130 @@ extern "C" int dgx_centernet_finalize(const float* sorted_boxes, const float* so
     DGX_LAUNCH_CHECK();
     return DGX_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// dgx_centernet_head_outputs / _bwd: the tail of CenterNetHead.forward + the flattening of CenterNet.forward
+// (CN/modeling/dense_heads/centernet_head.py:113-131 `agn_hm`, `F.relu(self.scales[l](bbox_pred(...)))`; centernet.py:179-235
+// `_flatten_outputs`) over ALL levels in one launch each way.  Input per level: the grouped predictor output, channels-last
+// (rows, C) bf16 with the heat-map logit in channel 0 and the four regression channels behind it; outputs: the loss operands
+// reg (M, 4) f32 = relu(float(x[1..4]) * scale_l) and hm (M,) f32 = float(x[0]), levels stacked.  Backward: dx rows (all C channels:
+// the unused ones zero) bf16 = [g_hm, g_reg * (reg > 0) * scale_l, 0...] and d scale_l = sum g_reg * (reg > 0) * float(x) -- block
+// partials in a fixed order, folded by a second launch (bit-reproducible).  The composed form is ~60 tiny launches per step
+// inside the tower graph (per-level slices, scale, ReLU, permuting views, concatenations, casts and their backward).
+namespace {
+constexpr int HO_MAXL = 8;
+struct HoLevels {
+    const uint16_t* x[HO_MAXL];
+    uint16_t* dx[HO_MAXL];
+    const float* scale[HO_MAXL];
+    int rows[HO_MAXL], off[HO_MAXL + 1];
+    int L, C;
+};
+}  // namespace
+
+__global__ __launch_bounds__(256) void cn_head_outputs_kernel(HoLevels P, float* __restrict__ reg, float* __restrict__ hm) {
+    const int l = blockIdx.y;
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= P.rows[l]) return;
+    const u32x4 v = *reinterpret_cast<const u32x4*>(P.x[l] + (int64_t)r * P.C);          // channels 0 .. 7 of the row
+    const float s = P.scale[l][0];
+    const float c0 = __uint_as_float(v[0] << 16), c1 = __uint_as_float(v[0] & 0xffff0000u), c2 = __uint_as_float(v[1] << 16),
+                c3 = __uint_as_float(v[1] & 0xffff0000u), c4 = __uint_as_float(v[2] << 16);
+    const int64_t m = P.off[l] + r;
+    hm[m] = c0;
+    *reinterpret_cast<float4*>(reg + 4 * m) = make_float4(fmaxf(c1 * s, 0.f), fmaxf(c2 * s, 0.f), fmaxf(c3 * s, 0.f), fmaxf(c4 * s, 0.f));
+}
+
+// 8 lanes per row (16 bytes each): lane 0 of a row holds the live channels, the others write zeros
+__global__ __launch_bounds__(256) void cn_head_outputs_bwd_kernel(HoLevels P, const float* __restrict__ g_reg, const float* __restrict__ g_hm,
+                                                                  float* __restrict__ part, int max_blocks) {
+    __shared__ float red[4];
+    const int l = blockIdx.y;
+    const int cpr = P.C >> 3;                       // 16-byte chunks per row
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t r = i / cpr;
+    const int ch = (int)(i - r * cpr);
+    float ds = 0.f;
+    if (r < P.rows[l]) {
+        u32x4 o = {0u, 0u, 0u, 0u};
+        if (ch == 0) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(P.x[l] + r * P.C);
+            const float s = P.scale[l][0];
+            const float c[4] = {__uint_as_float(v[0] & 0xffff0000u), __uint_as_float(v[1] << 16), __uint_as_float(v[1] & 0xffff0000u),
+                                __uint_as_float(v[2] << 16)};
+            const int64_t m = P.off[l] + r;
+            const float4 g4 = *reinterpret_cast<const float4*>(g_reg + 4 * m);
+            const float g[4] = {g4.x, g4.y, g4.z, g4.w};
+            float d[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float gk = c[k] * s > 0.f ? g[k] : 0.f;      // ReLU': the forward value relu(c * s) is positive
+                d[k] = gk * s;
+                ds += gk * c[k];
+            }
+            o = u32x4{pack_bf2(g_hm[m], d[0]), pack_bf2(d[1], d[2]), pack_bf2(d[3], 0.f), 0u};
+        }
+        *reinterpret_cast<u32x4*>(P.dx[l] + r * P.C + 8 * ch) = o;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ds += __shfl_xor(ds, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ds;
+    __syncthreads();
+    if (threadIdx.x == 0) part[(int64_t)l * max_blocks + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(64) void cn_head_scale_grad_kernel(HoLevels P, const float* __restrict__ part, int max_blocks, float* __restrict__ d_scale) {
+    const int l = blockIdx.x;
+    const int nb = (int)(((int64_t)P.rows[l] * (P.C >> 3) + 255) / 256);
+    float s = 0.f;
+    for (int b = threadIdx.x; b < nb; b += 64) s += part[(int64_t)l * max_blocks + b];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (threadIdx.x == 0) d_scale[l] = s;
+}
+
+static int ho_fill(HoLevels& P, const dgx_head_level* levels, int n, int C, bool bwd) {
+    if (!levels || n <= 0 || n > HO_MAXL || C < 8 || (C & 7)) return DGX_ERR_BAD_ARG;
+    P.L = n; P.C = C;
+    int off = 0, maxr = 0;
+    for (int l = 0; l < n; ++l) {
+        if (!levels[l].x || !levels[l].scale || levels[l].rows <= 0 || (bwd && !levels[l].dx)) return DGX_ERR_BAD_ARG;
+        if (((uintptr_t)levels[l].x & 15) || ((uintptr_t)levels[l].dx & 15)) return DGX_ERR_UNSUPPORTED;
+        P.x[l] = (const uint16_t*)levels[l].x; P.dx[l] = (uint16_t*)levels[l].dx; P.scale[l] = levels[l].scale;
+        P.rows[l] = levels[l].rows; P.off[l] = off;
+        off += levels[l].rows;
+        maxr = levels[l].rows > maxr ? levels[l].rows : maxr;
+    }
+    P.off[n] = off;
+    return maxr;
+}
+
+extern "C" int dgx_centernet_head_outputs(const dgx_head_level* levels, int n, int C, float* reg, float* hm, void* stream) {
+    HoLevels P;
+    const int maxr = ho_fill(P, levels, n, C, false);
+    if (maxr < 0) return maxr;
+    if (!reg || !hm || ((uintptr_t)reg & 15)) return DGX_ERR_BAD_ARG;
+    hipLaunchKernelGGL(cn_head_outputs_kernel, dim3((maxr + 255) / 256, n), dim3(256), 0, (hipStream_t)stream, P, reg, hm);
+    DGX_LAUNCH_CHECK();
+    return DGX_OK;
+}
+
+extern "C" int64_t dgx_centernet_head_outputs_bwd_workspace_floats(const dgx_head_level* levels, int n, int C) {
+    if (!levels || n <= 0 || C < 8) return 0;
+    int maxr = 0;
+    for (int l = 0; l < n; ++l) maxr = levels[l].rows > maxr ? levels[l].rows : maxr;
+    return (int64_t)n * (((int64_t)maxr * (C >> 3) + 255) / 256);
+}
+
+extern "C" int dgx_centernet_head_outputs_bwd(const dgx_head_level* levels, int n, int C, const float* g_reg, const float* g_hm,
+                                              float* d_scale, float* workspace, void* stream) {
+    HoLevels P;
+    const int maxr = ho_fill(P, levels, n, C, true);
+    if (maxr < 0) return maxr;
+    if (!g_reg || !g_hm || !d_scale || !workspace || ((uintptr_t)g_reg & 15)) return DGX_ERR_BAD_ARG;
+    const int max_blocks = (int)(((int64_t)maxr * (C >> 3) + 255) / 256);
+    hipLaunchKernelGGL(cn_head_outputs_bwd_kernel, dim3(max_blocks, n), dim3(256), 0, (hipStream_t)stream, P, g_reg, g_hm, workspace, max_blocks);
+    hipLaunchKernelGGL(cn_head_scale_grad_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, P, workspace, max_blocks, d_scale);
+    DGX_LAUNCH_CHECK();
+    return DGX_OK;
+}

@@ -427,13 +427,9 @@ class _HeadSegment(nn.Module):
         self.amp = False
 
     def forward(self, *feats):
+        # centernet.py:179-235: per level (B, C, h, w) -> (B h w, C), levels stacked
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.amp, cache_enabled=False):
-            _, reg, hm = self.head(list(feats))
-        # centernet.py:179-235: per level (B, C, h, w) -> (B h w, C), levels stacked; float(bf16) is exact, so casting after the cat
-        # gives the values of the reference's order (cast, then cat)
-        reg_flat = torch.cat([x.permute(0, 2, 3, 1).reshape(-1, 4) for x in reg], dim=0).float()
-        hm_flat = torch.cat([x.permute(0, 2, 3, 1).reshape(-1) for x in hm], dim=0).float()
-        return reg_flat, hm_flat
+            return self.head.forward_flat(list(feats))
 
 
 class _CenterNetLosses(torch.autograd.Function):

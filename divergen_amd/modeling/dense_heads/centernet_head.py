@@ -11,6 +11,7 @@ from ...config import configurable
 from ...layers.norm_ops import groupnorm_relu, groupnorm_relu_multi
 from ...layers.conv_ops import Conv2d, conv3x3, conv3x3_group, conv3x3_group_usable, conv3x3_multi
 from ...layers.linear_ops import group_parameters
+from ...layers.dense_ops import centernet_head_outputs
 
 
 class Scale(nn.Module):
@@ -22,6 +23,7 @@ class Scale(nn.Module):
         return x * self.scale
 
 
+_HEAD_OUT = __import__("os").environ.get("DGX_HEAD_OUT", "1") == "1"      # A/B switch: the head's tail + flattening as one kernel each way
 _GN_MULTI = __import__("os").environ.get("DGX_GN_MULTI", "1") == "1"      # A/B switch: GroupNorm of a tower layer over all levels at once
 
 
@@ -108,13 +110,37 @@ class CenterNetHead(nn.Module):
                 i += 1
         return xs
 
+    def _multi(self, x):
+        return (_GN_MULTI and len(x) > 1 and len(x) <= 8 and all(f.is_cuda for f in x) and len(self.share_tower) == 0 and len(self.cls_tower) == 0
+                and all(not isinstance(m, nn.GroupNorm) or self.bbox_tower[0].out_channels == 8 * m.num_groups for m in self.bbox_tower))
+
+    def forward_flat(self, x):
+        """-> (reg (M, 4) f32, agn_hm logits (M,) f32), levels stacked in (level, image, y, x) order: the loss operands of
+        centernet.py:179-235.  On the layer-major path the tail (slices, scale, ReLU, permutes, concatenations, casts) is one
+        kernel each way (layers.dense_ops.centernet_head_outputs); otherwise forward() + the reference's flattening."""
+        if _HEAD_OUT and self.only_proposal and self.with_agn_hm and torch.is_grad_enabled() and self._multi(x):
+            towers = self._run_tower_levels(self.bbox_tower, list(x))
+            boths = conv3x3_multi(towers, self.agn_hm.weight, self.agn_hm.bias)
+            if boths is not None and all(b.dtype == torch.bfloat16 and b.permute(0, 2, 3, 1).is_contiguous() for b in boths):
+                return centernet_head_outputs(boths, [s.scale for s in self.scales[:len(boths)]])
+            _, reg, hm = self._tail(x, towers, boths)
+        else:
+            _, reg, hm = self.forward(x)
+        # float(bf16) is exact, so casting after the cat gives the values of the reference's order (cast, then cat)
+        reg_flat = torch.cat([r.permute(0, 2, 3, 1).reshape(-1, 4) for r in reg], dim=0).float()
+        hm_flat = torch.cat([h.permute(0, 2, 3, 1).reshape(-1) for h in hm], dim=0).float()
+        return reg_flat, hm_flat
+
     def forward(self, x):
-        clss, bbox_reg, agn_hms = [], [], []
-        multi = (_GN_MULTI and len(x) > 1 and len(x) <= 8 and all(f.is_cuda for f in x) and len(self.share_tower) == 0 and len(self.cls_tower) == 0
-                 and all(not isinstance(m, nn.GroupNorm) or self.bbox_tower[0].out_channels == 8 * m.num_groups for m in self.bbox_tower))
+        multi = self._multi(x)
         towers = self._run_tower_levels(self.bbox_tower, list(x)) if multi else None
         # the grouped predictor convolution (agn_hm | bbox_pred) over all levels with one padded-copy launch per pass
         boths = conv3x3_multi(towers, self.agn_hm.weight, self.agn_hm.bias) if multi and self.with_agn_hm else None
+        return self._tail(x, towers, boths)
+
+    def _tail(self, x, towers, boths):
+        multi = towers is not None
+        clss, bbox_reg, agn_hms = [], [], []
         for l, feature in enumerate(x):
             if multi:
                 cls_tower, bbox_tower = feature, towers[l]

@@ -176,6 +176,19 @@ int dgx_centernet_decode(const void* const* reg_levels, int reg_pixel_stride, in
 int dgx_centernet_finalize(const float* sorted_boxes, const float* sorted_scores, const int32_t* keep_idx, const int32_t* num_keep,
                            int B, int K, int cap, float* out_boxes, float* out_scores, uint8_t* out_valid, void* stream);
 
+/* The tail of CenterNetHead.forward and CenterNet's output flattening over ALL levels, one launch each way
+ * (CN/modeling/dense_heads/centernet_head.py:113-131: `agn_hm(bbox_tower)`, `F.relu(self.scales[l](bbox_pred(bbox_tower)))`;
+ * centernet.py:179-235: per level (B, C, h, w) -> (B h w, C), levels stacked).  Level l: x bf16 (rows_l, C) channels-last, the
+ * grouped predictor output (channel 0 = heat-map logit, 1..4 = regression, C a multiple of 8), scale f32 (1) DEVICE pointer
+ * (scales[l].scale).  Forward: reg f32 (M, 4) = relu(float(x[1..4]) * scale_l), hm f32 (M) = float(x[0]), M = sum rows_l.
+ * Backward: dx bf16 (rows_l, C) = [g_hm, g_reg * (reg > 0) * scale_l, zeros], d_scale f32 (n); workspace:
+ * dgx_centernet_head_outputs_bwd_workspace_floats(...) floats.  Bit-reproducible (fixed partial order). */
+typedef struct dgx_head_level { const void* x; void* dx; const float* scale; int rows; } dgx_head_level;
+int dgx_centernet_head_outputs(const dgx_head_level* levels, int n, int C, float* reg, float* hm, void* stream);
+int64_t dgx_centernet_head_outputs_bwd_workspace_floats(const dgx_head_level* levels, int n, int C);
+int dgx_centernet_head_outputs_bwd(const dgx_head_level* levels, int n, int C, const float* g_reg, const float* g_hm,
+                                   float* d_scale, float* workspace, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Proposal labelling and sampling of the RoI heads for the whole batch (detic_roi_heads.py:273-307
  * `label_and_sample_proposals`; D2 proposal_utils.py:126-196, boxes.py:334-357, matcher.py:62-104, sampling.py:9-54).

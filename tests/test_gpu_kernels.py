@@ -1189,3 +1189,35 @@ def test_conv3x3_wgrad_bias_multi_equals_sum_over_images(Cin, Cout, beta):
     gw_c, gb_c = gw0.clone(), gb0.clone()
     L.check(lib.dgx_conv3x3_wgrad_bias_multi(items, len(xs), gw_c.data_ptr(), gb_c.data_ptr(), Cin, Cout, beta, L.ptr(ws), L.stream()), "multi")
     assert torch.equal(gw_b, gw_c) and torch.equal(gb_b, gb_c)
+
+
+@pytest.mark.gpu
+def test_centernet_head_outputs_equal_the_composed_tail():
+    """dgx_centernet_head_outputs / _bwd against the level-by-level composition it replaces (centernet_head.py:113-131 slices,
+    Scale, ReLU; centernet.py:179-235 permute / reshape / cat / float) on the same bf16 predictor outputs: outputs and the input
+    gradients bit-identical, the scale gradients to fp32 summation order."""
+    from divergen_amd.layers.dense_ops import centernet_head_outputs
+    g = torch.Generator(device=DEV).manual_seed(77)
+    shapes = [(2, 32, 32), (2, 16, 16), (2, 8, 8), (2, 5, 3), (1, 2, 2)]
+    C = 64
+    base = [torch.randn(b, h, w, C, device=DEV, generator=g).to(torch.bfloat16) for b, h, w in shapes]
+    sc0 = [torch.tensor([v], device=DEV) for v in (1.0, 0.7, -1.3, 2.0, 0.0)]       # a negative and a zero scale: ReLU' follows the product
+
+    def leaves():
+        xs = [t.clone().permute(0, 3, 1, 2).requires_grad_(True) for t in base]     # logical (B, C, h, w) on channels-last storage
+        ss = [s.clone().requires_grad_(True) for s in sc0]
+        return xs, ss
+    xs_a, ss_a = leaves()
+    reg_a = torch.cat([torch.relu(x[:, 1:5] * s).permute(0, 2, 3, 1).reshape(-1, 4) for x, s in zip(xs_a, ss_a)], 0).float()
+    hm_a = torch.cat([x[:, :1].permute(0, 2, 3, 1).reshape(-1) for x in xs_a], 0).float()
+    xs_b, ss_b = leaves()
+    reg_b, hm_b = centernet_head_outputs(xs_b, ss_b)
+    assert reg_a.dtype == reg_b.dtype == torch.float32 and torch.equal(reg_a, reg_b) and torch.equal(hm_a, hm_b)
+    gr = torch.randn(reg_a.shape, device=DEV, generator=g)
+    gh = torch.randn(hm_a.shape, device=DEV, generator=g)
+    torch.autograd.backward([reg_a, hm_a], [gr, gh])
+    torch.autograd.backward([reg_b, hm_b], [gr, gh])
+    for xa, xb in zip(xs_a, xs_b):
+        assert xb.grad.dtype == torch.bfloat16 and torch.equal(xa.grad.float(), xb.grad.float())
+    for sa, sb in zip(ss_a, ss_b):
+        assert abs(float(sa.grad) - float(sb.grad)) <= 1e-4 * max(1.0, abs(float(sa.grad)))

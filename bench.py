@@ -350,10 +350,10 @@ def main():
                     batch.append(d)
                     continue
                 out = la.copy_paste(d["image"], inst.gt_masks.tensor.view(torch.uint8), inst.gt_boxes.tensor,
-                                    inst.gt_classes, ps)
+                                    inst.gt_classes, ps, lazy_masks=True)
                 ni = Instances(inst.image_size)
                 ni.gt_boxes, ni.gt_classes = Boxes(out["boxes"]), out["labels"]
-                ni.gt_masks, ni.instance_source = BitMasks(out["masks"]), out["source"]
+                ni.gt_masks, ni.instance_source = BitMasks(out["masks"].view(torch.bool), index=out["keep"]), out["source"]   # 0/1 bytes: a view; rows through the index
                 batch.append({"image": out["image"], "instances": ni, "height": d["height"], "width": d["width"],
                               "file_name": d["file_name"]})
             ev = torch.cuda.Event()
@@ -368,7 +368,10 @@ def main():
         for d in batch:                                  # ... and owns them from here on (allocator stream bookkeeping)
             d["image"].record_stream(torch.cuda.current_stream())
             if "instances" in d and d["instances"].has("gt_masks"):
-                d["instances"].gt_masks.tensor.record_stream(torch.cuda.current_stream())
+                gm = d["instances"].gt_masks
+                gm._base.record_stream(torch.cuda.current_stream())
+                if gm._index is not None:
+                    gm._index.record_stream(torch.cuda.current_stream())
         # next batch on the side stream, issued BEFORE this step's forward: the host is ahead of the GPU here, whereas after the
         # forward's one device->host read (proposal sampler) every host microsecond is GPU idle time (measured: -0.55 ms/step
         # against issuing it between forward and backward)

@@ -171,10 +171,10 @@ class InstPool:
             names.append(str(key))
         dev = image.device if image.is_cuda else torch.device("cuda")
         out = copy_paste(image.to(dev), inst.gt_masks.tensor.to(dev).view(torch.uint8), inst.gt_boxes.tensor.to(dev),
-                         inst.gt_classes.to(dev), pastes)
+                         inst.gt_classes.to(dev), pastes, lazy_masks=True)
         ni = Instances((H, W))
         ni.gt_boxes, ni.gt_classes = Boxes(out["boxes"]), out["labels"]
-        ni.gt_masks, ni.instance_source = BitMasks(out["masks"]), out["source"]
+        ni.gt_masks, ni.instance_source = BitMasks(out["masks"].view(torch.bool), index=out["keep"]), out["source"]      # 0/1 bytes: a view; rows through the index
         data = dict(data)
         data["image"], data["instances"], data["height"], data["width"] = out["image"], ni, H, W
         data["paste_labels"], data["paste_filename_list"] = [p[3] for p in pastes], names      # BSGAL's selection reads these

@@ -51,16 +51,21 @@ def pack_pastes(pastes, device):
     return PackedPastes(flat, desc_t, labels, K)
 
 
-def copy_paste(image, masks, boxes, labels, pastes):
+def copy_paste(image, masks, boxes, labels, pastes, lazy_masks=False):
     """image uint8 (3,H,W), masks uint8 (n,H,W), boxes f32 (n,4), labels i64 (n) -- GPU tensors.
     pastes: list of (rgba uint8 numpy/tensor (h,w,4), x0, y0, label) applied in order, or a PackedPastes (pack_pastes).
-    Returns dict(image, masks, boxes, labels, source) exactly like the sequential reference."""
+    Returns dict(image, masks, boxes, labels, source) exactly like the sequential reference.  Mask bytes pass through (0/1 in,
+    0/1 out).  lazy_masks: `masks` holds ALL n + K objects' rows and `keep` (i64) the rows of the surviving ones, in order --
+    what structures.BitMasks(masks, index=keep) takes: the full-resolution rows of the survivors are then never gathered
+    (the only consumer, crop_and_resize, reads a few rows through the index)."""
     K = len(pastes)
     dev = image.device
     n0, H, W = masks.shape[0], image.shape[1], image.shape[2]
     if K == 0:
-        return dict(image=image, masks=masks, boxes=boxes, labels=labels,
-                    source=torch.zeros(n0, dtype=torch.int64, device=dev))
+        out = dict(image=image, masks=masks, boxes=boxes, labels=labels, source=torch.zeros(n0, dtype=torch.int64, device=dev))
+        if lazy_masks:
+            out["keep"] = torch.arange(n0, dtype=torch.int64, device=dev)
+        return out
     pk = pastes if isinstance(pastes, PackedPastes) else pack_pastes(pastes, dev)
     flat, desc_t = pk.flat, pk.desc
     image = image.contiguous().clone()
@@ -77,5 +82,9 @@ def copy_paste(image, masks, boxes, labels, pastes):
     keep = out_valid.nonzero().squeeze(1)          # ONE compaction (and one device->host count) for the four per-object tensors
     all_labels = torch.cat([labels.to(torch.int64), pk.labels])
     source = torch.cat([torch.zeros(n0, dtype=torch.int64, device=dev), torch.ones(K, dtype=torch.int64, device=dev)])
-    return dict(image=image, masks=out_masks.index_select(0, keep), boxes=out_boxes.index_select(0, keep),
-                labels=all_labels.index_select(0, keep), source=source.index_select(0, keep))
+    out = dict(image=image, boxes=out_boxes.index_select(0, keep), labels=all_labels.index_select(0, keep), source=source.index_select(0, keep))
+    if lazy_masks:
+        out["masks"], out["keep"] = out_masks, keep
+    else:
+        out["masks"] = out_masks.index_select(0, keep)
+    return out

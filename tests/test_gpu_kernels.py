@@ -417,6 +417,12 @@ def test_copy_paste_ragged_sizes_vs_oracle(H, W, n, K):
     out = la.copy_paste(T(img).to(DEV), T(masks).to(DEV), T(boxes).to(DEV), T(labels).to(DEV), pastes)
     for k in ("image", "masks", "boxes", "labels", "source"):
         assert np.array_equal(out[k].cpu().numpy(), ref[k]), k
+    # lazy_masks: all objects' rows + the surviving rows' indices (what BitMasks(base, index) takes) = the gathered form
+    from divergen_amd.structures import BitMasks
+    lz = la.copy_paste(T(img).to(DEV), T(masks).to(DEV), T(boxes).to(DEV), T(labels).to(DEV), pastes, lazy_masks=True)
+    assert torch.equal(lz["masks"].index_select(0, lz["keep"]), out["masks"]) and torch.equal(lz["boxes"], out["boxes"])
+    bm = BitMasks(lz["masks"].view(torch.bool), index=lz["keep"])
+    assert len(bm) == out["masks"].shape[0] and torch.equal(bm.tensor.view(torch.uint8), out["masks"])
 
 
 # ------------------------------------------------------------------ optimizer

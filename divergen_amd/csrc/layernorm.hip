@@ -212,31 +212,49 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const DT* __rest
 }
 
 // dgamma += sum_blocks part[b][0], dbeta += sum_blocks part[b][1].
-// block = 64 float4 column-quads x 16 row groups (1024 threads): 1 KiB contiguous per row read
-__global__ __launch_bounds__(1024) void ln_param_reduce_kernel(const float* __restrict__ part, float* __restrict__ dgamma,
-                                                               float* __restrict__ dbeta, int nblk, int C) {
-    __shared__ float4 red[16][64];
-    const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
-    const int q = blockIdx.x * 64 + lane;          // float4 index inside the 2*C-wide partial row
+// block = LNR_QB float4 column-quads x LNR_RG row groups (1024 threads): 256 B contiguous per row read.  Round 2 used 64 quads x 16
+// row groups: 6 workgroups for a C = 768 norm -- the whole second stage ran on 6 (12 for two norms) of the 256 CUs, 10.7 us for
+// 6 MB; 16 quads x 64 row groups are 24 (48) workgroups.  Summation order (both kernels, so the one- and two-norm forms stay
+// bit-identical): row group rg takes rows rg, rg + 64, ...; eight threads fold eight groups each, the first folds those eight.
+constexpr int LNR_QB = 16, LNR_RG = 64;
+__device__ __forceinline__ void ln_reduce_rows(const float* __restrict__ part, float* __restrict__ dgamma, float* __restrict__ dbeta, int nblk,
+                                               int C, int qblock, float4 (*red)[LNR_QB]) {
+    const int lane = threadIdx.x % LNR_QB, rg = threadIdx.x / LNR_QB;
+    const int q = qblock * LNR_QB + lane;          // float4 index inside the 2*C-wide partial row
     const int nq = 2 * C / 4;
     float4 s = {0.f, 0.f, 0.f, 0.f};
     if (q < nq) {
         const float4* p4 = reinterpret_cast<const float4*>(part);
 #pragma unroll 4
-        for (int b = rg; b < nblk; b += 16) {
+        for (int b = rg; b < nblk; b += LNR_RG) {
             const float4 v = p4[(int64_t)b * nq + q];
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
     }
     red[rg][lane] = s;
     __syncthreads();
+    if (rg < 8) {
+        float4 a = red[8 * rg][lane];
+#pragma unroll
+        for (int r = 1; r < 8; ++r) { const float4 v = red[8 * rg + r][lane]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+        s = a;
+    }
+    __syncthreads();
+    if (rg < 8) red[rg][lane] = s;
+    __syncthreads();
     if (rg == 0 && q < nq) {
         float4 a = red[0][lane];
-        for (int r = 1; r < 16; ++r) { const float4 v = red[r][lane]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+#pragma unroll
+        for (int r = 1; r < 8; ++r) { const float4 v = red[r][lane]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
         // the partial row is [dgamma(C) | dbeta(C)]; C % 4 == 0 so a quad never straddles the two
         float* dst = (4 * q < C) ? dgamma + 4 * q : dbeta + (4 * q - C);
         dst[0] += a.x; dst[1] += a.y; dst[2] += a.z; dst[3] += a.w;
     }
+}
+__global__ __launch_bounds__(1024) void ln_param_reduce_kernel(const float* __restrict__ part, float* __restrict__ dgamma,
+                                                               float* __restrict__ dbeta, int nblk, int C) {
+    __shared__ float4 red[LNR_RG][LNR_QB];
+    ln_reduce_rows(part, dgamma, dbeta, nblk, C, blockIdx.x, red);
 }
 
 static WinMap make_map(int B, int H, int W, int ws, int shift) {
@@ -302,38 +320,16 @@ extern "C" int dgx_layernorm_bwd(const void* dy_bf16, const void* x, const float
     else LN_BWD(6);
 #undef LN_BWD
     // dgamma == dbeta == NULL: the per-block partial rows stay in `part` for dgx_layernorm_param_reduce2 (two norms, one launch)
-    if (dgamma) hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * C / 4 + 63) / 64), dim3(1024), 0, st, part, dgamma, dbeta, grid, C);
+    if (dgamma) hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * C / 4 + LNR_QB - 1) / LNR_QB), dim3(1024), 0, st, part, dgamma, dbeta, grid, C);
     DGX_LAUNCH_CHECK();
     return DGX_OK;
 }
 
 struct LnRed2 { const float* part[2]; float* dgamma[2]; float* dbeta[2]; };
 __global__ __launch_bounds__(1024) void ln_param_reduce2_kernel(LnRed2 R, int nblk, int C) {
-    __shared__ float4 red[16][64];
+    __shared__ float4 red[LNR_RG][LNR_QB];
     const int which = blockIdx.y;
-    const float* part = R.part[which];
-    float* dgamma = R.dgamma[which];
-    float* dbeta = R.dbeta[which];
-    const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
-    const int q = blockIdx.x * 64 + lane;
-    const int nq = 2 * C / 4;
-    float4 s = {0.f, 0.f, 0.f, 0.f};
-    if (q < nq) {
-        const float4* p4 = reinterpret_cast<const float4*>(part);
-#pragma unroll 4
-        for (int b = rg; b < nblk; b += 16) {
-            const float4 v = p4[(int64_t)b * nq + q];
-            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-        }
-    }
-    red[rg][lane] = s;
-    __syncthreads();
-    if (rg == 0 && q < nq) {
-        float4 a = red[0][lane];
-        for (int r = 1; r < 16; ++r) { const float4 v = red[r][lane]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
-        float* dst = (4 * q < C) ? dgamma + 4 * q : dbeta + (4 * q - C);
-        dst[0] += a.x; dst[1] += a.y; dst[2] += a.z; dst[3] += a.w;
-    }
+    ln_reduce_rows(R.part[which], R.dgamma[which], R.dbeta[which], nblk, C, blockIdx.x, red);
 }
 
 // The second stage of TWO dgx_layernorm_bwd calls made with dgamma = dbeta = NULL (same T, hence the same number of partial
@@ -343,7 +339,7 @@ extern "C" int dgx_layernorm_param_reduce2(const float* part_a, float* dgamma_a,
     if (T <= 0) return DGX_OK;
     if (!part_a || !dgamma_a || !dbeta_a || !part_b || !dgamma_b || !dbeta_b || (C & 3) || C > 1536) return DGX_ERR_BAD_ARG;
     LnRed2 R = {{part_a, part_b}, {dgamma_a, dgamma_b}, {dbeta_a, dbeta_b}};
-    hipLaunchKernelGGL(ln_param_reduce2_kernel, dim3((2 * C / 4 + 63) / 64, 2), dim3(1024), 0, (hipStream_t)stream, R,
+    hipLaunchKernelGGL(ln_param_reduce2_kernel, dim3((2 * C / 4 + LNR_QB - 1) / LNR_QB, 2), dim3(1024), 0, (hipStream_t)stream, R,
                        dgx_layernorm_bwd_blocks(T), C);
     DGX_LAUNCH_CHECK();
     return DGX_OK;
@@ -526,7 +522,7 @@ extern "C" int dgx_patch_merge_ln_bwd(const void* dy_bf16, const void* x, const 
         hipLaunchKernelGGL((pm_ln_bwd_kernel<12, float, 4>), dim3(grid), dim3(256), 0, st, (const uint16_t*)dy_bf16,
                            (const float*)x, mean, rstd, gamma, (float*)dx, part, m);
 #undef PM_BWD
-    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * C / 4 + 63) / 64), dim3(1024), 0, st, part, dgamma, dbeta, grid, C);
+    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * C / 4 + LNR_QB - 1) / LNR_QB), dim3(1024), 0, st, part, dgamma, dbeta, grid, C);
     DGX_LAUNCH_CHECK();
     return DGX_OK;
 }
@@ -570,7 +566,7 @@ extern "C" int dgx_layernorm_f32out_bwd(const float* dy, const void* x, const fl
     else if (nj <= 2) LNF_BWD(2);
     else LNF_BWD(3);
 #undef LNF_BWD
-    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * C / 4 + 63) / 64), dim3(1024), 0, st, part, dgamma, dbeta, grid, C);
+    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * C / 4 + LNR_QB - 1) / LNR_QB), dim3(1024), 0, st, part, dgamma, dbeta, grid, C);
     DGX_LAUNCH_CHECK();
     return DGX_OK;
 }

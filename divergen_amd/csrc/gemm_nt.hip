@@ -680,7 +680,10 @@ extern "C" int dgx_conv3x3_gemm_multi(const dgx_conv_item* items, int n, const v
     if (FILE* lf = gemm_log_file()) {              // one line per LAUNCH (tools/gemm_insitu.py joins lines with dispatches): M = all images' rows
         int msum = 0;
         for (int i = 0; i < n; ++i) msum += Ms[i];
-        fprintf(lf, "%d %d %d %d %d %d\n", msum, P.N, P.K, 9, 128, Cout > 128 ? 256 : 128);
+        int t128 = 0, t192 = 0;
+        for (int i = 0; i < n; ++i) { t128 += (Ms[i] + 127) / 128; t192 += (Ms[i] + 191) / 192; }
+        const bool big = Cout > 128 && tile_192x256() && ((t192 + 255) / 256) * 192 < ((t128 + 255) / 256) * 128;
+        fprintf(lf, "%d %d %d %d %d %d\n", msum, P.N, P.K, 9, big ? 192 : 128, Cout > 128 ? 256 : 128);
         fflush(lf);
     }
     DgxProfScope prof(DGX_PROF_GEMM_NT, stream, fl, by);

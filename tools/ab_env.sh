@@ -7,7 +7,7 @@ for v in 0 1; do
 import sys,json
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 r=d['roofline']; o={x['family']:x for x in d['roofline_other']}
-print('$1=$v', 'ms/step %.2f' % d['ms_per_step'], 'gemm ms %.2f frac %.3f' % (r['total_ms_per_step'], r['frac']), 'wgrad ms %.2f' % o['wgrad']['total_ms_per_step'], 'attn bwd %.2f fwd %.2f' % (o['attn_bwd']['total_ms_per_step'], o['attn_fwd']['total_ms_per_step']))
+print('$1=$v', 'ms/step %.2f' % d['ms_per_step'], 'gemm ms %.2f frac %.3f' % (r['total_ms_per_step'], r['frac']), ' '.join('%s %.2f' % (k, o[k]['total_ms_per_step']) for k in ('wgrad', 'attn_bwd', 'attn_fwd') if k in o))
 "
 done
 done

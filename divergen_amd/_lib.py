@@ -152,6 +152,8 @@ SIGNATURES = {
     "dgx_conv3x3_pad": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     "dgx_conv3x3_pad_relu_grad": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     "dgx_conv3x3_pad_multi": (c_i, [c_p, c_i, c_i, c_p]),
+    "dgx_deconv2x2_shuffle": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
+    "dgx_deconv2x2_unshuffle_relu_grad": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     "dgx_conv3x3_gemm_multi": (c_i, [c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_p]),
     "dgx_conv3x3_wgrad_bias_multi_workspace_bytes": (c_i64, [c_p, c_i, c_i, c_i]),
     "dgx_conv3x3_wgrad_bias_multi": (c_i, [c_p, c_i, c_p, c_p, c_i, c_i, c_f, c_p, c_p]),

@@ -245,3 +245,104 @@ extern "C" int dgx_conv3x3_pad(const void* x, void* xpad, int N, int H, int W, i
     DGX_LAUNCH_CHECK();
     return DGX_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// ConvTranspose2d(kernel 2, stride 2) = ONE GEMM over the weight as stored, (Cin, Cout*2*2), + a pixel shuffle
+// (mask_head.py:209-284 `deconv`; D2 wrappers.ConvTranspose2d): the GEMM's row m = (n, h, w) holds columns (co, dy, dx);
+//   dgx_deconv2x2_shuffle             out[n][2h+dy][2w+dx][co] = y2[m][4 co + 2 dy + dx]                     (forward)
+//   dgx_deconv2x2_unshuffle_relu_grad g2[m][4 co + 2 dy + dx]  = yout[p][co] > 0 ? gy[p][co] : 0, p = that pixel (backward: the
+//                                     un-shuffle of the output gradient with the ReLU' of the layer's fused ReLU folded in;
+//                                     yout NULL = no ReLU)
+// One lane = 8 channels of one input pixel: 64 contiguous bytes on the GEMM side, four 16-byte chunks on the image side.  The
+// composed form was a permuting copy each way + compare + multiply launches (0.15 ms per step on the mask head).
+__device__ __forceinline__ uint32_t dc_pick(const uint32_t w[16], int e) {     // bf16 element e (0 .. 31) of 16 packed words
+    const uint32_t v = w[e >> 1];
+    return (e & 1) ? (v >> 16) : (v & 0xffffu);
+}
+__global__ __launch_bounds__(256) void deconv2x2_shuffle_kernel(const uint4* __restrict__ y2, uint4* __restrict__ out, int64_t M, int H, int W,
+                                                                int C8) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M * C8) return;
+    const int64_t m = i / C8;
+    const int c8 = (int)(i - m * C8);
+    const int w_ = (int)(m % W), h = (int)((m / W) % H);
+    const int64_t n = m / ((int64_t)W * H);
+    uint32_t in[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint4 v = y2[(m * C8 + c8) * 4 + q];
+        in[4 * q] = v.x; in[4 * q + 1] = v.y; in[4 * q + 2] = v.z; in[4 * q + 3] = v.w;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {                  // k = 2 dy + dx: element j of the chunk = input element 4 j + k
+        uint32_t o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = dc_pick(in, 8 * j + k) | (dc_pick(in, 8 * j + 4 + k) << 16);
+        const int64_t p = ((n * 2 * H + 2 * h + (k >> 1)) * 2 * W + 2 * w_ + (k & 1));
+        out[p * C8 + c8] = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+__global__ __launch_bounds__(256) void deconv2x2_unshuffle_kernel(const uint4* __restrict__ gy, const uint4* __restrict__ yout,
+                                                                  uint4* __restrict__ g2, int64_t M, int H, int W, int C8) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M * C8) return;
+    const int64_t m = i / C8;
+    const int c8 = (int)(i - m * C8);
+    const int w_ = (int)(m % W), h = (int)((m / W) % H);
+    const int64_t n = m / ((int64_t)W * H);
+    uint32_t ch[4][4];                             // ch[k][j]: channels 2j, 2j+1 of sub-pixel k
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int64_t p = ((n * 2 * H + 2 * h + (k >> 1)) * 2 * W + 2 * w_ + (k & 1));
+        const uint4 g = gy[p * C8 + c8];
+        uint32_t gw[4] = {g.x, g.y, g.z, g.w};
+        if (yout) {
+            const uint4 yv = yout[p * C8 + c8];
+            const uint32_t yw[4] = {yv.x, yv.y, yv.z, yv.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {          // bf16 > 0: sign bit clear and not (+)zero
+                const uint32_t a = yw[j];
+                const uint32_t lo = ((a & 0x8000u) || !(a & 0x7fffu)) ? 0u : 0xffffu;
+                const uint32_t hi = ((a & 0x80000000u) || !(a & 0x7fff0000u)) ? 0u : 0xffff0000u;
+                gw[j] &= lo | hi;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ch[k][j] = gw[j];
+    }
+    // output element e = 4 c + k (c = 0 .. 7): word e / 2 holds (c, k = 0 | 2) low and (c, k = 1 | 3) high
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        uint32_t o[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int e = 8 * q + 2 * t;           // even element: channel c = e / 4, sub-pixel k = e % 4 (0 or 2), and k + 1 behind it
+            const int c = e >> 2, k = e & 3;
+            const uint32_t lo = (c & 1) ? (ch[k][c >> 1] >> 16) : (ch[k][c >> 1] & 0xffffu);
+            const uint32_t hi = (c & 1) ? (ch[k + 1][c >> 1] >> 16) : (ch[k + 1][c >> 1] & 0xffffu);
+            o[t] = lo | (hi << 16);
+        }
+        g2[(m * C8 + c8) * 4 + q] = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+extern "C" int dgx_deconv2x2_shuffle(const void* y2, void* out, int N, int H, int W, int Cout, void* stream) {
+    if (N <= 0 || H <= 0 || W <= 0) return DGX_OK;
+    if (!y2 || !out || Cout <= 0 || (Cout & 7) || ((uintptr_t)y2 & 15) || ((uintptr_t)out & 15)) return DGX_ERR_BAD_ARG;
+    const int64_t M = (int64_t)N * H * W, total = M * (Cout / 8);
+    if ((total + 255) / 256 >= (1ll << 31)) return DGX_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(deconv2x2_shuffle_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint4*)y2,
+                       (uint4*)out, M, H, W, Cout / 8);
+    DGX_LAUNCH_CHECK();
+    return DGX_OK;
+}
+extern "C" int dgx_deconv2x2_unshuffle_relu_grad(const void* gy, const void* yout, void* g2, int N, int H, int W, int Cout, void* stream) {
+    if (N <= 0 || H <= 0 || W <= 0) return DGX_OK;
+    if (!gy || !g2 || Cout <= 0 || (Cout & 7) || ((uintptr_t)gy & 15) || ((uintptr_t)g2 & 15) || ((uintptr_t)yout & 15)) return DGX_ERR_BAD_ARG;
+    const int64_t M = (int64_t)N * H * W, total = M * (Cout / 8);
+    if ((total + 255) / 256 >= (1ll << 31)) return DGX_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(deconv2x2_unshuffle_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint4*)gy,
+                       (const uint4*)yout, (uint4*)g2, M, H, W, Cout / 8);
+    DGX_LAUNCH_CHECK();
+    return DGX_OK;
+}

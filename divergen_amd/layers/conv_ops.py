@@ -505,29 +505,37 @@ class _Deconv2x2(torch.autograd.Function):
     """ConvTranspose2d(k 2, s 2) as ONE MFMA GEMM per direction over the weight as stored, (Cin, Cout*2*2):
     y[pix][(co,dy,dx)] = x[pix] . W[:, (co,dy,dx)] + b[co]  (+ ReLU, which commutes with the pixel shuffle that follows);
     forward reads the arena's transposed twin (4 Cout, Cin), the input gradient the stored matrix itself, the weight gradient
-    is x^T dy in the stored layout (accumulated in place in the arena)."""
+    is x^T dy in the stored layout (accumulated in place in the arena).  The pixel shuffle is one kernel each way
+    (dgx_deconv2x2_shuffle / _unshuffle_relu_grad: the backward one carries the ReLU'), the bias gradient a column sum of the
+    un-shuffled gradient (dgx_colsum_bf16) folded over the four sub-pixels."""
 
     @staticmethod
-    def forward(ctx, x2, weight, bias, relu):
+    def forward(ctx, x2, weight, bias, relu, geom):
+        N, H, W = geom
         w16 = shadow(weight)
         Cin = w16.shape[0]
+        Cout = weight.shape[1]
         wt = getattr(weight, "_dgx16t", None)
         if wt is None or getattr(weight, "_dgx16t_flipped", False):
             wt = w16.reshape(Cin, -1).t().contiguous()
         b4 = shadow(bias).repeat_interleave(4) if bias is not None else None
         from .gemm_ops import gemm_nt_act
-        y = gemm_nt_act(x2, wt, b4, relu)
-        ctx.save_for_backward(x2, y if relu else None)
-        ctx.weight, ctx.bias, ctx.w16, ctx.relu = weight, bias, w16, relu
-        return y
+        y2 = gemm_nt_act(x2, wt, b4, relu)
+        out = torch.empty(N, 2 * H, 2 * W, Cout, dtype=torch.bfloat16, device=x2.device)
+        L.check(L.lib().dgx_deconv2x2_shuffle(L.ptr(y2), L.ptr(out), N, H, W, Cout, L.stream()), "dgx_deconv2x2_shuffle")
+        ctx.save_for_backward(x2, out if relu else None)
+        ctx.weight, ctx.bias, ctx.w16, ctx.relu, ctx.geom = weight, bias, w16, relu, (N, H, W, Cout)
+        return out
 
     @staticmethod
     def backward(ctx, gy):
-        x2, yact = ctx.saved_tensors
+        x2, yout = ctx.saved_tensors
         weight, bias, w16 = ctx.weight, ctx.bias, ctx.w16
-        g2 = gy.to(torch.bfloat16).contiguous()
-        if ctx.relu:
-            g2 = g2 * (yact > 0)
+        N, H, W, Cout = ctx.geom
+        gy = gy.to(torch.bfloat16).contiguous()
+        g2 = torch.empty(N * H * W, 4 * Cout, dtype=torch.bfloat16, device=gy.device)
+        L.check(L.lib().dgx_deconv2x2_unshuffle_relu_grad(L.ptr(gy), L.ptr(yout) if ctx.relu else None, L.ptr(g2), N, H, W, Cout, L.stream()),
+                "dgx_deconv2x2_unshuffle_relu_grad")
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             gx = gemm_nt(g2, w16.reshape(w16.shape[0], -1))           # (M, 4 Cout) x (Cin, 4 Cout)^T
@@ -536,8 +544,13 @@ class _Deconv2x2(torch.autograd.Function):
                 wgrad_into(g.view(g.shape[0], -1), x2, g2)             # (Cin, 4 Cout) = x^T dy
             gw = accumulate_grad(weight, lambda: torch.mm(x2.t(), g2, out_dtype=torch.float32).view(weight.shape), gemm_into=into)
         if bias is not None and ctx.needs_input_grad[2]:
-            gb = accumulate_grad(bias, lambda: torch.sum(g2.view(g2.shape[0], -1, 4), (0, 2), dtype=torch.float32))
-        return gx, gw, gb, None
+            def colsums():
+                from .swin_block import colsum_into
+                s4 = torch.empty(4 * Cout, dtype=torch.float32, device=g2.device)
+                colsum_into(s4, g2, beta=0.0)
+                return s4.view(Cout, 4).sum(1)
+            gb = accumulate_grad(bias, colsums)
+        return gx, gw, gb, None, None
 
 
 def deconv2x2(x, weight, bias, relu=False):
@@ -545,11 +558,10 @@ def deconv2x2(x, weight, bias, relu=False):
     xh = _nhwc(x)
     N, H, W, Cin = xh.shape
     Cout = weight.shape[1]
-    if not (xh.is_cuda and Cin % 8 == 0 and Cout % 2 == 0):
-        raise L.DgxError("deconv2x2: GPU input with Cin %% 8 == 0 and even Cout required (Cin %d, Cout %d, %s)" % (Cin, Cout, xh.device))
+    if not (xh.is_cuda and Cin % 8 == 0 and Cout % 8 == 0):
+        raise L.DgxError("deconv2x2: GPU input with Cin %% 8 == 0 and Cout %% 8 == 0 required (Cin %d, Cout %d, %s)" % (Cin, Cout, xh.device))
     with torch.autocast("cuda", enabled=False):
-        y = _Deconv2x2.apply(xh.reshape(-1, Cin).to(torch.bfloat16), weight, bias, relu)
-    y = y.view(N, H, W, Cout, 2, 2).permute(0, 1, 4, 2, 5, 3).reshape(N, 2 * H, 2 * W, Cout)
+        y = _Deconv2x2.apply(xh.reshape(-1, Cin).to(torch.bfloat16), weight, bias, relu, (N, H, W))
     return y.permute(0, 3, 1, 2)
 
 

@@ -616,6 +616,13 @@ typedef struct dgx_pad_item { const void* x; void* xpad; int N, H, W; } dgx_pad_
 int dgx_conv3x3_pad_multi(const dgx_pad_item* items, int n, int C, void* stream);
 /* dgx_conv3x3_gemm over n <= 6 zero-bordered images that share the weights (and bias / ReLU) in ONE launch: the FPN levels under a
  * CenterNet tower layer (centernet_head.py:141-162).  Cout <= 256.  The input gradient is the same call on the tap-flipped twin. */
+/* ConvTranspose2d(kernel 2, stride 2) as ONE GEMM over the weight as stored (Cin, Cout*2*2) + a pixel shuffle (mask_head.py:209-284
+ * `deconv`): GEMM row m = (n, h, w), columns (co, dy, dx), bf16.
+ *   dgx_deconv2x2_shuffle:             out (N, 2H, 2W, Cout) channels-last: out[n][2h+dy][2w+dx][co] = y2[m][4 co + 2 dy + dx].
+ *   dgx_deconv2x2_unshuffle_relu_grad: g2 (N*H*W, 4 Cout): the inverse on the output gradient gy (N, 2H, 2W, Cout), zeroed where the
+ *                                      layer's own ReLU-ed output yout (same layout as gy) is not positive; yout NULL = no ReLU. */
+int dgx_deconv2x2_shuffle(const void* y2, void* out, int N, int H, int W, int Cout, void* stream);
+int dgx_deconv2x2_unshuffle_relu_grad(const void* gy, const void* yout, void* g2, int N, int H, int W, int Cout, void* stream);
 typedef struct dgx_conv_item { const void* xpad; void* y; int N, H, W; } dgx_conv_item;
 int dgx_conv3x3_gemm_multi(const dgx_conv_item* items, int n, const void* w, const void* bias, int Cin, int Cout, int relu, void* stream);
 /* The weight (+ bias) gradient of ONE convolution accumulated over n <= 6 zero-bordered image pairs (output gradient, input) -- the FPN

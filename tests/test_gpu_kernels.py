@@ -1227,3 +1227,26 @@ def test_centernet_head_outputs_equal_the_composed_tail():
         assert xb.grad.dtype == torch.bfloat16 and torch.equal(xa.grad.float(), xb.grad.float())
     for sa, sb in zip(ss_a, ss_b):
         assert abs(float(sa.grad) - float(sb.grad)) <= 1e-4 * max(1.0, abs(float(sa.grad)))
+
+
+@pytest.mark.gpu
+def test_deconv2x2_shuffle_kernels_equal_the_permuting_views():
+    """dgx_deconv2x2_shuffle / _unshuffle_relu_grad against the view / permute / reshape (and compare + multiply) they replace:
+    bit-identical, ragged sizes."""
+    from divergen_amd import _lib as L
+    lib = L.lib()
+    g = torch.Generator(device=DEV).manual_seed(5)
+    N, H, W, Co = 3, 7, 5, 24
+    y2 = torch.randn(N * H * W, 4 * Co, device=DEV, generator=g).to(torch.bfloat16)
+    out = torch.empty(N, 2 * H, 2 * W, Co, dtype=torch.bfloat16, device=DEV)
+    L.check(lib.dgx_deconv2x2_shuffle(L.ptr(y2), L.ptr(out), N, H, W, Co, L.stream()), "shuffle")
+    ref = y2.view(N, H, W, Co, 2, 2).permute(0, 1, 4, 2, 5, 3).reshape(N, 2 * H, 2 * W, Co)
+    assert torch.equal(out.float(), ref.float())
+    gy = torch.randn(N, 2 * H, 2 * W, Co, device=DEV, generator=g).to(torch.bfloat16)
+    yout = torch.relu(torch.randn(N, 2 * H, 2 * W, Co, device=DEV, generator=g)).to(torch.bfloat16)
+    for use_relu in (False, True):
+        g2 = torch.full((N * H * W, 4 * Co), float("nan"), dtype=torch.bfloat16, device=DEV)
+        L.check(lib.dgx_deconv2x2_unshuffle_relu_grad(L.ptr(gy), L.ptr(yout) if use_relu else None, L.ptr(g2), N, H, W, Co, L.stream()), "unshuffle")
+        src = gy * (yout > 0) if use_relu else gy
+        want = src.view(N, H, 2, W, 2, Co).permute(0, 1, 3, 5, 2, 4).reshape(N * H * W, 4 * Co)
+        assert torch.equal(g2.float(), want.float())

@@ -163,6 +163,7 @@ SIGNATURES = {
     "dgx_conv3x3_wgrad_bias_workspace_bytes": (c_i64, [c_i, c_i, c_i, c_i, c_i]),
     "dgx_conv3x3_wgrad_bias": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_p]),
     "dgx_transpose_bf16_grouped": (c_i, [c_p, c_p, c_p, c_i, c_i64, c_p]),
+    "dgx_zero_ranges_f32": (c_i, [c_p, c_p, c_i64, c_p]),
     "dgx_sgd_ema_step": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i64, c_f, c_f, c_i, c_f, c_f, c_f, c_p, c_i, c_f, c_p, c_p, c_i, c_p, c_p]),
     "dgx_clip_coef_workspace_floats": (c_i64, []),
     "dgx_clip_coef_f32": (c_i, [c_p, c_i64, c_f, c_f, c_p, c_p, c_p]),

@@ -176,3 +176,18 @@ extern "C" int dgx_clip_coef_f32(const float* g, int64_t n, float grad_scale, fl
     DGX_LAUNCH_CHECK();
     return DGX_OK;
 }
+
+// Zero a list of ranges of a flat f32 arena in one launch: ranges i64 (n, 2) DEVICE = (first element, count), each a multiple of 4
+// and at most 65 536 elements (one workgroup per range).  The gradient arena minus the segments that their first writer overwrites
+// (solver.FlatArena.zero_grad(lazy=True)).
+__global__ __launch_bounds__(256) void zero_ranges_kernel(float4* __restrict__ g, const int64_t* __restrict__ ranges) {
+    const int64_t p4 = ranges[2 * (int64_t)blockIdx.x] >> 2, n4 = ranges[2 * (int64_t)blockIdx.x + 1] >> 2;
+    for (int64_t i = threadIdx.x; i < n4; i += 256) g[p4 + i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+extern "C" int dgx_zero_ranges_f32(float* g, const int64_t* ranges, int64_t n, void* stream) {
+    if (n <= 0) return DGX_OK;
+    if (!g || !ranges || ((uintptr_t)g & 15) || n >= (1ll << 31)) return DGX_ERR_BAD_ARG;
+    hipLaunchKernelGGL(zero_ranges_kernel, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, (float4*)g, ranges);
+    DGX_LAUNCH_CHECK();
+    return DGX_OK;
+}

@@ -100,6 +100,7 @@ class ArenaReducer:
     def finish(self):
         """Call after backward: flush never-ready buckets, wait for every collective.  Returns the
         factor the optimizer must apply to the summed gradients."""
+        self.arena.finish_grads() if hasattr(self.arena, "finish_grads") else None     # directly-written segments nobody wrote: zeroed
         if self.active:
             self.last_early = self._next          # buckets that left while backward was still running (diagnostic)
             for b in range(self._next, len(self.buckets)):

@@ -135,11 +135,23 @@ def group_parameters(first_weight_or_bias, *others, pad_to=8):
         q._dgx_group_members = members
 
 
+def ensure_zeroed(p):
+    """A gradient segment that the lazy zero_grad (solver.FlatArena.zero_grad(lazy=True)) left to its usual first writer, reached by an
+    ACCUMULATING path instead: zero it now (and stop treating it as directly written)."""
+    slot = getattr(p, "_dgx_arena_slot", None) if p is not None else None
+    if slot is not None and slot[1] in slot[0]._lazy_pending:
+        a, i = slot
+        a.g[a.offsets[i]:a.offsets[i] + a.sizes[i]].zero_()
+        a._lazy_pending.discard(i)
+        a.direct.discard(i)
+
+
 def accumulate_grad(p, make_grad_fp32, gemm_into=None):
     """Write a gradient into p's arena view.  Returns None if done in place (and signals the
     data-parallel reducer), else the gradient tensor for autograd to accumulate."""
     g = p.grad if p.is_leaf else None
     if g is not None and g.dtype == torch.float32 and getattr(p, "_dgx16", None) is not None:
+        ensure_zeroed(p)
         if gemm_into is not None:
             gemm_into(g)
         else:
@@ -178,6 +190,8 @@ class _LinearFn(torch.autograd.Function):
         from .gemm_ops import gemm_nt
         x2, = ctx.saved_tensors
         weight, bias = ctx.weight, ctx.bias
+        ensure_zeroed(weight)                  # (this path accumulates: see solver.FlatArena.zero_grad(lazy=True))
+        ensure_zeroed(bias)
         dy2 = dy.reshape(-1, dy.shape[-1])
         if dy2.dtype != BF16:
             dy2 = dy2.to(BF16)

@@ -71,7 +71,12 @@ def _tiles(g):
 def _launch(items):
     # weight AND bias gradients in one grouped launch: the bias gradient is dY^T 1 on the fragments the weight-gradient kernel
     # holds anyway (round 3; the separate column-sum kernels cost 95 launches / 1.1 ms per step)
-    wgrad_grouped([(g, d, x_, b.grad if b is not None else None) for (g, d, x_, b, w), _ in items])
+    # every problem of the launch the FIRST writer of its gradient segments in this pass (solver.FlatArena.claim_first_write): the
+    # launch overwrites (beta = 0) -- nothing read, nothing that had to be zeroed
+    members = [q for (g, d, x_, b, w), _ in items for q in ((w,) if b is None else (w, b))]
+    slot = getattr(members[0], "_dgx_arena_slot", None)
+    first = slot is not None and all(getattr(q, "_dgx_arena_slot", (None,))[0] is slot[0] for q in members) and slot[0].claim_first_write(members)
+    wgrad_grouped([(g, d, x_, b.grad if b is not None else None) for (g, d, x_, b, w), _ in items], beta=0.0 if first else 1.0)
     for (g, d, x_, b, w), _ in items:
         _ready(w) if b is None else _ready(w, b)
 

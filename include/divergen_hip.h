@@ -281,6 +281,10 @@ int dgx_sgd_ema_step(float* p, const float* g, float* buf, float* ema, void* p_b
 /* FullModelGradientClippingOptimizer (custom_solver.py:46-60: torch.nn.utils.clip_grad_norm_ over all parameters) without a host
  * read: out2[0] = min(1, max_norm / (||g * grad_scale||_2 + 1e-6)), out2[1] = the norm; out2 is what dgx_sgd_ema_step takes as
  * grad_scale_dev.  workspace: dgx_clip_coef_workspace_floats() floats.  Deterministic (fixed partial order, double fold). */
+/* g[first .. first + count) = 0 for n ranges, ranges i64 (n, 2) DEVICE, first / count multiples of 4, count <= 65536: the gradient
+ * arena minus the segments their first writer overwrites (`optimizer.zero_grad()` of train_net.py:248-304 without touching what the
+ * weight-gradient launches rewrite anyway). */
+int dgx_zero_ranges_f32(float* g, const int64_t* ranges, int64_t n, void* stream);
 int64_t dgx_clip_coef_workspace_floats(void);
 int dgx_clip_coef_f32(const float* g, int64_t n, float grad_scale, float max_norm, float* workspace, float* out2, void* stream);
 

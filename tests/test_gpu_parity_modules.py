@@ -543,3 +543,61 @@ def test_drop_path_factors_survive_activation_checkpointing():
     for k in res[False]:
         a, b = res[False][k], res[True][k]
         assert float((a - b).abs().max()) <= 1e-4 * float(a.abs().max()) + 1e-7, k
+
+
+def test_lazy_zero_grad_first_writer_gradients_equal_zero_filled_ones(monkeypatch):
+    """FlatArena.zero_grad(lazy=True): from the second step on the Swin block's Linear weight / bias gradient segments are left
+    to their first writer (the grouped weight-gradient launch with beta = 0) instead of being zero-filled and accumulated into.
+    Over four steps with different inputs the whole gradient arena must equal that of the zero-filled run bit for bit, the
+    segments must really have been skipped, a pass that goes through the OTHER (composed) path finds its segments zeroed, and a
+    step in which the layer does not run at all leaves zeros, not the previous step's gradient."""
+    from divergen_amd import solver
+    from divergen_amd.layers import shift_regions
+    from divergen_amd.modeling.backbone import swintransformer as S
+    dim, nH, ws, B, H, W = 192, 6, 12, 2, 30, 26
+
+    def run(lazy, composed_at=None, skip_at=None):
+        monkeypatch.setattr(solver, "_LAZY_ZERO", lazy)
+        torch.manual_seed(5)
+        blk = S.SwinTransformerBlock(dim, nH, window_size=ws, shift_size=6, drop_path=0.0).to(DEV).train()
+        for p in blk.parameters():
+            torch.nn.init.normal_(p, std=0.05)
+        blk.H, blk.W = H, W
+        arena = solver.FlatArena(blk)
+        region = shift_regions(H, W, ws).to(DEV)
+        gen = torch.Generator(device=DEV).manual_seed(9)
+        grads, skipped = [], []
+        for step in range(4):
+            arena.zero_grad(lazy=True)
+            skipped.append(len(arena._lazy_pending))
+            monkeypatch.setattr(S, "_FUSED_BLOCK", step != composed_at)
+            x = torch.randn(B, H * W, dim, device=DEV, generator=gen).to(torch.bfloat16).requires_grad_(True)
+            go = torch.randn(B, H * W, dim, device=DEV, generator=gen).to(torch.bfloat16)
+            if step != skip_at:
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    y = blk(x, region)
+                y.backward(go)
+            arena.finish_grads()
+            grads.append(arena.g.clone())
+        monkeypatch.setattr(S, "_FUSED_BLOCK", True)
+        lin = torch.zeros(arena.numel, dtype=torch.bool, device=DEV)      # the Linear weights / biases: deterministic kernels
+        for n_, o, q in zip(arena.names, arena.offsets, arena.params):
+            if any(k in n_ for k in ("qkv", "proj", "fc1", "fc2")):
+                lin[o:o + q.numel()] = True
+        return grads, skipped, lin
+
+    def same(a, b, lin):
+        # Linear segments bit for bit; the rest (LayerNorm parameters, the relative-position table: fp32 atomics) to summation order
+        return torch.equal(a[lin], b[lin]) and float((a - b).abs().max()) <= 1e-4 * float(a.abs().max())
+    ref, sk0, lin = run(False)
+    got, sk1, _ = run(True)
+    assert sk0 == [0, 0, 0, 0] and sk1[0] == 0 and sk1[1] == sk1[2] == sk1[3] == 8          # qkv, proj, fc1, fc2: weight + bias
+    for a, b in zip(ref, got):
+        assert float(a[lin].abs().max()) > 0 and same(a, b, lin)
+    ref_c, _, _ = run(False, composed_at=2)
+    got_c, sk, _ = run(True, composed_at=2)
+    assert sk[2] == 8 and sk[3] == 0          # step 2 went the other way: its segments are no longer taken to be written directly
+    for a, b in zip(ref_c, got_c):
+        assert same(a, b, lin)
+    got_s, _, _ = run(True, skip_at=2)
+    assert float(got_s[2].abs().max()) == 0.0 and same(got_s[1], ref[1], lin)

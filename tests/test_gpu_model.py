@@ -350,3 +350,34 @@ def test_fused_sampler_equals_composed_sampler(monkeypatch):
             res.append(({k: float(v) for k, v in losses.items()}, float(st.latest()["roi_head/num_fg_samples"][0])))
     assert used == [True, False]
     assert res[0] == res[1], res
+
+
+def test_first_writer_gradients_train_like_zero_filled_ones(monkeypatch):
+    """Three optimizer steps of the assembled model (Swin-T CenterNet2, two different batches) with the training loop's
+    zero_grad(lazy=True) -- backbone Linear and box-cascade gradient segments left to their first writers -- against the same
+    steps with every segment zero-filled: the same weights up to the summation order of the kernels that use atomics, and the
+    lazy run really skipped segments."""
+    from divergen_amd import solver
+    from divergen_amd.data import synthetic_batch
+    from divergen_amd.utils.events import EventStorage
+
+    def run(lazy):
+        monkeypatch.setattr(solver, "_LAZY_ZERO", lazy)
+        cfg, model, opt = _build(False)
+        batches = [synthetic_batch(2, 256, cfg.MODEL.ROI_HEADS.NUM_CLASSES, seed=11 + k, device="cuda") for k in range(2)]
+        skipped = []
+        with EventStorage(0):
+            for k in range(3):
+                opt.zero_grad()
+                skipped.append(len(opt.arena._lazy_pending))
+                torch.manual_seed(100 + k)
+                losses = model(batches[k % 2])
+                sum(losses.values()).backward()
+                opt.step()
+        return opt.arena.p.clone(), skipped, opt.arena
+    p0, s0, _ = run(False)
+    p1, s1, arena = run(True)
+    assert s0 == [0, 0, 0] and s1[0] == 0 and s1[1] == s1[2] > 40, (s0, s1)
+    assert float((p0 - p1).abs().max()) <= 2e-3 * float(p0.abs().max())
+    names = {arena.names[i] for i in arena.direct}
+    assert any("box_head" in n for n in names) and any("mlp.fc1.weight" in n for n in names)

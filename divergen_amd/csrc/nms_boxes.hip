@@ -165,10 +165,11 @@ __device__ __forceinline__ uint64_t readlane64(uint64_t v, int lane) {
     return ((uint64_t)hi << 32) | lo;
 }
 
-// One workgroup per image.  Inside a 64-box block the survivors are found by a SCALAR loop over the kept
+// The two-barrier form with the kept rows read from global memory: any K (the pipelined form below holds two blocks of rows in LDS
+// and serves K <= ~4 900).  One workgroup per image.  Inside a 64-box block the survivors are found by a SCALAR loop over the kept
 // boxes only (find-first-set on the alive word, readlane of that row's diagonal word); then all threads OR
 // the kept rows into the running "removed" vector in LDS.
-__global__ __launch_bounds__(1024) void nms_sweep_batched_kernel(const uint64_t* __restrict__ mask_all, const float* __restrict__ scores_all,
+__global__ __launch_bounds__(1024) void nms_sweep_batched_global_kernel(const uint64_t* __restrict__ mask_all, const float* __restrict__ scores_all,
                                                                  const int32_t* __restrict__ n_valid, int K, int nb, int max_keep,
                                                                  int32_t* __restrict__ keep_idx_all, int cap, int32_t* __restrict__ num_keep) {
     extern __shared__ uint64_t remv[];  // [nb]
@@ -246,6 +247,132 @@ __global__ __launch_bounds__(1024) void nms_sweep_batched_kernel(const uint64_t*
     if (tid == 0) num_keep[b] = total < cap ? total : cap;
 }
 
+constexpr int NMS_PRE = 3;        // removed-word requests a worker lane keeps in flight per phase (covers 2 880 kept rows)
+// Round 3: the sweep as a pipeline with ONE barrier per 64-box block and no memory latency on its serial path, and with the
+// removed words computed only for the columns the sweep reaches (it stops at max_keep kept boxes: ~35 of the 167 blocks of a
+// 10 688-candidate image; the eager form above ORs every kept row into ALL later columns -- ten times the loads).  The mask of
+// such an image is 14 MB, i.e. every request is a memory-side access of a few microseconds -- longer than a phase -- so every
+// request is made TWO phases before its use.  Column c gets
+//   * the rows kept in blocks <= c - 4 from the 15 worker waves: requested in phase c - 3 (one word per kept row, list in LDS), folded
+//     into remv[c] in phase c - 1;
+//   * the rows kept in blocks c - 3, c - 2 and c - 1 from the resolver wave itself: every row's words of the next THREE columns are
+//     requested next to its diagonal word two phases ahead, and the kept rows' words are OR-ed out of the lanes (c - 3, c - 2: into
+//     remv[c]; c - 1: kept in a register for the next phase).
+struct NmsRowWords { uint64_t d, c1, c2, c3; };
+__global__ __launch_bounds__(1024) void nms_sweep_batched_kernel(const uint64_t* __restrict__ mask_all, const float* __restrict__ scores_all,
+                                                                 const int32_t* __restrict__ n_valid, int K, int nb, int max_keep,
+                                                                 int32_t* __restrict__ keep_idx_all, int cap, int32_t* __restrict__ num_keep) {
+    extern __shared__ uint64_t remv[];  // [nb], then the kept rows in keep order, int [K]
+    int* kept_list = reinterpret_cast<int*>(remv + nb);
+    __shared__ int total2[2], done;
+    __shared__ float tie_score;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int n = min(n_valid[b], K);
+    const int nbv = (n + 63) / 64;
+    const uint64_t* mask = mask_all + (int64_t)b * K * nb;
+    const float* scores = scores_all ? scores_all + (int64_t)b * K : nullptr;
+    int32_t* keep_idx = keep_idx_all + (int64_t)b * cap;
+    for (int i = tid; i < nb; i += blockDim.x) remv[i] = 0;
+    for (int i = tid; i < cap; i += blockDim.x) keep_idx[i] = -1;
+    if (tid == 0) { total2[0] = total2[1] = 0; done = 0; tie_score = 0.f; }
+    __syncthreads();
+    auto row_words = [&](int blk) {                  // resolver lane: row 64 blk + tid
+        NmsRowWords w = {0ull, 0ull, 0ull, 0ull};
+        const int r = 64 * blk + tid;
+        if (blk < nbv && r < n) {
+            const uint64_t* p = mask + (int64_t)r * nb + blk;
+            w.d = p[0];
+            if (blk + 1 < nbv) w.c1 = p[1];
+            if (blk + 2 < nbv) w.c2 = p[2];
+            if (blk + 3 < nbv) w.c3 = p[3];
+        }
+        return w;
+    };
+    NmsRowWords w0 = {0ull, 0ull, 0ull, 0ull}, w1 = w0;     // this block's and the next block's words
+    if (tid < 64) { w0 = row_words(0); w1 = row_words(1); }
+    uint64_t add = 0;
+    const int nworkers = blockDim.x - 64, wid = tid - 64;
+    uint64_t preA[NMS_PRE], preB[NMS_PRE];                  // requested in the previous phase / two phases ago
+#pragma unroll
+    for (int q = 0; q < NMS_PRE; ++q) preA[q] = preB[q] = 0;
+    int total_end = 0;
+    for (int blk = 0; blk < nbv; ++blk) {
+        const int cur = blk & 1;
+        const int tot = total2[cur ^ 1];               // kept in the blocks before this one (written in the previous phase)
+        if (tid < 64) {
+            const NmsRowWords w = w0;
+            w0 = w1;
+            w1 = row_words(blk + 2);
+            const int cnt = min(64, n - 64 * blk);
+            const uint64_t vbits = cnt == 64 ? ~0ull : ((1ull << cnt) - 1ull);
+            uint64_t alive = uniform64(~(remv[blk] | add) & vbits);
+            float tie = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, tie_score)));
+            // the serial part is scalar only: find-first-set, one diagonal word out of its lane, two bit operations per kept box
+            int k = 0, stop = 0;
+            uint64_t keptbits = 0;
+            while (alive) {
+                const int j = __builtin_ctzll(alive);
+                if (max_keep > 0 && tot + k >= max_keep) {
+                    // quota reached: only boxes tied with the max_keep-th kept score are still eligible
+                    // (the reference keeps every survivor with score >= the k-th score, centernet.py:727-731)
+                    if (!scores || scores[64 * blk + j] != tie) { stop = 1; break; }
+                }
+                ++k;
+                keptbits |= 1ull << j;
+                if (max_keep > 0 && scores && tot + k == max_keep) tie = scores[64 * blk + j];
+                alive &= ~(readlane64(w.d, j) | (1ull << j));
+            }
+            if (max_keep > 0 && !scores && tot + k >= max_keep) stop = 1;
+            const bool kept = (keptbits >> tid) & 1ull;
+            if (kept) {                                                  // lane = box: its rank among the kept ones of the block
+                const int pos = tot + __popcll(keptbits & ((1ull << tid) - 1ull));
+                kept_list[pos] = 64 * blk + tid;
+                if (pos < cap) keep_idx[pos] = 64 * blk + tid;
+            }
+            uint64_t a1 = kept ? w.c1 : 0ull, a2 = kept ? w.c2 : 0ull, a3 = kept ? w.c3 : 0ull;   // what the kept rows remove further on
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                a1 |= ((uint64_t)__shfl_xor((uint32_t)(a1 >> 32), o) << 32) | __shfl_xor((uint32_t)a1, o);
+                a2 |= ((uint64_t)__shfl_xor((uint32_t)(a2 >> 32), o) << 32) | __shfl_xor((uint32_t)a2, o);
+                a3 |= ((uint64_t)__shfl_xor((uint32_t)(a3 >> 32), o) << 32) | __shfl_xor((uint32_t)a3, o);
+            }
+            add = a1;
+            if (tid == 0) {
+                if (a2 && blk + 2 < nbv) atomicOr((unsigned long long*)&remv[blk + 2], (unsigned long long)a2);
+                if (a3 && blk + 3 < nbv) atomicOr((unsigned long long*)&remv[blk + 3], (unsigned long long)a3);
+                total2[cur] = tot + k;
+                done = stop;
+                tie_score = tie;
+            }
+        } else {
+            // (a) fold what was requested two phases ago: column blk + 1, rows kept in blocks <= blk - 3
+            uint64_t acc = 0;
+#pragma unroll
+            for (int q = 0; q < NMS_PRE; ++q) { acc |= preB[q]; preB[q] = preA[q]; }
+            if (acc) atomicOr((unsigned long long*)&remv[blk + 1], (unsigned long long)acc);
+            // (b) request column blk + 3 for the rows kept in blocks <= blk - 1 (`tot` of them)
+            const int col = blk + 3;
+#pragma unroll
+            for (int q = 0; q < NMS_PRE; ++q) {
+                const int e = wid + q * nworkers;
+                preA[q] = (col < nbv && e < tot) ? mask[(int64_t)kept_list[e] * nb + col] : 0ull;
+            }
+            if (col < nbv && tot > NMS_PRE * nworkers) {                 // more kept rows than the lanes hold in flight (no quota): the rest now
+                uint64_t more = 0;
+                for (int e = wid + NMS_PRE * nworkers; e < tot; e += nworkers) more |= mask[(int64_t)kept_list[e] * nb + col];
+                if (more) atomicOr((unsigned long long*)&remv[col], (unsigned long long)more);
+            }
+        }
+        // LDS-only barrier: __syncthreads() would also wait for the global requests in flight (s_waitcnt vmcnt(0)) -- they are made
+        // precisely to be waited for two phases later; everything the phases exchange (removed words, kept list, counters) lives
+        // in LDS, the mask is read-only and keep_idx write-only
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        total_end = total2[cur];
+        if (done) break;
+    }
+    if (tid == 0) num_keep[b] = total_end < cap ? total_end : cap;
+}
+
 extern "C" int64_t dgx_nms_batched_workspace_words(int B, int K) {
     return (B <= 0 || K <= 0) ? 0 : (int64_t)B * K * ((K + 63) / 64);
 }
@@ -258,8 +385,19 @@ extern "C" int dgx_nms_batched(const float* boxes, const float* scores, const in
     if ((size_t)nb * 8 > 60000 || B > 65535) return DGX_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(nms_mask_batched_kernel, dim3(nb, nb, B), dim3(64), 0, st, boxes, n_valid, K, iou_thr, nb, mask);
-    hipLaunchKernelGGL(nms_sweep_batched_kernel, dim3(B), dim3(1024), (size_t)nb * 8, st, mask, scores, n_valid, K, nb, max_keep,
-                       keep_idx, cap, num_keep);
+    const size_t sm = (size_t)nb * 8 + (size_t)K * 4 + 8;
+    if (sm > 150 * 1024) {                          // K > ~36 000: the kept list does not fit LDS -- the eager form
+        hipLaunchKernelGGL(nms_sweep_batched_global_kernel, dim3(B), dim3(1024), (size_t)nb * 8, st, mask, scores, n_valid, K, nb, max_keep,
+                           keep_idx, cap, num_keep);
+        DGX_LAUNCH_CHECK();
+        return DGX_OK;
+    }
+    static bool once = false;
+    if (!once) {
+        (void)hipFuncSetAttribute((const void*)nms_sweep_batched_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        once = true;
+    }
+    hipLaunchKernelGGL(nms_sweep_batched_kernel, dim3(B), dim3(1024), sm, st, mask, scores, n_valid, K, nb, max_keep, keep_idx, cap, num_keep);
     DGX_LAUNCH_CHECK();
     return DGX_OK;
 }

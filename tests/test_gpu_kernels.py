@@ -329,6 +329,34 @@ def test_nms_batched_device_counts_bit_exact(max_keep):
         assert bool((keep_idx[b, n:] == -1).all())
 
 
+@pytest.mark.parametrize("spread,max_keep", [(4000.0, 0), (300.0, 0), (300.0, 600), (900.0, 2000)])
+def test_nms_batched_sweep_pipeline_long_lists(spread, max_keep):
+    """The pipelined sweep over many 64-box blocks (67 here): sparse boxes -- nearly everything kept, more kept rows than the worker
+    lanes hold in flight, so the overflow path runs -- and dense ones -- suppression chains reaching one, two, three and more blocks
+    ahead, i.e. every route a removed bit can take (resolver registers, its two deferred words, the workers' column requests) --
+    against the oracle's sequential NMS, with and without the quota."""
+    g = torch.Generator().manual_seed(int(spread) + max_keep)
+    B, K = 2, 4288
+    nv = [4288, 4100]
+    xy = torch.rand(B, K, 2, generator=g) * spread
+    wh = torch.rand(B, K, 2, generator=g) * 60 + 4
+    boxes = torch.cat([xy, xy + wh], -1)
+    scores, order = torch.sort(torch.rand(B, K, generator=g), dim=1, descending=True, stable=True)
+    boxes = torch.gather(boxes, 1, order[:, :, None].expand(-1, -1, 4))
+    keep_idx, num_keep = la.nms_batched_sorted(boxes.to(DEV), scores.to(DEV), torch.tensor(nv, dtype=torch.int32, device=DEV), 0.5,
+                                               max_keep=max_keep, cap=K if max_keep == 0 else max_keep + 64)
+    for b in range(B):
+        ref = OR.nms(boxes[b, :nv[b]], scores[b, :nv[b]], 0.5).tolist()
+        if spread >= 4000.0:
+            assert len(ref) > 3 * 960                       # the overflow path is really taken
+        if max_keep and len(ref) > max_keep:
+            kth = scores[b, ref[max_keep - 1]]
+            ref = [i for i in ref if scores[b, i] >= kth]
+        n = int(num_keep[b])
+        assert n == len(ref)
+        assert keep_idx[b, :n].cpu().tolist() == ref
+
+
 def test_iou_match_bit_exact(golden):
     g = golden("roi_match")
     gt, pr = T(g["gt"]), T(g["proposals"])

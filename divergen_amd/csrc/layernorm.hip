@@ -147,51 +147,65 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const DT* __rest
 #pragma unroll
         for (int k = 0; k < 4; ++k) dg[j][k] = db[j][k] = 0.f;
     const float4* g4 = reinterpret_cast<const float4*>(gamma);
-    for (int64_t tok = wave; tok < T; tok += nwaves) {
-        const int64_t drow = m.ws ? win_dst(m, tok) : tok;
-        const DT* dyr = dy + drow * C;
-        const XT* xr = x + tok * C;
-        const float mu = mean[tok], rs = rstd[tok];
-        float xh[NJ][4], gv[NJ][4];
-        float s1 = 0.f, s2 = 0.f;
+    // two rows per trip: both rows' loads are in flight before the first row's reductions (T / waves = 2 rows per wave at
+    // Swin-L stage 2: one memory latency per launch instead of two on a 16 us kernel)
+    for (int64_t tok0 = wave; tok0 < T; tok0 += 2 * nwaves) {
+        float xh[2][NJ][4], gv[2][NJ][4], s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f}, rsv[2] = {0.f, 0.f};
+        int64_t toks[2] = {tok0, tok0 + nwaves};
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int i = lane + 64 * j;
-            if (i < C / 4) {
-                const float4 v = ld4<XT>(xr, i), g = g4[i];
-                const float4 d4 = ld4<DT>(dyr, i);
-                const float dv[4] = {d4.x, d4.y, d4.z, d4.w};
-                const float xv[4] = {v.x, v.y, v.z, v.w}, gg[4] = {g.x, g.y, g.z, g.w};
+        for (int u = 0; u < 2; ++u) {
+            const int64_t tok = toks[u];
+            if (tok >= T) continue;
+            const int64_t drow = m.ws ? win_dst(m, tok) : tok;
+            const DT* dyr = dy + drow * C;
+            const XT* xr = x + tok * C;
+            const float mu = mean[tok], rs = rstd[tok];
+            rsv[u] = rs;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    xh[j][k] = (xv[k] - mu) * rs;
-                    gv[j][k] = dv[k] * gg[k];
-                    s1 += gv[j][k];
-                    s2 += gv[j][k] * xh[j][k];
-                    dg[j][k] += dv[k] * xh[j][k];
-                    db[j][k] += dv[k];
+            for (int j = 0; j < NJ; ++j) {
+                const int i = lane + 64 * j;
+                if (i < C / 4) {
+                    const float4 v = ld4<XT>(xr, i), g = g4[i];
+                    const float4 d4 = ld4<DT>(dyr, i);
+                    const float dv[4] = {d4.x, d4.y, d4.z, d4.w};
+                    const float xv[4] = {v.x, v.y, v.z, v.w}, gg[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        xh[u][j][k] = (xv[k] - mu) * rs;
+                        gv[u][j][k] = dv[k] * gg[k];
+                        s1[u] += gv[u][j][k];
+                        s2[u] += gv[u][j][k] * xh[u][j][k];
+                        dg[j][k] += dv[k] * xh[u][j][k];
+                        db[j][k] += dv[k];
+                    }
                 }
             }
         }
-        s1 = wave_sum(s1) / (float)C;
-        s2 = wave_sum(s2) / (float)C;
-        XT* dxr = dx + tok * C;
-        const XT* drr = dres ? dres + tok * C : nullptr;   // gradient arriving on the residual branch (may alias dx)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int i = lane + 64 * j;
-            if (i < C / 4) {
-                float4 o = make_float4(rs * (gv[j][0] - s1 - xh[j][0] * s2), rs * (gv[j][1] - s1 - xh[j][1] * s2),
-                                       rs * (gv[j][2] - s1 - xh[j][2] * s2), rs * (gv[j][3] - s1 - xh[j][3] * s2));
-                if (drr) {
-                    const float4 a = ld4<XT>(drr, i);
-                    o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+        for (int u = 0; u < 2; ++u) {
+            const int64_t tok = toks[u];
+            if (tok >= T) continue;
+            const float a1 = wave_sum(s1[u]) / (float)C, a2 = wave_sum(s2[u]) / (float)C, rs = rsv[u];
+            XT* dxr = dx + tok * C;
+            const XT* drr = dres ? dres + tok * C : nullptr;   // gradient arriving on the residual branch (may alias dx)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int i = lane + 64 * j;
+                if (i < C / 4) {
+                    float4 o = make_float4(rs * (gv[u][j][0] - a1 - xh[u][j][0] * a2), rs * (gv[u][j][1] - a1 - xh[u][j][1] * a2),
+                                           rs * (gv[u][j][2] - a1 - xh[u][j][2] * a2), rs * (gv[u][j][3] - a1 - xh[u][j][3] * a2));
+                    if (drr) {
+                        const float4 a = ld4<XT>(drr, i);
+                        o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+                    }
+                    st4<XT>(dxr, i, o);
                 }
-                st4<XT>(dxr, i, o);
             }
         }
     }
-    // block partials: the 4 waves fold into one LDS row in turn -> one row of `part` per block: [block][2][C]
+    // block partials: the 8 waves fold into one LDS row in turn -> one row of `part` per block: [block][2][C]
+    // (tried: every wave into its own LDS row + one barrier -- 49 KB of LDS per workgroup cost more occupancy than the seven barriers:
+    // 16.1 -> 22.3 us)
     for (int turn = 0; turn < LNB_WAVES; ++turn) {
         if (w == turn) {
 #pragma unroll

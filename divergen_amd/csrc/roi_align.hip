@@ -8,6 +8,7 @@
 // Backward scatters with hardware fp32 atomics into an fp32 (N,H,W,C) gradient.
 // (The GT-mask crop keeps the per-sample form: its thresholded output must be bit-exact.)
 #include "dgx_common.h"
+#include <stdlib.h>
 
 #define MAX_LEVELS 4
 struct PoolLevels {
@@ -305,9 +306,9 @@ __device__ __forceinline__ void gather_axis_rows(float* w, int nw, int i, float 
 
 __device__ __forceinline__ int clamp_bin(float v, int hi) { return (int)fminf(fmaxf(v, 0.0f), (float)hi); }
 
-template <typename T>
+template <typename T, int TH>
 __global__ __launch_bounds__(256) void roi_pool_bwd_gather_kernel(GatherP P, const float* __restrict__ rois, const T* __restrict__ go) {
-    __shared__ __attribute__((aligned(16))) float WY[GT_QB][GT_PMAX][GT_TH];
+    __shared__ __attribute__((aligned(16))) float WY[GT_QB][GT_PMAX][TH];
     __shared__ float WX[GT_QB][GT_PMAX][GT_TWMAX];
     __shared__ int list[256];
     __shared__ int wcount[4];
@@ -321,12 +322,12 @@ __global__ __launch_bounds__(256) void roi_pool_bwd_gather_kernel(GatherP P, con
     const int C = P.C, CV = C >> 3, TW = 256 / CV, ph = P.ph, pw = P.pw, bins = ph * pw;
     const int n = local / (txn * tyn);
     local -= n * txn * tyn;
-    const int y0 = (local / txn) * GT_TH, x0 = (local % txn) * TW;
+    const int y0 = (local / txn) * TH, x0 = (local % txn) * TW;
     const int cv = tid % CV, tx = tid / CV;
     const float scale = P.scale[l];
-    float acc[GT_TH][8];
+    float acc[TH][8];
 #pragma unroll
-    for (int a = 0; a < GT_TH; ++a)
+    for (int a = 0; a < TH; ++a)
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[a][e] = 0.0f;
 
@@ -339,7 +340,7 @@ __global__ __launch_bounds__(256) void roi_pool_bwd_gather_kernel(GatherP P, con
             if ((int)roi[0] == n && lvl == l) {
                 const RoiGeom G = roi_geom(roi, scale, ph, pw, P.sampling_ratio, P.aligned != 0);
                 // a sample at y weighs rows floor(y) and floor(y)+1 (after clamping into the map): rows within [y-1, y+1]
-                hit = G.gh > 0 && G.gw > 0 && G.sh - 1.0f <= (float)(y0 + GT_TH - 1) && G.sh + G.bin_h * ph + 1.0f >= (float)y0 &&
+                hit = G.gh > 0 && G.gw > 0 && G.sh - 1.0f <= (float)(y0 + TH - 1) && G.sh + G.bin_h * ph + 1.0f >= (float)y0 &&
                       G.sw - 1.0f <= (float)(x0 + TW - 1) && G.sw + G.bin_w * pw + 1.0f >= (float)x0;
             }
         }
@@ -360,7 +361,7 @@ __global__ __launch_bounds__(256) void roi_pool_bwd_gather_kernel(GatherP P, con
                     const int rr = list[q0 + q];
                     const RoiGeom G = roi_geom(rois + 5 * (int64_t)rr, scale, ph, pw, P.sampling_ratio, P.aligned != 0);
                     if (t5 < 16) {
-                        if (t5 < ph) gather_axis_rows(&WY[q][t5][0], GT_TH, t5, G.sh, G.bin_h, G.gh, H, y0);
+                        if (t5 < ph) gather_axis_rows(&WY[q][t5][0], TH, t5, G.sh, G.bin_h, G.gh, H, y0);
                     } else if (t5 - 16 < pw) {
                         float* w = &WX[q][t5 - 16][0];
                         gather_axis_rows(w, TW, t5 - 16, G.sw, G.bin_w, G.gw, W, x0);
@@ -372,7 +373,7 @@ __global__ __launch_bounds__(256) void roi_pool_bwd_gather_kernel(GatherP P, con
                         mt.i_lo = 0; mt.i_hi = ph;
                         if (G.bin_h > 0.0f) {   // bins whose interval meets [y0 - 1, y0 + TH], one bin of slack either side
                             mt.i_lo = clamp_bin(floorf(((float)(y0 - 1) - G.sh) / G.bin_h) - 1.0f, ph);
-                            mt.i_hi = clamp_bin(floorf(((float)(y0 + GT_TH) - G.sh) / G.bin_h) + 2.0f, ph);
+                            mt.i_hi = clamp_bin(floorf(((float)(y0 + TH) - G.sh) / G.bin_h) + 2.0f, ph);
                         }
                         meta[q] = mt;
                     }
@@ -389,11 +390,15 @@ __global__ __launch_bounds__(256) void roi_pool_bwd_gather_kernel(GatherP P, con
                 }
                 const T* gr = go + (int64_t)mt.r * bins * C + 8 * cv;
                 for (int i = mt.i_lo; i < mt.i_hi; ++i) {
-                    const f32x4 wa = *reinterpret_cast<const f32x4*>(&WY[q][i][0]), wb = *reinterpret_cast<const f32x4*>(&WY[q][i][4]);
-                    const float wy[8] = {wa[0], wa[1], wa[2], wa[3], wb[0], wb[1], wb[2], wb[3]};
+                    float wy[TH];
+#pragma unroll
+                    for (int a4 = 0; a4 < TH; a4 += 4) {
+                        const f32x4 wv = *reinterpret_cast<const f32x4*>(&WY[q][i][a4]);
+                        wy[a4] = wv[0]; wy[a4 + 1] = wv[1]; wy[a4 + 2] = wv[2]; wy[a4 + 3] = wv[3];
+                    }
                     bool any = false;
 #pragma unroll
-                    for (int a = 0; a < 8; ++a) any = any || wy[a] != 0.0f;
+                    for (int a = 0; a < TH; ++a) any = any || wy[a] != 0.0f;
                     if (!any) continue;
                     float gx[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                     const T* gi = gr + (int64_t)i * pw * C;
@@ -412,7 +417,7 @@ __global__ __launch_bounds__(256) void roi_pool_bwd_gather_kernel(GatherP P, con
                             }
                     }
 #pragma unroll
-                    for (int a = 0; a < 8; ++a)
+                    for (int a = 0; a < TH; ++a)
 #pragma unroll
                         for (int e = 0; e < 8; ++e) acc[a][e] += wy[a] * gx[e];
                 }
@@ -424,7 +429,7 @@ __global__ __launch_bounds__(256) void roi_pool_bwd_gather_kernel(GatherP P, con
     const int x = x0 + tx;
     if (x < W) {
 #pragma unroll
-        for (int a = 0; a < GT_TH; ++a)
+        for (int a = 0; a < TH; ++a)
             if (y0 + a < H) Vec8<T>::store(ob + ((int64_t)(y0 + a) * W + x) * C, acc[a]);
     }
 }
@@ -438,21 +443,35 @@ static int launch_gather(GatherP& P, const float* rois, const void* go, int dtyp
         return DGX_ERR_UNSUPPORTED;
     if (((uintptr_t)go & 15) != 0) return DGX_ERR_UNSUPPORTED;
     const int TW = 256 / (C >> 3);
+    // tile height: 8 rows, or 4 when that is what it takes to give every CU a tile (a tile's workgroup walks the RoIs that reach it
+    // one after the other: with the RoI heads' three levels at 1024^2 x 2 images the 32 tiles of the coarsest level take most of the
+    // boxes of an untrained model each, while 650 small-level tiles finish early -- 4-row tiles halve the longest walk's work)
+    int th = GT_TH;
+    {
+        int64_t t8 = 0;
+        for (int l = 0; l < P.num_levels; ++l) t8 += (int64_t)P.N * ((P.W[l] + TW - 1) / TW) * ((P.H[l] + 7) / 8);
+        static const int force = getenv("DGX_ROI_BWD_TH") ? atoi(getenv("DGX_ROI_BWD_TH")) : 0;
+        if (force == 4 || force == 8) th = force;
+        else if (t8 < 4 * 256) th = 4;
+    }
     int total = 0;
     for (int l = 0; l < P.num_levels; ++l) {
         if (!P.out[l] || ((uintptr_t)P.out[l] & 15)) return P.out[l] ? DGX_ERR_UNSUPPORTED : DGX_ERR_BAD_ARG;
         P.tile0[l] = total;
         P.tiles_x[l] = (P.W[l] + TW - 1) / TW;
-        P.tiles_y[l] = (P.H[l] + GT_TH - 1) / GT_TH;
+        P.tiles_y[l] = (P.H[l] + th - 1) / th;
         total += P.N * P.tiles_x[l] * P.tiles_y[l];
     }
     P.tile0[P.num_levels] = total;
     P.total = total;
     if (total <= 0) return DGX_OK;
-    if (dtype == DGX_BF16)
-        hipLaunchKernelGGL((roi_pool_bwd_gather_kernel<uint16_t>), dim3(total), dim3(256), 0, (hipStream_t)stream, P, rois, (const uint16_t*)go);
-    else
-        hipLaunchKernelGGL((roi_pool_bwd_gather_kernel<float>), dim3(total), dim3(256), 0, (hipStream_t)stream, P, rois, (const float*)go);
+    if (dtype == DGX_BF16) {
+        if (th == 4) hipLaunchKernelGGL((roi_pool_bwd_gather_kernel<uint16_t, 4>), dim3(total), dim3(256), 0, (hipStream_t)stream, P, rois, (const uint16_t*)go);
+        else hipLaunchKernelGGL((roi_pool_bwd_gather_kernel<uint16_t, 8>), dim3(total), dim3(256), 0, (hipStream_t)stream, P, rois, (const uint16_t*)go);
+    } else {
+        if (th == 4) hipLaunchKernelGGL((roi_pool_bwd_gather_kernel<float, 4>), dim3(total), dim3(256), 0, (hipStream_t)stream, P, rois, (const float*)go);
+        else hipLaunchKernelGGL((roi_pool_bwd_gather_kernel<float, 8>), dim3(total), dim3(256), 0, (hipStream_t)stream, P, rois, (const float*)go);
+    }
     DGX_LAUNCH_CHECK();
     return DGX_OK;
 }

@@ -56,18 +56,26 @@ __device__ __forceinline__ void gn_apply_body(const uint16_t* __restrict__ x, co
                                                        uint16_t* __restrict__ y, int HW, int C, int G, int S, float eps, int relu, int bx, int by, int gdx) {
     __shared__ float mu_s[256], rs_s[256];
     const int n = by;
-    for (int g = threadIdx.x; g < G; g += 256) {
-        const int ng = n * G + g;
-        const float x0 = bf2f(x[(int64_t)n * HW * C + 8 * g]);
+    // eight lanes per group fold the slab partials (lane u: slabs u, u + 8, ..; then across the eight by shuffles) -- with one lane per
+    // group this was a serial chain of 2 S dependent loads in front of every workgroup's work
+    for (int g0 = 0; g0 < G; g0 += 32) {
+        const int g = g0 + (threadIdx.x >> 3), u = threadIdx.x & 7;
         float a = 0.f, q = 0.f;
-        for (int s = 0; s < S; ++s) { a += part[((int64_t)ng * S + s) * 2]; q += part[((int64_t)ng * S + s) * 2 + 1]; }
-        const float m = (float)HW * 8.0f;
-        const float md = a / m;
-        const float var = fmaxf(q / m - md * md, 0.0f);
-        const float mu = x0 + md, rs = rsqrtf(var + eps);
-        mu_s[g] = mu;
-        rs_s[g] = rs;
-        if (bx == 0) { mean[ng] = mu; rstd[ng] = rs; }
+        const int ng = n * G + (g < G ? g : 0);
+        if (g < G)
+            for (int s = u; s < S; s += 8) { a += part[((int64_t)ng * S + s) * 2]; q += part[((int64_t)ng * S + s) * 2 + 1]; }
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) { a += __shfl_xor(a, o); q += __shfl_xor(q, o); }
+        if (g < G && u == 0) {
+            const float x0 = bf2f(x[(int64_t)n * HW * C + 8 * g]);
+            const float m = (float)HW * 8.0f;
+            const float md = a / m;
+            const float var = fmaxf(q / m - md * md, 0.0f);
+            const float mu = x0 + md, rs = rsqrtf(var + eps);
+            mu_s[g] = mu;
+            rs_s[g] = rs;
+            if (bx == 0) { mean[ng] = mu; rstd[ng] = rs; }
+        }
     }
     __syncthreads();
     const int64_t per_n = (int64_t)HW * G;
@@ -132,6 +140,77 @@ __device__ __forceinline__ void gn_bwd_reduce_body(const uint16_t* __restrict__ 
     }
 }
 
+// ---- G = 32 (C = 256: every GroupNorm of the shipped heads): the two reduction passes PIXEL-major.  The forms above give a
+// workgroup one (sample, group): 16 bytes out of every 512-byte pixel row -- each 128-byte line is fetched by eight workgroups at
+// different times (bwd reduce: 44 MB in 58 us).  Here a workgroup owns a slab of whole pixels of one sample: lane t reads group
+// t & 31 of pixel t >> 5 (a wave = two whole rows, 1 KB contiguous), keeps its sums in registers, and the eight lanes of a group
+// (t, t + 32, ..: lane pairs through a shuffle, waves through LDS) fold into the same [n*G + g][slab] partials as before
+// (58 -> 33 us, statistics pass 27 -> 14 us).
+constexpr int GN_RG = 32;
+__device__ __forceinline__ void gn_fold32(float v, int k, float (*red)[GN_RG][18]) {   // value k of this lane's group -> red[wave][g][k]
+    v += __shfl_xor(v, 32);
+    if ((threadIdx.x & 63) < 32) red[threadIdx.x >> 6][threadIdx.x & 31][k] = v;
+}
+__device__ __forceinline__ void gn_stats_rows_body(const uint16_t* __restrict__ x, float* __restrict__ part, int HW, int C, int S, int s,
+                                                   int n) {
+    __shared__ float red[4][GN_RG][18];
+    const int g = threadIdx.x & 31, j = threadIdx.x >> 5;
+    const uint16_t* base = x + (int64_t)n * HW * C + 8 * g;
+    const float x0 = bf2f(base[0]);
+    const int per = (HW + S - 1) / S, p0 = s * per, p1 = min(HW, p0 + per);
+    float a = 0.f, q = 0.f;
+    for (int p = p0 + j; p < p1; p += 8) {
+        float v[8];
+        unpack8(*reinterpret_cast<const u32x4*>(base + (int64_t)p * C), v);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const float d = v[i] - x0; a += d; q += d * d; }
+    }
+    gn_fold32(a, 0, red);
+    gn_fold32(q, 1, red);
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int gg = threadIdx.x >> 1, k = threadIdx.x & 1;
+        part[(((int64_t)n * GN_RG + gg) * S + s) * 2 + k] = (red[0][gg][k] + red[1][gg][k]) + (red[2][gg][k] + red[3][gg][k]);
+    }
+}
+__device__ __forceinline__ void gn_bwd_reduce_rows_body(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy,
+                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        float* __restrict__ part2, int HW, int C, int relu, int S, int s, int n) {
+    __shared__ float red[4][GN_RG][18];
+    const int g = threadIdx.x & 31, j = threadIdx.x >> 5;
+    const int64_t off = (int64_t)n * HW * C + 8 * g;
+    const float mu = mean[n * GN_RG + g], rs = rstd[n * GN_RG + g];
+    float gm[8], bt[8], dg[8], db[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { gm[k] = gamma[8 * g + k]; bt[k] = beta[8 * g + k]; dg[k] = db[k] = 0.f; }
+    float s1 = 0.f, s2 = 0.f;
+    const int per = (HW + S - 1) / S, p0 = s * per, p1 = min(HW, p0 + per);
+    for (int p = p0 + j; p < p1; p += 8) {
+        float v[8], d[8];
+        unpack8(*reinterpret_cast<const u32x4*>(x + off + (int64_t)p * C), v);
+        unpack8(*reinterpret_cast<const u32x4*>(dy + off + (int64_t)p * C), d);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float xh = (v[k] - mu) * rs;
+            const float dh = (relu && !(xh * gm[k] + bt[k] > 0.f)) ? 0.f : d[k];
+            dg[k] += dh * xh;
+            db[k] += dh;
+            s1 += dh * gm[k];
+            s2 += dh * gm[k] * xh;
+        }
+    }
+    gn_fold32(s1, 0, red);
+    gn_fold32(s2, 1, red);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { gn_fold32(dg[k], 2 + k, red); gn_fold32(db[k], 10 + k, red); }
+    __syncthreads();
+    for (int e = threadIdx.x; e < GN_RG * 18; e += 256) {
+        const int gg = e / 18, k = e - gg * 18;
+        part2[(((int64_t)n * GN_RG + gg) * S + s) * 18 + k] = (red[0][gg][k] + red[1][gg][k]) + (red[2][gg][k] + red[3][gg][k]);
+    }
+}
+
 // grid (blocks per sample, N): s1 / s2 of the sample's groups folded from the slab partials into LDS, then dx
 __device__ __forceinline__ void gn_bwd_dx_body(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy,
                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -140,14 +219,17 @@ __device__ __forceinline__ void gn_bwd_dx_body(const uint16_t* __restrict__ x, c
                                                         int G, int S, int relu, int bx, int by, int gdx) {
     __shared__ float s1_s[256], s2_s[256];
     const int n = by;
-    for (int g = threadIdx.x; g < G; g += 256) {
+    for (int g0 = 0; g0 < G; g0 += 32) {           // eight lanes per group: see gn_apply_body
+        const int g = g0 + (threadIdx.x >> 3), u = threadIdx.x & 7;
         float a = 0.f, b = 0.f;
-        for (int s = 0; s < S; ++s) {
-            a += part2[(((int64_t)n * G + g) * S + s) * 18];
-            b += part2[(((int64_t)n * G + g) * S + s) * 18 + 1];
-        }
-        s1_s[g] = a;
-        s2_s[g] = b;
+        if (g < G)
+            for (int s = u; s < S; s += 8) {
+                a += part2[(((int64_t)n * G + g) * S + s) * 18];
+                b += part2[(((int64_t)n * G + g) * S + s) * 18 + 1];
+            }
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+        if (g < G && u == 0) { s1_s[g] = a; s2_s[g] = b; }
     }
     __syncthreads();
     const float inv_m = 1.0f / ((float)HW * 8.0f);
@@ -162,9 +244,11 @@ __device__ __forceinline__ void gn_bwd_dx_body(const uint16_t* __restrict__ x, c
         float v[8], d[8], o[8];
         unpack8(xv[i], v);
         unpack8(dv[i], d);
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + 8 * g), g1 = *reinterpret_cast<const f32x4*>(gamma + 8 * g + 4);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + 8 * g), b1 = *reinterpret_cast<const f32x4*>(beta + 8 * g + 4);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const float gm = gamma[8 * g + k], bt = beta[8 * g + k];
+            const float gm = k < 4 ? g0[k] : g1[k - 4], bt = k < 4 ? b0[k] : b1[k - 4];
             const float xh = (v[k] - mu) * rs;
             const float dh = (relu && !(xh * gm + bt > 0.f)) ? 0.f : d[k];
             o[k] = rs * (dh * gm - (s1 + xh * s2) * inv_m);
@@ -173,24 +257,33 @@ __device__ __forceinline__ void gn_bwd_dx_body(const uint16_t* __restrict__ x, c
     }
 }
 
-// dgamma[c] += sum over samples and slabs of part2[n][g][s][2 + k], dbeta likewise (c = 8 g + k); fixed order
-__global__ __launch_bounds__(256) void gn_bwd_param_kernel(const float* __restrict__ part2, float* __restrict__ dgamma,
-                                                           float* __restrict__ dbeta, int N, int C, int G, int S) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    const int g = c >> 3, k = c & 7;
-    float a = 0.f, b = 0.f;
-    for (int n = 0; n < N; ++n) {
-        float an = 0.f, bn = 0.f;
-        for (int s = 0; s < S; ++s) {
-            an += part2[(((int64_t)n * G + g) * S + s) * 18 + 2 + k];
-            bn += part2[(((int64_t)n * G + g) * S + s) * 18 + 10 + k];
-        }
-        a += an;
-        b += bn;
+// dgamma[c] += sum over samples and slabs of part2[n][g][s][2 + k], dbeta likewise (c = 8 g + k); fixed order.  One wave per group:
+// lane l takes the (sample, slab) entries l, l + 64, .. and the 16 sums go through a shuffle tree (one lane per channel walking
+// every entry was 14 us on a single workgroup, 35 us with the 64 slabs per sample of the pixel-major passes)
+__device__ __forceinline__ void gn_param_wave_store(float (&acc)[16], float* __restrict__ dgamma, float* __restrict__ dbeta, int g) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc[k] += __shfl_xor(acc[k], o);
     }
-    dgamma[c] += a;
-    dbeta[c] += b;
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { dgamma[8 * g + k] += acc[k]; dbeta[8 * g + k] += acc[8 + k]; }
+    }
+}
+__global__ __launch_bounds__(64) void gn_bwd_param_kernel(const float* __restrict__ part2, float* __restrict__ dgamma,
+                                                          float* __restrict__ dbeta, int N, int C, int G, int S) {
+    const int g = blockIdx.x;
+    float acc[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+    for (int e = threadIdx.x; e < N * S; e += 64) {
+        const int n = e / S, s = e - n * S;
+        const float* p = part2 + (((int64_t)n * G + g) * S + s) * 18 + 2;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[k] += p[k];
+    }
+    gn_param_wave_store(acc, dgamma, dbeta, g);
 }
 
 // ---- launchable forms: one tensor, or up to GN_MAXI tensors (the FPN levels of one tower layer: same weights, same C / G, different
@@ -204,7 +297,8 @@ struct GnItem {
 struct GnMulti { GnItem it[GN_MAXI]; int n; };
 
 __global__ __launch_bounds__(256) void gn_stats_partial_kernel(const uint16_t* x, float* part, int HW, int C, int G, int S) {
-    gn_stats_partial_body(x, part, HW, C, G, S, blockIdx.x, blockIdx.y);
+    if (G == GN_RG) gn_stats_rows_body(x, part, HW, C, S, blockIdx.x, blockIdx.y);       // grid (slabs, samples)
+    else gn_stats_partial_body(x, part, HW, C, G, S, blockIdx.x, blockIdx.y);
 }
 __global__ __launch_bounds__(256) void gn_apply_kernel(const uint16_t* x, const float* part, float* mean, float* rstd, const float* gamma,
                                                        const float* beta, uint16_t* y, int HW, int C, int G, int S, float eps, int relu) {
@@ -213,7 +307,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const uint16_t* x, const 
 __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const uint16_t* x, const uint16_t* dy, const float* mean, const float* rstd,
                                                             const float* gamma, const float* beta, float* part2, int HW, int C, int G, int relu,
                                                             int S) {
-    gn_bwd_reduce_body(x, dy, mean, rstd, gamma, beta, part2, HW, C, G, relu, S, blockIdx.x, blockIdx.y);
+    if (G == GN_RG) gn_bwd_reduce_rows_body(x, dy, mean, rstd, gamma, beta, part2, HW, C, relu, S, blockIdx.x, blockIdx.y);
+    else gn_bwd_reduce_body(x, dy, mean, rstd, gamma, beta, part2, HW, C, G, relu, S, blockIdx.x, blockIdx.y);
 }
 __global__ __launch_bounds__(256) void gn_bwd_dx_kernel(const uint16_t* x, const uint16_t* dy, const float* mean, const float* rstd,
                                                         const float* gamma, const float* beta, const float* part2, uint16_t* dx, int HW, int C,
@@ -223,6 +318,10 @@ __global__ __launch_bounds__(256) void gn_bwd_dx_kernel(const uint16_t* x, const
 
 __global__ __launch_bounds__(256) void gn_stats_partial_multi_kernel(GnMulti M, int C, int G) {
     const GnItem& t = M.it[blockIdx.z];
+    if (G == GN_RG) {                              // grid (slabs, samples, tensors)
+        if ((int)blockIdx.x < t.S && (int)blockIdx.y < t.N) gn_stats_rows_body(t.x, t.scratch, t.HW, C, t.S, blockIdx.x, blockIdx.y);
+        return;
+    }
     if ((int)blockIdx.x >= t.N * G || (int)blockIdx.y >= t.S) return;
     gn_stats_partial_body(t.x, t.scratch, t.HW, C, G, t.S, blockIdx.x, blockIdx.y);
 }
@@ -234,6 +333,11 @@ __global__ __launch_bounds__(256) void gn_apply_multi_kernel(GnMulti M, const fl
 }
 __global__ __launch_bounds__(256) void gn_bwd_reduce_multi_kernel(GnMulti M, const float* gamma, const float* beta, int C, int G, int relu) {
     const GnItem& t = M.it[blockIdx.z];
+    if (G == GN_RG) {
+        if ((int)blockIdx.x < t.S && (int)blockIdx.y < t.N)
+            gn_bwd_reduce_rows_body(t.x, t.dy, t.mean, t.rstd, gamma, beta, t.scratch + (int64_t)t.N * G * 18, t.HW, C, relu, t.S, blockIdx.x, blockIdx.y);
+        return;
+    }
     if ((int)blockIdx.x >= t.N * G || (int)blockIdx.y >= t.S) return;
     gn_bwd_reduce_body(t.x, t.dy, t.mean, t.rstd, gamma, beta, t.scratch + (int64_t)t.N * G * 18, t.HW, C, G, relu, t.S, blockIdx.x, blockIdx.y);
 }
@@ -243,50 +347,47 @@ __global__ __launch_bounds__(256) void gn_bwd_dx_multi_kernel(GnMulti M, const f
     gn_bwd_dx_body(t.x, t.dy, t.mean, t.rstd, gamma, beta, t.scratch + (int64_t)t.N * G * 18, t.out, t.HW, C, G, t.S, relu, blockIdx.x, blockIdx.y,
                    t.bpn);
 }
-// dgamma[c] += sum over the tensors (in list order), their samples and slabs -- one lane per channel, fixed order
-__global__ __launch_bounds__(256) void gn_bwd_param_multi_kernel(GnMulti M, float* __restrict__ dgamma, float* __restrict__ dbeta, int C, int G) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    const int g = c >> 3, k = c & 7;
-    float a = 0.f, b = 0.f;
+// dgamma[c] += sum over the tensors (in list order), their samples and slabs -- one wave per group, fixed order
+__global__ __launch_bounds__(64) void gn_bwd_param_multi_kernel(GnMulti M, float* __restrict__ dgamma, float* __restrict__ dbeta, int C, int G) {
+    const int g = blockIdx.x;
+    float acc[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[k] = 0.f;
     for (int i = 0; i < M.n; ++i) {
         const GnItem& t = M.it[i];
         const float* part2 = t.scratch + (int64_t)t.N * G * 18;
-        float ai = 0.f, bi = 0.f;
-        for (int n = 0; n < t.N; ++n) {
-            float an = 0.f, bn = 0.f;
-            for (int s = 0; s < t.S; ++s) {
-                an += part2[(((int64_t)n * G + g) * t.S + s) * 18 + 2 + k];
-                bn += part2[(((int64_t)n * G + g) * t.S + s) * 18 + 10 + k];
-            }
-            ai += an;
-            bi += bn;
+        for (int e = threadIdx.x; e < t.N * t.S; e += 64) {
+            const int n = e / t.S, s = e - n * t.S;
+            const float* p = part2 + (((int64_t)n * G + g) * t.S + s) * 18 + 2;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[k] += p[k];
         }
-        a += ai;
-        b += bi;
     }
-    dgamma[c] += a;
-    dbeta[c] += b;
+    gn_param_wave_store(acc, dgamma, dbeta, g);
 }
 
 // pixel slabs per (n, g) so that the two reduction kernels fill the GPU (N*G alone is 64 workgroups for a batch of 2)
-static int gn_slabs(int NG, int HW) {
+static int gn_slabs(int NG, int HW, int G) {
+    if (G == GN_RG) {                              // pixel-major passes: slabs of whole pixels per SAMPLE, >= 128 pixels each
+        const int S = (HW + 127) / 128;
+        return S < 1 ? 1 : (S > 64 ? 64 : S);
+    }
     int S = (1024 + NG - 1) / NG;
     const int mx = (HW + 255) / 256;
     if (S > mx) S = mx;
     return S < 1 ? 1 : (S > 64 ? 64 : S);
 }
 
-extern "C" int64_t dgx_groupnorm_scratch_floats(int N, int HW, int G) { return (int64_t)N * G * (gn_slabs(N * G, HW) * 18 + 18); }
+extern "C" int64_t dgx_groupnorm_scratch_floats(int N, int HW, int G) { return (int64_t)N * G * (gn_slabs(N * G, HW, G) * 18 + 18); }
 
 extern "C" int dgx_groupnorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                                  float* scratch, int N, int HW, int C, int G, float eps, int relu, void* stream) {
     if (N <= 0 || HW <= 0) return DGX_OK;
     if (!x || !gamma || !beta || !y || !mean || !rstd || C != 8 * G) return DGX_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
-    const int S = gn_slabs(N * G, HW);
+    const int S = gn_slabs(N * G, HW, G);
     if (!scratch) return DGX_ERR_BAD_ARG;
-    hipLaunchKernelGGL(gn_stats_partial_kernel, dim3(N * G, S), dim3(256), 0, st, (const uint16_t*)x, scratch, HW, C, G, S);
+    hipLaunchKernelGGL(gn_stats_partial_kernel, G == GN_RG ? dim3(S, N) : dim3(N * G, S), dim3(256), 0, st, (const uint16_t*)x, scratch, HW, C, G, S);
     if (G > 256) return DGX_ERR_UNSUPPORTED;
     const int64_t per_n = (int64_t)HW * G;
     int bpn = (int)((per_n + 255) / 256);
@@ -304,9 +405,9 @@ extern "C" int dgx_groupnorm_bwd(const void* x, const void* dy, const float* mea
     if (N <= 0 || HW <= 0) return DGX_OK;
     if (!x || !dy || !mean || !rstd || !gamma || !beta || !dx || !dgamma || !dbeta || !part || C != 8 * G) return DGX_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
-    const int S = gn_slabs(N * G, HW);
+    const int S = gn_slabs(N * G, HW, G);
     float* part2 = part + (int64_t)N * G * 18;      // scratch layout: [N*G][18] folded, then [N*G][S][18]
-    hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(N * G, S), dim3(256), 0, st, (const uint16_t*)x, (const uint16_t*)dy, mean, rstd, gamma,
+    hipLaunchKernelGGL(gn_bwd_reduce_kernel, G == GN_RG ? dim3(S, N) : dim3(N * G, S), dim3(256), 0, st, (const uint16_t*)x, (const uint16_t*)dy, mean, rstd, gamma,
                        beta, part2, HW, C, G, relu, S);
     if (G > 256) return DGX_ERR_UNSUPPORTED;
     const int64_t per_n = (int64_t)HW * G;
@@ -315,7 +416,7 @@ extern "C" int dgx_groupnorm_bwd(const void* x, const void* dy, const float* mea
     if (bpn > cap) bpn = cap;
     hipLaunchKernelGGL(gn_bwd_dx_kernel, dim3(bpn, N), dim3(256), 0, st, (const uint16_t*)x, (const uint16_t*)dy, mean, rstd, gamma, beta,
                        part2, (uint16_t*)dx, HW, C, G, S, relu);
-    hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((C + 255) / 256), dim3(256), 0, st, part2, dgamma, dbeta, N, C, G, S);
+    hipLaunchKernelGGL(gn_bwd_param_kernel, dim3(G), dim3(64), 0, st, part2, dgamma, dbeta, N, C, G, S);
     DGX_LAUNCH_CHECK();
     return DGX_OK;
 }
@@ -331,7 +432,7 @@ static int gn_fill(GnMulti& M, const dgx_gn_item* items, int n, int G, bool bwd,
         GnItem& t = M.it[i];
         t.x = (const uint16_t*)a.x; t.dy = (const uint16_t*)a.dy; t.out = (uint16_t*)a.out;
         t.mean = a.mean; t.rstd = a.rstd; t.scratch = a.scratch;
-        t.N = a.N; t.HW = a.HW; t.S = gn_slabs(a.N * G, a.HW);
+        t.N = a.N; t.HW = a.HW; t.S = gn_slabs(a.N * G, a.HW, G);
         const int64_t per_n = (int64_t)a.HW * G;
         int bpn = (int)((per_n + 255) / 256);
         const int cap = (4096 + a.N - 1) / a.N;
@@ -354,7 +455,7 @@ extern "C" int dgx_groupnorm_fwd_multi(const dgx_gn_item* items, int n, const fl
     const int rc = gn_fill(M, items, n, G, false, maxNG, maxS, maxN, maxbpn);
     if (rc != DGX_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(gn_stats_partial_multi_kernel, dim3(maxNG, maxS, n), dim3(256), 0, st, M, C, G);
+    hipLaunchKernelGGL(gn_stats_partial_multi_kernel, G == GN_RG ? dim3(maxS, maxN, n) : dim3(maxNG, maxS, n), dim3(256), 0, st, M, C, G);
     hipLaunchKernelGGL(gn_apply_multi_kernel, dim3(maxbpn, maxN, n), dim3(256), 0, st, M, gamma, beta, C, G, eps, relu);
     DGX_LAUNCH_CHECK();
     return DGX_OK;
@@ -369,9 +470,9 @@ extern "C" int dgx_groupnorm_bwd_multi(const dgx_gn_item* items, int n, const fl
     const int rc = gn_fill(M, items, n, G, true, maxNG, maxS, maxN, maxbpn);
     if (rc != DGX_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(gn_bwd_reduce_multi_kernel, dim3(maxNG, maxS, n), dim3(256), 0, st, M, gamma, beta, C, G, relu);
+    hipLaunchKernelGGL(gn_bwd_reduce_multi_kernel, G == GN_RG ? dim3(maxS, maxN, n) : dim3(maxNG, maxS, n), dim3(256), 0, st, M, gamma, beta, C, G, relu);
     hipLaunchKernelGGL(gn_bwd_dx_multi_kernel, dim3(maxbpn, maxN, n), dim3(256), 0, st, M, gamma, beta, C, G, relu);
-    hipLaunchKernelGGL(gn_bwd_param_multi_kernel, dim3((C + 255) / 256), dim3(256), 0, st, M, dgamma, dbeta, C, G);
+    hipLaunchKernelGGL(gn_bwd_param_multi_kernel, dim3(G), dim3(64), 0, st, M, dgamma, dbeta, C, G);
     DGX_LAUNCH_CHECK();
     return DGX_OK;
 }

@@ -309,7 +309,16 @@ __global__ __launch_bounds__(256) void wgrad256_reduce_kernel(Params256 P, int64
         const int64_t e = i - q.red0, n4 = (int64_t)q.Nn * q.Kk / 4;
         const float4* ws = reinterpret_cast<const float4*>(q.ws);
         float4 a = {0.f, 0.f, 0.f, 0.f};
-        for (int s = sub; s < q.S; s += LPQ) {
+        int s = sub;
+        for (; s + 3 * LPQ < q.S; s += 4 * LPQ) {      // four slabs in flight; the additions keep the slab order
+            const float4 v0 = ws[(int64_t)s * n4 + e], v1 = ws[(int64_t)(s + LPQ) * n4 + e], v2 = ws[(int64_t)(s + 2 * LPQ) * n4 + e],
+                         v3 = ws[(int64_t)(s + 3 * LPQ) * n4 + e];
+            a.x += v0.x; a.y += v0.y; a.z += v0.z; a.w += v0.w;
+            a.x += v1.x; a.y += v1.y; a.z += v1.z; a.w += v1.w;
+            a.x += v2.x; a.y += v2.y; a.z += v2.z; a.w += v2.w;
+            a.x += v3.x; a.y += v3.y; a.z += v3.z; a.w += v3.w;
+        }
+        for (; s < q.S; s += LPQ) {
             const float4 v = ws[(int64_t)s * n4 + e];
             a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
         }

@@ -27,7 +27,7 @@ class _BoxStageFn(torch.autograd.Function):
         R, C, wts, grad_scale = cfg
         lib, st, dev = L.lib(), L.stream(), x.device
         Rp = x.shape[0]
-        x2 = x.reshape(Rp, -1)
+        x2 = x.permute(0, 2, 3, 1).reshape(Rp, -1)         # (h, w, c) columns, the order fc1's weight is stored in: a view of the pooler's output
         if x2.dtype != BF16:
             x2 = x2.to(BF16)
         x2 = x2.contiguous()
@@ -72,7 +72,7 @@ class _BoxStageFn(torch.autograd.Function):
             dx = G.gemm_nt(dz1, shadow_t(fc1w))
             if grad_scale != 1.0:
                 dx = dx * grad_scale                                # _ScaleGradient (cascade_rcnn.py:20-28): features only
-            dx = dx.view(xshape)
+            dx = dx.view(xshape[0], xshape[2], xshape[3], xshape[1]).permute(0, 3, 1, 2)
             if xdtype != BF16:
                 dx = dx.to(xdtype)
         # the stage's one grouped launch is the first (and only) writer of all eight gradient segments in a pass: it overwrites

@@ -29,6 +29,39 @@ class FastRCNNConvFCHead(nn.Sequential):
             self._output_size = fc_dim
         for l in self.fcs:
             c2_xavier_fill(l)
+        # The first FC reads the pooled (R, C, S, S) features flattened.  The pooler's output is channels-last in memory, so the
+        # parameter is STORED with its columns in (h, w, c) order: the flattening is then a view (the reference's (c, h, w) order cost
+        # a transposing copy of the (1024, 256, 7, 7) tensor per cascade stage and pass).  State dicts keep the reference's column
+        # order: the two hooks below permute on the way out and in, so checkpoints and goldens load unchanged.
+        self._chw = None
+        if input_shape.height and input_shape.width:
+            self._chw = (int(input_shape.channels), int(input_shape.height), int(input_shape.width))
+            self.fcs[0].weight._dgx_sd_perm = (self._cols_to_chw, self._cols_to_hwc)
+            self._register_state_dict_hook(self._sd_out)
+            self._register_load_state_dict_pre_hook(self._sd_in)
+
+    def _cols_to_chw(self, w):          # stored (O, h*w*c) -> the reference's (O, c*h*w)
+        c, h, w_ = self._chw
+        return w.reshape(w.shape[0], h, w_, c).permute(0, 3, 1, 2).reshape(w.shape[0], -1).contiguous()
+
+    def _cols_to_hwc(self, w):
+        c, h, w_ = self._chw
+        return w.reshape(w.shape[0], c, h, w_).permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous()
+
+    @staticmethod
+    def _sd_out(module, state_dict, prefix, local_metadata):
+        k = prefix + "fc1.weight"
+        if k in state_dict:
+            state_dict[k] = module._cols_to_chw(state_dict[k])
+
+    def _sd_in(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        k = prefix + "fc1.weight"
+        if k in state_dict and tuple(state_dict[k].shape) == tuple(self.fcs[0].weight.shape):
+            state_dict[k] = self._cols_to_hwc(state_dict[k])
+
+    def flatten_rows(self, x):
+        """(R, C, S, S) logical -> (R, S*S*C): a view when the storage is channels-last (the pooler's output)."""
+        return x.permute(0, 2, 3, 1).reshape(x.shape[0], -1) if (x.dim() == 4 and self._chw is not None) else x.flatten(1)
 
     @classmethod
     def from_config(cls, cfg, input_shape):
@@ -38,7 +71,7 @@ class FastRCNNConvFCHead(nn.Sequential):
 
     def forward(self, x):
         for layer in self:
-            x = layer(x)
+            x = self.flatten_rows(x) if isinstance(layer, nn.Flatten) else layer(x)
         return x
 
     @property

@@ -144,7 +144,8 @@ class DeticCascadeROIHeads(nn.Module):
         ret = dict(num_classes=rh.NUM_CLASSES, batch_size_per_image=rh.BATCH_SIZE_PER_IMAGE,
                    positive_fraction=rh.POSITIVE_FRACTION, proposal_append_gt=rh.PROPOSAL_APPEND_GT,
                    box_in_features=in_features,
-                   box_pooler=ROIPooler(bh.POOLER_RESOLUTION, scales, bh.POOLER_SAMPLING_RATIO, bh.POOLER_TYPE),
+                   # channels-last pooled rows: the box heads' first FC keeps its columns in (h, w, c) order (box_head.py)
+                   box_pooler=ROIPooler(bh.POOLER_RESOLUTION, scales, bh.POOLER_SAMPLING_RATIO, bh.POOLER_TYPE, out_nhwc=True),
                    box_heads=heads, box_predictors=preds, cascade_ious=ch.IOUS,
                    mult_proposal_score=bh.MULT_PROPOSAL_SCORE, mask_weight=rh.MASK_WEIGHT,
                    divergen_mask_loss=cfg.MODEL.USE_DIVERGEN_MASK_LOSS and cfg.MODEL.get("USE_XPASTE_MASK_LOSS", True), one_class_per_proposal=rh.ONE_CLASS_PER_PROPOSAL)

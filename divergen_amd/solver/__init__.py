@@ -301,7 +301,9 @@ class FusedAdamWEMA:
     # ---- EMA surface (DG/divergen/ema.py: state_dict / load_state_dict, keys = model state-dict keys)
     def ema_state_dict(self, model):
         out = OrderedDict()
-        view = {n: self.arena.view(self.ema, p, o) for n, o, p in zip(self.arena.names, self.arena.offsets, self.arena.params)}
+        # (parameters stored in another column order than their state-dict form -- the box heads' first FC -- go out permuted)
+        view = {n: (p._dgx_sd_perm[0](self.arena.view(self.ema, p, o)) if hasattr(p, "_dgx_sd_perm") else self.arena.view(self.ema, p, o))
+                for n, o, p in zip(self.arena.names, self.arena.offsets, self.arena.params)}
         for k, v in model.state_dict().items():
             out[k] = view[k] if k in view else v
         return out
@@ -310,7 +312,10 @@ class FusedAdamWEMA:
         for n, o, p in zip(self.arena.names, self.arena.offsets, self.arena.params):
             key = n if n in sd else ("module." + n if "module." + n in sd else None)
             if key is not None:
-                self.arena.view(self.ema, p, o).copy_(sd[key])
+                src = sd[key]
+                if hasattr(p, "_dgx_sd_perm") and tuple(src.shape) == tuple(p.shape):
+                    src = p._dgx_sd_perm[1](src.to(self.ema.device))
+                self.arena.view(self.ema, p, o).copy_(src)
 
 
 class FusedSGDEMA(FusedAdamWEMA):

@@ -25,7 +25,10 @@ def fill_by_name(module, seed, scale):
             v = torch.randn(p.shape, generator=g) * scale
             if p.dim() == 1 and name.endswith("weight"):
                 v = v + 1.0
-            p.copy_(v.to(torch.bfloat16).float())
+            v = v.to(torch.bfloat16).float()
+            if hasattr(p, "_dgx_sd_perm"):      # a parameter stored in another column order than its reference / state-dict form
+                v = p._dgx_sd_perm[1](v)        # (the values are defined in the reference's order)
+            p.copy_(v)
 
 
 def swin_param_shapes(embed_dim, depths, num_heads, ws, out_indices=(1, 2, 3), mlp_ratio=4):

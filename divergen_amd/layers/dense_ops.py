@@ -80,7 +80,12 @@ class _HeadOutputs(torch.autograd.Function):
         d_scale = torch.empty(n, dtype=torch.float32, device=dev)
         L.check(lib.dgx_centernet_head_outputs_bwd(lv, n, C, L.ptr(g_reg), L.ptr(g_hm), L.ptr(d_scale), L.ptr(ws), L.stream()),
                 "dgx_centernet_head_outputs_bwd")
-        return (None,) + tuple(dxs) + tuple(d_scale[i:i + 1] for i in range(n))
+        # the scale gradients go straight into the parameters' arena views (linear_ops.accumulate_grad: None when done in place):
+        # no AccumulateGrad node runs for them -- inside a replayed segment those nodes were born on the capture warm-up's side
+        # stream, and autograd would run (and warn about) their accumulation there, outside the stream the reducer orders itself behind
+        from .linear_ops import accumulate_grad
+        return (None,) + tuple(dxs) + tuple(accumulate_grad(s, lambda i=i: d_scale[i:i + 1]) if ctx.needs_input_grad[1 + n + i] else None
+                                            for i, s in enumerate(scales))
 
 
 def centernet_head_outputs(boths, scales):

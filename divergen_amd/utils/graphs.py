@@ -19,6 +19,7 @@ from ..layers import linear_ops
 from . import prof
 
 ENABLED = os.environ.get("DGX_GRAPH_HEADS", "1") == "1"
+ALIAS_STATIC = os.environ.get("DGX_GRAPH_ALIAS", "1") == "1"     # A/B switch: chained segments share their hand-over buffers
 
 
 class _SignalAfterBackward(torch.autograd.Function):
@@ -51,12 +52,27 @@ class GraphedSegment:
         fn = self._fns.get(key)
         if fn is None:
             self.module.amp = torch.is_autocast_enabled()
-            sample = tuple(t.detach().clone().requires_grad_(t.requires_grad) for t in inputs)
+            # an input that IS another segment's static output (the FPN's levels handed to the tower) becomes this graph's static
+            # input as it stands: same address on every replay, so the replay wrapper's address check skips its input copy
+            sample = tuple((t.detach() if ALIAS_STATIC and getattr(t, "_dgx_static_output", False) else t.detach().clone())
+                           .requires_grad_(t.requires_grad) for t in inputs)
             # capture outside the caller's autocast region (its weight-cast cache cannot be captured); the segment
             # module re-enters autocast itself with the cache off
             before = prof.captured_snapshot() if prof.ON else None
-            with linear_ops.suspend_ready(), torch.autocast("cuda", enabled=False):
-                fn = torch.cuda.make_graphed_callables(self.module, sample, allow_unused_input=True)
+            # make_graphed_callables warms up on one side stream and captures on another: the sample inputs' AccumulateGrad nodes are
+            # born on the first and meet gradients produced on the second, which autograd reports ("AccumulateGrad node's stream does
+            # not match ...").  That is the capture itself; afterwards NO parameter gradient of the model passes through an
+            # AccumulateGrad node (all are written in place into the arena: tools/accum_grad_params.py prints 0 of 408 per step), so
+            # the report is silenced for the capture only and stays armed for the training steps.
+            warn = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+            if warn is not None:
+                warn(False)
+            try:
+                with linear_ops.suspend_ready(), torch.autocast("cuda", enabled=False):
+                    fn = torch.cuda.make_graphed_callables(self.module, sample, allow_unused_input=True)
+            finally:
+                if warn is not None:
+                    warn(True)
             if before is not None:      # heavy launches recorded into the two graphs (forward + backward): credited per replay
                 after = prof.captured_snapshot()
                 self._work[key] = {k: tuple(x - y for x, y in zip(after[k], before[k])) for k in after}
@@ -74,4 +90,8 @@ class GraphedSegment:
             inputs = inputs[:k] + (_SignalAfterBackward.apply(inputs[k], params),) + inputs[k + 1:]
         if prof.ON and key in self._work:
             prof.add_replay(self._work[key])
-        return fn(*inputs)
+        outs = fn(*inputs)
+        for o in outs:
+            if isinstance(o, torch.Tensor):
+                o._dgx_static_output = True
+        return outs

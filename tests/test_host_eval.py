@@ -84,3 +84,33 @@ def test_iou_threshold_sweep_and_area_ranges():
     assert abs(out["AP50"] - 1.0) < 1e-9
     # area ranges: gt areas 200, 400 (category 1) and 100 (category 2) are all "small" (< 32^2); nothing medium / large
     assert out["APm"] == -1.0 and out["APl"] == -1.0 and out["APs"] == out["AP"]
+
+
+def test_rle_iou_by_runs_equals_dense_iou():
+    """The binary-search intersection of run lists (lvis_eval.runs_iou) against the IoU of the decoded bitmaps: random masks incl.
+    empty, full, first-pixel-set and single-run ones (maskApi.c rleIou, iscrowd = 0)."""
+    import numpy as np
+    from divergen_amd.evaluation.lvis_eval import rle_iou
+
+    def enc(m):
+        flat = m.T.reshape(-1)
+        change = np.flatnonzero(flat[1:] != flat[:-1]) + 1
+        counts = np.diff(np.concatenate([[0], change, [flat.size]])).tolist()
+        return {"size": list(m.shape), "counts": ([0] + counts) if flat[0] else counts}
+
+    rng = np.random.default_rng(5)
+    h, w = 23, 31
+    masks = [np.zeros((h, w), bool), np.ones((h, w), bool)]
+    one = np.zeros((h, w), bool)
+    one[3:9, 4:20] = True
+    masks.append(one)
+    for p in (0.05, 0.3, 0.5, 0.9):
+        for _ in range(4):
+            m = rng.random((h, w)) < p
+            m[0, 0] = bool(rng.integers(2))
+            masks.append(m)
+    for a in masks:
+        for b in masks:
+            inter, union = int((a & b).sum()), int((a | b).sum())
+            want = inter / union if union else 0.0
+            assert abs(rle_iou(enc(a), enc(b)) - want) < 1e-15, (a.sum(), b.sum())

@@ -495,6 +495,34 @@ int launch_gemm(GemmP& P, hipStream_t st) {
 }
 }  // namespace
 
+int gemm_lw_launch(GemmP& P, int bm, int bn, hipStream_t st);     // gemm_lw.hip: the loader-wave form
+static int lw_mode() {            // development switch while both forms exist: 0 off, 1 every tile, 2 only where K > 768
+    static const int v = getenv("DGX_GEMM_LW") ? atoi(getenv("DGX_GEMM_LW")) : 0;
+    return v;
+}
+// tiling fields of a bm x bn launch (what launch_gemm<> computes for its instantiation)
+static void plan_tiles(GemmP& P, int bm, int bn) {
+    const int tiles_m = (P.M + bm - 1) / bm;
+    P.tiles_n = (P.N + bn - 1) / bn;
+    P.total = tiles_m * P.tiles_n;
+    const int nt = (P.K + GBK - 1) / GBK;
+    P.splits = choose_splits(P.total, P.K, P.M, P.N, P.ws ? g_ws_bytes_cur : 0);
+    P.kt_per_split = (nt + P.splits - 1) / P.splits;
+    P.splits = (nt + P.kt_per_split - 1) / P.kt_per_split;
+    P.per_xcd = (P.total * P.splits + 7) / 8;
+}
+static int launch_lw(GemmP& P, int bm, int bn, hipStream_t st) {
+    plan_tiles(P, bm, bn);
+    const int rc = gemm_lw_launch(P, bm, bn, st);
+    if (rc != DGX_OK) return rc;
+    if (P.splits > 1) {
+        const int64_t chunks = (int64_t)P.M * (P.N >> 3);
+        const int grid = (int)((chunks + 255) / 256 < 4096 ? (chunks + 255) / 256 : 4096);
+        hipLaunchKernelGGL(gemm_splitk_fold_kernel, dim3(grid), dim3(256), 0, st, P);
+    }
+    DGX_LAUNCH_CHECK();
+    return DGX_OK;
+}
 static int dgx_gemm_dispatch(GemmP& P, hipStream_t st);
 static bool use_two_wg(const GemmP& P) {          // see dgx_gemm_dispatch
     static const int two_wg = getenv("DGX_GEMM_2WG") ? atoi(getenv("DGX_GEMM_2WG")) : 1;
@@ -597,6 +625,7 @@ static int dgx_gemm_dispatch(GemmP& P, hipStream_t st) {
             if (choose_splits(tiles, P.K, P.M, P.N, P.ws ? g_ws_bytes_cur : 0) == 1 || nt < 8 || tiles > 128) return gemm256_launch(P, force, st);
         }
     }
+    if (lw_mode() == 1 || (lw_mode() == 2 && !use_two_wg(P))) return launch_lw(P, tc.bm, tc.bn, st);
     if (tc.bn == 192) {
         // contractions of up to 12 K-tiles (K <= 768: every qkv / proj / fc1 / fc2-input-gradient GEMM of the backbone) spend a third of
         // a tile's time in prologue and read-out: TWO workgroups share a CU there (128 x 192 tiles, 2 stages = 80 KB of LDS, 128
@@ -617,6 +646,22 @@ static int dgx_gemm_dispatch(GemmP& P, hipStream_t st) {
 }
 
 extern "C" int64_t dgx_conv3x3_pad_rows(int N, int H, int W);
+static int launch_lw_grouped(GemmP& P, const int* Ms, int n, int bm, int bn, hipStream_t st) {
+    P.tiles_n = (P.N + bn - 1) / bn;
+    int tot = 0;
+    for (int i = 0; i < n; ++i) {
+        P.grp[i].tile0 = tot;
+        tot += ((Ms[i] + bm - 1) / bm) * P.tiles_n;
+    }
+    P.total = tot;
+    P.splits = 1;
+    P.kt_per_split = (P.K + GBK - 1) / GBK;
+    P.per_xcd = (P.total + 7) / 8;
+    const int rc = gemm_lw_launch(P, bm, bn, st);
+    if (rc != DGX_OK) return rc;
+    DGX_LAUNCH_CHECK();
+    return DGX_OK;
+}
 namespace {
 template <int BM, int BN, int NS, int MINW = 2>
 int launch_gemm_grouped(GemmP& P, const int* Ms, int n, hipStream_t st) {
@@ -694,9 +739,12 @@ extern "C" int dgx_conv3x3_gemm_multi(const dgx_conv_item* items, int n, const v
         // two rounds, 229 tiles of 192 rows = one)
         int t128 = 0, t192 = 0;
         for (int i = 0; i < n; ++i) { t128 += (Ms[i] + 127) / 128; t192 += (Ms[i] + 191) / 192; }
-        if (tile_192x256() && ((t192 + 255) / 256) * 192 < ((t128 + 255) / 256) * 128) return launch_gemm_grouped<192, 256, 2>(P, Ms, n, st);
+        const bool big = tile_192x256() && ((t192 + 255) / 256) * 192 < ((t128 + 255) / 256) * 128;
+        if (lw_mode()) return launch_lw_grouped(P, Ms, n, big ? 192 : 128, 256, st);
+        if (big) return launch_gemm_grouped<192, 256, 2>(P, Ms, n, st);
         return launch_gemm_grouped<128, 256, 3>(P, Ms, n, st);
     }
+    if (lw_mode()) return launch_lw_grouped(P, Ms, n, 128, 128, st);
     return launch_gemm_grouped<128, 128, 4>(P, Ms, n, st);
 }
 

@@ -153,41 +153,58 @@ class BitMasks:
         return BitMasks(torch.cat([m.tensor for m in lst], dim=0))
 
 
-class Instances:
-    """Per-image bag of equal-length fields (instances.py)."""
+def _join_field(values):
+    """One field of several Instances joined along the instance axis: tensors by torch.cat, lists by concatenation, anything
+    else through its own static `cat` (Boxes, BitMasks, ...)."""
+    head = values[0]
+    if torch.is_tensor(head):
+        return torch.cat(values, dim=0)
+    if isinstance(head, list):
+        return [x for part in values for x in part]
+    joiner = getattr(type(head), "cat", None)
+    if joiner is None:
+        raise ValueError("Instances.cat: no way to join fields of type %s" % type(head).__name__)
+    return joiner(values)
 
-    def __init__(self, image_size: Tuple[int, int], **kwargs: Any):
+
+class Instances:
+    """The per-image record of the Detectron2 batched-input contract (D2/structures/instances.py): an image size plus named
+    fields that all have one entry per instance.  Fields are reachable as attributes (`inst.gt_boxes`), through
+    set / get / has / remove, and the record as a whole can be indexed, moved between devices and concatenated."""
+
+    def __init__(self, image_size: Tuple[int, int], **fields: Any):
         object.__setattr__(self, "_image_size", image_size)
         object.__setattr__(self, "_fields", {})
-        for k, v in kwargs.items():
-            self.set(k, v)
+        for name, value in fields.items():
+            self.set(name, value)
 
+    # -- field access
     @property
     def image_size(self):
         return self._image_size
 
-    def __setattr__(self, name, val):
-        if name.startswith("_"):
-            object.__setattr__(self, name, val)
+    def __setattr__(self, name, value):
+        if name[:1] == "_":
+            object.__setattr__(self, name, value)
         else:
-            self.set(name, val)
+            self.set(name, value)
 
     def __getattr__(self, name):
-        if name == "_fields" or name not in self._fields:
+        fields = object.__getattribute__(self, "_fields") if name != "_fields" else None
+        if fields is None or name not in fields:
             raise AttributeError("Cannot find field '{}' in the given Instances!".format(name))
-        return self._fields[name]
+        return fields[name]
 
     def set(self, name, value):
-        data_len = len(value)
-        if len(self._fields):
-            assert len(self) == data_len, "Adding a field of length {} to a Instances of length {}".format(data_len, len(self))
+        if self._fields and len(value) != len(self):
+            raise AssertionError("field '%s' has %d entries, the Instances holds %d" % (name, len(value), len(self)))
         self._fields[name] = value
 
     def has(self, name):
         return name in self._fields
 
     def remove(self, name):
-        del self._fields[name]
+        self._fields.pop(name)
 
     def get(self, name):
         return self._fields[name]
@@ -195,54 +212,44 @@ class Instances:
     def get_fields(self):
         return self._fields
 
-    def to(self, *args, **kwargs):
-        ret = Instances(self._image_size)
-        for k, v in self._fields.items():
-            if hasattr(v, "to"):
-                v = v.to(*args, **kwargs)
-            ret.set(k, v)
-        return ret
+    # -- whole-record operations
+    def _rebuild(self, fn):
+        out = Instances(self._image_size)
+        for name, value in self._fields.items():
+            out.set(name, fn(value))
+        return out
 
-    def __getitem__(self, item):
-        if type(item) == int:
-            if item >= len(self) or item < -len(self):
-                raise IndexError("Instances index out of range!")
-            item = slice(item, None, len(self))
-        ret = Instances(self._image_size)
-        for k, v in self._fields.items():
-            ret.set(k, v[item])
-        return ret
+    def to(self, *args, **kwargs):
+        return self._rebuild(lambda v: v.to(*args, **kwargs) if hasattr(v, "to") else v)
 
     def __len__(self):
-        for v in self._fields.values():
-            return v.__len__()
-        raise NotImplementedError("Empty Instances does not support __len__!")
+        if not self._fields:
+            raise NotImplementedError("an Instances without fields has no length")
+        return len(next(iter(self._fields.values())))
+
+    def __getitem__(self, item):
+        if isinstance(item, int) and not isinstance(item, bool):
+            n = len(self)
+            if not -n <= item < n:
+                raise IndexError("Instances index %d out of range for %d instances" % (item, n))
+            item = slice(item % n, item % n + 1)            # keep the instance axis
+        return self._rebuild(lambda v: v[item])
 
     @staticmethod
     def cat(instance_lists):
-        assert len(instance_lists) > 0
+        if not instance_lists:
+            raise AssertionError("Instances.cat needs at least one Instances")
+        first = instance_lists[0]
         if len(instance_lists) == 1:
-            return instance_lists[0]
-        image_size = instance_lists[0].image_size
-        ret = Instances(image_size)
-        for k in instance_lists[0]._fields.keys():
-            values = [i.get(k) for i in instance_lists]
-            v0 = values[0]
-            if isinstance(v0, torch.Tensor):
-                values = torch.cat(values, dim=0)
-            elif isinstance(v0, list):
-                values = list(itertools.chain(*values))
-            elif hasattr(type(v0), "cat"):
-                values = type(v0).cat(values)
-            else:
-                raise ValueError("Unsupported type {} for concatenation".format(type(v0)))
-            ret.set(k, values)
-        return ret
+            return first
+        out = Instances(first.image_size)
+        for name in first._fields:
+            out.set(name, _join_field([inst.get(name) for inst in instance_lists]))
+        return out
 
     def __repr__(self):
-        return "Instances(num={}, size={}, fields=[{}])".format(
-            len(self) if self._fields else 0, self._image_size,
-            ", ".join("{}: {}".format(k, type(v).__name__) for k, v in self._fields.items()))
+        kinds = ", ".join("%s: %s" % (k, type(v).__name__) for k, v in self._fields.items())
+        return "Instances(num=%d, size=%s, fields=[%s])" % (len(self) if self._fields else 0, self._image_size, kinds)
 
 
 class PatchRows:

@@ -691,7 +691,42 @@ def gen_augment():
     save("augment", **store)
 
 
+def gen_samplers():
+    """Index streams of the reference's own samplers (D2/data/samplers/distributed_sampler.py) for seeded generators: what
+    divergen_amd/data/samplers.py has to reproduce so that a run visits the images in the reference's order."""
+    import importlib.util
+    import itertools
+    comm = types.ModuleType("detectron2.utils.comm")
+    comm.get_rank, comm.get_world_size, comm.shared_random_seed = (lambda: 0), (lambda: 1), (lambda: 1)
+    for nm in ("detectron2", "detectron2.utils"):
+        sys.modules.setdefault(nm, types.ModuleType(nm))
+    sys.modules["detectron2.utils.comm"] = comm
+    sys.modules["detectron2.utils"].comm = comm
+    spec = importlib.util.spec_from_file_location("ref_distributed_sampler", R.D2 + "/data/samplers/distributed_sampler.py")
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    g = torch.Generator().manual_seed(3)
+    rf = 1.0 + 2.5 * torch.rand(37, generator=g) ** 3
+    store = {"repeat_factors": npy(rf)}
+    cases = [(7, 0, 1, True), (7, 1, 3, True), (11, 2, 4, True), (5, 1, 2, False)]
+    store["cases"] = np.array([[a, b, c, int(d)] for a, b, c, d in cases], dtype=np.int64)
+    for ci, (seed, rank, world, shuffle) in enumerate(cases):
+        s = m.RepeatFactorTrainingSampler(rf, shuffle=shuffle, seed=seed)
+        s._rank, s._world_size = rank, world
+        store["rf_%d" % ci] = np.array(list(itertools.islice(iter(s), 300)), dtype=np.int64)
+        s = m.TrainingSampler(23, shuffle, seed)
+        s._rank, s._world_size = rank, world
+        store["tr_%d" % ci] = np.array(list(itertools.islice(iter(s), 100)), dtype=np.int64)
+    shards = []
+    for tot, w in ((100, 4), (10, 3), (5, 8), (0, 2)):
+        for r in range(w):
+            rg = m.InferenceSampler._get_local_indices(tot, w, r)
+            shards.append([tot, w, r, rg.start if len(rg) else 0, len(rg)])
+    store["inference_shards"] = np.array(shards, dtype=np.int64)
+    save("samplers", **store)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["swin", "centernet", "roi", "compositor", "solver", "heads", "heads_wide", "postprocess", "inference", "pool", "bsgal", "augment"]
+    which = sys.argv[1:] or ["swin", "centernet", "roi", "compositor", "solver", "heads", "heads_wide", "postprocess", "inference", "pool", "bsgal", "augment", "samplers"]
     for w in which:
         globals()["gen_" + w]()

@@ -30,6 +30,24 @@ def test_training_sampler_seeded_and_sharded():
     assert r0 == full[0::2] and r1 == full[1::2]
 
 
+def test_sampler_streams_equal_reference_golden():
+    """tests/golden/samplers.npz: streams of the reference's own sampler classes (make_golden.py::gen_samplers) -- seeded,
+    sharded, with and without shuffling; the inference shards as (start, length)."""
+    import itertools
+    import numpy as np
+    from divergen_amd.data.samplers import InferenceSampler, RepeatFactorTrainingSampler, TrainingSampler
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "samplers.npz"))
+    rf = torch.from_numpy(z["repeat_factors"])
+    for ci, (seed, rank, world, shuffle) in enumerate(z["cases"].tolist()):
+        s = RepeatFactorTrainingSampler(rf, shuffle=bool(shuffle), seed=seed, rank=rank, world_size=world)
+        assert list(itertools.islice(iter(s), 300)) == z["rf_%d" % ci].tolist()
+        s = TrainingSampler(23, bool(shuffle), seed=seed, rank=rank, world_size=world)
+        assert list(itertools.islice(iter(s), 100)) == z["tr_%d" % ci].tolist()
+    for tot, w, r, start, n in z["inference_shards"].tolist():
+        got = InferenceSampler._get_local_indices(tot, w, r)
+        assert len(got) == n and (n == 0 or got.start == start)
+
+
 def test_inference_sampler_shards():
     # D2T/data/test_sampler.py:94-111
     from divergen_amd.data.samplers import InferenceSampler

@@ -169,6 +169,8 @@ SIGNATURES = {
     "dgx_clip_coef_f32": (c_i, [c_p, c_i64, c_f, c_f, c_p, c_p, c_p]),
     "dgx_adamw_ema_step": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_f,
                                  c_p, c_p, c_i, c_p, c_p]),
+    "dgx_adamw_ema_step_scaled": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_p, c_i, c_f,
+                                        c_p, c_p, c_i, c_p, c_p]),
 }
 
 

@@ -496,9 +496,21 @@ int launch_gemm(GemmP& P, hipStream_t st) {
 }  // namespace
 
 int gemm_lw_launch(GemmP& P, int bm, int bn, hipStream_t st);     // gemm_lw.hip: the loader-wave form
-static int lw_mode() {            // development switch while both forms exist: 0 off, 1 every tile, 2 only where K > 768
-    static const int v = getenv("DGX_GEMM_LW") ? atoi(getenv("DGX_GEMM_LW")) : 0;
+// Which form runs a problem (measured in situ, profiles/r04_gemm_insitu_*.txt): the loader-wave persistent kernel wins wherever the
+// read-out is plain (modes 0 / 1, the implicit convolutions: 0.65-0.97x the time, the skinny K = N = 192 projection excepted) and on
+// the long contractions (K > 768) with a residual or GELU tail; the two-workgroup form of gemm_nt keeps the K <= 768 GEMMs whose
+// tails read a cold operand or write two tensors (its second workgroup's main loop hides them).  DGX_GEMM_LW = 0 | 1 forces
+// gemm_nt | gemm_lw everywhere (development A/B; tools/r04_insitu_ab.sh).
+static int lw_mode() {
+    static const int v = getenv("DGX_GEMM_LW") ? atoi(getenv("DGX_GEMM_LW")) : 2;
     return v;
+}
+static bool use_lw(const GemmP& P) {
+    const int m = lw_mode();
+    if (m != 2) return m == 1;
+    if (P.mode <= 1) return !(P.N <= 192 && P.K <= 192);
+    if (P.mode == 2 || P.mode == 3) return P.K > 768;
+    return false;
 }
 // tiling fields of a bm x bn launch (what launch_gemm<> computes for its instantiation)
 static void plan_tiles(GemmP& P, int bm, int bn) {
@@ -587,7 +599,7 @@ extern "C" int dgx_gemm_bf16_nt(const void* A, const void* B, int M, int N, int 
     const double mn = (double)M * N, rsz = ep->residual_dtype == DGX_F32 ? 4.0 : 2.0;
     const double obytes = ep->mode == DGX_EPI_BIAS_RESIDUAL ? 2.0 * rsz * mn : (ep->mode >= DGX_EPI_BIAS_GELU ? 4.0 * mn : 2.0 * mn);   // GELU / GELU' / ReLU': two tensors
     DgxProfScope prof(DGX_PROF_GEMM_NT, stream, 2.0 * mn * K, 2.0 * ((double)M * K + (double)N * K) + obytes);
-    if (FILE* lf = gemm_log_file()) { fprintf(lf, "%d %d %d %d %d %d\n", M, N, K, ep->mode, use_two_wg(P) ? 128 : tc.bm, tc.bn); fflush(lf); }
+    if (FILE* lf = gemm_log_file()) { fprintf(lf, "%d %d %d %d %d %d\n", M, N, K, ep->mode, (use_two_wg(P) && !use_lw(P)) ? 128 : tc.bm, tc.bn); fflush(lf); }
 #ifdef DGX_GEMM_DEV
     if (const char* dg = getenv("DGX_GEMM256") ? nullptr : getenv("DGX_GEMM_DIAG")) {
         switch (atoi(dg)) {
@@ -625,7 +637,7 @@ static int dgx_gemm_dispatch(GemmP& P, hipStream_t st) {
             if (choose_splits(tiles, P.K, P.M, P.N, P.ws ? g_ws_bytes_cur : 0) == 1 || nt < 8 || tiles > 128) return gemm256_launch(P, force, st);
         }
     }
-    if (lw_mode() == 1 || (lw_mode() == 2 && !use_two_wg(P))) return launch_lw(P, tc.bm, tc.bn, st);
+    if (use_lw(P)) return launch_lw(P, tc.bm, tc.bn, st);
     if (tc.bn == 192) {
         // contractions of up to 12 K-tiles (K <= 768: every qkv / proj / fc1 / fc2-input-gradient GEMM of the backbone) spend a third of
         // a tile's time in prologue and read-out: TWO workgroups share a CU there (128 x 192 tiles, 2 stages = 80 KB of LDS, 128

@@ -9,11 +9,12 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(float4* __restrict__ p, 
                                                         float4* __restrict__ m, float4* __restrict__ v,
                                                         float4* __restrict__ ema, uint2* __restrict__ pbf, int64_t n4,
                                                         float lr, float b1, float b2, float eps, float wd, float clip,
-                                                        float gscale, float bc1, float bc2s, float decay,
-                                                        const float* __restrict__ lr_scale,
+                                                        float gscale, const float* __restrict__ scale_dev, float bc1, float bc2s,
+                                                        float decay, const float* __restrict__ lr_scale,
                                                         const int64_t* __restrict__ seg_end, int n_seg,
                                                         const int32_t* __restrict__ found_inf) {
     if (found_inf && *found_inf) return;
+    if (scale_dev) gscale *= *scale_dev;       // full-model norm-clip coefficient (dgx_clip_coef_f32), kept on the device
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         float lre = lr;
         if (lr_scale) {  // binary search of the segment of element 4*i
@@ -50,10 +51,11 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(float4* __restrict__ p, 
     }
 }
 
-extern "C" int dgx_adamw_ema_step(float* p, const float* g, float* m, float* v, float* ema, void* p_bf16, int64_t n,
-                                  float lr, float beta1, float beta2, float eps, float weight_decay, float clip_value,
-                                  float grad_scale, int step, float ema_decay, const float* lr_scale,
-                                  const int64_t* seg_end, int n_seg, const int32_t* found_inf, void* stream) {
+extern "C" int dgx_adamw_ema_step_scaled(float* p, const float* g, float* m, float* v, float* ema, void* p_bf16, int64_t n,
+                                         float lr, float beta1, float beta2, float eps, float weight_decay, float clip_value,
+                                         float grad_scale, const float* grad_scale_dev, int step, float ema_decay,
+                                         const float* lr_scale, const int64_t* seg_end, int n_seg, const int32_t* found_inf,
+                                         void* stream) {
     if (n <= 0) return DGX_OK;
     if (!p || !g || !m || !v || (n & 3) || step < 1 || ((lr_scale != nullptr) != (seg_end != nullptr))) return DGX_ERR_BAD_ARG;
     const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
@@ -62,10 +64,18 @@ extern "C" int dgx_adamw_ema_step(float* p, const float* g, float* m, float* v, 
     const int grid = (int)((n4 + 255) / 256 < 16384 ? (n4 + 255) / 256 : 16384);
     hipLaunchKernelGGL(adamw_ema_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (float4*)p, (const float4*)g,
                        (float4*)m, (float4*)v, (float4*)ema, (uint2*)p_bf16, n4, lr, beta1, beta2, eps, weight_decay,
-                       clip_value > 0 ? clip_value : INFINITY, grad_scale, bc1, bc2s, ema_decay, lr_scale, seg_end,
+                       clip_value > 0 ? clip_value : INFINITY, grad_scale, grad_scale_dev, bc1, bc2s, ema_decay, lr_scale, seg_end,
                        n_seg, found_inf);
     DGX_LAUNCH_CHECK();
     return DGX_OK;
+}
+
+extern "C" int dgx_adamw_ema_step(float* p, const float* g, float* m, float* v, float* ema, void* p_bf16, int64_t n,
+                                  float lr, float beta1, float beta2, float eps, float weight_decay, float clip_value,
+                                  float grad_scale, int step, float ema_decay, const float* lr_scale,
+                                  const int64_t* seg_end, int n_seg, const int32_t* found_inf, void* stream) {
+    return dgx_adamw_ema_step_scaled(p, g, m, v, ema, p_bf16, n, lr, beta1, beta2, eps, weight_decay, clip_value, grad_scale, nullptr,
+                                     step, ema_decay, lr_scale, seg_end, n_seg, found_inf, stream);
 }
 
 // ------------------------------------------------------------------------------------------------------------------

@@ -137,13 +137,17 @@ def group_parameters(first_weight_or_bias, *others, pad_to=8):
 
 def ensure_zeroed(p):
     """A gradient segment that the lazy zero_grad (solver.FlatArena.zero_grad(lazy=True)) left to its usual first writer, reached by an
-    ACCUMULATING path instead: zero it now (and stop treating it as directly written)."""
-    slot = getattr(p, "_dgx_arena_slot", None) if p is not None else None
-    if slot is not None and slot[1] in slot[0]._lazy_pending:
-        a, i = slot
-        a.g[a.offsets[i]:a.offsets[i] + a.sizes[i]].zero_()
-        a._lazy_pending.discard(i)
-        a.direct.discard(i)
+    ACCUMULATING path instead: zero it now (and stop treating it as directly written).  A parameter-group handle stands for the
+    whole group: the accumulating GEMM writes every member's rows of the group view."""
+    if p is None:
+        return
+    for q in getattr(p, "_dgx_group_members", None) or (p,):
+        slot = getattr(q, "_dgx_arena_slot", None)
+        if slot is not None and slot[1] in slot[0]._lazy_pending:
+            a, i = slot
+            a.g[a.offsets[i]:a.offsets[i] + a.sizes[i]].zero_()
+            a._lazy_pending.discard(i)
+            a.direct.discard(i)
 
 
 def accumulate_grad(p, make_grad_fp32, gemm_into=None):

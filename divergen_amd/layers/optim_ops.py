@@ -4,14 +4,15 @@ from .. import _lib as L
 
 
 def adamw_ema_step(p, g, m, v, ema, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, clip_value=1.0,
-                   grad_scale=1.0, ema_decay=0.999, p_bf16=None, lr_scale=None, seg_end=None, found_inf=None):
+                   grad_scale=1.0, ema_decay=0.999, p_bf16=None, lr_scale=None, seg_end=None, found_inf=None, grad_scale_dev=None):
+    """grad_scale_dev: optional device scalar multiplied into the gradient (the full-model norm-clip coefficient of `clip_coef`)."""
     n = p.numel()
     assert n % 4 == 0, "arena length must be a multiple of 4"
     n_seg = 0 if lr_scale is None else lr_scale.numel()
-    L.check(L.lib().dgx_adamw_ema_step(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), L.ptr(ema), L.ptr(p_bf16), n, lr,
-                                       betas[0], betas[1], eps, weight_decay, clip_value, grad_scale, int(step),
-                                       ema_decay, L.ptr(lr_scale), L.ptr(seg_end), n_seg, L.ptr(found_inf),
-                                       L.stream()), "dgx_adamw_ema_step")
+    L.check(L.lib().dgx_adamw_ema_step_scaled(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), L.ptr(ema), L.ptr(p_bf16), n, lr,
+                                              betas[0], betas[1], eps, weight_decay, clip_value, grad_scale, L.ptr(grad_scale_dev),
+                                              int(step), ema_decay, L.ptr(lr_scale), L.ptr(seg_end), n_seg, L.ptr(found_inf),
+                                              L.stream()), "dgx_adamw_ema_step_scaled")
 
 
 def sgd_ema_step(p, g, buf, ema, step, lr, momentum=0.0, nesterov=False, weight_decay=0.0, clip_value=0.0, grad_scale=1.0,

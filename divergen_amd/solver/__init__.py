@@ -205,14 +205,20 @@ class FlatArena:
 
     def claim_first_write(self, params):
         """True when none of `params` (arena residents) has been written in this generation: the caller may overwrite their
-        gradient segments (beta = 0) instead of accumulating.  Marks them written either way."""
+        gradient segments (beta = 0) instead of accumulating.  Marks them written either way.  When the launch as a whole has to
+        accumulate (some member was already written: two forward passes before one backward, ACTIVE_COMPARE 'all', gradient
+        accumulation), the members the lazy zero_grad left un-zeroed and nobody has written yet are zeroed HERE -- otherwise the
+        accumulating launch would add onto last step's gradient."""
         self._direct_state()
         slots = [q._dgx_arena_slot[1] for q in params]
         first = all(self.written[i] != self.gen for i in slots)
         for i in slots:
-            self.written[i] = self.gen
             if first:
                 self.direct.add(i)
+            elif i in self._lazy_pending and self.written[i] != self.gen:
+                self.g[self.offsets[i]:self.offsets[i] + self.sizes[i]].zero_()
+                self.direct.discard(i)
+            self.written[i] = self.gen
             self._lazy_pending.discard(i)
         return first
 
@@ -232,15 +238,21 @@ class FlatArena:
         key = tuple(keep)
         tab = self._zero_tables.get(key)
         if tab is None:                        # complement of the kept segments, cut into work items of <= 64 K floats
+            # dgx_zero_ranges_f32 moves 16 bytes per lane: every range starts and ends on a 4-element boundary (the arena's
+            # length is a multiple of 4).  A kept segment therefore shrinks to its aligned interior [ceil4(start), floor4(end)):
+            # the up-to-3 elements on either side are zeroed with the neighbouring range, and the segment's first writer
+            # overwrites them anyway.
             items, pos = [], 0
             for i in keep + [None]:
-                end = self.numel if i is None else self.offsets[i]
+                end = self.numel if i is None else (self.offsets[i] + 3) // 4 * 4
+                end = max(end, pos)
                 while pos < end:
                     n = min(end - pos, 65536)
                     items += [pos, n]
                     pos += n
                 if i is not None:
-                    pos = self.offsets[i] + self.params[i].numel() // 4 * 4      # (a tail of < 4 elements is zeroed with the gap)
+                    pos = max(pos, (self.offsets[i] + self.params[i].numel()) // 4 * 4)
+            assert all(v % 4 == 0 for v in items), "zero ranges must be 16-byte aligned"
             self._zero_tables.clear()
             tab = self._zero_tables[key] = torch.tensor(items, dtype=torch.int64, device=self.g.device).view(-1, 2)
         from .. import _lib as L
@@ -259,14 +271,20 @@ class FlatArena:
         return [o + n for o, n in zip(self.offsets, self.sizes)]
 
 
+# Bumped whenever the STORAGE ORDER of a parameter inside its arena segment changes (round 3: segments on 64-element boundaries,
+# grouped predictors, (h, w, c) columns of the box heads' first FC): flat optimizer state of another version is not remapped.
+ARENA_LAYOUT_VERSION = 3
+
+
 class FusedAdamWEMA:
     """Optimizer + EMA over a FlatArena.  API mirrors torch.optim (step/zero_grad/state_dict) as far
     as the training loop and the checkpointer need."""
 
     def __init__(self, arena, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4, clip_value=1.0,
-                 ema_decay=0.0, lr_multipliers=None):
+                 ema_decay=0.0, lr_multipliers=None, clip_norm=0.0):
         self.arena, self.lr, self.betas, self.eps = arena, lr, betas, eps
         self.weight_decay, self.clip_value, self.ema_decay = weight_decay, clip_value, ema_decay
+        self.clip_norm, self.last_clip = clip_norm, None      # clip_norm > 0: FullModelGradientClippingOptimizer (custom_solver.py:46-60)
         self.m = torch.zeros_like(arena.p)
         self.v = torch.zeros_like(arena.p)
         self.ema = arena.p.clone() if ema_decay > 0 else None
@@ -283,20 +301,50 @@ class FusedAdamWEMA:
     def step(self, grad_scale=1.0, found_inf=None):
         self.step_count += 1
         self.arena.finish_grads()
+        if self.clip_norm > 0:                 # coefficient stays on the device: [min(1, max_norm / (norm + 1e-6)), norm]
+            from ..layers.optim_ops import clip_coef
+            self.last_clip = clip_coef(self.arena.g, self.clip_norm, grad_scale)
         adamw_ema_step(self.arena.p, self.arena.g, self.m, self.v, self.ema, self.step_count, self.param_groups[0]["lr"],
                        self.betas, self.eps, self.weight_decay, self.clip_value, grad_scale, self.ema_decay,
                        p_bf16=self.arena.p16 if self.arena.p16.is_cuda else None,
-                       lr_scale=self.lr_scale, seg_end=self.seg_end, found_inf=found_inf)
+                       lr_scale=self.lr_scale, seg_end=self.seg_end, found_inf=found_inf,
+                       grad_scale_dev=self.last_clip if self.clip_norm > 0 else None)
         self.arena.refresh_transposes()
 
+    def _layout(self):
+        return {"names": list(self.arena.names), "offsets": list(self.arena.offsets), "sizes": list(self.arena.sizes),
+                "layout_version": ARENA_LAYOUT_VERSION}
+
+    def _load_flat(self, dst, src, sd, what):
+        """Copy a saved flat state vector into `dst`.  Same layout (names, offsets, sizes, storage-order version): one copy.
+        Another arena layout of the SAME storage order: per parameter by name.  Anything else is refused -- a raw copy would put
+        the moments on the wrong parameters."""
+        cur = self._layout()
+        saved = {k: sd.get(k) for k in cur}
+        if all(saved[k] is not None and (list(saved[k]) if k != "layout_version" else saved[k]) == cur[k] for k in cur) \
+                and src.numel() == dst.numel():
+            dst.copy_(src)
+            return
+        if saved["layout_version"] != ARENA_LAYOUT_VERSION or saved["names"] is None or saved["sizes"] is None:
+            raise RuntimeError("optimizer state '%s' was written by a build with another parameter storage layout (saved version %s, "
+                               "this build %d): it cannot be mapped onto this arena -- resume with the model weights only, or from a "
+                               "checkpoint of this build" % (what, saved["layout_version"], ARENA_LAYOUT_VERSION))
+        where = {n: (o, z) for n, o, z in zip(saved["names"], saved["offsets"], saved["sizes"])}
+        dst.zero_()
+        for n, o, z in zip(cur["names"], cur["offsets"], cur["sizes"]):
+            if n in where:
+                so, sz = where[n]
+                if sz != z:
+                    raise RuntimeError("optimizer state '%s': parameter %s has %d stored elements, this arena holds %d" % (what, n, sz, z))
+                dst[o:o + z].copy_(src[so:so + sz])
+
     def state_dict(self):
-        return {"step": self.step_count, "exp_avg": self.m, "exp_avg_sq": self.v, "lr": self.param_groups[0]["lr"],
-                "names": self.arena.names, "offsets": self.arena.offsets}
+        return dict({"step": self.step_count, "exp_avg": self.m, "exp_avg_sq": self.v, "lr": self.param_groups[0]["lr"]}, **self._layout())
 
     def load_state_dict(self, sd):
         self.step_count = int(sd["step"])
-        self.m.copy_(sd["exp_avg"])
-        self.v.copy_(sd["exp_avg_sq"])
+        self._load_flat(self.m, sd["exp_avg"], sd, "exp_avg")
+        self._load_flat(self.v, sd["exp_avg_sq"], sd, "exp_avg_sq")
 
     # ---- EMA surface (DG/divergen/ema.py: state_dict / load_state_dict, keys = model state-dict keys)
     def ema_state_dict(self, model):
@@ -349,13 +397,12 @@ class FusedSGDEMA(FusedAdamWEMA):
         self.arena.refresh_transposes()
 
     def state_dict(self):
-        return {"step": self.step_count, "momentum_buffer": self.buf, "lr": self.param_groups[0]["lr"], "names": self.arena.names,
-                "offsets": self.arena.offsets}
+        return dict({"step": self.step_count, "momentum_buffer": self.buf, "lr": self.param_groups[0]["lr"]}, **self._layout())
 
     def load_state_dict(self, sd):
         self.step_count = int(sd["step"])
         if self.buf is not None and sd.get("momentum_buffer") is not None:
-            self.buf.copy_(sd["momentum_buffer"])
+            self._load_flat(self.buf, sd["momentum_buffer"], sd, "momentum_buffer")
 
 
 def build_optimizer(cfg, model):
@@ -366,8 +413,8 @@ def build_optimizer(cfg, model):
         raise NotImplementedError("no optimizer type %s (custom_solver.py:74-75); SOLVER.USE_CUSTOM_SOLVER is what the shipped configs set"
                                   % s.OPTIMIZER)
     ctype = s.CLIP_GRADIENTS.CLIP_TYPE
-    if s.CLIP_GRADIENTS.ENABLED and not (ctype == "value" or (ctype == "full_model" and s.OPTIMIZER == "SGD")):
-        raise NotImplementedError("CLIP_GRADIENTS.CLIP_TYPE '%s' with %s: built are 'value' (both) and 'full_model' (SGD)" % (ctype, s.OPTIMIZER))
+    if s.CLIP_GRADIENTS.ENABLED and ctype not in ("value", "full_model"):
+        raise NotImplementedError("CLIP_GRADIENTS.CLIP_TYPE '%s': built are 'value' and 'full_model' (custom_solver.py:28-60)" % ctype)
     arena = FlatArena(model)
     mult = []
     for name in arena.names:
@@ -382,8 +429,8 @@ def build_optimizer(cfg, model):
         return FusedSGDEMA(arena, s.BASE_LR, momentum=s.MOMENTUM, nesterov=s.NESTEROV, weight_decay=s.WEIGHT_DECAY,
                            clip_value=clip if ctype == "value" else 0.0, clip_norm=clip if ctype == "full_model" else 0.0,
                            ema_decay=s.MODEL_EMA, lr_multipliers=mult)
-    return FusedAdamWEMA(arena, s.BASE_LR, weight_decay=s.WEIGHT_DECAY, clip_value=clip, ema_decay=s.MODEL_EMA,
-                         lr_multipliers=mult)
+    return FusedAdamWEMA(arena, s.BASE_LR, weight_decay=s.WEIGHT_DECAY, clip_value=clip if ctype == "value" else 0.0,
+                         clip_norm=clip if ctype == "full_model" else 0.0, ema_decay=s.MODEL_EMA, lr_multipliers=mult)
 
 
 class WarmupCosineLR:

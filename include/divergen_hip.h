@@ -269,6 +269,14 @@ int dgx_adamw_ema_step(float* p, const float* g, float* m, float* v, float* ema,
                        float clip_value, float grad_scale, int step, float ema_decay,
                        const float* lr_scale, const int64_t* seg_end, int n_seg,
                        const int32_t* found_inf, void* stream);
+/* The same step with the gradient additionally multiplied by a DEVICE scalar: the full-model norm-clip coefficient of
+ * dgx_clip_coef_f32 (DG/divergen/custom_solver.py:46-60 wraps AdamW as well as SGD in FullModelGradientClippingOptimizer);
+ * grad_scale_dev may be NULL (= dgx_adamw_ema_step). */
+int dgx_adamw_ema_step_scaled(float* p, const float* g, float* m, float* v, float* ema, void* p_bf16,
+                              int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                              float clip_value, float grad_scale, const float* grad_scale_dev, int step, float ema_decay,
+                              const float* lr_scale, const int64_t* seg_end, int n_seg,
+                              const int32_t* found_inf, void* stream);
 
 /* The 'SGD' branch of build_custom_optimizer (DG/divergen/custom_solver.py:64-68 = torch.optim.SGD with momentum / nesterov and one
  * weight decay for every group) over the same arena, with the EMA lerp, bf16 shadow, per-segment lr multipliers and found_inf of

@@ -470,6 +470,27 @@ def test_adamw_ema_step_vs_oracle():
     torch.testing.assert_close(vd.cpu(), v, atol=1e-7, rtol=1e-5)
 
 
+def test_adamw_full_model_clip_vs_torch():
+    """FullModelGradientClippingOptimizer over AdamW (custom_solver.py:46-60,69-72): clip_grad_norm_ over all parameters, then
+    torch.optim.AdamW -- here the coefficient of dgx_clip_coef_f32 stays on the device and dgx_adamw_ema_step_scaled applies it."""
+    g = torch.Generator().manual_seed(47)
+    n = 4 * 900
+    a = torch.nn.Parameter(torch.randn(n, generator=g))
+    opt = torch.optim.AdamW([a], lr=2e-3, weight_decay=1e-2)
+    pd, md, vd = a.detach().to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    for step in range(1, 6):
+        gr = torch.randn(n, generator=g) * (0.01 if step == 3 else 3.0)      # step 3: norm below the bound, coefficient 1
+        a.grad = gr.clone()
+        total = torch.nn.utils.clip_grad_norm_([a], 1.5)
+        opt.step()
+        gd = gr.to(DEV)
+        coef = la.clip_coef(gd, 1.5)
+        assert abs(float(coef[1]) - float(total)) <= 1e-5 * float(total)
+        la.adamw_ema_step(pd, gd, md, vd, None, step, 2e-3, weight_decay=1e-2, clip_value=0.0, ema_decay=0.0, grad_scale_dev=coef)
+    torch.testing.assert_close(pd.cpu(), a.detach(), atol=2e-6, rtol=1e-5)
+    torch.testing.assert_close(vd.cpu(), opt.state[a]["exp_avg_sq"], atol=1e-7, rtol=1e-5)
+
+
 @pytest.mark.parametrize("momentum,nesterov,clip_norm", [(0.9, False, 0.0), (0.9, True, 0.0), (0.0, False, 0.0), (0.9, False, 2.5)])
 def test_sgd_ema_step_vs_torch_sgd(momentum, nesterov, clip_norm):
     """dgx_sgd_ema_step / dgx_clip_coef_f32 against what the 'SGD' branch of build_custom_optimizer constructs (custom_solver.py:46-68):

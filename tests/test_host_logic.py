@@ -416,9 +416,78 @@ def test_build_optimizer_branches_follow_build_custom_optimizer():
     cfg.SOLVER.CLIP_GRADIENTS.CLIP_TYPE = "norm"
     with pytest.raises(NotImplementedError):
         build_optimizer(cfg, Net())
+    # the reference wraps AdamW in the full-model clipper as well (custom_solver.py:46-60,69-72)
+    cfg.SOLVER.CLIP_GRADIENTS.CLIP_TYPE, cfg.SOLVER.OPTIMIZER = "full_model", "ADAMW"
+    opt = build_optimizer(cfg, Net())
+    assert type(opt) is FusedAdamWEMA and (opt.clip_norm, opt.clip_value) == (0.5, 0.0)
     cfg.SOLVER.CLIP_GRADIENTS.CLIP_TYPE, cfg.SOLVER.OPTIMIZER = "value", "LAMB"
     with pytest.raises(NotImplementedError):
         build_optimizer(cfg, Net())
+
+
+def test_optimizer_state_is_remapped_by_name_or_refused():
+    """--resume: flat moments written under another arena layout are mapped per parameter (same storage order) or refused with a
+    clear message (another storage-order version / no sizes) -- never copied raw onto the wrong parameters."""
+    from divergen_amd.solver import ARENA_LAYOUT_VERSION, FlatArena, FusedAdamWEMA
+
+    def net(order):
+        m = torch.nn.Module()
+        for nm in order:
+            setattr(m, nm, torch.nn.Linear(8, 8, bias=False))
+        return m
+    a = FusedAdamWEMA(FlatArena(net(["one", "two"])), 1e-3)
+    a.m.copy_(torch.arange(a.m.numel(), dtype=torch.float32))
+    a.v.copy_(torch.arange(a.v.numel(), dtype=torch.float32) * 2)
+    a.step_count = 7
+    sd = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in a.state_dict().items()}
+    assert sd["layout_version"] == ARENA_LAYOUT_VERSION and sd["sizes"] == list(a.arena.sizes)
+    b = FusedAdamWEMA(FlatArena(net(["two", "one"])), 1e-3)          # same parameters, other registration order
+    b.load_state_dict(sd)
+    assert b.step_count == 7
+    for nm in ("one.weight", "two.weight"):
+        ia, ib = a.arena.names.index(nm), b.arena.names.index(nm)
+        sa = slice(a.arena.offsets[ia], a.arena.offsets[ia] + a.arena.sizes[ia])
+        sb = slice(b.arena.offsets[ib], b.arena.offsets[ib] + b.arena.sizes[ib])
+        assert torch.equal(a.m[sa], b.m[sb]) and torch.equal(a.v[sa], b.v[sb])
+    c = FusedAdamWEMA(FlatArena(net(["one", "two"])), 1e-3)          # identical layout: plain copy
+    c.load_state_dict(sd)
+    assert torch.equal(c.m, a.m)
+    old = dict(sd)
+    old["layout_version"] = ARENA_LAYOUT_VERSION - 1
+    old["offsets"] = [o + 4 for o in sd["offsets"]]
+    with pytest.raises(RuntimeError, match="storage layout"):
+        b.load_state_dict(old)
+    legacy = {k: v for k, v in sd.items() if k not in ("sizes", "layout_version")}
+    legacy["offsets"] = [o + 4 for o in sd["offsets"]]
+    with pytest.raises(RuntimeError, match="storage layout"):
+        b.load_state_dict(legacy)
+
+
+def test_lazy_zero_grad_mixed_launch_does_not_accumulate_onto_stale_gradients():
+    """A grouped weight-gradient launch that has to ACCUMULATE (one of its members was already written in this pass) may contain
+    members the lazy zero_grad left un-zeroed: claim_first_write zeroes those before the launch adds into them.  The zero table of
+    the lazy path is built on 4-element boundaries."""
+    from divergen_amd.solver import FlatArena
+    m = torch.nn.Module()
+    m.a, m.b = torch.nn.Linear(8, 8, bias=False), torch.nn.Linear(8, 6, bias=False)
+    ar = FlatArena(m)
+    ar._direct_state()
+    pa, pb = m.a.weight, m.b.weight
+    ia, ib = pa._dgx_arena_slot[1], pb._dgx_arena_slot[1]
+    seg = lambda i: ar.g[ar.offsets[i]:ar.offsets[i] + ar.sizes[i]]
+    # step 1: both written first -> direct; the "launch" overwrites
+    ar.zero_grad()
+    assert ar.claim_first_write([pa, pb])
+    seg(ia).fill_(1.0), seg(ib).fill_(2.0)
+    # step 2 (what zero_grad(lazy=True) does on the device is emulated: the kept segments are left alone)
+    ar.gen += 1
+    ar.direct = {ia, ib}
+    ar._lazy_pending = {ia, ib}
+    assert ar.claim_first_write([pa])                    # first forward's backward writes a
+    seg(ia).fill_(5.0)
+    assert not ar.claim_first_write([pa, pb])            # mixed launch: a already written, b still holds last step's 2.0
+    assert float(seg(ib).abs().max()) == 0.0 and float(seg(ia).max()) == 5.0
+    assert ib not in ar._lazy_pending and ib not in ar.direct
 
 
 def test_box_head_first_fc_is_stored_hwc_and_state_dicts_keep_the_reference_order():

@@ -5,14 +5,21 @@ import sys
 from collections import defaultdict
 
 trace, log, steps = sys.argv[1], sys.argv[2], float(sys.argv[3])
-rows = [r for r in csv.DictReader(open(trace)) if "gemm_nt_kernel" in r["Kernel_Name"] or "gemm256_kernel" in r["Kernel_Name"]]
+rows = [r for r in csv.DictReader(open(trace)) if "gemm_nt_kernel" in r["Kernel_Name"] or "gemm256_kernel" in r["Kernel_Name"] or "gemm_lw_kernel" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 lines = [l.split() for l in open(log) if l.strip()]
 print("dispatches %d, log lines %d" % (len(rows), len(lines)))
 n = min(len(rows), len(lines))
 agg = defaultdict(lambda: [0, 0.0])
 for r, l in zip(rows[-n:], lines[-n:]):
-    key = tuple(l) + (("g%s" % r["Kernel_Name"].split("<")[1].split(",")[0].split(">")[0]) if "gemm256" in r["Kernel_Name"] else "",)
+    kn = r["Kernel_Name"]
+    tag = ""
+    if "gemm256" in kn:
+        tag = "g%s" % kn.split("<")[1].split(",")[0].split(">")[0]
+    elif "gemm_lw" in kn:
+        a = kn.split("<")[1].split(">")[0].split(",")
+        tag = "L%sx%s" % (a[0].strip(), a[1].strip())
+    key = tuple(l) + (tag,)
     agg[key][0] += 1
     agg[key][1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
 tot = 0.0

@@ -196,7 +196,8 @@ def do_train(cfg, model, resume=False):
                 pending = []
                 for w in writers:
                     w.write()
-            extra = {"model_ema": kwargs["model_ema"].state_dict()} if kwargs else {}
+            # (the EMA state dict materialises permuted copies of the box heads' first FC: only when a checkpoint is written)
+            extra = {"model_ema": kwargs["model_ema"].state_dict()} if (kwargs and saves_now) else {}
             periodic.step(iteration, **extra)
         logger.info("Total training time: {}".format(str(datetime.timedelta(seconds=int(time.perf_counter() - t_start)))))
     return optimizer

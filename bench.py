@@ -39,7 +39,13 @@ def parse():
                         "differ from step to step, so the data-dependent paths are inside the timed region")
     p.add_argument("--launch-check", action="store_true",
                    help="bring up the N ranks, run the collective self-check and print its JSON line; no model, no GPU needed "
-                        "(backend from DGX_DIST_BACKEND, default nccl = RCCL)")
+                        "(see --backend)")
+    # The three flags below exist for ONE purpose: exercising the multi-rank code path (reducer hooks, graph capture next to
+    # collectives, CenterNet normaliser all-reduces) where no N-GPU node is at hand.  None of them changes a measured number.
+    p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="collective backend (nccl = RCCL on ROCm)")
+    p.add_argument("--share-device", type=int, default=None, metavar="D",
+                   help="all ranks on GPU D: N-rank plumbing test on a one-GPU box (use with --backend gloo); not a scaling run")
+    p.add_argument("--force-pg", action="store_true", help="create a process group even at N = 1 (RCCL next to hipGraph capture)")
     return p.parse_args()
 
 
@@ -245,16 +251,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    # DGX_FORCE_DEVICE / DGX_DIST_BACKEND exist for ONE purpose: exercising the multi-rank code path (reducer hooks,
-    # graph capture next to collectives, CenterNet normaliser all-reduces) on a single-GPU box with gloo
-    if "DGX_FORCE_DEVICE" in os.environ:
-        local = int(os.environ["DGX_FORCE_DEVICE"])
-    backend = os.environ.get("DGX_DIST_BACKEND", "nccl")
+    if a.share_device is not None:
+        local = a.share_device
+    backend = a.backend
     on_gpu = not (a.launch_check and backend != "nccl")      # the launch check over gloo runs without a GPU (CPU-container test)
     if on_gpu:
         torch.cuda.set_device(local)
     dev = torch.device("cuda", local) if on_gpu else torch.device("cpu")
-    if world > 1 or os.environ.get("DGX_FORCE_PG") == "1":      # DGX_FORCE_PG: a 1-rank RCCL group, to test RCCL next to graph capture
+    if world > 1 or a.force_pg:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -276,7 +280,7 @@ def main():
         ranks_seen = int(probe[0].item())
         devs = [int(v) - 1 for v in probe[1:].tolist()]
         assert ranks_seen == world, "collective saw %d of %d ranks" % (ranks_seen, world)
-        assert "DGX_FORCE_DEVICE" in os.environ or not on_gpu or len(set(devs)) == world, "ranks share GPUs: %s" % devs
+        assert a.share_device is not None or not on_gpu or len(set(devs)) == world, "ranks share GPUs: %s" % devs
     if a.launch_check:
         if world > 1:
             dist.barrier()
@@ -288,12 +292,6 @@ def main():
         if rank == 0:
             print(json.dumps(line), flush=True)
         return
-    # DGX_GRAPH_BACKBONE=1 (opt-in) replays the static-shape backbone fwd+bwd as a hipGraph: -6 % step
-    # time at N=1 (the step is CPU-launch-bound), but per-kernel HIP events (the roofline object) and the
-    # per-layer gradient readiness the arena reducer overlaps on are only available on the eager path,
-    # which is therefore the default and what `value` reports.
-    os.environ.setdefault("DGX_GRAPH_BACKBONE", "0")
-
     from divergen_amd import _lib
     from divergen_amd import layers as la
     from divergen_amd.config import get_cfg
@@ -313,7 +311,7 @@ def main():
     model = build_model(cfg).train()
     opt = build_optimizer(cfg, model)
     sched = build_lr_scheduler(cfg, opt)
-    reducer = ArenaReducer(opt.arena)
+    reducer = ArenaReducer(opt.arena, single_rank_group=a.force_pg)
     reducer.broadcast_parameters()
     if opt.ema is not None:
         opt.ema.copy_(opt.arena.p)

@@ -1,6 +1,7 @@
-// Shared pieces of libdgx's forward / input-gradient GEMM kernels (gemm_nt.hip: 8 waves, LDS-direct operands; gemm256.hip:
-// 4 waves, AGPR accumulators, register-staged A operand): problem descriptor, LDS-direct load helper, exact-GELU arithmetic and
-// the fused tails of the read-out (bias | bias + GELU with both tensors | x GELU'(f1) | window-reverse + DropPath + residual).
+// Shared pieces of libdgx's forward / input-gradient GEMM kernels (gemm_nt.hip: 8 waves that load their own operands, two workgroups
+// per CU for the short contractions; gemm_lw.hip: 8 MFMA waves + 4 loader waves, persistent): problem descriptor, LDS-direct load
+// helper, exact-GELU arithmetic and the fused tails of the read-out (bias | bias + GELU with both tensors | x GELU'(f1) |
+// x ReLU'(act) | window-reverse + DropPath + residual).
 #pragma once
 #include "dgx_common.h"
 
@@ -49,9 +50,6 @@ constexpr int GEMM_MAXG = 6;
 }  // namespace dgxgemm
 using dgxgemm::GMap;
 using dgxgemm::GemmP;
-// gemm256.hip: 256 x BN tiles (BN = 256 | 192), one tile per workgroup; plain / bias / GELU / GELU' / residual tails, no split-K
-int gemm256_launch(GemmP& P, int bn, hipStream_t st);
-bool gemm256_supported(const GemmP& P);
 
 namespace {
 

@@ -601,7 +601,7 @@ extern "C" int dgx_gemm_bf16_nt(const void* A, const void* B, int M, int N, int 
     DgxProfScope prof(DGX_PROF_GEMM_NT, stream, 2.0 * mn * K, 2.0 * ((double)M * K + (double)N * K) + obytes);
     if (FILE* lf = gemm_log_file()) { fprintf(lf, "%d %d %d %d %d %d\n", M, N, K, ep->mode, (use_two_wg(P) && !use_lw(P)) ? 128 : tc.bm, tc.bn); fflush(lf); }
 #ifdef DGX_GEMM_DEV
-    if (const char* dg = getenv("DGX_GEMM256") ? nullptr : getenv("DGX_GEMM_DIAG")) {
+    if (const char* dg = getenv("DGX_GEMM_DIAG")) {
         switch (atoi(dg)) {
             case 1: return launch_gemm<256, 192, 2, 2, 1>(P, st);
             case 2: return launch_gemm<256, 192, 2, 2, 2>(P, st);
@@ -623,20 +623,6 @@ extern "C" int dgx_gemm_bf16_nt(const void* A, const void* B, int M, int N, int 
 
 static int dgx_gemm_dispatch(GemmP& P, hipStream_t st) {
     const TileChoice tc = choose_tile(P.M, P.N);
-    // The 4-wave 256 x BN kernel (gemm256.hip) is NOT dispatched by default.  Measured in round 3 (profiles/r03_gemm256_*.txt):
-    // back to back on hot operands with the bias tail it is 5-18 % faster than the tiles below on the problems that fill the
-    // chip for >= ~1.75 rounds (stage-0 / stage-1 fc1, fc2 input gradient, qkv; stage-2 qkv / fc1), but inside the training step
-    // -- GELU / GELU' / residual tails, operands written by the previous kernel -- the GEMM family came out 0.2-0.3 ms per step
-    // SLOWER with it (13.7 vs 13.4 ms), so the 8-wave kernel stays the product path.  DGX_GEMM256 = 256 | 192 forces the new
-    // kernel wherever it is supported (development, tools/gemm_shapes_probe.py / gemm_phase_probe.py).
-    if (const char* e = getenv("DGX_GEMM256")) {
-        const int force = atoi(e);
-        if ((force == 256 || force == 192) && gemm256_supported(P)) {
-            const int nt = (P.K + GBK - 1) / GBK;
-            const int64_t tiles = (int64_t)((P.M + 255) / 256) * ((P.N + force - 1) / force);
-            if (choose_splits(tiles, P.K, P.M, P.N, P.ws ? g_ws_bytes_cur : 0) == 1 || nt < 8 || tiles > 128) return gemm256_launch(P, force, st);
-        }
-    }
     if (use_lw(P)) return launch_lw(P, tc.bm, tc.bn, st);
     if (tc.bn == 192) {
         // contractions of up to 12 K-tiles (K <= 768: every qkv / proj / fc1 / fc2-input-gradient GEMM of the backbone) spend a third of

@@ -55,6 +55,31 @@ template <> __device__ __forceinline__ void st4<uint16_t>(uint16_t* row, int i, 
     reinterpret_cast<uint2*>(row)[i] = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
 }
 
+// a row quad as loaded (kept packed in registers: 2 registers for bf16, 4 for fp32) and its fp32 expansion
+template <typename T> struct Raw4;
+template <> struct Raw4<float> {
+    typedef float4 type;
+    static __device__ __forceinline__ float4 ld(const float* row, int i) { return reinterpret_cast<const float4*>(row)[i]; }
+    static __device__ __forceinline__ float4 f(float4 r) { return r; }
+    static __device__ __forceinline__ float4 zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+};
+template <> struct Raw4<uint16_t> {
+    typedef uint2 type;
+    static __device__ __forceinline__ uint2 ld(const uint16_t* row, int i) { return reinterpret_cast<const uint2*>(row)[i]; }
+    static __device__ __forceinline__ float4 f(uint2 d) {
+        return make_float4(__uint_as_float(d.x << 16), __uint_as_float(d.x & 0xffff0000u), __uint_as_float(d.y << 16), __uint_as_float(d.y & 0xffff0000u));
+    }
+    static __device__ __forceinline__ uint2 zero() { return make_uint2(0u, 0u); }
+};
+
+// v as it reads back after a store in type T
+template <typename T> __device__ __forceinline__ float4 rnd4(float4 v);
+template <> __device__ __forceinline__ float4 rnd4<float>(float4 v) { return v; }
+template <> __device__ __forceinline__ float4 rnd4<uint16_t>(float4 v) {
+    const uint32_t a = pack_bf2(v.x, v.y), b = pack_bf2(v.z, v.w);
+    return make_float4(__uint_as_float(a << 16), __uint_as_float(a & 0xffff0000u), __uint_as_float(b << 16), __uint_as_float(b & 0xffff0000u));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -73,6 +98,58 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const XT* __restrict__ x, c
     const int64_t nwaves = (int64_t)gridDim.x * 4;
     const float4* g4 = reinterpret_cast<const float4*>(gamma);
     const float4* b4 = reinterpret_cast<const float4*>(beta);
+    if (NJ > 0) {
+        // two rows per trip: both rows' loads are in flight before the first row's reductions (one wave = 1-3 rows of a Swin
+        // stage: the kernel is one memory latency long, not one per row); the arithmetic per row is unchanged
+        for (int64_t orow0 = wave; orow0 < T_out; orow0 += 2 * nwaves) {
+            float4 v[2][NJ > 0 ? NJ : 1];
+            int64_t toks[2], orows[2] = {orow0, orow0 + nwaves};
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                toks[u] = orows[u] < T_out ? (m.ws ? win_src(m, orows[u]) : orows[u]) : -2;      // -1: padding row, -2: no row
+                if (toks[u] >= 0) {
+                    const XT* xr = x + toks[u] * C;
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        const int i = lane + 64 * j;
+                        v[u][j] = i < C / 4 ? ld4<XT>(xr, i) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (toks[u] == -2) continue;
+                YT* yo = y + orows[u] * C;
+                if (toks[u] < 0) {
+                    for (int i = lane; i < C / 4; i += 64) st4<YT>(yo, i, make_float4(0.f, 0.f, 0.f, 0.f));
+                    continue;
+                }
+                float s = 0.f;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) s += (v[u][j].x + v[u][j].y) + (v[u][j].z + v[u][j].w);
+                const float mu = wave_sum(s) / (float)C;
+                float q = 0.f;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    if (lane + 64 * j < C / 4) {
+                        const float a = v[u][j].x - mu, b = v[u][j].y - mu, c = v[u][j].z - mu, d = v[u][j].w - mu;
+                        q += (a * a + b * b) + (c * c + d * d);
+                    }
+                const float rs = rsqrtf(wave_sum(q) / (float)C + eps);
+                if (lane == 0) { mean[toks[u]] = mu; rstd[toks[u]] = rs; }
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const int i = lane + 64 * j;
+                    if (i < C / 4) {
+                        const float4 g = g4[i], b = b4[i];
+                        st4<YT>(yo, i, make_float4((v[u][j].x - mu) * rs * g.x + b.x, (v[u][j].y - mu) * rs * g.y + b.y,
+                                                   (v[u][j].z - mu) * rs * g.z + b.z, (v[u][j].w - mu) * rs * g.w + b.w));
+                    }
+                }
+            }
+        }
+        return;
+    }
     for (int64_t orow = wave; orow < T_out; orow += nwaves) {
         const int64_t tok = m.ws ? win_src(m, orow) : orow;
         YT* yo = y + orow * C;
@@ -81,36 +158,6 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const XT* __restrict__ x, c
             continue;
         }
         const XT* xr = x + tok * C;
-        if (NJ > 0) {
-            float4 v[NJ > 0 ? NJ : 1];
-            float s = 0.f;
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int i = lane + 64 * j;
-                v[j] = i < C / 4 ? ld4<XT>(xr, i) : make_float4(0.f, 0.f, 0.f, 0.f);
-                s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
-            }
-            const float mu = wave_sum(s) / (float)C;
-            float q = 0.f;
-#pragma unroll
-            for (int j = 0; j < NJ; ++j)
-                if (lane + 64 * j < C / 4) {
-                    const float a = v[j].x - mu, b = v[j].y - mu, c = v[j].z - mu, d = v[j].w - mu;
-                    q += (a * a + b * b) + (c * c + d * d);
-                }
-            const float rs = rsqrtf(wave_sum(q) / (float)C + eps);
-            if (lane == 0) { mean[tok] = mu; rstd[tok] = rs; }
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int i = lane + 64 * j;
-                if (i < C / 4) {
-                    const float4 g = g4[i], b = b4[i];
-                    st4<YT>(yo, i, make_float4((v[j].x - mu) * rs * g.x + b.x, (v[j].y - mu) * rs * g.y + b.y,
-                                               (v[j].z - mu) * rs * g.z + b.z, (v[j].w - mu) * rs * g.w + b.w));
-                }
-            }
-            continue;
-        }
         float s = 0.f;
         for (int i = lane; i < C / 4; i += 64) { const float4 v = ld4<XT>(xr, i); s += (v.x + v.y) + (v.z + v.w); }
         const float mu = wave_sum(s) / (float)C;
@@ -132,11 +179,17 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const XT* __restrict__ x, c
 
 // NJ = ceil(C/256): float4 columns per lane
 constexpr int LNB_WAVES = 8;          // waves per backward workgroup: one partial row of (dgamma | dbeta) per workgroup
-template <int NJ, typename XT, typename DT = uint16_t>
-__global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const DT* __restrict__ dy, const XT* __restrict__ x,
+// EMIT (dgx_layernorm_bwd_emit): the kernel also writes  emit[row(tok)] = bf16(escale[b] * dx[tok])  -- the operand of the NEXT
+// GEMM of the backward pass -- in token order (em.ws == 0) or in window order (zero rows for the padding tokens), i.e. what a
+// separate dgx_residual_bwd pass over dx produced before (one read of dx and one launch less per use).  The value is formed from
+// dx AS STORED (rounded to its dtype first), so the two-kernel path gives the same bits.
+template <int NJ, typename XT, typename DT = uint16_t, bool EMIT = false>
+__global__ __launch_bounds__(64 * LNB_WAVES, ((NJ <= 2 || (NJ == 3 && sizeof(XT) == 2)) ? 4 : 2)) void ln_bwd_kernel(const DT* __restrict__ dy, const XT* __restrict__ x,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, const XT* dres, XT* dx,
-                                                     float* __restrict__ part, int64_t T, int C, WinMap m) {
+                                                     float* __restrict__ part, int64_t T, int C, WinMap m,
+                                                     uint16_t* __restrict__ emit = nullptr, const float* __restrict__ escale = nullptr,
+                                                     WinMap em = WinMap{0, 0, 0, 0, 0, 0, 0}) {
     __shared__ float red[2][NJ * 256];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t wave = (int64_t)blockIdx.x * LNB_WAVES + w;
@@ -150,7 +203,13 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const DT* __rest
     // two rows per trip: both rows' loads are in flight before the first row's reductions (T / waves = 2 rows per wave at
     // Swin-L stage 2: one memory latency per launch instead of two on a 16 us kernel)
     for (int64_t tok0 = wave; tok0 < T; tok0 += 2 * nwaves) {
-        float xh[2][NJ][4], gv[2][NJ][4], s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f}, rsv[2] = {0.f, 0.f};
+        // The two rows stay in registers AS LOADED (packed: 6 registers per bf16 quad for x, dy and the residual-branch gradient,
+        // requested together: one memory latency per trip); x_hat and dy * gamma are formed twice, for the sums and for the
+        // result, by the same operations.  (Holding them as fp32 took 158-169 registers: one 8-wave workgroup per CU and two
+        // rounds of the chip for the 512 workgroups of a stage-2 launch -- 15 -> 21 us; this form stays under 128.)
+        typename Raw4<XT>::type xr_[2][NJ], rr_[2][NJ];
+        typename Raw4<DT>::type dr_[2][NJ];
+        float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f}, rsv[2] = {0.f, 0.f}, muv[2] = {0.f, 0.f};
         int64_t toks[2] = {tok0, tok0 + nwaves};
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -159,23 +218,35 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const DT* __rest
             const int64_t drow = m.ws ? win_dst(m, tok) : tok;
             const DT* dyr = dy + drow * C;
             const XT* xr = x + tok * C;
-            const float mu = mean[tok], rs = rstd[tok];
-            rsv[u] = rs;
+            const XT* drr0 = dres ? dres + tok * C : nullptr;
+            muv[u] = mean[tok];
+            rsv[u] = rstd[tok];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int i = lane + 64 * j;
+                const bool in = i < C / 4;
+                xr_[u][j] = in ? Raw4<XT>::ld(xr, i) : Raw4<XT>::zero();
+                dr_[u][j] = in ? Raw4<DT>::ld(dyr, i) : Raw4<DT>::zero();
+                rr_[u][j] = (in && drr0) ? Raw4<XT>::ld(drr0, i) : Raw4<XT>::zero();
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (toks[u] >= T) continue;
+            const float mu = muv[u], rs = rsv[u];
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 const int i = lane + 64 * j;
                 if (i < C / 4) {
-                    const float4 v = ld4<XT>(xr, i), g = g4[i];
-                    const float4 d4 = ld4<DT>(dyr, i);
+                    const float4 v = Raw4<XT>::f(xr_[u][j]), g = g4[i], d4 = Raw4<DT>::f(dr_[u][j]);
                     const float dv[4] = {d4.x, d4.y, d4.z, d4.w};
                     const float xv[4] = {v.x, v.y, v.z, v.w}, gg[4] = {g.x, g.y, g.z, g.w};
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        xh[u][j][k] = (xv[k] - mu) * rs;
-                        gv[u][j][k] = dv[k] * gg[k];
-                        s1[u] += gv[u][j][k];
-                        s2[u] += gv[u][j][k] * xh[u][j][k];
-                        dg[j][k] += dv[k] * xh[u][j][k];
+                        const float xh = (xv[k] - mu) * rs, gv = dv[k] * gg[k];
+                        s1[u] += gv;
+                        s2[u] += gv * xh;
+                        dg[j][k] += dv[k] * xh;
                         db[j][k] += dv[k];
                     }
                 }
@@ -185,23 +256,47 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const DT* __rest
         for (int u = 0; u < 2; ++u) {
             const int64_t tok = toks[u];
             if (tok >= T) continue;
-            const float a1 = wave_sum(s1[u]) / (float)C, a2 = wave_sum(s2[u]) / (float)C, rs = rsv[u];
+            const float a1 = wave_sum(s1[u]) / (float)C, a2 = wave_sum(s2[u]) / (float)C, rs = rsv[u], mu = muv[u];
             XT* dxr = dx + tok * C;
-            const XT* drr = dres ? dres + tok * C : nullptr;   // gradient arriving on the residual branch (may alias dx)
+            uint16_t* er = nullptr;
+            float es = 1.0f;
+            if (EMIT) {
+                er = emit + (em.ws ? win_dst(em, tok) : tok) * C;
+                if (escale) es = escale[(int)(tok / ((int64_t)em.H * em.W))];
+            }
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 const int i = lane + 64 * j;
                 if (i < C / 4) {
-                    float4 o = make_float4(rs * (gv[u][j][0] - a1 - xh[u][j][0] * a2), rs * (gv[u][j][1] - a1 - xh[u][j][1] * a2),
-                                           rs * (gv[u][j][2] - a1 - xh[u][j][2] * a2), rs * (gv[u][j][3] - a1 - xh[u][j][3] * a2));
-                    if (drr) {
-                        const float4 a = ld4<XT>(drr, i);
+                    const float4 v = Raw4<XT>::f(xr_[u][j]), g = g4[i], d4 = Raw4<DT>::f(dr_[u][j]);
+                    const float dv[4] = {d4.x, d4.y, d4.z, d4.w};
+                    const float xv[4] = {v.x, v.y, v.z, v.w}, gg[4] = {g.x, g.y, g.z, g.w};
+                    float ov[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float xh = (xv[k] - mu) * rs, gv = dv[k] * gg[k];
+                        ov[k] = rs * (gv - a1 - xh * a2);
+                    }
+                    float4 o = make_float4(ov[0], ov[1], ov[2], ov[3]);
+                    if (dres) {                // gradient arriving on the residual branch (may alias dx: read above, before this store)
+                        const float4 a = Raw4<XT>::f(rr_[u][j]);
                         o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
                     }
                     st4<XT>(dxr, i, o);
+                    if (EMIT) {
+                        const float4 r = rnd4<XT>(o);     // dx as stored
+                        st4<uint16_t>(er, i, make_float4(es * r.x, es * r.y, es * r.z, es * r.w));
+                    }
                 }
             }
         }
+    }
+    if (EMIT && em.ws) {                       // window order: the rows of the padding tokens are zero
+        const int64_t rows = (int64_t)em.B * em.nWh * em.nWw * em.ws * em.ws;
+        if (rows != T)
+            for (int64_t orow = wave; orow < rows; orow += nwaves)
+                if (win_src(em, orow) < 0)
+                    for (int i = lane; i < C / 4; i += 64) st4<uint16_t>(emit + orow * C, i, make_float4(0.f, 0.f, 0.f, 0.f));
     }
     // block partials: the 8 waves fold into one LDS row in turn -> one row of `part` per block: [block][2][C]
     // (tried: every wave into its own LDS row + one barrier -- 49 KB of LDS per workgroup cost more occupancy than the seven barriers:
@@ -285,8 +380,9 @@ extern "C" int dgx_layernorm_fwd(const void* x, const float* gamma, const float*
         return DGX_ERR_BAD_ARG;
     const WinMap m = make_map(B, H, W, ws, shift);
     const int64_t T_out = ws > 0 ? (int64_t)B * m.nWh * m.nWw * ws * ws : T;
-    const int grid = (int)((T_out + 3) / 4 < 8192 ? (T_out + 3) / 4 : 8192);
     const int nj = (C + 255) / 256;
+    const int64_t per_wg = nj <= 6 ? 8 : 4;       // rows per workgroup and trip: 4 waves x 2 rows (register-resident rows)
+    const int grid = (int)((T_out + per_wg - 1) / per_wg < 8192 ? (T_out + per_wg - 1) / per_wg : 8192);
 #define LN_FWD(XT, YT, YP, NJ) hipLaunchKernelGGL((ln_fwd_kernel<XT, YT, NJ>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const XT*)x, \
                                                   gamma, beta, (YT*)YP, mean, rstd, T_out, C, eps, m)
 #define LN_FWD_NJ(XT, YT, YP)                                                                                          \
@@ -308,35 +404,57 @@ extern "C" int dgx_layernorm_bwd_blocks(int64_t T) {
     return (int)(b < 512 ? (b < 1 ? 1 : b) : 512);
 }
 
-extern "C" int dgx_layernorm_bwd(const void* dy_bf16, const void* x, const float* mean, const float* rstd,
-                                 const float* gamma, const void* dres, void* dx, float* dgamma, float* dbeta, float* part,
-                                 int64_t T, int C, int B, int H, int W, int ws, int shift, int x_dtype, void* stream) {
+static int ln_bwd_launch(const void* dy_bf16, const void* x, const float* mean, const float* rstd, const float* gamma, const void* dres,
+                         void* dx, float* dgamma, float* dbeta, float* part, int64_t T, int C, int B, int H, int W, int ws, int shift,
+                         int x_dtype, void* emit, const float* escale, int eB, int eH, int eW, int ews, int eshift, void* stream) {
     if (T <= 0) return DGX_OK;
     if (!dy_bf16 || !x || !mean || !rstd || !gamma || !dx || ((dgamma == nullptr) != (dbeta == nullptr)) || !part || (C & 3) || C > 1536 ||
         (ws > 0 && (int64_t)B * H * W != T))
         return DGX_ERR_BAD_ARG;
+    if (emit && ((int64_t)eB * eH * eW != T || eshift < 0 || (ews > 0 && eshift >= ews))) return DGX_ERR_BAD_ARG;
     const WinMap m = make_map(B, H, W, ws, shift);
+    const WinMap em = emit ? make_map(eB, eH, eW, ews, eshift) : WinMap{0, 0, 0, 0, 0, 0, 0};
     const int grid = dgx_layernorm_bwd_blocks(T);
     hipStream_t st = (hipStream_t)stream;
     const int nj = (C + 255) / 256;
-#define LN_BWD(NJ)                                                                                                         \
-    do {                                                                                                                   \
-        if (x_dtype == DGX_BF16)                                                                                           \
-            hipLaunchKernelGGL((ln_bwd_kernel<NJ, uint16_t>), dim3(grid), dim3(64 * LNB_WAVES), 0, st, (const uint16_t*)dy_bf16,       \
-                               (const uint16_t*)x, mean, rstd, gamma, (const uint16_t*)dres, (uint16_t*)dx, part, T, C, m);                        \
-        else                                                                                                               \
-            hipLaunchKernelGGL((ln_bwd_kernel<NJ, float>), dim3(grid), dim3(64 * LNB_WAVES), 0, st, (const uint16_t*)dy_bf16,          \
-                               (const float*)x, mean, rstd, gamma, (const float*)dres, (float*)dx, part, T, C, m);                              \
+#define LN_BWD_E(NJ, E)                                                                                                                \
+    do {                                                                                                                               \
+        if (x_dtype == DGX_BF16)                                                                                                       \
+            hipLaunchKernelGGL((ln_bwd_kernel<NJ, uint16_t, uint16_t, E>), dim3(grid), dim3(64 * LNB_WAVES), 0, st, (const uint16_t*)dy_bf16, \
+                               (const uint16_t*)x, mean, rstd, gamma, (const uint16_t*)dres, (uint16_t*)dx, part, T, C, m, (uint16_t*)emit,   \
+                               escale, em);                                                                                            \
+        else                                                                                                                           \
+            hipLaunchKernelGGL((ln_bwd_kernel<NJ, float, uint16_t, E>), dim3(grid), dim3(64 * LNB_WAVES), 0, st, (const uint16_t*)dy_bf16,    \
+                               (const float*)x, mean, rstd, gamma, (const float*)dres, (float*)dx, part, T, C, m, (uint16_t*)emit, escale,    \
+                               em);                                                                                                    \
     } while (0)
+#define LN_BWD(NJ) do { if (emit) LN_BWD_E(NJ, true); else LN_BWD_E(NJ, false); } while (0)
     if (nj <= 1) LN_BWD(1);
     else if (nj <= 2) LN_BWD(2);
     else if (nj <= 3) LN_BWD(3);
     else LN_BWD(6);
 #undef LN_BWD
+#undef LN_BWD_E
     // dgamma == dbeta == NULL: the per-block partial rows stay in `part` for dgx_layernorm_param_reduce2 (two norms, one launch)
     if (dgamma) hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * C / 4 + LNR_QB - 1) / LNR_QB), dim3(1024), 0, st, part, dgamma, dbeta, grid, C);
     DGX_LAUNCH_CHECK();
     return DGX_OK;
+}
+
+extern "C" int dgx_layernorm_bwd(const void* dy_bf16, const void* x, const float* mean, const float* rstd,
+                                 const float* gamma, const void* dres, void* dx, float* dgamma, float* dbeta, float* part,
+                                 int64_t T, int C, int B, int H, int W, int ws, int shift, int x_dtype, void* stream) {
+    return ln_bwd_launch(dy_bf16, x, mean, rstd, gamma, dres, dx, dgamma, dbeta, part, T, C, B, H, W, ws, shift, x_dtype, nullptr, nullptr,
+                         0, 0, 0, 0, 0, stream);
+}
+
+extern "C" int dgx_layernorm_bwd_emit(const void* dy_bf16, const void* x, const float* mean, const float* rstd, const float* gamma,
+                                      const void* dres, void* dx, float* dgamma, float* dbeta, float* part, int64_t T, int C, int B,
+                                      int H, int W, int ws, int shift, int x_dtype, void* emit_bf16, const float* emit_scale, int eB,
+                                      int eH, int eW, int ews, int eshift, void* stream) {
+    if (!emit_bf16) return DGX_ERR_BAD_ARG;
+    return ln_bwd_launch(dy_bf16, x, mean, rstd, gamma, dres, dx, dgamma, dbeta, part, T, C, B, H, W, ws, shift, x_dtype, emit_bf16,
+                         emit_scale, eB, eH, eW, ews, eshift, stream);
 }
 
 struct LnRed2 { const float* part[2]; float* dgamma[2]; float* dbeta[2]; };

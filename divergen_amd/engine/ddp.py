@@ -28,7 +28,7 @@ from ..layers import linear_ops
 
 
 class ArenaReducer:
-    def __init__(self, arena, bucket_bytes=64 << 20, process_group=None):
+    def __init__(self, arena, bucket_bytes=64 << 20, process_group=None, single_rank_group=False):
         self.arena, self.group = arena, process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         n = len(arena.params)
@@ -53,7 +53,8 @@ class ArenaReducer:
         self.last_early = 0
         self._got = [0] * n            # ready signals of this step, per parameter
         self._expected = None          # learned from the first step; None = calibrating (no early launches)
-        self.active = self.world > 1 or (dist.is_initialized() and os.environ.get("DGX_FORCE_PG") == "1")
+        # single_rank_group: reduce over a one-rank group as well (bench.py --force-pg: RCCL next to hipGraph capture on one GPU)
+        self.active = self.world > 1 or (dist.is_initialized() and single_rank_group)
         if self.active:
             for i, p in enumerate(arena.params):
                 hook = self._make_hook(i)

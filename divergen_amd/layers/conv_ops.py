@@ -84,11 +84,11 @@ class _Conv3x3(torch.autograd.Function):
             notify_ready(ctx.weight)
         elif ctx.needs_input_grad[1]:
             def wgrad():
-                if col.dtype == torch.bfloat16:
-                    g = torch.empty(9 * C, g2.shape[1], dtype=torch.float32, device=col.device)
-                    wgrad_into(g, col, g2.contiguous(), beta=0.0)      # M-split MFMA kernel for long M
-                else:
-                    g = (col.t() @ g2).float()
+                if col.dtype != torch.bfloat16:
+                    raise L.DgxError("conv3x3 weight gradient: bf16 operands required (got %s): the only GEMM on the path is "
+                                     "libdgx's" % col.dtype)
+                g = torch.empty(9 * C, g2.shape[1], dtype=torch.float32, device=col.device)
+                wgrad_into(g, col, g2.contiguous(), beta=0.0)      # M-split MFMA kernel for long M
                 return g.view(3, 3, C, -1).permute(3, 2, 0, 1)
             gw = accumulate_grad(ctx.weight, wgrad)
         if has_bias and ctx.needs_input_grad[2]:
@@ -542,7 +542,11 @@ class _Deconv2x2(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             def into(g):
                 wgrad_into(g.view(g.shape[0], -1), x2, g2)             # (Cin, 4 Cout) = x^T dy
-            gw = accumulate_grad(weight, lambda: torch.mm(x2.t(), g2, out_dtype=torch.float32).view(weight.shape), gemm_into=into)
+            def outside_arena():           # a deconvolution weight that does not live in a parameter arena: own GEMM into a temporary
+                g = torch.empty(weight.shape[0], weight.numel() // weight.shape[0], dtype=torch.float32, device=g2.device)
+                wgrad_into(g, x2, g2, beta=0.0)
+                return g.view(weight.shape)
+            gw = accumulate_grad(weight, outside_arena, gemm_into=into)
         if bias is not None and ctx.needs_input_grad[2]:
             def colsums():
                 from .swin_block import colsum_into

@@ -143,9 +143,25 @@ def _linear_bwd(dy2, x2, weight, bias, wgrads, gelu_of=None):
     return G.gemm_gelu_grad(dy2, wt, gelu_of) if gelu_of is not None else G.gemm_nt(dy2, wt)
 
 
+# Hand-over between consecutive blocks of a stage in the backward pass: block i+1's LayerNorm-1 backward writes block i's incoming
+# gradient g AND its DropPath-scaled bf16 copy (the operand of block i's fc2 gradients) in the same pass; block i picks the copy up
+# here instead of running dgx_residual_bwd over g.  The slot holds g itself, so its storage cannot be recycled while the entry is
+# live; a gradient that autograd accumulated from several consumers is another tensor and simply does not match.
+_HANDOVER = [None]        # (g tensor, scale tensor or None, scaled bf16 copy)
+
+
+def _take_handover(g, s2):
+    h, _HANDOVER[0] = _HANDOVER[0], None
+    if h is None or h[0].data_ptr() != g.data_ptr() or h[0].shape != g.shape or h[0].dtype != g.dtype:
+        return None
+    same_scale = (h[1] is None and s2 is None) or (h[1] is not None and s2 is not None and h[1].data_ptr() == s2.data_ptr())
+    return h[2] if same_scale else None
+
+
 class _SwinBlockFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, region, s1, s2, cfg, n1w, n1b, qw, qb, table, pw, pb, n2w, n2b, w1, b1, w2, b2):
+    def forward(ctx, x, region, s1, s2, cfg, prev_scale, n1w, n1b, qw, qb, table, pw, pb, n2w, n2b, w1, b1, w2, b2):
+        ctx.prev_scale = prev_scale                # (scale,) when x came straight out of another block of this kind (swin_block below)
         B, H, W, ws, shift, nH, scale, eps1, eps2 = cfg
         lib, st, dev = L.lib(), L.stream(), x.device
         x = x.contiguous()
@@ -197,23 +213,28 @@ class _SwinBlockFn(torch.autograd.Function):
         nW = (-(-H // ws)) * (-(-W // ws))
         B_, N = B * nW, ws * ws
         Tw = B_ * N
-        # MLP branch
-        df2 = torch.empty(T, C, dtype=BF16, device=dev)
-        L.check(lib.dgx_residual_bwd(g.data_ptr(), L.ptr(s2), df2.data_ptr(), B, H, W, C, 0, 0, code, st), "dgx_residual_bwd")
+        # MLP branch: df2 = s2 * g as bf16 -- handed over by the next block's LayerNorm-1 backward, g itself when there is nothing
+        # to scale or convert, a pass over g otherwise
+        df2 = _take_handover(g, s2)
+        if df2 is None:
+            if s2 is None and g.dtype == BF16:
+                df2 = g.view(T, C)
+            else:
+                df2 = torch.empty(T, C, dtype=BF16, device=dev)
+                L.check(lib.dgx_residual_bwd(g.data_ptr(), L.ptr(s2), df2.data_ptr(), B, H, W, C, 0, 0, code, st), "dgx_residual_bwd")
         wgrads = []
         df1 = _linear_bwd(df2, a, w2, b2, wgrads, gelu_of=f1)       # (df2 W2) * GELU'(f1)
         dh2 = _linear_bwd(df1, h2, w1, b1, wgrads)
         # LN2 backward + the residual-branch gradient g -> dx1
         nblk = lib.dgx_layernorm_bwd_blocks(T)
         part = torch.empty(2, nblk * 2 * C, dtype=torch.float32, device=dev)     # partial (dgamma | dbeta) rows of norm2, norm1
+        # ... and, from the same pass, the attention branch's operand dpr = s1 * dx1 in window order (zero rows for the padding)
         dx1 = torch.empty_like(x)
-        L.check(lib.dgx_layernorm_bwd(dh2.data_ptr(), x1.data_ptr(), mean2.data_ptr(), rstd2.data_ptr(), n2w.data_ptr(),
-                                      g.data_ptr(), dx1.data_ptr(), None, None, part[0].data_ptr(),
-                                      T, C, 0, 0, 0, 0, 0, code, st), "dgx_layernorm_bwd")
-        # attention branch
         dpr = torch.empty(Tw, C, dtype=BF16, device=dev)
-        L.check(lib.dgx_residual_bwd(dx1.data_ptr(), L.ptr(s1), dpr.data_ptr(), B, H, W, C, ws, shift, code, st),
-                "dgx_residual_bwd")
+        L.check(lib.dgx_layernorm_bwd_emit(dh2.data_ptr(), x1.data_ptr(), mean2.data_ptr(), rstd2.data_ptr(), n2w.data_ptr(),
+                                           g.data_ptr(), dx1.data_ptr(), None, None, part[0].data_ptr(),
+                                           T, C, 0, 0, 0, 0, 0, code, dpr.data_ptr(), L.ptr(s1), B, H, W, ws, shift, st),
+                "dgx_layernorm_bwd_emit")
         do = _linear_bwd(dpr, o, pw, pb, wgrads)
         dqkv = torch.empty_like(qkv)
         assert table.grad.stride() == table.stride()          # one pair of strides serves the table and its gradient
@@ -223,9 +244,18 @@ class _SwinBlockFn(torch.autograd.Function):
         _ready(table)
         dxw = _linear_bwd(dqkv, xw, qw, qb, wgrads)
         # LN1 backward through the window map, accumulated onto dx1 in place
-        L.check(lib.dgx_layernorm_bwd(dxw.data_ptr(), x.data_ptr(), mean1.data_ptr(), rstd1.data_ptr(), n1w.data_ptr(),
-                                      dx1.data_ptr(), dx1.data_ptr(), None, None, part[1].data_ptr(),
-                                      T, C, B, H, W, ws, shift, code, st), "dgx_layernorm_bwd")
+        prev = ctx.prev_scale                      # (scale,) when x came straight out of another block of this kind
+        if prev and (prev[0] is not None or dx1.dtype != BF16):
+            scaled = torch.empty(T, C, dtype=BF16, device=dev)      # the previous block's fc2-gradient operand, from this pass
+            L.check(lib.dgx_layernorm_bwd_emit(dxw.data_ptr(), x.data_ptr(), mean1.data_ptr(), rstd1.data_ptr(), n1w.data_ptr(),
+                                               dx1.data_ptr(), dx1.data_ptr(), None, None, part[1].data_ptr(),
+                                               T, C, B, H, W, ws, shift, code, scaled.data_ptr(), L.ptr(prev[0]), B, H, W, 0, 0, st),
+                    "dgx_layernorm_bwd_emit")
+            _HANDOVER[0] = (dx1, prev[0], scaled)
+        else:
+            L.check(lib.dgx_layernorm_bwd(dxw.data_ptr(), x.data_ptr(), mean1.data_ptr(), rstd1.data_ptr(), n1w.data_ptr(),
+                                          dx1.data_ptr(), dx1.data_ptr(), None, None, part[1].data_ptr(),
+                                          T, C, B, H, W, ws, shift, code, st), "dgx_layernorm_bwd")
         # the second stage of both norms' parameter gradients in one launch
         L.check(lib.dgx_layernorm_param_reduce2(part[0].data_ptr(), n2w.grad.data_ptr(), n2b.grad.data_ptr(), part[1].data_ptr(),
                                                 n1w.grad.data_ptr(), n1b.grad.data_ptr(), T, C, st), "dgx_layernorm_param_reduce2")
@@ -233,11 +263,14 @@ class _SwinBlockFn(torch.autograd.Function):
         # the four weight gradients of the block: one grouped launch (256x256 tiles, small M-split)
         # the four weight gradients of the block (256x256 tiles): launched together with the next block's (flush_wgrads)
         _defer_wgrads(wgrads, (w2, w1, pw, qw, b2, b1, pb, qb))
-        return (dx1,) + (None,) * 17
+        return (dx1,) + (None,) * 18
 
 
 def swin_block(x, region, s1, s2, cfg, params):
     """x (B, H*W, C) fp32|bf16 -> same.  cfg = (B, H, W, ws, shift, nH, scale, eps1, eps2); params in the
     order norm1.{w,b}, qkv.{w,b}, bias table, proj.{w,b}, norm2.{w,b}, fc1.{w,b}, fc2.{w,b}."""
+    prev = getattr(x, "_dgx_next_scale", None)     # left on x by the block that produced it (below)
     with torch.autocast("cuda", enabled=False):
-        return _SwinBlockFn.apply(x, region, s1, s2, cfg, *params)
+        out = _SwinBlockFn.apply(x, region, s1, s2, cfg, prev, *params)
+    out._dgx_next_scale = (s2,)                    # a tuple: None is a valid scale
+    return out

@@ -36,8 +36,6 @@ class CustomRCNN(nn.Module):
             raise NotImplementedError("cfg.FP16 False: this build computes in bf16 with fp32 accumulation on its own HIP kernels; "
                                       "an fp32-activation mode does not exist (every shipped configuration sets FP16: True)")
         # hipGraph capture of the static-shape backbone fwd+bwd (launch-bound otherwise: ~3.5k launches)
-        self.graph_backbone = os.environ.get("DGX_GRAPH_BACKBONE", "0") == "1"
-        self._graphed = {}
         self.return_proposal = False
 
     @classmethod
@@ -67,26 +65,10 @@ class CustomRCNN(nn.Module):
     def _patch_rows_ok(self, images):
         bu = getattr(self.backbone, "bottom_up", None)
         pe = getattr(bu, "patch_embed", None)
-        return (_FUSED_PREPROCESS and pe is not None and pe.patch_size == (4, 4) and not (self.graph_backbone and self.training)
+        return (_FUSED_PREPROCESS and pe is not None and pe.patch_size == (4, 4)
                 and all(im.is_cuda and im.dtype == torch.uint8 and im.dim() == 3 and im.shape[0] == 3 for im in images))
 
-    def _graphed_backbone(self, x):
-        key = (tuple(x.shape), self.fp16)
-        if key not in self._graphed:
-            names = list(self.backbone.output_shape().keys())
-            mod = _BackboneForGraph(self.backbone, names, self.fp16)
-            self._graphed[key] = (torch.cuda.make_graphed_callables(mod, (x.clone(),), allow_unused_input=True), names)
-            # the capture warm-up ran real backward passes whose in-place weight-gradient writes landed
-            # in the arena; this step's backward has not started yet, so clearing them is exact
-            for p in self.backbone.parameters():
-                if p.grad is not None:
-                    p.grad.zero_()
-        fn, names = self._graphed[key]
-        return dict(zip(names, fn(x)))
-
     def _features(self, images):
-        if self.graph_backbone and self.training:
-            return self._graphed_backbone(images.tensor.to(memory_format=torch.channels_last))
         with torch.autocast("cuda", dtype=torch.bfloat16):
             if images.patch_rows is not None:
                 return self.backbone(images.patch_rows)
@@ -139,19 +121,6 @@ class CustomRCNN(nn.Module):
         for r, inp, size in zip(results, batched_inputs, images.image_sizes):
             out.append({"instances": detector_postprocess(r, inp.get("height", size[0]), inp.get("width", size[1]))})
         return out
-
-
-class _BackboneForGraph(nn.Module):
-    """Tuple-output wrapper so torch.cuda.make_graphed_callables can capture backbone fwd+bwd."""
-
-    def __init__(self, backbone, names, amp):
-        super().__init__()
-        self.backbone, self.names, self.amp = backbone, names, amp
-
-    def forward(self, x):
-        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.amp, cache_enabled=False):
-            out = self.backbone(x)
-        return tuple(out[n] for n in self.names)
 
 
 def detector_postprocess(results, output_height, output_width, mask_threshold=0.5, mask_format="bitmask"):

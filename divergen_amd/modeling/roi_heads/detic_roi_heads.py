@@ -34,19 +34,6 @@ class _ScaleGradient(torch.autograd.Function):
         return g * ctx.scale, None
 
 
-# Opt-in: measured on MI355X (Swin-L, 1024^2, same box A/B) the side-stream mask branch costs +0.6 ms/step -- the cascade's
-# GEMMs already fill the chip and the cross-stream joins serialise the tail of the backward pass -- so it is OFF by default.
-_MASK_SIDE_STREAM = os.environ.get("DGX_MASK_SIDE_STREAM", "0") == "1"
-_SIDE_STREAMS = {}
-
-
-def _side_stream(dev):
-    key = str(dev)
-    if key not in _SIDE_STREAMS:
-        _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
-    return _SIDE_STREAMS[key]
-
-
 def _subsample_labels(labels, num_samples, positive_fraction, bg_label, pre=None):
     """D2/modeling/sampling.py:9-54 (two torch.randperm draws on the labels' device).  pre = (positive, negative) index lists
     computed by the caller for the whole batch behind ONE device->host read (label_and_sample_proposals); the draws and their
@@ -502,23 +489,6 @@ class DeticCascadeROIHeads(nn.Module):
                 losses = self._forward_box(features, proposals, targets, only_gt_proposals=True)
                 if targets[0].has("gt_masks"):
                     losses.update({k: v * self.mask_weight for k, v in self._forward_mask(features, proposals).items()})
-                return proposals, losses
-            dev = proposals[0].objectness_logits.device
-            if _MASK_SIDE_STREAM and self.mask_on and targets[0].has("gt_masks") and dev.type == "cuda" \
-                    and not torch.cuda.is_current_stream_capturing():
-                # The mask branch depends only on the sampled proposals and the FPN features, not on the box cascade: it
-                # runs on a second HIP stream next to the three cascade stages (each is a chain of small launches that
-                # leaves most CUs idle).  Autograd replays every node on the stream of its forward, so the two branches
-                # overlap in the backward pass as well; it also orders the feature-gradient accumulation.
-                main, side = torch.cuda.current_stream(dev), _side_stream(dev)
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    mask_losses = {k: v * self.mask_weight for k, v in self._forward_mask(features, proposals).items()}
-                losses = self._forward_box(features, proposals, targets)
-                main.wait_stream(side)
-                for v in mask_losses.values():
-                    v.record_stream(main)
-                losses.update(mask_losses)
                 return proposals, losses
             losses = self._forward_box(features, proposals, targets)
             if targets[0].has("gt_masks"):

@@ -335,6 +335,15 @@ int dgx_layernorm_bwd_blocks(int64_t T);
 int dgx_layernorm_bwd(const void* dy_bf16, const void* x, const float* mean, const float* rstd,
                       const float* gamma, const void* dres, void* dx, float* dgamma, float* dbeta, float* part,
                       int64_t T, int C, int B, int H, int W, int ws, int shift, int x_dtype, void* stream);
+/* dgx_layernorm_bwd that ALSO writes the operand of the next GEMM of the backward pass (what a separate dgx_residual_bwd pass over
+ * dx produces: the reference's roll / window_partition / DropPath backward of swintransformer.py:216-255):
+ *   emit_bf16[row(tok)] = bf16(emit_scale[b] * dx[tok]),  b = tok / (eH * eW),  emit_scale f32 (eB) or NULL,
+ * rows in token order (ews == 0) or in window order with zero rows for the padding tokens (ews > 0, eshift: the block's shift).
+ * eB * eH * eW == T.  The value is formed from dx as stored, so it equals the two-kernel result bit for bit. */
+int dgx_layernorm_bwd_emit(const void* dy_bf16, const void* x, const float* mean, const float* rstd, const float* gamma,
+                           const void* dres, void* dx, float* dgamma, float* dbeta, float* part, int64_t T, int C, int B, int H,
+                           int W, int ws, int shift, int x_dtype, void* emit_bf16, const float* emit_scale, int eB, int eH,
+                           int eW, int ews, int eshift, void* stream);
 /* dgx_layernorm_bwd with dgamma = dbeta = NULL leaves its per-block partial sums in `part`; this folds the partial rows of TWO
  * such calls (same T and C: norm2 and norm1 of one Swin block) into their parameter gradients in one launch, in the summation
  * order of the single-norm second stage (bit-identical results). */

@@ -703,6 +703,48 @@ def test_layernorm_bwd_residual_input(xdt):
         torch.testing.assert_close(dx.float().cpu(), want.cpu(), **tol)
 
 
+@pytest.mark.parametrize("xdt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("gather,ews,eshift,scaled", [(False, 7, 3, True), (False, 12, 0, False), (True, 0, 0, True), (False, 0, 0, True)])
+def test_layernorm_bwd_emit_equals_the_two_kernel_path(xdt, gather, ews, eshift, scaled):
+    """dgx_layernorm_bwd_emit = dgx_layernorm_bwd + dgx_residual_bwd over its dx, bit for bit: dx, the partial parameter-gradient
+    rows, and the emitted bf16 operand -- in window order (zero rows for the padding tokens, with and without shift) as the
+    LayerNorm-2 backward of a Swin block emits it, in token order as the LayerNorm-1 backward hands it to the previous block
+    (there the dy operand is itself gathered from window order and dx is accumulated in place)."""
+    from divergen_amd import _lib as L
+    B, H, W, C = 2, 17, 13, 384
+    g = torch.Generator().manual_seed(97 + ews)
+    T = B * H * W
+    x = torch.randn(B, H * W, C, generator=g).to(xdt).to(DEV)
+    gam = torch.randn(C, generator=g).to(DEV)
+    mean = x.float().mean(-1).reshape(-1).contiguous()
+    rstd = (x.float().var(-1, unbiased=False) + 1e-5).rsqrt().reshape(-1).contiguous()
+    dws, dshift = (7, 2) if gather else (0, 0)
+    nW = (-(-H // 7)) * (-(-W // 7))
+    dy = bf(torch.randn((B * nW * 49 if gather else T), C, generator=g)).to(DEV)
+    dres = torch.randn(B, H * W, C, generator=g).to(xdt).to(DEV)
+    scale = torch.tensor([0.0, 1.0 / 0.7], device=DEV) if scaled else None
+    lib = L.lib()
+    nblk = lib.dgx_layernorm_bwd_blocks(T)
+    rows = B * (-(-H // ews)) * (-(-W // ews)) * ews * ews if ews else T
+    # two kernels
+    dx_a, part_a = dres.clone(), torch.zeros(nblk * 2 * C, device=DEV)
+    L.check(lib.dgx_layernorm_bwd(L.ptr(dy), L.ptr(x), L.ptr(mean), L.ptr(rstd), L.ptr(gam), L.ptr(dx_a), L.ptr(dx_a), None, None,
+                                  L.ptr(part_a), T, C, B if gather else 0, H if gather else 0, W if gather else 0, dws, dshift,
+                                  L.dtype_code(x), L.stream()), "ln_bwd")
+    em_a = torch.full((rows, C), 7.0, dtype=torch.bfloat16, device=DEV)
+    L.check(lib.dgx_residual_bwd(L.ptr(dx_a), L.ptr(scale), L.ptr(em_a), B, H, W, C, ews, eshift, L.dtype_code(x), L.stream()), "res_bwd")
+    # one kernel
+    dx_b, part_b = dres.clone(), torch.zeros(nblk * 2 * C, device=DEV)
+    em_b = torch.full((rows, C), 9.0, dtype=torch.bfloat16, device=DEV)
+    L.check(lib.dgx_layernorm_bwd_emit(L.ptr(dy), L.ptr(x), L.ptr(mean), L.ptr(rstd), L.ptr(gam), L.ptr(dx_b), L.ptr(dx_b), None, None,
+                                       L.ptr(part_b), T, C, B if gather else 0, H if gather else 0, W if gather else 0, dws, dshift,
+                                       L.dtype_code(x), L.ptr(em_b), L.ptr(scale), B, H, W, ews, eshift, L.stream()), "ln_bwd_emit")
+    assert torch.equal(dx_a, dx_b) and torch.equal(part_a, part_b)
+    assert torch.equal(em_a.view(torch.int16), em_b.view(torch.int16))
+    if ews:
+        assert int((em_b.float().abs().sum(1) == 0).sum()) >= rows - T        # the padding rows are zero
+
+
 @pytest.mark.parametrize("shapes", [
     [(8192, 768, 3072), (8192, 3072, 768), (10368, 768, 768), (10368, 2304, 768)],     # Swin-L stage 2 block
     [(100, 192, 264), (8192, 40, 768), (4000, 768, 776)],                                # ragged: partial stages / tiles

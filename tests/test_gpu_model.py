@@ -1,5 +1,5 @@
-"""GPU tests of the assembled model: loss keys / finiteness, eager vs hipGraph-captured backbone
-gradients, and the fused optimizer step through the arenas."""
+"""GPU tests of the assembled model: loss keys / finiteness, eager vs hipGraph-replayed head segments, the whole training forward
+against the assembled oracle, and the fused optimizer step through the arenas."""
 import os
 
 import pytest
@@ -10,7 +10,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _build(graph, swin="T"):
-    os.environ["DGX_GRAPH_BACKBONE"] = "1" if graph else "0"
     from divergen_amd.config import get_cfg
     from divergen_amd.modeling import build_model
     from divergen_amd.modeling.backbone.swintransformer import DropPath
@@ -25,34 +24,6 @@ def _build(graph, swin="T"):
         if isinstance(m, DropPath):
             m.drop_prob = 0.0
     return cfg, model, build_optimizer(cfg, model)
-
-
-def _backbone_grads(graph):
-    from divergen_amd.structures import ImageList
-    cfg, model, opt = _build(graph)
-    g = torch.Generator().manual_seed(5)
-    img = torch.randn(2, 3, 224, 256, generator=g).cuda()
-    w = [torch.randn(s, generator=g).cuda() for s in ((2, 256, 28, 32), (2, 256, 14, 16), (2, 256, 7, 8), (2, 256, 4, 4), (2, 256, 2, 2))]
-    opt.zero_grad()
-    feats = model._features(ImageList(img, [(224, 256)] * 2))
-    loss = sum((feats[k].float() * wi).sum() for k, wi in zip(["p3", "p4", "p5", "p6", "p7"], w))
-    loss.backward()
-    torch.cuda.synchronize()
-    names = [n for n in opt.arena.names if n.startswith("backbone.")]
-    sel = {n: p.grad.detach().clone() for n, p in zip(opt.arena.names, opt.arena.params) if n in names}
-    return float(loss), sel
-
-
-def test_graphed_backbone_matches_eager():
-    l0, g0 = _backbone_grads(False)
-    l1, g1 = _backbone_grads(True)
-    assert abs(l0 - l1) <= 2e-3 * abs(l0)
-    worst = 0.0
-    for k in g0:
-        denom = g0[k].abs().max().clamp(min=1e-6)
-        worst = max(worst, float((g0[k] - g1[k]).abs().max() / denom))
-    assert worst < 2e-2, worst      # atomics / split-slab summation order only
-    assert any(float(v.abs().max()) > 0 for v in g0.values())
 
 
 def test_training_step_losses_and_update():

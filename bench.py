@@ -34,6 +34,9 @@ def parse():
     p.add_argument("--no-roofline", action="store_true", help="leave the per-launch HIP events off (A/B of their cost)")
     p.add_argument("--roofline-every", type=int, default=10, help="instrument every n-th timed step with per-launch HIP events")
     p.add_argument("--no-copy-paste", action="store_true")
+    p.add_argument("--inputs-resident", action="store_true",
+                   help="stage images, ground truth and paste patches in HBM before the timed region (the round-3 form) instead of "
+                        "uploading them from pinned host memory every step")
     p.add_argument("--distinct-batches", type=int, default=8,
                    help="synthetic (images, ground truth, paste sets) in rotation: proposal / foreground / paste-survivor counts then "
                         "differ from step to step, so the data-dependent paths are inside the timed region")
@@ -81,7 +84,7 @@ def make_pastes(rng, size, k=19):
 #   r03_bench_swinL_1024_kernel_stats.csv     rocprofv3 --kernel-trace --stats of THIS script (+ r03_profile_meta.json: steps)
 PROFILE_TAG = "r03"
 FAMILY_KERNELS = {   # family -> substrings of the kernel names rocprof reports for it
-    "gemm_nt": ("gemm_nt_kernel", "gemm_splitk_fold_kernel"),
+    "gemm_nt": ("gemm_nt_kernel", "gemm_lw_kernel", "gemm_splitk_fold_kernel"),
     "wgrad": ("wgrad256_partial_kernel", "wgrad256_reduce_kernel", "wgrad256_bias_reduce_kernel", "wgrad_partial_kernel", "wgrad_reduce_kernel"),
     "attn_fwd": ("win_attn_fwd_kernel",),
     "attn_bwd": ("win_attn_bwd_kernel",),
@@ -324,10 +327,28 @@ def main():
         n_gt = (12, 10, 14, 12, 8, 16, 11, 13)[j % 8]          # 12 objects per image on average, not the same every step
         bases.append(synthetic_batch(a.batch, a.size, cfg.MODEL.ROI_HEADS.NUM_CLASSES, seed=1234 + rank + 1000 * j, n_gt=n_gt, device=dev))
         ps = [make_pastes(rng, a.size) for _ in range(a.batch)]
-        # pre-stage the paste patches of each image in the form the compositor takes them (one flat device buffer + descriptors,
-        # layers.pack_pastes: what a loader worker hands over after its single host->device copy), so that the timed region starts
-        # with inputs resident in HBM
+        # the paste patches of each image in the form the compositor takes them (one flat buffer + descriptors, layers.pack_pastes:
+        # what a loader worker hands over)
         paste_sets.append([la.pack_pastes(p_, dev) for p_ in ps])
+    # What a loader worker hands the training process lives in HOST memory (rcnn.py:220-227 moves the images and the instances to
+    # the device inside the step): the uint8 image, the ground-truth masks / boxes / classes and the packed paste patches of every
+    # batch are kept in pinned host buffers and go up on the loader's side stream INSIDE the timed region, every step
+    # (--inputs-resident restores the round-3 form: everything staged in HBM before the clock starts).
+    h2d_bytes = [0]
+
+    def pin(t):
+        return t.detach().cpu().pin_memory()
+    host_sets = None
+    if not a.inputs_resident:
+        host_sets = []
+        for base, pastes in zip(bases, paste_sets):
+            per = []
+            for d, pk in zip(base, pastes):
+                inst = d["instances"]
+                per.append(dict(image=pin(d["image"]), masks=pin(inst.gt_masks.tensor.view(torch.uint8)), boxes=pin(inst.gt_boxes.tensor),
+                                classes=pin(inst.gt_classes), flat=pin(pk.flat), desc=pin(pk.desc), labels=pin(pk.labels), K=pk.K))
+            host_sets.append(per)
+        h2d_bytes[0] = sum(v.numel() * v.element_size() for v in host_sets[0][0].values() if torch.is_tensor(v)) * a.batch
     turn = [0]
 
     # The copy-paste compositor is the data-loading side of the step (the reference runs it in loader workers,
@@ -341,14 +362,20 @@ def main():
         batch = []
         base, pastes = bases[turn[0] % nd], paste_sets[turn[0] % nd]
         turn[0] += 1
+        hosts = host_sets[(turn[0] - 1) % nd] if host_sets is not None else [None] * len(base)
         with torch.cuda.stream(side):
-            for d, ps in zip(base, pastes):
+            for d, ps, hs in zip(base, pastes, hosts):
                 inst = d["instances"]
                 if a.no_copy_paste:
                     batch.append(d)
                     continue
-                out = la.copy_paste(d["image"], inst.gt_masks.tensor.view(torch.uint8), inst.gt_boxes.tensor,
-                                    inst.gt_classes, ps, lazy_masks=True)
+                if hs is not None:              # this step's host -> device leg (pinned, asynchronous, on the loader stream)
+                    up = {k: v.to(dev, non_blocking=True) for k, v in hs.items() if torch.is_tensor(v)}
+                    img, gm, gb, gc = up["image"], up["masks"], up["boxes"], up["classes"]
+                    ps = la.PackedPastes(up["flat"], up["desc"], up["labels"], hs["K"])
+                else:
+                    img, gm, gb, gc = d["image"], inst.gt_masks.tensor.view(torch.uint8), inst.gt_boxes.tensor, inst.gt_classes
+                out = la.copy_paste(img, gm, gb, gc, ps, lazy_masks=True)
                 ni = Instances(inst.image_size)
                 ni.gt_boxes, ni.gt_classes = Boxes(out["boxes"]), out["labels"]
                 ni.gt_masks, ni.instance_source = BitMasks(out["masks"].view(torch.bool), index=out["keep"]), out["source"]   # 0/1 bytes: a view; rows through the index
@@ -359,6 +386,7 @@ def main():
         return batch, ev
 
     nxt = [compose()]
+    exposed = [] if (world > 1 and on_gpu) else None
 
     def one_step():
         batch, ev = nxt[0]
@@ -378,7 +406,14 @@ def main():
         losses = model(batch)
         total = sum(losses.values())
         total.backward()
-        scale = reducer.finish()
+        if exposed is not None:                 # N > 1: the time the training stream spends waiting for collectives BEHIND backward
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            scale = reducer.finish()
+            e1.record()
+            exposed.append((e0, e1))
+        else:
+            scale = reducer.finish()
         opt.step(grad_scale=scale)
         sched.step()
         return total
@@ -426,6 +461,27 @@ def main():
     # kernel, so the weights must still be IDENTICAL across ranks.  A bucket reduced before its last gradient write (or
     # any rank-local contribution that escaped the all-reduce) shows up here as diverged weights: fail loudly.
     in_sync = None
+    allreduce = None
+    if world > 1 and exposed:
+        # (a) exposed all-reduce time: stream time between the end of backward and the last collective the optimizer waits for,
+        #     mean over the timed steps (what overlap did NOT hide); (b) the bucket collective in isolation: 10 all-reduces of one
+        #     64 MiB fp32 bucket, bus bandwidth = 2 (N - 1) / N x bytes / time (ring all-reduce: what one xGMI link pair carries)
+        ex = [a_.elapsed_time(b_) for a_, b_ in exposed[-a.steps:]]
+        nb = reducer.buckets[0][1] - reducer.buckets[0][0]
+        buf = torch.zeros(nb, dtype=torch.float32, device=dev)
+        for _ in range(3):
+            dist.all_reduce(buf)
+        torch.cuda.synchronize()
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0.record()
+        for _ in range(10):
+            dist.all_reduce(buf)
+        c1.record()
+        torch.cuda.synchronize()
+        t_ar = c0.elapsed_time(c1) / 10.0 * 1e-3
+        allreduce = {"exposed_ms_per_step": sum(ex) / max(len(ex), 1), "bucket_bytes": nb * 4, "buckets": len(reducer.buckets),
+                     "gradient_bytes_per_step": int(opt.arena.g.numel()) * 4, "bucket_allreduce_ms": t_ar * 1e3,
+                     "bucket_bus_gb_per_s": 2.0 * (world - 1) / world * nb * 4 / t_ar / 1e9}
     if world > 1:
         chk = torch.stack([opt.arena.p.double().sum(), opt.arena.p.double().abs().sum()]).cpu()
         gathered = [torch.zeros_like(chk) for _ in range(world)]
@@ -458,6 +514,8 @@ def main():
              "peak": 2500.0 if mfma else 8000.0, "unit": "TFLOP/s" if mfma else "GB/s",
              "frac": (tf / 2500.0) if mfma else (gbs / 8000.0),
              "traffic": pm.get("hbm_bytes_per_launch"), "traffic_per_step": pm.get("hbm_bytes_per_step"),
+             # (counters cannot be collected next to the timed run: a separate rocprofv3 --pmc pass of this same command, committed)
+             "traffic_source": ("profiles/%s_pmc.json" % PROFILE_TAG) if pm else None,
              "traffic_launches_per_step": pm.get("launches_per_step"),
              "algorithmic_bytes_per_launch": b_all / max(n_all, 1e-9), "algorithmic_bytes_per_step": b_all, "launches_per_step": n_all,
              "traffic_over_algorithmic": (pm["hbm_bytes_per_step"] / b_all) if pm.get("hbm_bytes_per_step") and b_all > 0 else None,
@@ -496,12 +554,16 @@ def main():
                            "global_batch": a.batch * world, "parallelism": "dp%d" % world, "params_M": nparams / 1e6},
                 "roofline": roof, "roofline_other": objs[1:], "roofline_steps_sampled": sampled,
                 "host_issue_ms_per_step": t_issue / a.steps * 1e3,
+                "inputs": {"host_to_device_inside_timed_region": host_sets is not None, "h2d_bytes_per_step": h2d_bytes[0],
+                           "how": ("pinned host buffers, non_blocking copies on the loader (side) stream, every step" if host_sets is not None
+                                   else "staged in HBM before the timed region (--inputs-resident)")},
                 "peak_hbm_gb_rank0": torch.cuda.max_memory_allocated(dev) / 1e9}
         if in_sync is not None:
             line["ranks_seen_by_collective"] = ranks_seen
             line["collective_backend"] = "rccl" if dist.get_backend() == "nccl" else dist.get_backend()
             line["weights_identical_across_ranks"] = in_sync
             line["buckets_reduced_during_backward"] = "%d/%d" % (reducer.last_early, len(reducer.buckets))
+            line["allreduce"] = allreduce
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a.swin, model, cfg)
     # RCCL writes its version banner to the C-level stdout, which is block-buffered when redirected and would otherwise be

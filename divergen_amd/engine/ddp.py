@@ -98,6 +98,14 @@ class ArenaReducer:
             dist.broadcast(self.arena.p, src=src, group=self.group)
             self.arena.sync_shadow()
 
+    def agree_on_skip(self, flag):
+        """flag: int32 tensor, non-zero on a rank whose loss is not finite (DG/train_net.py:266 asserts there; here the flag stays
+        on the device and makes the optimizer kernel skip the step: `found_inf`).  With several ranks EVERY rank must skip, or the
+        weights diverge: the flag is MAX-reduced over the group, in place.  Returns the flag."""
+        if self.active and self.world > 1:
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
+        return flag
+
     def finish(self):
         """Call after backward: flush never-ready buckets, wait for every collective.  Returns the
         factor the optimizer must apply to the summed gradients."""

@@ -17,6 +17,7 @@ import torch
 import torch.nn.functional as F
 
 from . import roi
+from .quant import rb
 
 
 def fpn(feats, p, prefix="", in_features=("swin1", "swin2", "swin3")):
@@ -25,14 +26,14 @@ def fpn(feats, p, prefix="", in_features=("swin1", "swin2", "swin3")):
     prev = None
     res = {}
     for name, s in reversed(list(zip(in_features, stages))):
-        lat = F.conv2d(feats[name], p["%sfpn_lateral%d.weight" % (prefix, s)], p["%sfpn_lateral%d.bias" % (prefix, s)])
+        lat = rb(F.conv2d(feats[name], p["%sfpn_lateral%d.weight" % (prefix, s)], p["%sfpn_lateral%d.bias" % (prefix, s)]))
         if prev is not None:
-            lat = lat + F.interpolate(prev, scale_factor=2.0, mode="nearest")
+            lat = rb(lat + F.interpolate(prev, scale_factor=2.0, mode="nearest"))
         prev = lat
-        res["p%d" % s] = F.conv2d(lat, p["%sfpn_output%d.weight" % (prefix, s)],
-                                  p["%sfpn_output%d.bias" % (prefix, s)], padding=1)
-    p6 = F.conv2d(res["p5"], p[prefix + "top_block.p6.weight"], p[prefix + "top_block.p6.bias"], stride=2, padding=1)
-    p7 = F.conv2d(F.relu(p6), p[prefix + "top_block.p7.weight"], p[prefix + "top_block.p7.bias"], stride=2, padding=1)
+        res["p%d" % s] = rb(F.conv2d(lat, p["%sfpn_output%d.weight" % (prefix, s)],
+                                     p["%sfpn_output%d.bias" % (prefix, s)], padding=1))
+    p6 = rb(F.conv2d(res["p5"], p[prefix + "top_block.p6.weight"], p[prefix + "top_block.p6.bias"], stride=2, padding=1))
+    p7 = rb(F.conv2d(F.relu(p6), p[prefix + "top_block.p7.weight"], p[prefix + "top_block.p7.bias"], stride=2, padding=1))
     res["p6"], res["p7"] = p6, p7
     return {k: res[k] for k in ("p3", "p4", "p5", "p6", "p7")}
 
@@ -44,11 +45,11 @@ def centernet_head(xs, p, prefix="", num_box_convs=4):
     for l, x in enumerate(xs):
         t = x
         for i in range(num_box_convs):
-            t = F.conv2d(t, p["%sbbox_tower.%d.weight" % (prefix, 3 * i)], p["%sbbox_tower.%d.bias" % (prefix, 3 * i)], padding=1)
+            t = rb(F.conv2d(t, p["%sbbox_tower.%d.weight" % (prefix, 3 * i)], p["%sbbox_tower.%d.bias" % (prefix, 3 * i)], padding=1))
             t = F.group_norm(t, 32, p["%sbbox_tower.%d.weight" % (prefix, 3 * i + 1)], p["%sbbox_tower.%d.bias" % (prefix, 3 * i + 1)])
-            t = F.relu(t)
-        hms.append(F.conv2d(t, p[prefix + "agn_hm.weight"], p[prefix + "agn_hm.bias"], padding=1))
-        r = F.conv2d(t, p[prefix + "bbox_pred.weight"], p[prefix + "bbox_pred.bias"], padding=1)
+            t = rb(F.relu(t))
+        hms.append(rb(F.conv2d(t, p[prefix + "agn_hm.weight"], p[prefix + "agn_hm.bias"], padding=1)))
+        r = rb(F.conv2d(t, p[prefix + "bbox_pred.weight"], p[prefix + "bbox_pred.bias"], padding=1))
         regs.append(F.relu(r * p["%sscales.%d.scale" % (prefix, l)]))
     return regs, hms
 
@@ -56,13 +57,13 @@ def centernet_head(xs, p, prefix="", num_box_convs=4):
 def box_head(x, p, prefix):
     """(R,256,7,7) -> (R,1024): flatten, fc1, relu, fc2, relu."""
     x = x.flatten(1)
-    x = F.relu(F.linear(x, p[prefix + "fc1.weight"], p[prefix + "fc1.bias"]))
-    return F.relu(F.linear(x, p[prefix + "fc2.weight"], p[prefix + "fc2.bias"]))
+    x = F.relu(rb(F.linear(x, p[prefix + "fc1.weight"], p[prefix + "fc1.bias"])))
+    return F.relu(rb(F.linear(x, p[prefix + "fc2.weight"], p[prefix + "fc2.bias"])))
 
 
 def box_predictor(x, p, prefix):
-    return (F.linear(x, p[prefix + "cls_score.weight"], p[prefix + "cls_score.bias"]),
-            F.linear(x, p[prefix + "bbox_pred.weight"], p[prefix + "bbox_pred.bias"]))
+    return (rb(F.linear(x, p[prefix + "cls_score.weight"], p[prefix + "cls_score.bias"])),
+            rb(F.linear(x, p[prefix + "bbox_pred.weight"], p[prefix + "bbox_pred.bias"])))
 
 
 def fed_loss_inds(gt_classes, num_sample_cats, C, weight):
@@ -105,9 +106,9 @@ def box_reg_loss(prop_boxes, gt_boxes, pred_deltas, gt_classes, num_classes, wei
 
 def mask_head(x, p, prefix, num_conv=4):
     for i in range(num_conv):
-        x = F.relu(F.conv2d(x, p["%smask_fcn%d.weight" % (prefix, i + 1)], p["%smask_fcn%d.bias" % (prefix, i + 1)], padding=1))
-    x = F.relu(F.conv_transpose2d(x, p[prefix + "deconv.weight"], p[prefix + "deconv.bias"], stride=2))
-    return F.conv2d(x, p[prefix + "predictor.weight"], p[prefix + "predictor.bias"])
+        x = F.relu(rb(F.conv2d(x, p["%smask_fcn%d.weight" % (prefix, i + 1)], p["%smask_fcn%d.bias" % (prefix, i + 1)], padding=1)))
+    x = F.relu(rb(F.conv_transpose2d(x, p[prefix + "deconv.weight"], p[prefix + "deconv.bias"], stride=2)))
+    return rb(F.conv2d(x, p[prefix + "predictor.weight"], p[prefix + "predictor.bias"]))
 
 
 def mask_loss(mask_logits, gt_masks_list, prop_boxes_list):

@@ -17,6 +17,7 @@ from . import centernet as C
 from . import heads as H
 from . import roi as R
 from . import swin as S
+from .quant import rb
 
 BOX_W = ((10.0, 10.0, 5.0, 5.0), (20.0, 20.0, 10.0, 10.0), (30.0, 30.0, 15.0, 15.0))     # cascade_rcnn.py / Base yaml
 IOUS = (0.6, 0.7, 0.8)
@@ -104,7 +105,7 @@ def roi_head_losses(p, fp, proposals, gts, image_sizes, num_classes, batch_per_i
                 nc.append(c)
                 midx[i] = idx
             boxes, cls = nb, nc
-        x = R.roi_pooler(feats, boxes, 7, scales)
+        x = rb(R.roi_pooler(feats, boxes, 7, scales))         # (pooled features are stored in the feature maps' dtype)
         x = H.box_head(x, p, "%sbox_head.%d." % (prefix, k))
         logits, deltas = H.box_predictor(x, p, "%sbox_predictor.%d." % (prefix, k))
         gtc = torch.cat(cls)
@@ -122,7 +123,7 @@ def roi_head_losses(p, fp, proposals, gts, image_sizes, num_classes, batch_per_i
     if sum(len(b) for b in mb) == 0:
         losses["loss_mask"] = torch.zeros(())
     else:
-        x = R.roi_pooler(feats, mb, 14, scales)
+        x = rb(R.roi_pooler(feats, mb, 14, scales))
         logits = H.mask_head(x, p, prefix + "mask_head.")
         losses["loss_mask"] = H.mask_loss(logits, mm, mb) * mask_weight
     return losses

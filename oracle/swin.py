@@ -12,6 +12,9 @@ import math
 import torch
 import torch.nn.functional as F
 
+from .quant import active as _bf16_on
+from .quant import rb
+
 
 def relative_position_index(ws):
     """(ws*ws, ws*ws) int64 index into the (2ws-1)^2 bias table.  swintransformer.py:105-116."""
@@ -60,7 +63,7 @@ def window_attention(x, mask, p, prefix, num_heads):
     B_, N, C = x.shape
     hd = C // num_heads
     ws = int(round(math.sqrt(N)))
-    qkv = F.linear(x, p[prefix + "qkv.weight"], p[prefix + "qkv.bias"])
+    qkv = rb(F.linear(x, p[prefix + "qkv.weight"], p[prefix + "qkv.bias"]))
     qkv = qkv.reshape(B_, N, 3, num_heads, hd).permute(2, 0, 3, 1, 4)
     q, k, v = qkv[0] * (hd ** -0.5), qkv[1], qkv[2]
     s = q @ k.transpose(-2, -1)  # B_, nH, N, N
@@ -72,9 +75,15 @@ def window_attention(x, mask, p, prefix, num_heads):
     if mask is not None:
         nW = mask.shape[0]
         s = (s.reshape(B_ // nW, nW, num_heads, N, N) + mask[None, :, None]).reshape(B_, num_heads, N, N)
-    a = torch.softmax(s, dim=-1)
-    o = (a @ v).transpose(1, 2).reshape(B_, N, C)
-    return F.linear(o, p[prefix + "proj.weight"], p[prefix + "proj.bias"])
+    if _bf16_on():
+        # the product's kernel: e = exp(s - max) in fp32, the row sum from the fp32 values, P V on the bf16-rounded e, the
+        # division behind it, the output stored as bf16
+        e = torch.exp(s - s.amax(dim=-1, keepdim=True))
+        o = rb((rb(e) @ v) / e.sum(dim=-1, keepdim=True)).transpose(1, 2).reshape(B_, N, C)
+    else:
+        a = torch.softmax(s, dim=-1)
+        o = (a @ v).transpose(1, 2).reshape(B_, N, C)
+    return rb(F.linear(o, p[prefix + "proj.weight"], p[prefix + "proj.bias"]))
 
 
 def drop_path(x, rate, training):
@@ -87,11 +96,13 @@ def drop_path(x, rate, training):
     return x.div(keep) * r.floor()
 
 
-def swin_block(x, H, W, mask, p, prefix, num_heads, ws, shift, drop=0.0, training=False):
-    """swintransformer.py:201-257."""
+def swin_block(x, H, W, mask, p, prefix, num_heads, ws, shift, drop=0.0, training=False, stream=None):
+    """swintransformer.py:201-257.  stream: rounding of the residual stream (quant.rb for the stages whose stream the product
+    keeps in bf16; None = fp32)."""
     B, L, C = x.shape
+    rs = stream if stream is not None else (lambda t: t)
     shortcut = x
-    h = F.layer_norm(x, (C,), p[prefix + "norm1.weight"], p[prefix + "norm1.bias"]).reshape(B, H, W, C)
+    h = rb(F.layer_norm(x, (C,), p[prefix + "norm1.weight"], p[prefix + "norm1.bias"])).reshape(B, H, W, C)
     pad_r, pad_b = (ws - W % ws) % ws, (ws - H % ws) % ws
     h = F.pad(h, (0, 0, 0, pad_r, 0, pad_b))
     Hp, Wp = H + pad_b, W + pad_r
@@ -102,12 +113,12 @@ def swin_block(x, H, W, mask, p, prefix, num_heads, ws, shift, drop=0.0, trainin
     if shift > 0:
         h = torch.roll(h, shifts=(shift, shift), dims=(1, 2))
     h = h[:, :H, :W, :].reshape(B, H * W, C)
-    x = shortcut + drop_path(h, drop, training)
-    m = F.layer_norm(x, (C,), p[prefix + "norm2.weight"], p[prefix + "norm2.bias"])
-    m = F.linear(m, p[prefix + "mlp.fc1.weight"], p[prefix + "mlp.fc1.bias"])
-    m = F.gelu(m)
-    m = F.linear(m, p[prefix + "mlp.fc2.weight"], p[prefix + "mlp.fc2.bias"])
-    return x + drop_path(m, drop, training)
+    x = rs(shortcut + drop_path(h, drop, training))
+    m = rb(F.layer_norm(x, (C,), p[prefix + "norm2.weight"], p[prefix + "norm2.bias"]))
+    m = rb(F.linear(m, p[prefix + "mlp.fc1.weight"], p[prefix + "mlp.fc1.bias"]))
+    m = rb(F.gelu(m))
+    m = rb(F.linear(m, p[prefix + "mlp.fc2.weight"], p[prefix + "mlp.fc2.bias"]))
+    return rs(x + drop_path(m, drop, training))
 
 
 def patch_merging(x, H, W, p, prefix):
@@ -118,17 +129,17 @@ def patch_merging(x, H, W, p, prefix):
         x = F.pad(x, (0, 0, 0, W % 2, 0, H % 2))
     x = torch.cat([x[:, 0::2, 0::2], x[:, 1::2, 0::2], x[:, 0::2, 1::2], x[:, 1::2, 1::2]], -1)
     x = x.reshape(B, -1, 4 * C)
-    x = F.layer_norm(x, (4 * C,), p[prefix + "norm.weight"], p[prefix + "norm.bias"])
-    return F.linear(x, p[prefix + "reduction.weight"])
+    x = rb(F.layer_norm(x, (4 * C,), p[prefix + "norm.weight"], p[prefix + "norm.bias"]))
+    return rb(F.linear(x, p[prefix + "reduction.weight"]))
 
 
-def basic_layer(x, H, W, p, prefix, depth, num_heads, ws, downsample, drops=None, training=False):
+def basic_layer(x, H, W, p, prefix, depth, num_heads, ws, downsample, drops=None, training=False, stream=None):
     """swintransformer.py:361-400."""
     mask = shift_mask(H, W, ws)
     for i in range(depth):
         x = swin_block(x, H, W, mask, p, "%sblocks.%d." % (prefix, i), num_heads, ws,
                        0 if i % 2 == 0 else ws // 2,
-                       drops[i] if drops else 0.0, training)
+                       drops[i] if drops else 0.0, training, stream)
     if downsample:
         return x, patch_merging(x, H, W, p, prefix + "downsample."), (H + 1) // 2, (W + 1) // 2
     return x, x, H, W
@@ -142,7 +153,7 @@ def swin_forward(img, p, embed_dim, depths, num_heads, ws, out_indices=(1, 2, 3)
         img = F.pad(img, (0, 4 - W % 4))
     if H % 4:
         img = F.pad(img, (0, 0, 0, 4 - H % 4))
-    x = F.conv2d(img, p[prefix + "patch_embed.proj.weight"], p[prefix + "patch_embed.proj.bias"], stride=4)
+    x = rb(F.conv2d(img, p[prefix + "patch_embed.proj.weight"], p[prefix + "patch_embed.proj.bias"], stride=4))
     Wh, Ww = x.shape[2], x.shape[3]
     x = x.flatten(2).transpose(1, 2)
     x = F.layer_norm(x, (embed_dim,), p[prefix + "patch_embed.norm.weight"], p[prefix + "patch_embed.norm.bias"])
@@ -152,9 +163,10 @@ def swin_forward(img, p, embed_dim, depths, num_heads, ws, out_indices=(1, 2, 3)
         C = embed_dim * 2 ** i
         x_out, x, nWh, nWw = basic_layer(
             x, Wh, Ww, p, "%slayers.%d." % (prefix, i), depth, num_heads[i], ws,
-            i < len(depths) - 1, dpr[sum(depths[:i]):sum(depths[:i + 1])], training)
+            i < len(depths) - 1, dpr[sum(depths[:i]):sum(depths[:i + 1])], training,
+            rb if i >= 1 else None)                # the product's residual stream: fp32 in stage 0, bf16 from stage 1 on
         if i in out_indices:
-            y = F.layer_norm(x_out, (C,), p["%snorm%d.weight" % (prefix, i)], p["%snorm%d.bias" % (prefix, i)])
+            y = rb(F.layer_norm(x_out, (C,), p["%snorm%d.weight" % (prefix, i)], p["%snorm%d.bias" % (prefix, i)]))
             outs["swin%d" % i] = y.reshape(-1, Wh, Ww, C).permute(0, 3, 1, 2).contiguous()
         Wh, Ww = nWh, nWw
     return outs

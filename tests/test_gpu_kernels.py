@@ -470,6 +470,33 @@ def test_adamw_ema_step_vs_oracle():
     torch.testing.assert_close(vd.cpu(), v, atol=1e-7, rtol=1e-5)
 
 
+def test_optimizer_kernels_skip_the_step_when_found_inf_is_set():
+    """found_inf != 0 (a non-finite loss somewhere in the job, engine.ArenaReducer.agree_on_skip): weights, moments, EMA and the
+    bf16 shadow are left exactly as they were -- AdamW and SGD kernels."""
+    g = torch.Generator().manual_seed(53)
+    n = 4 * 512
+    p0 = torch.randn(n, generator=g)
+    gr = (torch.randn(n, generator=g) * float("inf")).nan_to_num(nan=float("nan")).to(DEV)
+    flag = torch.ones(1, dtype=torch.int32, device=DEV)
+    for kind in ("adamw", "sgd"):
+        pd, md, vd, ed = p0.to(DEV), torch.full((n,), 0.5, device=DEV), torch.full((n,), 0.25, device=DEV), (p0 * 2).to(DEV)
+        sh = pd.to(torch.bfloat16)
+        keep = [t.clone() for t in (pd, md, vd, ed, sh)]
+        if kind == "adamw":
+            la.adamw_ema_step(pd, gr, md, vd, ed, 3, 1e-3, weight_decay=1e-2, clip_value=1.0, ema_decay=0.999, p_bf16=sh, found_inf=flag)
+        else:
+            la.sgd_ema_step(pd, gr, md, ed, 3, 1e-2, 0.9, False, 1e-3, 1.0, 1.0, None, 0.999, p_bf16=sh, found_inf=flag)
+        for a, b in zip((pd, md, vd, ed, sh), keep):
+            assert torch.equal(a, b), kind
+        flag0 = torch.zeros(1, dtype=torch.int32, device=DEV)
+        g1 = torch.randn(n, generator=g).to(DEV)
+        if kind == "adamw":
+            la.adamw_ema_step(pd, g1, md, vd, ed, 3, 1e-3, weight_decay=1e-2, clip_value=1.0, ema_decay=0.999, p_bf16=sh, found_inf=flag0)
+        else:
+            la.sgd_ema_step(pd, g1, md, ed, 3, 1e-2, 0.9, False, 1e-3, 1.0, 1.0, None, 0.999, p_bf16=sh, found_inf=flag0)
+        assert not torch.equal(pd, keep[0]) and torch.equal(sh, pd.to(torch.bfloat16))
+
+
 def test_adamw_full_model_clip_vs_torch():
     """FullModelGradientClippingOptimizer over AdamW (custom_solver.py:46-60,69-72): clip_grad_norm_ over all parameters, then
     torch.optim.AdamW -- here the coefficient of dgx_clip_coef_f32 stays on the device and dgx_adamw_ema_step_scaled applies it."""

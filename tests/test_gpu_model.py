@@ -95,7 +95,7 @@ def library_compute_kernels(prof):
         for k in ev.kernels:
             if any(t in k.name for t in LIBRARY_COMPUTE):
                 names.add(k.name[:120])
-    own = ("gemm_nt_kernel", "gemm_splitk_fold_kernel", "wgrad256", "win_attn", "ln_fwd_kernel", "ln_bwd_kernel", "pm_ln_", "gn_",
+    own = ("gemm_nt_kernel", "gemm_lw_kernel", "gemm_splitk_fold_kernel", "wgrad256", "win_attn", "ln_fwd_kernel", "ln_bwd_kernel", "pm_ln_", "gn_",
            "gelu_fwd_kernel", "gelu_bwd_colsum_kernel", "gelu_colsum_final_kernel", "maxpool3x3s2")
     return sorted(n for n in names if not any(o in n for o in own))
 
@@ -113,8 +113,9 @@ def run_e2e_vs_oracle(monkeypatch, swin, size):
     scores the top-k / NMS survivor set is not stable under reordering; decoding is pinned separately by
     test_gpu_parity_modules / test_gpu_kernels) and each cascade stage's matched labels (a refined box within rounding of an
     IoU threshold would otherwise flip a label).  Everything continuous is the oracle's own.
-    Asserted: every one of the 10 losses within 1 % (bf16 activations through the backbone and the heads; measured values
-    are printed), and NO vendor / framework compute kernel in the launch list of the step."""
+    Asserted: every one of the 10 losses within 1e-3 (north_star) of the oracle run with the product's bf16 storage points
+    (oracle/quant.py) and within 1 % of the plain fp32 oracle (the bf16 deltas, printed as a table), and NO vendor / framework
+    compute kernel in the launch list of the step."""
     import divergen_amd.modeling.roi_heads.detic_fast_rcnn as FR
     import divergen_amd.modeling.roi_heads.detic_roi_heads as RH
     from divergen_amd.data import synthetic_batch
@@ -150,7 +151,8 @@ def run_e2e_vs_oracle(monkeypatch, swin, size):
     lib = library_compute_kernels(prof)
     assert not lib, "vendor / framework compute kernels on the product path: %s" % lib
     launched = {k.name for ev in prof.events() for k in ev.kernels}
-    for must in ("gemm_nt_kernel", "wgrad256_partial_kernel", "win_attn_fwd_kernel", "win_attn_bwd_kernel", "ln_fwd_kernel", "gn_"):
+    assert any(("gemm_nt_kernel" in n) or ("gemm_lw_kernel" in n) for n in launched), "own GEMM not launched"
+    for must in ("wgrad256_partial_kernel", "win_attn_fwd_kernel", "win_attn_bwd_kernel", "ln_fwd_kernel", "gn_"):
         assert any(must in n for n in launched), "expected libdgx kernel not launched: %s" % must
 
     # ---- oracle side
@@ -182,17 +184,33 @@ def run_e2e_vs_oracle(monkeypatch, swin, size):
             alive[i] = sel
             off += n
         stage_labels[k] = per
-    with torch.no_grad():
-        want = assembled_oracle_losses(p, images, gts, [tuple(b["instances"].image_size) for b in batch], swin, C, fw,
-                                       cfg.MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE, cfg.MODEL.ROI_HEADS.POSITIVE_FRACTION,
-                                       cfg.MODEL.ROI_BOX_HEAD.FED_LOSS_NUM_CAT, model.roi_heads.mask_weight,
-                                       proposals=captured["props"], stage_labels=stage_labels)
-    want = {k: float(v) for k, v in want.items()}
-    assert set(got) == set(want), (sorted(got), sorted(want))
-    report = {k: (got[k], want[k], abs(got[k] - want[k]) / max(abs(want[k]), 1e-6)) for k in sorted(got)}
-    print("e2e parity report, bf16 HIP product path vs fp32 oracle (product, oracle, rel):", report)
-    for k, (a, b, rel) in report.items():
-        assert abs(a - b) <= 1e-2 * abs(b) + 1e-5, report
+    from oracle.quant import bf16_storage
+
+    def oracle_losses():
+        with torch.no_grad():
+            w = assembled_oracle_losses(p, images, gts, [tuple(b["instances"].image_size) for b in batch], swin, C, fw,
+                                        cfg.MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE, cfg.MODEL.ROI_HEADS.POSITIVE_FRACTION,
+                                        cfg.MODEL.ROI_BOX_HEAD.FED_LOSS_NUM_CAT, model.roi_heads.mask_weight,
+                                        proposals=captured["props"], stage_labels=stage_labels)
+        return {k: float(v) for k, v in w.items()}
+    # (1) the oracle with the product's bf16 STORAGE points (oracle/quant.py: every tensor that crosses a kernel boundary rounded
+    # to bf16 where the product stores bf16, fp32 wherever it accumulates): what is left is summation order -> north_star's 1e-3
+    with bf16_storage():
+        want = oracle_losses()
+    # (2) the plain fp32 oracle: the bf16 deltas, listed separately, bounded at 1 %
+    want32 = oracle_losses()
+    assert set(got) == set(want) == set(want32), (sorted(got), sorted(want))
+    rel = lambda a, b: abs(a - b) / max(abs(b), 1e-6)
+    report = {k: dict(product=got[k], oracle_bf16_storage=want[k], rel=rel(got[k], want[k]), oracle_fp32=want32[k],
+                      bf16_delta=rel(got[k], want32[k])) for k in sorted(got)}
+    print("e2e parity report, bf16 HIP product path vs the oracle (Swin-%s, %d px):" % (swin, size))
+    for k, r in report.items():
+        print("  %-24s product %.7f | oracle with bf16 storage %.7f rel %.2e | fp32 oracle %.7f bf16 delta %.2e"
+              % (k, r["product"], r["oracle_bf16_storage"], r["rel"], r["oracle_fp32"], r["bf16_delta"]))
+    for k, r in report.items():
+        assert abs(r["product"] - r["oracle_bf16_storage"]) <= 1e-3 * abs(r["oracle_bf16_storage"]) + 1e-6, (k, report)
+        assert abs(r["product"] - r["oracle_fp32"]) <= 1e-2 * abs(r["oracle_fp32"]) + 1e-5, (k, report)
+    return report
 
 
 def test_overfits_a_fixed_batch():

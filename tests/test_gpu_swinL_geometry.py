@@ -47,14 +47,20 @@ def test_window_attention_at_bench_geometry(B_, nH, H, masked):
     out.backward(go.to(DEV))
     torch.cuda.synchronize()
 
-    def close(a, b, frac):
+    def close(a, b, frac, l2, what):
+        """max error against the tensor's scale (catches a wrong element) AND relative L2 error (catches a small systematic
+        error that a max-scaled bound hides under the tensor's largest entries)."""
         err, sc = float((a - b).abs().max()), float(b.abs().max())
-        assert err <= frac * sc, (err, sc)
-    # bf16 I/O, bf16 P / dS operands, fp32 accumulation: 1.5 % of the tensor's scale (the bar of the small-batch test)
-    close(out.float().cpu(), ref.detach(), 0.015)
-    close(qd.grad.float().cpu(), qr.grad, 0.015)
+        r2 = float((a - b).double().norm() / b.double().norm().clamp(min=1e-30))
+        print("%s (B_ %d nH %d masked %s): max err / scale %.2e, relative L2 %.2e" % (what, B_, nH, masked, err / sc, r2))
+        assert err <= frac * sc, (what, err, sc)
+        assert r2 <= l2, (what, r2)
+    # bf16 I/O, bf16 P / dS operands, fp32 accumulation: 1.5 % of the tensor's scale (the bar of the small-batch test); relative
+    # L2: one bf16 rounding of the result is 2^-9 / sqrt(3) = 1.1e-3, the bf16 P / dS operands add about as much again
+    close(out.float().cpu(), ref.detach(), 0.015, 4e-3, "out")
+    close(qd.grad.float().cpu(), qr.grad, 0.015, 6e-3, "dqkv")
     # the bias-table gradient sums B_/nW * N*N terms per entry in fp32 atomics across workgroup chunks: same 1.5 %
-    close(td.grad.cpu(), tr.grad, 0.015)
+    close(td.grad.cpu(), tr.grad, 0.015, 6e-3, "dtable")
 
 
 def test_swinL_stage0_layer_pair_vs_oracle():
@@ -91,17 +97,21 @@ def test_swinL_stage0_layer_pair_vs_oracle():
     ((y_out.float() * g1.to(DEV)).sum() + (y_down.float() * g2.to(DEV)).sum()).backward()
     torch.cuda.synchronize()
 
-    def close(a, b, frac):
+    def close(a, b, frac, l2, what):
         err, sc = float((a - b).abs().max()), float(b.abs().max())
-        assert err <= frac * sc, (err, sc)
-    # same budgets as the reference-golden BasicLayer test (bf16 GEMMs + bf16 attention operands through 2 blocks)
-    close(y_out.float().cpu(), x_out.detach(), 0.03)
-    close(y_down.float().cpu(), x_down.detach(), 0.03)
-    close(x.grad.float().cpu(), xr.grad, 0.05)
+        r2 = float((a - b).double().norm() / b.double().norm().clamp(min=1e-30))
+        print("%s: max err / scale %.2e, relative L2 %.2e" % (what, err / sc, r2))
+        assert err <= frac * sc, (what, err, sc)
+        assert r2 <= l2, (what, r2)
+    # same budgets as the reference-golden BasicLayer test (bf16 GEMMs + bf16 attention operands through 2 blocks); the relative
+    # L2 bounds sit at a few bf16 roundings (2^-9 each) accumulated over the ~12 stored tensors of a block pair
+    close(y_out.float().cpu(), x_out.detach(), 0.03, 1e-2, "x_out")
+    close(y_down.float().cpu(), x_down.detach(), 0.03, 1e-2, "x_down")
+    close(x.grad.float().cpu(), xr.grad, 0.05, 2e-2, "dx")
     named = dict(layer.named_parameters())
     for k in ("blocks.1.attn.qkv.weight", "blocks.0.mlp.fc1.weight", "blocks.1.attn.relative_position_bias_table",
               "blocks.0.attn.proj.bias", "downsample.reduction.weight"):
-        close(named[k].grad.float().cpu(), pr[k].grad, 0.06)
+        close(named[k].grad.float().cpu(), pr[k].grad, 0.06, 2e-2, k)
 
 
 def test_swinL_training_forward_vs_assembled_oracle(monkeypatch):

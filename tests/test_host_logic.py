@@ -286,6 +286,62 @@ def test_arena_reducer_world2_gloo():
     assert (g_a[-12:] == 0).all()           # the unused layer's bucket was flushed zero-filled
 
 
+def _ddp_skip_worker(rank, world, port, q):
+    """One rank's loss goes non-finite in step 1: the skip flag is MAX-reduced, so BOTH ranks leave their weights alone in that
+    step (the optimizer kernel's `found_inf` contract, emulated on the CPU here) and the weights stay identical afterwards."""
+    import os
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from divergen_amd.engine import ArenaReducer
+    from divergen_amd.solver import FlatArena
+    torch.manual_seed(3)
+    net = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.ReLU(), torch.nn.Linear(7, 2))
+    ar = FlatArena(net)
+    red = ArenaReducer(ar, bucket_bytes=64)
+    red.broadcast_parameters()
+    hist, flags = [], []
+    for it in range(3):
+        ar.zero_grad()
+        loss = net(torch.full((4, 5), 0.25 * (rank + 1))).sum()
+        if it == 1 and rank == 0:
+            loss = loss * float("inf")               # this rank's loss overflows
+        bad = red.agree_on_skip((~torch.isfinite(loss.detach())).to(torch.int32).reshape(1))
+        loss.backward()
+        scale = red.finish()
+        if not int(bad):                             # dgx_adamw_ema_step(found_inf): the whole update is skipped when the flag is set
+            with torch.no_grad():
+                ar.p.add_(torch.nan_to_num(ar.g) * scale, alpha=-0.1)
+        flags.append(int(bad))
+        hist.append(ar.p.numpy().copy())
+    q.put((rank, flags, hist))
+    dist.destroy_process_group()
+
+
+def test_non_finite_loss_on_one_rank_skips_the_step_on_every_rank_world2_gloo():
+    import socket
+    import numpy as np
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ddp_skip_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, f0, h0), (_, f1, h1) = res
+    assert f0 == [0, 1, 0] and f1 == [0, 1, 0]                       # rank 1 learned of rank 0's overflow
+    for a, b in zip(h0, h1):
+        assert np.array_equal(a, b)                                  # identical weights after every step
+    assert np.array_equal(h0[0], h0[1]) and not np.array_equal(h0[1], h0[2])      # step 1 skipped, step 2 applied
+
+
 def _ddp_trial_worker(rank, world, port, q):
     """BSGAL's selection runs extra backward passes INSIDE a training step (trial passes, rank-local decisions): under
     linear_ops.suspend_ready() they must neither count as gradient-ready signals nor launch a collective; the step's real

@@ -19,13 +19,13 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 FAMILY_KERNELS = {
-    "gemm_nt": ("gemm_nt_kernel", "gemm_splitk_fold_kernel"),
+    "gemm_nt": ("gemm_nt_kernel", "gemm_lw_kernel", "gemm_splitk_fold_kernel"),
     "wgrad": ("wgrad256_partial_kernel", "wgrad256_reduce_kernel", "wgrad256_bias_reduce_kernel", "wgrad_partial_kernel", "wgrad_reduce_kernel"),
     "attn_fwd": ("win_attn_fwd_kernel",),
     "attn_bwd": ("win_attn_bwd_kernel",),
 }
 # entry-point launches are counted on the family's MAIN kernel
-MAIN = {"gemm_nt": "gemm_nt_kernel", "wgrad": "partial_kernel", "attn_fwd": "win_attn_fwd_kernel", "attn_bwd": "win_attn_bwd_kernel"}
+MAIN = {"gemm_nt": ("gemm_nt_kernel", "gemm_lw_kernel"), "wgrad": "partial_kernel", "attn_fwd": "win_attn_fwd_kernel", "attn_bwd": "win_attn_bwd_kernel"}
 # 16 B/lane streaming reads (LDS-direct tile loads, float4 folds); window attention reads 64-byte head slices (64-B requests)
 WIDE = {"gemm_nt": True, "wgrad": True, "attn_fwd": False, "attn_bwd": False}
 
@@ -45,7 +45,7 @@ def collect(path, counter, warm, timed):
                 if any(p in r["Kernel_Name"] for p in pats):
                     out[fam]["kb"] += float(r["Counter_Value"])
                     out[fam]["dispatches"] += 1
-                    out[fam]["main"] += MAIN[fam] in r["Kernel_Name"]
+                    out[fam]["main"] += any(mk in r["Kernel_Name"] for mk in ((MAIN[fam],) if isinstance(MAIN[fam], str) else MAIN[fam]))
                     pk = out[fam]["per_kernel"].setdefault(r["Kernel_Name"].split("(")[0][-60:], [0, 0.0])
                     pk[0] += 1
                     pk[1] += float(r["Counter_Value"])

@@ -171,9 +171,7 @@ def do_train(cfg, model, resume=False):
             # DG/train_net.py:266 asserts isfinite(losses) before backward; here the flag stays on the device (no sync): a
             # non-finite loss makes the optimizer kernel skip the weights, moments and EMA of this step (found_inf), and the
             # deferred host check below runs BEFORE the periodic checkpointer can save
-            bad = (~torch.isfinite(losses.detach())).to(torch.int32)
-            if comm.get_world_size() > 1:
-                torch.distributed.all_reduce(bad, op=torch.distributed.ReduceOp.MAX)
+            bad = reducer.agree_on_skip((~torch.isfinite(losses.detach())).to(torch.int32))      # every rank skips, or none
             losses.backward()
             scale = reducer.finish()
             optimizer.step(grad_scale=scale, found_inf=bad)   # EMA of the pre-step weights + clip + AdamW, one kernel

@@ -35,9 +35,10 @@ def main():
     ss = sys.modules["detectron2.layers"].ShapeSpec
     NUM_CLASSES = 1453                                       # configs/DiverGen_swinL.yaml: MODEL.ROI_HEADS.NUM_CLASSES
     c = sw.size2config["L-22k-384"]
+    # (the Swin constructor calls .item() on its drop-path schedule: built on the CPU, 197 M parameters; the rest on `meta`)
+    swin = sw.SwinTransformer(embed_dim=c["embed_dim"], window_size=c["window_size"], depths=c["depth"], num_heads=c["num_heads"],
+                              drop_path_rate=c["drop_path_rate"], out_indices=(1, 2, 3), frozen_stages=-1, use_checkpoint=False)
     with torch.device("meta"):
-        swin = sw.SwinTransformer(embed_dim=c["embed_dim"], window_size=c["window_size"], depths=c["depth"], num_heads=c["num_heads"],
-                                  drop_path_rate=c["drop_path_rate"], out_indices=(1, 2, 3), frozen_stages=-1, use_checkpoint=False)
         fpn = fpn_m.FPN(bottom_up=swin, in_features=["swin1", "swin2", "swin3"], out_channels=256, norm="",
                         top_block=f5.LastLevelP6P7_P5(256, 256), fuse_type="sum")
         head = ch.CenterNetHead(in_channels=256, num_levels=5, num_classes=NUM_CLASSES, with_agn_hm=True, only_proposal=True,

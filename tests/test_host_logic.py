@@ -67,6 +67,25 @@ def test_registry_build_and_state_dict_keys():
         model.train()(synthetic_batch(1, 64, 1453))
 
 
+def test_state_dict_matches_the_reference_manifest():
+    """tests/golden/swinL_state_manifest.json = key -> shape of the state dict of the REFERENCE's own module classes at the
+    configuration of configs/DiverGen_swinL.yaml (tests/golden/make_manifest.py).  The registry-built model must expose exactly
+    these keys and shapes -- the released Swin-L checkpoint (DiverGen/README.md:57) is such a state dict -- and must take one
+    with strict loading (so `train_net.py --eval-only MODEL.WEIGHTS <checkpoint>`, the run that produces the AP number, cannot
+    fail on loading)."""
+    import json
+    from divergen_amd.modeling import build_model
+    man = json.load(open(os.path.join(ROOT, "tests", "golden", "swinL_state_manifest.json")))["entries"]
+    model = build_model(_cfg())
+    sd = {k: list(v.shape) for k, v in model.state_dict().items()}
+    assert sorted(sd) == sorted(man), (sorted(set(sd) - set(man))[:5], sorted(set(man) - set(sd))[:5])
+    bad = [(k, sd[k], man[k]) for k in sd if sd[k] != man[k]]
+    assert not bad, bad[:5]
+    ref_like = {k: torch.empty(v, dtype=model.state_dict()[k].dtype) for k, v in man.items()}
+    res = model.load_state_dict(ref_like, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+
+
 def test_lr_schedule_and_arena_buckets(golden):
     from divergen_amd.solver import warmup_cosine_lr
     g = golden("solver")

@@ -34,6 +34,7 @@ def parse():
     p.add_argument("--no-roofline", action="store_true", help="leave the per-launch HIP events off (A/B of their cost)")
     p.add_argument("--roofline-every", type=int, default=10, help="instrument every n-th timed step with per-launch HIP events")
     p.add_argument("--no-copy-paste", action="store_true")
+    p.add_argument("--copy-sources", action="store_true", help="development: list the ops of one step that end in device copies / fills (stderr)")
     p.add_argument("--inputs-resident", action="store_true",
                    help="stage images, ground truth and paste patches in HBM before the timed region (the round-3 form) instead of "
                         "uploading them from pinned host memory every step")
@@ -82,7 +83,7 @@ def make_pastes(rng, size, k=19):
 #   r03_pmc.json                              HBM bytes per launch / per step of each kernel family from rocprofv3 --pmc passes over
 #                                             THIS script, timed steps only (tools/pmc_summary.py)
 #   r03_bench_swinL_1024_kernel_stats.csv     rocprofv3 --kernel-trace --stats of THIS script (+ r03_profile_meta.json: steps)
-PROFILE_TAG = "r03"
+PROFILE_TAG = "r04"
 FAMILY_KERNELS = {   # family -> substrings of the kernel names rocprof reports for it
     "gemm_nt": ("gemm_nt_kernel", "gemm_lw_kernel", "gemm_splitk_fold_kernel"),
     "wgrad": ("wgrad256_partial_kernel", "wgrad256_reduce_kernel", "wgrad256_bias_reduce_kernel", "wgrad_partial_kernel", "wgrad_reduce_kernel"),
@@ -130,7 +131,7 @@ def window_mhsa_object(objs, swin_cfg, size, batch, nsamp):
 
 
 def _copy_sources(step):
-    """Development (DGX_BENCH_COPY_SOURCES=1): one bench step under the torch profiler with stacks; device copies / fills grouped by
+    """Development (--copy-sources): one bench step under the torch profiler with stacks; device copies / fills grouped by
     the innermost repo frame (or autograd node) that issued them, to stderr."""
     import collections
     from torch.profiler import ProfilerActivity, profile
@@ -263,6 +264,7 @@ def main():
     dev = torch.device("cuda", local) if on_gpu else torch.device("cpu")
     if world > 1 or a.force_pg:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", "16")      # CUs the all-reduce may take from the overlapped backward
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
@@ -429,7 +431,7 @@ def main():
         for _ in range(a.warmup):
             one_step()
         sync()
-        if os.environ.get("DGX_BENCH_COPY_SOURCES"):      # development: which ops of ONE bench step end in device copies / fills
+        if a.copy_sources:                    # development: which ops of ONE bench step end in device copies / fills
             _copy_sources(one_step)
             sync()
         prof.enable(not a.no_roofline)        # restart the tallies: the timed region only

@@ -99,6 +99,9 @@ SIGNATURES = {
     "dgx_centernet_head_outputs": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p]),
     "dgx_centernet_head_outputs_bwd_workspace_floats": (c_i64, [c_p, c_i, c_i]),
     "dgx_centernet_head_outputs_bwd": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
+    "dgx_set_reserved_cus": (None, [c_i]),
+    "dgx_get_reserved_cus": (c_i, []),
+    "dgx_gather_boxes": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p]),
     "dgx_centernet_finalize": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p]),
     "dgx_roi_label": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_i, c_f, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
     "dgx_roi_gather": (c_i, [c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f] + [c_p] * 10 + [c_p]),

@@ -148,6 +148,25 @@ extern "C" int dgx_centernet_decode(const void* const* reg_levels, int reg_pixel
     return DGX_OK;
 }
 
+// rows of 16 bytes (a box) picked by an index list per image: dst[b][k] = src[b][order[b][k]] -- the candidates' boxes brought into
+// score order behind torch.sort (torch.gather over the expanded index ran 87 us for 2 x 9 344 boxes: one lane per element)
+__global__ __launch_bounds__(256) void cn_gather_boxes_kernel(const float4* __restrict__ src, const int64_t* __restrict__ order, int B, int K,
+                                                              float4* __restrict__ dst) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)B * K) return;
+    const int b = (int)(i / K);
+    dst[i] = src[(int64_t)b * K + order[i]];
+}
+
+extern "C" int dgx_gather_boxes(const float* boxes, const int64_t* order, int B, int K, float* out, void* stream) {
+    if (B <= 0 || K <= 0) return DGX_OK;
+    if (!boxes || !order || !out) return DGX_ERR_BAD_ARG;
+    hipLaunchKernelGGL(cn_gather_boxes_kernel, dim3((int)(((int64_t)B * K + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)boxes,
+                       order, B, K, (float4*)out);
+    DGX_LAUNCH_CHECK();
+    return DGX_OK;
+}
+
 extern "C" int dgx_centernet_finalize(const float* sorted_boxes, const float* sorted_scores, const int32_t* keep_idx, const int32_t* num_keep,
                                       int B, int K, int cap, float* out_boxes, float* out_scores, uint8_t* out_valid, void* stream) {
     if (B <= 0 || cap <= 0) return DGX_OK;

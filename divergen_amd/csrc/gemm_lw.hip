@@ -470,6 +470,15 @@ __global__ __launch_bounds__(LW_THREADS) void gemm_lw_kernel(GemmP P0) {
     }
 }
 
+static int g_reserved_per_xcd = 0;
+// CUs (rounded up to one per XCD) that persistent kernels leave to something else running beside them: the RCCL channels of the
+// gradient all-reduce that overlaps backward (engine/ddp.ArenaReducer sets it to the channel count when the group has > 1 rank)
+extern "C" void dgx_set_reserved_cus(int n) {
+    int per = n <= 0 ? 0 : (n + 7) / 8;
+    g_reserved_per_xcd = per > 24 ? 24 : per;
+}
+extern "C" int dgx_get_reserved_cus(void) { return 8 * g_reserved_per_xcd; }
+
 namespace {
 template <int BM, int BN, int NSA, int NSB, int MC>
 int lw_launch_e(GemmP& P, hipStream_t st) {
@@ -479,7 +488,11 @@ int lw_launch_e(GemmP& P, hipStream_t st) {
             return DGX_ERR_UNSUPPORTED;
         once = true;
     }
-    const int wgx = P.per_xcd < 32 ? P.per_xcd : 32;       // workgroups per XCD: one per CU
+    // workgroups per XCD: one per CU, minus the CUs left to a concurrent collective (dgx_set_reserved_cus).  A workgroup of this
+    // kernel takes a CU's whole LDS and register file, so it cannot share a CU with an RCCL channel: with 256 workgroups launched
+    // and 16 CUs held by channels, 16 workgroups would wait for a second round -- the persistent tile loop simply runs on fewer
+    const int avail = 32 - g_reserved_per_xcd;
+    const int wgx = P.per_xcd < avail ? P.per_xcd : avail;
     hipLaunchKernelGGL((gemm_lw_kernel<BM, BN, NSA, NSB, MC>), dim3(8 * wgx), dim3(LW_THREADS), LW_LDS, st, P);
     return DGX_OK;
 }

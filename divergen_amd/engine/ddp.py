@@ -55,6 +55,14 @@ class ArenaReducer:
         self._expected = None          # learned from the first step; None = calibrating (no early launches)
         # single_rank_group: reduce over a one-rank group as well (bench.py --force-pg: RCCL next to hipGraph capture on one GPU)
         self.active = self.world > 1 or (dist.is_initialized() and single_rank_group)
+        self.reserved_cus = 0
+        if self.active and self.world > 1 and arena.g.is_cuda and dist.get_backend(self.group) == "nccl":
+            # RCCL runs one workgroup per channel, each pinned to a CU for the collective's duration, beside the backward kernels.
+            # libdgx's persistent kernels (one workgroup per CU, whole LDS + register file) cannot share a CU with a channel, so they
+            # are told to leave that many CUs alone (csrc/gemm_lw.hip): NCCL_MAX_NCHANNELS bounds the channel count
+            self.reserved_cus = int(os.environ.get("NCCL_MAX_NCHANNELS", "16"))
+            from .. import _lib as L
+            L.lib().dgx_set_reserved_cus(self.reserved_cus)
         if self.active:
             for i, p in enumerate(arena.params):
                 hook = self._make_hook(i)

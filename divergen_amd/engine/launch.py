@@ -29,6 +29,7 @@ def default_argument_parser(epilog=None):
 def _worker(local_rank, main_func, world_size, gpus_per_machine, machine_rank, dist_url, backend, args):
     rank = machine_rank * gpus_per_machine + local_rank
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("NCCL_MAX_NCHANNELS", "16")          # CUs the gradient all-reduce may take from the overlapped backward
     dist.init_process_group(backend=backend, init_method=dist_url, world_size=world_size, rank=rank)
     os.environ["LOCAL_RANK"] = str(local_rank)
     if backend == "nccl":

@@ -315,7 +315,9 @@ class CenterNet(nn.Module):
         L.check(lib.dgx_centernet_decode(rp, lay_r[0][0], 0, hw, st, Lv, B, L.ptr(idx), Kc, L.ptr(scores), float(self.score_thresh),
                                          L.ptr(boxes), L.ptr(sc), L.ptr(n_valid), code, L.stream()), "dgx_centernet_decode")
         sc, order = torch.sort(sc, dim=1, descending=True, stable=True)
-        boxes = torch.gather(boxes, 1, order[:, :, None].expand(-1, -1, 4))
+        sorted_boxes = torch.empty_like(boxes)
+        L.check(lib.dgx_gather_boxes(L.ptr(boxes), L.ptr(order.contiguous()), B, Kc, L.ptr(sorted_boxes), L.stream()), "dgx_gather_boxes")
+        boxes = sorted_boxes
         cap = min(Kc, post_topk + 64)
         keep_idx, num_keep = nms_batched_sorted(boxes, sc, n_valid, thr_nms, max_keep=post_topk, cap=cap)
         o_box = torch.empty(B, cap, 4, dtype=torch.float32, device=dev)

@@ -173,6 +173,9 @@ int dgx_centernet_scores(const void* const* hm_levels, int hm_pixel_stride, int 
 int dgx_centernet_decode(const void* const* reg_levels, int reg_pixel_stride, int reg_channel, const int32_t* level_hw,
                          const int32_t* strides, int L, int B, const int64_t* cand_idx, int Kc, const float* scores, float thr,
                          float* boxes, float* out_scores, int32_t* n_valid, int dtype, void* stream);
+/* boxes (B, K, 4) f32, order (B, K) i64 (the permutation torch.sort returns for the candidates' scores) -> out[b][k] =
+ * boxes[b][order[b][k]]: the gather of centernet.py:704-712 (`boxlist = boxlist[keep]` behind the score sort). */
+int dgx_gather_boxes(const float* boxes, const int64_t* order, int B, int K, float* out, void* stream);
 int dgx_centernet_finalize(const float* sorted_boxes, const float* sorted_scores, const int32_t* keep_idx, const int32_t* num_keep,
                            int B, int K, int cap, float* out_boxes, float* out_scores, uint8_t* out_valid, void* stream);
 
@@ -603,6 +606,11 @@ typedef struct dgx_gemm_epilogue {
 } dgx_gemm_epilogue;
 int dgx_gemm_bf16_nt(const void* A, const void* B, int M, int N, int K, int64_t lda, int64_t ldb,
                      const dgx_gemm_epilogue* epilogue, void* stream);
+/* Compute units that the library's persistent kernels (one workgroup per CU walking a tile list: the loader-wave GEMM) leave free
+ * for work that runs beside them -- the RCCL channels of the overlapped gradient all-reduce (DG/train_net.py:357-362 wraps the model
+ * in DistributedDataParallel: same overlap).  Rounded up to a multiple of 8 (one per XCD); 0 = use the whole chip (default). */
+void dgx_set_reserved_cus(int n);
+int dgx_get_reserved_cus(void);
 
 
 /* Transposed twins of the matrix parameters inside a flat bf16 arena (the operand layout dgx_gemm_bf16_nt needs for the

@@ -17,6 +17,8 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/p_w -o p -
 ff=$(find /tmp/p_f -name "*counter_collection.csv" | head -1)
 fw=$(find /tmp/p_w -name "*counter_collection.csv" | head -1)
 python $R/tools/pmc_summary.py $ff $fw 2 2 $O/r04_pmc.json > $O/pmc_summary.txt 2>&1
+# bench.py cross-checks its event-clock figures against the committed profile of THIS round: put this run's summaries where it reads them
+cp $O/r04_pmc.json $O/r04_profile_meta.json $O/r04_bench_swinL_1024_kernel_stats.csv $R/profiles/
 cd $R && python bench.py > $O/r04_bench_line.json 2> $O/bench.err
 tail -c 600 $O/r04_bench_line.json
 # what BASELINE.md asks to report beside the headline: the shipped configuration's 896^2 and a Swin-T line (same command, other size / backbone)

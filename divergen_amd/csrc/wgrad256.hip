@@ -73,7 +73,8 @@ __device__ unsigned long long w256_clk[8];
 // LDS-direct load writes 1 KiB = two whole rows).  Bank conflicts of the transpose reads (4 consecutive rows,
 // same columns) are removed by an XOR swizzle of the 16-byte chunk index:  physical = logical ^ ((row & 3) << 1).
 // (Additionally moving the rows of the second lane group of an LDS cycle, (row >> 3) & 1, to the other 32 banks
-// was measured and is NOT faster on hardware, so the simpler swizzle stays.)
+// was measured and is NOT faster on hardware HERE (LDS cycles are half the MFMA cycles even with the 2-way conflict), so the simpler
+// swizzle stays; wgrad_lw.hip, whose eight smaller wave tiles read 0.9 LDS cycles per MFMA cycle under the conflict, has it.)
 __global__ __launch_bounds__(256) void wgrad256_partial_kernel(Params256 P) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds_raw[];   // [NB256][A|B][32][512 B]
     // XCD-aware order: workgroups that share an XCD (blockIdx % 8, one L2 each) take CONSECUTIVE logical ids =
@@ -373,8 +374,15 @@ static int64_t ws_floats256(const dgx_wgrad_problem* pr, int n, const int* S, in
     return tot;
 }
 
+// wgrad_lw.hip: the persistent loader-wave form for groups of many tiles (no M-split, no workspace)
+bool wgrad_lw_wants(const dgx_wgrad_problem* pr, int n);
+int wgrad_lw_launch(const dgx_wgrad_problem* pr, int n, float beta, hipStream_t st);
+constexpr int MAXP_GROUP = 32;           // problems per dgx_linear_wgrad_grouped call: <= 12 on the split-M form, <= 32 on the loader-wave form
+
 extern "C" int64_t dgx_wgrad_grouped_workspace_bytes(const dgx_wgrad_problem* problems, int n) {
-    if (!problems || n <= 0 || n > MAXP256) return 0;
+    if (!problems || n <= 0 || n > MAXP_GROUP) return 0;
+    if (wgrad_lw_wants(problems, n)) return 0;
+    if (n > MAXP256) return 0;
     int S[MAXP256], slab[MAXP256];
     plan256(problems, n, S, slab);
     return ws_floats256(problems, n, S, nullptr) * 4;
@@ -385,11 +393,18 @@ static int wgrad_grouped_impl(const dgx_wgrad_problem* problems, const int* ldc,
 extern "C" int dgx_linear_wgrad_grouped(const dgx_wgrad_problem* problems, int n, float beta, void* workspace,
                                         void* stream) {
     double fl = 0.0, by = 0.0;
-    for (int i = 0; problems && i < n && i < MAXP256; ++i) {      // dY, X read once (bf16); fp32 gradient read + written (bias: free)
+    if (!problems || n <= 0 || n > MAXP_GROUP) return DGX_ERR_BAD_ARG;
+    for (int i = 0; i < n; ++i) {      // dY, X read once (bf16); fp32 gradient read + written (bias: free)
         fl += 2.0 * problems[i].M * problems[i].Nn * problems[i].Kk;
         by += 2.0 * problems[i].M * ((double)problems[i].Nn + problems[i].Kk) + 8.0 * problems[i].Nn * problems[i].Kk;
     }
     DgxProfScope prof(DGX_PROF_WGRAD, stream, fl, by);
+    if (wgrad_lw_wants(problems, n)) {
+        const int rc = wgrad_lw_launch(problems, n, beta, (hipStream_t)stream);
+        if (rc != DGX_OK) return rc;
+        DGX_LAUNCH_CHECK();
+        return DGX_OK;
+    }
     return wgrad_grouped_impl(problems, nullptr, n, beta, workspace, stream);
 }
 

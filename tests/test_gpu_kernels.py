@@ -798,6 +798,34 @@ def test_linear_wgrad_grouped(shapes):
         assert (gw.cpu().double() - ref0).abs().max() <= 2e-5 * ref0.abs().max() + 1e-3
 
 
+@pytest.mark.parametrize("M", [1100, 2048])
+def test_linear_wgrad_grouped_loader_wave(M):
+    """A group that fills the chip with 256x192 tiles goes to the persistent loader-wave kernel (wgrad_lw.hip): whole-M contraction
+    per tile, ragged tiles in both directions, M not a multiple of the 64-row K-tile, bias gradients from the same pass, beta 0 / 1."""
+    from divergen_amd.layers.linear_ops import wgrad_grouped
+    g = torch.Generator().manual_seed(197)
+    shapes = [(M, 1536, 1536)] * 5 + [(M + 8, 520, 392), (M, 8, 8)]        # 5 x 48 + 9 + 1 = 250 items: 0.98 of a round
+    probs, refs, brefs = [], [], []
+    for k, (m, Nn, Kk) in enumerate(shapes):
+        dy, x = bf(torch.randn(m, Nn, generator=g) * 0.5), bf(torch.randn(m, Kk, generator=g) * 0.5)
+        g0, b0 = torch.randn(Nn, Kk, generator=g), torch.randn(Nn, generator=g)
+        refs.append(g0.double() + dy.double().t() @ x.double())
+        brefs.append(b0.double() + dy.double().sum(0))
+        probs.append((g0.clone().to(DEV), dy.to(DEV), x.to(DEV), b0.clone().to(DEV) if k != 1 else None))
+    wgrad_grouped(probs, beta=1.0)
+    for (gw, _, _, gb), ref, bref in zip(probs, refs, brefs):
+        assert (gw.cpu().double() - ref).abs().max() <= 2e-5 * ref.abs().max() + 1e-3
+        if gb is not None:
+            assert (gb.cpu().double() - bref).abs().max() <= 2e-5 * bref.abs().max() + 1e-3
+    wgrad_grouped(probs, beta=0.0)
+    for (gw, dy, x, gb) in probs:
+        ref0 = dy.cpu().double().t() @ x.cpu().double()
+        assert (gw.cpu().double() - ref0).abs().max() <= 2e-5 * ref0.abs().max() + 1e-3
+        if gb is not None:
+            b0 = dy.cpu().double().sum(0)
+            assert (gb.cpu().double() - b0).abs().max() <= 2e-5 * b0.abs().max() + 1e-3
+
+
 @pytest.mark.parametrize("N,H,W,G,relu", [(2, 16, 12, 32, True), (1, 5, 7, 4, False), (2, 64, 64, 32, True)])
 def test_groupnorm_relu_channels_last(N, H, W, G, relu):
     """Fused GroupNorm(+ReLU) on channels-last bf16 vs torch fp32 group_norm on the same bf16-rounded input."""

@@ -122,6 +122,7 @@ SIGNATURES = {
     "dgx_layernorm_param_reduce2": (c_i, [c_p] * 6 + [c_i64, c_i, c_p]),
     "dgx_wgrad_grouped_workspace_bytes": (c_i64, [ctypes.POINTER(WgradProblem), c_i]),
     "dgx_linear_wgrad_grouped": (c_i, [ctypes.POINTER(WgradProblem), c_i, c_f, c_p, c_p]),
+    "dgx_wgrad_grouped_form": (c_i, [ctypes.POINTER(WgradProblem), c_i]),
     "dgx_cascade_refine": (c_i, [c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_i, c_f, c_f, c_f, c_f, c_f,
                                  c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p]),
     "dgx_paste_masks": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p]),

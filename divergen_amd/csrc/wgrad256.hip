@@ -379,6 +379,10 @@ bool wgrad_lw_wants(const dgx_wgrad_problem* pr, int n);
 int wgrad_lw_launch(const dgx_wgrad_problem* pr, int n, float beta, hipStream_t st);
 constexpr int MAXP_GROUP = 32;           // problems per dgx_linear_wgrad_grouped call: <= 12 on the split-M form, <= 32 on the loader-wave form
 
+extern "C" int dgx_wgrad_grouped_form(const dgx_wgrad_problem* problems, int n) {
+    return problems && n > 0 && n <= MAXP_GROUP && wgrad_lw_wants(problems, n) ? 1 : 0;
+}
+
 extern "C" int64_t dgx_wgrad_grouped_workspace_bytes(const dgx_wgrad_problem* problems, int n) {
     if (!problems || n <= 0 || n > MAXP_GROUP) return 0;
     if (wgrad_lw_wants(problems, n)) return 0;

@@ -27,17 +27,18 @@
 #include "dgx_common.h"
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 
 namespace {
 constexpr int WL_TN = 256, WL_TK = 192;          // tile: Nn rows x Kk columns of the weight gradient
 constexpr int WL_BM = 64;                        // m-depth of a K-tile (two K = 32 MFMA steps)
-constexpr int WL_SLOT = WL_BM * 512;             // bytes of one operand image per K-tile (512-byte rows)
-constexpr int WL_NSA = 3, WL_NSB = 2;
-constexpr int WL_B0 = WL_NSA * WL_SLOT;
-constexpr int WL_LDS = (WL_NSA + WL_NSB) * WL_SLOT;      // 160 KB
+constexpr int WL_GR = 32;                        // rows of a granule (half a K-tile: one K = 32 MFMA step)
+constexpr int WL_GB = WL_GR * 512;               // bytes of one granule image (512-byte rows)
+constexpr int WL_NGA = 6, WL_NGB = 4;            // ring depths (granules)
+constexpr int WL_B0 = WL_NGA * WL_GB;
+constexpr int WL_LDS = (WL_NGA + WL_NGB) * WL_GB;        // 160 KB
 constexpr int WL_MAXP = 32;
 constexpr int WL_THREADS = 768;
-constexpr int WL_NLA = 8, WL_NLB = 8;            // LDS-direct loads per loader wave per K-tile and operand (32 instructions of 2 rows over 4 loaders)
 
 struct WlProb {
     const uint16_t* A;
@@ -72,14 +73,12 @@ __device__ __forceinline__ void wl_bar() {
 }
 __device__ __forceinline__ void wl_lgkm0() { __builtin_amdgcn_s_waitcnt(0xc07f); }
 __device__ __forceinline__ uint32_t wl_sgpr(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
-typedef __bf16 wl_bf2 __attribute__((ext_vector_type(2)));
+template <int N> using wl_ic = std::integral_constant<int, N>;
+template <int N, int I = 0, typename F> __device__ __forceinline__ void wl_static_for(F&& f) {
+    if constexpr (I < N) { f(wl_ic<I>{}); wl_static_for<N, I + 1>(f); }
+}
 }  // namespace
 
-#ifdef WL_NO_STREAM            // timing experiment: the streamed dY fragments are not read (stale registers)
-#define WL_STREAM(a, f)
-#else
-#define WL_STREAM(a, f) frag2(a, f)
-#endif
 #ifdef DGX_GEMM_DEV       // phase time stamps of workgroup 0 (development build only): [wave 0 | wave 4 | wave 8][K-tile][4 stamps], plain stores
 constexpr int WL_CLK_KT = 1024;
 __device__ unsigned long long wl_clk[3 * WL_CLK_KT * 4 + 1];
@@ -123,15 +122,21 @@ __global__ __launch_bounds__(WL_THREADS) void wgrad_lw_kernel(WlParams P) {
         const int t = L - q.item0;
         const int tn = t / q.tiles_k;
         n0 = tn * WL_TN;
-        k0 = (t - tn * q.tiles_k) * WL_TK;
+        // the tile column is rotated per tile row (and once more every 8 rows) so that the items that also sum the bias gradient (k0 == 0)
+        // do not all fall to the same workgroups (item = workgroup + rounds * 32 keeps its residue mod tiles_k otherwise)
+        k0 = ((t - tn * q.tiles_k + tn + (tn >> 3)) % q.tiles_k) * WL_TK;
     };
-    auto a_slot = [](int s) -> uint32_t { return (uint32_t)s * WL_SLOT; };
-
-    // Barrier numbering per item as in gemm_lw.hip: #0 .. #(2 NT + 1); MFMA group 0 reads K-tile t (X fragments, first dY fragments)
-    // in I_{2t+1} and multiplies (streaming the other dY fragments) in I_{2t+2}, group 1 one interval later; the X slot of tile t is
-    // free behind #(2t+2), its dY slot behind #(2t+3); tile t must be visible at #(2t).
+    // Rings of 32-row granules (half a K-tile): dY granule g in slot g % 6, X granule g in slot g % 4 (16 KB each).  ONE barrier per half:
+    // at B_h the MFMA waves are about to multiply half h -- its X fragments they already hold -- and will read the rest of dY(h), the first
+    // fragments of dY(h+1) and all of X(h+1).  The loaders guarantee dY(h+1), X(h+1) landed, and may overwrite dY(h-1) and X(h): every read of
+    // those has returned, because LDS reads return in order and a YOUNGER read of each wave (a dY(h-1) fragment) fed an MFMA that was issued
+    // before the barrier.  So dY(h+5) and X(h+4) are issued behind B_h, 4 resp. 3 halves ahead of their use.
+    // Both MFMA groups run the same free-running loop (no read / multiply phases): the two MFMA waves of a SIMD hide each other's LDS
+    // reads and waits -- a lone wave loses ~6 cycles of MFMA issue per instruction it interleaves (measured: 48 MFMAs took 1 084 cycles in
+    // the two-phase form of this kernel against 778 back to back).
     if (w >= 8) {
-        // ---------------------------------------------------------------- loader waves
+        // ---------------------------------------------------------------- loader waves: the workgroup's pace-maker next to the MFMA waves
+        // (8 loads per half at ~65 cycles of issue each), so everything per load is a running register: no multiply, no modulo
         const int lw = w - 8;
         const int rip = l >> 5;                                       // row inside the 2-row instruction
         // logical 16-byte chunk of this lane in instruction s: row = 8 s + 2 lw + rip, row & 3 = 2 (lw & 1) + rip, (row >> 3) & 1 = s & 1
@@ -139,105 +144,106 @@ __global__ __launch_bounds__(WL_THREADS) void wgrad_lw_kernel(WlParams P) {
         const uint32_t ldsq = wl_sgpr(lds0 + 1024u * lw);
         const uint32_t OOB = 0x80000000u;
         WlProb q;
-        int n0, k0, NT = 0;
-        uint32_t vA[2] = {OOB, OOB}, vB[2] = {OOB, OOB};       // even / odd instructions
+        int n0, k0, NH = 0;
+        uint32_t va[4], vb[4];                     // byte offsets of this lane in the 4 instructions of the NEXT dY / X granule to issue
+        uint32_t stepA = 0, stepB = 0, sa = 0, sb = 0;     // bytes per granule; ring slots (byte offsets) of those granules
         u32x4 rA, rB;
         auto setup = [&](int L) {
             locate((P.diag & 1) ? 0 : L, q, n0, k0);
             if (P.diag & 1) { WlProb q1; int a1, b1; locate(L, q1, a1, b1); q.M = q1.M; }
-            NT = (q.M + WL_BM - 1) / WL_BM;
+            NH = 2 * ((q.M + WL_BM - 1) / WL_BM);
 #pragma unroll
-            for (int o = 0; o < 2; ++o) {
-                const int lc = o ? lc1 : lc0;
-                vA[o] = (n0 + 8 * lc < q.Nn) ? (uint32_t)(((2 * lw + rip + 8 * o) * q.Nn + n0 + 8 * lc) * 2) : OOB;
-                vB[o] = (8 * lc < WL_TK && k0 + 8 * lc < q.Kk) ? (uint32_t)(((2 * lw + rip + 8 * o) * q.Kk + k0 + 8 * lc) * 2) : OOB;
+            for (int s = 0; s < 4; ++s) {          // instruction s: rows 8 s + 2 lw + rip
+                const int lc = (s & 1) ? lc1 : lc0, row = 8 * s + 2 * lw + rip;
+                va[s] = (n0 + 8 * lc < q.Nn) ? (uint32_t)((row * q.Nn + n0 + 8 * lc) * 2) : OOB;
+                vb[s] = (8 * lc < WL_TK && k0 + 8 * lc < q.Kk) ? (uint32_t)((row * q.Kk + k0 + 8 * lc) * 2) : OOB;
             }
+            stepA = (uint32_t)(WL_GR * q.Nn * 2); stepB = (uint32_t)(WL_GR * q.Kk * 2);
+            sa = 0; sb = 0;
             rA = wl_rsrc(q.A, (uint32_t)((int64_t)q.M * q.Nn * 2));   // rows >= M are out of range: zeros
             rB = wl_rsrc(q.B, (uint32_t)((int64_t)q.M * q.Kk * 2));
         };
-        // instruction s of this loader covers image rows 2 (lw + 4 s), +1 = tile rows 8 s + 2 lw (+1).  The row offset goes through the
-        // VECTOR offset (an add per load, the loaders have nothing else to do) so that rows >= M fall under the descriptor's range check
-        // and arrive as zeros; lanes beyond the matrix width keep bit 31 set through the adds (M * width * 2 < 2^31)
-        auto issue_a = [&](int t) {
-            if (t >= NT) return;
-            const uint32_t dst = ldsq + a_slot(t % WL_NSA);
-            const uint32_t step = (uint32_t)(16 * q.Nn * 2), at = (uint32_t)(t * WL_BM) * (uint32_t)(q.Nn * 2);
-            uint32_t v0 = vA[0] + at, v1 = vA[1] + at;
+        // One granule = 4 instructions of this wave.  The row offset lives in the VECTOR offset so that rows >= M fall under the descriptor's
+        // range check and arrive as zeros (granules behind the end of M are issued all the same: no memory traffic, and the load counts
+        // the waits rely on stay fixed); lanes beyond the matrix width keep bit 31 set through the adds (M * width * 2 < 2^31)
+        auto issue_a1 = [&](int s) { wl_load_lds16(va[s], rA, wl_sgpr(ldsq + sa + 4096u * s), 0u); va[s] += stepA; };
+        auto issue_b1 = [&](int s) { wl_load_lds16(vb[s], rB, wl_sgpr(ldsq + WL_B0 + sb + 4096u * s), 0u); vb[s] += stepB; };
+        auto next_a = [&]() { sa = sa + WL_GB == WL_NGA * WL_GB ? 0u : sa + WL_GB; };
+        auto next_b = [&]() { sb = (sb + WL_GB) & (WL_NGB * WL_GB - 1); };
+        auto issue_a = [&]() {
 #pragma unroll
-            for (int s = 0; s < WL_NLA; s += 2, v0 += step, v1 += step) {
-                wl_load_lds16(v0, rA, wl_sgpr(dst + 4096u * s), 0u);
-                wl_load_lds16(v1, rA, wl_sgpr(dst + 4096u * (s + 1)), 0u);
-            }
+            for (int s = 0; s < 4; ++s) issue_a1(s);
+            next_a();
         };
-        auto issue_b = [&](int t) {
-            if (t >= NT) return;
-            const uint32_t dst = ldsq + WL_B0 + (uint32_t)(t % WL_NSB) * WL_SLOT;
-            const uint32_t step = (uint32_t)(16 * q.Kk * 2), at = (uint32_t)(t * WL_BM) * (uint32_t)(q.Kk * 2);
-            uint32_t v0 = vB[0] + at, v1 = vB[1] + at;
+        auto issue_b = [&]() {
 #pragma unroll
-            for (int s = 0; s < WL_NLB; s += 2, v0 += step, v1 += step) {
-                wl_load_lds16(v0, rB, wl_sgpr(dst + 4096u * s), 0u);
-                wl_load_lds16(v1, rB, wl_sgpr(dst + 4096u * (s + 1)), 0u);
-            }
+            for (int s = 0; s < 4; ++s) issue_b1(s);
+            next_b();
         };
-        // loads of this wave younger than B(tau) (the later one of the pair: NSA > NSB) when tiles up to A(ia), B(ib) have been issued
-        auto wait_tile = [&](int tau, int ia, int ib) {
-            const int la = min(ia, NT - 1), lb = min(ib, NT - 1);
-            const int n = max(0, la - tau) * WL_NLA + max(0, lb - tau) * WL_NLB;
-            if (n >= 2 * WL_NLA + WL_NLB) wl_vmcnt<2 * WL_NLA + WL_NLB>();
-            else if (n >= WL_NLA) wl_vmcnt<WL_NLA>();
-            else wl_vmcnt<0>();
-        };
-        // Bias gradient (column sums of dY) of the items of a problem's first tile column, on the loader waves (they idle between their
-        // loads; the MFMA waves have no register to spare): wave lw sums the 64 columns 64 lw .. of the dY image as it lands -- lane
-        // (rg = l >> 4, cq = l & 15) the 4 columns 4 cq .. of rows = rg (mod 4), 8 rows per half tile, by 8-byte reads at the swizzled place
-        const int rg = l >> 4, cq = l & 15;
-        const uint32_t boff = (uint32_t)(rg * 512 + (((8 * lw + (cq >> 1)) ^ (rg << 1)) << 4) + (cq & 1) * 8);
-        float bs[4] = {0.f, 0.f, 0.f, 0.f};
-        auto bias_rows = [&](int t, int half) {
-            DGX_LDS const unsigned char* sl = (DGX_LDS const unsigned char*)lds_raw + a_slot(t % WL_NSA) + half * (32 * 512);
-            DGX_LDS const u32x2* pr0 = reinterpret_cast<DGX_LDS const u32x2*>(sl + boff);            // rows with (row >> 3) & 1 = 0
-            DGX_LDS const u32x2* pr1 = reinterpret_cast<DGX_LDS const u32x2*>(sl + (boff ^ 128u));   // ... = 1: the other 128 bytes
+        // Bias gradient (column sums of dY) of the items of a problem's first tile column, on the loader waves -- and on the MATRIX pipe:
+        // any VALU instruction in this kernel waits ~20 cycles for an issue slot between the MFMA waves' instructions (32 adds per half
+        // cost 650 cycles when tried), while ones^T x fragment is 4 MFMAs per loader wave and half (+8 % pipe time on these items only).
+        // Wave lw owns the dY fragments 4 lw + f (columns 64 lw + 16 f ..): their transpose reads go out a half ahead (LDS latency under the
+        // MFMA waves' traffic is several hundred cycles), the MFMAs follow behind the next half's loads.
+        const int g = l >> 4, c16 = l & 15, x = c16 >> 2;
+        DGX_LDS const uint16_t* pf[4];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {                      // row 4 k + rg
-                const u32x2 v = ((k >> 1) & 1 ? pr1 : pr0)[k * (4 * 512 / 8)];
-                bs[0] += __uint_as_float(v[0] << 16); bs[1] += __uint_as_float(v[0] & 0xffff0000u);
-                bs[2] += __uint_as_float(v[1] << 16); bs[3] += __uint_as_float(v[1] & 0xffff0000u);
+        for (int f = 0; f < 4; ++f)
+            pf[f] = lds_opaque(reinterpret_cast<const uint16_t*>(lds_raw + (8 * g + x) * 512 + 16 * ((c16 >> 1) & 1) + 8 * (c16 & 1) + 32 * ((4 * lw + f) ^ x ^ ((g & 1) << 2))));
+        const bf16x8 ones = {(short)0x3F80, (short)0x3F80, (short)0x3F80, (short)0x3F80, (short)0x3F80, (short)0x3F80, (short)0x3F80, (short)0x3F80};
+        f32x4 bacc[4];
+        bf16x8 bfrag[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) bacc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+        uint32_t sbias = 0;                        // slot (in elements) of the dY granule whose fragments are read next
+        auto bias_read = [&]() {
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                DGX_LDS const uint16_t* p = pf[f] + sbias;
+                asm volatile("" : "+v"(p));
+                bfrag[f] = tr_frag(p, 0, 4 * 256);
             }
+            sbias = sbias + WL_GB / 2 == WL_NGA * WL_GB / 2 ? 0u : sbias + WL_GB / 2;
         };
+        auto bias_fold = [&](int f) { bacc[f] = mfma16(ones, bfrag[f], bacc[f]); };
         setup(first);
         WLCLK0();
         for (int L = first; L < bound; L += nwx) {
             const bool do_bias = q.gb != nullptr && k0 == 0;
-            // prologue in the order the schedule keeps: A(0), B(0), A(1), B(1), A(2).  Every slot is free here (the read-out uses no LDS)
-            issue_a(0); issue_b(0); issue_a(1); issue_b(1); issue_a(2);
-            wait_tile(0, WL_NSA - 1, WL_NSB - 1);
-            wl_bar();                              // #0
-            for (int t = 0; t < NT; ++t) {
-                if (t >= 1) issue_b(t - 1 + WL_NSB);   // I_{2t+1}
-                if (do_bias) bias_rows(t, 0);          // tile t is visible since #(2t); its dY slot is rewritten behind #(2t+3)
+            // every slot is free here (barrier E of the previous item); issue order A0 X0 A1 X1 A2 X2 A3 X3 A4, then A(h+5) X(h+4) behind B_h
+            issue_a(); issue_b(); issue_a(); issue_b(); issue_a(); issue_b(); issue_a(); issue_b(); issue_a();
+            wl_vmcnt<28>();                        // A0, X0 (7 granules younger)
+            wl_bar();                              // P: the MFMA waves read X(0) and the first dY(0) fragments
+            sbias = 0;
+            if (do_bias) bias_read();
+            for (int h = 0; h < NH; ++h) {
+                // before B_h: dY(h+1), X(h+1).  Younger than X(h+1): h = 0: A2 X2 A3 X3 A4; h = 1: A3 X3 A4 A5 X4; h = 2: A4 A5 X4 A6 X5; later:
+                // the four granules issued behind B_(h-2) and B_(h-1)
+                if (h < 3) wl_vmcnt<20>(); else wl_vmcnt<16>();
                 if (lw == 0) WLCLK(8, 0);
-                wl_bar();                          // #(2t+1)
+                wl_bar();                          // B_h
                 if (lw == 0) WLCLK(8, 1);
-                if (t >= 1) issue_a(t - 1 + WL_NSA);   // I_{2t+2}
-                if (do_bias) bias_rows(t, 1);
-                if (t + 1 < NT) wait_tile(t + 1, t - 1 + WL_NSA, t - 1 + WL_NSB);
+                if (do_bias) {                     // dY(h)'s rows were read a half ago (their LDS latency hides behind the barrier)
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) { issue_a1(s); bias_fold(s); }
+                    issue_b();
+                    next_a();
+                    bias_read();                   // dY(h+1): visible since this barrier, stays until B_(h+2); behind the end of M: zeros / unused
+                } else {
+                    issue_a();
+                    issue_b();
+                }
                 if (lw == 0) WLCLK(8, 2);
-                wl_bar();                          // #(2t+2)
                 if (lw == 0) WLCLK(8, 3);
                 WLCLKN();
             }
-            wl_vmcnt<0>();
-            wl_bar();                              // #(2 NT + 1)
-            if (do_bias) {                         // fold the four row classes, then lane cq of row class 0 owns 4 entries
+            wl_bar();                              // E: every read of this item's granules has fed its MFMA
+            if (do_bias) {                         // every row of the 16 x 16 result holds the column sums: lanes 0-15 own one entry per fragment
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float v = bs[e];
-                    v += __shfl_xor(v, 16);
-                    v += __shfl_xor(v, 32);
-                    const int n = n0 + 64 * lw + 4 * cq + e;
-                    if (rg == 0 && n < q.Nn) q.gb[n] = P.beta != 0.f ? P.beta * q.gb[n] + v : v;
-                    bs[e] = 0.f;
+                for (int f = 0; f < 4; ++f) {
+                    const int n = n0 + 64 * lw + 16 * f + c16;
+                    if (g == 0 && n < q.Nn) q.gb[n] = P.beta != 0.f ? P.beta * q.gb[n] + bacc[f][0] : bacc[f][0];
+                    bacc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
             }
             if (L + nwx < bound) setup(L + nwx);
@@ -246,20 +252,28 @@ __global__ __launch_bounds__(WL_THREADS) void wgrad_lw_kernel(WlParams P) {
     }
 
     // ---------------------------------------------------------------- MFMA waves
+    // Group grp owns the dY fragments I = 8 c + 4 grp + b (c = 0, 1; b = 0..3): the two 64-column blocks 64 grp .. and 128 + 64 grp ..; wave wc
+    // the X fragments 3 wc + j.  NO address arithmetic in the loop (a per-fragment v_add costs this instruction mix ~15 % of its MFMA rate,
+    // tools/probes/mfma_mix_probe.hip): transpose-read lane pointers -- lane p = c16 supplies row 8g + (p >> 2) (+ 4), the 8-byte piece p & 3
+    // of a fragment's 16 columns; fragment I of row r sits at byte 32 (I ^ (r & 3) ^ 4 ((r >> 3) & 1)), r & 3 = x = p >> 2 and (r >> 3) & 1 =
+    // g & 1 for every row this lane reads -- are formed once, four per 64 KB window of the dY ring (the DS offset field is 16 bits) and three
+    // for the X ring; granule slot, c and the second 4-row block are immediates because the loop is unrolled over the rings' common period
+    // of 12 halves.
     const int grp = (w >> 2) & 1, wc = w & 3;
     const int g = l >> 4, c16 = l & 15;
-    // transpose-read lane pointers (wgrad256.hip): lane p = c16 supplies row 8g + (p >> 2) (+ 4), the 8-byte piece p & 3 of a fragment's 16
-    // columns; fragment I of a row (columns 16 I ..) sits at byte 32 (I ^ x) + 16 hi + 8 lo under the swizzle, x = p >> 2
     const int x = c16 >> 2, hi = (c16 >> 1) & 1, lo = c16 & 1;
     const uint32_t rowb = (uint32_t)((8 * g + x) * 512 + 16 * hi + 8 * lo);
-    uint32_t fa[4], fb[3];
-    // fragment I of row r: byte 32 (I ^ (r & 3) ^ 4 ((r >> 3) & 1)); r & 3 = x and (r >> 3) & 1 = g & 1 for every row this lane reads
     const int gb = g & 1;
+    DGX_LDS const uint16_t* pa[2][4];
+    DGX_LDS const uint16_t* pb[3];
 #pragma unroll
-    for (int b = 0; b < 4; ++b) fa[b] = rowb + 32u * (uint32_t)(b ^ x) + 128u * (uint32_t)gb + (uint32_t)(grp * 128) * 2u;   // dY fragment i = 4 a + b, a = 0
-    const uint32_t fa1 = gb ? (uint32_t)-128 : 128u;                                                        // a = 1: the other 128 bytes
+    for (int b = 0; b < 4; ++b) {
+        const uint32_t o = rowb + 32u * (uint32_t)(b ^ x) + 128u * (uint32_t)(grp ^ gb);
+        pa[0][b] = lds_opaque(reinterpret_cast<const uint16_t*>(lds_raw + o));
+        pa[1][b] = lds_opaque(reinterpret_cast<const uint16_t*>(lds_raw + o + 4 * WL_GB));
+    }
 #pragma unroll
-    for (int j = 0; j < 3; ++j) fb[j] = (uint32_t)WL_B0 + rowb + 32u * (uint32_t)((3 * wc + j) ^ x ^ (gb << 2));      // X fragment j of this wave
+    for (int j = 0; j < 3; ++j) pb[j] = lds_opaque(reinterpret_cast<const uint16_t*>(lds_raw + WL_B0 + rowb + 32u * (uint32_t)((3 * wc + j) ^ x ^ (gb << 2))));
     WLCLK0();
 #ifdef DGX_GEMM_DEV
     if (blockIdx.x == 0 && tid == 0) { wl_clk2[92] = clock64(); wl_clk2[93] = wall_clock64(); }
@@ -268,67 +282,77 @@ __global__ __launch_bounds__(WL_THREADS) void wgrad_lw_kernel(WlParams P) {
         WlProb q;
         int n0, k0;
         locate(L, q, n0, k0);
-        const int NT = (q.M + WL_BM - 1) / WL_BM;
+        const int NH = 2 * ((q.M + WL_BM - 1) / WL_BM);
         f32x4 acc[8][3];
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int j = 0; j < 3; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        bf16x8 bfr[3][2], afr[8][2];
-        // both k-halves of a fragment from one lane address (made opaque: the four reads then differ by immediate offsets only)
-        auto frag2 = [&](uint32_t addr, bf16x8 (&f)[2]) {
-            DGX_LDS const uint16_t* p = reinterpret_cast<DGX_LDS const uint16_t*>((DGX_LDS const unsigned char*)lds_raw + addr);
-            asm volatile("" : "+v"(p));
-            f[0] = tr_frag(p, 0, 4 * 256);
-            f[1] = tr_frag(p, 32 * 256, 32 * 256 + 4 * 256);
+        bf16x8 b0[3], b1[3], afr[4];               // X fragments of the current / the next half; ring of streamed dY fragments
+        constexpr int PRE = 3;                     // dY fragments in flight ahead of their MFMAs (ring of PRE + 1)
+        // dY fragment i = 4 c + b of the granule in ring slot s (8 k-slots = the lane group's 8 rows): two reads, immediates only
+        auto fragA = [&](auto S, auto I) -> bf16x8 {
+            constexpr int s_ = decltype(S)::value, i_ = decltype(I)::value;
+            constexpr int off = (s_ & 3) * (WL_GB / 2) + 128 * (i_ >> 2);           // elements
+            return tr_frag(pa[s_ >> 2][i_ & 3], off, off + 4 * 256);
         };
-        constexpr int PRE = 2;
-        auto read_phase = [&](int t) {
-            const uint32_t bo = (uint32_t)(t % WL_NSB) * WL_SLOT, ao = a_slot(t % WL_NSA);
-#pragma unroll
-            for (int j = 0; j < 3; ++j) frag2(bo + fb[j], bfr[j]);
-#pragma unroll
-            for (int i = 0; i < PRE; ++i) frag2(ao + fa[i & 3] + ((i >> 2) ? fa1 : 0u), afr[i]);
+        auto fragB = [&](auto S, auto J) -> bf16x8 {
+            constexpr int off = decltype(S)::value * (WL_GB / 2);
+            return tr_frag(pb[decltype(J)::value], off, off + 4 * 256);
         };
-        auto mfma_phase = [&](int t) {
-            const uint32_t ao = a_slot(t % WL_NSA);
+        // half at ring position U (granule h = U mod 12): bc = X(h) fragments (held), bn <- X(h+1)
+        auto half = [&](auto U, const bf16x8 (&bc)[3], bf16x8 (&bn)[3]) {
+            constexpr int u = decltype(U)::value, sa = u % WL_NGA, sa1 = (u + 1) % WL_NGA, sb1 = (u + 1) % WL_NGB;
+            wl_bar();                              // B_h
             __builtin_amdgcn_s_setprio(1);
+            wl_static_for<8>([&](auto I) {
+                constexpr int i = decltype(I)::value, ip = i + PRE;
+                if constexpr (ip < 8) afr[ip & 3] = fragA(wl_ic<sa>{}, wl_ic<ip>{});
+                else afr[ip & 3] = fragA(wl_ic<sa1>{}, wl_ic<ip - 8>{});
+                if constexpr (i < 3) bn[i] = fragB(wl_ic<sb1>{}, wl_ic<i>{});
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                if (i + PRE < 8) WL_STREAM(ao + fa[(i + PRE) & 3] + (((i + PRE) >> 2) ? fa1 : 0u), afr[i + PRE]);
-#pragma unroll
-                for (int kh = 0; kh < 2; ++kh)
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) acc[i][j] = mfma16(bfr[j][kh], afr[i][kh], acc[i][j]);     // D[k'][n]^T: lane = 4 Kk columns of one Nn row
-                if (i + PRE < 8) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
-            }
+                for (int j = 0; j < 3; ++j) acc[i][j] = mfma16(bc[j], afr[i & 3], acc[i][j]);     // D[k'][n]^T: lane = 4 Kk columns of one Nn row
+            });
+            // pin the order: the compiler otherwise sinks the reads to just above their use (prefetch distance 1 instead of PRE)
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0); __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0); __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0); __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
             __builtin_amdgcn_s_setprio(0);
         };
-        wl_bar();                                  // #0
+        wl_bar();                                  // P: dY(0), X(0) landed
         if (wc == 0) WLCLKI(4 * grp, 2);
         WLCLKIN();
-        if (grp == 1) wl_bar();                    // #1: one phase behind group 0
-        for (int t = 0; t < NT; ++t) {
-            read_phase(t);
-            wl_lgkm0();
+        wl_static_for<3>([&](auto J) { b0[decltype(J)::value] = fragB(wl_ic<0>{}, J); });
+        wl_static_for<PRE>([&](auto I) { afr[decltype(I)::value] = fragA(wl_ic<0>{}, I); });
+        for (int h = 0; h < NH; h += 12) {         // NH is even; both rings are back at slot 0 after 12 halves
             if (wc == 0) WLCLK(4 * grp, 0);
-            wl_bar();
+            half(wl_ic<0>{}, b0, b1); half(wl_ic<1>{}, b1, b0);
             if (wc == 0) WLCLK(4 * grp, 1);
-            mfma_phase(t);
-            wl_lgkm0();
+            if (h + 2 >= NH) break;
+            half(wl_ic<2>{}, b0, b1); half(wl_ic<3>{}, b1, b0);
+            if (h + 4 >= NH) break;
+            half(wl_ic<4>{}, b0, b1); half(wl_ic<5>{}, b1, b0);
+            if (h + 6 >= NH) break;
+            half(wl_ic<6>{}, b0, b1); half(wl_ic<7>{}, b1, b0);
+            if (h + 8 >= NH) break;
+            half(wl_ic<8>{}, b0, b1); half(wl_ic<9>{}, b1, b0);
+            if (h + 10 >= NH) break;
+            half(wl_ic<10>{}, b0, b1); half(wl_ic<11>{}, b1, b0);
             if (wc == 0) WLCLK(4 * grp, 2);
-            wl_bar();
-            if (wc == 0) WLCLK(4 * grp, 3);
             WLCLKN();
         }
-        if (grp == 0) wl_bar();                    // #(2 NT + 1)
+        wl_bar();                                  // E
         if (wc == 0) WLCLKI(4 * grp, 0);
         // ---- read-out: fp32 read-modify-write of the gradient straight from the accumulators (16 bytes per lane, 64-byte runs per row)
         const float beta = P.beta;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int n = n0 + grp * 128 + 16 * i + c16;
+            const int n = n0 + 128 * (i >> 2) + 64 * grp + 16 * (i & 3) + c16;
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 const int k = k0 + wc * 48 + 16 * j + 4 * g;

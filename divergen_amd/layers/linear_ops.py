@@ -30,10 +30,7 @@ def wgrad_into(g2, dy2, x2, beta=1.0, gb=None):
     wgrad_grouped([(g2, dy2.contiguous(), x2.contiguous(), gb)], beta)
 
 
-def wgrad_grouped(problems, beta=1.0):
-    """[(g2 fp32 (Nn,Kk), dy2 bf16 (M,Nn), x2 bf16 (M,Kk)[, gb fp32 (Nn) | None]), ...] (<= 12): g2 = beta*g2 + dy2^T x2 and, with
-    gb, the bias gradient gb = beta*gb + dy2.sum(0) from the same pass -- ONE launch (dgx_linear_wgrad_grouped: 256x256 MFMA
-    tiles, M-split sized for the whole group)."""
+def _wgrad_array(problems):
     n = len(problems)
     arr = (L.WgradProblem * n)()
     for i, pr in enumerate(problems):
@@ -45,6 +42,23 @@ def wgrad_grouped(problems, beta=1.0):
         arr[i].dy, arr[i].x, arr[i].gw = dy2.data_ptr(), x2.data_ptr(), g2.data_ptr()
         arr[i].gb = gb.data_ptr() if gb is not None else None
         arr[i].M, arr[i].Nn, arr[i].Kk = dy2.shape[0], dy2.shape[1], x2.shape[1]
+    return arr
+
+
+def wgrad_group_form(problems):
+    """1 if dgx_linear_wgrad_grouped would take this group (<= 32 problems) on the persistent loader-wave kernel, 0 if on the
+    split-M kernel (which takes <= 12): dgx_wgrad_grouped_form."""
+    n = len(problems)
+    return 0 if n == 0 or n > 32 else int(L.lib().dgx_wgrad_grouped_form(_wgrad_array(problems), n))
+
+
+def wgrad_grouped(problems, beta=1.0):
+    """[(g2 fp32 (Nn,Kk), dy2 bf16 (M,Nn), x2 bf16 (M,Kk)[, gb fp32 (Nn) | None]), ...]: g2 = beta*g2 + dy2^T x2 and, with gb, the
+    bias gradient gb = beta*gb + dy2.sum(0) from the same pass -- ONE launch (dgx_linear_wgrad_grouped: 256x256 MFMA tiles with an
+    M-split sized for the whole group, <= 12 problems; or, for groups that fill the chip with 256x192 tiles for whole rounds, the
+    persistent loader-wave kernel, <= 32 problems -- wgrad_group_form tells which)."""
+    n = len(problems)
+    arr = _wgrad_array(problems)
     lib = L.lib()
     nbytes = int(lib.dgx_wgrad_grouped_workspace_bytes(arr, n))
     ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=problems[0][1].device)

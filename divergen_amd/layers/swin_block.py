@@ -17,7 +17,7 @@ import torch
 
 from .. import _lib as L
 from . import gemm_ops as G
-from .linear_ops import BF16, notify_ready, shadow, shadow_t, wgrad_grouped
+from .linear_ops import BF16, notify_ready, shadow, shadow_t, wgrad_group_form, wgrad_grouped
 
 
 def arena_resident(params):
@@ -58,10 +58,21 @@ import os
 # tiles instead of 216 on the 256 CUs, and 18 stage-2 blocks need 8 launches instead of 9 (a launch lasts one tile's contraction
 # whatever its tile count).  Operands stay alive until their problem has been launched; whatever is still pending when the backward
 # pass ends is flushed by an autograd end-of-backward callback.  DGX_WGRAD_PAIR=1 restores one launch per block, =2 block pairs.
+# Round 4: blocks with many output tiles and a long contraction (Swin-L stage 2: 144 tiles of 256x192 per block, M = 8 192 / 10 368) are
+# queued until ~4 rounds of the chip are together (7 blocks = 1 008 tiles, 28 problems) and run as ONE launch of the persistent
+# loader-wave kernel (csrc/wgrad_lw.hip: every tile contracts its whole M -- no split, no workspace, no reduce launch); the library says
+# whether a group qualifies (dgx_wgrad_grouped_form), otherwise the group goes the round-3 way.
 _PAIR = max(1, int(os.environ.get("DGX_WGRAD_PAIR", "3")))
 _PENDING = []          # [problem (g, dy, x, bias, weight), tiles] in arrival order
+_PENDING_LW = []       # problems queued for a loader-wave launch
 _CB_QUEUED = [False]
 _ROUND, _MAXP = 256, 12
+_LW_MIN_M = int(os.environ.get("DGX_WGRAD_LW_MIN_M", "4096"))      # shortest contraction queued for the loader-wave form (0: never)
+_LW_ITEMS, _LW_MAXP = 1000, 32
+
+
+def _lw_items(g):
+    return (-(-g.shape[0] // 256)) * (-(-g.shape[1] // 192))
 
 
 def _tiles(g):
@@ -86,6 +97,7 @@ def flush_wgrads(final=True):
     their parameters.  final=False (called when a block's problems arrive) keeps the tail that does not yet fill a round."""
     if final:
         _CB_QUEUED[0] = False
+        _flush_lw()
     while _PENDING:
         if not final and sum(t for _, t in _PENDING) < _ROUND:      # not enough queued to choose a full round from
             break
@@ -103,16 +115,48 @@ def flush_wgrads(final=True):
 def reset_pending():
     """Drop problems whose backward pass never completed (an exception unwound it): called when the gradients are cleared for a
     new step, so that a stale problem can never be launched into the gradients of the next step."""
-    if _PENDING:
+    if _PENDING or _PENDING_LW:
         import warnings
-        warnings.warn("divergen_amd: %d pending weight gradients dropped (an earlier backward pass did not finish)" % len(_PENDING))
+        warnings.warn("divergen_amd: %d pending weight gradients dropped (an earlier backward pass did not finish)"
+                      % (len(_PENDING) + len(_PENDING_LW)))
         del _PENDING[:]
+        del _PENDING_LW[:]
     _CB_QUEUED[0] = False
+
+
+def _flush_lw():
+    """Launch the queued loader-wave group -- in one launch if the library takes it in that form, else the round-3 way."""
+    if not _PENDING_LW:
+        return
+    items = [[p, _tiles(p[0])] for p in _PENDING_LW]
+    del _PENDING_LW[:]
+    if wgrad_group_form([(g, d, x_, b.grad if b is not None else None) for (g, d, x_, b, w), _ in items]):
+        _launch(items)
+    else:
+        _flush_all()
+        _PENDING.extend(items)
+        _flush_all()
+
+
+def _queue_callback():
+    if (_PENDING or _PENDING_LW) and not _CB_QUEUED[0]:
+        _CB_QUEUED[0] = True
+        torch.autograd.Variable._execution_engine.queue_callback(flush_wgrads)
 
 
 def _defer_wgrads(wgrads, params):
     blk = sum(_tiles(p[0]) for p in wgrads)
     M = wgrads[0][1].shape[0]
+    if _PENDING_LW and _PENDING_LW[0][1].shape[0] != M:   # a new stage: the queued group goes out
+        _flush_lw()
+    if _LW_MIN_M and min(p[1].shape[0] for p in wgrads) >= _LW_MIN_M and sum(_lw_items(p[0]) for p in wgrads) >= 128 and wgrads[0][1].is_cuda:
+        if len(_PENDING_LW) + len(wgrads) > _LW_MAXP:
+            _flush_lw()
+        _PENDING_LW.extend(wgrads)
+        if sum(_lw_items(p[0]) for p in _PENDING_LW) >= _LW_ITEMS or len(_PENDING_LW) + len(wgrads) > _LW_MAXP:
+            _flush_lw()
+        _queue_callback()
+        return
     if _PENDING and _PENDING[0][0][1].shape[0] != M:      # a new stage (other token count): its problems do not share launches
         _flush_all()
     if _PAIR >= 3 and 2 * blk <= _ROUND:                  # at least two blocks fit a round: pack by problem
@@ -122,9 +166,7 @@ def _defer_wgrads(wgrads, params):
         _PENDING.extend([p, 0] for p in wgrads)
         if len(_PENDING) // 4 >= min(_PAIR, 2):
             _flush_all()
-    if _PENDING and not _CB_QUEUED[0]:
-        _CB_QUEUED[0] = True
-        torch.autograd.Variable._execution_engine.queue_callback(flush_wgrads)
+    _queue_callback()
 
 
 def _flush_all():

@@ -384,7 +384,10 @@ int dgx_residual_bwd(const void* g, const float* scale, void* dy_bf16, int B, in
 /* ---------------------------------------------------------------------------------------------
  * Grouped form of dgx_linear_wgrad: the weight gradients of several Linear layers (the four of a Swin
  * block: qkv/proj/fc1/fc2, swintransformer.py:101-108,36-46) in ONE launch, so that large output tiles
- * fill the GPU with a small M-split.  n <= 12 problems; for each gw (Nn,Kk) = beta*gw + dy^T x  and, when gb != NULL, the
+ * fill the GPU with a small M-split.  n <= 12 problems -- or up to 32 when dgx_wgrad_grouped_form(problems, n) == 1: groups
+ * with enough 256x192 output tiles to fill the chip for whole rounds (the Linears of ~7 Swin-L stage-2 blocks) run on the
+ * persistent loader-wave kernel (wgrad_lw.hip: every tile contracts its whole M, no split, no workspace).  For each problem
+ * gw (Nn,Kk) = beta*gw + dy^T x  and, when gb != NULL, the
  * layer's BIAS gradient gb (Nn) = beta*gb + column sums of dy from the same pass (the sum over rows autograd performs for the
  * bias; computed as dy^T 1 on fragments the kernel holds anyway -- ABI version 3 added the field).
  * Nn % 8 == 0, Kk % 8 == 0.  workspace: dgx_wgrad_grouped_workspace_bytes(problems, n) bytes. */
@@ -398,6 +401,9 @@ typedef struct dgx_wgrad_problem {
 int64_t dgx_wgrad_grouped_workspace_bytes(const dgx_wgrad_problem* problems, int n);
 int dgx_linear_wgrad_grouped(const dgx_wgrad_problem* problems, int n, float beta, void* workspace,
                              void* stream);
+/* 1 when dgx_linear_wgrad_grouped would run this group on the loader-wave kernel (n <= 32 allowed), 0 when on the split-M
+ * kernel (n <= 12): the caller sizes its launches with it. */
+int dgx_wgrad_grouped_form(const dgx_wgrad_problem* problems, int n);
 
 /* ---------------------------------------------------------------------------------------------
  * Bias gradient of nn.Linear (the sum over rows autograd performs for the bias of qkv/proj/fc1/fc2,

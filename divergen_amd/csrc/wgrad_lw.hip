@@ -3,25 +3,31 @@
 // -- the contract of wgrad256.hip (the weight gradients autograd forms for nn.Linear at swintransformer.py:36-46,101-108), for
 // launches that hold MANY output tiles (the Linears of several Swin blocks of stages 2 / 3: 144 / 576 tiles of 256 x 192 per block).
 //
-// Why a second kernel.  wgrad256's four waves (256 x 256 tile, 256 AGPR accumulators each) issue their own LDS-direct loads: 8 per
-// wave and 32-row stage at ~60 cycles of in-order issue each, next to 64 MFMAs (1 024 cycles) and 32 transpose reads -- 0.9-1.2
-// PFLOP/s in situ.  With accumulators that size there is no room for a second wave per SIMD to take the loads.  The structure that
-// gave the forward GEMM 84-87 % MFMA issue in its main loop (gemm_lw.hip: 1 772-1 836 cycles per K-tile of a 256 x 192 tile against
-// 1 536 of MFMA issue) fits here as well, because the main loop is ALL there is to a weight gradient (M = 8 192 .. 10 368 rows = 128 ..
-// 162 K-tiles per tile, the read-out is 2 % of it):
-//   * 12 waves: waves 8-11 only load (LDS-direct, counted vmcnt, published by the workgroup barrier), waves 0-7 only multiply
-//     (2 groups x 4: wave tile 128 (Nn) x 48 (Kk), 96 accumulator registers, <= 168 registers per lane);
-//   * operand images as in memory, [m][n]: 64 rows x 512 B per K-tile and operand (the X image uses 384 of its 512 bytes per row, so
-//     that both operands share one layout: 16-byte chunk c of row r at chunk c ^ ((r & 3) << 1) ^ (((r >> 3) & 1) << 3) -- the first term spreads
-//     the four rows a 16-lane group reads, the second puts the rows of the odd lane groups into the other 128 bytes of the 256-byte bank
-//     period, without it the two 16-lane groups of a 32-lane LDS pass meet on the same 32 banks (SQ_LDS_BANK_CONFLICT = half of all LDS
-//     cycles, measured); fragments by ds_read_b64_tr_b16); rings of 3 (dY) + 2 (X) K-tiles = 160 KB;
+// Why a second kernel.  wgrad256's four waves (256 x 256 tile, 256 AGPR accumulators each) issue their own LDS-direct loads next to
+// 64 MFMAs and 32 transpose reads per 32-row stage: a lone wave per SIMD loses MFMA issue to every instruction it interleaves, and the
+// M-split that fills the chip costs fp32 partial slabs and a reduce launch.  Here (round 4):
+//   * 12 waves: waves 8-11 only load (LDS-direct, counted vmcnt, published by the workgroup barrier), waves 0-7 only multiply -- two
+//     per SIMD, both free-running through the same loop so that one's LDS reads and waits hide behind the other's MFMAs (wave tile
+//     128 (Nn) x 48 (Kk), 96 accumulator registers, 168 registers per lane = 3 waves per SIMD);
+//   * operand images as in memory, [m][n], in rings of 32-row GRANULES (one K = 32 MFMA step): 6 granules of dY + 4 of X, 16 KB each =
+//     160 KB (the X image uses 384 of its 512 bytes per row, so that both operands share one layout: 16-byte chunk c of row r at chunk
+//     c ^ ((r & 3) << 1) ^ (((r >> 3) & 1) << 3) -- the first term spreads the four rows a 16-lane group reads, the second puts the rows
+//     of the odd lane groups into the other 128 bytes of the 256-byte bank period; without it the two 16-lane groups of a 32-lane LDS
+//     pass meet on the same 32 banks: SQ_LDS_BANK_CONFLICT was half of all LDS cycles); fragments by ds_read_b64_tr_b16;
+//   * ONE barrier per half K-tile; dY is loaded 4 halves and X 3 halves ahead of its use;
+//   * NO VALU instruction in the MFMA waves' loop: it is unrolled over the rings' common period (12 halves), every LDS address is a
+//     lane pointer formed once plus an immediate.  Measured (tools/probes/mfma_mix_probe.hip, tools/wgrad_lw_clocks.py): with this
+//     instruction mix (22 transpose reads per 24 MFMAs and wave) one v_add per fragment costs 15 % of the MFMA rate -- 2 360 -> 2 000
+//     cycles per K-tile here; a VALU instruction of a loader wave waits ~20 cycles for an issue slot, which is why the bias gradient
+//     (column sums of dY on a problem's first tile column) is ones^T x fragment on the matrix pipe, 4 MFMAs per loader wave and half;
 //   * swapped MFMA operands (D = X-fragment^T x dY-fragment^T): a lane holds 4 consecutive Kk entries of one Nn row, the read-out is
 //     a 16-byte fp32 read-modify-write per lane straight from the accumulators -- no LDS staging, so the loaders fill the rings with the
-//     NEXT tile's first K-tiles while the finished tile is folded into the arena;
+//     NEXT tile's first granules while the finished tile is folded into the arena;
 //   * one workgroup per CU walks a list of (problem, tile) items; NO M-split (every tile contracts its whole M: nothing to reduce,
-//     no fp32 partial slabs); the bias gradient (column sums of dY) comes from the dY fragments of a problem's first tile column
-//     through v_dot2 (8 registers instead of the 32 an MFMA-with-ones accumulator would take).
+//     no fp32 partial slabs).
+// What bounds it: power.  The shader clock under this kernel is 1.5-1.7 GHz (2.38 under MFMAs alone, 1.9 with L2-resident operands):
+// fewer cycles per K-tile came back as a lower clock (2 360 cycles at 1.63 GHz -> 2 000 at 1.51), 0.93-0.99 PFLOP/s on 7 stage-2
+// blocks against 0.75 for the split-M form with its bias sums (profiles/r04_wgrad_lw_*).
 // The caller (layers/swin_block.py) queues the problems of ~7 blocks per launch so that the item count is a multiple of the CU count
 // to within a few percent (7 stage-2 blocks = 1 008 items = 3.94 rounds).
 #include "dgx_common.h"

@@ -10,6 +10,7 @@
 //   double-buffered LDS (2 x 68 KiB), next stage prefetched into registers under the MFMAs.
 //   Partials go to a workspace; a second (also grouped) kernel folds them into the arena.
 #include "dgx_common.h"
+#include <type_traits>
 
 namespace {
 constexpr int T256 = 256;               // tile edge
@@ -44,9 +45,11 @@ struct Params256 {
 
 // 16 bytes per lane from a raw buffer straight into LDS (no staging registers): lane i of the wave lands at
 // lds_wave_base + 16*i.  Out-of-range lanes (voff >= num_records) do not touch memory.  The caller orders the
-// data with s_waitcnt vmcnt + barrier; the compiler does not track these loads.
-__device__ __forceinline__ void buffer_load_lds16(uint32_t voff, u32x4 rsrc, uint32_t lds_wave_base) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(voff), "s"(rsrc), "s"(lds_wave_base)
+// data with s_waitcnt vmcnt + barrier; the compiler does not track these loads.  soff: scalar byte offset, part of the range check on
+// gfx950 (tools/probes/soffset_probe.hip) -- the row offset of a stage travels there, no VALU add per load in a loop whose lone wave per
+// SIMD pays for every instruction next to its MFMAs.
+__device__ __forceinline__ void buffer_load_lds16(uint32_t voff, u32x4 rsrc, uint32_t lds_wave_base, uint32_t soff) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" ::"v"(voff), "s"(rsrc), "s"(lds_wave_base), "s"(soff)
                  : "memory");
 }
 __device__ __forceinline__ u32x4 make_rsrc(const void* base, uint32_t bytes) {
@@ -59,6 +62,12 @@ __device__ __forceinline__ u32x4 make_rsrc(const void* base, uint32_t bytes) {
 // the MFMA->SrcC hazard window, so no software wait states are needed inside the loop.
 __device__ __forceinline__ void mfma16_agpr(f32x4& c, bf16x8 a, bf16x8 b) {
     asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+// ... and with the accumulator pinned to the VGPR half: the bias sums' four tiles.  Left to the allocator they were given AGPRs -- all 256
+// of which hold the weight-gradient tile -- and every bias MFMA swapped a tile out and back (8 v_accvgpr moves + wait states per MFMA: the
+// workgroups of a problem's first tile column, i.e. ALL of them where Kk <= 256, ran 160 such moves per 128 MFMAs; found in round 4).
+__device__ __forceinline__ void mfma16_vgpr(f32x4& c, bf16x8 a, bf16x8 b) {
+    asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
 }
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 }  // namespace
@@ -131,8 +140,8 @@ __global__ __launch_bounds__(256) void wgrad256_partial_kernel(Params256 P) {
         const uint32_t row0 = (uint32_t)(m_begin + st * BM256);
         const uint32_t dst = ldsw + (uint32_t)(st & (NB256 - 1)) * STB256;
         const int j = h & 3;
-        if (h < 4) buffer_load_lds16(vA + (row0 + 8 * j) * (uint32_t)(q.Nn * 2), rA, dst + 4096u * j);
-        else buffer_load_lds16(vB + (row0 + 8 * j) * (uint32_t)(q.Kk * 2), rB, dst + OPB256 + 4096u * j);
+        if (h < 4) buffer_load_lds16(vA, rA, dst + 4096u * j, (row0 + 8 * j) * (uint32_t)(q.Nn * 2));
+        else buffer_load_lds16(vB, rB, dst + OPB256 + 4096u * j, (row0 + 8 * j) * (uint32_t)(q.Kk * 2));
     };
     auto issue = [&](int st) {
 #pragma unroll
@@ -144,12 +153,19 @@ __global__ __launch_bounds__(256) void wgrad256_partial_kernel(Params256 P) {
     // that is physical byte  row*512 + colbase*2 + 32*(i ^ x) + 16*hi + 8*lo,  x = p >> 2, hi = (p>>1)&1, lo = p&1;
     // i ^ x = 4a + (b ^ x): four lane-dependent bases per operand, everything else is an immediate.
     const int x = c16 >> 2, hi = (c16 >> 1) & 1, lo = c16 & 1;
-    uint32_t fa[4], fb[4];
+    // Round 4: the lane pointers are formed ONCE (two per base: the DS offset field reaches 64 KB of the 128 KB ring); the stage slot is an
+    // immediate because the loop is unrolled over the ring -- a v_add per fragment in a loop whose lone wave per SIMD pays ~6 cycles of
+    // MFMA issue for every instruction it interleaves was 16 of them per 128 MFMAs.
+    DGX_LDS const uint16_t* pfa[2][4];
+    DGX_LDS const uint16_t* pfb[2][4];
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
         const uint32_t o = (uint32_t)((8 * g + x) * 512 + 32 * (b ^ x) + 16 * hi + 8 * lo);
-        fa[b] = o + wn * 2;
-        fb[b] = OPB256 + o + wk * 2;
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+            pfa[h2][b] = lds_opaque(reinterpret_cast<const uint16_t*>(lds_raw + o + wn * 2 + h2 * 2 * STB256));
+            pfb[h2][b] = lds_opaque(reinterpret_cast<const uint16_t*>(lds_raw + OPB256 + o + wk * 2 + h2 * 2 * STB256));
+        }
     }
 
     f32x4 acc[8][8];
@@ -164,30 +180,33 @@ __global__ __launch_bounds__(256) void wgrad256_partial_kernel(Params256 P) {
     f32x4 bacc[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) bacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const bf16x8 ones = {(short)0x3F80, (short)0x3F80, (short)0x3F80, (short)0x3F80, (short)0x3F80, (short)0x3F80, (short)0x3F80, (short)0x3F80};
+    bf16x8 ones = {(short)0x3F80, (short)0x3F80, (short)0x3F80, (short)0x3F80, (short)0x3F80, (short)0x3F80, (short)0x3F80, (short)0x3F80};
+    asm volatile("" : "+v"(ones));                // kept in registers: rematerialised in front of the inline-asm MFMA it would be a VALU write the
+                                                  // hazard recogniser cannot pair with its reader
     auto bias_mfmas = [&](const bf16x8 (&af)[8]) {
         if (do_bias) {
             if (w & 1) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) bacc[i] = mfma16(af[4 + i], ones, bacc[i]);
+                for (int i = 0; i < 4; ++i) mfma16_vgpr(bacc[i], af[4 + i], ones);
             } else {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) bacc[i] = mfma16(af[i], ones, bacc[i]);
+                for (int i = 0; i < 4; ++i) mfma16_vgpr(bacc[i], af[i], ones);
             }
         }
     };
 
     // Software pipeline: while the MFMAs of stage st run out of registers, the transpose reads of stage st+1
     // fill the other fragment set and the LDS-direct loads of stages st+2 .. st+4 are in flight.
-    auto read_frag = [&](int st, int f, bf16x8 (&af)[8], bf16x8 (&bfr)[8]) {   // f = 0..7: A fragment f, 8..15: B fragment f-8
-        DGX_LDS const unsigned char* sb = (DGX_LDS const unsigned char*)lds_raw + (st & (NB256 - 1)) * STB256;
+    auto read_frag = [&](auto SLOT, int f, bf16x8 (&af)[8], bf16x8 (&bfr)[8]) {   // f = 0..7: A fragment f, 8..15: B fragment f-8; SLOT: ring slot
+        constexpr int slot = decltype(SLOT)::value;
         const int i = f & 7;
-        if (f < 8) af[i] = tr_frag(reinterpret_cast<DGX_LDS const uint16_t*>(sb + fa[i & 3]), 64 * (i >> 2), 64 * (i >> 2) + 4 * 256);
-        else bfr[i] = tr_frag(reinterpret_cast<DGX_LDS const uint16_t*>(sb + fb[i & 3]), 64 * (i >> 2), 64 * (i >> 2) + 4 * 256);
+        const int off = (slot & 1) * (STB256 / 2) + 64 * (i >> 2);        // elements
+        if (f < 8) af[i] = tr_frag(pfa[slot >> 1][i & 3], off, off + 4 * 256);
+        else bfr[i] = tr_frag(pfb[slot >> 1][i & 3], off, off + 4 * 256);
     };
-    auto read_frags = [&](int st, bf16x8 (&af)[8], bf16x8 (&bfr)[8]) {
+    auto read_frags = [&](auto SLOT, bf16x8 (&af)[8], bf16x8 (&bfr)[8]) {
 #pragma unroll
-        for (int f = 0; f < 16; ++f) read_frag(st, f, af, bfr);
+        for (int f = 0; f < 16; ++f) read_frag(SLOT, f, af, bfr);
     };
     auto mfmas = [&](const bf16x8 (&af)[8], const bf16x8 (&bfr)[8]) {
 #pragma unroll
@@ -200,14 +219,14 @@ __global__ __launch_bounds__(256) void wgrad256_partial_kernel(Params256 P) {
     // barriers, the wave issues {a global->LDS load of stage st+4 (every other group), the two transpose reads of
     // one fragment of stage st+1, four MFMAs of stage st}.  The three pipes (TA 64 B/clk, LDS, MFMA) are fed at
     // their own rates; issued in bulk, the loads and reads fill their queues and stall the wave's MFMA issue.
-    auto step = [&](int st, const bf16x8 (&caf)[8], const bf16x8 (&cbf)[8], bf16x8 (&naf)[8], bf16x8 (&nbf)[8]) {
+    auto step = [&](int st, auto NSLOT, const bf16x8 (&caf)[8], const bf16x8 (&cbf)[8], bf16x8 (&naf)[8], bf16x8 (&nbf)[8]) {   // NSLOT = (st + 1) & 3
         wait_vmcnt<16>();                                      // own loads of stage st+1 done (st+2, st+3 may fly)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // own LDS reads of stage st done before its buffer is recycled
         __syncthreads();
 #pragma unroll
         for (int gq = 0; gq < 16; ++gq) {
             if ((gq & 1) == 0) issue1(st + 4, gq >> 1);        // into the buffer stage st used
-            read_frag(st + 1, gq, naf, nbf);
+            read_frag(NSLOT, gq, naf, nbf);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int e = 4 * gq + u;
@@ -224,11 +243,20 @@ __global__ __launch_bounds__(256) void wgrad256_partial_kernel(Params256 P) {
     issue(3);
     wait_vmcnt<24>();
     __syncthreads();
-    read_frags(0, af0, bf0);
+    typedef std::integral_constant<int, 0> S0; typedef std::integral_constant<int, 1> S1;
+    typedef std::integral_constant<int, 2> S2; typedef std::integral_constant<int, 3> S3;
+    read_frags(S0{}, af0, bf0);
     int st = 0;
-    for (; st + 2 <= nst; st += 2) {
-        step(st, af0, bf0, af1, bf1);
-        step(st + 1, af1, bf1, af0, bf0);
+    for (; st + 4 <= nst; st += 4) {         // st = 0 (mod 4) here: the slots of the stages read ahead are static
+        step(st, S1{}, af0, bf0, af1, bf1);
+        step(st + 1, S2{}, af1, bf1, af0, bf0);
+        step(st + 2, S3{}, af0, bf0, af1, bf1);
+        step(st + 3, S0{}, af1, bf1, af0, bf0);
+    }
+    if (st + 2 <= nst) {
+        step(st, S1{}, af0, bf0, af1, bf1);
+        step(st + 1, S2{}, af1, bf1, af0, bf0);
+        st += 2;
     }
     if (st < nst) mfmas(af0, bf0);   // odd stage count: the last stage's fragments are already in registers
     wait_vmcnt<0>();

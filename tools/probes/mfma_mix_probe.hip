@@ -9,12 +9,12 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 #define LDSQ __attribute__((address_space(3)))
-template <int R, int D, int BAR, int VA = 0>
+template <int R, int D, int BAR, int VA = 0, int VL = 0, int VM = 0>
 __global__ __launch_bounds__(768) void k(unsigned long long* out, const uint16_t* src, int halves) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     if (w >= 8) {
-        if (D == 0 && BAR == 0) return;
+        if (D == 0 && BAR == 0 && VL == 0) return;
         const uint64_t a = (uint64_t)src;
         const u32x4 rs = {(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a), (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(a >> 32) & 0xffff)), 1u << 28, 0x00020000u};
         const uint32_t lds0 = (uint32_t)(uintptr_t)(LDSQ unsigned char*)lds + 1024u * (w - 8);
@@ -24,6 +24,12 @@ __global__ __launch_bounds__(768) void k(unsigned long long* out, const uint16_t
             for (int s = 0; s < D; ++s) {
                 const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds0 + 4096u * s + 32768u * (h & 3)));
                 asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(v + 4096u * s + ((h & 31) << 11)), "s"(rs), "s"(dst) : "memory");
+            }
+            if (VL) {
+                uint32_t dummy = v;
+#pragma unroll
+                for (int u = 0; u < VL; ++u) asm volatile("v_add_u32 %0, %0, 1" : "+v"(dummy));
+                if (dummy == 0x12345) v += 1;
             }
             if (D) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D) : "memory");
             if (BAR) asm volatile("s_barrier" ::: "memory");
@@ -43,6 +49,7 @@ __global__ __launch_bounds__(768) void k(unsigned long long* out, const uint16_t
     const int g = l >> 4, c16 = l & 15, x = c16 >> 2, hi = (c16 >> 1) & 1, lo = c16 & 1;
     const uint32_t la = (uint32_t)((8 * g + x) * 512 + 32 * ((w & 3) ^ x) + 128 * (g & 1) + 16 * hi + 8 * lo);
     LDSQ const uint16_t* p0 = (LDSQ const uint16_t*)((LDSQ unsigned char*)lds + la);
+    uint32_t vdummy = l;
     const unsigned long long t0 = clock64(), r0 = wall_clock64();
     for (int h = 0; h < halves; ++h) {
         if (BAR) asm volatile("s_barrier" ::: "memory");
@@ -60,6 +67,7 @@ __global__ __launch_bounds__(768) void k(unsigned long long* out, const uint16_t
                 const s16x4 u0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDSQ s16x4*)(p + 4096 + 128 * i)), u1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDSQ s16x4*)(p + 4096 + 128 * i + 1024));
                 a[i] = __builtin_shufflevector(u0, u1, 0, 1, 2, 3, 4, 5, 6, 7);
             }
+            if (i < VM) asm volatile("v_add_u32 %0, %0, 1" : "+v"(vdummy));
 #pragma unroll
             for (int j = 0; j < 3; ++j) acc[3 * i + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[j], b[i & 3], acc[3 * i + j], 0, 0, 0);
         }
@@ -69,19 +77,19 @@ __global__ __launch_bounds__(768) void k(unsigned long long* out, const uint16_t
 #pragma unroll
     for (int i = 0; i < 24; ++i) s += acc[i][0] + acc[i][3];
     if (l == 0 && blockIdx.x == 0 && w == 0) { out[0] = t1 - t0; out[1] = r1 - r0; }
-    if (s == 12345.f) out[63] = 1;
+    if (s == 12345.f || vdummy == 0x7fffffff) out[63] = 1;
 }
-template <int R, int D, int BAR, int VA = 0> void run(unsigned long long* o, const uint16_t* src, int halves) {
-    hipFuncSetAttribute((const void*)k<R, D, BAR, VA>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+template <int R, int D, int BAR, int VA = 0, int VL = 0, int VM = 0> void run(unsigned long long* o, const uint16_t* src, int halves) {
+    hipFuncSetAttribute((const void*)k<R, D, BAR, VA, VL, VM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    k<R, D, BAR, VA><<<256, 768, 160 * 1024>>>(o, src, halves / 8);
+    k<R, D, BAR, VA, VL, VM><<<256, 768, 160 * 1024>>>(o, src, halves / 8);
     hipEventRecord(e0);
-    k<R, D, BAR, VA><<<256, 768, 160 * 1024>>>(o, src, halves);
+    k<R, D, BAR, VA, VL, VM><<<256, 768, 160 * 1024>>>(o, src, halves);
     hipEventRecord(e1);
     hipDeviceSynchronize();
     float ms; hipEventElapsedTime(&ms, e0, e1);
     unsigned long long h[2]; hipMemcpy(h, o, 16, hipMemcpyDeviceToHost);
-    printf("addr-add %d reads/half %2d  loads/loader/half %d  barrier %d: %7.1f cycles per half (768 = MFMA bound)  shader clock %4.0f MHz  %7.1f TF/s\n", VA, R, D, BAR, (double)h[0] / halves,
+    printf("VALU/half: loader %2d, MFMA wave %d | addr-add %d reads/half %2d  loads/loader/half %d  barrier %d: %7.1f cycles per half (768 = MFMA bound)  shader clock %4.0f MHz  %7.1f TF/s\n", VL, VM, VA, R, D, BAR, (double)h[0] / halves,
            (double)h[0] / ((double)h[1] / 100.0), 256.0 * 8 * 24.0 * halves * 16384.0 / (ms * 1e-3) / 1e12);
 }
 int main() {
@@ -92,5 +100,7 @@ int main() {
     run<6, 0, 0>(o, src, H); run<16, 0, 0>(o, src, H); run<22, 0, 0>(o, src, H); run<22, 0, 1>(o, src, H);
     run<0, 8, 1>(o, src, H); run<22, 4, 1>(o, src, H); run<22, 8, 1>(o, src, H); run<22, 8, 0>(o, src, H);
     run<22, 0, 1, 64>(o, src, H); run<22, 8, 1, 64>(o, src, H);
+    run<22, 8, 1, 0, 8>(o, src, H); run<22, 8, 1, 0, 32>(o, src, H); run<22, 8, 1, 0, 0, 4>(o, src, H); run<22, 8, 1, 0, 0, 8>(o, src, H);
+    run<11, 8, 1>(o, src, H); run<11, 8, 1, 0, 8>(o, src, H); run<11, 8, 1, 0, 0, 8>(o, src, H);
     return 0;
 }

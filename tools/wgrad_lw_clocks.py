@@ -29,8 +29,8 @@ print("loader wave 8            wait for the granules %.0f  barrier %.0f  issue 
 out2 = (ctypes.c_ulonglong * (3 * 1024 * 4))()
 raw.dgx_dev_wl_clocks(out2, 1)
 it = np.array(list(out2)[:96], dtype=np.int64).reshape(3, 8, 4)
-for wi in (0, 1):
+for wi in (0, 1):      # row j >= 1: [after barrier E of item j-1, after its read-out, after barrier P of item j]
     r = it[wi]
-    print("wave %d items:" % (4 * wi), " | ".join("read-out %d, then to barrier #0 of the next item %d" % (r[k, 1] - r[k, 0], r[k + 1, 2] - r[k, 1]) for k in range(3)))
+    print("wave %d, item boundaries:" % (4 * wi), " | ".join("read-out %d, then %d to the next item's first barrier" % (r[j, 1] - r[j, 0], r[j, 2] - r[j, 1]) for j in range(1, 4)))
 c = list(out2)[92:96]
 print("workgroup 0 lifetime: %d shader cycles in %.1f us (100 MHz counter) = %.0f MHz" % (c[2] - c[0], (c[3] - c[1]) / 100.0, (c[2] - c[0]) / ((c[3] - c[1]) / 100.0)))

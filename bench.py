@@ -86,13 +86,13 @@ def make_pastes(rng, size, k=19):
 PROFILE_TAG = "r04"
 FAMILY_KERNELS = {   # family -> substrings of the kernel names rocprof reports for it
     "gemm_nt": ("gemm_nt_kernel", "gemm_lw_kernel", "gemm_splitk_fold_kernel"),
-    "wgrad": ("wgrad256_partial_kernel", "wgrad256_reduce_kernel", "wgrad256_bias_reduce_kernel", "wgrad_partial_kernel", "wgrad_reduce_kernel"),
+    "wgrad": ("wgrad256_partial_kernel", "wgrad256_reduce_kernel", "wgrad256_bias_reduce_kernel", "wgrad_partial_kernel", "wgrad_reduce_kernel", "wgrad_lw_kernel"),
     "attn_fwd": ("win_attn_fwd_kernel",),
     "attn_bwd": ("win_attn_bwd_kernel",),
 }
 FAMILY_LABEL = {
     "gemm_nt": "gemm_nt_kernel<BM,BN> (dgx_gemm_bf16_nt + dgx_conv3x3_gemm: every Linear / 3x3-conv forward and input gradient)",
-    "wgrad": "wgrad256_partial/reduce (dgx_linear_wgrad_grouped + dgx_conv3x3_wgrad: every weight gradient)",
+    "wgrad": "wgrad256_partial/reduce + wgrad_lw (dgx_linear_wgrad_grouped + dgx_conv3x3_wgrad: every weight gradient)",
     "attn_fwd": "win_attn_fwd_kernel (dgx_window_attention_fwd)",
     "attn_bwd": "win_attn_bwd_kernel (dgx_window_attention_bwd)",
 }

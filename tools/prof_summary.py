@@ -4,7 +4,7 @@ rows=list(csv.DictReader(open(path)))
 cat={}; calls={}
 def c(name):
     if name.startswith('Cijk'): return 'gemm(hipblaslt)'
-    for k, lab in (('wgrad256', 'grouped wgrad GEMM (wgrad256)'), (' ln_', 'layernorm (ln_/pm_ln_)'), ('pm_ln', 'layernorm (ln_/pm_ln_)'), (' gn_', 'groupnorm (gn_)'), ('gelu_', 'gelu'), ('colsum', 'colsum (bias grads)'), ('residual_', 'residual add'), ('detic_', 'fused head losses'), ('cn_loss', 'fused head losses'), ('cascade_refine', 'cascade_refine'), ('wgrad_gemm', 'wgrad 128 kernel')):
+    for k, lab in (('wgrad256', 'grouped wgrad GEMM (wgrad256 / wgrad_lw)'), ('wgrad_lw', 'grouped wgrad GEMM (wgrad256 / wgrad_lw)'), (' ln_', 'layernorm (ln_/pm_ln_)'), ('pm_ln', 'layernorm (ln_/pm_ln_)'), (' gn_', 'groupnorm (gn_)'), ('gelu_', 'gelu'), ('colsum', 'colsum (bias grads)'), ('residual_', 'residual add'), ('detic_', 'fused head losses'), ('cn_loss', 'fused head losses'), ('cascade_refine', 'cascade_refine'), ('wgrad_gemm', 'wgrad 128 kernel')):
         if k in (' ' + name): return lab
     for k in ('win_attn_bwd','win_attn_fwd','nms_sweep','nms_mask','roi_align_sep_kernel<unsigned short, true','roi_align_sep_kernel<unsigned short, false','roi_align','adamw','im2col','col2im','window_shuffle','cp_','mask_crop','centernet_targets','iou_match','gemm_'):
         if k in name: return k

@@ -50,6 +50,8 @@ def parse():
     p.add_argument("--share-device", type=int, default=None, metavar="D",
                    help="all ranks on GPU D: N-rank plumbing test on a one-GPU box (use with --backend gloo); not a scaling run")
     p.add_argument("--force-pg", action="store_true", help="create a process group even at N = 1 (RCCL next to hipGraph capture)")
+    p.add_argument("--no-graphs", action="store_true",
+                   help="development: issue the hipGraph segments (FPN, tower, heads) eagerly so that every launch is logged / traced by name")
     return p.parse_args()
 
 
@@ -257,6 +259,9 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if a.share_device is not None:
         local = a.share_device
+    if a.no_graphs:
+        from divergen_amd.utils import graphs
+        graphs.ENABLED = False
     backend = a.backend
     on_gpu = not (a.launch_check and backend != "nccl")      # the launch check over gloo runs without a GPU (CPU-container test)
     if on_gpu:

@@ -103,7 +103,7 @@ __global__ __launch_bounds__(512, MINW) void gemm_nt_kernel(GemmP P) {
     const uint32_t lds0 = (uint32_t)(uintptr_t)(DGX_LDS unsigned char*)lds_raw;
     const uint32_t ldsw = __builtin_amdgcn_readfirstlane(lds0 + 1024u * w);
     // one of the NL loads of a tile: k < NA -> A rows, else B rows
-    // K rotation (DGX_GEMM_KROT=1, off by default): workgroups that share an operand panel walk K from different starting
+    // K rotation (development builds: DGX_GEMM_KROT=1; off in the product): workgroups that share an operand panel walk K from different starting
     // tiles, so a line fetched from HBM for one is in L2 when the others ask.  Measured (tools/gemm_cold_probe2.py): -7..10 %
     // when every operand is cold in HBM, +5..12 % when they sit in L2 / the memory-side cache, nothing on the training step.
     const int rot = (P.krot && NT >= 4) ? ((tm + tn) & 3) * (NT >> 2) : 0;
@@ -433,10 +433,7 @@ int choose_splits(int64_t tiles, int K, int64_t M, int64_t N, int64_t ws_bytes) 
 
 // Tile selection: BN from the divisibility of N (every Swin width is a multiple of 192), BM from how well the tile count
 // fills whole rounds of 256 CUs (one workgroup per CU), weighted by the CU-side efficiency of the smaller tiles.
-static bool tile_192x256() {        // DGX_GEMM_192x256=0: A/B switch for the 192 x 256 tile (2 stages) where it saves a round
-    static const int on = getenv("DGX_GEMM_192x256") ? atoi(getenv("DGX_GEMM_192x256")) : 1;
-    return on != 0;
-}
+static bool tile_192x256() { return true; }      // the 192 x 256 tile (2 stages) where it saves a round of the chip
 TileChoice choose_tile(int M, int N) {
     const char* env = getenv("DGX_GEMM_TILE");
     if (env) {
@@ -566,7 +563,9 @@ extern "C" int dgx_gemm_bf16_nt(const void* A, const void* B, int M, int N, int 
     P.ws = (float*)ep->workspace;
     g_ws_bytes_cur = ep->workspace ? ep->workspace_bytes : 0;
     P.relu = (ep->mode <= DGX_EPI_BIAS) ? ep->relu : 0;
-    if (const char* kr = getenv("DGX_GEMM_KROT")) P.krot = atoi(kr);
+#ifdef DGX_GEMM_DEV
+    if (const char* kr = getenv("DGX_GEMM_KROT")) P.krot = atoi(kr);     // development build only (tools/gemm_cold_probe2.py)
+#endif
     switch (ep->mode) {
         case DGX_EPI_NONE: case DGX_EPI_BIAS:
             if (!ep->c || ep->ldc < N || (ep->ldc & 7)) return DGX_ERR_BAD_ARG;

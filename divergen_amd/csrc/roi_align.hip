@@ -450,9 +450,7 @@ static int launch_gather(GatherP& P, const float* rois, const void* go, int dtyp
     {
         int64_t t8 = 0;
         for (int l = 0; l < P.num_levels; ++l) t8 += (int64_t)P.N * ((P.W[l] + TW - 1) / TW) * ((P.H[l] + 7) / 8);
-        static const int force = getenv("DGX_ROI_BWD_TH") ? atoi(getenv("DGX_ROI_BWD_TH")) : 0;
-        if (force == 4 || force == 8) th = force;
-        else if (t8 < 4 * 256) th = 4;
+        if (t8 < 4 * 256) th = 4;
     }
     int total = 0;
     for (int l = 0; l < P.num_levels; ++l) {

@@ -58,7 +58,7 @@ struct WlParams {
     int item0[WL_MAXP];              // first item of problem i (searched with constant indices)
     int n, total, per_xcd;
     float beta;
-    int diag;                        // DGX_WGRAD_LW_DIAG=1 (timing experiments only, results wrong): every workgroup streams the panels of item 0
+    int diag;                        // development builds, DGX_WGRAD_LW_DIAG=1 (timing experiments only, results wrong): every workgroup streams the panels of item 0
 };
 
 __device__ __forceinline__ void wl_load_lds16(uint32_t voff, u32x4 rsrc, uint32_t lds_addr, uint32_t soff) {
@@ -396,8 +396,10 @@ int wgrad_lw_launch(const dgx_wgrad_problem* pr, int n, float beta, hipStream_t 
     }
     for (int i = 0; i < WL_MAXP; ++i) P.item0[i] = i < n ? P.p[i].item0 : 0x7fffffff;
     P.n = n; P.total = items; P.beta = beta;
-    static const int diag = getenv("DGX_WGRAD_LW_DIAG") ? atoi(getenv("DGX_WGRAD_LW_DIAG")) : 0;
+#ifdef DGX_GEMM_DEV
+    static const int diag = getenv("DGX_WGRAD_LW_DIAG") ? atoi(getenv("DGX_WGRAD_LW_DIAG")) : 0;     // development build only (tools/wgrad_lw_clocks.py)
     P.diag = diag;
+#endif
     P.per_xcd = (items + 7) / 8;
     static bool once = false;
     if (!once) {

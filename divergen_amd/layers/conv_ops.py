@@ -128,7 +128,7 @@ def _flipped_twin(weight, w16):
     return w16.flip(2, 3).permute(1, 2, 3, 0).reshape(w16.shape[1], -1).contiguous()
 
 
-_SPLITK = os.environ.get("DGX_CONV_SPLITK", "1") != "0"      # dev switch for A/B runs
+_SPLITK = True      # split-K workspace handed to the GEMM (small-M convolutions of the coarse levels)
 
 
 class _NoWorkspace:
@@ -232,7 +232,7 @@ class _Conv3x3Implicit(torch.autograd.Function):
         return gx, gw, gb, None
 
 
-_IMPLICIT = os.environ.get("DGX_CONV_IMPLICIT", "1") == "1"      # A/B switch against the im2col path
+_IMPLICIT = True      # stride-1 3x3 convolutions with >= 64 channels run as implicit GEMMs; the column-matrix form serves stride 2 and narrow inputs
 
 
 class _Conv3x3Group(torch.autograd.Function):
@@ -297,8 +297,8 @@ def conv3x3_group(x, w_handle, b_handle):
     return y.permute(0, 3, 1, 2)
 
 
-_CONV_MULTI = os.environ.get("DGX_CONV_MULTI", "1") == "1"      # A/B switch: a tower layer's convolution over all levels with shared padded-copy launches
-_WGRAD_MULTI = os.environ.get("DGX_CONV_WGRAD_MULTI", "1") == "1"   # A/B switch: that layer's weight gradient over all levels in one partial + one reduce launch
+_CONV_MULTI = True      # a tower layer's convolution over all levels with shared padded-copy launches
+_WGRAD_MULTI = True     # that layer's weight gradient over all levels in one partial + one reduce launch
 
 
 def _pad_images(xs):
@@ -349,7 +349,7 @@ def conv3x3_group_usable_w(w_handle, b_handle):
             and getattr(w_handle, "_dgx16tg_flipped", False) and wg.shape[0] % 64 == 0 and gg.dtype == torch.float32)
 
 
-_CONV_GEMM_MULTI = os.environ.get("DGX_CONV_GEMM_MULTI", "1") == "1"      # A/B switch: one grouped implicit-GEMM launch for the levels
+_CONV_GEMM_MULTI = True      # one grouped implicit-GEMM launch for the levels
 
 
 def _conv_gemms(xps, ys, nhw, w, b16, Cin, Cout):
@@ -574,7 +574,7 @@ class Conv2d(torch.nn.Conv2d):
 
     def __init__(self, *a, **k):
         super().__init__(*a, **k)
-        if self.kernel_size == (3, 3) and self.groups == 1 and os.environ.get("DGX_CONV_OHWI", "1") == "1":
+        if self.kernel_size == (3, 3) and self.groups == 1:
             self.weight._dgx_ohwi = True       # FlatArena stores it (Cout, kh, kw, Cin): see solver.FlatArena.view
             self.weight._dgx_flip = self.stride == (1, 1)      # its bf16 twin: tap-flipped (Cin, kh, kw, Cout), the input-gradient operand
         if self.kernel_size == (1, 1) and self.groups == 1 and self.out_channels % 8:

@@ -9,8 +9,8 @@ import torch
 from .. import _lib as L
 
 
-# dev switch: DGX_ROI_GATHER=0 keeps the atomic-scatter backward (A/B runs and the parity test of the two forms)
-_GATHER = os.environ.get("DGX_ROI_GATHER", "1") != "0"
+# the atomic-scatter backward stays for the parity test of the two forms (tests/test_gpu_kernels.py sets _GATHER)
+_GATHER = True
 
 
 def _nhwc(feat):

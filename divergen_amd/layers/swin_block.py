@@ -57,17 +57,17 @@ import os
 # launch takes queued problems in order while they fit 256 tiles, i.e. two blocks and the fc1 (or qkv + proj) of a third = 252
 # tiles instead of 216 on the 256 CUs, and 18 stage-2 blocks need 8 launches instead of 9 (a launch lasts one tile's contraction
 # whatever its tile count).  Operands stay alive until their problem has been launched; whatever is still pending when the backward
-# pass ends is flushed by an autograd end-of-backward callback.  DGX_WGRAD_PAIR=1 restores one launch per block, =2 block pairs.
+# pass ends is flushed by an autograd end-of-backward callback.  (_PAIR = 1 / 2: one launch per block / per block pair, the rounds-2 forms.)
 # Round 4: blocks with many output tiles and a long contraction (Swin-L stage 2: 144 tiles of 256x192 per block, M = 8 192 / 10 368) are
 # queued until ~4 rounds of the chip are together (7 blocks = 1 008 tiles, 28 problems) and run as ONE launch of the persistent
 # loader-wave kernel (csrc/wgrad_lw.hip: every tile contracts its whole M -- no split, no workspace, no reduce launch); the library says
 # whether a group qualifies (dgx_wgrad_grouped_form), otherwise the group goes the round-3 way.
-_PAIR = max(1, int(os.environ.get("DGX_WGRAD_PAIR", "3")))
+_PAIR = 3
 _PENDING = []          # [problem (g, dy, x, bias, weight), tiles] in arrival order
 _PENDING_LW = []       # problems queued for a loader-wave launch
 _CB_QUEUED = [False]
 _ROUND, _MAXP = 256, 12
-_LW_MIN_M = int(os.environ.get("DGX_WGRAD_LW_MIN_M", "4096"))      # shortest contraction queued for the loader-wave form (0: never)
+_LW_MIN_M = 4096      # shortest contraction queued for the loader-wave form (stage 3, M = 2 048 / 2 592, is faster split: profiles/r04_wgrad_lw_probe.txt)
 _LW_ITEMS, _LW_MAXP = 1000, 32
 
 

@@ -20,7 +20,7 @@ from ...structures import Boxes, Instances, ProposalBatch
 from ...utils.comm import get_world_size
 from .centernet_head import CenterNetHead
 
-_FUSED_CN_LOSSES = os.environ.get("DGX_FUSED_CN_LOSSES", "1") == "1"      # A/B switch: dgx_centernet_losses
+_FUSED_CN_LOSSES = True      # dgx_centernet_losses; the composed form is the reference of its parity test
 
 INF = 100000000
 

@@ -23,8 +23,8 @@ class Scale(nn.Module):
         return x * self.scale
 
 
-_HEAD_OUT = __import__("os").environ.get("DGX_HEAD_OUT", "1") == "1"      # A/B switch: the head's tail + flattening as one kernel each way
-_GN_MULTI = __import__("os").environ.get("DGX_GN_MULTI", "1") == "1"      # A/B switch: GroupNorm of a tower layer over all levels at once
+_HEAD_OUT = True      # the head's tail + flattening as one kernel each way
+_GN_MULTI = True      # GroupNorm of a tower layer over all levels at once
 
 
 class CenterNetHead(nn.Module):

@@ -15,8 +15,8 @@ from ...config import configurable
 from ...layers.conv_ops import preprocess_patch_rows
 from ...structures import ImageList
 
-# dev switch: DGX_FUSED_PREPROCESS=0 keeps the torch normalise + pad + unfold path
-_FUSED_PREPROCESS = os.environ.get("DGX_FUSED_PREPROCESS", "1") != "0"
+# dgx_preprocess_patches; the composed normalise + pad + unfold form is the reference of its parity test
+_FUSED_PREPROCESS = True
 
 
 @META_ARCH_REGISTRY.register()

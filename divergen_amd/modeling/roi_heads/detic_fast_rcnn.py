@@ -18,7 +18,7 @@ from ..box_regression import Box2BoxTransform
 
 
 import os
-_FUSED_LOSSES = os.environ.get("DGX_FUSED_LOSSES", "1") == "1"
+_FUSED_LOSSES = True
 
 
 def load_class_freq(path="datasets/metadata/lvis_v1_train_cat_info.json", freq_weight=1.0):

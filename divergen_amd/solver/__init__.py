@@ -30,7 +30,7 @@ def warmup_cosine_lr(base_lr, it, max_iters, warmup_iters, warmup_factor, warmup
     return base_lr * wf * 0.5 * (1.0 + math.cos(math.pi * it / max_iters))
 
 
-_LAZY_ZERO = __import__("os").environ.get("DGX_LAZY_ZERO", "1") == "1"      # A/B switch: first-writer weight gradients (FlatArena.zero_grad(lazy=True))
+_LAZY_ZERO = True      # first-writer weight gradients (FlatArena.zero_grad(lazy=True)); the eager form stays for the parity test of the two
 
 
 class FlatArena:

@@ -18,8 +18,8 @@ import torch
 from ..layers import linear_ops
 from . import prof
 
-ENABLED = os.environ.get("DGX_GRAPH_HEADS", "1") == "1"
-ALIAS_STATIC = os.environ.get("DGX_GRAPH_ALIAS", "1") == "1"     # A/B switch: chained segments share their hand-over buffers
+ENABLED = True
+ALIAS_STATIC = True     # chained segments share their hand-over buffers
 
 
 class _SignalAfterBackward(torch.autograd.Function):

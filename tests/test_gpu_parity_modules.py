@@ -333,6 +333,53 @@ def test_fused_swin_block_equals_composed_path(xdt, shift, monkeypatch):
     assert (ga - gb).abs().max() <= 2e-3 * gb.abs().max()
 
 
+def test_swin_blocks_weight_gradients_loader_wave_group(monkeypatch):
+    """Three Swin blocks of width 768 whose weight gradients are queued for ONE launch of the persistent loader-wave kernel
+    (layers/swin_block.py::_defer_wgrads -> csrc/wgrad_lw.hip; 3 x 144 tiles = 0.84 of two rounds of the chip) against the same blocks
+    with one split-M launch per group of <= 12 problems (csrc/wgrad256.hip): same outputs, same input gradient (the data path does not
+    change), parameter gradients to fp32 summation order; the lazy zero-grad protocol must see every segment written in both."""
+    from divergen_amd.modeling.backbone import swintransformer as S
+    from divergen_amd.layers import swin_block as SB
+    from divergen_amd.solver import FlatArena
+    torch.manual_seed(15)
+    dim, nH, ws, B, H, W = 768, 24, 12, 2, 24, 24          # 1 152 tokens: every contraction >= 1 024 rows
+    blocks = torch.nn.ModuleList([S.SwinTransformerBlock(dim, nH, window_size=ws, shift_size=0 if i % 2 == 0 else 6, drop_path=0.1)
+                                  for i in range(3)]).to(DEV).train()
+    for p in blocks.parameters():
+        torch.nn.init.normal_(p, std=0.03)
+    for b in blocks:
+        b.H, b.W = H, W
+    arena = FlatArena(blocks)
+    from divergen_amd.layers import shift_regions
+    region = shift_regions(H, W, ws).to(DEV)
+    x0 = torch.randn(B, H * W, dim, device=DEV).bfloat16()
+    go = torch.randn(B, H * W, dim, device=DEV).bfloat16()
+    launched = []
+    orig = SB.wgrad_grouped
+    monkeypatch.setattr(SB, "wgrad_grouped", lambda problems, beta=1.0: (launched.append(len(problems)), orig(problems, beta))[1])
+    res = {}
+    for lw in (True, False):
+        monkeypatch.setattr(SB, "_LW_MIN_M", 1024 if lw else 0)
+        monkeypatch.setattr(SB, "_LW_ITEMS", 400)
+        del launched[:]
+        arena.zero_grad(lazy=True)
+        torch.manual_seed(21)           # same DropPath draws
+        x = x0.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = x
+            for i, b in enumerate(blocks):
+                y = b(y, region if i % 2 else None)
+        y.backward(go)
+        arena.finish_grads()
+        res[lw] = (y.detach().clone(), x.grad.clone(), arena.g.clone(), list(launched))
+    assert res[True][3] == [12], res[True][3]              # the three blocks' 12 problems in one launch
+    assert len(res[False][3]) >= 2 and max(res[False][3]) <= 12
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+    ga, gb = res[True][2], res[False][2]
+    assert float(gb.abs().max()) > 0
+    assert float((ga - gb).abs().max()) <= 2e-5 * float(gb.abs().max()) + 1e-6
+
+
 def test_fused_detic_losses_vs_reference_golden(golden):
     """dgx_detic_losses (one pass: sigmoid CE with the federated class weights + L1 box regression + gradients) against
     the outputs of the reference's own loss methods (golden 'roi_losses')."""

@@ -152,6 +152,8 @@ SIGNATURES = {
     "dgx_colsum_grouped": (c_i, [ctypes.POINTER(ColsumProblem), c_i, c_f, c_p, c_p]),
     "dgx_residual_fwd": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "dgx_residual_bwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "dgx_upsample2x_add_fwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "dgx_upsample2x_add_bwd": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "dgx_gemm_bf16_nt": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i64, c_i64, ctypes.POINTER(GemmEpilogue), c_p]),
     "dgx_conv3x3_pad_rows": (c_i64, [c_i, c_i, c_i]),
     "dgx_conv3x3_pad": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p]),

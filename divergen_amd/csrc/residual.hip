@@ -146,3 +146,86 @@ extern "C" int dgx_residual_bwd(const void* g, const float* scale, void* dy_bf16
     DGX_LAUNCH_CHECK();
     return DGX_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// FPN top-down step (D2/modeling/backbone/fpn.py:139-145: `F.interpolate(prev, scale_factor=2, mode="nearest")`, then
+// `lateral + top_down`): NHWC maps, 8 channels per lane.
+//   forward : out[n][y][x][c] = lat[n][y][x][c] + top[n][y >> 1][x >> 1][c]           (one rounding of the fp32 sum)
+//   backward: d lat = g (the caller aliases it);  d top[n][y][x][c] = g[n][2y][2x][c] + g[n][2y][2x+1][c] + g[n][2y+1][2x][c] + g[n][2y+1][2x+1][c]
+//             (fp32 sum of four values, one rounding -- what autograd's upsample_nearest2d_backward computes)
+template <typename T>
+__global__ __launch_bounds__(256) void upsample2x_add_fwd_kernel(const T* __restrict__ lat, const T* __restrict__ top, T* __restrict__ out,
+                                                                 int N, int H, int W, int C) {
+    const int CV = C >> 3;
+    const int64_t total = (int64_t)N * H * W * CV;
+    const int Ht = H >> 1, Wt = W >> 1;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % CV);
+        int64_t r = i / CV;
+        const int x = (int)(r % W); r /= W;
+        const int y = (int)(r % H);
+        const int n = (int)(r / H);
+        float a[8], b[8];
+        Vec<T>::ld(lat + i * 8, a);
+        Vec<T>::ld(top + ((((int64_t)n * Ht + (y >> 1)) * Wt + (x >> 1)) * CV + cv) * 8, b);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] += b[e];
+        Vec<T>::st(out + i * 8, a);
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void upsample2x_add_bwd_kernel(const T* __restrict__ g, T* __restrict__ gtop, int N, int H, int W, int C) {
+    const int CV = C >> 3;
+    const int Ht = H >> 1, Wt = W >> 1;
+    const int64_t total = (int64_t)N * Ht * Wt * CV;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % CV);
+        int64_t r = i / CV;
+        const int x = (int)(r % Wt); r /= Wt;
+        const int y = (int)(r % Ht);
+        const int n = (int)(r / Ht);
+        const T* p = g + ((((int64_t)n * H + 2 * y) * W + 2 * x) * CV + cv) * 8;
+        float a[8], b[8];
+        Vec<T>::ld(p, a);
+        Vec<T>::ld(p + (int64_t)CV * 8, b);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] += b[e];
+        Vec<T>::ld(p + (int64_t)W * CV * 8, b);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] += b[e];
+        Vec<T>::ld(p + ((int64_t)W + 1) * CV * 8, b);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] += b[e];
+        Vec<T>::st(gtop + i * 8, a);
+    }
+}
+
+extern "C" int dgx_upsample2x_add_fwd(const void* lat, const void* top, void* out, int N, int H, int W, int C, int dtype, void* stream) {
+    if (N <= 0 || H <= 0 || W <= 0) return DGX_OK;
+    if (!lat || !top || !out) return DGX_ERR_BAD_ARG;
+    if ((C & 7) || (H & 1) || (W & 1) || (((uintptr_t)lat | (uintptr_t)top | (uintptr_t)out) & 15)) return DGX_ERR_UNSUPPORTED;
+    const int64_t total = (int64_t)N * H * W * (C >> 3);
+    const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    if (dtype == DGX_BF16)
+        hipLaunchKernelGGL(upsample2x_add_fwd_kernel<uint16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)lat, (const uint16_t*)top, (uint16_t*)out, N, H, W, C);
+    else if (dtype == DGX_F32)
+        hipLaunchKernelGGL(upsample2x_add_fwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)lat, (const float*)top, (float*)out, N, H, W, C);
+    else return DGX_ERR_BAD_ARG;
+    DGX_LAUNCH_CHECK();
+    return DGX_OK;
+}
+
+extern "C" int dgx_upsample2x_add_bwd(const void* g, void* gtop, int N, int H, int W, int C, int dtype, void* stream) {
+    if (N <= 0 || H <= 0 || W <= 0) return DGX_OK;
+    if (!g || !gtop) return DGX_ERR_BAD_ARG;
+    if ((C & 7) || (H & 1) || (W & 1) || (((uintptr_t)g | (uintptr_t)gtop) & 15)) return DGX_ERR_UNSUPPORTED;
+    const int64_t total = (int64_t)N * (H >> 1) * (W >> 1) * (C >> 3);
+    const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    if (dtype == DGX_BF16)
+        hipLaunchKernelGGL(upsample2x_add_bwd_kernel<uint16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)g, (uint16_t*)gtop, N, H, W, C);
+    else if (dtype == DGX_F32)
+        hipLaunchKernelGGL(upsample2x_add_bwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)g, (float*)gtop, N, H, W, C);
+    else return DGX_ERR_BAD_ARG;
+    DGX_LAUNCH_CHECK();
+    return DGX_OK;
+}

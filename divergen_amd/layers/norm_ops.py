@@ -174,6 +174,42 @@ class _ResidualAdd(torch.autograd.Function):
         return g, dy, None, None, None, None, None, None
 
 
+class _Upsample2xAdd(torch.autograd.Function):
+    """lat + nearest-upsampled top on channels-last maps (FPN top-down step): one launch each way."""
+
+    @staticmethod
+    def forward(ctx, lat, top):
+        N, C, H, W = lat.shape
+        latc = lat.contiguous(memory_format=torch.channels_last)
+        topc = top.to(lat.dtype).contiguous(memory_format=torch.channels_last)
+        out = torch.empty_like(latc)
+        nhwc = lambda t: t.permute(0, 2, 3, 1)          # the channels-last storage as a contiguous (N, H, W, C) view
+        L.check(L.lib().dgx_upsample2x_add_fwd(L.ptr(nhwc(latc)), L.ptr(nhwc(topc)), L.ptr(nhwc(out)), N, H, W, C, L.dtype_code(latc),
+                                               L.stream()), "dgx_upsample2x_add_fwd")
+        ctx.cfg, ctx.top_dtype = (N, C, H, W), top.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        N, C, H, W = ctx.cfg
+        g = g.contiguous(memory_format=torch.channels_last)
+        gtop = torch.empty((N, C, H // 2, W // 2), dtype=g.dtype, device=g.device).contiguous(memory_format=torch.channels_last)
+        L.check(L.lib().dgx_upsample2x_add_bwd(L.ptr(g.permute(0, 2, 3, 1)), L.ptr(gtop.permute(0, 2, 3, 1)), N, H, W, C, L.dtype_code(g),
+                                               L.stream()), "dgx_upsample2x_add_bwd")
+        return g, gtop.to(ctx.top_dtype)
+
+
+def upsample2x_add(lat, top):
+    """FPN top-down step, fpn.py:139-145: lat (N,C,H,W) + F.interpolate(top (N,C,H/2,W/2), scale_factor=2, mode='nearest').  GPU maps with
+    C % 8 == 0 and even H, W run dgx_upsample2x_add_fwd/bwd (anything else on a GPU raises); host tensors take torch's two ops (host
+    logic tests)."""
+    if not lat.is_cuda:
+        return lat + torch.nn.functional.interpolate(top, scale_factor=2.0, mode="nearest")
+    if tuple(top.shape) != (lat.shape[0], lat.shape[1], lat.shape[2] // 2, lat.shape[3] // 2) or lat.shape[2] % 2 or lat.shape[3] % 2:
+        raise L.DgxError("upsample2x_add: lateral %s against top-down %s -- the kernel takes exact 2x pairs" % (tuple(lat.shape), tuple(top.shape)))
+    return _Upsample2xAdd.apply(lat, top)
+
+
 def residual_add(x, y, scale, B, H, W, ws=0, shift=0):
     """x (B, H*W, C) fp32|bf16, y bf16 ((B, H*W, C) or windows (B*nW, ws*ws, C)), scale (B,) f32 or None."""
     return _ResidualAdd.apply(x, y, scale, B, H, W, ws, shift)

@@ -9,6 +9,7 @@ import torch.nn.functional as F
 
 from .. import ShapeSpec
 from ...layers.conv_ops import Conv2d
+from ...layers.norm_ops import upsample2x_add
 from .swintransformer import Backbone
 
 
@@ -88,8 +89,7 @@ class FPN(Backbone):
         results.append(self.output_convs[0](prev))
         for idx, (lc, oc) in enumerate(zip(self.lateral_convs, self.output_convs)):
             if idx > 0:
-                top_down = F.interpolate(prev, scale_factor=2.0, mode="nearest")
-                prev = lc(feats[self.in_features[-idx - 1]]) + top_down
+                prev = upsample2x_add(lc(feats[self.in_features[-idx - 1]]), prev)       # lateral + nearest 2x of the level above, one launch
                 if self._fuse_type == "avg":
                     prev = prev / 2
                 results.insert(0, oc(prev))

@@ -382,6 +382,15 @@ int dgx_residual_bwd(const void* g, const float* scale, void* dy_bf16, int B, in
                      int shift, int g_dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * FPN top-down step (D2/modeling/backbone/fpn.py:139-145: F.interpolate(prev, scale_factor=2, mode="nearest") followed by
+ * `lateral + top_down`) on NHWC maps: out (N,H,W,C) = lat (N,H,W,C) + top (N,H/2,W/2,C)[y>>1][x>>1], fp32 sum, one rounding.
+ * Backward: the lateral's gradient is g itself; gtop (N,H/2,W/2,C) = the sum of g over each 2x2 block (fp32, one rounding) -- what
+ * autograd computes through upsample_nearest2d_backward.  dtype DGX_BF16 / DGX_F32; C % 8 == 0, H and W even, 16-byte aligned pointers
+ * (DGX_ERR_UNSUPPORTED otherwise). */
+int dgx_upsample2x_add_fwd(const void* lat, const void* top, void* out, int N, int H, int W, int C, int dtype, void* stream);
+int dgx_upsample2x_add_bwd(const void* g, void* gtop, int N, int H, int W, int C, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Grouped form of dgx_linear_wgrad: the weight gradients of several Linear layers (the four of a Swin
  * block: qkv/proj/fc1/fc2, swintransformer.py:101-108,36-46) in ONE launch, so that large output tiles
  * fill the GPU with a small M-split.  n <= 12 problems -- or up to 32 when dgx_wgrad_grouped_form(problems, n) == 1: groups

@@ -798,6 +798,27 @@ def test_linear_wgrad_grouped(shapes):
         assert (gw.cpu().double() - ref0).abs().max() <= 2e-5 * ref0.abs().max() + 1e-3
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+def test_fpn_upsample2x_add(dt):
+    """FPN top-down step (fpn.py:139-145) as one launch each way against torch's interpolate + add and their autograd: bit for bit
+    (one rounding of an fp32 sum of two resp. four values in both)."""
+    from divergen_amd.layers.norm_ops import upsample2x_add
+    g = torch.Generator().manual_seed(311)
+    N, C, H, W = 2, 256, 18, 14
+    lat = torch.randn(N, C, H, W, generator=g).to(dt).to(DEV).to(memory_format=torch.channels_last).requires_grad_(True)
+    top = torch.randn(N, C, H // 2, W // 2, generator=g).to(dt).to(DEV).to(memory_format=torch.channels_last).requires_grad_(True)
+    go = torch.randn(N, C, H, W, generator=g).to(dt).to(DEV).to(memory_format=torch.channels_last)
+    out = upsample2x_add(lat, top)
+    out.backward(go)
+    lr, tr = lat.detach().clone().requires_grad_(True), top.detach().clone().requires_grad_(True)
+    ref = lr + torch.nn.functional.interpolate(tr, scale_factor=2.0, mode="nearest")
+    ref.backward(go)
+    assert torch.equal(out, ref)
+    assert torch.equal(lat.grad, lr.grad) and torch.equal(top.grad, tr.grad)
+    with pytest.raises(Exception):
+        upsample2x_add(lat, top[:, :, :-1])
+
+
 @pytest.mark.parametrize("M", [1100, 2048])
 def test_linear_wgrad_grouped_loader_wave(M):
     """A group that fills the chip with 256x192 tiles goes to the persistent loader-wave kernel (wgrad_lw.hip): whole-M contraction

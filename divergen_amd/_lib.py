@@ -120,6 +120,7 @@ SIGNATURES = {
     "dgx_layernorm_bwd": (c_i, [c_p] * 10 + [c_i64, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "dgx_layernorm_bwd_emit": (c_i, [c_p] * 10 + [c_i64, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "dgx_layernorm_param_reduce2": (c_i, [c_p] * 6 + [c_i64, c_i, c_p]),
+    "dgx_layernorm_param_reduce_n": (c_i, [c_p, c_p, c_p, c_i, c_i64, c_i, c_p]),
     "dgx_wgrad_grouped_workspace_bytes": (c_i64, [ctypes.POINTER(WgradProblem), c_i]),
     "dgx_linear_wgrad_grouped": (c_i, [ctypes.POINTER(WgradProblem), c_i, c_f, c_p, c_p]),
     "dgx_wgrad_grouped_form": (c_i, [ctypes.POINTER(WgradProblem), c_i]),

@@ -477,6 +477,35 @@ extern "C" int dgx_layernorm_param_reduce2(const float* part_a, float* dgamma_a,
     return DGX_OK;
 }
 
+// The second stage of up to 16 norms in ONE launch (the two norms of up to eight consecutive Swin blocks of a stage: same T and C): per
+// norm the fixed summation order of the single-norm kernel (bit-identical); entries: part / dgamma / dbeta pointer triples.
+struct LnRedN { const float* part[16]; float* dgamma[16]; float* dbeta[16]; };
+__global__ __launch_bounds__(1024) void ln_param_reduce_n_kernel(LnRedN R, int nblk, int C) {
+    __shared__ float4 red[LNR_RG][LNR_QB];
+    const float* part = R.part[0];
+    float* dg = R.dgamma[0];
+    float* db = R.dbeta[0];
+#pragma unroll
+    for (int k = 1; k < 16; ++k)
+        if ((int)blockIdx.y == k) { part = R.part[k]; dg = R.dgamma[k]; db = R.dbeta[k]; }      // constant indices into the by-value table
+    ln_reduce_rows(part, dg, db, nblk, C, blockIdx.x, red);
+}
+extern "C" int dgx_layernorm_param_reduce_n(const float* const* parts, float* const* dgammas, float* const* dbetas, int n, int64_t T, int C,
+                                            void* stream) {
+    if (T <= 0 || n <= 0) return DGX_OK;
+    if (!parts || !dgammas || !dbetas || n > 16 || (C & 3) || C > 1536) return DGX_ERR_BAD_ARG;
+    LnRedN R;
+    for (int k = 0; k < 16; ++k) {
+        const int j = k < n ? k : 0;
+        if (!parts[j] || !dgammas[j] || !dbetas[j]) return DGX_ERR_BAD_ARG;
+        R.part[k] = parts[j]; R.dgamma[k] = dgammas[j]; R.dbeta[k] = dbetas[j];
+    }
+    hipLaunchKernelGGL(ln_param_reduce_n_kernel, dim3((2 * C / 4 + LNR_QB - 1) / LNR_QB, n), dim3(1024), 0, (hipStream_t)stream, R,
+                       dgx_layernorm_bwd_blocks(T), C);
+    DGX_LAUNCH_CHECK();
+    return DGX_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // PatchMerging front half (swintransformer.py:272-298): zero-pad to even H/W, gather the 2x2 neighbourhood
 // [x(2i,2j) | x(2i+1,2j) | x(2i,2j+1) | x(2i+1,2j+1)] into one 4*C0-wide row and LayerNorm it -- in ONE pass over x,

@@ -97,6 +97,7 @@ def flush_wgrads(final=True):
     their parameters.  final=False (called when a block's problems arrive) keeps the tail that does not yet fill a round."""
     if final:
         _CB_QUEUED[0] = False
+        _flush_ln()
         _flush_lw()
     while _PENDING:
         if not final and sum(t for _, t in _PENDING) < _ROUND:      # not enough queued to choose a full round from
@@ -115,13 +116,46 @@ def flush_wgrads(final=True):
 def reset_pending():
     """Drop problems whose backward pass never completed (an exception unwound it): called when the gradients are cleared for a
     new step, so that a stale problem can never be launched into the gradients of the next step."""
-    if _PENDING or _PENDING_LW:
+    if _PENDING or _PENDING_LW or _PENDING_LN:
         import warnings
-        warnings.warn("divergen_amd: %d pending weight gradients dropped (an earlier backward pass did not finish)"
-                      % (len(_PENDING) + len(_PENDING_LW)))
+        warnings.warn("divergen_amd: %d pending weight gradients dropped (LayerNorm parameter folds included; an earlier backward pass did not finish)"
+                      % (len(_PENDING) + len(_PENDING_LW) + len(_PENDING_LN)))
         del _PENDING[:]
         del _PENDING_LW[:]
+        del _PENDING_LN[:]
     _CB_QUEUED[0] = False
+
+
+_PENDING_LN = []       # [(partial rows, weight, bias)] of LayerNorm backward calls whose second stage has not run; _PENDING_LN_KEY = their (T, C)
+_PENDING_LN_KEY = [None]
+
+
+def _flush_ln():
+    """Second stage of the queued LayerNorm parameter gradients (<= 16 norms, one launch: dgx_layernorm_param_reduce_n), then their
+    gradient-ready signals."""
+    if not _PENDING_LN:
+        return
+    import ctypes
+    n = len(_PENDING_LN)
+    T, C = _PENDING_LN_KEY[0]
+    arr = lambda vals: (ctypes.c_void_p * n)(*vals)
+    L.check(L.lib().dgx_layernorm_param_reduce_n(arr([p.data_ptr() for p, _, _ in _PENDING_LN]), arr([w.grad.data_ptr() for _, w, _ in _PENDING_LN]),
+                                                 arr([b.grad.data_ptr() for _, _, b in _PENDING_LN]), n, T, C, L.stream()),
+            "dgx_layernorm_param_reduce_n")
+    for _, w, b in _PENDING_LN:
+        _ready(w, b)
+    del _PENDING_LN[:]
+
+
+def _defer_ln_reduce(part, norms, T, C):
+    n2w, n2b, n1w, n1b = norms
+    if _PENDING_LN and _PENDING_LN_KEY[0] != (T, C):
+        _flush_ln()
+    _PENDING_LN_KEY[0] = (T, C)
+    _PENDING_LN.append((part[0], n2w, n2b))
+    _PENDING_LN.append((part[1], n1w, n1b))
+    if len(_PENDING_LN) >= 16:
+        _flush_ln()
 
 
 def _flush_lw():
@@ -139,7 +173,7 @@ def _flush_lw():
 
 
 def _queue_callback():
-    if (_PENDING or _PENDING_LW) and not _CB_QUEUED[0]:
+    if (_PENDING or _PENDING_LW or _PENDING_LN) and not _CB_QUEUED[0]:
         _CB_QUEUED[0] = True
         torch.autograd.Variable._execution_engine.queue_callback(flush_wgrads)
 
@@ -298,10 +332,8 @@ class _SwinBlockFn(torch.autograd.Function):
             L.check(lib.dgx_layernorm_bwd(dxw.data_ptr(), x.data_ptr(), mean1.data_ptr(), rstd1.data_ptr(), n1w.data_ptr(),
                                           dx1.data_ptr(), dx1.data_ptr(), None, None, part[1].data_ptr(),
                                           T, C, B, H, W, ws, shift, code, st), "dgx_layernorm_bwd")
-        # the second stage of both norms' parameter gradients in one launch
-        L.check(lib.dgx_layernorm_param_reduce2(part[0].data_ptr(), n2w.grad.data_ptr(), n2b.grad.data_ptr(), part[1].data_ptr(),
-                                                n1w.grad.data_ptr(), n1b.grad.data_ptr(), T, C, st), "dgx_layernorm_param_reduce2")
-        _ready(n2w, n2b, n1w, n1b)
+        # the second stage of both norms' parameter gradients: queued, the norms of up to eight blocks of a stage share one launch
+        _defer_ln_reduce(part, (n2w, n2b, n1w, n1b), T, C)
         # the four weight gradients of the block: one grouped launch (256x256 tiles, small M-split)
         # the four weight gradients of the block (256x256 tiles): launched together with the next block's (flush_wgrads)
         _defer_wgrads(wgrads, (w2, w1, pw, qw, b2, b1, pb, qb))

@@ -352,6 +352,10 @@ int dgx_layernorm_bwd_emit(const void* dy_bf16, const void* x, const float* mean
  * order of the single-norm second stage (bit-identical results). */
 int dgx_layernorm_param_reduce2(const float* part_a, float* dgamma_a, float* dbeta_a, const float* part_b, float* dgamma_b,
                                 float* dbeta_b, int64_t T, int C, void* stream);
+/* ... and of up to 16 norms at once (the two norms of up to eight consecutive Swin blocks of one stage: same T and C): n pointer triples,
+ * per norm the summation order of the single-norm kernel. */
+int dgx_layernorm_param_reduce_n(const float* const* parts, float* const* dgammas, float* const* dbetas, int n, int64_t T, int C,
+                                 void* stream);
 /* LayerNorm with an fp32 result (PatchEmbed.norm, swintransformer.py:440-442; under autocast nn.LayerNorm returns fp32
  * and that tensor is the stage-0 residual stream).  x f32|bf16 (T,C) -> y f32 (T,C); backward: dy f32, dx in x's dtype,
  * ADDS into dgamma / dbeta; part as for dgx_layernorm_bwd.  C % 4 == 0, C <= 768 for backward. */

@@ -1145,6 +1145,41 @@ def test_layernorm_param_reduce2_is_bit_identical_to_the_single_norm_second_stag
     assert float((outs[1][1][0][0] - 0.25).abs().max()) > 0
 
 
+@pytest.mark.parametrize("n", [1, 5, 16])
+def test_layernorm_param_reduce_n_is_bit_identical_to_the_single_norm_second_stage(n):
+    """dgx_layernorm_param_reduce_n (the norms of up to eight Swin blocks, one launch) against one ordinary dgx_layernorm_bwd per norm:
+    parameter gradients bit for bit (same summation order per norm); more than 16 norms are refused."""
+    import ctypes
+    from divergen_amd import _lib as L
+    lib = L.lib()
+    T, C = 2500, 768
+    gg = torch.Generator().manual_seed(18)
+    nblk = lib.dgx_layernorm_bwd_blocks(T)
+    parts = torch.empty(n, nblk * 2 * C, device=DEV)
+    ref = [(torch.full((C,), 0.125, device=DEV), torch.full((C,), -0.75, device=DEV)) for _ in range(n)]
+    got = [(torch.full((C,), 0.125, device=DEV), torch.full((C,), -0.75, device=DEV)) for _ in range(n)]
+    for k in range(n):
+        x = bf(torch.randn(T, C, generator=gg)).to(DEV)
+        dy = bf(torch.randn(T, C, generator=gg)).to(DEV)
+        gam = torch.randn(C, generator=gg).to(DEV)
+        mean = x.float().mean(1)
+        rstd = (x.float().var(1, unbiased=False) + 1e-5).rsqrt()
+        dx = torch.empty_like(x)
+        scratch = torch.empty(nblk * 2 * C, device=DEV)
+        L.check(lib.dgx_layernorm_bwd(L.ptr(dy), L.ptr(x), L.ptr(mean), L.ptr(rstd), L.ptr(gam), None, L.ptr(dx), L.ptr(ref[k][0]), L.ptr(ref[k][1]),
+                                      L.ptr(scratch), T, C, 0, 0, 0, 0, 0, L.dtype_code(x), L.stream()), "ln_bwd")
+        L.check(lib.dgx_layernorm_bwd(L.ptr(dy), L.ptr(x), L.ptr(mean), L.ptr(rstd), L.ptr(gam), None, L.ptr(dx), None, None,
+                                      L.ptr(parts[k]), T, C, 0, 0, 0, 0, 0, L.dtype_code(x), L.stream()), "ln_bwd")
+    arr = lambda vals: (ctypes.c_void_p * len(vals))(*vals)
+    L.check(lib.dgx_layernorm_param_reduce_n(arr([parts[k].data_ptr() for k in range(n)]), arr([got[k][0].data_ptr() for k in range(n)]),
+                                             arr([got[k][1].data_ptr() for k in range(n)]), n, T, C, L.stream()), "reduce_n")
+    for k in range(n):
+        assert torch.equal(ref[k][0], got[k][0]) and torch.equal(ref[k][1], got[k][1])
+    assert float((got[0][0] - 0.125).abs().max()) > 0
+    big = arr([parts[0].data_ptr()] * 17)
+    assert lib.dgx_layernorm_param_reduce_n(big, big, big, 17, T, C, L.stream()) != 0
+
+
 @pytest.mark.parametrize("shapes", [[(16384, 576, 192)], [(1024, 1464, 1024)], [(8192, 768, 3072), (8192, 3072, 768), (10368, 768, 768), (10368, 2304, 768)],
                                     [(1024, 1024, 12544), (1024, 1024, 1024), (1024, 1464, 1024)], [(20000, 192, 768), (17000, 64, 72)]])
 def test_wgrad_grouped_with_bias_gradients(shapes):

@@ -305,7 +305,22 @@ class CenterNet(nn.Module):
             small = [torch.arange(offs[l], offs[l] + sizes[l], device=dev) for l in range(Lv) if sizes[l] <= pre_topk]
             cache[key] = (offs, torch.cat(small)[None].expand(B, -1).contiguous() if small else None)
         offs, small_idx = cache[key]
-        parts = [scores[:, offs[l]:offs[l] + n].topk(pre_topk, dim=1)[1] + offs[l] for l, n in enumerate(sizes) if n > pre_topk]
+        big = [l for l, n in enumerate(sizes) if n > pre_topk]
+        if len(big) > 1:
+            # the per-level top-k of all large levels as ONE torch.topk over rows padded with -inf to the largest level (the selection runs one
+            # workgroup per row and takes as long for 4 096 as for 16 384 entries: two launches of ~80 us were one too many); rows are
+            # independent, the padding can never be selected (n > k real entries, all > -inf)
+            nmax = max(sizes[l] for l in big)
+            pk = ("topk_pad", key)
+            if pk not in cache:
+                cache[pk] = (torch.full((B, len(big), nmax), float("-inf"), dtype=torch.float32, device=dev),
+                             torch.tensor([offs[l] for l in big], dtype=torch.int64, device=dev).view(1, len(big), 1))
+            pad, boff = cache[pk]
+            for j, l in enumerate(big):
+                pad[:, j, :sizes[l]].copy_(scores[:, offs[l]:offs[l] + sizes[l]])
+            parts = [(pad.view(B * len(big), nmax).topk(pre_topk, dim=1)[1].view(B, len(big), pre_topk) + boff).view(B, len(big) * pre_topk)]
+        else:
+            parts = [scores[:, offs[l]:offs[l] + sizes[l]].topk(pre_topk, dim=1)[1] + offs[l] for l in big]
         if small_idx is not None:
             parts.append(small_idx)
         idx = torch.cat(parts, 1).contiguous() if len(parts) > 1 else parts[0].contiguous()

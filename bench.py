@@ -50,6 +50,9 @@ def parse():
     p.add_argument("--share-device", type=int, default=None, metavar="D",
                    help="all ranks on GPU D: N-rank plumbing test on a one-GPU box (use with --backend gloo); not a scaling run")
     p.add_argument("--force-pg", action="store_true", help="create a process group even at N = 1 (RCCL next to hipGraph capture)")
+    p.add_argument("--dev", action="append", default=[], metavar="KEY=VALUE",
+                   help="development A/B: dgx_dev_set(KEY, VALUE) before the model is built (include/divergen_hip.h; e.g. gemm_lw=1); "
+                        "'gemm_log=PATH' opens the per-launch GEMM log.  The library itself reads no environment variable")
     p.add_argument("--no-graphs", action="store_true",
                    help="development: issue the hipGraph segments (FPN, tower, heads) eagerly so that every launch is logged / traced by name")
     return p.parse_args()
@@ -307,6 +310,10 @@ def main():
     from divergen_amd.config import get_cfg
     from divergen_amd.data import synthetic_batch
     from divergen_amd.engine import ArenaReducer
+    for kv in a.dev:                         # development A/B only; the default run sets nothing
+        k, v = kv.split("=", 1)
+        rc = _lib.lib().dgx_dev_gemm_log(v.encode()) if k == "gemm_log" else _lib.lib().dgx_dev_set(k.encode(), int(v))
+        assert rc == 0, kv
     from divergen_amd.modeling import build_model
     from divergen_amd.solver import build_lr_scheduler, build_optimizer
     from divergen_amd.structures import BitMasks, Boxes, Instances

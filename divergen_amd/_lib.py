@@ -101,6 +101,9 @@ SIGNATURES = {
     "dgx_centernet_head_outputs_bwd": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
     "dgx_set_reserved_cus": (None, [c_i]),
     "dgx_get_reserved_cus": (c_i, []),
+    "dgx_dev_set": (c_i, [ctypes.c_char_p, c_i]),
+    "dgx_gemm_last_form": (c_i, [ctypes.POINTER(c_i)] * 3),
+    "dgx_dev_gemm_log": (c_i, [ctypes.c_char_p]),
     "dgx_gather_boxes": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p]),
     "dgx_centernet_finalize": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p]),
     "dgx_roi_label": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_i, c_f, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),

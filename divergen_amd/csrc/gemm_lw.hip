@@ -235,6 +235,7 @@ __global__ __launch_bounds__(LW_THREADS) void gemm_lw_kernel(GemmP P0) {
                 if (P0.mode == 3) g_bar();
 #pragma unroll
                 for (int p = 0; p < NPASS; ++p) { g_bar(); g_bar(); }
+                if constexpr ((MC == 3 || MC == 6) && Cfg::TOK0 < Cfg::RING) g_bar();      // the row table inside the last A slot has been read
             }
         }
         return;
@@ -466,6 +467,11 @@ __global__ __launch_bounds__(LW_THREADS) void gemm_lw_kernel(GemmP P0) {
                 __builtin_amdgcn_sched_barrier(0);  // one chunk's tail at a time: interleaved, the GELU arithmetic of three chunks spills
             }
         }
+        // Where the rings fill the whole LDS (128 x 192, 4 + 4 slots) the row table of the residual tails lies INSIDE the last A slot:
+        // the loaders' `issue_a(NSA - 1)` for the NEXT item would overwrite it while `locate` above still reads it for the last slab
+        // (a garbage token = a store far outside the tensor: found by tests/test_gpu_pins.py with dgx_set_reserved_cus(16), the first
+        // configuration that gives a 128 x 192 residual launch a second item per workgroup).  One more barrier per item, this layout only.
+        if constexpr ((MC == 3 || MC == 6) && Cfg::TOK0 < Cfg::RING) { lw_lgkm0(); g_bar(); }
         LCLK(4);
     }
 }

@@ -414,14 +414,18 @@ __global__ __launch_bounds__(256) void gemm_splitk_fold_kernel(GemmP P) {
 namespace {
 struct TileChoice { int bm, bn; };
 int64_t g_ws_bytes_cur = 0;     // size of the workspace of the call being planned
+// Test / A-B knobs of the dispatch (dgx_dev_set): -1 / 0 = the library's own plan.  The product never sets them; the GEMM tests
+// force every tile shape and the split-K path through the one ABI entry with them, the tools compare own form A with own form B.
+struct DevKnobs { int lw = -1, two_wg = -1, tile_bm = 0, tile_bn = 0, splitk = 0; } g_dev;
+struct LastForm { int form = -1, bm = 0, bn = 0, splits = 0; } g_last;     // what the most recent dispatch launched (dgx_gemm_last_form)
 
 // split-K plan: few output tiles and a long contraction (box-head FC 1024 x 1024 x 12544, 3x3 convolutions over the small
 // FPN levels, stage-3 Linears) leave most CUs idle; S slabs of >= 4 K-tiles each fill them.  Returns 1 when not worth it.
 int choose_splits(int64_t tiles, int K, int64_t M, int64_t N, int64_t ws_bytes) {
     const int nt = (K + GBK - 1) / GBK;
-    if (const char* e = getenv("DGX_GEMM_SPLITK")) {
-        const int v = atoi(e);
-        if (v >= 1) return (v <= nt && (int64_t)v * M * N * 4 <= ws_bytes) ? v : 1;
+    if (g_dev.splitk >= 1) {
+        const int v = g_dev.splitk;
+        return (v <= nt && (int64_t)v * M * N * 4 <= ws_bytes) ? v : 1;
     }
     if (tiles > 128 || nt < 8) return 1;
     int S = (int)(256 / tiles);
@@ -435,11 +439,9 @@ int choose_splits(int64_t tiles, int K, int64_t M, int64_t N, int64_t ws_bytes) 
 // fills whole rounds of 256 CUs (one workgroup per CU), weighted by the CU-side efficiency of the smaller tiles.
 static bool tile_192x256() { return true; }      // the 192 x 256 tile (2 stages) where it saves a round of the chip
 TileChoice choose_tile(int M, int N) {
-    const char* env = getenv("DGX_GEMM_TILE");
-    if (env) {
-        int bm = 0, bn = 0;
-        if (sscanf(env, "%dx%d", &bm, &bn) == 2 && (bm == 256 || bm == 192 || bm == 128) && (bn == 192 || bn == 128 || bn == 256) &&
-            !(bm == 256 && bn == 256) && !(bm == 192 && bn == 128))
+    if (g_dev.tile_bm) {
+        const int bm = g_dev.tile_bm, bn = g_dev.tile_bn;
+        if ((bm == 256 || bm == 192 || bm == 128) && (bn == 192 || bn == 128 || bn == 256) && !(bm == 256 && bn == 256) && !(bm == 192 && bn == 128))
             return {bm, bn};
     }
     int bn;
@@ -481,6 +483,7 @@ int launch_gemm(GemmP& P, hipStream_t st) {
             return DGX_ERR_UNSUPPORTED;
         once = true;
     }
+    g_last = {MINW == 4 ? 2 : 0, BM, BN, P.splits};
     hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, NS, MINW, DIAG>), dim3(8 * P.per_xcd), dim3(512), Cfg::LDS, st, P);
     if (P.splits > 1) {
         const int64_t chunks = (int64_t)P.M * (P.N >> 3);
@@ -496,15 +499,10 @@ int gemm_lw_launch(GemmP& P, int bm, int bn, hipStream_t st);     // gemm_lw.hip
 // Which form runs a problem (measured in situ, profiles/r04_gemm_insitu_*.txt): the loader-wave persistent kernel wins wherever the
 // read-out is plain (modes 0 / 1, the implicit convolutions: 0.65-0.97x the time, the skinny K = N = 192 projection excepted) and on
 // the long contractions (K > 768) with a residual or GELU tail; the two-workgroup form of gemm_nt keeps the K <= 768 GEMMs whose
-// tails read a cold operand or write two tensors (its second workgroup's main loop hides them).  DGX_GEMM_LW = 0 | 1 forces
-// gemm_nt | gemm_lw everywhere (development A/B; tools/r04_insitu_ab.sh).
-static int lw_mode() {
-    static const int v = getenv("DGX_GEMM_LW") ? atoi(getenv("DGX_GEMM_LW")) : 2;
-    return v;
-}
+// tails read a cold operand or write two tensors (its second workgroup's main loop hides them).  dgx_dev_set("gemm_lw", 0 | 1) forces
+// gemm_nt | gemm_lw everywhere (tests and A/B tools only).
 static bool use_lw(const GemmP& P) {
-    const int m = lw_mode();
-    if (m != 2) return m == 1;
+    if (g_dev.lw >= 0) return g_dev.lw == 1;
     if (P.mode <= 1) return !(P.N <= 192 && P.K <= 192);
     if (P.mode == 2 || P.mode == 3) return P.K > 768;
     return false;
@@ -524,6 +522,7 @@ static int launch_lw(GemmP& P, int bm, int bn, hipStream_t st) {
     plan_tiles(P, bm, bn);
     const int rc = gemm_lw_launch(P, bm, bn, st);
     if (rc != DGX_OK) return rc;
+    g_last = {1, bm, bn, P.splits};
     if (P.splits > 1) {
         const int64_t chunks = (int64_t)P.M * (P.N >> 3);
         const int grid = (int)((chunks + 255) / 256 < 4096 ? (chunks + 255) / 256 : 4096);
@@ -534,16 +533,35 @@ static int launch_lw(GemmP& P, int bm, int bn, hipStream_t st) {
 }
 static int dgx_gemm_dispatch(GemmP& P, hipStream_t st);
 static bool use_two_wg(const GemmP& P) {          // see dgx_gemm_dispatch
-    static const int two_wg = getenv("DGX_GEMM_2WG") ? atoi(getenv("DGX_GEMM_2WG")) : 1;
-    return two_wg && P.N % 192 == 0 && P.K <= 768 && P.M >= 8192 && !P.conv_kc;
+    return g_dev.two_wg != 0 && P.N % 192 == 0 && P.K <= 768 && P.M >= 8192 && !P.conv_kc;
 }
 static void* g_dbg_buffer = nullptr;
-static FILE* gemm_log_file() {     // development: one line per launch (DGX_GEMM_LOG=path), joined with a kernel trace
-    static const char* logp = getenv("DGX_GEMM_LOG");
-    static FILE* lf = logp ? fopen(logp, "w") : nullptr;
-    return lf;
-}   // development: set through dgx_dev_gemm_set_debug
+static FILE* g_gemm_log = nullptr;     // one line per launch (dgx_dev_gemm_log), joined with a kernel trace by tools/gemm_insitu.py
+static FILE* gemm_log_file() { return g_gemm_log; }
 extern "C" void dgx_dev_gemm_set_debug(void* device_buffer) { g_dbg_buffer = device_buffer; }
+extern "C" int dgx_dev_gemm_log(const char* path) {
+    if (g_gemm_log) { fclose(g_gemm_log); g_gemm_log = nullptr; }
+    if (path && *path && !(g_gemm_log = fopen(path, "w"))) return DGX_ERR_BAD_ARG;
+    return DGX_OK;
+}
+extern int g_dgx_dev_wgrad_lw;      // wgrad_lw.hip
+extern "C" int dgx_dev_set(const char* key, int value) {
+    if (!key) return DGX_ERR_BAD_ARG;
+    if (!strcmp(key, "gemm_lw")) g_dev.lw = value;                   // -1 plan, 0 gemm_nt everywhere, 1 gemm_lw everywhere
+    else if (!strcmp(key, "gemm_2wg")) g_dev.two_wg = value;         // -1 / 1 plan, 0 never the two-workgroup form
+    else if (!strcmp(key, "gemm_tile")) { g_dev.tile_bm = value / 1000; g_dev.tile_bn = value % 1000; }     // bm * 1000 + bn, 0 = plan
+    else if (!strcmp(key, "gemm_splitk")) g_dev.splitk = value;      // 0 plan, >= 1 forced slab count
+    else if (!strcmp(key, "wgrad_lw")) g_dgx_dev_wgrad_lw = value;   // 1 plan, 0 never the loader-wave form, 2 always
+    else if (!strcmp(key, "reset")) { g_dev = DevKnobs(); g_dgx_dev_wgrad_lw = 1; }
+    else return DGX_ERR_BAD_ARG;
+    return DGX_OK;
+}
+extern "C" int dgx_gemm_last_form(int* bm, int* bn, int* splits) {
+    if (bm) *bm = g_last.bm;
+    if (bn) *bn = g_last.bn;
+    if (splits) *splits = g_last.splits;
+    return g_last.form;
+}
 
 extern "C" int dgx_gemm_bf16_nt(const void* A, const void* B, int M, int N, int K, int64_t lda, int64_t ldb,
                                 const dgx_gemm_epilogue* ep, void* stream) {
@@ -656,6 +674,7 @@ static int launch_lw_grouped(GemmP& P, const int* Ms, int n, int bm, int bn, hip
     P.per_xcd = (P.total + 7) / 8;
     const int rc = gemm_lw_launch(P, bm, bn, st);
     if (rc != DGX_OK) return rc;
+    g_last = {1, bm, bn, P.splits};
     DGX_LAUNCH_CHECK();
     return DGX_OK;
 }
@@ -737,11 +756,11 @@ extern "C" int dgx_conv3x3_gemm_multi(const dgx_conv_item* items, int n, const v
         int t128 = 0, t192 = 0;
         for (int i = 0; i < n; ++i) { t128 += (Ms[i] + 127) / 128; t192 += (Ms[i] + 191) / 192; }
         const bool big = tile_192x256() && ((t192 + 255) / 256) * 192 < ((t128 + 255) / 256) * 128;
-        if (lw_mode()) return launch_lw_grouped(P, Ms, n, big ? 192 : 128, 256, st);
+        if (g_dev.lw != 0) return launch_lw_grouped(P, Ms, n, big ? 192 : 128, 256, st);
         if (big) return launch_gemm_grouped<192, 256, 2>(P, Ms, n, st);
         return launch_gemm_grouped<128, 256, 3>(P, Ms, n, st);
     }
-    if (lw_mode()) return launch_lw_grouped(P, Ms, n, 128, 128, st);
+    if (g_dev.lw != 0) return launch_lw_grouped(P, Ms, n, 128, 128, st);
     return launch_gemm_grouped<128, 128, 4>(P, Ms, n, st);
 }
 

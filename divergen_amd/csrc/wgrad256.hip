@@ -411,13 +411,19 @@ extern "C" int dgx_wgrad_grouped_form(const dgx_wgrad_problem* problems, int n) 
     return problems && n > 0 && n <= MAXP_GROUP && wgrad_lw_wants(problems, n) ? 1 : 0;
 }
 
-extern "C" int64_t dgx_wgrad_grouped_workspace_bytes(const dgx_wgrad_problem* problems, int n) {
-    if (!problems || n <= 0 || n > MAXP_GROUP) return 0;
-    if (wgrad_lw_wants(problems, n)) return 0;
-    if (n > MAXP256) return 0;
+// workspace of the split-M form for a group (what wgrad_grouped_impl writes): the ONLY place its size is computed
+static int64_t split_workspace_bytes(const dgx_wgrad_problem* problems, int n) {
+    if (!problems || n <= 0 || n > MAXP256) return 0;
     int S[MAXP256], slab[MAXP256];
     plan256(problems, n, S, slab);
     return ws_floats256(problems, n, S, nullptr) * 4;
+}
+extern "C" int64_t dgx_wgrad_grouped_workspace_bytes(const dgx_wgrad_problem* problems, int n) {
+    if (!problems || n <= 0 || n > MAXP_GROUP) return 0;
+    // a group the loader-wave form takes needs none -- unless its launch checks can still send it to the split-M form (n <= 12):
+    // then the split form's size is reported, so the fall-back in dgx_linear_wgrad_grouped never writes past the caller's buffer
+    if (wgrad_lw_wants(problems, n) && n > MAXP256) return 0;
+    return split_workspace_bytes(problems, n);
 }
 
 static int wgrad_grouped_impl(const dgx_wgrad_problem* problems, const int* ldc, int n, float beta, void* workspace, void* stream);
@@ -433,9 +439,8 @@ extern "C" int dgx_linear_wgrad_grouped(const dgx_wgrad_problem* problems, int n
     DgxProfScope prof(DGX_PROF_WGRAD, stream, fl, by);
     if (wgrad_lw_wants(problems, n)) {
         const int rc = wgrad_lw_launch(problems, n, beta, (hipStream_t)stream);
-        if (rc != DGX_OK) return rc;
-        DGX_LAUNCH_CHECK();
-        return DGX_OK;
+        if (rc == DGX_OK) { DGX_LAUNCH_CHECK(); return DGX_OK; }
+        if (rc != DGX_ERR_UNSUPPORTED || n > MAXP256) return rc;      // an operand over 2^31 bytes, ...: the split-M form takes <= 12 problems
     }
     return wgrad_grouped_impl(problems, nullptr, n, beta, workspace, stream);
 }
@@ -447,7 +452,7 @@ extern "C" int64_t dgx_conv3x3_wgrad_workspace_bytes(int N, int H, int W, int Ci
     dgx_wgrad_problem pr[9];
     const int64_t Mp = (int64_t)N * (H + 2) * (W + 2);
     for (int t = 0; t < 9; ++t) { pr[t].dy = pr[t].x = nullptr; pr[t].gw = nullptr; pr[t].gb = nullptr; pr[t].M = (int)Mp; pr[t].Nn = Cout; pr[t].Kk = Cin; }
-    return dgx_wgrad_grouped_workspace_bytes(pr, 9);
+    return split_workspace_bytes(pr, 9);       // the tap problems always run on the split-M form (ldc = 9 Cin), whatever wgrad_lw_wants says
 }
 extern "C" int dgx_conv3x3_wgrad_bias(const void* dypad, const void* xpad, float* gw, float* gb, int N, int H, int W, int Cin, int Cout,
                                       float beta, void* workspace, void* stream);
@@ -460,7 +465,7 @@ extern "C" int64_t dgx_conv3x3_wgrad_bias_workspace_bytes(int N, int H, int W, i
     const int64_t Mp = (int64_t)N * (H + 2) * (W + 2);
     float dummy;
     for (int t = 0; t < 9; ++t) { pr[t].dy = pr[t].x = nullptr; pr[t].gw = nullptr; pr[t].gb = t == 0 ? &dummy : nullptr; pr[t].M = (int)Mp; pr[t].Nn = Cout; pr[t].Kk = Cin; }
-    return dgx_wgrad_grouped_workspace_bytes(pr, 9);
+    return split_workspace_bytes(pr, 9);
 }
 extern "C" int dgx_conv3x3_wgrad_bias(const void* dypad, const void* xpad, float* gw, float* gb, int N, int H, int W, int Cin, int Cout,
                                       float beta, void* workspace, void* stream) {
@@ -494,7 +499,7 @@ static int wgrad_grouped_impl(const dgx_wgrad_problem* problems, const int* ldc,
     int S[MAXP256], slab[MAXP256];
     int64_t off[MAXP256], offb[MAXP256];
     plan256(problems, n, S, slab);
-    ws_floats256(problems, n, S, off, offb);
+    if (ws_floats256(problems, n, S, off, offb) > 0 && !workspace) return DGX_ERR_BAD_ARG;      // a split plan without a buffer to fold through
     Params256 P;
     P.n = n;
     P.beta = beta;

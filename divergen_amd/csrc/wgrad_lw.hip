@@ -415,8 +415,9 @@ int wgrad_lw_launch(const dgx_wgrad_problem* pr, int n, float beta, hipStream_t 
 
 // Is this group worth the persistent form?  Many tiles of the loader-wave kernel (>= 3/4 of a round of the chip) whose contraction is
 // long enough for the main loop to dominate, and whose item count fills whole rounds to >= 74 % (4 stage-2 blocks = 2.25 rounds still win).
+int g_dgx_dev_wgrad_lw = 1;      // dgx_dev_set("wgrad_lw", v): 1 = the plan below, 0 = never this form, 2 = always (tests / A-B tools)
 bool wgrad_lw_wants(const dgx_wgrad_problem* pr, int n) {
-    static const int mode = getenv("DGX_WGRAD_LW") ? atoi(getenv("DGX_WGRAD_LW")) : 1;
+    const int mode = g_dgx_dev_wgrad_lw;
     if (!mode || n <= 0 || n > WL_MAXP) return false;
     int items = 0;
     for (int i = 0; i < n; ++i) {

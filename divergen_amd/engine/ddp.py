@@ -60,7 +60,16 @@ class ArenaReducer:
             # RCCL runs one workgroup per channel, each pinned to a CU for the collective's duration, beside the backward kernels.
             # libdgx's persistent kernels (one workgroup per CU, whole LDS + register file) cannot share a CU with a channel, so they
             # are told to leave that many CUs alone (csrc/gemm_lw.hip): NCCL_MAX_NCHANNELS bounds the channel count
-            self.reserved_cus = int(os.environ.get("NCCL_MAX_NCHANNELS", "16"))
+            if "NCCL_MAX_NCHANNELS" not in os.environ:
+                # torch creates the RCCL communicator at the first collective, so a default set here still bounds the channels when
+                # no collective has run yet; a launcher that already ran one keeps RCCL's own (larger) count -- say so
+                import warnings
+                os.environ["NCCL_MAX_NCHANNELS"] = "16"
+                warnings.warn("divergen_amd: NCCL_MAX_NCHANNELS was not set by the launcher; set to 16 now (engine/launch.py, train_net.py "
+                              "and bench.py export it before init_process_group) -- if a collective has already run, RCCL keeps its own "
+                              "channel count and its channels will contend with the persistent GEMM workgroups")
+            self.reserved_cus = int(os.environ["NCCL_MAX_NCHANNELS"])
+        if arena.g.is_cuda:      # process-global in libdgx: an inactive / single-rank reducer gives the CUs back
             from .. import _lib as L
             L.lib().dgx_set_reserved_cus(self.reserved_cus)
         if self.active:

@@ -151,6 +151,8 @@ def _defer_ln_reduce(part, norms, T, C):
     n2w, n2b, n1w, n1b = norms
     if _PENDING_LN and _PENDING_LN_KEY[0] != (T, C):
         _flush_ln()
+    if any(w is n2w or w is n1w for _, w, _ in _PENDING_LN):       # a norm queued twice (shared / re-entered block): two slices of one
+        _flush_ln()                                                 # launch would race on its dgamma / dbeta -- serialise as before
     _PENDING_LN_KEY[0] = (T, C)
     _PENDING_LN.append((part[0], n2w, n2b))
     _PENDING_LN.append((part[1], n1w, n1b))

@@ -325,6 +325,10 @@ class FusedAdamWEMA:
                 and src.numel() == dst.numel():
             dst.copy_(src)
             return
+        if saved["layout_version"] is None and saved["names"] is not None and saved["offsets"] is not None \
+                and list(saved["names"]) == cur["names"] and list(saved["offsets"]) == cur["offsets"] and src.numel() == dst.numel():
+            dst.copy_(src)          # a checkpoint from before the version field whose names and offsets ARE this arena's: same layout
+            return
         if saved["layout_version"] != ARENA_LAYOUT_VERSION or saved["names"] is None or saved["sizes"] is None:
             raise RuntimeError("optimizer state '%s' was written by a build with another parameter storage layout (saved version %s, "
                                "this build %d): it cannot be mapped onto this arena -- resume with the model weights only, or from a "

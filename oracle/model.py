@@ -66,6 +66,21 @@ def _match(gt_boxes, gt_classes, boxes, thr, num_classes):
     return idx, cls
 
 
+class _ScaleGradient(torch.autograd.Function):
+    """cascade_rcnn.py:20-28: identity forward, gradient x scale backward.  DeticCascadeROIHeads._run_stage
+    (detic_roi_heads.py:396-414) applies it with 1 / num_cascade_stages to the pooled box features of every stage: the three stages'
+    losses are summed, and the gradient they send into the SHARED feature maps is averaged."""
+
+    @staticmethod
+    def forward(ctx, x, scale):
+        ctx.scale = scale
+        return x
+
+    @staticmethod
+    def backward(ctx, g):
+        return g * ctx.scale, None
+
+
 def roi_head_losses(p, fp, proposals, gts, image_sizes, num_classes, batch_per_image, pos_fraction, freq_weight, fed_num,
                     sample_fn, fed_fn, mask_weight=1.0, prefix="roi_heads.", stage_labels=None):
     """proposals: per image (boxes (n,4)).  gts: per image dict(boxes, classes, masks (n,H,W) bool).
@@ -106,6 +121,7 @@ def roi_head_losses(p, fp, proposals, gts, image_sizes, num_classes, batch_per_i
                 midx[i] = idx
             boxes, cls = nb, nc
         x = rb(R.roi_pooler(feats, boxes, 7, scales))         # (pooled features are stored in the feature maps' dtype)
+        x = _ScaleGradient.apply(x, 1.0 / 3)                  # detic_roi_heads.py:403 (cascade_rcnn.py:20-28): features only
         x = H.box_head(x, p, "%sbox_head.%d." % (prefix, k))
         logits, deltas = H.box_predictor(x, p, "%sbox_predictor.%d." % (prefix, k))
         gtc = torch.cat(cls)

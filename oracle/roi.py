@@ -38,8 +38,32 @@ def _fp(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
 
+class _RoIAlignFn(torch.autograd.Function):
+    """ROIAlign as the reference's autograd sees it (D2/layers/roi_align.py:49-65 -> torchvision.ops.roi_align: differentiable with
+    respect to the feature map, not to the boxes): forward and backward are the two C functions of oracle/roi_nms.c, both pinned on
+    the reference's known-answer test and on ROIAlignRotated_cpu.cpp compiled in place (tests/test_oracle_roi.py)."""
+
+    @staticmethod
+    def forward(ctx, inp, rois, scale, out_size, sampling_ratio, aligned):
+        ctx.save_for_backward(rois)
+        ctx.meta = (scale, tuple(inp.shape), sampling_ratio, aligned)
+        return _roi_align_values(inp, rois, scale, out_size, sampling_ratio, aligned)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (rois,) = ctx.saved_tensors
+        scale, in_shape, sampling_ratio, aligned = ctx.meta
+        return roi_align_backward(grad_out.contiguous(), rois, scale, in_shape, sampling_ratio, aligned), None, None, None, None, None
+
+
 def roi_align(inp, rois, scale, out_size, sampling_ratio=0, aligned=True):
-    """inp (N,C,H,W) float32 tensor, rois (R,5) -> (R,C,ph,pw)."""
+    """inp (N,C,H,W) float32 tensor, rois (R,5) -> (R,C,ph,pw); differentiable w.r.t. inp when it requires grad."""
+    if torch.is_grad_enabled() and inp.requires_grad:
+        return _RoIAlignFn.apply(inp, rois, scale, out_size, sampling_ratio, aligned)
+    return _roi_align_values(inp, rois, scale, out_size, sampling_ratio, aligned)
+
+
+def _roi_align_values(inp, rois, scale, out_size, sampling_ratio=0, aligned=True):
     x = np.ascontiguousarray(inp.detach().numpy(), dtype=np.float32)
     r = np.ascontiguousarray(rois.detach().numpy(), dtype=np.float32)
     ph, pw = (out_size, out_size) if isinstance(out_size, int) else out_size

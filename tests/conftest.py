@@ -19,3 +19,16 @@ def golden():
     def load(name):
         return np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
     return load
+
+
+@pytest.fixture
+def dgx_dev():
+    """dgx_dev_set(key, value) for one test (forced GEMM tile / split-K / kernel form: include/divergen_hip.h); everything back to the
+    library's own plan afterwards."""
+    from divergen_amd import _lib
+    L = _lib.lib()
+
+    def setk(key, value):
+        assert L.dgx_dev_set(key.encode(), int(value)) == 0, key
+    yield setk
+    L.dgx_dev_set(b"reset", 0)

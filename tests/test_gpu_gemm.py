@@ -28,12 +28,11 @@ def close_bf16(got, ref, extra=0.0):
 
 
 @pytest.fixture
-def tile(request, monkeypatch):
+def tile(request, dgx_dev):
     t = request.param
-    if t is None:
-        monkeypatch.delenv("DGX_GEMM_TILE", raising=False)
-    else:
-        monkeypatch.setenv("DGX_GEMM_TILE", t)
+    if t is not None:
+        bm, bn = t.split("x")
+        dgx_dev("gemm_tile", int(bm) * 1000 + int(bn))
     return t
 
 
@@ -51,11 +50,11 @@ def test_gemm_nt_bias(tile, M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K,S", [(1024, 1024, 12544, 0), (128, 256, 2304, 0), (2048, 1536, 6144, 4), (300, 200, 1096, 3), (512, 384, 640, 2)])
-def test_gemm_split_k(monkeypatch, M, N, K, S):
+def test_gemm_split_k(dgx_dev, M, N, K, S):
     """Few output tiles and a long contraction: K is cut into slabs (fp32 partial sums in the workspace) and folded by a
     second launch with the same epilogue; S = 0 leaves the split count to the library's plan."""
     if S:
-        monkeypatch.setenv("DGX_GEMM_SPLITK", str(S))
+        dgx_dev("gemm_splitk", S)
     g = torch.Generator().manual_seed(K)
     a, b = bf(torch.randn(M, K, generator=g)), bf(torch.randn(N, K, generator=g) * 0.1)
     bias = bf(torch.randn(N, generator=g))

@@ -101,10 +101,21 @@ def library_compute_kernels(prof):
 
 
 def test_end_to_end_losses_vs_assembled_oracle(monkeypatch):
-    run_e2e_vs_oracle(monkeypatch, "T", 256)
+    # losses within 1e-3 of both oracles; gradients of the SUM of the ten losses: whole arena <= 8 %, any parameter <= 25 % (measured
+    # 4.8 % / 17 %: the CenterNet tower's four GroupNorm + ReLU layers put ~15 % on everything upstream of them -- ReLU masks that flip
+    # within bf16 rounding of zero, see _compare_gradients and profiles/r05_tower_grad_probe.txt; the sharp check is the next test)
+    run_e2e_vs_oracle(monkeypatch, "T", 256, grads=True, grad_bounds=(8e-2, 0.25))
 
 
-def run_e2e_vs_oracle(monkeypatch, swin, size):
+def test_end_to_end_gradients_of_the_mask_loss_are_sharp(monkeypatch):
+    """The gradient of loss_mask alone: mask head -> RoIAlign backward (gather form) -> FPN -> the whole Swin backbone (attention
+    backward, LayerNorm backward, the grouped weight gradients, PatchMerging, PatchEmbed) without a GroupNorm + ReLU tower in the way.
+    Every parameter of the backbone within 6 % (measured <= 3.0 %, the relative-position tables; segments 1.2-1.5 %), the whole arena
+    within 2e-3 (measured 5e-4) of the oracle's autograd."""
+    run_e2e_vs_oracle(monkeypatch, "T", 256, grads=True, loss_filter=lambda k: k == "loss_mask", grad_bounds=(2e-3, 6e-2))
+
+
+def run_e2e_vs_oracle(monkeypatch, swin, size, grads=False, loss_filter=None, grad_bounds=(2e-2, 5e-2)):
     """Whole training forward of the PRODUCT path -- the one bench.py times: bf16 operands, fp32 accumulation, every GEMM /
     convolution / normalisation / attention / loss on libdgx kernels -- against the assembled CPU oracle (oracle/model.py,
     fp32) on the same operands: same batch, the oracle's Linear / convolution weights rounded to bf16 (the values the product's
@@ -114,8 +125,11 @@ def run_e2e_vs_oracle(monkeypatch, swin, size):
     test_gpu_parity_modules / test_gpu_kernels) and each cascade stage's matched labels (a refined box within rounding of an
     IoU threshold would otherwise flip a label).  Everything continuous is the oracle's own.
     Asserted: every one of the 10 losses within 1e-3 (north_star) of the oracle run with the product's bf16 storage points
-    (oracle/quant.py) and within 1 % of the plain fp32 oracle (the bf16 deltas, printed as a table), and NO vendor / framework
-    compute kernel in the launch list of the step."""
+    (oracle/quant.py) AND within 1e-3 (+ 1e-5 absolute) of the plain fp32 oracle (round 5; the deltas are printed as a table), and NO
+    vendor / framework compute kernel in the launch list of the step.
+    grads=True: the PARAMETER GRADIENTS of the same step as well -- the whole gradient arena of the product (every hand-written
+    backward: attention, LayerNorm, the grouped weight gradients, GroupNorm, RoIAlign's gather, the fused losses) against the
+    autograd of the fp32 oracle on the same batch: relative L2 over the arena and per parameter, printed as a table."""
     import divergen_amd.modeling.roi_heads.detic_fast_rcnn as FR
     import divergen_amd.modeling.roi_heads.detic_roi_heads as RH
     from divergen_amd.data import synthetic_batch
@@ -145,9 +159,11 @@ def run_e2e_vs_oracle(monkeypatch, swin, size):
         opt.zero_grad()
         with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
             losses = model(batch)
-            sum(losses.values()).backward()
+            sum(v for k, v in losses.items() if loss_filter is None or loss_filter(k)).backward()
             torch.cuda.synchronize()
     got = {k: float(v) for k, v in losses.items()}
+    opt.arena.finish_grads()        # segments no first writer reached are zeroed now (what optimizer.step() does first)
+    torch.cuda.synchronize()
     lib = library_compute_kernels(prof)
     assert not lib, "vendor / framework compute kernels on the product path: %s" % lib
     launched = {k.name for ev in prof.events() for k in ev.kernels}
@@ -209,8 +225,76 @@ def run_e2e_vs_oracle(monkeypatch, swin, size):
               % (k, r["product"], r["oracle_bf16_storage"], r["rel"], r["oracle_fp32"], r["bf16_delta"]))
     for k, r in report.items():
         assert abs(r["product"] - r["oracle_bf16_storage"]) <= 1e-3 * abs(r["oracle_bf16_storage"]) + 1e-6, (k, report)
-        assert abs(r["product"] - r["oracle_fp32"]) <= 1e-2 * abs(r["oracle_fp32"]) + 1e-5, (k, report)
+        assert abs(r["product"] - r["oracle_fp32"]) <= 1e-3 * abs(r["oracle_fp32"]) + 1e-5, (k, report)
+    if grads:
+        report["_grad_rows"] = _compare_gradients(model, p, oracle_losses_fn=lambda pp: assembled_oracle_losses(
+            pp, images, gts, [tuple(b["instances"].image_size) for b in batch], swin, C, fw, cfg.MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE,
+            cfg.MODEL.ROI_HEADS.POSITIVE_FRACTION, cfg.MODEL.ROI_BOX_HEAD.FED_LOSS_NUM_CAT, model.roi_heads.mask_weight,
+            proposals=captured["props"], stage_labels=stage_labels), swin=swin, size=size, loss_filter=loss_filter, bounds=grad_bounds)
     return report
+
+
+def _compare_gradients(model, p, oracle_losses_fn, swin, size, loss_filter=None, bounds=(2e-2, 5e-2)):
+    """d(sum of the 10 losses) / d(parameter) for EVERY parameter: the product's gradient arena (bf16 operands, fp32 accumulation,
+    hand-written backward kernels) against torch autograd through the oracle at the same point (the oracle's GEMM weights are the
+    bf16-rounded values the product reads), twice:
+      * the oracle with the product's bf16 STORAGE points (oracle/quant.py; autograd rounds the gradients at the same points on the
+        way back) -- ASSERTED: what is left is summation order, so a wrong ring wrap, a dropped tile or a mis-scaled term in any
+        backward kernel shows up as O(1) on its parameter;
+      * the plain fp32 oracle -- REPORTED as the bf16 delta of the gradients.  It is large by construction, not by defect: a ReLU
+        whose bf16-stored pre-activation lies within rounding of zero flips its mask, and a fraction f of flipped elements is a
+        relative L2 error of sqrt(f) in the gradient behind it (~3-5 % per GroupNorm + ReLU layer of the CenterNet tower, measured
+        layer by layer with tools/grad_parity_probe.py); the reference's own fp16 autocast has the same property against fp32."""
+    from oracle.quant import bf16_storage
+
+    def oracle_grads(storage):
+        pg = {k: v.clone().requires_grad_(True) for k, v in p.items() if v.is_floating_point()}
+        pall = dict(p)
+        pall.update(pg)
+        with bf16_storage(storage):
+            total = sum(v for k, v in oracle_losses_fn(pall).items() if loss_filter is None or loss_filter(k))
+            total.backward()
+        return {k: v.grad for k, v in pg.items()}
+    ref_q, ref_f = oracle_grads(True), oracle_grads(False)
+    rows, num, den, numf = [], 0.0, 0.0, 0.0
+    for name, q in model.named_parameters():
+        if not q.requires_grad or q.grad is None:
+            continue
+        g = q.grad.detach()
+        if hasattr(q, "_dgx_sd_perm"):            # stored in another column order than its state-dict form (box heads' first FC)
+            g = q._dgx_sd_perm[0](g)
+        g = g.double().cpu()
+        r = torch.zeros_like(g) if ref_q[name] is None else ref_q[name].double()
+        rf = torch.zeros_like(g) if ref_f[name] is None else ref_f[name].double()
+        d2, r2, f2 = float((g - r).square().sum()), float(r.square().sum()), float((g - rf).square().sum())
+        num += d2
+        den += r2
+        numf += f2
+        rel = lambda e2: (e2 / r2) ** 0.5 if r2 > 0 else (0.0 if e2 == 0 else float("inf"))
+        rows.append((name, tuple(g.shape), r2 ** 0.5, rel(d2), rel(f2)))
+    whole, whole_f = (num / den) ** 0.5, (numf / den) ** 0.5
+    print("e2e gradient parity, product gradient arena vs the oracle's autograd (Swin-%s, %d px), relative L2 over all %d parameters: "
+          "%.3e vs the oracle with bf16 storage, %.3e vs the fp32 oracle (|g| = %.4e)" % (swin, size, len(rows), whole, whole_f, den ** 0.5))
+    for name, shape, nr, rel_q, rel_f in sorted(rows, key=lambda t: -t[3])[:12]:
+        print("  %-64s %-20s |g| %.3e  rel L2 %.3e  (fp32 oracle: %.3e)" % (name, shape, nr, rel_q, rel_f))
+    by_group = {}
+    for name, shape, nr, rel_q, rel_f in rows:
+        key = ".".join(name.split(".")[:4]) if name.startswith("backbone.bottom_up.layers") else ".".join(name.split(".")[:2])
+        a = by_group.setdefault(key, [0.0, 0.0, 0.0])
+        a[0] += (rel_q * nr) ** 2
+        a[1] += nr ** 2
+        a[2] += (rel_f * nr) ** 2
+    for key, (d2, r2, f2) in sorted(by_group.items()):
+        print("  segment %-44s |g| %.3e  rel L2 %.3e  (fp32 oracle: %.3e)" % (key, r2 ** 0.5, (d2 / r2) ** 0.5 if r2 > 0 else 0.0,
+                                                                              (f2 / r2) ** 0.5 if r2 > 0 else 0.0))
+    if bounds is None:
+        return rows
+    assert whole <= bounds[0], whole
+    tot = den ** 0.5
+    for name, shape, nr, rel_q, rel_f in rows:
+        # per parameter; the tiny ones (a bias whose gradient is 1e-6 of the total) are bounded through their share of the whole
+        assert rel_q <= bounds[1] or rel_q * nr <= 2e-3 * tot, (name, shape, nr, rel_q)
+    return rows
 
 
 def test_overfits_a_fixed_batch():

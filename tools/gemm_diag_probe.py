@@ -6,6 +6,10 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _dev  # noqa: E402
+_dev.apply_env()       # DGX_GEMM_LW / DGX_GEMM_TILE / DGX_WGRAD_LW ... of the calling script -> dgx_dev_set
+
 from divergen_amd.layers import gemm_ops as G  # noqa: E402
 
 shapes = [("s2.fc1", 8192, 3072, 768), ("s2.fc2", 8192, 768, 3072), ("s2.qkv", 10368, 2304, 768), ("s2.qkvd", 10368, 768, 2304),
@@ -25,7 +29,7 @@ for name, M, N, K in shapes:
         for st in ("", "2"):
             if tile in ("256x192", "128x256") and st == "2":
                 continue
-            os.environ["DGX_GEMM_TILE"] = tile
+            __import__("_dev").set_tile(tile)
             if st:
                 os.environ["DGX_GEMM_STAGES"] = st
             else:

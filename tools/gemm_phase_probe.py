@@ -7,6 +7,10 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _dev  # noqa: E402
+_dev.apply_env()       # DGX_GEMM_LW / DGX_GEMM_TILE / DGX_WGRAD_LW ... of the calling script -> dgx_dev_set
+
 from divergen_amd import _lib as L  # noqa: E402
 from divergen_amd.layers import gemm_ops as G  # noqa: E402
 
@@ -25,7 +29,7 @@ for name, M, N, K in shapes:
             os.environ["DGX_GEMM256"] = tile[1:]
         else:
             os.environ.pop("DGX_GEMM256", None)
-            os.environ["DGX_GEMM_TILE"] = tile
+            __import__("_dev").set_tile(tile)
         os.environ["DGX_GEMM_DIAG"] = str(dg)
         for _ in range(3):
             G.gemm_nt(x, w)

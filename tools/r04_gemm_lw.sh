@@ -11,7 +11,7 @@ DGX_GEMM_LW=1 timeout 300 python tools/gemm_phase_probe.py 256x192,192x192,128x1
 DGX_GEMM_LW=0 DGX_GEMM_2WG=0 timeout 300 python tools/gemm_phase_probe.py 256x192,192x192,128x192 0 > $O/phases_lw0.txt 2>&1
 grep -h "per K-tile" $O/phases_lw1.txt $O/phases_lw0.txt
 for r in 1 2; do for v in 0 1 2; do
-  DGX_GEMM_LW=$v timeout 600 python bench.py --steps 40 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "
+  timeout 600 python bench.py --dev gemm_lw=$v --steps 40 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "
 import sys,json
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 r=d['roofline']; o={x['family']:x for x in d['roofline_other']}

@@ -7,7 +7,7 @@ timeout 900 python -m pytest tests/test_gpu_gemm.py -x -q > $O/test_gemm_policy.
 DGX_GEMM_LW=1 timeout 900 python -m pytest tests/test_gpu_gemm.py -x -q > $O/test_gemm_lw1.txt 2>&1; echo "gemm tests LW=1 rc=$?"; tail -1 $O/test_gemm_lw1.txt
 timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_parity_modules.py tests/test_gpu_swinL_geometry.py -x -q > $O/test_modules.txt 2>&1; echo "module tests rc=$?"; tail -1 $O/test_modules.txt
 for r in 1 2; do for v in 0 2; do
-  DGX_GEMM_LW=$v timeout 600 python bench.py --steps 40 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "
+  timeout 600 python bench.py --dev gemm_lw=$v --steps 40 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "
 import sys,json
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 r=d['roofline']; o={x['family']:x for x in d['roofline_other']}

@@ -2,6 +2,10 @@
 the split-M 256x256 form (wgrad256.hip), timed with events over back-to-back launches; DGX_WGRAD_LW=0 forces the second.
 usage: python tools/wgrad_lw_probe.py [blocks ...]"""
 import os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _dev  # noqa: E402
+_dev.apply_env()       # DGX_GEMM_LW / DGX_GEMM_TILE / DGX_WGRAD_LW ... of the calling script -> dgx_dev_set
+
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from divergen_amd.layers.linear_ops import wgrad_grouped
 

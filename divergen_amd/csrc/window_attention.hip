@@ -9,6 +9,8 @@
 // the bias gradient accumulates in registers across the windows of a chunk); dS goes through LDS
 // once for dQ = dS K.
 #include "dgx_common.h"
+#include <type_traits>
+typedef float wa_f32x2 __attribute__((ext_vector_type(2)));
 
 template <int WS> struct WinCfg;
 template <> struct WinCfg<12> { static constexpr int N = 144, NT = 9, NTK = 10, RS = 168, TBL = 529; };
@@ -77,7 +79,10 @@ __global__ __launch_bounds__(WinCfg<WS>::NT * 64) void win_attn_fwd_kernel(
     uint16_t* __restrict__ out, float* __restrict__ lse, int B_, int nW, int nH, float scale, int64_t t_sh, int64_t t_si) {
     using Cf = WinCfg<WS>;
     constexpr int N = Cf::N, NT = Cf::NT, NTK = Cf::NTK, NP = NTK * 16, RS = Cf::RS, TBL = Cf::TBL;
-    constexpr int RR = 40;   // row stride (elements) of the row-major V image
+    // row stride (elements) of the row-major K / V images: 48 = 24 banks.  The 16-byte fragment reads (8 consecutive rows per pass, 4
+    // banks each) AND the transpose reads (4 consecutive rows x 8 banks per 16-lane pass) are both conflict-free at 24 banks; at the
+    // former 40 (20 banks) the fourth row of a transpose read wrapped onto the first (60 + 8 > 64): a 2-way conflict on every one
+    constexpr int RR = WS == 12 ? 48 : 40;
     __shared__ __attribute__((aligned(16))) uint16_t Vs[NP * RR];
     __shared__ __attribute__((aligned(16))) uint16_t Ks[NP * RR];   // K rows too: one coalesced load per workgroup instead of
                                                                     // nine per-wave passes over K with their global latencies
@@ -199,24 +204,42 @@ __device__ unsigned long long dgx_clk[16];
 #define CLK(i)
 #endif
 
+// value of lane (4 * (lane / 4) + R) of every quad: v_mov_b32_dpp quad_perm:[R,R,R,R] -- no LDS traffic (the backward kernel is
+// bound by the LDS pipe: profiles/r05_attn_bwd_*.txt)
+template <int R>
+__device__ __forceinline__ float quad_bcast(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), R * 0x55, 0xf, 0xf, true));
+}
+template <int R>
+__device__ __forceinline__ int quad_bcast(int v) { return __builtin_amdgcn_update_dpp(0, v, R * 0x55, 0xf, 0xf, true); }
+
 // One window's worth of global loads for one thread, held in registers while the previous window computes.
 struct BwdPrefetch {
     bf16x8 q, d, o, k;   // this thread's 16-byte chunk (row tid>>2, chunk tid&3) of Q, dO, O, K
-    bf16x8 v;            // phase-1 operand: V[key 16w + c16][8g .. 8g+7]
+    bf16x8 v;            // ... and of V (staged like K since round 5: the fragment a wave needs is read from the LDS image)
     float lse;           // chunk-0 threads: lse / region id of the row
     int reg;
 };
 
-template <int WS, bool MASKED>
-__global__ __launch_bounds__(WinCfg<WS>::NT * 64) void win_attn_bwd_kernel(
+// HELP (window 12 only): 12 waves instead of 9.  The hardware deals the waves of a workgroup round-robin over the four SIMDs, so with nine
+// strip waves SIMD 0 runs three of them (strips 0, 4, 8) and sets the pace of phase 1 (27 of the 81 query-tile steps against 18 on the
+// other SIMDs: the other waves waited ~1 800 of ~14 000 cycles per window at the barrier behind it, profiles/r03_attn_bwd_phases.txt).
+// Waves 9-11 land on SIMDs 1-3 and take the query tiles 6-8 of strips 0 / 4 / 8 (21 + 20 + 20 + 20 steps): they write their rows of the
+// dS^T image and their own bias-gradient terms like any strip wave and hand their partial dK / dV to the strip's owner through LDS.
+template <int WS, bool MASKED, bool HELP = false>
+__global__ __launch_bounds__((WinCfg<WS>::NT + (HELP ? 3 : 0)) * 64) void win_attn_bwd_kernel(
     const uint16_t* __restrict__ qkv, const float* __restrict__ table, const int8_t* __restrict__ region,
     const uint16_t* __restrict__ out, const float* __restrict__ lse, const uint16_t* __restrict__ dout,
     uint16_t* __restrict__ dqkv, float* __restrict__ dtable, int B_, int nW, int nH, float scale, int chunk,
     int64_t dt_sh, int64_t dt_si) {
     using Cf = WinCfg<WS>;
     constexpr int N = Cf::N, NT = Cf::NT, NTK = Cf::NTK, NP = NTK * 16, TBL = Cf::TBL;
-    constexpr int RR = 40;       // row stride (elements) of the row-major [NP][32] images
-    constexpr int RD = NP + 8;   // row stride of the dS^T image [key][query]; RD/2 dwords = 4*odd (mod 64)
+    // row strides (elements): the [NP][32] images 48 (24 banks: 16-byte fragment reads over 8 rows and transpose reads over 4 rows x 8
+    // banks both conflict-free; 40 = 20 banks put the fourth row of every transpose read onto the first), the dS^T image [key][query]
+    // 184 (92 = 28 mod 64 banks: the 8-byte writes of 16 key rows hit 16 distinct bank pairs AND the four rows of a transpose read
+    // 0 / 28 / 56 / 20 do not overlap; the former 168 = 20 mod 64 had the same wrap)
+    constexpr int RR = WS == 12 ? 48 : 40;
+    constexpr int RD = WS == 12 ? 184 : NP + 8;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint16_t* Qs = reinterpret_cast<uint16_t*>(smem);       // [NP][RR] row-major Q
     uint16_t* dOs = Qs + NP * RR;                            // [NP][RR] row-major dO
@@ -228,14 +251,29 @@ __global__ __launch_bounds__(WinCfg<WS>::NT * 64) void win_attn_bwd_kernel(
     int* reg_s = qoff_s + NP;                                // [NP] region id of query q (this window)
     float* tbl = reinterpret_cast<float*>(reg_s + NP);       // [TBL]
     float* tblacc = tbl + TBL;                               // [TBL]
+    float* part_s = tblacc + TBL + ((4 - (2 * TBL) % 4) % 4);    // HELP: [3 helpers][4 vectors][64 lanes] f32x4 partial dV / dK (16-B aligned)
+    // PK (window 12): per-query terms and bias rows in the form that costs the LDS pipe least.  The kernel is LDS-bound (~1 MB of LDS
+    // traffic per (window, head); 36 % of it the four 16-byte BROADCAST reads of lse / delta / bias offset / region per query tile, in
+    // which 16 lanes fetch the same 16 bytes):  * (lse, delta) interleaved, one 8-byte read per lane (its quad's query r = lane & 3),
+    // spread over the quad by DPP;  * the bias row: the four queries 4 j .. 4 j + 3 of a lane never straddle a window row (12 = 3 x 4),
+    // so their table entries are CONSECUTIVE -- four copies of the table shifted by 0..3 entries make that run a 16-byte ALIGNED read
+    // at a per-lane address that is constant for the whole kernel (9 registers) instead of an offset vector + four gathers
+    constexpr bool PK = WS == 12;
+    constexpr int TBLS = (TBL + 3 + 3) / 4 * 4;                   // stride (floats) of a shifted copy
+    float* tbl4 = part_s + (HELP ? 3 * 4 * 64 * 4 : 0);           // [4][TBLS]
+    uint16_t* Vs = reinterpret_cast<uint16_t*>(tbl4 + (PK ? 4 * TBLS : 0));     // [NP][RR] row-major V
 
     const int h = blockIdx.x % nH;
     const int b0 = (blockIdx.x / nH) * chunk;
     const int b1 = min(B_, b0 + chunk);
     const int C = nH * 32;
     const int64_t rowst = 3 * (int64_t)C;
-    const int tid = threadIdx.x, nthreads = NT * 64;
-    const int w = tid >> 6, l = tid & 63, g = l >> 4, c16 = l & 15;
+    const int tid = threadIdx.x, nthreads = (NT + (HELP ? 3 : 0)) * 64;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool helper = HELP && wv >= NT;      // waves 9..11: strips 0 / 4 / 8, query tiles 6..8
+    const int w = helper ? 4 * (wv - NT) : wv; // the key strip this wave works on
+    const bool shared = HELP && !helper && (w & 3) == 0;      // a strip owner that has a helper: query tiles 0..5 only
+    const int l = tid & 63, g = l >> 4, c16 = l & 15;
     const int srow = tid >> 2, sc = tid & 3;   // staging role: row, 16-byte chunk
     const bool stager = tid < N * 4;
     const int key = 16 * w + c16;              // this lane's key in phase 1
@@ -246,10 +284,13 @@ __global__ __launch_bounds__(WinCfg<WS>::NT * 64) void win_attn_bwd_kernel(
     DGX_LDS const uint16_t* k_l8 = tr_lane_ptr(Ks, RR, 8 * g, 0, c16);
     DGX_LDS const uint16_t* ds_l8 = tr_lane_ptr(dSt, RD, 8 * g, 16 * w, c16);
     DGX_LDS uint16_t* img_st = lds_opaque(Qs + srow * RR + 8 * sc);         // staging destinations
-    DGX_LDS float* meta_st = lds_opaque(lse_s + srow);                      // lse_s / delta_s / qoff_s / reg_s are NP apart
+    DGX_LDS uint16_t* v_st = lds_opaque(Vs + srow * RR + 8 * sc);
+    DGX_LDS float* meta_st = lds_opaque(lse_s + (PK ? 2 * srow : srow));    // lse_s / delta_s / qoff_s / reg_s are NP apart (PK: pairs)
     // phase-1 lane pointers (everything in the unrolled loop is one of these + a constant)
     DGX_LDS const uint16_t* q_row = lds_opaque(Qs + c16 * RR + 8 * g);      // A fragment of query tile qt: + 16*qt*RR
     DGX_LDS const uint16_t* do_row = q_row + NP * RR;
+    DGX_LDS const float* ld_lane = lds_opaque(lse_s + 2 * (4 * g + (c16 & 3)));   // PK: {-lse/scale, -delta} of query 16 qt + 4 g + (lane & 3): + 32 qt
+    DGX_LDS const int* reg_lane = lds_opaque(reg_s + 4 * g + (c16 & 3));          // PK: its region id: + 16 qt
     DGX_LDS const float* lse_g = lds_opaque(lse_s + 4 * g);                 // rows 16*qt + 4g .. +3; the four arrays are NP apart
     DGX_LDS const float* delta_g = lse_g + NP;
     DGX_LDS const int* qoff_g = reinterpret_cast<DGX_LDS const int*>(lse_g) + 2 * NP;
@@ -259,46 +300,63 @@ __global__ __launch_bounds__(WinCfg<WS>::NT * 64) void win_attn_bwd_kernel(
     // global addressing = uniform (SGPR) window base + one 32-bit lane offset per access pattern
     const uint32_t st_qk_c = (uint32_t)(srow * (int)rowst + 8 * sc);     // staging chunk inside this window's qkv rows
     const uint32_t st_o_c = (uint32_t)(srow * C + 8 * sc);               // ... inside out / dout rows
-    const uint32_t v_off_c = (uint32_t)((kok ? key : 0) * (int)rowst + 8 * g);
     const uint32_t row4_c = (uint32_t)((kok ? key : 0) * (int)rowst + 4 * g);   // output row = this lane's key / query, entries 4g ..
     auto issue = [&](int b, BwdPrefetch& P) {
         const uint16_t* base = qkv + (int64_t)b * N * rowst + h * 32;
         const uint16_t* dob = dout + (int64_t)b * N * C + h * 32;
         const uint16_t* ob = out + (int64_t)b * N * C + h * 32;
-        const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-        P.q = P.d = P.o = P.k = z;
-        P.lse = INFINITY;
-        P.reg = 0;
+        // (the registers of lanes that stage nothing are initialised ONCE in front of the loop: re-writing them here made the compiler
+        // order the writes behind every outstanding memory operation of the previous window -- its six stores included)
         // opaque copies: the 64-bit addresses are rebuilt per window (2 VALU each) instead of living in
         // ~20 registers across the whole loop
-        uint32_t st_qk = st_qk_c, st_o = st_o_c, v_off = v_off_c;
-        asm volatile("" : "+v"(st_qk), "+v"(st_o), "+v"(v_off));
+        uint32_t st_qk = st_qk_c, st_o = st_o_c;
+        asm volatile("" : "+v"(st_qk), "+v"(st_o));
         if (stager) {
             P.q = *reinterpret_cast<const bf16x8*>(base + st_qk);
             P.k = *reinterpret_cast<const bf16x8*>(base + C + st_qk);
+            P.v = *reinterpret_cast<const bf16x8*>(base + 2 * C + st_qk);
             P.d = *reinterpret_cast<const bf16x8*>(dob + st_o);
             P.o = *reinterpret_cast<const bf16x8*>(ob + st_o);
             P.lse = (lse + ((int64_t)b * nH + h) * N)[(uint32_t)srow];
             P.reg = (int)(region + (int64_t)(b % nW) * N)[(uint32_t)srow];
         }
-        P.v = *reinterpret_cast<const bf16x8*>(base + 2 * C + v_off);
-        if (!kok) P.v = z;
+        // (no select on the loaded value here: `if (!kok) P.v = z` made the compiler wait for EVERY load of this prefetch -- vmcnt(0)
+        // -- right behind their issue, at the top of phase 1: the whole memory latency of the next window's operands, ~half of the
+        // kernel's time, was exposed in front of the math it was meant to fly under (round 5, tools/r05_attn_variants.sh: removing
+        // the exponentials, the metadata reads, the transpose reads or the S / dP MFMAs changed the phase's duration by < 3 % each).
+        // Rows past the window (window 7 only) are zeroed where the fragment is consumed.)
     };
 
     // ---- one-time LDS setup: bias row, zero padding rows/columns, rel-pos offsets
     for (int i = tid; i < TBL; i += nthreads) { tbl[i] = table[h * dt_sh + i * dt_si] * DGX_LOG2E; tblacc[i] = 0.f; }   // log2 domain
-    for (int i = tid; i < (NP - N) * RR; i += nthreads) { Qs[N * RR + i] = 0; dOs[N * RR + i] = 0; Ks[N * RR + i] = 0; }
+    for (int i = tid; i < (NP - N) * RR; i += nthreads) { Qs[N * RR + i] = 0; dOs[N * RR + i] = 0; Ks[N * RR + i] = 0; Vs[N * RR + i] = 0; }
     for (int i = tid; i < (NP - N) * RD; i += nthreads) dSt[N * RD + i] = 0;   // padded key rows feed the last K=32 step of dQ
     for (int i = tid; i < NP; i += nthreads) {
         const int yq = i / WS;
         qoff_s[i] = i < N ? yq * (2 * WS - 1) + (i - yq * WS) : 0;
-        if (i >= N) { lse_s[i] = -INFINITY; delta_s[i] = 0.f; reg_s[i] = 0; }   // padded queries: p = 0
+        if (i >= N) {                                                           // padded queries: p = 0
+            if (PK) { lse_s[2 * i] = -INFINITY; lse_s[2 * i + 1] = 0.f; }
+            else { lse_s[i] = -INFINITY; delta_s[i] = 0.f; }
+            reg_s[i] = 0;
+        }
     }
+    if (PK)
+        for (int i = tid; i < 4 * TBLS; i += nthreads) {
+            const int sft = i / TBLS, j = i - sft * TBLS + sft;
+            tbl4[i] = j < TBL ? table[h * dt_sh + j * dt_si] * DGX_LOG2E : 0.f;
+        }
     const int yk = key / WS, xk = key - yk * WS;
     const int kbase = kok ? (WS - 1) * (2 * WS - 1) + (WS - 1) - (yk * (2 * WS - 1) + xk) : 0;
     const float kneg = kok ? 0.0f : -INFINITY;   // padded key columns: p = 0
     const float scale2 = scale * DGX_LOG2E, inv_scale = 1.0f / scale;
     DGX_LDS const float* tbl_k = lds_opaque(tbl + kbase);
+    DGX_LDS const float* bptr[NT];       // PK: this lane's bias run of query tile qt (queries 16 qt + 4 g .. + 3, key `key`)
+#pragma unroll
+    for (int qt = 0; qt < NT; ++qt) {
+        const int q0 = 16 * qt + 4 * g, y0 = q0 / WS;
+        const int idx0 = kbase + y0 * (2 * WS - 1) + (q0 - y0 * WS);
+        bptr[qt] = lds_opaque(tbl4 + (idx0 & 3) * TBLS + (idx0 & ~3));
+    }
     float dbias[NT][4];
 #pragma unroll
     for (int i = 0; i < NT; ++i)
@@ -306,6 +364,12 @@ __global__ __launch_bounds__(WinCfg<WS>::NT * 64) void win_attn_bwd_kernel(
         for (int r = 0; r < 4; ++r) dbias[i][r] = 0.f;
 
     BwdPrefetch P;
+    {
+        const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        P.q = P.d = P.o = P.k = P.v = z;
+        P.lse = INFINITY;
+        P.reg = 0;
+    }
     if (b0 < b1) issue(b0, P);
     for (int b = b0; b < b1; ++b) {
         __syncthreads();  // previous window's LDS consumers are done
@@ -316,6 +380,7 @@ __global__ __launch_bounds__(WinCfg<WS>::NT * 64) void win_attn_bwd_kernel(
             *reinterpret_cast<DGX_LDS bf16x8*>(img_st) = P.q;                   // Qs, dOs, Ks are NP*RR apart
             *reinterpret_cast<DGX_LDS bf16x8*>(img_st + NP * RR) = P.d;
             *reinterpret_cast<DGX_LDS bf16x8*>(img_st + 2 * NP * RR) = P.k;
+            *reinterpret_cast<DGX_LDS bf16x8*>(v_st) = P.v;
             float d = 0.f;
 #pragma unroll
             for (int i = 0; i < 8; ++i) d += bf2f((uint16_t)P.d[i]) * bf2f((uint16_t)P.o[i]);
@@ -323,9 +388,15 @@ __global__ __launch_bounds__(WinCfg<WS>::NT * 64) void win_attn_bwd_kernel(
             d += __shfl_xor(d, 2);
             // stored negated and pre-divided: they are the INITIAL accumulators of the two MFMAs of phase 1, so that
             // S*scale2 - lse2 and dP - delta cost no VALU instruction (lse_s = -lse/scale, delta_s = -delta)
-            if (sc == 0) { meta_st[NP] = -d; meta_st[0] = -P.lse * inv_scale; reinterpret_cast<DGX_LDS int*>(meta_st)[3 * NP] = P.reg; }
+            if (sc == 0) {
+                if (PK) {
+                    *reinterpret_cast<DGX_LDS wa_f32x2*>(meta_st) = wa_f32x2{-P.lse * inv_scale, -d};
+                    reinterpret_cast<DGX_LDS int*>(lds_opaque(reg_s + srow))[0] = P.reg;
+                } else {
+                    meta_st[NP] = -d; meta_st[0] = -P.lse * inv_scale; reinterpret_cast<DGX_LDS int*>(meta_st)[3 * NP] = P.reg;
+                }
+            }
         }
-        const bf16x8 vf = P.v;
         CLK(0);
         __syncthreads();
         CLK(1);
@@ -333,13 +404,18 @@ __global__ __launch_bounds__(WinCfg<WS>::NT * 64) void win_attn_bwd_kernel(
         if (b + 1 < b1) issue(b + 1, P);   // next window's loads fly under this window's math
 #endif
         const bf16x8 kf = *reinterpret_cast<const bf16x8*>(&Ks[(kok ? key : 0) * RR + 8 * g]);
+        const bf16x8 vf = *reinterpret_cast<const bf16x8*>(&Vs[(kok ? key : 0) * RR + 8 * g]);
         const int rk = MASKED ? reg_s[kok ? key : 0] : 0;
 
-        // ---- phase 1: this wave's 16 keys x all queries, two query tiles (one K=32 step) at a time
+        // ---- phase 1: this wave's 16 keys x its query tiles, two query tiles (one K=32 step) at a time
         f32x4 dV[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
         f32x4 dK[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        // ONE unrolled copy of the five steps (every register index below is static); a wave skips the steps of the other wave of its
+        // strip with a scalar branch: the owner of a shared strip runs steps 0..2, its helper steps 3..4
+        constexpr int TSPLIT = 3;
 #pragma unroll
         for (int t = 0; t < NTK / 2; ++t) {
+            if (HELP && (t < TSPLIT ? helper : shared)) continue;
             uint32_t ppk[2][2], dpk[2][2];
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
@@ -348,19 +424,43 @@ __global__ __launch_bounds__(WinCfg<WS>::NT * 64) void win_attn_bwd_kernel(
                 if (qt < NT) {
                     const bf16x8 qa = *reinterpret_cast<DGX_LDS const bf16x8*>(q_row + 16 * qt * RR);
                     const bf16x8 da = *reinterpret_cast<DGX_LDS const bf16x8*>(do_row + 16 * qt * RR);
-                    const f32x4 lv = *reinterpret_cast<DGX_LDS const f32x4*>(lse_g + 16 * qt);     // -lse[q] / scale
-                    const f32x4 dl = *reinterpret_cast<DGX_LDS const f32x4*>(delta_g + 16 * qt);   // -delta[q]
+                    f32x4 lv, dl, bv = {0.f, 0.f, 0.f, 0.f};
+                    i32x4 ov = {0, 0, 0, 0}, rv = {0, 0, 0, 0};
+#ifdef ABL_META
+                    if constexpr (PK) { lv = f32x4{scale2, scale2, inv_scale, 0.f}; dl = lv; bv = lv; }
+                    else
+#endif
+                    if constexpr (PK) {
+                        const wa_f32x2 ld = *reinterpret_cast<DGX_LDS const wa_f32x2*>(ld_lane + 32 * qt);
+                        lv = f32x4{quad_bcast<0>(ld.x), quad_bcast<1>(ld.x), quad_bcast<2>(ld.x), quad_bcast<3>(ld.x)};
+                        dl = f32x4{quad_bcast<0>(ld.y), quad_bcast<1>(ld.y), quad_bcast<2>(ld.y), quad_bcast<3>(ld.y)};
+                        bv = *reinterpret_cast<DGX_LDS const f32x4*>(bptr[qt]);
+                        if (MASKED) {
+                            const int rq1 = reg_lane[16 * qt];
+                            rv = i32x4{quad_bcast<0>(rq1), quad_bcast<1>(rq1), quad_bcast<2>(rq1), quad_bcast<3>(rq1)};
+                        }
+                    } else {
+                        lv = *reinterpret_cast<DGX_LDS const f32x4*>(lse_g + 16 * qt);     // -lse[q] / scale
+                        dl = *reinterpret_cast<DGX_LDS const f32x4*>(delta_g + 16 * qt);   // -delta[q]
+                        ov = *reinterpret_cast<DGX_LDS const i32x4*>(qoff_g + 16 * qt);
+                        if (MASKED) rv = *reinterpret_cast<DGX_LDS const i32x4*>(reg_g + 16 * qt);
+                    }
+#ifdef ABL_MFMA1
+                    const f32x4 s = lv + f32x4{bf2f(qa[0]), bf2f(qa[1]), bf2f(kf[0]), bf2f(kf[1])}, dp = dl + f32x4{bf2f(da[0]), bf2f(da[1]), bf2f(vf[0]), bf2f(vf[1])};
+#else
                     const f32x4 s = mfma16(qa, kf, lv);    // s[r]  = S[q 16qt+4g+r][key] - lse[q]/scale
                     const f32x4 dp = mfma16(da, vf, dl);   // dp[r] = dP[q][key] - delta[q]
-                    const i32x4 ov = *reinterpret_cast<DGX_LDS const i32x4*>(qoff_g + 16 * qt);
-                    i32x4 rv = {0, 0, 0, 0};
-                    if (MASKED) rv = *reinterpret_cast<DGX_LDS const i32x4*>(reg_g + 16 * qt);
+#endif
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        float sv = __builtin_fmaf(s[r], scale2, tbl_k[ov[r]]);       // log2 domain (bias row, lse pre-scaled)
+                        float sv = __builtin_fmaf(s[r], scale2, PK ? bv[r] : tbl_k[ov[r]]);       // log2 domain (bias row, lse pre-scaled)
                         if (N % 16 != 0) sv += kneg;
                         if (MASKED) sv += rv[r] != rk ? -100.0f * DGX_LOG2E : 0.0f;
+#ifdef ABL_EXP
+                        pv[r] = sv * 0.001f;
+#else
                         pv[r] = __builtin_amdgcn_exp2f(sv);
+#endif
                         dsv[r] = pv[r] * dp[r];
                         dbias[qt < NT ? qt : 0][r] += dsv[r];
                     }
@@ -370,8 +470,10 @@ __global__ __launch_bounds__(WinCfg<WS>::NT * 64) void win_attn_bwd_kernel(
                 dpk[hh][0] = pack_bf2(dsv[0], dsv[1]);
                 dpk[hh][1] = pack_bf2(dsv[2], dsv[3]);
                 // dS^T image row = key, 4 consecutive queries: one 8-byte store
+#ifndef ABL_DSWRITE
                 if (qt < NT)
                     *reinterpret_cast<DGX_LDS u32x2*>(ds_w + 16 * qt) = u32x2{dpk[hh][0], dpk[hh][1]};
+#endif
 #ifndef NO_HH_BARRIER
                 __builtin_amdgcn_sched_barrier(0);   // one query tile at a time: its 40-odd temporaries die before the next starts
 #endif
@@ -383,27 +485,46 @@ __global__ __launch_bounds__(WinCfg<WS>::NT * 64) void win_attn_bwd_kernel(
             // B operands = dO / Q rows {32t+4g+j, 32t+16+4g+j} (the k-slot order of P^T / dS^T), by transpose reads
             // swapped operands: D = (dO^T) (P) = dV^T, so a lane ends up with 4 CONSECUTIVE head-dim entries of ONE key
             // (8-byte stores; with P^T as the A operand it held one entry of 4 keys: 2-byte stores, 4 x 32-byte pieces each)
+#ifdef ABL_TR
+            dV[0] = mfma16(pf, pf, dV[0]); dV[1] = mfma16(df, pf, dV[1]); dK[0] = mfma16(pf, df, dK[0]); dK[1] = mfma16(df, df, dK[1]);
+#else
             dV[0] = mfma16(tr_frag(do_l4, 32 * t * RR, (32 * t + 16) * RR), pf, dV[0]);
             dV[1] = mfma16(tr_frag(do_l4, 32 * t * RR + 16, (32 * t + 16) * RR + 16), pf, dV[1]);
             dK[0] = mfma16(tr_frag(q_l4, 32 * t * RR, (32 * t + 16) * RR), df, dK[0]);
             dK[1] = mfma16(tr_frag(q_l4, 32 * t * RR + 16, (32 * t + 16) * RR + 16), df, dK[1]);
+#endif
+#ifndef NO_T_BARRIER
             __builtin_amdgcn_sched_barrier(0);   // keep the t-steps apart: shorter live ranges, no spills
+#endif
         }
         CLK(2);
         uint16_t* dqb = dqkv + (int64_t)b * N * rowst + h * 32;
         uint32_t row4 = row4_c;
         asm volatile("" : "+v"(row4));   // same: store addresses are per-window temporaries
-        if (kok) {                       // this lane: key 16w + c16, head-dim entries 16 dt + 4g .. + 3
+        auto store_dkdv = [&]() {
+            if (kok) {                   // this lane: key 16w + c16, head-dim entries 16 dt + 4g .. + 3
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt) {
-                *reinterpret_cast<u32x2*>(dqb + C + row4 + 16 * dt) =
-                    u32x2{pack_bf2(dK[dt][0] * scale, dK[dt][1] * scale), pack_bf2(dK[dt][2] * scale, dK[dt][3] * scale)};
-                *reinterpret_cast<u32x2*>(dqb + 2 * C + row4 + 16 * dt) = u32x2{pack_bf2(dV[dt][0], dV[dt][1]), pack_bf2(dV[dt][2], dV[dt][3])};
+                for (int dt = 0; dt < 2; ++dt) {
+                    *reinterpret_cast<u32x2*>(dqb + C + row4 + 16 * dt) =
+                        u32x2{pack_bf2(dK[dt][0] * scale, dK[dt][1] * scale), pack_bf2(dK[dt][2] * scale, dK[dt][3] * scale)};
+                    *reinterpret_cast<u32x2*>(dqb + 2 * C + row4 + 16 * dt) = u32x2{pack_bf2(dV[dt][0], dV[dt][1]), pack_bf2(dV[dt][2], dV[dt][3])};
+                }
             }
+        };
+        DGX_LDS f32x4* part_l = reinterpret_cast<DGX_LDS f32x4*>(lds_opaque(part_s + ((w >> 2) * 4 * 64 + l) * 4));   // + 64 f32x4 per vector
+        if (helper) {                    // partial dV / dK of query tiles 6..8 -> the strip's owner
+            part_l[0] = dV[0]; part_l[64] = dV[1]; part_l[128] = dK[0]; part_l[192] = dK[1];
+        } else if (!shared) {
+            store_dkdv();
         }
         CLK(3);
-        __syncthreads();  // dS^T image complete
+        __syncthreads();  // dS^T image (and the helpers' partial sums) complete
         CLK(4);
+        if (shared) {
+            dV[0] += part_l[0]; dV[1] += part_l[64]; dK[0] += part_l[128]; dK[1] += part_l[192];
+            store_dkdv();
+        }
+        if (helper) continue;            // phase 2 belongs to the nine query strips
 #if defined(PREFETCH_LATE)
         if (b + 1 < b1) issue(b + 1, P);   // next window's loads fly under phase 2 (phase 1 has no registers to spare)
 #endif
@@ -425,26 +546,30 @@ __global__ __launch_bounds__(WinCfg<WS>::NT * 64) void win_attn_bwd_kernel(
         CLK(6);
     }
     // ---- relative-position-bias gradient: registers -> LDS table (ds_add_f32) -> global atomics
+    constexpr int TSPLIT_Q = 3;      // = TSPLIT of the window loop
     int kb = kbase;
     asm volatile("" : "+v"(kb));   // opaque: keeps the 36 scatter addresses from being hoisted above the window loop
     if (kok) {
 #pragma unroll
-        for (int qt = 0; qt < NT; ++qt)
+        for (int qt = 0; qt < NT; ++qt) {
+            if (HELP && (qt < 2 * TSPLIT_Q ? helper : shared)) continue;      // the other wave of the strip holds these terms
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int q = 16 * qt + 4 * g + r;
                 if (q < N) atomicAdd(&tblacc[kb + qoff_s[q]], dbias[qt][r]);
             }
+        }
     }
     __syncthreads();
     for (int i = tid; i < TBL; i += nthreads) atomicAdd(&dtable[h * dt_sh + i * dt_si], tblacc[i]);
 }
 
 template <int WS>
-static size_t bwd_smem_bytes() {
+static size_t bwd_smem_bytes(bool help = false) {
     using Cf = WinCfg<WS>;
     constexpr int NP = Cf::NTK * 16;
-    return (size_t)(3 * NP * 40 + NP * (NP + 8)) * 2 + (size_t)(4 * NP + 2 * Cf::TBL) * 4 + 64;
+    return (size_t)(3 * NP * (WS == 12 ? 48 : 40) + NP * (WS == 12 ? 184 : NP + 8)) * 2 + (size_t)(4 * NP + 2 * Cf::TBL) * 4 + 64 + (help ? 16 + 3 * 4 * 64 * 16 : 0) +
+           (WS == 12 ? 16 + 4 * ((Cf::TBL + 6) / 4 * 4) * 4 : 0) + (size_t)NP * (WS == 12 ? 48 : 40) * 2;
 }
 
 // NULL region (W-MSA) is served by a process-lifetime all-zero row: one code path in the kernels
@@ -505,14 +630,14 @@ extern "C" int dgx_window_attention_bwd(const void* qkv, const float* table, con
                  scale, chunk, dtable_stride_head, dtable_stride_index
     if (ws == 12) {
         static bool once = false;
-        const size_t sm = bwd_smem_bytes<12>();
+        const size_t sm = bwd_smem_bytes<12>(true);
         if (!once) {
-            (void)hipFuncSetAttribute((const void*)win_attn_bwd_kernel<12, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-            (void)hipFuncSetAttribute((const void*)win_attn_bwd_kernel<12, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+            (void)hipFuncSetAttribute((const void*)win_attn_bwd_kernel<12, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+            (void)hipFuncSetAttribute((const void*)win_attn_bwd_kernel<12, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
             once = true;
         }
-        if (masked) hipLaunchKernelGGL((win_attn_bwd_kernel<12, true>), dim3(grid), dim3(WinCfg<12>::NT * 64), sm, st, BWD_ARGS);
-        else hipLaunchKernelGGL((win_attn_bwd_kernel<12, false>), dim3(grid), dim3(WinCfg<12>::NT * 64), sm, st, BWD_ARGS);
+        if (masked) hipLaunchKernelGGL((win_attn_bwd_kernel<12, true, true>), dim3(grid), dim3((WinCfg<12>::NT + 3) * 64), sm, st, BWD_ARGS);
+        else hipLaunchKernelGGL((win_attn_bwd_kernel<12, false, true>), dim3(grid), dim3((WinCfg<12>::NT + 3) * 64), sm, st, BWD_ARGS);
     } else if (ws == 7) {
         const size_t sm = bwd_smem_bytes<7>();
         if (masked) hipLaunchKernelGGL((win_attn_bwd_kernel<7, true>), dim3(grid), dim3(WinCfg<7>::NT * 64), sm, st, BWD_ARGS);

@@ -540,6 +540,12 @@ def main():
              "graph_replayed": {"launches_per_step": st["graph_launches"] / nsamp, "flops_per_step": st["graph_flops"] / nsamp,
                                 "bytes_per_step": st["graph_bytes"] / nsamp},
              "flops_per_step": (st["flops"] + st["graph_flops"]) / nsamp}
+        if not mfma:
+            # the attention kernels are bound by neither roof: the backward's time is VALU / LDS issue per (window, head) (softmax terms at
+            # head_dim 32: ~10 VALU instructions per score against 128 MFMA FLOP; measured by ablation, tools/r05_attn_variants.sh), so the
+            # distance to BOTH roofs is reported
+            o["mfma_frac"] = tf / 2500.0
+            o["limited_by"] = "VALU / LDS issue per score (head_dim 32), not HBM or MFMA: see DESIGN.md section 8, round 5"
         pc = prof_csv.get(fam)
         if pc and pc["family_ms_per_step"] > 0:
             pc = dict(pc)

@@ -45,7 +45,7 @@ template <int BM, int BN, int NSA_, int NSB_> struct LwCfg {
     static constexpr int RING = STG0 + SA;
     static_assert(RING <= LW_LDS, "rings do not fit");
     static constexpr int SROW = BN * 2 + 16;      // staging row stride (bytes)
-    static constexpr int TOK0 = LW_LDS - BM * 8;  // mode 3: (token << 12 | sample) per tile row
+    static constexpr int TOK0 = LW_LDS - BM * 8;  // mode 3: (token << 32 | DropPath factor bits) per tile row
     static constexpr int STGB = TOK0 - STG0;
     static constexpr int HALF = BM / 2;           // rows per MFMA group
     // a slab = HC rows of EACH group (so that every MFMA wave hands over the same share of its accumulators per pass): the largest
@@ -339,7 +339,11 @@ __global__ __launch_bounds__(LW_THREADS) void gemm_lw_kernel(GemmP P0) {
                 int b = 0;
                 const int64_t orow = (int64_t)m0 + tid;
                 const int64_t tok = orow < P.M ? g_row_token(P.map, orow, b) : -1;
-                rowtok[tid] = tok < 0 ? -1 : ((tok << 12) | (int64_t)b);
+                // (token, DropPath factor of its sample): the factor is fetched HERE, once per tile row -- as a load inside `locate` it sat in
+                // front of every chunk's store behind an s_waitcnt vmcnt(0) that also waited for the prefetched operands of the next slab and
+                // for the stores before it (round 5, tools/isa_wait_scan.py)
+                const float scv = (tok >= 0 && P.scale) ? P.scale[b] : 1.0f;
+                rowtok[tid] = tok < 0 ? -1 : ((tok << 32) | (int64_t)__float_as_uint(scv));
             }
             lw_lgkm0();
             g_bar();
@@ -361,8 +365,8 @@ __global__ __launch_bounds__(LW_THREADS) void gemm_lw_kernel(GemmP P0) {
             if (P.mode == 3 && ok) {
                 const int64_t rt = rowtok[tile_row(p, row)];
                 ok = rt >= 0;
-                tok = rt >> 12;
-                if (ok && P.scale) sc = P.scale[(int)(rt & 4095)];
+                tok = rt >> 32;
+                sc = __uint_as_float((uint32_t)rt);
             }
             return ok;
         };
@@ -382,7 +386,7 @@ __global__ __launch_bounds__(LW_THREADS) void gemm_lw_kernel(GemmP P0) {
                     for (int k = 0; k < ITERS; ++k) {
                         const int idx = tid_e + k * LW_MFMA_THREADS, row = idx / CPR, gm = m0 + tile_row(p, row), gn = n0 + 8 * (idx - row * CPR);
                         const int64_t rt = idx < NCH ? rowtok[tile_row(p, row)] : -1;
-                        const int64_t off = (gm < P.M && gn < P.N && rt >= 0) ? (rt >> 12) * P.N + gn : 0;
+                        const int64_t off = (gm < P.M && gn < P.N && rt >= 0) ? (rt >> 32) * P.N + gn : 0;
                         xa[p % XD][k] = *reinterpret_cast<const u32x4*>((const uint16_t*)P.res + off);
                     }
                 } else {
@@ -398,7 +402,7 @@ __global__ __launch_bounds__(LW_THREADS) void gemm_lw_kernel(GemmP P0) {
                 for (int k = 0; k < ITERS; ++k) {
                     const int idx = tid_e + k * LW_MFMA_THREADS, row = idx / CPR, gm = m0 + tile_row(p, row), gn = n0 + 8 * (idx - row * CPR);
                     const int64_t rt = idx < NCH ? rowtok[tile_row(p, row)] : -1;
-                    const int64_t off = (gm < P.M && gn < P.N && rt >= 0) ? (rt >> 12) * P.N + gn : 0;
+                    const int64_t off = (gm < P.M && gn < P.N && rt >= 0) ? (rt >> 32) * P.N + gn : 0;
                     xa[p & 1][k] = reinterpret_cast<const u32x4*>((const float*)P.res + off)[0];
                     xb[p & 1][k] = reinterpret_cast<const u32x4*>((const float*)P.res + off)[1];
                 }

@@ -263,7 +263,7 @@ __global__ __launch_bounds__(512, MINW) void gemm_nt_kernel(GemmP P) {
     // for the WHOLE tile before the accumulators are staged (ITERS 16-byte loads per lane in flight, hidden behind the staging
     // pass and its barrier); round 2 fetched them in batches of four behind the barrier and the read-out waited on each batch.
     DGX_LDS unsigned char* stg = (DGX_LDS unsigned char*)lds_raw;
-    DGX_LDS int64_t* rowtok = reinterpret_cast<DGX_LDS int64_t*>(stg + BM * SROW);   // mode 3: (token << 12 | sample) per tile row
+    DGX_LDS int64_t* rowtok = reinterpret_cast<DGX_LDS int64_t*>(stg + BM * SROW);   // mode 3: (token << 32 | DropPath factor bits) per tile row
     constexpr int CPR = BN / 8;                    // 16-byte chunks per tile row
     constexpr int ITERS = (BM * CPR + 511) / 512;
     if (P.mode == 3) {
@@ -271,7 +271,11 @@ __global__ __launch_bounds__(512, MINW) void gemm_nt_kernel(GemmP P) {
             int b = 0;
             const int64_t orow = (int64_t)m0 + tid;
             const int64_t tok = orow < P.M ? g_row_token(P.map, orow, b) : -1;
-            rowtok[tid] = tok < 0 ? -1 : ((tok << 12) | (int64_t)b);
+            // (token, DropPath factor of its sample): the factor is fetched HERE, once per tile row -- as a load inside `locate` it sat in
+            // front of every chunk's store behind an s_waitcnt vmcnt(0) that also waited for the prefetched operands of the next slab and
+            // for the stores before it (round 5, tools/isa_wait_scan.py)
+            const float scv = (tok >= 0 && P.scale) ? P.scale[b] : 1.0f;
+            rowtok[tid] = tok < 0 ? -1 : ((tok << 32) | (int64_t)__float_as_uint(scv));
         }
         __syncthreads();
     }
@@ -295,8 +299,8 @@ __global__ __launch_bounds__(512, MINW) void gemm_nt_kernel(GemmP P) {
         if (P.mode == 3 && ok) {
             const int64_t rt = rowtok[row];
             ok = rt >= 0;
-            tok = rt >> 12;
-            if (ok && P.scale) sc = P.scale[(int)(rt & 4095)];
+            tok = rt >> 32;
+            sc = __uint_as_float((uint32_t)rt);
         }
         return ok;
     };
@@ -315,14 +319,14 @@ __global__ __launch_bounds__(512, MINW) void gemm_nt_kernel(GemmP P) {
             _Pragma("unroll") for (int it = 0; it < PFN; ++it) {                                                                  \
                 const int idx = tid_e + ((IT0) + it) * 512, row = idx / CPR, gm = m0 + row, gn = n0 + 8 * (idx - row * CPR);      \
                 const int64_t rt = rowtok[row];                                                                                   \
-                const int64_t off = (gm < P.M && gn < P.N && rt >= 0) ? (rt >> 12) * P.N + gn : 0;                                \
+                const int64_t off = (gm < P.M && gn < P.N && rt >= 0) ? (rt >> 32) * P.N + gn : 0;                                \
                 xa[it] = *reinterpret_cast<const u32x4*>((const uint16_t*)P.res + off);                                           \
             }                                                                                                                     \
         } else {                                                                                                                  \
             _Pragma("unroll") for (int it = 0; it < PFN; ++it) {                                                                  \
                 const int idx = tid_e + ((IT0) + it) * 512, row = idx / CPR, gm = m0 + row, gn = n0 + 8 * (idx - row * CPR);      \
                 const int64_t rt = rowtok[row];                                                                                   \
-                const int64_t off = (gm < P.M && gn < P.N && rt >= 0) ? (rt >> 12) * P.N + gn : 0;                                \
+                const int64_t off = (gm < P.M && gn < P.N && rt >= 0) ? (rt >> 32) * P.N + gn : 0;                                \
                 xa[it] = reinterpret_cast<const u32x4*>((const float*)P.res + off)[0];                                            \
                 xb[it] = reinterpret_cast<const u32x4*>((const float*)P.res + off)[1];                                            \
             }                                                                                                                     \

@@ -26,6 +26,34 @@ __device__ __forceinline__ int64_t win_src(const WinMap& m, int64_t orow) {
     return ((int64_t)b * m.H + hh) * m.W + ww;
 }
 
+// the same map in 32-bit arithmetic (every row / token count on the path is far below 2^31; the launchers check it): the 64-bit
+// divisions of win_src / win_dst are software sequences of ~150 VALU instructions each -- a large share of a kernel that handles two
+// to four rows per wave
+__device__ __forceinline__ int win_src32(const WinMap& m, int orow) {
+    const int N = m.ws * m.ws;
+    const int t0 = orow / N, n = orow - t0 * N;
+    const int t1 = t0 / m.nWw, wc = t0 - t1 * m.nWw;
+    const int b = t1 / m.nWh, wr = t1 - b * m.nWh;
+    const int nr = n / m.ws;
+    int hh = wr * m.ws + nr + m.shift, ww = wc * m.ws + (n - nr * m.ws) + m.shift;
+    const int Hp = m.nWh * m.ws, Wp = m.nWw * m.ws;
+    if (hh >= Hp) hh -= Hp;
+    if (ww >= Wp) ww -= Wp;
+    if (hh >= m.H || ww >= m.W) return -1;
+    return (b * m.H + hh) * m.W + ww;
+}
+__device__ __forceinline__ int win_dst32(const WinMap& m, int tok) {
+    const int t = tok / m.W, ww0 = tok - t * m.W;
+    const int b = t / m.H, hh0 = t - b * m.H;
+    const int Hp = m.nWh * m.ws, Wp = m.nWw * m.ws;
+    int hs = hh0 - m.shift, wsx = ww0 - m.shift;
+    if (hs < 0) hs += Hp;
+    if (wsx < 0) wsx += Wp;
+    const int wr = hs / m.ws, wc = wsx / m.ws;
+    const int n = (hs - wr * m.ws) * m.ws + (wsx - wc * m.ws);
+    return ((b * m.nWh + wr) * m.nWw + wc) * (m.ws * m.ws) + n;
+}
+
 // source token -> its row in window order
 __device__ __forceinline__ int64_t win_dst(const WinMap& m, int64_t tok) {
     const int ww0 = (int)(tok % m.W);
@@ -98,41 +126,65 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const XT* __restrict__ x, c
     const int64_t nwaves = (int64_t)gridDim.x * 4;
     const float4* g4 = reinterpret_cast<const float4*>(gamma);
     const float4* b4 = reinterpret_cast<const float4*>(beta);
-    if (NJ > 0) {
-        // two rows per trip: both rows' loads are in flight before the first row's reductions (one wave = 1-3 rows of a Swin
-        // stage: the kernel is one memory latency long, not one per row); the arithmetic per row is unchanged
-        for (int64_t orow0 = wave; orow0 < T_out; orow0 += 2 * nwaves) {
-            float4 v[2][NJ > 0 ? NJ : 1];
-            int64_t toks[2], orows[2] = {orow0, orow0 + nwaves};
+    if constexpr (NJ > 0) {
+        // Two rows per trip, EVERY load of the trip in flight before anything is consumed: the rows as raw bits (no conversion, no
+        // select next to the load: round 5 found each `i < C/4 ? ld4(...) : 0` compiled to load + s_waitcnt vmcnt(0) in its own
+        // predicated block -- six memory latencies in series per trip on a kernel that should be ONE latency long), gamma and beta
+        // with them; out-of-row lanes read the row's last quad (clamped index) and are masked where the value is used.
+        const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        const int wave32 = (int)blockIdx.x * 4 + wv, nwaves32 = (int)gridDim.x * 4, T32 = (int)T_out, nq = C / 4;
+        constexpr int NJ1 = NJ > 0 ? NJ : 1;
+        float4 gv[NJ1], bv[NJ1];
+        bool in[NJ1];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int i = lane + 64 * j;
+            in[j] = i < nq;
+            gv[j] = g4[in[j] ? i : nq - 1];
+            bv[j] = b4[in[j] ? i : nq - 1];
+        }
+        for (int orow0 = wave32; orow0 < T32; orow0 += 2 * nwaves32) {
+            typename Raw4<XT>::type raw[2][NJ1];
+            int toks[2];
+            const int orows[2] = {orow0, orow0 + nwaves32};
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                toks[u] = orows[u] < T_out ? (m.ws ? win_src(m, orows[u]) : orows[u]) : -2;      // -1: padding row, -2: no row
-                if (toks[u] >= 0) {
-                    const XT* xr = x + toks[u] * C;
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j) {
-                        const int i = lane + 64 * j;
-                        v[u][j] = i < C / 4 ? ld4<XT>(xr, i) : make_float4(0.f, 0.f, 0.f, 0.f);
-                    }
-                }
+                toks[u] = orows[u] < T32 ? (m.ws ? win_src32(m, orows[u]) : orows[u]) : -2;      // -1: padding row, -2: no row
+                toks[u] = __builtin_amdgcn_readfirstlane(toks[u]);
             }
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) raw[u][j] = Raw4<XT>::zero();
+                if (toks[u] >= 0) {
+                    const XT* xr = x + (int64_t)toks[u] * C;
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) raw[u][j] = Raw4<XT>::ld(xr, in[j] ? lane + 64 * j : nq - 1);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);      // the loads stay together, in front of every use
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
                 if (toks[u] == -2) continue;
-                YT* yo = y + orows[u] * C;
+                YT* yo = y + (int64_t)orows[u] * C;
                 if (toks[u] < 0) {
-                    for (int i = lane; i < C / 4; i += 64) st4<YT>(yo, i, make_float4(0.f, 0.f, 0.f, 0.f));
+                    for (int i = lane; i < nq; i += 64) st4<YT>(yo, i, make_float4(0.f, 0.f, 0.f, 0.f));
                     continue;
                 }
+                float4 v[NJ1];
                 float s = 0.f;
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) s += (v[u][j].x + v[u][j].y) + (v[u][j].z + v[u][j].w);
+                for (int j = 0; j < NJ; ++j) {
+                    v[j] = Raw4<XT>::f(raw[u][j]);
+                    if (!in[j]) v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+                }
                 const float mu = wave_sum(s) / (float)C;
                 float q = 0.f;
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
-                    if (lane + 64 * j < C / 4) {
-                        const float a = v[u][j].x - mu, b = v[u][j].y - mu, c = v[u][j].z - mu, d = v[u][j].w - mu;
+                    if (in[j]) {
+                        const float a = v[j].x - mu, b = v[j].y - mu, c = v[j].z - mu, d = v[j].w - mu;
                         q += (a * a + b * b) + (c * c + d * d);
                     }
                 const float rs = rsqrtf(wave_sum(q) / (float)C + eps);
@@ -140,10 +192,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const XT* __restrict__ x, c
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
                     const int i = lane + 64 * j;
-                    if (i < C / 4) {
-                        const float4 g = g4[i], b = b4[i];
-                        st4<YT>(yo, i, make_float4((v[u][j].x - mu) * rs * g.x + b.x, (v[u][j].y - mu) * rs * g.y + b.y,
-                                                   (v[u][j].z - mu) * rs * g.z + b.z, (v[u][j].w - mu) * rs * g.w + b.w));
+                    if (in[j]) {
+                        const float4 g = gv[j], b = bv[j];
+                        st4<YT>(yo, i, make_float4((v[j].x - mu) * rs * g.x + b.x, (v[j].y - mu) * rs * g.y + b.y,
+                                                   (v[j].z - mu) * rs * g.z + b.z, (v[j].w - mu) * rs * g.w + b.w));
                     }
                 }
             }
@@ -202,43 +254,56 @@ __global__ __launch_bounds__(64 * LNB_WAVES, ((NJ <= 2 || (NJ == 3 && sizeof(XT)
     const float4* g4 = reinterpret_cast<const float4*>(gamma);
     // two rows per trip: both rows' loads are in flight before the first row's reductions (T / waves = 2 rows per wave at
     // Swin-L stage 2: one memory latency per launch instead of two on a 16 us kernel)
-    for (int64_t tok0 = wave; tok0 < T; tok0 += 2 * nwaves) {
-        // The two rows stay in registers AS LOADED (packed: 6 registers per bf16 quad for x, dy and the residual-branch gradient,
-        // requested together: one memory latency per trip); x_hat and dy * gamma are formed twice, for the sums and for the
-        // result, by the same operations.  (Holding them as fp32 took 158-169 registers: one 8-wave workgroup per CU and two
-        // rounds of the chip for the 512 workgroups of a stage-2 launch -- 15 -> 21 us; this form stays under 128.)
+    // Row / token indices are wave-uniform and far below 2^31: 32-bit scalar arithmetic (the 64-bit divisions of the window map were
+    // ~150 VALU instructions per row and map).
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wave32 = (int)blockIdx.x * LNB_WAVES + wv, nwaves32 = (int)gridDim.x * LNB_WAVES, T32 = (int)T, nq = C / 4;
+    bool in[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) in[j] = lane + 64 * j < nq;
+    for (int tok0 = wave32; tok0 < T32; tok0 += 2 * nwaves32) {
+        // The two rows stay in registers AS LOADED (packed: 6 registers per bf16 quad for x, dy and the residual-branch gradient).
+        // EVERY load of the trip -- both rows' statistics, their 3 x NJ quads each, gamma -- is issued before anything is consumed
+        // (round 5: the compiler had waited for row 0 before requesting row 1 and re-requested gamma in front of each use: ~8 exposed
+        // L2 / HBM latencies per trip on a kernel that is one trip long).  x_hat and dy * gamma are formed twice, for the sums and for
+        // the result, by the same operations.
         typename Raw4<XT>::type xr_[2][NJ], rr_[2][NJ];
         typename Raw4<DT>::type dr_[2][NJ];
+        float4 gq[NJ];
         float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f}, rsv[2] = {0.f, 0.f}, muv[2] = {0.f, 0.f};
-        int64_t toks[2] = {tok0, tok0 + nwaves};
+        const int toks[2] = {tok0, tok0 + nwaves32};
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const int64_t tok = toks[u];
-            if (tok >= T) continue;
-            const int64_t drow = m.ws ? win_dst(m, tok) : tok;
-            const DT* dyr = dy + drow * C;
-            const XT* xr = x + tok * C;
-            const XT* drr0 = dres ? dres + tok * C : nullptr;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) { xr_[u][j] = Raw4<XT>::zero(); dr_[u][j] = Raw4<DT>::zero(); rr_[u][j] = Raw4<XT>::zero(); }
+            const int tok = toks[u];
+            if (tok >= T32) continue;
+            const int drow = __builtin_amdgcn_readfirstlane(m.ws ? win_dst32(m, tok) : tok);
+            const DT* dyr = dy + (int64_t)drow * C;
+            const XT* xr = x + (int64_t)tok * C;
+            const XT* drr0 = dres ? dres + (int64_t)tok * C : nullptr;
             muv[u] = mean[tok];
             rsv[u] = rstd[tok];
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                const int i = lane + 64 * j;
-                const bool in = i < C / 4;
-                xr_[u][j] = in ? Raw4<XT>::ld(xr, i) : Raw4<XT>::zero();
-                dr_[u][j] = in ? Raw4<DT>::ld(dyr, i) : Raw4<DT>::zero();
-                rr_[u][j] = (in && drr0) ? Raw4<XT>::ld(drr0, i) : Raw4<XT>::zero();
+                const int i = in[j] ? lane + 64 * j : nq - 1;        // out-of-row lanes re-read the last quad and are masked at the uses
+                xr_[u][j] = Raw4<XT>::ld(xr, i);
+                dr_[u][j] = Raw4<DT>::ld(dyr, i);
+                if (drr0) rr_[u][j] = Raw4<XT>::ld(drr0, i);
             }
         }
+        __builtin_amdgcn_sched_barrier(0);      // (gamma behind the rows: an L2 hit, it lands first anyway)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) gq[j] = g4[in[j] ? lane + 64 * j : nq - 1];
+        __builtin_amdgcn_sched_barrier(0);      // the loads stay together, in front of every use
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            if (toks[u] >= T) continue;
+            if (toks[u] >= T32) continue;
             const float mu = muv[u], rs = rsv[u];
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                const int i = lane + 64 * j;
-                if (i < C / 4) {
-                    const float4 v = Raw4<XT>::f(xr_[u][j]), g = g4[i], d4 = Raw4<DT>::f(dr_[u][j]);
+                if (in[j]) {
+                    const float4 v = Raw4<XT>::f(xr_[u][j]), g = gq[j], d4 = Raw4<DT>::f(dr_[u][j]);
                     const float dv[4] = {d4.x, d4.y, d4.z, d4.w};
                     const float xv[4] = {v.x, v.y, v.z, v.w}, gg[4] = {g.x, g.y, g.z, g.w};
 #pragma unroll
@@ -254,21 +319,21 @@ __global__ __launch_bounds__(64 * LNB_WAVES, ((NJ <= 2 || (NJ == 3 && sizeof(XT)
         }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const int64_t tok = toks[u];
-            if (tok >= T) continue;
+            const int tok = toks[u];
+            if (tok >= T32) continue;
             const float a1 = wave_sum(s1[u]) / (float)C, a2 = wave_sum(s2[u]) / (float)C, rs = rsv[u], mu = muv[u];
-            XT* dxr = dx + tok * C;
+            XT* dxr = dx + (int64_t)tok * C;
             uint16_t* er = nullptr;
             float es = 1.0f;
             if (EMIT) {
-                er = emit + (em.ws ? win_dst(em, tok) : tok) * C;
-                if (escale) es = escale[(int)(tok / ((int64_t)em.H * em.W))];
+                er = emit + (int64_t)__builtin_amdgcn_readfirstlane(em.ws ? win_dst32(em, tok) : tok) * C;
+                if (escale) es = escale[tok / (em.H * em.W)];
             }
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 const int i = lane + 64 * j;
-                if (i < C / 4) {
-                    const float4 v = Raw4<XT>::f(xr_[u][j]), g = g4[i], d4 = Raw4<DT>::f(dr_[u][j]);
+                if (in[j]) {
+                    const float4 v = Raw4<XT>::f(xr_[u][j]), g = gq[j], d4 = Raw4<DT>::f(dr_[u][j]);
                     const float dv[4] = {d4.x, d4.y, d4.z, d4.w};
                     const float xv[4] = {v.x, v.y, v.z, v.w}, gg[4] = {g.x, g.y, g.z, g.w};
                     float ov[4];

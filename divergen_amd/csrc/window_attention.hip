@@ -371,11 +371,11 @@ __global__ __launch_bounds__((WinCfg<WS>::NT + (HELP ? 3 : 0)) * 64) void win_at
         P.reg = 0;
     }
     if (b0 < b1) issue(b0, P);
-    for (int b = b0; b < b1; ++b) {
-        __syncthreads();  // previous window's LDS consumers are done
-#ifdef DIAG_CLOCK
-        unsigned long long tprev = clock64();
-#endif
+    // The window loop is ROTATED: staging of window b + 1 closes iteration b.  With the staging at the top, the compiler's wait-count
+    // model merged the pre-loop path (prefetch in flight, nothing behind it) into the loop header and waited `vmcnt(3..0)` there -- in
+    // steady state that is "all loads AND the previous window's six dQ / dK / dV stores complete": the stores' latency was exposed in
+    // front of every staging.  Here the wait sits behind a unique path (7 loads, then 6 stores) and only covers the loads.
+    auto stage = [&]() {
         if (stager) {
             *reinterpret_cast<DGX_LDS bf16x8*>(img_st) = P.q;                   // Qs, dOs, Ks are NP*RR apart
             *reinterpret_cast<DGX_LDS bf16x8*>(img_st + NP * RR) = P.d;
@@ -397,6 +397,12 @@ __global__ __launch_bounds__((WinCfg<WS>::NT + (HELP ? 3 : 0)) * 64) void win_at
                 }
             }
         }
+    };
+    if (b0 < b1) stage();
+    for (int b = b0; b < b1; ++b) {
+#ifdef DIAG_CLOCK
+        unsigned long long tprev = clock64();
+#endif
         CLK(0);
         __syncthreads();
         CLK(1);
@@ -524,7 +530,8 @@ __global__ __launch_bounds__((WinCfg<WS>::NT + (HELP ? 3 : 0)) * 64) void win_at
             dV[0] += part_l[0]; dV[1] += part_l[64]; dK[0] += part_l[128]; dK[1] += part_l[192];
             store_dkdv();
         }
-        if (helper) continue;            // phase 2 belongs to the nine query strips
+        u32x2 dqpk[2] = {{0u, 0u}, {0u, 0u}};
+        if (!helper) {                   // phase 2 belongs to the nine query strips
 #if defined(PREFETCH_LATE)
         if (b + 1 < b1) issue(b + 1, P);   // next window's loads fly under phase 2 (phase 1 has no registers to spare)
 #endif
@@ -537,13 +544,20 @@ __global__ __launch_bounds__((WinCfg<WS>::NT + (HELP ? 3 : 0)) * 64) void win_at
             dQ[1] = mfma16(tr_frag(k_l8, 32 * t * RR + 16, (32 * t + 4) * RR + 16), sa, dQ[1]);
         }
         CLK(5);
-        if (kok) {                       // query 16w + c16
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
-                *reinterpret_cast<u32x2*>(dqb + row4 + 16 * dt) =
-                    u32x2{pack_bf2(dQ[dt][0] * scale, dQ[dt][1] * scale), pack_bf2(dQ[dt][2] * scale, dQ[dt][3] * scale)};
-        }
+        for (int dt = 0; dt < 2; ++dt)
+            dqpk[dt] = u32x2{pack_bf2(dQ[dt][0] * scale, dQ[dt][1] * scale), pack_bf2(dQ[dt][2] * scale, dQ[dt][3] * scale)};
         CLK(6);
+        }
+        __syncthreads();                 // this window's LDS consumers are done
+        if (b + 1 < b1) stage();
+        // the dQ rows leave BEHIND the staging of the next window: the staging waits for its prefetch with vmcnt counts that also
+        // cover every store issued before it (one in-order counter), and stores issued a few cycles earlier would put their whole
+        // latency in front of it; the dK / dV stores are a phase 2 old by then
+        if (!helper && kok) {            // query 16w + c16
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) *reinterpret_cast<u32x2*>(dqb + row4 + 16 * dt) = dqpk[dt];
+        }
     }
     // ---- relative-position-bias gradient: registers -> LDS table (ds_add_f32) -> global atomics
     constexpr int TSPLIT_Q = 3;      // = TSPLIT of the window loop

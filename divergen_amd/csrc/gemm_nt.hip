@@ -39,8 +39,15 @@ template <int BM, int BN, int NS_> struct GemmCfg {
 }  // namespace
 
 // DIAG (development builds only, -DDGX_GEMM_DEV): ablation bits -- 1 no steady-state loads, 2 no MFMAs, 4 no fragment reads
-template <int BM, int BN, int NS, int MINW, int DIAG = 0>
+// MC >= 0: the fused tail is a compile-time constant (2: bias + GELU, 3 / 6: bf16 / fp32 residual, 4: x GELU'(f1)), as in gemm_lw --
+// the two-workgroup instantiation that runs the K <= 768 fused-tail GEMMs.  With the mode a run-time field the tail's operand prefetch
+// sat under mode branches, and the compiler's wait-count model, merging the path without a prefetch, waited for every outstanding load
+// (vmcnt(0)) before the staging pass the prefetch was meant to overlap (round 5, tools/isa_wait_scan.py).  MC = -1: run-time mode.
+template <int BM, int BN, int NS, int MINW, int DIAG = 0, int MC = -1>
 __global__ __launch_bounds__(512, MINW) void gemm_nt_kernel(GemmP P) {
+    if constexpr (MC == 6) { P.mode = 3; P.res_dtype = DGX_F32; }
+    else if constexpr (MC == 3) { P.mode = 3; P.res_dtype = DGX_BF16; }
+    else if constexpr (MC >= 0) P.mode = MC;
     using Cfg = GemmCfg<BM, BN, NS>;
     constexpr int NL = Cfg::NA + Cfg::NB;          // LDS-direct loads per wave per K-tile
     constexpr int WMF = Cfg::WMF, WNF = Cfg::WNF, NA = Cfg::NA, NB = Cfg::NB, SB = Cfg::SB, SROW = Cfg::SROW;
@@ -307,44 +314,43 @@ __global__ __launch_bounds__(512, MINW) void gemm_nt_kernel(GemmP P) {
     // branch-free per lane (a chunk outside the problem reads element 0 of the operand and is dropped in the finish loop): with
     // the loads under per-lane conditions the compiler carries both arrays through every join and spills them
     static_assert((BM * CPR) % 512 == 0, "every lane owns exactly ITERS chunks");
-#define DGX_EPI_PREFETCH(IT0)                                                                                                     \
-    if (P.mode == 4 || P.mode == 5) {                                                                                             \
-        _Pragma("unroll") for (int it = 0; it < PFN; ++it) {                                                                      \
-            const int idx = tid_e + ((IT0) + it) * 512, row = idx / CPR, gm = m0 + row, gn = n0 + 8 * (idx - row * CPR);          \
-            const int64_t off = (gm < P.M && gn < P.N) ? (int64_t)gm * P.ldaux + gn : 0;                                          \
-            xa[it] = *reinterpret_cast<const u32x4*>(P.aux + off);                                                                \
-        }                                                                                                                         \
-    } else if (P.mode == 3) {                                                                                                     \
-        if (P.res_dtype == DGX_BF16) {                                                                                            \
-            _Pragma("unroll") for (int it = 0; it < PFN; ++it) {                                                                  \
-                const int idx = tid_e + ((IT0) + it) * 512, row = idx / CPR, gm = m0 + row, gn = n0 + 8 * (idx - row * CPR);      \
-                const int64_t rt = rowtok[row];                                                                                   \
-                const int64_t off = (gm < P.M && gn < P.N && rt >= 0) ? (rt >> 32) * P.N + gn : 0;                                \
-                xa[it] = *reinterpret_cast<const u32x4*>((const uint16_t*)P.res + off);                                           \
-            }                                                                                                                     \
-        } else {                                                                                                                  \
-            _Pragma("unroll") for (int it = 0; it < PFN; ++it) {                                                                  \
-                const int idx = tid_e + ((IT0) + it) * 512, row = idx / CPR, gm = m0 + row, gn = n0 + 8 * (idx - row * CPR);      \
-                const int64_t rt = rowtok[row];                                                                                   \
-                const int64_t off = (gm < P.M && gn < P.N && rt >= 0) ? (rt >> 32) * P.N + gn : 0;                                \
-                xa[it] = reinterpret_cast<const u32x4*>((const float*)P.res + off)[0];                                            \
-                xb[it] = reinterpret_cast<const u32x4*>((const float*)P.res + off)[1];                                            \
-            }                                                                                                                     \
+    // ONE straight-line set of loads for every tail that reads an operand: the address is chosen per mode, the load is common.  With a
+    // load per mode branch (round 4) the values met in different registers at the join and the compiler copied them there -- behind an
+    // s_waitcnt vmcnt(0) at the end of each branch, i.e. the prefetch was waited for before the staging pass it was meant to overlap.
+#define DGX_EPI_PREFETCH_N(IT0, SLOT0, CNT)                                                                                       \
+    if (P.mode >= 3) {                                                                                                            \
+        const bool m3_ = P.mode == 3, f32_ = m3_ && P.res_dtype != DGX_BF16;                                                      \
+        const char* base_ = m3_ ? (const char*)P.res : (const char*)P.aux;                                                        \
+        _Pragma("unroll") for (int pi_ = 0; pi_ < (CNT); ++pi_) {                                                                    \
+            const int idx = tid_e + ((IT0) + pi_) * 512, row = idx / CPR, gm = m0 + row, gn = n0 + 8 * (idx - row * CPR);          \
+            const bool in_ = gm < P.M && gn < P.N;                                                                                \
+            int64_t off = 0;                                                                                                      \
+            if (m3_) { const int64_t rt = rowtok[row]; if (in_ && rt >= 0) off = (rt >> 32) * P.N + gn; }                         \
+            else if (in_) off = (int64_t)gm * P.ldaux + gn;                                                                       \
+            const char* p_ = base_ + off * (f32_ ? 4 : 2);                                                                        \
+            xa[(SLOT0) + pi_] = *reinterpret_cast<const u32x4*>(p_);                                                               \
+            if (f32_) xb[(SLOT0) + pi_] = *reinterpret_cast<const u32x4*>(p_ + 16);                                                \
         }                                                                                                                         \
     }
-    DGX_EPI_PREFETCH(0)
+#define DGX_EPI_PREFETCH(IT0) DGX_EPI_PREFETCH_N(IT0, 0, PFN)
     {
         const int colw = wc * (BN / 4) + 4 * g;    // + 16 j: this lane's 4 consecutive columns
-        float bv[WNF][4];
+        // the bias row is requested IN FRONT of the tail's operands: vmcnt retires in order, so waiting for a bias load that was issued
+        // behind the prefetch meant waiting for the whole prefetch before the staging pass it was to hide under (round 5)
+        u32x2 braw[WNF];
 #pragma unroll
         for (int j = 0; j < WNF; ++j) {
             const int n = n0 + colw + 16 * j;
-            uint32_t b01 = 0, b23 = 0;
-            if (P.bias && n < P.N) {
-                const u32x2 raw = *reinterpret_cast<const u32x2*>(P.bias + n);
-                b01 = raw[0];
-                b23 = raw[1];
-            }
+            braw[j] = u32x2{0u, 0u};
+            if (P.bias && n < P.N) braw[j] = *reinterpret_cast<const u32x2*>(P.bias + n);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        DGX_EPI_PREFETCH(0)
+        __builtin_amdgcn_sched_barrier(0);
+        float bv[WNF][4];
+#pragma unroll
+        for (int j = 0; j < WNF; ++j) {
+            const uint32_t b01 = braw[j][0], b23 = braw[j][1];
             bv[j][0] = __uint_as_float(b01 << 16); bv[j][1] = __uint_as_float(b01 & 0xffff0000u);
             bv[j][2] = __uint_as_float(b23 << 16); bv[j][3] = __uint_as_float(b23 & 0xffff0000u);
         }
@@ -368,9 +374,11 @@ __global__ __launch_bounds__(512, MINW) void gemm_nt_kernel(GemmP P) {
         float sc;
         if (locate(it, row, ch, gm, gn, tok, sc))
             g_epi_finish(P, gm, gn, *reinterpret_cast<DGX_LDS const u32x4*>(stg + row * SROW + ch * 16), tok, sc, xa[it], xb[it]);
+        // second half (two workgroups per CU: half the tile's operands fit the registers): chunk PFN + it is requested into the
+        // registers chunk `it` has just released, so it flies while the rest of the first half is finished
+        if constexpr (PFN < ITERS) { DGX_EPI_PREFETCH_N(PFN + it, it, 1) }
     }
     if constexpr (PFN < ITERS) {
-        DGX_EPI_PREFETCH(PFN)
 #pragma unroll
         for (int it = 0; it < PFN; ++it) {
             int row, ch, gm, gn;
@@ -381,6 +389,7 @@ __global__ __launch_bounds__(512, MINW) void gemm_nt_kernel(GemmP P) {
         }
     }
 #undef DGX_EPI_PREFETCH
+#undef DGX_EPI_PREFETCH_N
     GCLK(4);
     GCLKR(6);
 }
@@ -470,7 +479,7 @@ TileChoice choose_tile(int M, int N) {
     return {bm, bn};
 }
 
-template <int BM, int BN, int NS, int MINW = 2, int DIAG = 0>
+template <int BM, int BN, int NS, int MINW = 2, int DIAG = 0, int MC = -1>
 int launch_gemm(GemmP& P, hipStream_t st) {
     using Cfg = GemmCfg<BM, BN, NS>;
     const int tiles_m = (P.M + BM - 1) / BM;
@@ -483,12 +492,12 @@ int launch_gemm(GemmP& P, hipStream_t st) {
     P.per_xcd = (P.total * P.splits + 7) / 8;
     static bool once = false;
     if (!once) {
-        if (hipFuncSetAttribute((const void*)gemm_nt_kernel<BM, BN, NS, MINW, DIAG>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)gemm_nt_kernel<BM, BN, NS, MINW, DIAG, MC>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS) != hipSuccess)
             return DGX_ERR_UNSUPPORTED;
         once = true;
     }
     g_last = {MINW == 4 ? 2 : 0, BM, BN, P.splits};
-    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, NS, MINW, DIAG>), dim3(8 * P.per_xcd), dim3(512), Cfg::LDS, st, P);
+    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, NS, MINW, DIAG, MC>), dim3(8 * P.per_xcd), dim3(512), Cfg::LDS, st, P);
     if (P.splits > 1) {
         const int64_t chunks = (int64_t)P.M * (P.N >> 3);
         const int grid = (int)((chunks + 255) / 256 < 4096 ? (chunks + 255) / 256 : 4096);
@@ -537,7 +546,7 @@ static int launch_lw(GemmP& P, int bm, int bn, hipStream_t st) {
 }
 static int dgx_gemm_dispatch(GemmP& P, hipStream_t st);
 static bool use_two_wg(const GemmP& P) {          // see dgx_gemm_dispatch
-    return g_dev.two_wg != 0 && P.N % 192 == 0 && P.K <= 768 && P.M >= 8192 && !P.conv_kc;
+    return g_dev.two_wg != 0 && P.N % 192 == 0 && P.K <= 768 && P.M >= (g_dev.two_wg >= 2 ? g_dev.two_wg : 4096) && !P.conv_kc;
 }
 static void* g_dbg_buffer = nullptr;
 static FILE* g_gemm_log = nullptr;     // one line per launch (dgx_dev_gemm_log), joined with a kernel trace by tools/gemm_insitu.py
@@ -552,7 +561,7 @@ extern int g_dgx_dev_wgrad_lw;      // wgrad_lw.hip
 extern "C" int dgx_dev_set(const char* key, int value) {
     if (!key) return DGX_ERR_BAD_ARG;
     if (!strcmp(key, "gemm_lw")) g_dev.lw = value;                   // -1 plan, 0 gemm_nt everywhere, 1 gemm_lw everywhere
-    else if (!strcmp(key, "gemm_2wg")) g_dev.two_wg = value;         // -1 / 1 plan, 0 never the two-workgroup form
+    else if (!strcmp(key, "gemm_2wg")) g_dev.two_wg = value;         // -1 / 1 plan, 0 never the two-workgroup form, >= 2: its row threshold
     else if (!strcmp(key, "gemm_tile")) { g_dev.tile_bm = value / 1000; g_dev.tile_bn = value % 1000; }     // bm * 1000 + bn, 0 = plan
     else if (!strcmp(key, "gemm_splitk")) g_dev.splitk = value;      // 0 plan, >= 1 forced slab count
     else if (!strcmp(key, "wgrad_lw")) g_dgx_dev_wgrad_lw = value;   // 1 plan, 0 never the loader-wave form, 2 always
@@ -653,7 +662,14 @@ static int dgx_gemm_dispatch(GemmP& P, hipStream_t st) {
         // inside the step, where the tails are the real ones, it wins wherever K <= 768 (round 3, same call: GEMM family
         // 11.80 -> 11.18 ms/step; K <= 384 only: 11.58; every K: 11.70) and loses on the long contractions, which keep the deeper rings.
         // DGX_GEMM_2WG=0 switches it off (A/B).
-        if (use_two_wg(P)) return launch_gemm<128, 192, 2, 4>(P, st);
+        if (use_two_wg(P)) {
+            switch (P.mode) {            // the tails this form exists for, each with its mode compiled in
+                case 2: return launch_gemm<128, 192, 2, 4, 0, 2>(P, st);
+                case 3: return P.res_dtype == DGX_BF16 ? launch_gemm<128, 192, 2, 4, 0, 3>(P, st) : launch_gemm<128, 192, 2, 4, 0, 6>(P, st);
+                case 4: return launch_gemm<128, 192, 2, 4, 0, 4>(P, st);
+                default: return launch_gemm<128, 192, 2, 4>(P, st);
+            }
+        }
         if (tc.bm == 256) return launch_gemm<256, 192, 2>(P, st);
         if (tc.bm == 192) return launch_gemm<192, 192, 3>(P, st);
         return launch_gemm<128, 192, 4>(P, st);

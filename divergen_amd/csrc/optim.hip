@@ -15,7 +15,20 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(float4* __restrict__ p, 
                                                         const int32_t* __restrict__ found_inf) {
     if (found_inf && *found_inf) return;
     if (scale_dev) gscale *= *scale_dev;       // full-model norm-clip coefficient (dgx_clip_coef_f32), kept on the device
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    constexpr int AU = 2;      // quads per trip: all their streams are requested before the first is consumed (10 x 16 B in flight per lane; 4 quads: no further gain)
+    for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n4; i0 += AU * stride) {
+      float4 Pq[AU], Gq[AU], Mq[AU], Vq[AU], Eq[AU];
+#pragma unroll
+      for (int u = 0; u < AU; ++u) {
+        const int64_t i = i0 + u * stride < n4 ? i0 + u * stride : i0;
+        Pq[u] = p[i]; Gq[u] = g[i]; Mq[u] = m[i]; Vq[u] = v[i];
+        if (ema) Eq[u] = ema[i];
+      }
+#pragma unroll
+      for (int u = 0; u < AU; ++u) {
+        const int64_t i = i0 + u * stride;
+        if (i >= n4) break;
         float lre = lr;
         if (lr_scale) {  // binary search of the segment of element 4*i
             int lo = 0, hi = n_seg - 1;
@@ -23,11 +36,11 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(float4* __restrict__ p, 
             while (lo < hi) { const int mid = (lo + hi) >> 1; if (seg_end[mid] > e) hi = mid; else lo = mid + 1; }
             lre = lr * lr_scale[lo];
         }
-        float4 P = p[i], G = g[i], M = m[i], V = v[i];
+        float4 P = Pq[u], G = Gq[u], M = Mq[u], V = Vq[u];
         float pe[4] = {P.x, P.y, P.z, P.w}, ge[4] = {G.x, G.y, G.z, G.w}, me[4] = {M.x, M.y, M.z, M.w},
               ve[4] = {V.x, V.y, V.z, V.w};
         if (ema) {
-            float4 E = ema[i];
+            float4 E = Eq[u];
             E.x = E.x * decay + (1.0f - decay) * pe[0];
             E.y = E.y * decay + (1.0f - decay) * pe[1];
             E.z = E.z * decay + (1.0f - decay) * pe[2];
@@ -48,6 +61,7 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(float4* __restrict__ p, 
         m[i] = make_float4(me[0], me[1], me[2], me[3]);
         v[i] = make_float4(ve[0], ve[1], ve[2], ve[3]);
         if (pbf) pbf[i] = make_uint2(pack_bf2(pe[0], pe[1]), pack_bf2(pe[2], pe[3]));
+      }
     }
 }
 

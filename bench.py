@@ -53,6 +53,8 @@ def parse():
     p.add_argument("--dev", action="append", default=[], metavar="KEY=VALUE",
                    help="development A/B: dgx_dev_set(KEY, VALUE) before the model is built (include/divergen_hip.h; e.g. gemm_lw=1); "
                         "'gemm_log=PATH' opens the per-launch GEMM log.  The library itself reads no environment variable")
+    p.add_argument("--late-proposal-backward", action="store_true",
+                   help="A/B: back-propagate the proposal generator's losses with the rest (model.early_proposal_backward off)")
     p.add_argument("--no-graphs", action="store_true",
                    help="development: issue the hipGraph segments (FPN, tower, heads) eagerly so that every launch is logged / traced by name")
     return p.parse_args()
@@ -309,7 +311,7 @@ def main():
     from divergen_amd import layers as la
     from divergen_amd.config import get_cfg
     from divergen_amd.data import synthetic_batch
-    from divergen_amd.engine import ArenaReducer
+    from divergen_amd.engine import ArenaReducer, total_loss
     for kv in a.dev:                         # development A/B only; the default run sets nothing
         k, v = kv.split("=", 1)
         rc = _lib.lib().dgx_dev_gemm_log(v.encode()) if k == "gemm_log" else _lib.lib().dgx_dev_set(k.encode(), int(v))
@@ -326,6 +328,7 @@ def main():
                                       "ImageNet2012_filtered04_lvis_v1_train_cat_info_250.json")])
     torch.manual_seed(cfg.SEED + rank)
     model = build_model(cfg).train()
+    model.early_proposal_backward = not a.late_proposal_backward
     opt = build_optimizer(cfg, model)
     sched = build_lr_scheduler(cfg, opt)
     reducer = ArenaReducer(opt.arena, single_rank_group=a.force_pg)
@@ -418,7 +421,7 @@ def main():
         nxt[0] = compose()
         opt.zero_grad()
         losses = model(batch)
-        total = sum(losses.values())
+        total = total_loss(losses)
         total.backward()
         if exposed is not None:                 # N > 1: the time the training stream spends waiting for collectives BEHIND backward
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

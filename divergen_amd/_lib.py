@@ -87,6 +87,7 @@ SIGNATURES = {
     "dgx_prof_pause": (c_i, [c_i]),
     "dgx_prof_read": (c_i, [c_i, c_p]),
     "dgx_roi_pooler_bwd_gather": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "dgx_roi_pooler_bwd_gather_accum": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_p]),
     "dgx_mask_crop": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "dgx_nms_sorted": (c_i, [c_p, c_i, c_f, c_p, c_p, c_p, c_p]),
     "dgx_nms_workspace_words": (c_i64, [c_i]),

@@ -287,6 +287,8 @@ struct GatherP {
     float scale[MAX_LEVELS];
     int tile0[MAX_LEVELS + 1], tiles_x[MAX_LEVELS], tiles_y[MAX_LEVELS];
     int num_levels, min_level, N, C, R, ph, pw, sampling_ratio, aligned, total;
+    int accumulate;      // the maps already hold a gradient (another pooling of the same features): add to it, one rounding
+    float gscale;        // factor on this pooling's contribution (the cascade's _ScaleGradient on the pooled features), folded into the x table
 };
 struct GatherMeta { int r, i_lo, i_hi; float sw, bin_w; };
 
@@ -365,7 +367,7 @@ __global__ __launch_bounds__(256) void roi_pool_bwd_gather_kernel(GatherP P, con
                     } else if (t5 - 16 < pw) {
                         float* w = &WX[q][t5 - 16][0];
                         gather_axis_rows(w, TW, t5 - 16, G.sw, G.bin_w, G.gw, W, x0);
-                        for (int k = 0; k < TW; ++k) w[k] = w[k] / G.count;
+                        for (int k = 0; k < TW; ++k) w[k] = w[k] / G.count * P.gscale;
                     }
                     if (t5 == 0) {
                         GatherMeta mt;
@@ -428,6 +430,18 @@ __global__ __launch_bounds__(256) void roi_pool_bwd_gather_kernel(GatherP P, con
     T* ob = (T*)P.out[l] + (int64_t)n * H * W * C + 8 * cv;
     const int x = x0 + tx;
     if (x < W) {
+        if (P.accumulate) {
+            float prev[TH][8];
+#pragma unroll
+            for (int a = 0; a < TH; ++a)
+                if (y0 + a < H) Vec8<T>::load(ob + ((int64_t)(y0 + a) * W + x) * C, prev[a]);
+#pragma unroll
+            for (int a = 0; a < TH; ++a)
+                if (y0 + a < H) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[a][e] += prev[a][e];
+                }
+        }
 #pragma unroll
         for (int a = 0; a < TH; ++a)
             if (y0 + a < H) Vec8<T>::store(ob + ((int64_t)(y0 + a) * W + x) * C, acc[a]);
@@ -592,9 +606,13 @@ extern "C" int dgx_roi_pooler_bwd(const void* grad_out, float* const* grad_feats
 // num_levels == 1: plain ROIAlign with `spatial_scale` / `aligned`; otherwise the ROIPooler level rule with scales
 // 2^-(min_level + l).  DGX_ERR_UNSUPPORTED when C % 8 != 0, 256 % (C/8) != 0, C < 64, the output side exceeds 16 or a
 // pointer is not 16-byte aligned: the caller then uses the scatter forms above.
-extern "C" int dgx_roi_pooler_bwd_gather(const void* grad_out, void* const* grad_feats, const int* Hs, const int* Ws, int num_levels,
-                                         int min_level, float spatial_scale, int aligned, const float* rois, int N, int C, int R,
-                                         int ph, int pw, int sampling_ratio, int dtype, void* stream) {
+// _accum: accumulate != 0 ADDS to the maps (fp32 sum of the map's value and this pooling's contribution, rounded once): the
+// gradients of several poolings of the same features (three cascade stages + the mask head) then need no separate additions.
+// grad_scale multiplies this pooling's contribution (cascade_rcnn.py:20-28 _ScaleGradient sits between pooler and box head).
+extern "C" int dgx_roi_pooler_bwd_gather_accum(const void* grad_out, void* const* grad_feats, const int* Hs, const int* Ws, int num_levels,
+                                               int min_level, float spatial_scale, int aligned, const float* rois, int N, int C, int R,
+                                               int ph, int pw, int sampling_ratio, int accumulate, float grad_scale, int dtype,
+                                               void* stream) {
     if (!grad_feats || !Hs || !Ws || num_levels < 1 || num_levels > MAX_LEVELS) return DGX_ERR_BAD_ARG;
     if (dtype != DGX_BF16 && dtype != DGX_F32) return DGX_ERR_BAD_ARG;
     GatherP P = {};
@@ -604,7 +622,15 @@ extern "C" int dgx_roi_pooler_bwd_gather(const void* grad_out, void* const* grad
         P.out[l] = grad_feats[l]; P.H[l] = Hs[l]; P.W[l] = Ws[l];
         P.scale[l] = num_levels > 1 ? 1.0f / (float)(1 << (min_level + l)) : spatial_scale;
     }
+    P.accumulate = accumulate != 0;
+    P.gscale = grad_scale;
     return launch_gather(P, rois, grad_out, dtype, stream);
+}
+extern "C" int dgx_roi_pooler_bwd_gather(const void* grad_out, void* const* grad_feats, const int* Hs, const int* Ws, int num_levels,
+                                         int min_level, float spatial_scale, int aligned, const float* rois, int N, int C, int R,
+                                         int ph, int pw, int sampling_ratio, int dtype, void* stream) {
+    return dgx_roi_pooler_bwd_gather_accum(grad_out, grad_feats, Hs, Ws, num_levels, min_level, spatial_scale, aligned, rois, N, C, R, ph, pw,
+                                           sampling_ratio, 0, 1.0f, dtype, stream);
 }
 
 // ---- GT mask crop: one workgroup per box, one lane per output pixel, byte taps --------------

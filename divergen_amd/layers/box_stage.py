@@ -25,6 +25,7 @@ class _BoxStageFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gt_classes, class_w, prop, gtb, src, cfg, fc1w, fc1b, fc2w, fc2b, clsw, clsb, boxw, boxb):
         R, C, wts, grad_scale = cfg
+        ctx.set_materialize_grads(False)            # the statistics' and the deltas' gradients do not exist: no zero maps for them
         lib, st, dev = L.lib(), L.stream(), x.device
         Rp = x.shape[0]
         x2 = x.permute(0, 2, 3, 1).reshape(Rp, -1)         # (h, w, c) columns, the order fc1's weight is stored in: a view of the pooler's output

@@ -18,9 +18,40 @@ def _nhwc(feat):
     return feat.permute(0, 2, 3, 1).contiguous()
 
 
+class FeatureGradients:
+    """Gradient maps of a list of feature tensors that their consumers' backward passes fill IN PLACE, instead of returning one
+    map each for autograd to add up: `maps[i]` is None or the (N,C,H,W) gradient of feature i so far.  The FPN levels have up to
+    five consumers per step (CenterNet head, three cascade stages, mask head); at 1024^2 one addition of a P3-sized pair of maps
+    moves 50 MB.  Whoever owns the features joins the maps back into autograd after the last consumer ran
+    (modeling/meta_arch/custom_rcnn.py _JoinGradients); a feature tensor announces its slot as `_dgx_grad_sink = (self, i)`."""
+
+    def __init__(self, n):
+        self.maps = [None] * n
+
+    def add(self, i, g):
+        m = self.maps[i]
+        if m is None:
+            self.maps[i] = g
+        else:
+            m.add_(g)
+
+    def take(self, i):
+        m, self.maps[i] = self.maps[i], None
+        return m
+
+
+def _sink_of(feats):
+    """(FeatureGradients, slots) when every feature announces a slot of the SAME object, else None."""
+    sinks = [getattr(f, "_dgx_grad_sink", None) for f in feats]
+    if any(s is None for s in sinks) or any(s[0] is not sinks[0][0] for s in sinks):
+        return None
+    return sinks[0][0], [s[1] for s in sinks]
+
+
 class _ROIPooler(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, rois, out_size, min_level, sampling_ratio, out_nhwc, aligned, scale0, *feats):
+    def forward(ctx, rois, out_size, min_level, sampling_ratio, out_nhwc, aligned, scale0, sink, grad_scale, *feats):
+        ctx.sink, ctx.grad_scale = sink, float(grad_scale)
         nl = len(feats)
         f0 = feats[0]
         N, C = f0.shape[0], f0.shape[1]
@@ -67,12 +98,33 @@ class _ROIPooler(torch.autograd.Function):
         Ws = (ctypes.c_int * nl)(*[s[3] for s in shapes])
         if out_nhwc and _GATHER and C % 8 == 0 and C >= 64 and 256 % (C // 8) == 0 and out_size <= 16:
             # output-stationary gather: every gradient pixel written once, in the feature dtype (no fp32 staging maps)
-            grads = [torch.empty(s[0], s[2], s[3], s[1], dtype=g_phys.dtype, device=gout.device) for s in shapes]
+            accumulate = 0
+            if ctx.sink is not None:
+                # the maps other consumers of these features already wrote (channels-last storage, this dtype) take the sum in place
+                fg, slots = ctx.sink
+                grads = []
+                for s, i in zip(shapes, slots):
+                    m = fg.maps[i]
+                    if m is not None and not (m.dtype == g_phys.dtype and tuple(m.shape) == tuple(s) and m.permute(0, 2, 3, 1).is_contiguous()
+                                              and m.data_ptr() % 16 == 0):
+                        m = m.to(g_phys.dtype).contiguous(memory_format=torch.channels_last)
+                    grads.append(None if m is None else m.permute(0, 2, 3, 1))
+                accumulate = int(any(g is not None for g in grads))
+                mk = torch.zeros if accumulate else torch.empty
+                grads = [mk(s[0], s[2], s[3], s[1], dtype=g_phys.dtype, device=gout.device) if g is None else g for g, s in zip(grads, shapes)]
+            else:
+                grads = [torch.empty(s[0], s[2], s[3], s[1], dtype=g_phys.dtype, device=gout.device) for s in shapes]
             ptrs = (ctypes.c_void_p * nl)(*[L.ptr(g) for g in grads])
-            L.check(L.lib().dgx_roi_pooler_bwd_gather(L.ptr(g_phys), ptrs, Hs, Ws, nl, min_level, scale0, int(aligned),
-                                                      L.ptr(rois), N, C, R, out_size, out_size, sampling_ratio,
-                                                      L.dtype_code(g_phys), L.stream()), "dgx_roi_pooler_bwd_gather")
-            return (None,) * 7 + tuple(g.permute(0, 3, 1, 2).to(dt) for g in grads)
+            L.check(L.lib().dgx_roi_pooler_bwd_gather_accum(L.ptr(g_phys), ptrs, Hs, Ws, nl, min_level, scale0, int(aligned),
+                                                            L.ptr(rois), N, C, R, out_size, out_size, sampling_ratio, accumulate,
+                                                            ctx.grad_scale, L.dtype_code(g_phys), L.stream()), "dgx_roi_pooler_bwd_gather_accum")
+            if ctx.sink is not None:
+                for g, i in zip(grads, slots):
+                    fg.maps[i] = g.permute(0, 3, 1, 2)
+                return (None,) * (9 + nl)
+            return (None,) * 9 + tuple(g.permute(0, 3, 1, 2).to(dt) for g in grads)
+        if ctx.grad_scale != 1.0:
+            g_phys = g_phys * ctx.grad_scale
         grads = [torch.zeros(s[0], s[2], s[3], s[1], dtype=torch.float32, device=gout.device) for s in shapes]
         if nl == 1:
             L.check(L.lib().dgx_roi_align_bwd(L.ptr(g_phys), L.ptr(rois), L.ptr(grads[0]), N, Hs[0], Ws[0], C, R,
@@ -84,21 +136,26 @@ class _ROIPooler(torch.autograd.Function):
                                                out_size, out_size, sampling_ratio, int(out_nhwc),
                                                L.dtype_code(g_phys), L.stream()), "dgx_roi_pooler_bwd")
         outs = [g.permute(0, 3, 1, 2).to(dt) for g in grads]
-        return (None,) * 7 + tuple(outs)
+        if ctx.sink is not None:
+            for o, i in zip(outs, ctx.sink[1]):
+                ctx.sink[0].add(i, o)
+            return (None,) * (9 + nl)
+        return (None,) * 9 + tuple(outs)
 
 
-def roi_align(feat, rois, spatial_scale, out_size, sampling_ratio=0, aligned=True, out_nhwc=False):
+def roi_align(feat, rois, spatial_scale, out_size, sampling_ratio=0, aligned=True, out_nhwc=False, grad_scale=1.0):
     """feat (N,C,H,W) (any memory format), rois (R,5) -> (R,C,S,S)."""
-    return _ROIPooler.apply(rois, out_size, 0, sampling_ratio, out_nhwc, aligned, float(spatial_scale), feat)
+    return _ROIPooler.apply(rois, out_size, 0, sampling_ratio, out_nhwc, aligned, float(spatial_scale), _sink_of([feat]), grad_scale, feat)
 
 
-def roi_pooler(feats, rois, out_size, scales, sampling_ratio=0, out_nhwc=False):
+def roi_pooler(feats, rois, out_size, scales, sampling_ratio=0, out_nhwc=False, grad_scale=1.0):
     """Multi-level ROIAlignV2 (poolers.py:185-245).  feats: list of (N,C,H,W); rois (R,5) with
-    batch index in column 0; scales: per-level spatial scales (powers of two)."""
+    batch index in column 0; scales: per-level spatial scales (powers of two).
+    grad_scale: the factor of a _ScaleGradient (cascade_rcnn.py:20-28) placed on the pooled features, applied inside the backward."""
     min_level = int(round(-math.log2(scales[0])))
     if len(feats) == 1:
-        return roi_align(feats[0], rois, scales[0], out_size, sampling_ratio, True, out_nhwc)
-    return _ROIPooler.apply(rois, out_size, min_level, sampling_ratio, out_nhwc, True, float(scales[0]), *feats)
+        return roi_align(feats[0], rois, scales[0], out_size, sampling_ratio, True, out_nhwc, grad_scale)
+    return _ROIPooler.apply(rois, out_size, min_level, sampling_ratio, out_nhwc, True, float(scales[0]), _sink_of(feats), grad_scale, *feats)
 
 
 def mask_crop(masks, boxes, mask_idx, size):

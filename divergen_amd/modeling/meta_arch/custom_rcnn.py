@@ -13,10 +13,64 @@ from torch import nn
 from .. import META_ARCH_REGISTRY, build_backbone, build_proposal_generator, build_roi_heads
 from ...config import configurable
 from ...layers.conv_ops import preprocess_patch_rows
+from ...layers.roi_ops import FeatureGradients
 from ...structures import ImageList
 
 # dgx_preprocess_patches; the composed normalise + pad + unfold form is the reference of its parity test
 _FUSED_PREPROCESS = True
+
+
+class _CaptureGradient(torch.autograd.Function):
+    """Identity; its backward hands the incoming gradient to slot i of a FeatureGradients (no copy) and ends the pass there."""
+
+    @staticmethod
+    def forward(ctx, fg, i, x):
+        ctx.fg, ctx.i = fg, i
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.fg.add(ctx.i, g)
+        return None, None, None
+
+
+class _JoinGradients(torch.autograd.Function):
+    """Identity on the feature maps; its backward -- which autograd runs after every consumer of its outputs -- returns what the
+    consumers left in the FeatureGradients (the RoI poolers add in place, layers/roi_ops.py; an EARLIER backward pass of the
+    proposal generator, `early_proposal_backward`, through _CaptureGradient) plus whatever arrived the ordinary way."""
+
+    @staticmethod
+    def forward(ctx, fg, *feats):
+        ctx.fg = fg
+        ctx.set_materialize_grads(False)
+        return tuple(f.view_as(f) for f in feats)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        out = []
+        for i, g in enumerate(grads):
+            e = ctx.fg.take(i)
+            out.append(g if e is None else e if g is None else e.add_(g))
+        return (None,) + tuple(out)
+
+
+def _shared_gradient_maps(features):
+    """features (dict of maps that require grad) -> (FeatureGradients, the same dict behind _JoinGradients with the slots announced)"""
+    names = list(features.keys())
+    fg = FeatureGradients(len(names))
+    joined = _JoinGradients.apply(fg, *[features[k] for k in names])
+    for i, (k, j) in enumerate(zip(names, joined)):
+        j._dgx_grad_sink = (fg, i)
+        _same_buffer(features[k], j)
+    return fg, dict(zip(names, joined))
+
+
+def _same_buffer(src, view):
+    """`view` is `src` behind an identity node: a hipGraph segment that takes `src` as its static input as it stands
+    (utils/graphs.py ALIAS_STATIC) may do so with `view`."""
+    if getattr(src, "_dgx_static_output", False):
+        view._dgx_static_output = True
+    return view
 
 
 @META_ARCH_REGISTRY.register()
@@ -37,6 +91,12 @@ class CustomRCNN(nn.Module):
                                       "an fp32-activation mode does not exist (every shipped configuration sets FP16: True)")
         # hipGraph capture of the static-shape backbone fwd+bwd (launch-bound otherwise: ~3.5k launches)
         self.return_proposal = False
+        # Trainer opt-in (bench.py, train_net.py's plain loop): the proposal generator's losses are back-propagated from INSIDE the
+        # forward, queued on the GPU before the RoI heads' one device->host read (the proposal sampler), so the device has that
+        # backward to run while the host -- which loses its whole lead at that read -- issues the RoI heads.  The loss dict then
+        # carries those losses DETACHED (their gradients are already in the arena / on the feature maps): only valid for a loop
+        # that calls backward once on the plain sum of the dict, after a zero_grad.
+        self.early_proposal_backward = False
 
     @classmethod
     def from_config(cls, cfg):
@@ -91,17 +151,38 @@ class CustomRCNN(nn.Module):
             if sel.mode == "paste_or_zero" and not paste:                           # :769-771: the step trains on nothing
                 losses = {k: v * 0.0 for k, v in losses.items()}
             return losses
-        return self.training_losses(batched_inputs)
+        return self.training_losses(batched_inputs, early=self.early_proposal_backward and not self.return_proposal)
 
-    def training_losses(self, batched_inputs, only_gt_proposals=False):
+    def training_losses(self, batched_inputs, only_gt_proposals=False, early=False):
         """custom_rcnn.py:118-207 for the box-supervised path: the loss dict of one batch."""
         images = self.preprocess_image(batched_inputs)
         gt_instances = [x["instances"].to(self.device) for x in batched_inputs]
         features = self._features(images)
+        grads_on = torch.is_grad_enabled() and all(f.requires_grad for f in features.values())
         with torch.autocast("cuda", dtype=torch.bfloat16):
-            proposals, proposal_losses = self.proposal_generator(images, features, gt_instances)
-            proposals, detector_losses = self.roi_heads(images, features, proposals, gt_instances, ann_type="box",
-                                                        only_gt_proposals=only_gt_proposals)
+            if grads_on:
+                # the consumers of the FPN levels write ONE gradient map per level between them
+                fg, joined = _shared_gradient_maps(features)
+            if early and grads_on:
+                stubs = {k: _same_buffer(f, _CaptureGradient.apply(fg, i, f.detach().requires_grad_(True)))
+                         for i, (k, f) in enumerate(features.items())}
+                proposals, proposal_losses = self.proposal_generator(images, stubs, gt_instances)
+                pl_total = torch.stack([v.float().reshape(()) for v in proposal_losses.values()]).sum()
+                self.roi_heads.__dict__["_before_host_read"] = pl_total.backward
+                try:
+                    proposals, detector_losses = self.roi_heads(images, joined, proposals, gt_instances, ann_type="box",
+                                                                only_gt_proposals=only_gt_proposals)
+                finally:
+                    pending = self.roi_heads.__dict__.pop("_before_host_read", None)
+                if pending is not None:         # the RoI heads took a path without the fused sampler
+                    pending()
+                proposal_losses = {k: v.detach() for k, v in proposal_losses.items()}
+            else:
+                if grads_on:
+                    features = joined
+                proposals, proposal_losses = self.proposal_generator(images, features, gt_instances)
+                proposals, detector_losses = self.roi_heads(images, features, proposals, gt_instances, ann_type="box",
+                                                            only_gt_proposals=only_gt_proposals)
         losses = {}
         losses.update(detector_losses)
         losses.update(proposal_losses)

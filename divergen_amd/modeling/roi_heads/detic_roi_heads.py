@@ -15,7 +15,7 @@ from ...config import configurable
 from ...layers import iou_match
 from ...layers.box_stage import box_stage, box_stage_supported
 from ...structures import Boxes, Instances, ProposalBatch
-from ...utils.events import get_event_storage
+from ...utils.events import DeferredScalar, get_event_storage
 from ..box_regression import Box2BoxTransform
 from .box_head import build_box_head
 from .detic_fast_rcnn import DeticFastRCNNOutputLayers, fast_rcnn_inference
@@ -258,7 +258,22 @@ class DeticCascadeROIHeads(nn.Module):
         L.check(lib.dgx_roi_label(L.ptr(boxes), L.ptr(valid_u8), B, K, L.ptr(gt_boxes), L.ptr(gt_classes), L.ptr(offs_t), max(gts),
                                   float(self.cascade_ious[0]), self.num_classes, 1, Nmax, L.ptr(midx), L.ptr(labels), L.ptr(pos_idx),
                                   L.ptr(neg_idx), L.ptr(counts), L.stream()), "dgx_roi_label")
-        c = counts.tolist()                                           # THE device->host read of the step
+        before = self.__dict__.pop("_before_host_read", None)
+        if before is not None:
+            # (meta_arch/custom_rcnn.py early_proposal_backward) the counts start their way to the host NOW; the work queued by
+            # `before` runs behind them, so the device is busy while the host reads and issues the rest of the heads
+            host = self.__dict__.get("_counts_host")
+            if host is None or host.numel() < 2 * B:
+                host = self.__dict__["_counts_host"] = torch.empty(max(2 * B, 32), dtype=torch.int32).pin_memory()
+                self.__dict__["_counts_event"] = torch.cuda.Event()
+            host[:2 * B].copy_(counts, non_blocking=True)
+            ev = self.__dict__["_counts_event"]
+            ev.record()
+            before()
+            ev.synchronize()
+            c = host[:2 * B].tolist()
+        else:
+            c = counts.tolist()                                       # THE device->host read of the step
         perms, npos, nneg = [], [], []
         for i in range(B):
             k_pos = min(c[2 * i], int(self.batch_size_per_image * self.positive_fraction))
@@ -400,20 +415,22 @@ class DeticCascadeROIHeads(nn.Module):
                                                    float(tr.scale_clamp), L.ptr(nb), L.ptr(nvalid), L.ptr(gtc), L.ptr(gtb), L.ptr(src),
                                                    L.ptr(nfg), L.dtype_code(d), L.stream()), "dgx_cascade_refine")
                 prop, valid = nb, nvalid
-                f = nfg[0].float()
-                st.put_scalar("stage{}/roi_head/num_fg_samples".format(k), f / B)
-                st.put_scalar("stage{}/roi_head/num_bg_samples".format(k), (R - f) / B)
+                st.put_scalar("stage{}/roi_head/num_fg_samples".format(k), DeferredScalar(lambda f, B=B: f[0] / B, nfg))
+                st.put_scalar("stage{}/roi_head/num_bg_samples".format(k), DeferredScalar(lambda f, B=B, R=R: (R - f[0]) / B, nfg))
             obs = self.__dict__.get("stage_observer")
             if obs is not None:      # tests: the labels this stage trains on (hand-over to the CPU oracle)
                 obs(k, dict(boxes=prop, valid=valid, gt_classes=gtc, gt_boxes=gtb, counts=counts))
-            x = self.box_pooler.forward_rows(feats, prop, counts, pad_to=256)
             pred = self.box_predictor[k]
-            if box_stage_supported(self.box_head[k], pred):
+            fused = box_stage_supported(self.box_head[k], pred)
+            # _ScaleGradient (cascade_rcnn.py:20-28, :150) sits on the pooled features: the fused stage leaves the factor to the pooler's
+            # backward, which folds it into its interpolation table (no pass over the 25 MB pooled gradient)
+            x = self.box_pooler.forward_rows(feats, prop, counts, pad_to=256, grad_scale=1.0 / self.num_cascade_stages if fused else 1.0)
+            if fused:
                 # flatten -> fc1 -> ReLU -> fc2 -> ReLU -> cls_score | bbox_pred -> losses: one autograd node (layers/box_stage.py)
                 C = pred.num_classes
                 w = pred._class_weight(gtc, C)
                 loss_cls, loss_box, out, deltas = box_stage(x, self.box_head[k], pred, gtc, w, prop, gtb,
-                                                            None if pred.divergen_box_loss else src, R, 1.0 / self.num_cascade_stages)
+                                                            None if pred.divergen_box_loss else src, R, 1.0)
                 with st.name_scope("stage{}".format(k)):
                     st.put_scalar("fast_rcnn/cls_accuracy", out[11])
                     st.put_scalar("fast_rcnn/fg_cls_accuracy", out[12])

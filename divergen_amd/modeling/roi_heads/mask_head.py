@@ -9,7 +9,7 @@ from .. import ROI_MASK_HEAD_REGISTRY
 from ...config import configurable
 from ...layers.conv_ops import Conv2d, ConvTranspose2d
 from ...layers.mask_ops import mask_bce_with_stats
-from ...utils.events import get_event_storage
+from ...utils.events import DeferredScalar, get_event_storage
 from ..backbone.fpn import c2_msra_fill
 
 
@@ -34,12 +34,12 @@ def mask_rcnn_loss(pred_mask_logits, instances, vis_period=0):
     if pred.is_cuda and pred.dtype in (torch.float32, torch.bfloat16):
         # loss, gradient and the three statistics in one pass over the logits (dgx_mask_bce)
         loss, stats = mask_bce_with_stats(pred, gt_masks)
-        with torch.no_grad():  # statistics stay on the device; writers convert lazily
-            n = float(max(gt_masks.numel(), 1))
-            st = get_event_storage()
-            st.put_scalar("mask_rcnn/accuracy", 1 - stats[1] / n)
-            st.put_scalar("mask_rcnn/false_positive", stats[2] / (gt_masks.numel() - stats[4]).clamp(min=1.0))
-            st.put_scalar("mask_rcnn/false_negative", stats[3] / stats[4].clamp(min=1.0))
+        # statistics: the raw counters stay on the device, the three ratios are formed when a writer reads them
+        n = float(max(gt_masks.numel(), 1))
+        st = get_event_storage()
+        st.put_scalar("mask_rcnn/accuracy", DeferredScalar(lambda s, n=n: 1 - s[1] / n, stats))
+        st.put_scalar("mask_rcnn/false_positive", DeferredScalar(lambda s, n=n: s[2] / max(n - s[4], 1.0), stats))
+        st.put_scalar("mask_rcnn/false_negative", DeferredScalar(lambda s: s[3] / max(s[4], 1.0), stats))
         return loss
     gt_bool = gt_masks
     with torch.no_grad():

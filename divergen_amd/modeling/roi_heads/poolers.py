@@ -21,7 +21,7 @@ class ROIPooler(nn.Module):
         self.min_level, self.max_level = int(mn), int(mx)
         assert len(scales) == self.max_level - self.min_level + 1
 
-    def forward_rows(self, x, boxes, counts, pad_to=0):
+    def forward_rows(self, x, boxes, counts, pad_to=0, grad_scale=1.0):
         """`forward` for RoIs that already sit in ONE (R, 4) tensor with `counts` rows per image (the cascade keeps them that way):
         the image-index column and the shape-padding rows are constants of (counts, pad_to), built once."""
         R = int(boxes.shape[0])
@@ -34,10 +34,12 @@ class ROIPooler(nn.Module):
                 cache.clear()
             col = torch.cat([torch.full((n,), float(i)) for i, n in enumerate(counts)] + [torch.zeros(Rp - R)])
             idx = cache[key] = col.to(boxes.device).view(Rp, 1)
-        rois = torch.zeros(Rp, 5, dtype=torch.float32, device=boxes.device) if Rp > R else torch.empty(Rp, 5, dtype=torch.float32, device=boxes.device)
-        rois[:, :1] = idx
-        rois[:R, 1:] = boxes
-        return roi_pooler(list(x), rois, self.output_size, self.scales, self.sampling_ratio, self.out_nhwc)
+        if Rp > R:       # shape-padding rows: empty boxes of image 0
+            rois = torch.zeros(Rp, 5, dtype=torch.float32, device=boxes.device)
+            rois[:R] = torch.cat([idx[:R], boxes.float()], dim=1)
+        else:
+            rois = torch.cat([idx, boxes.float()], dim=1)
+        return roi_pooler(list(x), rois, self.output_size, self.scales, self.sampling_ratio, self.out_nhwc, grad_scale)
 
     def forward(self, x, box_lists, pad_to=0):
         """x: list of (N,C,H,W); box_lists: list[Boxes] per image -> (R, C, S, S).

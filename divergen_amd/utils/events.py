@@ -18,6 +18,18 @@ def has_event_storage():
     return len(_CURRENT_STORAGE_STACK) > 0
 
 
+class DeferredScalar:
+    """A statistic whose arithmetic waits for a reader: `fn` over the host values of the raw device counters in `tensors`,
+    evaluated in float().  The training step then carries no launches for numbers only a writer looks at (every 20 iterations)."""
+    __slots__ = ("_fn", "_t")
+
+    def __init__(self, fn, *tensors):
+        self._fn, self._t = fn, tuple(t.detach() for t in tensors)
+
+    def __float__(self):
+        return float(self._fn(*[t.tolist() for t in self._t]))
+
+
 class EventStorage:
     def __init__(self, start_iter=0):
         self._history = defaultdict(list)
@@ -28,7 +40,7 @@ class EventStorage:
     def put_scalar(self, name, value, smoothing_hint=True):
         name = self._prefix + name
         # device tensors are kept as-is and converted when a writer reads them: no host sync per iter
-        value = value.detach() if hasattr(value, "detach") else float(value)
+        value = value if isinstance(value, DeferredScalar) else value.detach() if hasattr(value, "detach") else float(value)
         self._history[name].append((value, self._iter))
         self._latest[name] = (value, self._iter)
 

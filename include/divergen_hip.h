@@ -112,6 +112,14 @@ int dgx_roi_pooler_bwd(const void* grad_out, float* const* grad_feats, const int
 int dgx_roi_pooler_bwd_gather(const void* grad_out, void* const* grad_feats, const int* Hs, const int* Ws,
                               int num_levels, int min_level, float spatial_scale, int aligned, const float* rois,
                               int N, int C, int R, int ph, int pw, int sampling_ratio, int dtype, void* stream);
+/* The same with accumulate != 0: the maps already hold a gradient of the same features (autograd's sum over the consumers of
+ * one FPN level -- D2/modeling/roi_heads/cascade_rcnn.py:137-160 pools them once per stage, the mask head once more) and this
+ * pooling's contribution is ADDED: fp32 sum, one rounding into the map's dtype.  grad_scale multiplies this pooling's
+ * contribution (D2/modeling/roi_heads/cascade_rcnn.py:20-28 _ScaleGradient between pooler and box head; 1 otherwise). */
+int dgx_roi_pooler_bwd_gather_accum(const void* grad_out, void* const* grad_feats, const int* Hs, const int* Ws,
+                                    int num_levels, int min_level, float spatial_scale, int aligned, const float* rois,
+                                    int N, int C, int R, int ph, int pw, int sampling_ratio, int accumulate, float grad_scale,
+                                    int dtype, void* stream);
 
 /* GT-mask crop for the mask loss: ROIAlign(S x S, scale 1, ratio 0, aligned) on uint8/bool masks
  * and `>= 0.5`, without materialising the fp32 mask.  Replaces BitMasks.crop_and_resize,

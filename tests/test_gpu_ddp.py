@@ -33,15 +33,16 @@ def _build(swin, size):
     return cfg, model, build_optimizer(cfg, model)
 
 
-def _run(with_reducer, steps=3, swin="L-22k-384", size=1024, weights_in=None):
+def _run(with_reducer, steps=3, swin="L-22k-384", size=1024, weights_in=None, early=True):
     import torch.distributed as dist
     from divergen_amd import _lib as L
     from divergen_amd.data import synthetic_batch
-    from divergen_amd.engine import ArenaReducer
+    from divergen_amd.engine import ArenaReducer, total_loss
     from divergen_amd.engine import ddp as DDP
     from divergen_amd.layers import swin_block as SB
     from divergen_amd.utils.events import EventStorage
     cfg, model, opt = _build(swin, size)
+    model.early_proposal_backward = early          # as bench.py / train_net.py run it: CenterNet's gradients are written DURING the forward
     reducer = ArenaReducer(opt.arena, single_rank_group=with_reducer)
     assert reducer.active == with_reducer
     if with_reducer:
@@ -82,7 +83,7 @@ def _run(with_reducer, steps=3, swin="L-22k-384", size=1024, weights_in=None):
                 del log[:]
                 opt.zero_grad()
                 losses = model(batch)
-                sum(losses.values()).backward()
+                total_loss(losses).backward()
                 scale = reducer.finish()
                 torch.cuda.synchronize()
                 grads.append(opt.arena.g.clone())
@@ -94,11 +95,12 @@ def _run(with_reducer, steps=3, swin="L-22k-384", size=1024, weights_in=None):
     return opt, grads, per_step, reducer, weights
 
 
-def test_one_rank_rccl_group_trains_like_no_reducer():
+@pytest.mark.parametrize("early", [True, False])
+def test_one_rank_rccl_group_trains_like_no_reducer(early):
     import torch.distributed as dist
     from divergen_amd.utils import graphs
     assert graphs.ENABLED, "the hipGraph segments are part of what is being proven"
-    opt0, grads0, log0, _, weights0 = _run(False)
+    opt0, grads0, log0, _, weights0 = _run(False, early=early)
     assert max(n for kind, _, _, _, n in log0[-1][0] if kind == "w") >= 28, "the deferred 28-problem loader-wave group must be active"
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -106,7 +108,7 @@ def test_one_rank_rccl_group_trains_like_no_reducer():
     os.environ.setdefault("NCCL_MAX_NCHANNELS", "16")
     dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
     try:
-        opt1, grads1, log1, reducer, _ = _run(True, weights_in=weights0)
+        opt1, grads1, log1, reducer, _ = _run(True, weights_in=weights0, early=early)
     finally:
         dist.destroy_process_group()
     # ---- gradients: bit for bit outside the atomically scattered relative-position tables

@@ -280,6 +280,79 @@ def test_roi_pooler_backward_gather_many_large_boxes(dt):
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_roi_pooler_backward_into_shared_gradient_maps(dt):
+    """Several poolings of the same feature maps (three cascade stages at 7x7 + the mask head at 14x14, cascade_rcnn.py:137-160,
+    roi_heads.py:789-813) writing ONE gradient map per level between them (FeatureGradients + dgx_roi_pooler_bwd_gather_accum)
+    against autograd's sum of the separately produced maps: equal in fp32 (the same two addends per step, float addition commutes),
+    within one rounding of the running sum in bf16; a map that starts from another consumer's gradient (the proposal generator's)
+    takes the poolings on top; the slots are empty again after the join."""
+    from divergen_amd.layers.roi_ops import FeatureGradients
+    from divergen_amd.modeling.meta_arch.custom_rcnn import _CaptureGradient, _JoinGradients
+    g = torch.Generator().manual_seed(11)
+    C = 256
+    sizes = [(40, 56), (20, 28), (10, 14)]
+    scales = (1 / 8, 1 / 16, 1 / 32)
+    feats = [(torch.randn(2, C, h, w, generator=g) * 0.5) for h, w in sizes]
+    pools = []
+    for k, (n, S) in enumerate([(150, 7), (150, 7), (150, 7), (40, 14)]):
+        r = _rand_rois(g, n, 2, 40 * 8, 56 * 8)
+        r = r[torch.argsort(r[:, 0], stable=True)]
+        go = torch.randn(n, C, S, S, generator=g) * 0.1
+        pools.append((r, S, bf(go).float() if dt == torch.bfloat16 else go, 1.0 / 3 if S == 7 else 1.0))
+    head_grad = [torch.randn(2, C, h, w, generator=g) * 0.1 for h, w in sizes]
+
+    def leaves():
+        return [f.to(DEV).to(dt).contiguous(memory_format=torch.channels_last).requires_grad_(True) for f in feats]
+
+    def losses(fs, extra, in_pooler=True):
+        # the box stages' pooled features sit behind a _ScaleGradient(1/3): as a factor on the loss term (reference form), or handed to
+        # the pooler, whose backward folds it into its table
+        tot = 0
+        for r, S, go, sc in pools:
+            pooled = la.roi_pooler(list(fs), r.to(DEV), S, scales, out_nhwc=True, grad_scale=sc if in_pooler else 1.0)
+            tot = tot + (pooled.float() * go.to(DEV)).sum() * (1.0 if in_pooler else sc)
+        for f, h in zip(extra, head_grad):       # another consumer whose gradient is h
+            tot = tot + (f * h.to(DEV).to(dt)).sum()
+        return tot
+
+    # separate maps, summed by autograd
+    fd = leaves()
+    losses(fd, fd, in_pooler=False).backward()
+    ref = [f.grad.float().cpu() for f in fd]
+    # one map per level: the other consumer's gradient arrives first (as with early_proposal_backward), the poolings add to it
+    fd = leaves()
+    fg = FeatureGradients(3)
+    stubs = [_CaptureGradient.apply(fg, i, f.detach().requires_grad_(True)) for i, f in enumerate(fd)]
+    sum((s * h.to(DEV).to(dt)).sum() for s, h in zip(stubs, head_grad)).backward()
+    assert all(m is not None for m in fg.maps)
+    joined = _JoinGradients.apply(fg, *fd)
+    for i, j in enumerate(joined):
+        j._dgx_grad_sink = (fg, i)
+    losses(joined, []).backward()
+    got = [f.grad.float().cpu() for f in fd]
+    assert all(m is None for m in fg.maps)
+    # ... and with nothing in the slots beforehand (the first pooling allocates)
+    fd = leaves()
+    fg = FeatureGradients(3)
+    joined = _JoinGradients.apply(fg, *fd)
+    for i, j in enumerate(joined):
+        j._dgx_grad_sink = (fg, i)
+    losses(joined, []).backward()
+    only = [f.grad.float().cpu() for f in fd]
+    fd = leaves()
+    losses(fd, [], in_pooler=False).backward()
+    ref_only = [f.grad.float().cpu() for f in fd]
+    for l in range(3):
+        sc = float(ref[l].abs().max())
+        if dt == torch.float32:
+            assert float((got[l] - ref[l]).abs().max()) <= 4e-6 * sc, l          # same addends, other association; the 1/3 applied to the table
+            assert float((only[l] - ref_only[l]).abs().max()) <= 4e-6 * sc, l
+        else:       # autograd rounds every partial sum to bf16, the shared map rounds once per pooling on an fp32 sum
+            assert float((got[l] - ref[l]).abs().max()) <= 2.0 ** -6 * sc, l
+            assert float((only[l] - ref_only[l]).abs().max()) <= 2.0 ** -6 * sc, l
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_mask_bce_matches_torch_formulation(dt):
     """dgx_mask_bce (loss, gradient, statistics of mask_rcnn_loss, mask_head.py:35-110) against the torch formulation the
     reference calls, incl. a strided class-gather view, saturated logits and an empty input."""

@@ -454,3 +454,44 @@ def test_first_writer_gradients_train_like_zero_filled_ones(monkeypatch):
     assert float((p0 - p1).abs().max()) <= 2e-3 * float(p0.abs().max())
     names = {arena.names[i] for i in arena.direct}
     assert any("box_head" in n for n in names) and any("mlp.fc1.weight" in n for n in names)
+
+
+def test_early_proposal_backward_is_the_same_step():
+    """model.early_proposal_backward (the training loops switch it on: the proposal generator's losses are back-propagated from inside the
+    forward, ahead of the RoI heads' device->host read): the forward is untouched -- every loss bit-identical, the same random draws --,
+    the proposal losses come back detached, the parameters whose gradient does not pass through the FPN levels (CenterNet head, RoI
+    heads) get bit-identical gradients, and backbone + FPN differ only by the association of the per-level sum of the consumers'
+    gradients (bf16 maps: the poolers add onto the head's map instead of the head's map being added last)."""
+    from divergen_amd.data import synthetic_batch
+    from divergen_amd.engine import total_loss
+    from divergen_amd.utils.events import EventStorage
+    res = []
+    for early in (False, True):
+        cfg, model, opt = _build(True)
+        model.early_proposal_backward = early
+        batch = synthetic_batch(2, 256, cfg.MODEL.ROI_HEADS.NUM_CLASSES, device="cuda")
+        with EventStorage(0):
+            for k in range(2):          # the second pass replays the captured segments
+                torch.manual_seed(7)
+                opt.zero_grad()
+                losses = model(batch)
+                total_loss(losses).backward()
+                torch.cuda.synchronize()
+        assert all(v.requires_grad != early for k, v in losses.items() if "centernet" in k)
+        assert all(v.requires_grad for k, v in losses.items() if "centernet" not in k)
+        res.append(({k: float(v) for k, v in losses.items()}, opt.arena.g.clone(), opt.arena))
+    (l0, g0, arena), (l1, g1, _) = res
+    assert l0 == l1, (l0, l1)
+    up = torch.zeros(g0.numel(), dtype=torch.bool, device="cuda")          # upstream of the FPN levels
+    tables = torch.zeros_like(up)
+    for n, o, z in zip(arena.names, arena.offsets, arena.sizes):
+        if n.startswith("backbone."):
+            up[o:o + z] = True
+        if "relative_position_bias_table" in n:
+            tables[o:o + z] = True
+    assert bool(up.any()) and bool((~up).any())
+    assert torch.equal(g0[~up], g1[~up])
+    a, b = g0[up & ~tables].double(), g1[up & ~tables].double()
+    # measured 8e-3: one-ulp differences of the bf16 level gradients, carried through the FPN and the backbone's backward in bf16 storage
+    assert float((a - b).norm() / a.norm()) <= 2e-2
+    assert float(a.norm()) > 0

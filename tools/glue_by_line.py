@@ -38,6 +38,8 @@ cfg.merge_from_list(["MODEL.SWIN.SIZE", a.swin, "MODEL.ROI_BOX_HEAD.CAT_FREQ_PAT
                      os.path.join(ROOT, "configs", "metadata", "ImageNet2012_filtered04_lvis_v1_train_cat_info_250.json")])
 torch.manual_seed(42)
 model = build_model(cfg).train()
+model.early_proposal_backward = True
+from divergen_amd.engine import total_loss  # noqa: E402
 opt = build_optimizer(cfg, model)
 batch = synthetic_batch(2, a.size, cfg.MODEL.ROI_HEADS.NUM_CLASSES, device="cuda")
 
@@ -67,21 +69,22 @@ class Count(TorchDispatchMode):
             if "/divergen_amd/" in fr.filename and "tools/" not in fr.filename:
                 site = "%s:%d %s" % (fr.filename.split("/divergen_amd/")[-1], fr.lineno, fr.name)
                 break
-        if site is None:
-            site = "[%s, no divergen_amd frame]" % self.phase
+        if site is None:      # autograd's own arithmetic: name it by operand shapes
+            shp = ["x".join(map(str, x.shape)) + ":" + str(x.dtype).replace("torch.", "") for x in flat[:3]]
+            site = "[%s, no divergen_amd frame] %s" % (self.phase, " ".join(shp))
         self.rows[(self.phase, site)][name.replace("aten::", "")] += 1
         return out
 
 
 with EventStorage(0):
     for _ in range(2):
-        opt.zero_grad(); l = model(batch); sum(l.values()).backward(); opt.step()
+        opt.zero_grad(); l = model(batch); total_loss(l).backward(); opt.step()
     torch.cuda.synchronize()
     cnt = Count()
     with cnt:
         opt.zero_grad()
         l = model(batch)
-        tot = sum(l.values())
+        tot = total_loss(l)
         cnt.phase = "bwd"
         tot.backward()
         cnt.phase = "opt"

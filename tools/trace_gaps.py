@@ -60,6 +60,14 @@ print("idle per segment (first occurrence of each marker kernel in the step):")
 for k in ["start"] + ["from " + m for m in marks]:
     if k in seg_len:
         print("  %-34s length %7.2f ms  idle %6.3f ms" % (k, seg_len[k] / 1e3 / nst, seg_idle.get(k, 0.0) / 1e3 / nst))
+pair = {}
+for g, p_, n_ in big:
+    a_ = pair.setdefault((p_, n_), [0, 0.0])
+    a_[0] += 1
+    a_[1] += g
+print("idle by (kernel before -> kernel after), us per step (count per step):")
+for (p_, n_), (c_, g_) in sorted(pair.items(), key=lambda kv: -kv[1][1])[:40]:
+    print("  %8.1f  (%4.1f)  %s -> %s" % (g_ / nst, c_ / nst, p_, n_))
 print("largest gaps (us, kernel before -> kernel after):")
-for g, p, n in sorted(big, reverse=True)[:25]:
+for g, p, n in sorted(big, reverse=True)[:12]:
     print("  %8.1f  %s -> %s" % (g, p, n))

@@ -26,7 +26,7 @@ import torch  # noqa: E402
 from divergen_amd.checkpoint import DetectionCheckpointer, PeriodicCheckpointer  # noqa: E402
 from divergen_amd.config import add_bsgal_config, add_centernet_config, add_divergen_config, get_cfg  # noqa: E402
 from divergen_amd.data import synthetic_batch  # noqa: E402
-from divergen_amd.engine import ArenaReducer, default_argument_parser, launch  # noqa: E402
+from divergen_amd.engine import ArenaReducer, default_argument_parser, launch, total_loss  # noqa: E402
 from divergen_amd.modeling import build_model  # noqa: E402
 from divergen_amd.solver import build_lr_scheduler, build_optimizer  # noqa: E402
 from divergen_amd.utils import comm  # noqa: E402
@@ -131,6 +131,9 @@ def do_train(cfg, model, resume=False):
     optimizer = build_optimizer(cfg, model)
     scheduler = build_lr_scheduler(cfg, optimizer)
     reducer = ArenaReducer(optimizer.arena)
+    # this loop back-propagates the plain sum of the loss dict once per zero_grad: the proposal generator's part may run from inside
+    # the forward, ahead of the RoI heads' device->host read (meta_arch/custom_rcnn.py)
+    model.early_proposal_backward = True
     if cfg.INPUT.get("ACTIVE_SELECT", False):
         # BSGAL (BS/train_net.py:358-557 + the selection inside its CustomRCNN.forward): the model decides per step whether the
         # pasted batch or its un-pasted original is trained on; needs the parameter arena, hence attached here
@@ -166,7 +169,7 @@ def do_train(cfg, model, resume=False):
             storage.step()
             optimizer.zero_grad()
             loss_dict = model(data)
-            losses = sum(loss_dict.values())
+            losses = total_loss(loss_dict)
             pending.append((iteration, {k: v.detach() for k, v in loss_dict.items()}))
             # DG/train_net.py:266 asserts isfinite(losses) before backward; here the flag stays on the device (no sync): a
             # non-finite loss makes the optimizer kernel skip the weights, moments and EMA of this step (found_inf), and the

@@ -11,16 +11,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from divergen_amd.config import get_cfg  # noqa: E402
 from divergen_amd.data import synthetic_batch  # noqa: E402
+from divergen_amd.engine import total_loss  # noqa: E402
 from divergen_amd.modeling import build_model  # noqa: E402
 from divergen_amd.solver import build_optimizer  # noqa: E402
 from divergen_amd.utils.events import EventStorage  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+ONLY = sys.argv[2] if len(sys.argv) > 2 else ""       # "roi": profile only inside roi_heads.forward (the host-bound part of the step)
 cfg = get_cfg()
 cfg.merge_from_file(os.path.join(ROOT, "configs/DiverGen_swinL.yaml"))
 cfg.merge_from_list(["MODEL.ROI_BOX_HEAD.CAT_FREQ_PATH", os.path.join(ROOT, "configs/metadata/ImageNet2012_filtered04_lvis_v1_train_cat_info_250.json")])
 torch.manual_seed(42)
 model = build_model(cfg).train()
+model.early_proposal_backward = True
 opt = build_optimizer(cfg, model)
 batch = synthetic_batch(2, 1024, cfg.MODEL.ROI_HEADS.NUM_CLASSES, device="cuda")
 
@@ -28,7 +31,7 @@ batch = synthetic_batch(2, 1024, cfg.MODEL.ROI_HEADS.NUM_CLASSES, device="cuda")
 def step():
     opt.zero_grad()
     losses = model(batch)
-    sum(losses.values()).backward()
+    total_loss(losses).backward()
     opt.step()
 
 
@@ -37,7 +40,18 @@ with EventStorage(0):
         step()
     torch.cuda.synchronize()
     pr = cProfile.Profile()
-    pr.enable()
+    if ONLY == "roi":
+        inner = model.roi_heads.forward
+
+        def wrapped(*a, **k):
+            pr.enable()
+            try:
+                return inner(*a, **k)
+            finally:
+                pr.disable()
+        model.roi_heads.forward = wrapped
+    else:
+        pr.enable()
     for _ in range(N):
         step()
     pr.disable()

@@ -422,6 +422,7 @@ def main():
         opt.zero_grad()
         losses = model(batch)
         total = total_loss(losses)
+        reducer.begin_backward()
         total.backward()
         if exposed is not None:                 # N > 1: the time the training stream spends waiting for collectives BEHIND backward
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -226,6 +226,19 @@ _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 _cur_device = getattr(torch._C, "_cuda_getDevice", None)
 
 
+_RESERVED = [0]
+
+
+def set_reserved_cus(n):
+    """dgx_set_reserved_cus with the value remembered on this side (utils/graphs.py restores it around a capture)."""
+    lib().dgx_set_reserved_cus(int(n))
+    _RESERVED[0] = int(n)
+
+
+def reserved_cus():
+    return _RESERVED[0]
+
+
 def stream():
     """hipStream_t of torch's current stream on the current device.  `torch.cuda.current_stream().cuda_stream` builds a Stream
     object through five layers of Python (device-index resolution, availability probes, an os.environ lookup): 9 us per call,

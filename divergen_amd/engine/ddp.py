@@ -69,9 +69,14 @@ class ArenaReducer:
                               "and bench.py export it before init_process_group) -- if a collective has already run, RCCL keeps its own "
                               "channel count and its channels will contend with the persistent GEMM workgroups")
             self.reserved_cus = int(os.environ["NCCL_MAX_NCHANNELS"])
+        # The CUs are left to RCCL only while collectives can be in flight -- from the start of backward (`begin_backward`, or the first
+        # bucket of a loop that does not announce it) to `finish()`: forward and optimizer run on all 256.  hipGraph segments fix their
+        # grids at capture, and their backward graphs replay beside the collectives: they are captured at the reduced width.
+        self._cus_on = False
         if arena.g.is_cuda:      # process-global in libdgx: an inactive / single-rank reducer gives the CUs back
-            from .. import _lib as L
-            L.lib().dgx_set_reserved_cus(self.reserved_cus)
+            from ..utils import graphs
+            graphs.CAPTURE_RESERVED_CUS = self.reserved_cus
+            self._reserve(False)
         if self.active:
             for i, p in enumerate(arena.params):
                 hook = self._make_hook(i)
@@ -79,6 +84,17 @@ class ArenaReducer:
                 # ops that write their gradient straight into the arena (layers/linear_ops.py) bypass
                 # AccumulateGrad and call this instead
                 p._dgx_ready = (lambda h=hook: h(None))
+
+    def _reserve(self, on):
+        if self.arena.g.is_cuda:
+            from .. import _lib as L
+            L.set_reserved_cus(self.reserved_cus if on else 0)
+        self._cus_on = bool(on)
+
+    def begin_backward(self):
+        """Call right before `loss.backward()`: from here to `finish()` the persistent kernels leave `reserved_cus` CUs to RCCL."""
+        if self.active and self.reserved_cus and not self._cus_on:
+            self._reserve(True)
 
     def _make_hook(self, i):
         b = self.bucket_of[i]
@@ -106,6 +122,8 @@ class ArenaReducer:
         if self._launched[b]:
             return
         self._launched[b] = True
+        if self.reserved_cus and not self._cus_on:      # a loop that did not call begin_backward: from the first collective on
+            self._reserve(True)
         s, e, _ = self.buckets[b]
         self._works.append(dist.all_reduce(self.arena.g[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
@@ -134,6 +152,8 @@ class ArenaReducer:
             for w in self._works:
                 w.wait()
         self._works = []
+        if self._cus_on:
+            self._reserve(False)
         if self.active:
             if self._expected is None:
                 self._expected = list(self._got)

@@ -19,6 +19,7 @@ from ..layers import linear_ops
 from . import prof
 
 ENABLED = True
+CAPTURE_RESERVED_CUS = 0     # engine/ddp.ArenaReducer: the width (256 - this many CUs) the captured persistent kernels are launched at
 ALIAS_STATIC = True     # chained segments share their hand-over buffers
 
 
@@ -67,10 +68,16 @@ class GraphedSegment:
             warn = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
             if warn is not None:
                 warn(False)
+            from .. import _lib as L
+            width = L.reserved_cus()
+            if CAPTURE_RESERVED_CUS != width:
+                L.set_reserved_cus(CAPTURE_RESERVED_CUS)
             try:
                 with linear_ops.suspend_ready(), torch.autocast("cuda", enabled=False):
                     fn = torch.cuda.make_graphed_callables(self.module, sample, allow_unused_input=True)
             finally:
+                if CAPTURE_RESERVED_CUS != width:
+                    L.set_reserved_cus(width)
                 if warn is not None:
                     warn(True)
             if before is not None:      # heavy launches recorded into the two graphs (forward + backward): credited per replay

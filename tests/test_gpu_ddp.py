@@ -46,7 +46,9 @@ def _run(with_reducer, steps=3, swin="L-22k-384", size=1024, weights_in=None, ea
     reducer = ArenaReducer(opt.arena, single_rank_group=with_reducer)
     assert reducer.active == with_reducer
     if with_reducer:
-        L.lib().dgx_set_reserved_cus(16)          # what ArenaReducer does when the group has more than one rank
+        from divergen_amd.utils import graphs
+        reducer.reserved_cus = 16                 # what ArenaReducer takes from NCCL_MAX_NCHANNELS when the group has more than one rank:
+        graphs.CAPTURE_RESERVED_CUS = 16          # 16 CUs left alone from begin_backward() to finish(), graphs captured at that width
         reducer.broadcast_parameters()
     log, seq = [], [0]
     orig_w, orig_b = SB.wgrad_grouped, reducer._launch
@@ -83,15 +85,21 @@ def _run(with_reducer, steps=3, swin="L-22k-384", size=1024, weights_in=None, ea
                 del log[:]
                 opt.zero_grad()
                 losses = model(batch)
+                reducer.begin_backward()
+                assert L.reserved_cus() == (16 if with_reducer else 0)
                 total_loss(losses).backward()
                 scale = reducer.finish()
+                assert L.reserved_cus() == 0
                 torch.cuda.synchronize()
                 grads.append(opt.arena.g.clone())
                 per_step.append((list(log), reducer.last_early if with_reducer else 0))
                 opt.step(grad_scale=scale)
     finally:
         SB.wgrad_grouped = orig_w
-        L.lib().dgx_set_reserved_cus(0)
+        L.set_reserved_cus(0)
+        if with_reducer:
+            from divergen_amd.utils import graphs
+            graphs.CAPTURE_RESERVED_CUS = 0
     return opt, grads, per_step, reducer, weights
 
 

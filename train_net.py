@@ -175,6 +175,7 @@ def do_train(cfg, model, resume=False):
             # non-finite loss makes the optimizer kernel skip the weights, moments and EMA of this step (found_inf), and the
             # deferred host check below runs BEFORE the periodic checkpointer can save
             bad = reducer.agree_on_skip((~torch.isfinite(losses.detach())).to(torch.int32))      # every rank skips, or none
+            reducer.begin_backward()
             losses.backward()
             scale = reducer.finish()
             optimizer.step(grad_scale=scale, found_inf=bad)   # EMA of the pre-step weights + clip + AdamW, one kernel

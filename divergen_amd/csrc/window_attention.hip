@@ -230,7 +230,7 @@ template <int WS, bool MASKED, bool HELP = false>
 __global__ __launch_bounds__((WinCfg<WS>::NT + (HELP ? 3 : 0)) * 64) void win_attn_bwd_kernel(
     const uint16_t* __restrict__ qkv, const float* __restrict__ table, const int8_t* __restrict__ region,
     const uint16_t* __restrict__ out, const float* __restrict__ lse, const uint16_t* __restrict__ dout,
-    uint16_t* __restrict__ dqkv, float* __restrict__ dtable, int B_, int nW, int nH, float scale, int chunk,
+    uint16_t* __restrict__ dqkv, float* __restrict__ dtable, int B_, int nW, int nH, float scale, int upw, int upl, float* __restrict__ part_ws, int* __restrict__ head_cnt,
     int64_t dt_sh, int64_t dt_si) {
     using Cf = WinCfg<WS>;
     constexpr int N = Cf::N, NT = Cf::NT, NTK = Cf::NTK, NP = NTK * 16, TBL = Cf::TBL;
@@ -263,9 +263,25 @@ __global__ __launch_bounds__((WinCfg<WS>::NT + (HELP ? 3 : 0)) * 64) void win_at
     float* tbl4 = part_s + (HELP ? 3 * 4 * 64 * 4 : 0);           // [4][TBLS]
     uint16_t* Vs = reinterpret_cast<uint16_t*>(tbl4 + (PK ? 4 * TBLS : 0));     // [NP][RR] row-major V
 
-    const int h = blockIdx.x % nH;
-    const int b0 = (blockIdx.x / nH) * chunk;
-    const int b1 = min(B_, b0 + chunk);
+    // Runs of `upw` (window, head) units per workgroup.  Each head's B_ windows are cut into q = B_ / upw full runs, served by the first
+    // q * nH workgroups -- neighbouring workgroups take the SAME windows of different heads (together they read whole qkv rows; a head-major
+    // order, every workgroup on its own windows, ran 30-45 % slower) -- and the B_ % upw windows left over per head are strung together
+    // head-major into further runs of `upl` units, which cross a head boundary every B_ % upw units: there the bias-gradient row is flushed
+    // and the next head's bias row loaded (~10 us: these runs are kept SHORT -- upl fills the CUs the full runs leave -- so that they end
+    // with the full runs in spite of it).  Binding every workgroup to one head (round 4) left Swin-L stage 2 (72 windows x 24 heads) at 216
+    // workgroups of 8 units on 256 CUs; this gives 240 runs of 7 + 16 of 3.
+    const int q_runs = B_ / upw, main_wgs = q_runs * nH, left = B_ - q_runs * upw;
+    int h, b, lo, hi, count;             // current unit, the window range [lo, hi) the run walks per head, units in the run
+    if ((int)blockIdx.x < main_wgs) {
+        h = (int)blockIdx.x % nH;
+        lo = ((int)blockIdx.x / nH) * upw; hi = lo + upw;
+        b = lo; count = upw;
+    } else {
+        const int j0 = ((int)blockIdx.x - main_wgs) * upl;           // first leftover unit of this run; unit j = (head j / left, window lo + j % left)
+        lo = q_runs * upw; hi = B_;
+        h = j0 / left; b = lo + (j0 - h * left);
+        count = min(upl, nH * left - j0);
+    }
     const int C = nH * 32;
     const int64_t rowst = 3 * (int64_t)C;
     const int tid = threadIdx.x, nthreads = (NT + (HELP ? 3 : 0)) * 64;
@@ -301,7 +317,7 @@ __global__ __launch_bounds__((WinCfg<WS>::NT + (HELP ? 3 : 0)) * 64) void win_at
     const uint32_t st_qk_c = (uint32_t)(srow * (int)rowst + 8 * sc);     // staging chunk inside this window's qkv rows
     const uint32_t st_o_c = (uint32_t)(srow * C + 8 * sc);               // ... inside out / dout rows
     const uint32_t row4_c = (uint32_t)((kok ? key : 0) * (int)rowst + 4 * g);   // output row = this lane's key / query, entries 4g ..
-    auto issue = [&](int b, BwdPrefetch& P) {
+    auto issue = [&](int b, int h, BwdPrefetch& P) {
         const uint16_t* base = qkv + (int64_t)b * N * rowst + h * 32;
         const uint16_t* dob = dout + (int64_t)b * N * C + h * 32;
         const uint16_t* ob = out + (int64_t)b * N * C + h * 32;
@@ -327,10 +343,45 @@ __global__ __launch_bounds__((WinCfg<WS>::NT + (HELP ? 3 : 0)) * 64) void win_at
         // Rows past the window (window 7 only) are zeroed where the fragment is consumed.)
     };
 
-    // ---- one-time LDS setup: bias row, zero padding rows/columns, rel-pos offsets
-    for (int i = tid; i < TBL; i += nthreads) { tbl[i] = table[h * dt_sh + i * dt_si] * DGX_LOG2E; tblacc[i] = 0.f; }   // log2 domain
-    for (int i = tid; i < (NP - N) * RR; i += nthreads) { Qs[N * RR + i] = 0; dOs[N * RR + i] = 0; Ks[N * RR + i] = 0; Vs[N * RR + i] = 0; }
-    for (int i = tid; i < (NP - N) * RD; i += nthreads) dSt[N * RD + i] = 0;   // padded key rows feed the last K=32 step of dQ
+    // ---- LDS setup: the head's bias row (again at a head boundary inside the run), once: zero padding rows/columns, rel-pos offsets
+    // The row is read from memory ONCE, every lane's entries requested before the first is used, and the four shifted copies are made
+    // from the LDS copy: as five loops of `load, wait, write` per entry (round 4) this prologue cost every workgroup 4-5 memory round trips
+    // in series -- ~20 us of a 56-94 us launch (the per-window clocks of r05_attn_bwd_phases.txt add up to 28-40 us).
+    BwdPrefetch P;
+    {
+        const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        P.q = P.d = P.o = P.k = P.v = z;
+        P.lse = INFINITY;
+        P.reg = 0;
+    }
+    if (count > 0) issue(b, h, P);       // the first window's operands fly under the whole prologue
+    auto load_head = [&](int hh) {
+        constexpr int NTHR = (NT + (HELP ? 3 : 0)) * 64, KT = (TBL + NTHR - 1) / NTHR;
+        float tv[KT];
+#pragma unroll
+        for (int k = 0; k < KT; ++k) {
+            const int i = tid + k * NTHR;
+            tv[k] = table[hh * dt_sh + (i < TBL ? i : 0) * dt_si];
+        }
+#pragma unroll
+        for (int k = 0; k < KT; ++k) {
+            const int i = tid + k * NTHR;
+            if (i < TBL) { tbl[i] = tv[k] * DGX_LOG2E; tblacc[i] = 0.f; }      // log2 domain
+        }
+        if (PK) {
+            __syncthreads();
+            for (int i = tid; i < 4 * TBLS; i += nthreads) {
+                const int sft = i / TBLS, j = i - sft * TBLS + sft;
+                tbl4[i] = j < TBL ? tbl[j] : 0.f;
+            }
+        }
+    };
+    load_head(h);
+    auto zero_pads = [&]() {             // (window 7: rows N .. NP of the images; window 12 has none)
+        for (int i = tid; i < (NP - N) * RR; i += nthreads) { Qs[N * RR + i] = 0; dOs[N * RR + i] = 0; Ks[N * RR + i] = 0; Vs[N * RR + i] = 0; }
+        for (int i = tid; i < (NP - N) * RD; i += nthreads) dSt[N * RD + i] = 0;   // padded key rows feed the last K=32 step of dQ
+    };
+    zero_pads();
     for (int i = tid; i < NP; i += nthreads) {
         const int yq = i / WS;
         qoff_s[i] = i < N ? yq * (2 * WS - 1) + (i - yq * WS) : 0;
@@ -340,11 +391,6 @@ __global__ __launch_bounds__((WinCfg<WS>::NT + (HELP ? 3 : 0)) * 64) void win_at
             reg_s[i] = 0;
         }
     }
-    if (PK)
-        for (int i = tid; i < 4 * TBLS; i += nthreads) {
-            const int sft = i / TBLS, j = i - sft * TBLS + sft;
-            tbl4[i] = j < TBL ? table[h * dt_sh + j * dt_si] * DGX_LOG2E : 0.f;
-        }
     const int yk = key / WS, xk = key - yk * WS;
     const int kbase = kok ? (WS - 1) * (2 * WS - 1) + (WS - 1) - (yk * (2 * WS - 1) + xk) : 0;
     const float kneg = kok ? 0.0f : -INFINITY;   // padded key columns: p = 0
@@ -363,14 +409,6 @@ __global__ __launch_bounds__((WinCfg<WS>::NT + (HELP ? 3 : 0)) * 64) void win_at
 #pragma unroll
         for (int r = 0; r < 4; ++r) dbias[i][r] = 0.f;
 
-    BwdPrefetch P;
-    {
-        const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-        P.q = P.d = P.o = P.k = P.v = z;
-        P.lse = INFINITY;
-        P.reg = 0;
-    }
-    if (b0 < b1) issue(b0, P);
     // The window loop is ROTATED: staging of window b + 1 closes iteration b.  With the staging at the top, the compiler's wait-count
     // model merged the pre-loop path (prefetch in flight, nothing behind it) into the loop header and waited `vmcnt(3..0)` there -- in
     // steady state that is "all loads AND the previous window's six dQ / dK / dV stores complete": the stores' latency was exposed in
@@ -398,8 +436,84 @@ __global__ __launch_bounds__((WinCfg<WS>::NT + (HELP ? 3 : 0)) * 64) void win_at
             }
         }
     };
-    if (b0 < b1) stage();
-    for (int b = b0; b < b1; ++b) {
+    // Bias gradient of head hh.  A lane's 36 registers are the entries dS_sum[q][key] of the run's summed dS for its key and its queries;
+    // entry (dy, dx) of the bias row is the sum of dS_sum over the pairs with yq - yk = dy, xq - xk = dx (1 .. N pairs).  The registers
+    // are WRITTEN as the N x N matrix over the staging images (free between two windows), and one lane per table entry adds its pairs
+    // up in a fixed order.  Rounds 2-4 reduced them with `ds_add_f32` into an LDS table: LDS float atomics whose lanes share
+    // addresses run at about one LANE per two cycles -- 27 600 of them cost every workgroup 24-27 us behind its last window, a third of the
+    // stage-2 launch (45 -> 73 us at 72 x 24; tools/r05_attn_sw.sh ablations; the global float atomics behind them cost 2 us).
+    // The entries then go to this run's slot of the workspace, and the LAST of the runs that hold a part of head hh (a device counter per
+    // head tells which one that is) adds the slots up in slot order onto dtable: one atomic per run and head, and a sum that no longer
+    // depends on the order of arrival.  The registers start again at zero.
+    constexpr int TBLP = (TBL + 3) / 4 * 4;          // stride of a slot
+    constexpr int LDM = N + 1;                       // row stride of the matrix (odd: the 16 keys of a wave's store land in 16 banks)
+    static_assert((size_t)N * LDM * 4 <= (size_t)(3 * NP * RR + NP * RD) * 2, "the pair matrix lies over the Q / dO / K / dS^T images");
+    const int slots_per_head = q_runs + (left > 0 ? (left + upl - 1) / upl + 1 : 0);      // the head's full runs + the runs over its left-over windows
+    __shared__ int last_s;
+    auto flush_head = [&](int hh) {
+        constexpr int TSPLIT_Q = 3;      // = TSPLIT of the window loop
+        DGX_LDS float* M = reinterpret_cast<DGX_LDS float*>(lds_opaque(Qs));
+        if (kok) {
+#pragma unroll
+            for (int qt = 0; qt < NT; ++qt) {
+                if (HELP && (qt < 2 * TSPLIT_Q ? helper : shared)) continue;      // the other wave of the strip holds these terms
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int q = 16 * qt + 4 * g + r;
+                    if (q < N) M[key * LDM + q] = dbias[qt][r];
+                    dbias[qt][r] = 0.f;
+                }
+            }
+        }
+        __syncthreads();
+        // the runs over head hh's left-over windows: units [hh * left, (hh + 1) * left) of the left-over list, run = unit / upl
+        const int lrun0 = left > 0 ? (hh * left) / upl : 0;
+        const int nlrun = left > 0 ? ((hh + 1) * left - 1) / upl - lrun0 + 1 : 0;
+        const int slot = (int)blockIdx.x < main_wgs ? (int)blockIdx.x / nH : q_runs + ((int)blockIdx.x - main_wgs - lrun0);
+        float* mine = part_ws + ((int64_t)hh * slots_per_head + slot) * TBLP;
+        // Slots and counter are DEVICE-scope accesses (write-through stores, L2-bypassing loads: the runs of a head sit on different XCDs,
+        // whose L2s do not snoop each other), ordered by completion: every store of the slot is acknowledged (vmcnt 0) before the barrier
+        // behind which the counter moves, and the slots are read behind the counter's return.  A device-scope FENCE here (__threadfence)
+        // writes back the whole L2 -- full of this kernel's dq / dk / dv rows -- and cost 40 us per flush.
+        for (int i = tid; i < TBL; i += nthreads) {
+            const int iy = i / (2 * WS - 1), dy = iy - (WS - 1), dx = i - iy * (2 * WS - 1) - (WS - 1);
+            const int yk0 = dy < 0 ? -dy : 0, yk1 = dy > 0 ? WS - dy : WS, xk0 = dx < 0 ? -dx : 0, xk1 = dx > 0 ? WS - dx : WS;
+            float sum = 0.f;
+            for (int yk = yk0; yk < yk1; ++yk) {
+                DGX_LDS const float* row = M + (yk * WS) * LDM + (yk + dy) * WS + dx;        // + xk * (LDM + 1)
+                for (int xk = xk0; xk < xk1; ++xk) sum += row[xk * (LDM + 1)];
+            }
+            __hip_atomic_store(mine + i, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                 // (the matrix has been read: the images may be staged again)
+        if (tid == 0) last_s = __hip_atomic_fetch_add(&head_cnt[hh], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == q_runs + nlrun - 1;
+        __syncthreads();
+        if (last_s) {
+            const float* p0 = part_ws + (int64_t)hh * slots_per_head * TBLP;
+            const int ns = q_runs + nlrun;
+            for (int i = tid; i < TBL; i += nthreads) {
+                float sum = dtable[hh * dt_sh + i * dt_si];
+                for (int s0 = 0; s0 < ns; s0 += 16) {          // sixteen slots requested before the first is added: one round trip per batch
+                    float v[16];
+#pragma unroll
+                    for (int k = 0; k < 16; ++k)
+                        v[k] = __hip_atomic_load(p0 + (s0 + k < ns ? s0 + k : s0) * TBLP + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) sum += s0 + k < ns ? v[k] : 0.f;
+                }
+                dtable[hh * dt_sh + i * dt_si] = sum;
+            }
+            if (tid == 0) __hip_atomic_store(&head_cnt[hh], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch on this stream
+        }
+    };
+    if (count > 0) stage();
+    int h_last = h;
+    for (int u = 0; u < count; ++u) {
+        const bool more = u + 1 < count;
+        const bool wrap = b + 1 == hi;
+        const int bn = wrap ? lo : b + 1, hn = wrap ? h + 1 : h;     // the next unit of the run
+        h_last = h;
 #ifdef DIAG_CLOCK
         unsigned long long tprev = clock64();
 #endif
@@ -407,7 +521,7 @@ __global__ __launch_bounds__((WinCfg<WS>::NT + (HELP ? 3 : 0)) * 64) void win_at
         __syncthreads();
         CLK(1);
 #if !defined(PREFETCH_LATE)
-        if (b + 1 < b1) issue(b + 1, P);   // next window's loads fly under this window's math
+        if (more) issue(bn, hn, P);   // next window's loads fly under this window's math
 #endif
         const bf16x8 kf = *reinterpret_cast<const bf16x8*>(&Ks[(kok ? key : 0) * RR + 8 * g]);
         const bf16x8 vf = *reinterpret_cast<const bf16x8*>(&Vs[(kok ? key : 0) * RR + 8 * g]);
@@ -533,7 +647,7 @@ __global__ __launch_bounds__((WinCfg<WS>::NT + (HELP ? 3 : 0)) * 64) void win_at
         u32x2 dqpk[2] = {{0u, 0u}, {0u, 0u}};
         if (!helper) {                   // phase 2 belongs to the nine query strips
 #if defined(PREFETCH_LATE)
-        if (b + 1 < b1) issue(b + 1, P);   // next window's loads fly under phase 2 (phase 1 has no registers to spare)
+        if (more) issue(bn, hn, P);   // next window's loads fly under phase 2 (phase 1 has no registers to spare)
 #endif
         // ---- phase 2: dQ strip w = dS[16w.., :] K ; A = dS rows (queries 16w + c16) out of the key-major image
         f32x4 dQ[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -550,7 +664,12 @@ __global__ __launch_bounds__((WinCfg<WS>::NT + (HELP ? 3 : 0)) * 64) void win_at
         CLK(6);
         }
         __syncthreads();                 // this window's LDS consumers are done
-        if (b + 1 < b1) stage();
+        if (more && wrap) {              // head boundary inside the run: nobody reads the bias row until the barrier at the top of the loop
+            flush_head(h);               // (its matrix lay over the images' padding rows)
+            if (NP > N) zero_pads();
+            load_head(hn);
+        }
+        if (more) stage();
         // the dQ rows leave BEHIND the staging of the next window: the staging waits for its prefetch with vmcnt counts that also
         // cover every store issued before it (one in-order counter), and stores issued a few cycles earlier would put their whole
         // latency in front of it; the dK / dV stores are a phase 2 old by then
@@ -558,24 +677,10 @@ __global__ __launch_bounds__((WinCfg<WS>::NT + (HELP ? 3 : 0)) * 64) void win_at
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) *reinterpret_cast<u32x2*>(dqb + row4 + 16 * dt) = dqpk[dt];
         }
+        b = bn;
+        h = hn;
     }
-    // ---- relative-position-bias gradient: registers -> LDS table (ds_add_f32) -> global atomics
-    constexpr int TSPLIT_Q = 3;      // = TSPLIT of the window loop
-    int kb = kbase;
-    asm volatile("" : "+v"(kb));   // opaque: keeps the 36 scatter addresses from being hoisted above the window loop
-    if (kok) {
-#pragma unroll
-        for (int qt = 0; qt < NT; ++qt) {
-            if (HELP && (qt < 2 * TSPLIT_Q ? helper : shared)) continue;      // the other wave of the strip holds these terms
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int q = 16 * qt + 4 * g + r;
-                if (q < N) atomicAdd(&tblacc[kb + qoff_s[q]], dbias[qt][r]);
-            }
-        }
-    }
-    __syncthreads();
-    for (int i = tid; i < TBL; i += nthreads) atomicAdd(&dtable[h * dt_sh + i * dt_si], tblacc[i]);
+    if (count > 0) flush_head(h_last);
 }
 
 template <int WS>
@@ -584,6 +689,30 @@ static size_t bwd_smem_bytes(bool help = false) {
     constexpr int NP = Cf::NTK * 16;
     return (size_t)(3 * NP * (WS == 12 ? 48 : 40) + NP * (WS == 12 ? 184 : NP + 8)) * 2 + (size_t)(4 * NP + 2 * Cf::TBL) * 4 + 64 + (help ? 16 + 3 * 4 * 64 * 16 : 0) +
            (WS == 12 ? 16 + 4 * ((Cf::TBL + 6) / 4 * 4) * 4 : 0) + (size_t)NP * (WS == 12 ? 48 : 40) * 2;
+}
+
+// Workspace of the backward kernel's bias-gradient reduction: one slot of TBL floats per (head, run) and a counter per head, zero between
+// launches (the last run of a head resets it).  One per stream: launches on ONE stream are ordered, launches on different streams must not
+// share slots.  Allocated at the first call on a stream (outside any graph capture: the backbone's attention is launched eagerly).
+struct BwdTableWs { float* part; int* cnt; int64_t floats; int heads; };
+#include <map>
+#include <mutex>
+static BwdTableWs* bwd_table_ws(hipStream_t st, int64_t floats, int heads) {
+    static std::map<hipStream_t, BwdTableWs> pool;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    BwdTableWs& w = pool[st];
+    if (w.part && w.floats >= floats && w.heads >= heads) return &w;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) return nullptr;      // no allocation inside a capture
+    if (w.part) { (void)hipStreamSynchronize(st); (void)hipFree(w.part); (void)hipFree(w.cnt); w.part = nullptr; w.cnt = nullptr; }
+    const int64_t nf = floats > (int64_t)300 * 532 ? floats : (int64_t)300 * 532;     // every Swin-L / Swin-T launch shape fits the first allocation
+    const int nh = heads > 64 ? heads : 64;
+    if (hipMalloc((void**)&w.part, (size_t)nf * 4) != hipSuccess) { w.part = nullptr; return nullptr; }
+    if (hipMalloc((void**)&w.cnt, (size_t)nh * 4) != hipSuccess) { (void)hipFree(w.part); w.part = nullptr; return nullptr; }
+    (void)hipMemset(w.cnt, 0, (size_t)nh * 4);
+    w.floats = nf; w.heads = nh;
+    return &w;
 }
 
 // NULL region (W-MSA) is served by a process-lifetime all-zero row: one code path in the kernels
@@ -631,17 +760,30 @@ extern "C" int dgx_window_attention_bwd(const void* qkv, const float* table, con
     hipStream_t st = (hipStream_t)stream;
     const bool masked = region != nullptr;
     if (!region) { region = zero_region(); nW = 1; if (!region) return DGX_ERR_BAD_ARG; }
-    // One workgroup per CU (LDS-limited) in a single round: per-workgroup setup (bias row, flush of the
-    // bias-gradient row) is amortised over the chunk; measured best among 256/512/768/2048 targets.
-    const int nchunks = nH >= 256 ? 1 : 256 / nH;
-    int chunk = (B_ + nchunks - 1) / nchunks;
-    if (chunk < 1) chunk = 1;
-    const int grid = ((B_ + chunk - 1) / chunk) * nH;
+    // One workgroup per CU (LDS-limited) in a single round: per-workgroup setup (bias row, flush of the bias-gradient row) is amortised
+    // over the run (measured best among 256/512/768/2048 workgroup targets), runs of equal length over the CUs the persistent kernels'
+    // reservation leaves (engine/ddp.py: RCCL's channels at N > 1); the kernel's header says how the runs are laid over windows and heads
+    extern int dgx_get_reserved_cus(void);
+    const int cus = 256 - dgx_get_reserved_cus();
+    const int64_t total = (int64_t)B_ * nH;
+    if (total > 0x7fffffff) return DGX_ERR_UNSUPPORTED;
+    int upw = (int)((total + cus - 1) / cus);
+    if (upw > B_) upw = B_;                                            // more heads than CUs: one run per head
+    const int left = B_ % upw, main_wgs = (B_ / upw) * nH;
+    int upl = upw;                                                     // length of the runs over the windows left per head: what fills
+    if (left > 0 && cus > main_wgs) {                                  // the CUs the full runs leave (see the kernel)
+        upl = (nH * left + (cus - main_wgs) - 1) / (cus - main_wgs);
+        if (upl > upw) upl = upw;
+    }
+    const int grid = main_wgs + (nH * left + upl - 1) / upl;
     // S, dP, dV, dK, dQ (5 x 2 N^2 32 FLOP per head); q, k, v, out, dout in + dq, dk, dv out (bf16) + lse
     const double heads = (double)B_ * nH, ntok = (double)ws * ws;
     DgxProfScope prof(DGX_PROF_ATTN_BWD, stream, heads * 5.0 * 2.0 * ntok * ntok * 32.0, heads * ntok * (32.0 * 2.0 * 8.0 + 4.0));
+    const int64_t tblp = ((2 * ws - 1) * (2 * ws - 1) + 3) / 4 * 4;
+    BwdTableWs* tw = bwd_table_ws(st, (int64_t)nH * (B_ / upw + (left > 0 ? (left + upl - 1) / upl + 1 : 0)) * tblp, nH);
+    if (!tw) return DGX_ERR_UNSUPPORTED;
 #define BWD_ARGS (const uint16_t*)qkv, table, region, (const uint16_t*)out, lse, (const uint16_t*)dout, (uint16_t*)dqkv, dtable, B_, nW, nH, \
-                 scale, chunk, dtable_stride_head, dtable_stride_index
+                 scale, upw, upl, tw->part, tw->cnt, dtable_stride_head, dtable_stride_index
     if (ws == 12) {
         static bool once = false;
         const size_t sm = bwd_smem_bytes<12>(true);

@@ -63,6 +63,49 @@ def test_window_attention_at_bench_geometry(B_, nH, H, masked):
     close(td.grad.cpu(), tr.grad, 0.015, 6e-3, "dtable")
 
 
+@pytest.mark.parametrize("ws,B_,nH,reserved", [(12, 74, 24, 0), (12, 72, 24, 16), (12, 13, 48, 0), (7, 103, 24, 0), (7, 5, 3, 0)])
+def test_window_attention_backward_runs_across_heads(ws, B_, nH, reserved):
+    """The backward kernel's workgroups walk runs of (window, head) units; the runs over the windows a head has left after its full runs
+    cross head boundaries: the bias-gradient row is flushed (pair matrix over the staging images, one lane per table entry, slot in the
+    workspace, the last run of a head adds the slots up) and the next head's bias row loaded in the middle of a run.  Shapes whose runs
+    do that (74 x 24: 240 runs of 7 + 16 of 6 over 4 left-over windows per head; 13 x 48 and window 7 at 103 x 24 likewise -- window 7
+    also re-zeroes the images' padding rows behind the matrix), the stage-2 shape on the grid the data-parallel reducer leaves
+    (`dgx_set_reserved_cus(16)`: 216 runs of 8), and a launch with fewer units than CUs: dqkv and the table gradient against the fp32
+    oracle math, the table gradient BIT-identical from run to run (it was a sum of float atomics in arrival order before round 5),
+    and -- the gradient is ADDED to what the table's gradient holds -- twice the value after a second backward."""
+    from divergen_amd import _lib as L
+    N = ws * ws
+    g = torch.Generator().manual_seed(B_ * 7 + nH)
+    qkv = bf(torch.randn(B_, N, 3 * nH * 32, generator=g) * 1.5)
+    table = torch.randn((2 * ws - 1) ** 2, nH, generator=g)
+    scale = 32 ** -0.5
+    go = bf(torch.randn(B_, N, nH * 32, generator=g))
+    qr = qkv.clone().float().requires_grad_(True)
+    tr = table.clone().requires_grad_(True)
+    _attn_ref(qr, tr, None, nH, ws, scale).backward(go.float())
+
+    def run(twice=False):
+        qd = qkv.to(DEV).requires_grad_(True)
+        td = table.to(DEV).requires_grad_(True)
+        out = la.window_attention_core(qd, td, None, 1, nH, ws, scale)
+        out.backward(go.to(DEV), retain_graph=twice)
+        if twice:
+            out.backward(go.to(DEV))
+        torch.cuda.synchronize()
+        return qd.grad.float().cpu(), td.grad.cpu()
+    L.set_reserved_cus(reserved)
+    try:
+        (dq, dt), (dq2, dt2), (_, dt3) = run(), run(), run(twice=True)
+    finally:
+        L.set_reserved_cus(0)
+    assert torch.equal(dt, dt2) and torch.equal(dq, dq2)
+    for a, b, what in ((dq, qr.grad, "dqkv"), (dt, tr.grad, "dtable")):
+        err, sc = float((a - b).abs().max()), float(b.abs().max())
+        r2 = float((a - b).double().norm() / b.double().norm())
+        assert err <= 0.015 * sc and r2 <= 6e-3, (what, err, sc, r2)
+    assert float((dt3 - 2 * dt).abs().max()) <= 1e-5 * float(dt.abs().max())
+
+
 def test_swinL_stage0_layer_pair_vs_oracle():
     """BasicLayer of Swin-L stage 0 at 1024 px: 256x256 tokens (padded to 264 for window 12), C = 192, 6 heads, one W-MSA
     and one SW-MSA block + PatchMerging, one image; product under bf16 autocast (fused block path through the arenas) vs

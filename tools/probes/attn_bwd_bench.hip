@@ -1,7 +1,8 @@
 // Standalone timing harness for the window-attention kernels (no torch): hipcc -DDIAG_CLOCK -DDIAG_WAVE=0 ...
+#include <cstdlib>
 #include "../../divergen_amd/csrc/window_attention.hip"
 #include <cstdio>
-#include <cstdlib>
+extern "C" int dgx_get_reserved_cus(void) { return getenv("RESERVED_CUS") ? atoi(getenv("RESERVED_CUS")) : 0; }   // (libdgx: gemm_lw.hip)
 #include <vector>
 int main(int argc, char** argv) {
     const int B_ = argc > 1 ? atoi(argv[1]) : 968, nH = argc > 2 ? atoi(argv[2]) : 6, N = 144, C = nH * 32;

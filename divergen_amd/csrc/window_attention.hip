@@ -10,6 +10,8 @@
 // once for dQ = dS K.
 #include "dgx_common.h"
 #include <type_traits>
+#include <map>
+#include <mutex>
 typedef float wa_f32x2 __attribute__((ext_vector_type(2)));
 
 template <int WS> struct WinCfg;
@@ -695,8 +697,6 @@ static size_t bwd_smem_bytes(bool help = false) {
 // launches (the last run of a head resets it).  One per stream: launches on ONE stream are ordered, launches on different streams must not
 // share slots.  Allocated at the first call on a stream (outside any graph capture: the backbone's attention is launched eagerly).
 struct BwdTableWs { float* part; int* cnt; int64_t floats; int heads; };
-#include <map>
-#include <mutex>
 static BwdTableWs* bwd_table_ws(hipStream_t st, int64_t floats, int heads) {
     static std::map<hipStream_t, BwdTableWs> pool;
     static std::mutex mu;

@@ -455,6 +455,8 @@ __global__ __launch_bounds__((WinCfg<WS>::NT + (HELP ? 3 : 0)) * 64) void win_at
     auto flush_head = [&](int hh) {
         constexpr int TSPLIT_Q = 3;      // = TSPLIT of the window loop
         DGX_LDS float* M = reinterpret_cast<DGX_LDS float*>(lds_opaque(Qs));
+        int krow = key * LDM + 4 * g;
+        asm volatile("" : "+v"(krow));   // opaque: keeps the 36 store addresses from being formed above the window loop (registers)
         if (kok) {
 #pragma unroll
             for (int qt = 0; qt < NT; ++qt) {
@@ -462,7 +464,7 @@ __global__ __launch_bounds__((WinCfg<WS>::NT + (HELP ? 3 : 0)) * 64) void win_at
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int q = 16 * qt + 4 * g + r;
-                    if (q < N) M[key * LDM + q] = dbias[qt][r];
+                    if (q < N) M[krow + 16 * qt + r] = dbias[qt][r];
                     dbias[qt][r] = 0.f;
                 }
             }
@@ -510,12 +512,16 @@ __global__ __launch_bounds__((WinCfg<WS>::NT + (HELP ? 3 : 0)) * 64) void win_at
         }
     };
     if (count > 0) stage();
-    int h_last = h;
-    for (int u = 0; u < count; ++u) {
-        const bool more = u + 1 < count;
-        const bool wrap = b + 1 == hi;
-        const int bn = wrap ? lo : b + 1, hn = wrap ? h + 1 : h;     // the next unit of the run
-        h_last = h;
+    // The run as segments of one head each: the window loop inside, the change of head (flush, next bias row) between two segments --
+    // written INTO the window loop it lengthened every live range of the loop and the masked kernel spilled 12 registers, whose reloads
+    // wait for the prefetch in flight.
+    int done = 0;
+    while (done < count) {
+    const int seg = min(count - done, hi - b);       // units up to the end of the run or of this head's windows
+    for (int u = 0; u < seg; ++u) {
+        const bool more = done + u + 1 < count;      // another unit in the run: its operands are requested under this one's math
+        const bool wrap = u + 1 == seg;              // ... and it is the first unit of the next segment
+        const int bn = b + 1 == hi ? lo : b + 1, hn = b + 1 == hi ? h + 1 : h;
 #ifdef DIAG_CLOCK
         unsigned long long tprev = clock64();
 #endif
@@ -535,6 +541,20 @@ __global__ __launch_bounds__((WinCfg<WS>::NT + (HELP ? 3 : 0)) * 64) void win_at
         // ONE unrolled copy of the five steps (every register index below is static); a wave skips the steps of the other wave of its
         // strip with a scalar branch: the owner of a shared strip runs steps 0..2, its helper steps 3..4
         constexpr int TSPLIT = 3;
+        // Shifted windows: most windows of a shifted layer lie inside ONE region (25 of the 36 of a 6 x 6 grid) and need no mask; the
+        // phase is VALU-bound with three waves per SIMD, so the 16 instructions per query tile that fetch, spread and compare the region
+        // ids cost it 60 % (6 900 against 4 200 cycles per window on the harness).  Such a window skips them;
+        // in the others a masked pair's probability is SET to zero behind the exponential (the reference's exp(s - 100 - lse) is below
+        // 4e-44 times the unmasked value: zero in the bf16 operands it feeds, and nothing in an fp32 sum next to real terms).
+        bool mixed = false;
+        if (MASKED) {
+            const int r0 = reg_s[0];
+            bool diff = false;
+            for (int i = l; i < N; i += 64) diff = diff || reg_s[i] != r0;
+            mixed = __builtin_amdgcn_readfirstlane((int)(__ballot(diff) != 0ull)) != 0;
+        }
+        // (ONE copy of the phase with scalar branches around the mask's instructions: two copies behind one branch spilled 58 registers)
+        const bool MK = MASKED && mixed;
 #pragma unroll
         for (int t = 0; t < NTK / 2; ++t) {
             if (HELP && (t < TSPLIT ? helper : shared)) continue;
@@ -557,7 +577,7 @@ __global__ __launch_bounds__((WinCfg<WS>::NT + (HELP ? 3 : 0)) * 64) void win_at
                         lv = f32x4{quad_bcast<0>(ld.x), quad_bcast<1>(ld.x), quad_bcast<2>(ld.x), quad_bcast<3>(ld.x)};
                         dl = f32x4{quad_bcast<0>(ld.y), quad_bcast<1>(ld.y), quad_bcast<2>(ld.y), quad_bcast<3>(ld.y)};
                         bv = *reinterpret_cast<DGX_LDS const f32x4*>(bptr[qt]);
-                        if (MASKED) {
+                        if (MK) {
                             const int rq1 = reg_lane[16 * qt];
                             rv = i32x4{quad_bcast<0>(rq1), quad_bcast<1>(rq1), quad_bcast<2>(rq1), quad_bcast<3>(rq1)};
                         }
@@ -565,7 +585,7 @@ __global__ __launch_bounds__((WinCfg<WS>::NT + (HELP ? 3 : 0)) * 64) void win_at
                         lv = *reinterpret_cast<DGX_LDS const f32x4*>(lse_g + 16 * qt);     // -lse[q] / scale
                         dl = *reinterpret_cast<DGX_LDS const f32x4*>(delta_g + 16 * qt);   // -delta[q]
                         ov = *reinterpret_cast<DGX_LDS const i32x4*>(qoff_g + 16 * qt);
-                        if (MASKED) rv = *reinterpret_cast<DGX_LDS const i32x4*>(reg_g + 16 * qt);
+                        if (MK) rv = *reinterpret_cast<DGX_LDS const i32x4*>(reg_g + 16 * qt);
                     }
 #ifdef ABL_MFMA1
                     const f32x4 s = lv + f32x4{bf2f(qa[0]), bf2f(qa[1]), bf2f(kf[0]), bf2f(kf[1])}, dp = dl + f32x4{bf2f(da[0]), bf2f(da[1]), bf2f(vf[0]), bf2f(vf[1])};
@@ -577,12 +597,12 @@ __global__ __launch_bounds__((WinCfg<WS>::NT + (HELP ? 3 : 0)) * 64) void win_at
                     for (int r = 0; r < 4; ++r) {
                         float sv = __builtin_fmaf(s[r], scale2, PK ? bv[r] : tbl_k[ov[r]]);       // log2 domain (bias row, lse pre-scaled)
                         if (N % 16 != 0) sv += kneg;
-                        if (MASKED) sv += rv[r] != rk ? -100.0f * DGX_LOG2E : 0.0f;
 #ifdef ABL_EXP
                         pv[r] = sv * 0.001f;
 #else
                         pv[r] = __builtin_amdgcn_exp2f(sv);
 #endif
+                        if (MK) pv[r] = rv[r] != rk ? 0.0f : pv[r];
                         dsv[r] = pv[r] * dp[r];
                         dbias[qt < NT ? qt : 0][r] += dsv[r];
                     }
@@ -666,12 +686,7 @@ __global__ __launch_bounds__((WinCfg<WS>::NT + (HELP ? 3 : 0)) * 64) void win_at
         CLK(6);
         }
         __syncthreads();                 // this window's LDS consumers are done
-        if (more && wrap) {              // head boundary inside the run: nobody reads the bias row until the barrier at the top of the loop
-            flush_head(h);               // (its matrix lay over the images' padding rows)
-            if (NP > N) zero_pads();
-            load_head(hn);
-        }
-        if (more) stage();
+        if (more && !wrap) stage();
         // the dQ rows leave BEHIND the staging of the next window: the staging waits for its prefetch with vmcnt counts that also
         // cover every store issued before it (one in-order counter), and stores issued a few cycles earlier would put their whole
         // latency in front of it; the dK / dV stores are a phase 2 old by then
@@ -679,10 +694,18 @@ __global__ __launch_bounds__((WinCfg<WS>::NT + (HELP ? 3 : 0)) * 64) void win_at
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) *reinterpret_cast<u32x2*>(dqb + row4 + 16 * dt) = dqpk[dt];
         }
-        b = bn;
-        h = hn;
+        if (!wrap) { b = bn; h = hn; }
     }
-    if (count > 0) flush_head(h_last);
+    done += seg;
+    flush_head(h);                       // nobody reads the bias row or the images between the loop's last barrier and the next staging
+    if (done < count) {                  // head boundary inside the run
+        if (NP > N) zero_pads();         // (the flush's matrix lay over the images' padding rows)
+        h = b + 1 == hi ? h + 1 : h;
+        b = b + 1 == hi ? lo : b + 1;
+        load_head(h);
+        stage();
+    }
+    }
 }
 
 template <int WS>

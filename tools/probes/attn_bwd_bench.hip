@@ -6,6 +6,7 @@ extern "C" int dgx_get_reserved_cus(void) { return getenv("RESERVED_CUS") ? atoi
 #include <vector>
 int main(int argc, char** argv) {
     const int B_ = argc > 1 ? atoi(argv[1]) : 968, nH = argc > 2 ? atoi(argv[2]) : 6, N = 144, C = nH * 32;
+    const int nWm = argc > 3 ? atoi(argv[3]) : 0;      // > 0: shifted-window launch with that many windows per image (region ids 0..3)
     size_t nq = (size_t)B_ * N * 3 * C, no = (size_t)B_ * N * C;
     std::vector<uint16_t> h(nq);
     for (size_t i = 0; i < nq; ++i) h[i] = 0x3c00 + (rand() & 0x3ff) - ((rand() & 1) << 15);  // ~ +-[0.0078..0.0156]... small bf16
@@ -15,10 +16,17 @@ int main(int argc, char** argv) {
     hipMemcpy(qkv, h.data(), nq * 2, hipMemcpyHostToDevice);
     hipMemcpy(dout, h.data(), no * 2, hipMemcpyHostToDevice);
     hipMemset(table, 0, 529 * nH * 4); hipMemset(dtable, 0, 529 * nH * 4);
+    int8_t* region = nullptr;
+    if (nWm > 0) {
+        std::vector<int8_t> hr((size_t)nWm * N);
+        for (size_t i = 0; i < hr.size(); ++i) hr[i] = (int8_t)(getenv("REGION_ZERO") || (i / N) % 3 == 0 ? 0 : rand() & 3);
+        hipMalloc(&region, hr.size()); hipMemcpy(region, hr.data(), hr.size(), hipMemcpyHostToDevice);
+    }
+    const int nWv = nWm > 0 ? nWm : 1;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int it = 0; it < 3; ++it) {
-        dgx_window_attention_fwd(qkv, table, 529, 1, nullptr, out, lse, B_, 1, nH, 12, 0.17677f, nullptr);
-        dgx_window_attention_bwd(qkv, table, nullptr, out, lse, dout, dqkv, dtable, 529, 1, B_, 1, nH, 12, 0.17677f, nullptr);
+        dgx_window_attention_fwd(qkv, table, 529, 1, region, out, lse, B_, nWv, nH, 12, 0.17677f, nullptr);
+        dgx_window_attention_bwd(qkv, table, region, out, lse, dout, dqkv, dtable, 529, 1, B_, nWv, nH, 12, 0.17677f, nullptr);
     }
     hipDeviceSynchronize();
 #ifdef DIAG_CLOCK
@@ -26,12 +34,12 @@ int main(int argc, char** argv) {
 #endif
     const int iters = 10; float msf = 0, msb = 0, ms;
     for (int it = 0; it < iters; ++it) {
-        hipEventRecord(e0); dgx_window_attention_fwd(qkv, table, 529, 1, nullptr, out, lse, B_, 1, nH, 12, 0.17677f, nullptr);
+        hipEventRecord(e0); dgx_window_attention_fwd(qkv, table, 529, 1, region, out, lse, B_, nWv, nH, 12, 0.17677f, nullptr);
         hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1); msf += ms;
-        hipEventRecord(e0); dgx_window_attention_bwd(qkv, table, nullptr, out, lse, dout, dqkv, dtable, 529, 1, B_, 1, nH, 12, 0.17677f, nullptr);
+        hipEventRecord(e0); dgx_window_attention_bwd(qkv, table, region, out, lse, dout, dqkv, dtable, 529, 1, B_, nWv, nH, 12, 0.17677f, nullptr);
         hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1); msb += ms;
     }
-    printf("B_=%d nH=%d fwd %.1f us bwd %.1f us\n", B_, nH, msf / iters * 1e3, msb / iters * 1e3);
+    printf("B_=%d nH=%d%s fwd %.1f us bwd %.1f us\n", B_, nH, nWm > 0 ? " shifted" : "", msf / iters * 1e3, msb / iters * 1e3);
 #ifdef DIAG_CLOCK
     hipMemcpyFromSymbol(z, HIP_SYMBOL(dgx_clk), sizeof z);
     const int nchunks = 256 / nH; const int chunk = (B_ + nchunks - 1) / nchunks;

@@ -23,10 +23,12 @@ int main(int argc, char** argv) {
         hipMalloc(&region, hr.size()); hipMemcpy(region, hr.data(), hr.size(), hipMemcpyHostToDevice);
     }
     const int nWv = nWm > 0 ? nWm : 1;
+    const bool strided = getenv("TABLE_STRIDED") != nullptr;      // the model's layout: table (529, nH), head stride 1, index stride nH
+    const int64_t t_sh = strided ? 1 : 529, t_si = strided ? nH : 1;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int it = 0; it < 3; ++it) {
-        dgx_window_attention_fwd(qkv, table, 529, 1, region, out, lse, B_, nWv, nH, 12, 0.17677f, nullptr);
-        dgx_window_attention_bwd(qkv, table, region, out, lse, dout, dqkv, dtable, 529, 1, B_, nWv, nH, 12, 0.17677f, nullptr);
+        dgx_window_attention_fwd(qkv, table, t_sh, t_si, region, out, lse, B_, nWv, nH, 12, 0.17677f, nullptr);
+        dgx_window_attention_bwd(qkv, table, region, out, lse, dout, dqkv, dtable, t_sh, t_si, B_, nWv, nH, 12, 0.17677f, nullptr);
     }
     hipDeviceSynchronize();
 #ifdef DIAG_CLOCK
@@ -34,9 +36,9 @@ int main(int argc, char** argv) {
 #endif
     const int iters = 10; float msf = 0, msb = 0, ms;
     for (int it = 0; it < iters; ++it) {
-        hipEventRecord(e0); dgx_window_attention_fwd(qkv, table, 529, 1, region, out, lse, B_, nWv, nH, 12, 0.17677f, nullptr);
+        hipEventRecord(e0); dgx_window_attention_fwd(qkv, table, t_sh, t_si, region, out, lse, B_, nWv, nH, 12, 0.17677f, nullptr);
         hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1); msf += ms;
-        hipEventRecord(e0); dgx_window_attention_bwd(qkv, table, region, out, lse, dout, dqkv, dtable, 529, 1, B_, nWv, nH, 12, 0.17677f, nullptr);
+        hipEventRecord(e0); dgx_window_attention_bwd(qkv, table, region, out, lse, dout, dqkv, dtable, t_sh, t_si, B_, nWv, nH, 12, 0.17677f, nullptr);
         hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1); msb += ms;
     }
     printf("B_=%d nH=%d%s fwd %.1f us bwd %.1f us\n", B_, nH, nWm > 0 ? " shifted" : "", msf / iters * 1e3, msb / iters * 1e3);

@@ -55,6 +55,7 @@ def parse():
                         "'gemm_log=PATH' opens the per-launch GEMM log.  The library itself reads no environment variable")
     p.add_argument("--late-proposal-backward", action="store_true",
                    help="A/B: back-propagate the proposal generator's losses with the rest (model.early_proposal_backward off)")
+    p.add_argument("--early-box-backward", action="store_true", help="A/B: the box cascade's losses back-propagated right behind its forward (measured slower)")
     p.add_argument("--no-graphs", action="store_true",
                    help="development: issue the hipGraph segments (FPN, tower, heads) eagerly so that every launch is logged / traced by name")
     return p.parse_args()
@@ -329,6 +330,7 @@ def main():
     torch.manual_seed(cfg.SEED + rank)
     model = build_model(cfg).train()
     model.early_proposal_backward = not a.late_proposal_backward
+    model.early_box_backward = a.early_box_backward
     opt = build_optimizer(cfg, model)
     sched = build_lr_scheduler(cfg, opt)
     reducer = ArenaReducer(opt.arena, single_rank_group=a.force_pg)

@@ -508,6 +508,15 @@ class DeticCascadeROIHeads(nn.Module):
                     losses.update({k: v * self.mask_weight for k, v in self._forward_mask(features, proposals).items()})
                 return proposals, losses
             losses = self._forward_box(features, proposals, targets)
+            stop_at = self.__dict__.pop("_early_box_backward", None)
+            if stop_at is not None and losses and all(v.requires_grad for v in losses.values()):
+                # (meta_arch/custom_rcnn.py early_proposal_backward) the cascade's losses are back-propagated HERE, up to the feature maps in
+                # `stop_at` -- whose gradient maps the poolers add into in place -- so that the device has the three stages' backward to run
+                # while the host issues the mask head, the loss sum and the start of the final backward (the host-bound stretch of the step)
+                tot = torch.stack([v.float().reshape(()) for v in losses.values()]).sum()
+                params = [q for m in (self.box_head, self.box_predictor) for q in m.parameters() if q.requires_grad]
+                torch.autograd.backward(tot, inputs=list(stop_at) + params)       # (parameters that take their gradient through autograd)
+                losses = {k: v.detach() for k, v in losses.items()}
             if targets[0].has("gt_masks"):
                 losses.update({k: v * self.mask_weight for k, v in self._forward_mask(features, proposals).items()})
             elif self.mask_on:

@@ -458,7 +458,7 @@ def test_first_writer_gradients_train_like_zero_filled_ones(monkeypatch):
 
 def test_early_proposal_backward_is_the_same_step():
     """model.early_proposal_backward (the training loops switch it on: the proposal generator's losses are back-propagated from inside the
-    forward, ahead of the RoI heads' device->host read): the forward is untouched -- every loss bit-identical, the same random draws --,
+    forward, ahead of the RoI heads' device->host read, the box cascade's right behind its forward): the forward is untouched -- every loss bit-identical, the same random draws --,
     the proposal losses come back detached, the parameters whose gradient does not pass through the FPN levels (CenterNet head, RoI
     heads) get bit-identical gradients, and backbone + FPN differ only by the association of the per-level sum of the consumers'
     gradients (bf16 maps: the poolers add onto the head's map instead of the head's map being added last)."""
@@ -466,9 +466,9 @@ def test_early_proposal_backward_is_the_same_step():
     from divergen_amd.engine import total_loss
     from divergen_amd.utils.events import EventStorage
     res = []
-    for early in (False, True):
+    for early, box in ((False, False), (True, False), (True, True)):
         cfg, model, opt = _build(True)
-        model.early_proposal_backward = early
+        model.early_proposal_backward, model.early_box_backward = early, box
         batch = synthetic_batch(2, 256, cfg.MODEL.ROI_HEADS.NUM_CLASSES, device="cuda")
         with EventStorage(0):
             for k in range(2):          # the second pass replays the captured segments
@@ -477,11 +477,13 @@ def test_early_proposal_backward_is_the_same_step():
                 losses = model(batch)
                 total_loss(losses).backward()
                 torch.cuda.synchronize()
+        # early: the proposal generator's losses (and with early_box_backward the box cascade's) come back detached
         assert all(v.requires_grad != early for k, v in losses.items() if "centernet" in k)
-        assert all(v.requires_grad for k, v in losses.items() if "centernet" not in k)
+        assert all(v.requires_grad != (early and box) for k, v in losses.items() if "stage" in k)
+        assert losses["loss_mask"].requires_grad
         res.append(({k: float(v) for k, v in losses.items()}, opt.arena.g.clone(), opt.arena))
-    (l0, g0, arena), (l1, g1, _) = res
-    assert l0 == l1, (l0, l1)
+    (l0, g0, arena), (l1, g1, _), (l2, g2, _) = res
+    assert l0 == l1 == l2, (l0, l1, l2)
     up = torch.zeros(g0.numel(), dtype=torch.bool, device="cuda")          # upstream of the FPN levels
     tables = torch.zeros_like(up)
     for n, o, z in zip(arena.names, arena.offsets, arena.sizes):
@@ -490,8 +492,9 @@ def test_early_proposal_backward_is_the_same_step():
         if "relative_position_bias_table" in n:
             tables[o:o + z] = True
     assert bool(up.any()) and bool((~up).any())
-    assert torch.equal(g0[~up], g1[~up])
-    a, b = g0[up & ~tables].double(), g1[up & ~tables].double()
-    # measured 8e-3: one-ulp differences of the bf16 level gradients, carried through the FPN and the backbone's backward in bf16 storage
-    assert float((a - b).norm() / a.norm()) <= 2e-2
-    assert float(a.norm()) > 0
+    for g in (g1, g2):
+        assert torch.equal(g0[~up], g[~up])
+        a, b = g0[up & ~tables].double(), g[up & ~tables].double()
+        # measured 8e-3: one-ulp differences of the bf16 level gradients, carried through the FPN and the backbone's backward in bf16 storage
+        assert float((a - b).norm() / a.norm()) <= 2e-2
+        assert float(a.norm()) > 0

@@ -21,6 +21,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          "-munsafe-fp-atomics", "-Wno-unused-result"]
 if os.environ.get("DGX_DEV") == "1":       # development build: ablation instantiations of the GEMM (tools/gemm_phase_probe.py)
     FLAGS.append("-DDGX_GEMM_DEV")
+FLAGS += os.environ.get("DGX_EXTRA_FLAGS", "").split()      # experiments (-D switches of one gpurun call); the product build sets none
 
 
 def build(verbose=False, force=False):

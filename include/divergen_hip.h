@@ -55,9 +55,14 @@ int dgx_window_attention_fwd(const void* qkv, const float* table, int64_t table_
                              int nW, int nH, int ws, float scale, void* stream);
 
 /* Backward of the above.  dqkv bf16 (B_,N,3,nH,32) is fully overwritten; the bias-table gradient is
- * ACCUMULATED (atomic fp32 adds) into dtable[h*dtable_stride_head + i*dtable_stride_index], so the
- * caller can point it at the parameter's own (T, nH) gradient (strides 1, nH) or at a zeroed
- * (nH, T) scratch (strides T, 1).  `table` is read with the SAME two strides.  `out`/`lse` are the forward results. */
+ * ADDED to dtable[h*dtable_stride_head + i*dtable_stride_index], so the caller can point it at the
+ * parameter's own (T, nH) gradient (strides 1, nH) or at a zeroed (nH, T) scratch (strides T, 1).
+ * `table` is read with the SAME two strides.  `out`/`lse` are the forward results.
+ * The table gradient is summed in a fixed order (per workgroup run, then over the runs of a head by the
+ * last run to finish: bit-reproducible for a given launch shape and CU reservation, no float atomics);
+ * the partial sums live in a workspace the library keeps PER STREAM (allocated at the first call on a
+ * stream, outside any graph capture): launches on one stream are ordered with each other, launches on
+ * different streams do not share it.  DGX_ERR_UNSUPPORTED when that workspace cannot be allocated. */
 int dgx_window_attention_bwd(const void* qkv, const float* table, const int8_t* region,
                              const void* out, const float* lse, const void* dout,
                              void* dqkv, float* dtable, int64_t dtable_stride_head,

@@ -188,6 +188,13 @@ template <> struct Vec8<uint16_t> {
     static __device__ __forceinline__ void store(uint16_t* p, const float (&v)[8]) {
         *reinterpret_cast<u32x4*>(p) = u32x4{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
     }
+    // the load and its conversion apart: a batch of loads is requested before the first value is touched
+    struct Raw { u32x4 r; };
+    static __device__ __forceinline__ Raw load_raw(const uint16_t* p) { return Raw{*reinterpret_cast<const u32x4*>(p)}; }
+    static __device__ __forceinline__ void unpack(const Raw& w, float (&v)[8]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w.r[i] << 16); v[2 * i + 1] = __uint_as_float(w.r[i] & 0xffff0000u); }
+    }
 };
 template <> struct Vec8<float> {
     static __device__ __forceinline__ void load(const float* p, float (&v)[8]) {
@@ -198,6 +205,12 @@ template <> struct Vec8<float> {
     static __device__ __forceinline__ void store(float* p, const float (&v)[8]) {
         *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
         *reinterpret_cast<f32x4*>(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
+    }
+    struct Raw { f32x4 a, b; };
+    static __device__ __forceinline__ Raw load_raw(const float* p) { return Raw{*reinterpret_cast<const f32x4*>(p), *reinterpret_cast<const f32x4*>(p + 4)}; }
+    static __device__ __forceinline__ void unpack(const Raw& w, float (&v)[8]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[i] = w.a[i]; v[4 + i] = w.b[i]; }
     }
 };
 
@@ -404,19 +417,27 @@ __global__ __launch_bounds__(256) void roi_pool_bwd_gather_kernel(GatherP P, con
                     if (!any) continue;
                     float gx[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                     const T* gi = gr + (int64_t)i * pw * C;
+                    // The four columns of a chunk are requested TOGETHER and unconditionally (a column past the range repeats the last valid
+                    // address with weight 0; a zero weight multiplies what it loaded): as `if (wx != 0) load` per column (round 3) the loads
+                    // sat under lane conditions, each behind its own wait -- a box of 7 x 7 bins inside one pixel cost its tile 14 memory
+                    // round trips in series (tools/roi_gather_probe.py: 1 024 such boxes 91 -> 61 us, in the step 115 -> 102 us per
+                    // launch; eight columns, or two bin rows, per request lose again: more loads than the weights use).
                     for (int j0 = j_lo; j0 < j_hi; j0 += 4) {
-                        float wx[4], v[4][8];
+                        typename Vec8<T>::Raw raw[4];
+                        float wx[4];
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) wx[k] = (j0 + k < j_hi) ? WX[q][j0 + k][tx] : 0.0f;
+                        for (int k = 0; k < 4; ++k) {
+                            const int j = j0 + k < j_hi ? j0 + k : j_hi - 1;
+                            wx[k] = j0 + k < j_hi ? WX[q][j][tx] : 0.0f;
+                            raw[k] = Vec8<T>::load_raw(gi + (int64_t)j * C);
+                        }
 #pragma unroll
-                        for (int k = 0; k < 4; ++k)
-                            if (wx[k] != 0.0f) Vec8<T>::load(gi + (int64_t)(j0 + k) * C, v[k]);
+                        for (int k = 0; k < 4; ++k) {
+                            float v[8];
+                            Vec8<T>::unpack(raw[k], v);
 #pragma unroll
-                        for (int k = 0; k < 4; ++k)
-                            if (wx[k] != 0.0f) {
-#pragma unroll
-                                for (int e = 0; e < 8; ++e) gx[e] += wx[k] * v[k][e];
-                            }
+                            for (int e = 0; e < 8; ++e) gx[e] += wx[k] * v[e];
+                        }
                     }
 #pragma unroll
                     for (int a = 0; a < TH; ++a)

@@ -106,6 +106,40 @@ def test_window_attention_backward_runs_across_heads(ws, B_, nH, reserved):
     assert float((dt3 - 2 * dt).abs().max()) <= 1e-5 * float(dt.abs().max())
 
 
+def test_window_attention_backward_back_to_back_launches():
+    """The table gradient's workspace protocol (slot stores, per-head counters that the last run of a head resets, one workspace per
+    stream) under launches of ten different shapes queued back to back, three times over, with no host synchronisation in between: every
+    launch's table gradient against the fp32 evaluation of the same sums and bit-identical in a second pass over the same inputs."""
+    torch.manual_seed(0)
+    shapes = [(12, 72, 24), (12, 74, 24), (12, 13, 48), (12, 242, 12), (7, 103, 24), (7, 50, 3), (12, 5, 6), (12, 968, 6), (12, 18, 48), (7, 8, 1)]
+    scale = 32 ** -0.5
+    cases = []
+    for _ in range(3):
+        for ws, B_, nH in shapes:
+            N = ws * ws
+            cases.append((ws, nH, (torch.randn(B_, N, 3 * nH * 32, device=DEV) * 1.5).to(torch.bfloat16),
+                          torch.randn((2 * ws - 1) ** 2, nH, device=DEV), torch.randn(B_, N, nH * 32, device=DEV).to(torch.bfloat16)))
+    passes = []
+    for _ in range(2):
+        res = []
+        for ws, nH, qkv, table, go in cases:
+            qd, td = qkv.clone().requires_grad_(True), table.clone().requires_grad_(True)
+            la.window_attention_core(qd, td, None, 1, nH, ws, scale).backward(go)
+            res.append(td.grad)
+        torch.cuda.synchronize()
+        passes.append(res)
+    for (ws, nH, qkv, table, go), a, b in zip(cases, passes[0], passes[1]):
+        B_, N = qkv.shape[0], ws * ws
+        q, k, v = qkv.float().view(B_, N, 3, nH, 32).permute(2, 0, 3, 1, 4)
+        idx = OSW.relative_position_index(ws).to(DEV).reshape(-1)
+        p = torch.softmax((q * scale) @ k.transpose(-2, -1) + table[idx].reshape(N, N, nH).permute(2, 0, 1)[None], -1)
+        dp = go.float().view(B_, N, nH, 32).permute(0, 2, 1, 3) @ v.transpose(-2, -1)
+        ds = p * (dp - (dp * p).sum(-1, keepdim=True))
+        ref = torch.zeros_like(table).index_add_(0, idx, ds.sum(0).permute(1, 2, 0).reshape(N * N, nH))
+        assert torch.equal(a, b), (ws, B_, nH)
+        assert float((a - ref).abs().max()) <= 0.015 * float(ref.abs().max()), (ws, B_, nH)
+
+
 def test_swinL_stage0_layer_pair_vs_oracle():
     """BasicLayer of Swin-L stage 0 at 1024 px: 256x256 tokens (padded to 264 for window 12), C = 192, 6 heads, one W-MSA
     and one SW-MSA block + PatchMerging, one image; product under bf16 autocast (fused block path through the arenas) vs

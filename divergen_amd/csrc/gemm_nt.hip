@@ -429,7 +429,7 @@ struct TileChoice { int bm, bn; };
 int64_t g_ws_bytes_cur = 0;     // size of the workspace of the call being planned
 // Test / A-B knobs of the dispatch (dgx_dev_set): -1 / 0 = the library's own plan.  The product never sets them; the GEMM tests
 // force every tile shape and the split-K path through the one ABI entry with them, the tools compare own form A with own form B.
-struct DevKnobs { int lw = -1, two_wg = -1, tile_bm = 0, tile_bn = 0, splitk = 0; } g_dev;
+struct DevKnobs { int lw = -1, two_wg = -1, tile_bm = 0, tile_bn = 0, splitk = 0, k192 = -1; } g_dev;
 struct LastForm { int form = -1, bm = 0, bn = 0, splits = 0; } g_last;     // what the most recent dispatch launched (dgx_gemm_last_form)
 
 // split-K plan: few output tiles and a long contraction (box-head FC 1024 x 1024 x 12544, 3x3 convolutions over the small
@@ -564,6 +564,7 @@ extern "C" int dgx_dev_set(const char* key, int value) {
     else if (!strcmp(key, "gemm_2wg")) g_dev.two_wg = value;         // -1 / 1 plan, 0 never the two-workgroup form, >= 2: its row threshold
     else if (!strcmp(key, "gemm_tile")) { g_dev.tile_bm = value / 1000; g_dev.tile_bn = value % 1000; }     // bm * 1000 + bn, 0 = plan
     else if (!strcmp(key, "gemm_splitk")) g_dev.splitk = value;      // 0 plan, >= 1 forced slab count
+    else if (!strcmp(key, "gemm_k192")) g_dev.k192 = value;          // -1 / 1 plan, 0 never the resident-panel kernel (gemm_k192.hip)
     else if (!strcmp(key, "wgrad_lw")) g_dgx_dev_wgrad_lw = value;   // 1 plan, 0 never the loader-wave form, 2 always
     else if (!strcmp(key, "reset")) { g_dev = DevKnobs(); g_dgx_dev_wgrad_lw = 1; }
     else return DGX_ERR_BAD_ARG;
@@ -651,7 +652,16 @@ extern "C" int dgx_gemm_bf16_nt(const void* A, const void* B, int M, int N, int 
     return dgx_gemm_dispatch(P, st);
 }
 
+bool dgx_gemm_k192_takes(const GemmP& P);              // gemm_k192.hip: the HBM-bound K = 192 problems of Swin stage 0
+int dgx_gemm_k192_launch(const GemmP& P, hipStream_t st);
 static int dgx_gemm_dispatch(GemmP& P, hipStream_t st) {
+    if (g_dev.k192 != 0 && g_dev.lw < 0 && g_dev.tile_bm == 0 && g_dev.splitk == 0 && g_dev.two_wg < 0 && dgx_gemm_k192_takes(P)) {
+        const int rc = dgx_gemm_k192_launch(P, st);
+        if (rc != DGX_ERR_UNSUPPORTED) {
+            g_last = {3, 32, 192, 1};
+            return rc;
+        }
+    }
     const TileChoice tc = choose_tile(P.M, P.N);
     if (use_lw(P)) return launch_lw(P, tc.bm, tc.bn, st);
     if (tc.bn == 192) {

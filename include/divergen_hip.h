@@ -647,10 +647,12 @@ int dgx_get_reserved_cus(void);
  * which kernel form trains the model cannot depend on a user's shell.
  *   dgx_dev_set(key, value)   "gemm_lw" (-1 plan | 0 gemm_nt everywhere | 1 gemm_lw everywhere), "gemm_2wg" (0 = never the
  *                             two-workgroup form), "gemm_tile" (bm * 1000 + bn, 0 = plan), "gemm_splitk" (forced slab count, 0 = plan),
- *                             "wgrad_lw" (1 plan | 0 never the loader-wave weight-gradient form | 2 always), "reset" (all of them
- *                             back to the plan).  DGX_ERR_BAD_ARG for an unknown key.
+ *                             "wgrad_lw" (1 plan | 0 never the loader-wave weight-gradient form | 2 always), "gemm_k192" (0 = never
+ *                             the resident-panel kernel of the K = 192 problems), "reset" (all of them back to the plan).
+ *                             DGX_ERR_BAD_ARG for an unknown key.
  *   dgx_gemm_last_form        which kernel the most recent dgx_gemm_bf16_nt / dgx_conv3x3_gemm call launched: returns 0 = gemm_nt,
- *                             1 = gemm_lw (persistent loader-wave form), 2 = gemm_nt's two-workgroups-per-CU form, -1 = none yet;
+ *                             1 = gemm_lw (persistent loader-wave form), 2 = gemm_nt's two-workgroups-per-CU form, 3 = gemm_k192
+ *                             (K = 192, M >= 32 768: weight panel resident in LDS, one wave per row tile), -1 = none yet;
  *                             tile and split-K slab count through the pointers (NULL = not wanted).  The parity tests assert with
  *                             it that the form the bench times is the form they checked.
  *   dgx_dev_gemm_log(path)    one line "M N K mode bm bn" per GEMM launch into path (NULL / "" closes it); joined with a kernel

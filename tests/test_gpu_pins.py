@@ -102,7 +102,7 @@ def test_wgrad_lw_32_problems_and_ragged_contraction():
 
 
 # --------------------------------------------------------------------------------------------------------------- forward / dgrad GEMMs
-NT, LW, TWO = 0, 1, 2      # dgx_gemm_last_form: gemm_nt, gemm_lw (persistent loader-wave), gemm_nt two workgroups per CU
+NT, LW, TWO, K192 = 0, 1, 2, 3      # dgx_gemm_last_form: gemm_nt, gemm_lw (persistent loader-wave), gemm_nt two workgroups per CU, gemm_k192 (resident panel)
 # (M, N, K, mode, window map (B, H, W, ws, shift, residual dtype) or None, expected (form, bm, bn) under DEFAULT dispatch).
 # Shapes x tail modes: the top rows of profiles/r04_gemm_insitu.txt (>= 0.1 ms/step each; 9.6 of the family's 11.1 ms/step).
 # The expected form is this round's dispatch (csrc/gemm_nt.hip::use_lw / use_two_wg): when the dispatch changes, this table changes
@@ -116,17 +116,18 @@ BENCH_GEMMS = [
     (10368, 768, 2304, 0, None, (LW, 192, 192)),                        # qkv input gradient
     (10368, 768, 768, 3, (2, 64, 64, 12, 6, BF), None),                 # proj + window reverse + roll + crop + DropPath + residual
     (10368, 768, 768, 0, None, (LW, 192, 192)),                         # proj input gradient
-    (131072, 768, 192, 2, None, None),                                  # stage 0 fc1 + GELU
-    (131072, 768, 192, 4, None, None),                                  # stage 0 fc2 input gradient
+    (131072, 768, 192, 2, None, (K192, 32, 192)),                       # stage 0 fc1 + GELU
+    (131072, 768, 192, 4, None, (K192, 32, 192)),                       # stage 0 fc2 input gradient
     (131072, 192, 768, 3, (2, 256, 256, 0, 0, torch.float32), None),    # stage 0 fc2 + residual (fp32 stream)
     (32768, 1536, 384, 2, None, None),                                  # stage 1
     (32768, 1536, 384, 4, None, None),
-    (139392, 576, 192, 1, None, (LW, 192, 192)),                        # stage 0 qkv (264-padded grid)
+    (139392, 576, 192, 1, None, (K192, 32, 192)),                       # stage 0 qkv (264-padded grid)
     (1024, 12544, 1024, 0, None, (LW, 128, 256)),                       # box head fc1 input gradient
     (1024, 1024, 12544, 1, None, (LW, 128, 256)),                       # box head fc1 (split-K)
     (32768, 384, 1536, 3, (2, 128, 128, 0, 0, BF), (LW, 256, 192)),     # stage 1 fc2 + residual
     (131072, 192, 768, 0, None, (LW, 256, 192)),                        # stage 0 fc1 input gradient
-    (139392, 192, 192, 3, (2, 256, 256, 12, 6, torch.float32), None),   # stage 0 proj + residual
+    (139392, 192, 192, 3, (2, 256, 256, 12, 6, torch.float32), (K192, 32, 192)),   # stage 0 proj + residual
+    (139392, 192, 192, 0, None, (K192, 32, 192)),                       # stage 0 proj input gradient
     (2048, 6144, 1536, 4, None, (NT, 256, 192)),                        # stage 3 fc2 input gradient x GELU'(f1)
     (34848, 1152, 384, 1, None, (LW, 192, 192)),                        # stage 1 qkv
     (2592, 4608, 1536, 1, None, (LW, 128, 192)),                        # stage 3 qkv
@@ -210,7 +211,19 @@ def test_bench_gemm_shapes_through_default_dispatch(M, N, K, mode, wmap, expect,
 @pytest.mark.parametrize("force", [0, 1])
 @pytest.mark.parametrize("M,N,K,mode,wmap,expect", [r for r in BENCH_GEMMS if r[3] in (2, 3, 4) and r[2] <= 768])
 def test_bench_gemm_fused_tails_on_both_forms(M, N, K, mode, wmap, expect, force, dgx_dev):
-    """The K <= 768 fused-tail shapes on gemm_nt AND on gemm_lw: whichever the dispatcher picks in a later build has been checked."""
+    """The K <= 768 fused-tail shapes on gemm_nt AND on gemm_lw: whichever the dispatcher picks in a later build has been checked
+    (forcing a form also takes the K = 192 shapes away from the resident-panel kernel, which the default-dispatch test covers)."""
     dgx_dev("gemm_lw", force)
     form, bm, bn, _ = _run_bench_gemm(M, N, K, mode, wmap)
     assert (form == LW) == bool(force)
+
+
+@pytest.mark.parametrize("reserved", [0, 16], indirect=True)
+@pytest.mark.parametrize("M,N,K,mode,wmap", [(131072 + 40, 768, 192, 2, None), (4356 * 32 - 24, 576, 192, 1, None), (65536, 192, 192, 0, None),
+                                             (139392, 192, 192, 3, (2, 256, 256, 12, 6, BF)), (40000, 384, 192, 4, None)])
+def test_resident_panel_gemm_edges(M, N, K, mode, wmap, reserved):
+    """gemm_k192 (one workgroup = one 192-column panel of W resident in LDS, one wave = one 32-row tile at a time) away from the benchmark's
+    sizes: row counts that are no multiple of 32 (the last tile of some wave is partial), one / two / three / four column panels (three do
+    not divide the workgroups of an XCD), a bf16 residual stream through the window map, and the grid the reducer leaves (`reserved`)."""
+    form, bm, bn, _ = _run_bench_gemm(M, N, K, mode, wmap)
+    assert (form, bm, bn) == (K192, 32, 192)

@@ -19,13 +19,13 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 FAMILY_KERNELS = {
-    "gemm_nt": ("gemm_nt_kernel", "gemm_lw_kernel", "gemm_splitk_fold_kernel"),
+    "gemm_nt": ("gemm_nt_kernel", "gemm_lw_kernel", "gemm_k192_kernel", "gemm_splitk_fold_kernel"),
     "wgrad": ("wgrad256_partial_kernel", "wgrad256_reduce_kernel", "wgrad256_bias_reduce_kernel", "wgrad_partial_kernel", "wgrad_reduce_kernel", "wgrad_lw_kernel"),
     "attn_fwd": ("win_attn_fwd_kernel",),
     "attn_bwd": ("win_attn_bwd_kernel",),
 }
 # entry-point launches are counted on the family's MAIN kernel
-MAIN = {"gemm_nt": ("gemm_nt_kernel", "gemm_lw_kernel"), "wgrad": ("partial_kernel", "wgrad_lw_kernel"), "attn_fwd": "win_attn_fwd_kernel", "attn_bwd": "win_attn_bwd_kernel"}
+MAIN = {"gemm_nt": ("gemm_nt_kernel", "gemm_lw_kernel", "gemm_k192_kernel"), "wgrad": ("partial_kernel", "wgrad_lw_kernel"), "attn_fwd": "win_attn_fwd_kernel", "attn_bwd": "win_attn_bwd_kernel"}
 # 16 B/lane streaming reads (LDS-direct tile loads, float4 folds); window attention reads 64-byte head slices (64-B requests)
 WIDE = {"gemm_nt": True, "wgrad": True, "attn_fwd": False, "attn_bwd": False}
 

@@ -90,7 +90,21 @@ __global__ __launch_bounds__(KwCfg<AR>::WAVES * 64, 1) void gemm_k192_kernel(KwP
     DGX_LDS const unsigned char* pb1 = lds_opaque((const unsigned char*)lds_raw + (fa ^ 64u));
     const bool even = (g & 1) == 0;
 
+    // this lane's chunk columns: even lane groups finish the chunk of column tile 2p (their piece + the next group's), odd ones that of 2p + 1
+    int gn[6];
+#pragma unroll
+    for (int p = 0; p < 6; ++p) gn[p] = n0 + 16 * (2 * p + (even ? 0 : 1)) + 4 * (even ? g : g - 1);
     for (; tile < K.row_tiles; tile += wave_count) {
+        // GELU': the saved pre-activation chunks of the tile are requested in front of the MFMAs (their latency under the contraction)
+        u32x4 xpre[MC == 4 ? RI : 1][6];
+        if constexpr (MC == 4) {
+#pragma unroll
+            for (int i = 0; i < RI; ++i) {
+                const int gm = tile * KW_AROWS + 16 * i + c;
+#pragma unroll
+                for (int p = 0; p < 6; ++p) xpre[i][p] = *reinterpret_cast<const u32x4*>(P.aux + (int64_t)(gm < P.M ? gm : 0) * P.ldaux + gn[p]);
+            }
+        }
         f32x4 acc[RI][12];
 #pragma unroll
         for (int i = 0; i < RI; ++i)
@@ -132,7 +146,6 @@ __global__ __launch_bounds__(KwCfg<AR>::WAVES * 64, 1) void gemm_k192_kernel(KwP
                 if (ok && P.scale) sc = P.scale[b];
             }
             u32x4 y[6];
-            int gn[6];
 #pragma unroll
             for (int p = 0; p < 6; ++p) {
                 u32x2 pk[2];
@@ -144,14 +157,15 @@ __global__ __launch_bounds__(KwCfg<AR>::WAVES * 64, 1) void gemm_k192_kernel(KwP
                     const float b2 = __uint_as_float(braw[j][1] << 16), b3 = __uint_as_float(braw[j][1] & 0xffff0000u);
                     pk[h] = u32x2{pack_bf2(a[0] + b0, a[1] + b1), pack_bf2(a[2] + b2, a[3] + b3)};
                 }
-                // even lane groups finish the chunk of column tile 2p (their piece + the next group's), odd ones that of 2p + 1
                 const u32x2 give = even ? pk[1] : pk[0];
                 const u32x2 got = u32x2{(uint32_t)__shfl_xor((int)give[0], 16), (uint32_t)__shfl_xor((int)give[1], 16)};
                 y[p] = even ? u32x4{pk[0][0], pk[0][1], got[0], got[1]} : u32x4{got[0], got[1], pk[1][0], pk[1][1]};
-                gn[p] = n0 + 16 * (2 * p + (even ? 0 : 1)) + 4 * (even ? g : g - 1);
             }
             u32x4 xa[6], xb[6];
-            if (P.mode >= 3) {
+            if constexpr (MC == 4) {
+#pragma unroll
+                for (int p = 0; p < 6; ++p) { xa[p] = xpre[i][p]; xb[p] = xa[p]; }
+            } else if (P.mode >= 3) {
 #pragma unroll
                 for (int p = 0; p < 6; ++p) {
                     xa[p] = u32x4{0u, 0u, 0u, 0u}; xb[p] = xa[p];
@@ -163,7 +177,11 @@ __global__ __launch_bounds__(KwCfg<AR>::WAVES * 64, 1) void gemm_k192_kernel(KwP
                 for (int p = 0; p < 6; ++p) g_epi_finish(P, gm, gn[p], y[p], tok, sc, xa[p], xb[p]);
             }
         }
-        g_vmcnt<0>();      // the next tile's operands (and, in order behind them, this tile's stores)
+        // the next tile's operands must have landed; this tile's stores, issued behind them (the counter retires in order), need not:
+        // a full tile issues a known number of them
+        constexpr int NST = (MC == 1 || MC == 4) ? RI * 6 : MC == 2 ? RI * 12 : -1;
+        if (NST >= 0 && m0 + KW_AROWS <= P.M) g_vmcnt<(NST >= 0 ? NST : 0)>();
+        else g_vmcnt<0>();
     }
 }
 

@@ -183,18 +183,16 @@ __global__ __launch_bounds__(WinCfg<WS>::NT * 64) void win_attn_fwd_kernel(
         // A = P^T-slot fragment: row (l&15) = query, slots (g, j) = keys {32t+4g+j, 32t+16+4g+j-4}
         const bf16x8 pf = __builtin_bit_cast(bf16x8, pk);
         // B = V with the same k-slot order as P: keys {32t+4g+j, 32t+16+4g+j}, straight from the row-major image
-        o[0] = mfma16(pf, tr_frag(v_l4, 32 * t * RR, (32 * t + 16) * RR), o[0]);  // o[dt][r] = O[query 16w+4g+r][d 16dt+c16]
-        o[1] = mfma16(pf, tr_frag(v_l4, 32 * t * RR + 16, (32 * t + 16) * RR + 16), o[1]);
+        // swapped operands (as the backward's dV / dK / dQ): D = V^T P^T = O^T, so a lane ends up with 4 CONSECUTIVE head-dim entries of ITS
+        // query -- two 8-byte stores per lane and the lane's own 1 / sum, instead of eight 2-byte stores and four shuffles (rounds 1-4)
+        o[0] = mfma16(tr_frag(v_l4, 32 * t * RR, (32 * t + 16) * RR), pf, o[0]);  // o[dt][r] = O[query 16w+c16][d 16dt+4g+r]
+        o[1] = mfma16(tr_frag(v_l4, 32 * t * RR + 16, (32 * t + 16) * RR + 16), pf, o[1]);
     }
+    if (qok) {
+        uint16_t* orow = out + ((int64_t)b * N + qi) * C + h * 32 + 4 * g;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const float invr = __shfl(inv, 4 * g + r);
-        const int q = 16 * w + 4 * g + r;
-        if (q < N) {
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
-                out[((int64_t)b * N + q) * C + h * 32 + 16 * dt + c16] = f2bf(o[dt][r] * invr);
-        }
+        for (int dt = 0; dt < 2; ++dt)
+            *reinterpret_cast<u32x2*>(orow + 16 * dt) = u32x2{pack_bf2(o[dt][0] * inv, o[dt][1] * inv), pack_bf2(o[dt][2] * inv, o[dt][3] * inv)};
     }
 }
 

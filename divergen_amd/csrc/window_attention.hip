@@ -452,6 +452,9 @@ __global__ __launch_bounds__((WinCfg<WS>::NT + (HELP ? 3 : 0)) * 64) void win_at
     __shared__ int last_s;
     auto flush_head = [&](int hh) {
         constexpr int TSPLIT_Q = 3;      // = TSPLIT of the window loop
+#ifdef ABL_NOFLUSH      // (tools/r05_attn_sw.sh: no table-gradient reduction at all -- which also lets the compiler drop the 36 accumulations
+        return;         //  per window from the VALU-bound phase 1, so the difference to the kernel as built overstates the flush)
+#endif
         DGX_LDS float* M = reinterpret_cast<DGX_LDS float*>(lds_opaque(Qs));
         int krow = key * LDM + 4 * g;
         asm volatile("" : "+v"(krow));   // opaque: keeps the 36 store addresses from being formed above the window loop (registers)
@@ -487,6 +490,10 @@ __global__ __launch_bounds__((WinCfg<WS>::NT + (HELP ? 3 : 0)) * 64) void win_at
             }
             __hip_atomic_store(mine + i, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+#ifdef ABL_NOCOUNT      // (breakdown: the flush without the slot hand-over)
+        __syncthreads();
+        return;
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                 // (the matrix has been read: the images may be staged again)
         if (tid == 0) last_s = __hip_atomic_fetch_add(&head_cnt[hh], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == q_runs + nlrun - 1;

@@ -4,9 +4,11 @@ synthetic data + copy-paste) on N MI355X of one node.
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" = for the rank's 2 images: GPU copy-paste compositor (19 pastes/image) -> forward ->
-backward (gradient all-reduce over RCCL overlapped) -> fused clip+AdamW+EMA.  Inputs are resident in
-HBM when the timed region starts.  Prints ONE JSON line (rank 0)."""
+A "step" = for the rank's 2 images: upload from pinned host memory + GPU copy-paste compositor (19 pastes/image), one batch
+ahead on a side stream -> forward -> backward (gradient all-reduce over RCCL overlapped) -> fused clip+AdamW+EMA.
+The images, ground truth and packed paste patches sit in pinned HOST buffers when the timed region starts (what the loader's
+pin thread hands over) and go up every step inside it; --inputs-resident stages them in HBM instead; --through-loader feeds the
+same step from the product's real loader (worker processes).  Prints ONE JSON line (rank 0)."""
 import argparse
 import json
 import os
@@ -38,6 +40,16 @@ def parse():
     p.add_argument("--inputs-resident", action="store_true",
                    help="stage images, ground truth and paste patches in HBM before the timed region (the round-3 form) instead of "
                         "uploading them from pinned host memory every step")
+    p.add_argument("--through-loader", action="store_true",
+                   help="feed the step from the product's real data path (divergen_amd.data.build.build_detection_train_loader: worker "
+                        "processes, pin thread, compositor one batch ahead) over a generated LVIS-format split + PNG instance pool")
+    p.add_argument("--workers", type=int, default=16, help="--through-loader: DATALOADER.NUM_WORKERS (the shipped configs: 16 per GPU)")
+    p.add_argument("--loader-images", type=int, default=48)
+    p.add_argument("--loader-pool", type=int, default=192)
+    p.add_argument("--loader-shards", action="store_true", help="--through-loader: INPUT.INST_POOL_SHARDS (mmap-ed decoded pool) instead of PNG files")
+    p.add_argument("--loader-scale-range", type=float, nargs=2, default=(1.0, 2.0),
+                   help="--through-loader: INPUT.SCALE_RANGE; (1.0, 2.0) makes every crop a full size x size image, i.e. the GPU work of the "
+                        "default bench line; the shipped (0.1, 2.0) also produces smaller images")
     p.add_argument("--distinct-batches", type=int, default=8,
                    help="synthetic (images, ground truth, paste sets) in rotation: proposal / foreground / paste-survivor counts then "
                         "differ from step to step, so the data-dependent paths are inside the timed region")
@@ -339,88 +351,85 @@ def main():
         opt.ema.copy_(opt.arena.p)
     nparams = sum(p.numel() for p in model.parameters())
 
+    from divergen_amd.data.build import BatchAhead
+    from divergen_amd.data.copypaste import InstPool
     nd = max(1, a.distinct_batches)
-    rng = np.random.default_rng(7 + rank)
-    bases, paste_sets = [], []
-    for j in range(nd):
-        n_gt = (12, 10, 14, 12, 8, 16, 11, 13)[j % 8]          # 12 objects per image on average, not the same every step
-        bases.append(synthetic_batch(a.batch, a.size, cfg.MODEL.ROI_HEADS.NUM_CLASSES, seed=1234 + rank + 1000 * j, n_gt=n_gt, device=dev))
-        ps = [make_pastes(rng, a.size) for _ in range(a.batch)]
-        # the paste patches of each image in the form the compositor takes them (one flat buffer + descriptors, layers.pack_pastes:
-        # what a loader worker hands over)
-        paste_sets.append([la.pack_pastes(p_, dev) for p_ in ps])
-    # What a loader worker hands the training process lives in HOST memory (rcnn.py:220-227 moves the images and the instances to
-    # the device inside the step): the uint8 image, the ground-truth masks / boxes / classes and the packed paste patches of every
-    # batch are kept in pinned host buffers and go up on the loader's side stream INSIDE the timed region, every step
-    # (--inputs-resident restores the round-3 form: everything staged in HBM before the clock starts).
     h2d_bytes = [0]
-
-    def pin(t):
-        return t.detach().cpu().pin_memory()
-    host_sets = None
-    if not a.inputs_resident:
-        host_sets = []
-        for base, pastes in zip(bases, paste_sets):
+    loader_info = None
+    if a.through_loader:
+        # The product's REAL data path feeding the same step: json -> dataset dicts -> repeat-factor sampler -> DATALOADER.NUM_WORKERS
+        # worker processes running the whole mapper (JPEG decode, EfficientDetResizeCrop, flip, polygon rasterisation, instance-pool
+        # draws + PNG / shard decode + largest component + resize + flip + placement + packing) -> pin thread -> BatchAhead (upload +
+        # compositor one batch ahead on a side stream).  LVIS is absent here: a generated LVIS-format split + PNG pool stands in.
+        import tempfile
+        from divergen_amd.data.build import build_detection_train_loader
+        from divergen_amd.data.synthetic import write_mini_lvis
+        root = os.path.join(tempfile.gettempdir(), "dgx_bench_lvis_%d_r%d" % (a.size, rank))
+        info = write_mini_lvis(root, n_images=a.loader_images, image_hw=(a.size, a.size), n_obj=12, n_pool=a.loader_pool, pool_px=(256, 512), seed=rank)
+        os.environ["DETECTRON2_DATASETS"] = root
+        opts = ["DATASETS.TRAIN", ("lvis_v1_train",), "INPUT.INST_POOL_PATH", info["pool_json"], "DATALOADER.NUM_WORKERS", a.workers,
+                "INPUT.SCALE_RANGE", tuple(a.loader_scale_range), "INPUT.MEAN_STD2_PATH", os.path.join(ROOT, "configs", "metadata", "area_mean_std2.json")]
+        if a.loader_shards:
+            from divergen_amd.data import pool_store
+            with open(info["pool_json"]) as f:
+                r = pool_store.build_shards(json.load(f), os.path.join(root, "shards"))
+            assert r["failed"] == [], r
+            opts += ["INPUT.INST_POOL_SHARDS", os.path.join(root, "shards")]
+        cfg.merge_from_list(opts)
+        feed = build_detection_train_loader(cfg, a.batch, dev, cfg.SEED)
+        loader_info = {"workers": a.workers, "images": a.loader_images, "pool_instances": a.loader_pool, "pool_format": "shards" if a.loader_shards else "png",
+                       "scale_range": list(a.loader_scale_range), "prefetch_factor": cfg.DATALOADER.PREFETCH_FACTOR}
+    else:
+        # What a loader worker hands the training process lives in HOST memory (rcnn.py:220-227 moves the images and the instances to
+        # the device inside the step): the uint8 image, the ground-truth masks / boxes / classes and the packed paste patches of every
+        # batch are kept in pinned host buffers -- the form the DataLoader's pin thread leaves worker results in -- and go up on the
+        # loader's side stream INSIDE the timed region, every step (--inputs-resident: everything staged in HBM before the clock starts).
+        rng = np.random.default_rng(7 + rank)
+        place = (lambda t: t.to(dev)) if a.inputs_resident else (lambda t: t.detach().cpu().pin_memory())
+        host_batches = []
+        for j in range(nd):
+            n_gt = (12, 10, 14, 12, 8, 16, 11, 13)[j % 8]          # 12 objects per image on average, not the same every step
             per = []
-            for d, pk in zip(base, pastes):
+            for d in synthetic_batch(a.batch, a.size, cfg.MODEL.ROI_HEADS.NUM_CLASSES, seed=1234 + rank + 1000 * j, n_gt=n_gt):
+                flat, desc, labels = la.pack_pastes_host(make_pastes(rng, a.size))
                 inst = d["instances"]
-                per.append(dict(image=pin(d["image"]), masks=pin(inst.gt_masks.tensor.view(torch.uint8)), boxes=pin(inst.gt_boxes.tensor),
-                                classes=pin(inst.gt_classes), flat=pin(pk.flat), desc=pin(pk.desc), labels=pin(pk.labels), K=pk.K))
-            host_sets.append(per)
-        h2d_bytes[0] = sum(v.numel() * v.element_size() for v in host_sets[0][0].values() if torch.is_tensor(v)) * a.batch
-    turn = [0]
+                d["image"] = place(d["image"])
+                d["instances"] = Instances(inst.image_size, gt_boxes=Boxes(place(inst.gt_boxes.tensor)), gt_classes=place(inst.gt_classes),
+                                           gt_masks=BitMasks(place(inst.gt_masks.tensor)))
+                d["paste_pack"] = {"flat": place(flat), "desc": place(desc), "labels": place(labels), "K": int(desc.shape[0])}
+                per.append(d)
+            host_batches.append(per)
+        if not a.inputs_resident:
+            d0 = host_batches[0][0]
+            h2d_bytes[0] = a.batch * sum(t.numel() * t.element_size() for t in (
+                d0["image"], d0["instances"].gt_masks.tensor, d0["instances"].gt_boxes.tensor, d0["instances"].gt_classes,
+                d0["paste_pack"]["flat"], d0["paste_pack"]["desc"], d0["paste_pack"]["labels"]))
 
-    # The copy-paste compositor is the data-loading side of the step (the reference runs it in loader workers,
-    # DG/divergen/data/custom_build_copypaste_mapper.py): it depends on nothing the optimizer produces, so the batch of
-    # step t+1 is composited on a side HIP stream while step t trains, and its one data-dependent shape (objects that
-    # end up fully covered are dropped) is read back from THAT stream instead of draining the training stream.
-    # Every step still composites exactly one batch inside the timed region.
-    side = torch.cuda.Stream()
+        def finish(d, device):
+            if a.no_copy_paste:
+                d = {k: v for k, v in d.items() if k != "paste_pack"}
+                d["image"], d["instances"] = d["image"].to(device, non_blocking=True), d["instances"].to(device)
+                return d
+            out = InstPool.composite(d, device)
+            out.pop("_uploaded")
+            return out
 
-    def compose():
-        batch = []
-        base, pastes = bases[turn[0] % nd], paste_sets[turn[0] % nd]
-        turn[0] += 1
-        hosts = host_sets[(turn[0] - 1) % nd] if host_sets is not None else [None] * len(base)
-        with torch.cuda.stream(side):
-            for d, ps, hs in zip(base, pastes, hosts):
-                inst = d["instances"]
-                if a.no_copy_paste:
-                    batch.append(d)
-                    continue
-                if hs is not None:              # this step's host -> device leg (pinned, asynchronous, on the loader stream)
-                    up = {k: v.to(dev, non_blocking=True) for k, v in hs.items() if torch.is_tensor(v)}
-                    img, gm, gb, gc = up["image"], up["masks"], up["boxes"], up["classes"]
-                    ps = la.PackedPastes(up["flat"], up["desc"], up["labels"], hs["K"])
-                else:
-                    img, gm, gb, gc = d["image"], inst.gt_masks.tensor.view(torch.uint8), inst.gt_boxes.tensor, inst.gt_classes
-                out = la.copy_paste(img, gm, gb, gc, ps, lazy_masks=True)
-                ni = Instances(inst.image_size)
-                ni.gt_boxes, ni.gt_classes = Boxes(out["boxes"]), out["labels"]
-                ni.gt_masks, ni.instance_source = BitMasks(out["masks"].view(torch.bool), index=out["keep"]), out["source"]   # 0/1 bytes: a view; rows through the index
-                batch.append({"image": out["image"], "instances": ni, "height": d["height"], "width": d["width"],
-                              "file_name": d["file_name"]})
-            ev = torch.cuda.Event()
-            ev.record(side)
-        return batch, ev
-
-    nxt = [compose()]
+        def rotation():
+            k = 0
+            while True:
+                yield host_batches[k % nd]
+                k += 1
+        # The copy-paste compositor is the data-loading side of the step (the reference runs it in loader workers,
+        # DG/divergen/data/custom_build_copypaste_mapper.py): BatchAhead uploads and composites the batch of step t+1 on a side
+        # HIP stream while step t trains -- the same object train_net.py's loader is (divergen_amd/data/build.py).
+        # Every step still uploads and composites exactly one batch inside the timed region.
+        feed = BatchAhead(rotation(), finish, dev)
     exposed = [] if (world > 1 and on_gpu) else None
+    data_wait = []
 
     def one_step():
-        batch, ev = nxt[0]
-        torch.cuda.current_stream().wait_event(ev)      # the training stream consumes the composited tensors
-        for d in batch:                                  # ... and owns them from here on (allocator stream bookkeeping)
-            d["image"].record_stream(torch.cuda.current_stream())
-            if "instances" in d and d["instances"].has("gt_masks"):
-                gm = d["instances"].gt_masks
-                gm._base.record_stream(torch.cuda.current_stream())
-                if gm._index is not None:
-                    gm._index.record_stream(torch.cuda.current_stream())
-        # next batch on the side stream, issued BEFORE this step's forward: the host is ahead of the GPU here, whereas after the
-        # forward's one device->host read (proposal sampler) every host microsecond is GPU idle time (measured: -0.55 ms/step
-        # against issuing it between forward and backward)
-        nxt[0] = compose()
+        batch = next(feed)                      # hands over batch t, issues upload + compositor of batch t + 1 on the side stream
+        data_wait.append(feed.wait_s)
         opt.zero_grad()
         losses = model(batch)
         total = total_loss(losses)
@@ -574,16 +583,24 @@ def main():
         line = {"metric": "images/sec (node) Swin-L CenterNet2 LVIS 1024px", "value": imgs / dt, "unit": "images/s",
                 "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
-                "data": "synthetic (random-init weights, LVIS-shaped boxes/masks, 19 RGBA pastes per image; %d distinct batches in rotation)" % nd,
+                "data": ("synthetic (random-init weights; a generated LVIS-format split of %d %dx%d JPEGs with 12 polygon objects each + a pool of %d RGBA PNG "
+                         "instances, through the product's loader: %d worker processes)" % (a.loader_images, a.size, a.size, a.loader_pool, a.workers)) if a.through_loader
+                else "synthetic (random-init weights, LVIS-shaped boxes/masks, 19 RGBA pastes per image; %d distinct batches in rotation)" % nd,
                 "config": {"workload": "CenterNet2 Swin-%s, %dx%d, %d images/GPU, 1453 classes, GPU copy-paste + fwd + bwd + "
                                        "fused clip/AdamW/EMA; configs/DiverGen_swinL.yaml" % (a.swin, a.size, a.size, a.batch),
                            "global_batch": a.batch * world, "parallelism": "dp%d" % world, "params_M": nparams / 1e6},
                 "roofline": roof, "roofline_other": objs[1:], "roofline_steps_sampled": sampled,
                 "host_issue_ms_per_step": t_issue / a.steps * 1e3,
-                "inputs": {"host_to_device_inside_timed_region": host_sets is not None, "h2d_bytes_per_step": h2d_bytes[0],
-                           "how": ("pinned host buffers, non_blocking copies on the loader (side) stream, every step" if host_sets is not None
-                                   else "staged in HBM before the timed region (--inputs-resident)")},
+                "inputs": {"host_to_device_inside_timed_region": not a.inputs_resident, "h2d_bytes_per_step": h2d_bytes[0] or None,
+                           "how": ("worker processes -> pin thread -> non_blocking copies + compositor one batch ahead on the loader (side) stream "
+                                   "(divergen_amd.data.build.BatchAhead fed by build_detection_train_loader)" if a.through_loader else
+                                   "pinned host buffers, non_blocking copies + compositor one batch ahead on the loader (side) stream, every step "
+                                   "(divergen_amd.data.build.BatchAhead, the object train_net.py's loader is)" if not a.inputs_resident
+                                   else "staged in HBM before the timed region (--inputs-resident)"),
+                           "blocked_on_data_ms_per_step": 1e3 * sum(data_wait[-a.steps:]) / max(a.steps, 1)},
                 "peak_hbm_gb_rank0": torch.cuda.max_memory_allocated(dev) / 1e9}
+        if loader_info is not None:
+            line["loader"] = loader_info
         if in_sync is not None:
             line["ranks_seen_by_collective"] = ranks_seen
             line["collective_backend"] = "rccl" if dist.get_backend() == "nccl" else dist.get_backend()

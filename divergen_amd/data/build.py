@@ -257,59 +257,57 @@ def build_custom_augmentation(cfg, is_train):
 
 
 # ----------------------------------------------------------------------------------------------- polygons -> bitmask
-def polygon_to_rle_counts(xy, h, w):
-    """pycocotools maskApi.c rleFrPoly: run lengths (column-major, first run = zeros) of one polygon given as a flat
-    [x0, y0, x1, y1, ...] list.  Restated from the published C source: 5x upsampled integer polygon, all boundary points
-    by the longer-axis walk, the points where the boundary crosses a pixel column centre, sorted -> run lengths."""
+def polygon_crossings(xy, h, w):
+    """pycocotools maskApi.c rleFrPoly up to its sort: the column-major flat positions at which the fill toggles, for one polygon
+    given as a flat [x0, y0, x1, y1, ...] list.  Restated from the published C source -- 5x upsampled integer polygon, all
+    boundary points by the longer-axis walk, the points where the boundary crosses a pixel-column centre -- as numpy array
+    arithmetic (a loader worker rasterises ~12 polygons per image; the per-point Python loop of round 1-5 cost 5 ms each)."""
     k = len(xy) // 2
     scale = 5.0
-    x = [int(scale * xy[2 * j] + 0.5) for j in range(k)]
-    y = [int(scale * xy[2 * j + 1] + 0.5) for j in range(k)]
-    x.append(x[0])
-    y.append(y[0])
-    u, v = [], []
+    pts = np.asarray(xy, dtype=np.float64).reshape(k, 2)
+    x = (scale * pts[:, 0] + 0.5).astype(np.int64)              # C (int) cast: truncation toward zero, as astype does
+    y = (scale * pts[:, 1] + 0.5).astype(np.int64)
+    x, y = np.append(x, x[0]), np.append(y, y[0])
+    us, vs = [], []
     for j in range(k):
-        xs, xe, ys, ye = x[j], x[j + 1], y[j], y[j + 1]
+        xs, xe, ys, ye = int(x[j]), int(x[j + 1]), int(y[j]), int(y[j + 1])
         dx, dy = abs(xe - xs), abs(ys - ye)
         flip = (dx >= dy and xs > xe) or (dx < dy and ys > ye)
         if flip:
             xs, xe, ys, ye = xe, xs, ye, ys
-        s = 0.0 if dx >= dy and dx == 0 else ((ye - ys) / dx if dx >= dy else (0.0 if dy == 0 else (xe - xs) / dy))
         if dx >= dy:
-            for d in range(dx + 1):
-                t = dx - d if flip else d
-                u.append(t + xs)
-                v.append(int(ys + s * t + 0.5))
+            s = 0.0 if dx == 0 else (ye - ys) / dx
+            t = np.arange(dx, -1, -1) if flip else np.arange(dx + 1)
+            us.append(t + xs)
+            vs.append((ys + s * t + 0.5).astype(np.int64))
         else:
-            for d in range(dy + 1):
-                t = dy - d if flip else d
-                v.append(t + ys)
-                u.append(int(xs + s * t + 0.5))
+            s = 0.0 if dy == 0 else (xe - xs) / dy
+            t = np.arange(dy, -1, -1) if flip else np.arange(dy + 1)
+            vs.append(t + ys)
+            us.append((xs + s * t + 0.5).astype(np.int64))
+    u, v = np.concatenate(us), np.concatenate(vs)
     # points along the y-boundary, downsampled
-    xs_, ys_ = [], []
-    for j in range(1, len(u)):
-        if u[j] != u[j - 1]:
-            xd = float(u[j] if u[j] < u[j - 1] else u[j] - 1)
-            xd = (xd + 0.5) / scale - 0.5
-            if np.floor(xd) != xd or xd < 0 or xd > w - 1:
-                continue
-            yd = float(v[j] if v[j] < v[j - 1] else v[j - 1])
-            yd = (yd + 0.5) / scale - 0.5
-            if yd < 0:
-                yd = 0.0
-            elif yd > h:
-                yd = float(h)
-            yd = np.ceil(yd)
-            xs_.append(int(xd))
-            ys_.append(int(yd))
-    a = sorted(xs_[j] * h + ys_[j] for j in range(len(xs_)))
+    u1, u0, v1, v0 = u[1:], u[:-1], v[1:], v[:-1]
+    sel = u1 != u0
+    u1, u0, v1, v0 = u1[sel], u0[sel], v1[sel], v0[sel]
+    xd = (np.where(u1 < u0, u1, u1 - 1).astype(np.float64) + 0.5) / scale - 0.5
+    ok = (np.floor(xd) == xd) & (xd >= 0) & (xd <= w - 1)
+    yd = (np.where(v1 < v0, v1, v0).astype(np.float64) + 0.5) / scale - 0.5
+    yd = np.ceil(np.clip(yd, 0.0, float(h)))
+    return xd[ok].astype(np.int64) * h + yd[ok].astype(np.int64)
+
+
+def polygon_to_rle_counts(xy, h, w):
+    """The run lengths rleFrPoly returns (column-major, first run = zeros): sorted crossings -> differences -> zero-length
+    runs merged into their neighbours (the first run may be zero).  Kept for the known-answer tests; the mapper fills masks
+    from the crossings directly (polygons_to_bitmask)."""
+    a = sorted(int(p) for p in polygon_crossings(xy, h, w))
     a.append(h * w)
     p = 0
     for j in range(len(a)):
         t = a[j]
         a[j] -= p
         p = t
-    # drop zero-length runs by merging their neighbours (the first run may be zero)
     b = []
     j = 0
     if a:
@@ -327,20 +325,25 @@ def polygon_to_rle_counts(xy, h, w):
     return b
 
 
-def polygons_to_bitmask(polygons, h, w):
-    """D2/structures/masks.py:polygons_to_bitmask: union (rleMerge) of the polygons of one instance, decoded (h, w) bool."""
-    m = np.zeros(h * w, dtype=bool)
+def polygons_to_bitmask(polygons, h, w, out=None):
+    """D2/structures/masks.py:polygons_to_bitmask: union (rleMerge) of the polygons of one instance, decoded (h, w) bool
+    (row-major; written into `out` when given).  Decoding the run lengths of rleFrPoly = the parity of the number of crossings
+    at or before each column-major position (a zero-length run is two toggles at one position); only the columns between the
+    first and the last crossing are computed, and transposed into the row-major mask."""
+    m = np.zeros((h, w), dtype=bool) if out is None else out
     for poly in polygons:
-        counts = polygon_to_rle_counts([float(c) for c in poly], h, w)
-        pos, val = 0, False
-        one = np.zeros(h * w, dtype=bool)
-        for c in counts:
-            if val:
-                one[pos:pos + c] = True
-            pos += c
-            val = not val
-        m |= one
-    return m.reshape(w, h).T          # RLE is column-major
+        pos = polygon_crossings([float(c) for c in poly], h, w)
+        pos = pos[pos < h * w]
+        if pos.size == 0:
+            continue
+        c0, c1 = int(pos.min()) // h, int(pos.max()) // h
+        tog = np.zeros((c1 - c0 + 1) * h, dtype=np.uint8)
+        np.add.at(tog, pos - c0 * h, 1)                      # a few hundred crossings
+        tog &= 1
+        m[:, c0:c1 + 1] |= np.bitwise_xor.accumulate(tog).view(bool).reshape(c1 - c0 + 1, h).T
+        if pos.size & 1:                      # an odd number of crossings: the last run of ones reaches the end of the canvas
+            m[:, c1 + 1:] = True
+    return m
 
 
 # ----------------------------------------------------------------------------------------------- mapper
@@ -382,8 +385,10 @@ def annotations_to_instances(annos, image_size):
     target.gt_boxes = Boxes(torch.as_tensor(boxes, dtype=torch.float32).reshape(-1, 4))
     target.gt_classes = torch.tensor([int(a["category_id"]) for a in annos], dtype=torch.int64)
     if annos and "segmentation" in annos[0]:
-        masks = [polygons_to_bitmask(a["segmentation"], h, w) for a in annos]
-        target.gt_masks = BitMasks(torch.from_numpy(np.stack(masks)) if masks else torch.zeros(0, h, w, dtype=torch.bool))
+        masks = np.zeros((len(annos), h, w), dtype=bool)          # one contiguous block: it is pinned and uploaded as it is
+        for i, a in enumerate(annos):
+            polygons_to_bitmask(a["segmentation"], h, w, out=masks[i])
+        target.gt_masks = BitMasks(torch.from_numpy(masks))
     return target
 
 
@@ -392,7 +397,8 @@ def filter_empty_instances(instances, box_threshold=1e-5):
     b = instances.gt_boxes.tensor
     keep = ((b[:, 2] - b[:, 0]) > box_threshold) & ((b[:, 3] - b[:, 1]) > box_threshold)
     if instances.has("gt_masks"):
-        keep &= instances.gt_masks.tensor.flatten(1).any(1)
+        gm = instances.gt_masks.tensor
+        keep &= torch.from_numpy(gm.numpy().reshape(gm.shape[0], -1).any(1)) if not gm.is_cuda else gm.flatten(1).any(1)
     return instances[keep]
 
 
@@ -504,33 +510,48 @@ class CopyPasteMapper:
             test["instances"] = test["instances"][test["instances"].gt_classes == cls]
         return cls, test
 
-    def cpu_part(self, dataset_dict):
-        """What a loader worker runs: decode + augment + rasterise (and the self-copy index draw of mapper.py:877)."""
+    def __call__(self, dataset_dict):
+        """What a LOADER WORKER runs -- all of CopyPasteMapper.__call__ (mapper.py:856-958) except the pixel blend: decode +
+        augment + rasterise, the self-copy index draw (:877), the instance pool's draws / decode / largest component / resize /
+        flip / placement packed for the compositor (InstPool.prepare), BSGAL's held-out image.  CPU tensors only."""
         result = self.mapper(dataset_dict)
+        if "instances" not in result or not result["instances"].has("gt_masks"):        # mapper.py:862-864
+            return result
         if self.use_scp and self.dataset is not None:
             for _ in range(self.num_src):
                 np.random.randint(0, len(self.dataset))
+        if self.inst_pool is None:
+            return result
+        result = self.inst_pool.prepare(result)
+        if self.active_select:
+            cls, test = self._held_out(result.get("paste_labels", []), result["instances"].gt_classes.tolist())
+            result["test_image"], result["test_instances"] = test["image"], test["instances"]
+            result["test_image_class"], result["test_file_name"] = cls, test.get("file_name")
         return result
 
-    def gpu_part(self, result):
-        if "instances" not in result or not result["instances"].has("gt_masks") or self.inst_pool is None:
+    def finish(self, result, device):
+        """What the TRAINING PROCESS runs on one worker result, on the current stream: upload (asynchronous from pinned memory) and
+        the compositor kernel; with INPUT.ACTIVE_SELECT the un-pasted sample stays available as origin_* (it is the uploaded
+        input: the compositor writes a copy)."""
+        from .copypaste import InstPool
+        dev = torch.device(device)
+        if "instances" not in result:
+            result["image"] = result["image"].to(dev, non_blocking=True)
             return result
-        if not self.active_select:
-            return self.inst_pool(result)
-        import copy
-        origin_image, origin_instances = result["image"].clone(), copy.deepcopy(result["instances"])
-        out = self.inst_pool(result)
-        dev = out["image"].device
-        out["origin_image"], out["origin_instances"] = origin_image.to(dev), origin_instances.to(dev)
-        if not origin_instances.has("instance_source"):
-            out["origin_instances"].instance_source = torch.zeros(len(origin_instances), dtype=torch.int64, device=dev)
-        cls, test = self._held_out(out.get("paste_labels", []), origin_instances.gt_classes.tolist())
-        out["test_image"], out["test_instances"] = test["image"].to(dev), test["instances"].to(dev)
-        out["test_image_class"], out["test_file_name"] = cls, test.get("file_name")
+        if "paste_pack" in result and dev.type == "cuda":
+            out = InstPool.composite(result, dev)
+            img, gm, gb, gc = out.pop("_uploaded")
+            origin = Instances(tuple(img.shape[-2:]), gt_boxes=Boxes(gb), gt_classes=gc, gt_masks=BitMasks(gm.view(torch.bool)))
+        else:
+            out = {k: v for k, v in result.items() if k != "paste_pack"}
+            out["image"], out["instances"] = out["image"].to(dev, non_blocking=True), out["instances"].to(dev)
+            img, origin = out["image"], out["instances"]
+        if self.active_select and "test_image" in out:
+            out["origin_image"], out["origin_instances"] = img, origin
+            if not origin.has("instance_source"):
+                origin.instance_source = torch.zeros(len(origin), dtype=torch.int64, device=dev)
+            out["test_image"], out["test_instances"] = out["test_image"].to(dev, non_blocking=True), out["test_instances"].to(dev)
         return out
-
-    def __call__(self, dataset_dict):
-        return self.gpu_part(self.cpu_part(dataset_dict))
 
 
 class _MapDataset(torch.utils.data.Dataset):
@@ -544,16 +565,93 @@ class _MapDataset(torch.utils.data.Dataset):
         return self.fn(self.dicts[i])
 
 
-def _worker_init(worker_id, base_seed):
+def _worker_init(worker_id, base_seed, in_worker=True):
     seed = (base_seed + worker_id) % (2 ** 31)
     np.random.seed(seed)
     torch.manual_seed(seed)
+    if in_worker:
+        torch.set_num_threads(1)      # 16 workers per GPU: one core each
+
+
+def _tensors_of(obj):
+    """Every device tensor reachable from one batched-input dict (image, Instances fields, lazily indexed masks)."""
+    if torch.is_tensor(obj):
+        yield obj
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            yield from _tensors_of(v)
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            yield from _tensors_of(v)
+    elif isinstance(obj, Instances):
+        yield from _tensors_of(obj.get_fields())
+    elif isinstance(obj, Boxes):
+        yield obj.tensor
+    elif isinstance(obj, BitMasks):
+        yield obj._base
+        if obj._index is not None:
+            yield obj._index
+
+
+class BatchAhead:
+    """Host batches (lists of worker results, CPU tensors) -> device batches, prepared ONE BATCH AHEAD on a side HIP stream.
+
+    The copy-paste compositor is the data-loading side of the step (the reference runs it in loader workers): it depends on
+    nothing the optimizer produces.  So while step t trains, the batch of step t+1 is uploaded (pinned memory, asynchronous)
+    and composited on `side`, and its one data-dependent shape (objects that end up fully covered are dropped: one
+    device->host count per image) is read back from THAT stream instead of draining the training stream.  __next__ hands over
+    batch t (the training stream waits for its event and takes ownership of the tensors) and then issues batch t+1 -- before the
+    caller's forward: the host is ahead of the GPU at that point, whereas after the forward's device->host read every host
+    microsecond is GPU idle time.  bench.py's timed step is this class fed with fixed host batches; train_net.py's is this class
+    fed by the DataLoader."""
+
+    def __init__(self, host_batches, finish, device):
+        self.it, self.finish, self.device = iter(host_batches), finish, torch.device(device)
+        self.side = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None
+        self.nxt, self.started = None, False
+        self.wait_s = 0.0                   # seconds __next__ last spent blocked on the workers (the loop's real data_time)
+
+    def _compose(self):
+        import time
+        t0 = time.perf_counter()
+        try:
+            host = next(self.it)
+        except StopIteration:
+            return None
+        self.wait_s = time.perf_counter() - t0
+        if self.side is None:
+            return [self.finish(d, self.device) for d in host], None
+        with torch.cuda.stream(self.side):
+            batch = [self.finish(d, self.device) for d in host]
+            ev = torch.cuda.Event()
+            ev.record(self.side)
+        return batch, ev
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        if not self.started:
+            self.started, self.nxt = True, self._compose()
+        cur = self.nxt
+        if cur is None:
+            raise StopIteration
+        batch, ev = cur
+        if ev is not None:
+            cs = torch.cuda.current_stream(self.device)
+            cs.wait_event(ev)                       # the training stream consumes the composited tensors ...
+            for t in _tensors_of(batch):            # ... and owns them from here on (allocator stream bookkeeping)
+                if t.is_cuda:
+                    t.record_stream(cs)
+        self.nxt = self._compose()
+        return batch
 
 
 def build_detection_train_loader(cfg, per_gpu, device, seed):
     """DG/train_net.py:164-239 + D2/data/build.py:build_detection_train_loader: dataset dicts, sampler by
-    DATALOADER.SAMPLER_TRAIN, CPU mapper in DATALOADER.NUM_WORKERS worker processes, instance copy-paste on the GPU in the
-    training process, batches of `per_gpu` dicts moved to `device`."""
+    DATALOADER.SAMPLER_TRAIN, the whole mapper (copy-paste preparation included) in DATALOADER.NUM_WORKERS worker processes,
+    results pinned by the loader's pin thread; the training process only uploads and runs the compositor kernel, one batch
+    ahead on a side stream (BatchAhead)."""
     import functools
     dicts = get_detection_dataset_dicts(cfg.DATASETS.TRAIN, filter_empty=cfg.DATALOADER.FILTER_EMPTY_ANNOTATIONS)
     name = cfg.DATALOADER.SAMPLER_TRAIN
@@ -567,22 +665,19 @@ def build_detection_train_loader(cfg, per_gpu, device, seed):
     mapper = CopyPasteMapper(DatasetMapper(cfg, True), cfg)
     mapper.set_dataset(dicts)
     rank_seed = seed * 1009 + comm.get_rank() * 131
+    nw = cfg.DATALOADER.NUM_WORKERS
+    on_gpu = torch.device(device).type == "cuda"
     loader = torch.utils.data.DataLoader(
-        _MapDataset(dicts, mapper.cpu_part), sampler=sampler, batch_size=per_gpu, drop_last=True,
-        num_workers=cfg.DATALOADER.NUM_WORKERS, collate_fn=lambda b: b,
-        worker_init_fn=functools.partial(_worker_init, base_seed=rank_seed),
-        prefetch_factor=cfg.DATALOADER.PREFETCH_FACTOR if cfg.DATALOADER.NUM_WORKERS > 0 else None)
-    if cfg.DATALOADER.NUM_WORKERS == 0:
-        _worker_init(0, rank_seed)
-    for batch in loader:
-        out = []
-        for d in batch:
-            d = mapper.gpu_part(d)
-            d["image"] = d["image"].to(device, non_blocking=True)
-            if "instances" in d:
-                d["instances"] = d["instances"].to(device)
-            out.append(d)
-        yield out
+        _MapDataset(dicts, mapper), sampler=sampler, batch_size=per_gpu, drop_last=True, num_workers=nw, collate_fn=_identity,
+        worker_init_fn=functools.partial(_worker_init, base_seed=rank_seed), pin_memory=on_gpu,
+        prefetch_factor=cfg.DATALOADER.PREFETCH_FACTOR if nw > 0 else None, persistent_workers=nw > 0)
+    if nw == 0:
+        _worker_init(0, rank_seed, in_worker=False)
+    return BatchAhead(loader, mapper.finish, device)
+
+
+def _identity(batch):
+    return batch
 
 
 def build_detection_test_loader(cfg, dataset_name, device):

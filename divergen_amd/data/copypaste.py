@@ -4,9 +4,12 @@ Host-side mirror of InstPool (DG/divergen/data/custom_build_copypaste_mapper.py:
 configuration (INST_POOL_FORMAT 'RGBA', INST_POOL_SAMPLE_TYPE 'cas_random', CP_METHOD ['basic'],
 USE_COPY_METHOD 'syn_copy'): class-balanced sampling of generated instances, size prior (Gaussian
 relative-area prior for LVIS classes with statistics, U(RANDOM_SCALE_MIN, MAX) of the source size for
-the rest), random placement -- all numpy/PIL on the CPU worker, with the same np.random call order --
-and ONE call into libdgx (dgx_copy_paste) for the pixels: image blend, mask occlusion updates, box
-recomputation and the occlusion filter of `_copy_paste`, for all pastes of the image at once."""
+the rest), random placement.  Two halves:
+  InstPool.prepare    numpy / PIL only, the reference's np.random call order (pinned on tests/golden/pool_draws.npz, draws of
+                      the reference's own InstPool); runs in the DATALOADER.NUM_WORKERS loader processes and returns the K
+                      patches packed into one flat buffer + descriptors (CPU tensors)
+  InstPool.composite  training process: upload + ONE call into libdgx (dgx_copy_paste) for the pixels -- image blend, mask
+                      occlusion updates, box recomputation and the occlusion filter of `_copy_paste`, all pastes at once."""
 import json
 import os
 from collections import defaultdict
@@ -14,7 +17,7 @@ from collections import defaultdict
 import numpy as np
 import torch
 
-from ..layers import copy_paste
+from ..layers.copy_paste import PackedPastes, copy_paste
 from ..structures import BitMasks, Boxes, Instances
 
 
@@ -154,28 +157,64 @@ class InstPool:
         H, W = train_hw
         return np.random.randint(-x_mid, W - x_mid), np.random.randint(-y_mid, H - y_mid)
 
-    def __call__(self, data):
-        """get_mix_result('cas_random') (mapper.py:213-261) on one mapped sample dict."""
-        image = data["image"]
-        inst = data["instances"]
-        H, W = image.shape[-2:]
+    def draw(self, image_hw):
+        """The random part of get_mix_result('cas_random') + _cat_a_new_image (mapper.py:213-261, :488-496) for one image of size
+        image_hw, in the reference's np.random order: the number of samples, the (class, instance) pairs, then EVERY _load_RGBA
+        (size prior / scale, jitter, flip), and only then the placement of the instances that survived
+        (`datas = [self._load_RGBA(...) ...]` completes before `datas = [random_start_xy(...) ...]` starts).
+        Returns (pastes [(rgba (h,w,4) uint8, x0, y0, label)], names).  Pure numpy / PIL: this is what a loader worker runs."""
+        H, W = image_hw
         num = np.random.randint(0, self.max_samples)
-        pastes, names = [], []
-        for key in [self.dataset[i] for i in self.sample_ids(num)]:
+        keys = [self.dataset[i] for i in self.sample_ids(num)]
+        loaded = []
+        for key in keys:
             r = self.load_rgba(key, (H, W))
-            if r is None:
-                continue
-            rgba, label = r
+            if r is not None:
+                loaded.append((r[0], int(r[1]), str(key)))
+        pastes, names = [], []
+        for rgba, label, key in loaded:
             x0, y0 = self.random_start_xy(rgba, (H, W))
-            pastes.append((rgba, int(x0), int(y0), int(label)))
-            names.append(str(key))
-        dev = image.device if image.is_cuda else torch.device("cuda")
-        out = copy_paste(image.to(dev), inst.gt_masks.tensor.to(dev).view(torch.uint8), inst.gt_boxes.tensor.to(dev),
-                         inst.gt_classes.to(dev), pastes, lazy_masks=True)
+            pastes.append((rgba, int(x0), int(y0), label))
+            names.append(key)
+        return pastes, names
+
+    def prepare(self, data):
+        """Loader-worker half of get_mix_result: draw + decode + clean + resize + flip + place + pack.  Adds to the mapped sample
+        `paste_pack` = dict(flat uint8, desc int32 (K,5), labels int64 (K), K) -- CPU tensors, the compositor's input form --
+        and `paste_labels` / `paste_filename_list` (BSGAL's selection reads these).  No device, no libdgx."""
+        from ..layers.copy_paste import pack_pastes_host
+        H, W = data["image"].shape[-2:]
+        pastes, names = self.draw((H, W))
+        flat, desc, labels = pack_pastes_host(pastes)
+        data = dict(data)
+        data["paste_pack"] = {"flat": flat, "desc": desc, "labels": labels, "K": len(pastes)}
+        data["paste_labels"], data["paste_filename_list"] = [p[3] for p in pastes], names
+        return data
+
+    @staticmethod
+    def composite(data, device):
+        """Training-process half: the prepared sample's tensors go to `device` (asynchronously when they are pinned) and ONE
+        dgx_copy_paste call on the CURRENT stream blends all K patches, updates masks / boxes and drops covered objects.  The
+        caller chooses the stream (data/build.py: a side stream, one batch ahead of the training stream)."""
+        pk = data["paste_pack"]
+        inst = data["instances"]
+        H, W = data["image"].shape[-2:]
+        up = lambda t: t.to(device, non_blocking=True)     # noqa: E731
+        image, gm = up(data["image"]), up(inst.gt_masks.tensor.view(torch.uint8))
+        gb, gc = up(inst.gt_boxes.tensor), up(inst.gt_classes)
+        packed = PackedPastes(up(pk["flat"]), up(pk["desc"]), up(pk["labels"]), int(pk["K"]))
+        out = copy_paste(image, gm, gb, gc, packed, lazy_masks=True)
         ni = Instances((H, W))
         ni.gt_boxes, ni.gt_classes = Boxes(out["boxes"]), out["labels"]
         ni.gt_masks, ni.instance_source = BitMasks(out["masks"].view(torch.bool), index=out["keep"]), out["source"]      # 0/1 bytes: a view; rows through the index
-        data = dict(data)
+        data = {k: v for k, v in data.items() if k != "paste_pack"}
         data["image"], data["instances"], data["height"], data["width"] = out["image"], ni, H, W
-        data["paste_labels"], data["paste_filename_list"] = [p[3] for p in pastes], names      # BSGAL's selection reads these
+        data["_uploaded"] = (image, gm, gb, gc)      # the un-pasted sample on the device (BSGAL keeps it; copy_paste wrote a clone)
+        return data
+
+    def __call__(self, data):
+        """get_mix_result('cas_random') (mapper.py:213-261) on one mapped sample dict, both halves in this process."""
+        dev = data["image"].device if data["image"].is_cuda else torch.device("cuda")
+        data = self.composite(self.prepare(data), dev)
+        data.pop("_uploaded", None)
         return data

@@ -18,36 +18,51 @@ class PackedPastes:
         return self.K
 
 
+def pack_pastes_host(pastes):
+    """list of (rgba uint8 (h, w, 4) numpy, x0, y0, label) -> (flat uint8, desc int32 (K, 5), labels int64 (K)) as CPU tensors:
+    what a LOADER WORKER hands the training process for one image (no device, no libdgx).  K = 0 gives a 4-byte flat buffer."""
+    desc, off = [], 0
+    for rgba, x0, y0, _ in pastes:
+        h, w = int(rgba.shape[0]), int(rgba.shape[1])
+        n = h * w * 4
+        desc.append([off, h, w, int(x0), int(y0)])
+        off += n + ((-n) % 4)
+    host = np.zeros(max(off, 4), dtype=np.uint8)
+    for (rgba, _, _, _), d in zip(pastes, desc):
+        n = d[1] * d[2] * 4
+        a = rgba.detach().cpu().numpy() if isinstance(rgba, torch.Tensor) else np.asarray(rgba)
+        host[d[0]:d[0] + n] = np.ascontiguousarray(a, dtype=np.uint8).reshape(-1)
+    labels = np.array([int(np.asarray(p[3]).reshape(-1)[0]) for p in pastes], dtype=np.int64)
+    return torch.from_numpy(host), torch.from_numpy(np.asarray(desc, dtype=np.int32).reshape(-1, 5)), torch.from_numpy(labels)
+
+
 def pack_pastes(pastes, device):
     """list of (rgba uint8 (h, w, 4) numpy | tensor, x0, y0, label) -> PackedPastes.  Host arrays (the loader's case: patches come
     out of the instance pool in host memory) are laid out in one host buffer and go up in ONE copy; patches that already live on
     the device are gathered with one concatenation.  Round 2 concatenated 2 K device chunks per image inside every step, which
     torch executes as one hipMemcpyAsync per chunk: 38 blit launches of ~10 us per image (0.8 ms per step on the loader stream)."""
     K = len(pastes)
-    desc, off = [], 0
     on_dev = [isinstance(r, torch.Tensor) and r.is_cuda for r, _, _, _ in pastes]
-    sizes = []
-    for rgba, x0, y0, _ in pastes:
-        h, w = int(rgba.shape[0]), int(rgba.shape[1])
-        n = h * w * 4
-        desc.append([off, h, w, int(x0), int(y0)])
-        sizes.append(n)
-        off += n + ((-n) % 4)
     if K and all(on_dev):
-        chunks = []
-        for (rgba, _, _, _), n in zip(pastes, sizes):
+        desc, off, chunks = [], 0, []
+        for rgba, x0, y0, _ in pastes:
+            h, w = int(rgba.shape[0]), int(rgba.shape[1])
+            n = h * w * 4
+            desc.append([off, h, w, int(x0), int(y0)])
+            off += n + ((-n) % 4)
             chunks.append(rgba.reshape(-1))
             if (-n) % 4:
                 chunks.append(torch.zeros((-n) % 4, dtype=torch.uint8, device=device))
         flat = torch.cat(chunks)
-    else:
-        host = np.zeros(max(off, 4), dtype=np.uint8)
-        for (rgba, _, _, _), d, n in zip(pastes, desc, sizes):
-            a = rgba.detach().cpu().numpy() if isinstance(rgba, torch.Tensor) else np.asarray(rgba)
-            host[d[0]:d[0] + n] = np.ascontiguousarray(a, dtype=np.uint8).reshape(-1)
-        flat = torch.from_numpy(host).pin_memory().to(device, non_blocking=True) if torch.device(device).type == "cuda" else torch.from_numpy(host)
-    desc_t = upload_i32(desc, device).view(-1, 5) if K else torch.zeros(0, 5, dtype=torch.int32, device=device)
-    labels = upload_i32([int(np.asarray(p[3]).reshape(-1)[0]) for p in pastes], device).long() if K else torch.zeros(0, dtype=torch.int64, device=device)
+        desc_t = upload_i32(desc, device).view(-1, 5)
+        labels = upload_i32([int(np.asarray(p[3]).reshape(-1)[0]) for p in pastes], device).long()
+        return PackedPastes(flat, desc_t, labels, K)
+    flat, desc, labels = pack_pastes_host(pastes)
+    if torch.device(device).type != "cuda":
+        return PackedPastes(flat, desc, labels, K)
+    flat = flat.pin_memory().to(device, non_blocking=True)
+    desc_t = upload_i32(desc.numpy(), device).view(-1, 5) if K else torch.zeros(0, 5, dtype=torch.int32, device=device)
+    labels = upload_i32(labels.numpy(), device).long() if K else torch.zeros(0, dtype=torch.int64, device=device)
     return PackedPastes(flat, desc_t, labels, K)
 
 

@@ -88,6 +88,15 @@ def _same_buffer(src, view):
     return view
 
 
+class EarlyLosses(dict):
+    """The loss dict of a forward that ALREADY back-propagated the proposal generator's part (early_proposal_backward): those
+    entries are detached, their gradients sit in the arena / on the feature maps.  Correct only for exactly one backward of the
+    plain, unweighted sum of the dict -- which is what engine.total_loss() builds; it marks the dict consumed, and the next
+    early forward refuses to run while an unconsumed one is outstanding (a second forward before backward, a loop that sums
+    the dict itself, per-loss weights or gradient accumulation would otherwise get wrong gradients without a word)."""
+    consumed = False
+
+
 @META_ARCH_REGISTRY.register()
 class CustomRCNN(nn.Module):
     @configurable
@@ -182,6 +191,11 @@ class CustomRCNN(nn.Module):
                 # the consumers of the FPN levels write ONE gradient map per level between them
                 fg, joined = _shared_gradient_maps(features)
             if early and grads_on:
+                prev = self.__dict__.get("_early_outstanding")
+                if prev is not None and not prev.consumed:
+                    raise RuntimeError("early_proposal_backward: the previous forward's loss dict was never passed to engine.total_loss() "
+                                       "(one backward of the plain sum per forward is the contract; switch model.early_proposal_backward "
+                                       "off for loops that weight losses, accumulate gradients or run two forwards per backward)")
                 stubs = {k: _same_buffer(f, _CaptureGradient.apply(fg, i, f.detach().requires_grad_(True)))
                          for i, (k, f) in enumerate(features.items())}
                 proposals, proposal_losses = self.proposal_generator(images, stubs, gt_instances)
@@ -211,9 +225,11 @@ class CustomRCNN(nn.Module):
                 proposals, proposal_losses = self.proposal_generator(images, features, gt_instances)
                 proposals, detector_losses = self.roi_heads(images, features, proposals, gt_instances, ann_type="box",
                                                             only_gt_proposals=only_gt_proposals)
-        losses = {}
+        losses = EarlyLosses() if (early and grads_on) else {}
         losses.update(detector_losses)
         losses.update(proposal_losses)
+        if isinstance(losses, EarlyLosses):
+            self.__dict__["_early_outstanding"] = losses
         return (proposals, losses) if self.return_proposal else losses
 
     @torch.no_grad()

@@ -23,7 +23,10 @@ class Boxes:
         return Boxes(self.tensor.clone())
 
     def to(self, device):
-        return Boxes(self.tensor.to(device=device))
+        return Boxes(self.tensor.to(device=device, non_blocking=torch.device(device).type == "cuda"))      # host -> device only
+
+    def pin_memory(self):
+        return Boxes(self.tensor.pin_memory())
 
     def area(self):
         b = self.tensor
@@ -103,6 +106,9 @@ class BitMasks:
     def to(self, *args, **kwargs):
         base = self._base.to(*args, **kwargs)
         return BitMasks(base, None if self._index is None else self._index.to(base.device))
+
+    def pin_memory(self):
+        return BitMasks(self._base.pin_memory(), None if self._index is None else self._index.pin_memory())
 
     @property
     def device(self):
@@ -221,6 +227,10 @@ class Instances:
 
     def to(self, *args, **kwargs):
         return self._rebuild(lambda v: v.to(*args, **kwargs) if hasattr(v, "to") else v)
+
+    def pin_memory(self):
+        """torch.utils.data's pin thread calls this on custom batch members: worker results go up asynchronously."""
+        return self._rebuild(lambda v: v.pin_memory() if hasattr(v, "pin_memory") else v)
 
     def __len__(self):
         if not self._fields:

@@ -599,6 +599,185 @@ def gen_pool():
     save("pool_decode", **store)
 
 
+def _install_fvcore_transforms():
+    """fvcore.transforms.transform is third-party and absent: the four members the reference's D2 augmentation files use here,
+    restated from fvcore's published semantics (Transform.apply_box through the four corners; HFlipTransform flips axis 1 and
+    maps x -> width - x; NoOpTransform; TransformList).  Everything else they import is a bare name (never called)."""
+    class Transform:
+        def _set_attributes(self, params=None):
+            if params:
+                for k, v in params.items():
+                    if k != "self" and not k.startswith("_"):
+                        setattr(self, k, v)
+
+        def apply_box(self, box):
+            idxs = np.array([(0, 1), (2, 1), (0, 3), (2, 3)]).flatten()
+            coords = np.asarray(box).reshape(-1, 4)[:, idxs].reshape(-1, 2)
+            coords = self.apply_coords(coords).reshape((-1, 4, 2))
+            return np.concatenate((coords.min(axis=1), coords.max(axis=1)), axis=1)
+
+        def apply_segmentation(self, segmentation):
+            return self.apply_image(segmentation)
+
+        @classmethod
+        def register_type(cls, data_type, func):          # D2's transform.py registers rotated-box handlers at import
+            setattr(cls, "apply_" + data_type, func)
+
+    class HFlipTransform(Transform):
+        def __init__(self, width):
+            self.width = width
+
+        def apply_image(self, img):
+            return np.flip(img, axis=1) if img.ndim <= 3 else np.flip(img, axis=-2)
+
+        def apply_coords(self, coords):
+            coords[:, 0] = self.width - coords[:, 0]
+            return coords
+
+    class NoOpTransform(Transform):
+        def apply_image(self, img):
+            return img
+
+        def apply_coords(self, coords):
+            return coords
+
+        def apply_segmentation(self, seg):
+            return seg
+
+    class TransformList(Transform):
+        def __init__(self, transforms):
+            self.transforms = list(transforms)
+
+    ft = types.ModuleType("fvcore.transforms.transform")
+    for nm in ("BlendTransform", "CropTransform", "PadTransform", "VFlipTransform"):
+        setattr(ft, nm, type(nm, (Transform,), {}))
+    ft.Transform, ft.HFlipTransform, ft.NoOpTransform, ft.TransformList = Transform, HFlipTransform, NoOpTransform, TransformList
+    pkg = types.ModuleType("fvcore.transforms")
+    pkg.transform = ft
+    sys.modules["fvcore.transforms"] = pkg
+    sys.modules["fvcore.transforms.transform"] = ft
+
+
+def gen_pool_draws():
+    """The reference's InstPool.get_mix_result('cas_random') END TO END (mapper.py:213-261 -> _get_cls_balanced_random_samples
+    :263-296 -> _cat_a_new_image :488-507 -> _load_RGBA :359-456 -> random_start_xy :45-66 -> _copy_paste :510-566) on the PNG
+    fixtures under tests/golden/pool/, from seeded np.random streams, with the reference's own D2 RandomFlip / AugInput /
+    AugmentationList (D2/data/transforms/augmentation*.py run from their files).  Recorded: the order and values of every draw
+    that reaches a side effect (key, target size, flip, placement) and the final image / boxes / classes / masks /
+    instance_source.  cv2 is absent: cv2.resize is a PIL-bilinear stand-in (the build's own `_resize`, so the PIXELS of a resized
+    patch are not pinned by this file, their position / size / order are), cv2.warpAffine with the integer translation
+    pad_to_hw builds is a shifted copy with a zero border."""
+    import importlib.util
+    from PIL import Image
+    mp = R.ref("divergen.data.custom_build_copypaste_mapper")
+    _install_fvcore_transforms()
+    if not hasattr(Image, "LINEAR"):          # removed from Pillow 10; D2's transform.py names it in a default argument
+        Image.LINEAR = Image.BILINEAR
+    for nm in ("detectron2.data.transforms", "detectron2.data.transforms.augmentation", "detectron2.data.transforms.transform",
+               "detectron2.data.transforms.augmentation_impl"):
+        sys.modules.pop(nm, None)
+    pkg = types.ModuleType("detectron2.data.transforms")
+    pkg.__path__ = [R.D2 + "/data/transforms"]
+    sys.modules["detectron2.data.transforms"] = pkg
+    for leaf in ("augmentation", "transform", "augmentation_impl"):
+        spec = importlib.util.spec_from_file_location("detectron2.data.transforms." + leaf, R.D2 + "/data/transforms/%s.py" % leaf)
+        m = importlib.util.module_from_spec(spec)
+        sys.modules[spec.name] = m
+        spec.loader.exec_module(m)
+        setattr(pkg, leaf, m)
+    T = types.SimpleNamespace(AugInput=pkg.augmentation.AugInput, AugmentationList=pkg.augmentation.AugmentationList,
+                              RandomFlip=pkg.augmentation_impl.RandomFlip)
+    mp.T = T
+    log = []
+
+    def resize(img, size):
+        tw, th = int(size[0]), int(size[1])
+        log.append(("resize", img.shape[0], img.shape[1], tw, th))
+        return np.array(Image.fromarray(np.ascontiguousarray(img), "RGBA").resize((tw, th), Image.BILINEAR))
+
+    def warp_affine(data, M, wh):
+        w, h = wh
+        x0, y0 = int(M[0][2]), int(M[1][2])
+        assert float(M[0][2]) == x0 and float(M[1][2]) == y0 and M[0][0] == 1 and M[1][1] == 1
+        src = data if data.ndim == 3 else data[:, :, None]
+        out = np.zeros((h, w, src.shape[2]), dtype=data.dtype)
+        sh, sw = src.shape[:2]
+        ys, xs, ye, xe = max(y0, 0), max(x0, 0), min(y0 + sh, h), min(x0 + sw, w)
+        if ye > ys and xe > xs:
+            out[ys:ye, xs:xe] = src[ys - y0:ye - y0, xs - x0:xe - x0]
+        return out if data.ndim == 3 else out[:, :, 0]
+    mp.cv2.resize, mp.cv2.warpAffine = resize, warp_affine
+    real_start_xy = mp.start_xy
+
+    def start_xy(data_dict, bb, train_size):
+        log.append(("place", int(bb[0]), int(bb[1]), int(data_dict["gt_labels"][0])))
+        return real_start_xy(data_dict, bb, train_size)
+    mp.start_xy = start_xy
+
+    class _Masks:
+        def __init__(self, t):
+            self.tensor = torch.as_tensor(t)
+
+        def __len__(self):
+            return self.tensor.shape[0]
+    mp.BitMasks = _Masks
+
+    names = [str(k) for k in np.load(os.path.join(HERE, "pool_decode.npz"))["keys"]]
+    pool = {3: names[0:2], 7: names[2:3], 11: names[3:6]}
+    ip = mp.InstPool.__new__(mp.InstPool)
+    ip.dataset, ip.data_to_cat, ip.per_cat_pool = [], {}, {}
+    for c, keys in pool.items():
+        ip.per_cat_pool[c] = list(range(len(ip.dataset), len(ip.dataset) + len(keys)))
+        ip.dataset += keys
+        for k in keys:
+            ip.data_to_cat[k] = c
+    ip.cats = list(ip.per_cat_pool.keys())
+    ip.HWms = {"4": [0.16, 0.05], "12": [0.2, 0.08]}             # category 7 (key "8") has no statistics: uniform-scale branch
+    ip.augmentations = T.AugmentationList([T.RandomFlip()])
+    ip.cumstom_augmentations = lambda image: {"image": image}    # albumentations.Compose([]) (COLOR_AUG false): identity, no draws
+    ip.order_seed_state_dict = None
+    ip.image_format, ip.cp_method, ip.max_samples = "RGBA", ["basic"], 8
+    ip.bbox_occluded_thr, ip.mask_occluded_thr = 10, 300
+    ip.scale_min, ip.scale_max, ip.instance_filter_min, ip.instance_filter_max = 10, 0.5, 0.01, 1.0
+    ip.mask_threshold, ip.use_largest_part, ip.shape_jitter = 128, False, 0.2
+    ip.random_scale, ip.random_scale_min, ip.random_scale_max, ip.random_scale_min_size = False, 0.5, 2.0, 5
+    H, W = 160, 192
+    rng = np.random.default_rng(33)
+    store = {"pool_cats": np.array([3, 3, 7, 11, 11, 11]), "hw": np.array([H, W]), "max_samples": np.array(8),
+             "HWms_keys": np.array(["4", "12"]), "HWms_vals": np.array([[0.16, 0.05], [0.2, 0.08]])}
+    cwd = os.getcwd()
+    os.chdir(HERE)
+    try:
+        for ci, seed in enumerate([11, 12, 13, 14, 15, 16, 17, 18]):
+            n0 = int(rng.integers(0, 5)) if ci else 3
+            img = rng.integers(0, 256, (3, H, W), dtype=np.uint8)
+            yy, xx = np.mgrid[0:H, 0:W]
+            masks = np.zeros((n0, H, W), np.uint8)
+            for i in range(n0):
+                cx, cy, rx, ry = rng.uniform(20, W - 20), rng.uniform(20, H - 20), rng.uniform(6, 40), rng.uniform(6, 40)
+                masks[i] = ((((xx - cx) / rx) ** 2 + ((yy - cy) / ry) ** 2) <= 1)
+            boxes = mp.get_bboxes(masks)
+            labels = rng.integers(0, 1203, n0).astype(np.int64)
+            inst = mp.Instances((H, W))
+            inst.gt_boxes, inst.gt_classes, inst.gt_masks = mp.Boxes(torch.from_numpy(boxes)), torch.from_numpy(labels), _Masks(masks)
+            d = {"image": torch.from_numpy(img.copy()), "instances": inst, "file_name": "case%d" % ci}
+            del log[:]
+            np.random.seed(seed)
+            out = ip.get_mix_result("cas_random", None, data_dict=d)
+            after = np.random.randint(0, 2 ** 31 - 1)            # the stream position after the call: one more draw
+            o = out["instances"]
+            store.update({"c%d_seed" % ci: np.array(seed), "c%d_image" % ci: img, "c%d_masks" % ci: masks, "c%d_boxes" % ci: boxes,
+                          "c%d_labels" % ci: labels, "c%d_after" % ci: np.array(after),
+                          "c%d_resize" % ci: np.array([e[1:] for e in log if e[0] == "resize"], dtype=np.int64).reshape(-1, 4),
+                          "c%d_place" % ci: np.array([e[1:] for e in log if e[0] == "place"], dtype=np.int64).reshape(-1, 3),
+                          "c%d_out_image" % ci: npy(out["image"]), "c%d_out_boxes" % ci: npy(o.gt_boxes.tensor),
+                          "c%d_out_labels" % ci: npy(o.gt_classes), "c%d_out_masks" % ci: npy(o.gt_masks.tensor).astype(np.uint8),
+                          "c%d_out_source" % ci: npy(o.instance_source)})
+    finally:
+        os.chdir(cwd)
+    save("pool_draws", **store)
+
+
 def gen_bsgal():
     """BSGAL gradient bank: update_grad_bank / compute_grad_sim of the reference's CustomRCNN
     (BS/bsgal/modeling/meta_arch/custom_rcnn.py:1046-1086) called unbound on a stand-in `self`."""
@@ -727,6 +906,6 @@ def gen_samplers():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["swin", "centernet", "roi", "compositor", "solver", "heads", "heads_wide", "postprocess", "inference", "pool", "bsgal", "augment", "samplers"]
+    which = sys.argv[1:] or ["swin", "centernet", "roi", "compositor", "solver", "heads", "heads_wide", "postprocess", "inference", "pool", "bsgal", "augment", "samplers", "pool_draws"]
     for w in which:
         globals()["gen_" + w]()

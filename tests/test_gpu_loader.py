@@ -1,0 +1,148 @@
+"""GPU: the product's REAL data path, end to end.
+(a) InstPool (worker half + compositor kernel) on the PNG fixtures against the reference's own get_mix_result outputs
+    (tests/golden/pool_draws.npz) and against oracle/compositor.py fed the same draws -- directly and through the shard store;
+(b) build_detection_train_loader with worker processes: what comes out is what one process computes, composited one batch ahead;
+(c) train_net.do_train on a generated LVIS-format split + PNG pool with DATALOADER.NUM_WORKERS 4: loss keys, metrics.json,
+    checkpoint file set and contents, --resume.
+Reference: DG/divergen/data/custom_build_copypaste_mapper.py:856-958,213-296,359-456,488-566; DG/train_net.py:164-239,248-304."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+FREQ = os.path.join(ROOT, "configs", "metadata", "ImageNet2012_filtered04_lvis_v1_train_cat_info_250.json")
+
+
+@pytest.fixture()
+def in_golden_dir(monkeypatch):
+    monkeypatch.chdir(GOLD)
+
+
+def _case_input(z, ci, H, W):
+    from divergen_amd.structures import BitMasks, Boxes, Instances
+    inst = Instances((H, W), gt_boxes=Boxes(torch.from_numpy(z["c%d_boxes" % ci])), gt_classes=torch.from_numpy(z["c%d_labels" % ci]),
+                     gt_masks=BitMasks(torch.from_numpy(z["c%d_masks" % ci])))
+    return {"image": torch.from_numpy(z["c%d_image" % ci]), "instances": inst, "file_name": "case%d" % ci}
+
+
+@pytest.mark.parametrize("through_shards", [False, True])
+def test_instpool_end_to_end_equals_reference_mix_result(in_golden_dir, tmp_path, through_shards):
+    from oracle import compositor as OK
+    from tests.test_host_pool_draws import cases, make_pool
+    z = np.load(os.path.join(GOLD, "pool_draws.npz"))
+    loader = None
+    if through_shards:          # INPUT.INST_POOL_SHARDS: the same keys decoded once into mmap-ed shard files
+        from divergen_amd.data import pool_store as PS
+        keys = [str(k) for k in np.load(os.path.join(GOLD, "pool_decode.npz"))["keys"]]
+        r = PS.build_shards({"0": keys}, str(tmp_path / "shards"))
+        assert r["records"] == len(keys)
+        loader = PS.PoolStore(str(tmp_path / "shards")).loader
+    ip = make_pool(z, loader)
+    H, W = (int(v) for v in z["hw"])
+    n_pasted = 0
+    for ci in cases(z):
+        np.random.seed(int(z["c%d_seed" % ci]))
+        out = ip(_case_input(z, ci, H, W))              # prepare (CPU) + composite (dgx_copy_paste)
+        o = out["instances"]
+        assert out["image"].is_cuda and (out["height"], out["width"]) == (H, W)
+        assert np.array_equal(out["image"].cpu().numpy(), z["c%d_out_image" % ci]), ci
+        assert np.array_equal(o.gt_boxes.tensor.cpu().numpy(), z["c%d_out_boxes" % ci])
+        assert np.array_equal(o.gt_classes.cpu().numpy(), z["c%d_out_labels" % ci])
+        assert np.array_equal(o.gt_masks.tensor.cpu().numpy().astype(np.uint8), z["c%d_out_masks" % ci])
+        assert np.array_equal(o.instance_source.cpu().numpy(), z["c%d_out_source" % ci])
+        n_pasted += int(o.instance_source.sum())
+        # the same draws through the oracle compositor
+        np.random.seed(int(z["c%d_seed" % ci]))
+        pastes, _ = ip.draw((H, W))
+        ref = OK.composite(z["c%d_image" % ci], z["c%d_masks" % ci], z["c%d_boxes" % ci], z["c%d_labels" % ci], pastes)
+        assert np.array_equal(out["image"].cpu().numpy(), ref["image"]) and np.array_equal(o.gt_masks.tensor.cpu().numpy().astype(np.uint8), ref["masks"])
+        assert out["paste_labels"] == [p[3] for p in pastes]
+    assert n_pasted >= 10
+
+
+def _mini_cfg(tmp_path, size, workers, extra=()):
+    from divergen_amd.config import add_bsgal_config, add_centernet_config, add_divergen_config, get_cfg
+    from divergen_amd.data.synthetic import write_mini_lvis
+    info = write_mini_lvis(str(tmp_path / "data"), n_images=12, image_hw=(120, 160), n_obj=5, n_pool=10, pool_px=(40, 90), seed=5, poly_vertices=16)
+    cfg = get_cfg()
+    add_centernet_config(cfg), add_divergen_config(cfg), add_bsgal_config(cfg)
+    cfg.merge_from_file(os.path.join(ROOT, "configs", "DiverGen_swinL.yaml"))
+    cfg.merge_from_list(["MODEL.SWIN.SIZE", "T", "MODEL.ROI_BOX_HEAD.CAT_FREQ_PATH", FREQ, "INPUT.TRAIN_SIZE", size,
+                         "INPUT.INST_POOL_PATH", info["pool_json"], "INPUT.MEAN_STD2_PATH", os.path.join(ROOT, "configs", "metadata", "area_mean_std2.json"),
+                         "INPUT.RANDOM_SCALE_MIN", 0.3, "INPUT.RANDOM_SCALE_MAX", 1.2, "DATALOADER.NUM_WORKERS", workers,
+                         "SOLVER.IMS_PER_BATCH", 2, "MODEL.WEIGHTS", "", "OUTPUT_DIR", str(tmp_path / "out"), "MODEL.DEVICE", "cuda"] + list(extra))
+    return cfg, info
+
+
+def test_loader_with_workers_equals_one_process(tmp_path, monkeypatch):
+    """4 worker processes + pin thread + side-stream compositor against the same mapper run inline with the workers' seeds:
+    every batch bit-identical (a batch comes from ONE worker, seeded base + worker_id, visiting samples in sampler order)."""
+    from divergen_amd.data import build as B
+    cfg, info = _mini_cfg(tmp_path, 128, 4)
+    monkeypatch.setenv("DETECTRON2_DATASETS", info["root"])
+    seed, per_gpu, nb = 3, 2, 6
+    it = B.build_detection_train_loader(cfg, per_gpu, "cuda", seed)
+    got = [next(it) for _ in range(nb)]
+    torch.cuda.synchronize()
+    # inline: worker w handles batches w, w + 4, ... with np.random seeded (seed * 1009 + w)
+    dicts = B.get_detection_dataset_dicts(cfg.DATASETS.TRAIN, filter_empty=cfg.DATALOADER.FILTER_EMPTY_ANNOTATIONS)
+    mapper = B.CopyPasteMapper(B.DatasetMapper(cfg, True), cfg)
+    mapper.set_dataset(dicts)
+    from divergen_amd.data.samplers import RepeatFactorTrainingSampler
+    rf = RepeatFactorTrainingSampler.repeat_factors_from_category_frequency(dicts, cfg.DATALOADER.REPEAT_THRESHOLD)
+    import itertools
+    idx = list(itertools.islice(iter(RepeatFactorTrainingSampler(rf, seed=seed)), nb * per_gpu))
+    pasted = 0
+    for w in range(4):
+        np.random.seed((seed * 1009 + w) % (2 ** 31))
+        for b in range(w, nb, 4):
+            for j in range(per_gpu):
+                want = mapper.finish(mapper(dicts[idx[b * per_gpu + j]]), "cuda")
+                have = got[b][j]
+                assert have["file_name"] == want["file_name"]
+                assert torch.equal(have["image"], want["image"]), (b, j)
+                hi, wi = have["instances"], want["instances"]
+                assert torch.equal(hi.gt_boxes.tensor, wi.gt_boxes.tensor) and torch.equal(hi.gt_classes, wi.gt_classes)
+                assert torch.equal(hi.gt_masks.tensor, wi.gt_masks.tensor) and torch.equal(hi.instance_source, wi.instance_source)
+                assert "paste_pack" not in have and have["paste_filename_list"] == want["paste_filename_list"]
+                pasted += int(hi.instance_source.sum())
+    assert pasted > 0 and it.side is not None
+
+
+def test_do_train_through_the_real_loader_checkpoints_and_resumes(tmp_path, monkeypatch):
+    sys.path.insert(0, ROOT)
+    import train_net
+    from divergen_amd.modeling import build_model
+    cfg, info = _mini_cfg(tmp_path, 128, 4, ["SOLVER.MAX_ITER", 30, "SOLVER.CHECKPOINT_PERIOD", 12, "SOLVER.WARMUP_ITERS", 5, "SEED", 7])
+    monkeypatch.setenv("DETECTRON2_DATASETS", info["root"])
+    torch.manual_seed(7)
+    opt = train_net.do_train(cfg, build_model(cfg))
+    out = str(tmp_path / "out")
+    files = sorted(f for f in os.listdir(out) if f.endswith(".pth") or f == "last_checkpoint")
+    assert files == ["last_checkpoint", "model_0000011.pth", "model_0000023.pth", "model_final.pth"], files
+    assert open(os.path.join(out, "last_checkpoint")).read().strip() == "model_final.pth"
+    ck = torch.load(os.path.join(out, "model_final.pth"), map_location="cpu", weights_only=False)
+    assert {"model", "optimizer", "scheduler", "model_ema", "iteration"} <= set(ck) and ck["iteration"] == 30      # DG/train_net.py:257 counts from 1; the final save fires at max_iter - 1 and max_iter
+    rows = [json.loads(line) for line in open(os.path.join(out, "metrics.json"))]
+    keys = {"loss_cls_stage0", "loss_box_reg_stage0", "loss_cls_stage1", "loss_box_reg_stage1", "loss_cls_stage2", "loss_box_reg_stage2",
+            "loss_mask", "loss_centernet_loc", "loss_centernet_agn_pos", "loss_centernet_agn_neg", "total_loss", "lr", "data_time", "time", "iteration"}
+    assert rows and keys <= set(rows[-1]), sorted(set(rows[-1]))
+    assert all(np.isfinite(r["total_loss"]) for r in rows)
+    p_end = opt.arena.p.clone()
+    # --resume: continues after iteration 30 of a longer schedule, with the saved optimizer / scheduler / EMA
+    cfg2 = cfg.clone()
+    cfg2.defrost()
+    cfg2.merge_from_list(["SOLVER.MAX_ITER", 36])
+    torch.manual_seed(8)
+    opt2 = train_net.do_train(cfg2, build_model(cfg2), resume=True)
+    ck2 = torch.load(os.path.join(out, "model_final.pth"), map_location="cpu", weights_only=False)
+    assert ck2["iteration"] == 36
+    assert float((opt2.arena.p - p_end).abs().max()) > 0                     # it trained on ...
+    rows2 = [json.loads(line) for line in open(os.path.join(out, "metrics.json"))]
+    assert rows2[-1]["iteration"] > rows[-1]["iteration"]

@@ -456,6 +456,32 @@ def test_first_writer_gradients_train_like_zero_filled_ones(monkeypatch):
     assert any("box_head" in n for n in names) and any("mlp.fc1.weight" in n for n in names)
 
 
+def test_early_proposal_backward_contract_is_enforced():
+    """the early mode is correct only for ONE backward of the plain sum per forward.  The loss dict is marked
+    (EarlyLosses), engine.total_loss() consumes it once, and a forward while an unconsumed dict is outstanding raises."""
+    from divergen_amd.data import synthetic_batch
+    from divergen_amd.engine import total_loss
+    from divergen_amd.modeling.meta_arch.custom_rcnn import EarlyLosses
+    from divergen_amd.utils.events import EventStorage
+    cfg, model, opt = _build(False)
+    model.early_proposal_backward = True
+    batch = synthetic_batch(2, 256, cfg.MODEL.ROI_HEADS.NUM_CLASSES, device="cuda")
+    with EventStorage(0):
+        opt.zero_grad()
+        losses = model(batch)
+        assert isinstance(losses, EarlyLosses) and not losses.consumed
+        with pytest.raises(RuntimeError, match="never passed to engine.total_loss"):
+            model(batch)                               # a second forward before the first one's backward
+        total_loss(losses).backward()
+        with pytest.raises(RuntimeError, match="summed before"):
+            total_loss(losses)
+        opt.zero_grad()
+        total_loss(model(batch)).backward()            # the ordinary sequence goes on working
+        model.early_proposal_backward = False
+        assert not isinstance(model(batch), EarlyLosses)
+    torch.cuda.synchronize()
+
+
 def test_early_proposal_backward_is_the_same_step():
     """model.early_proposal_backward (the training loops switch it on: the proposal generator's losses are back-propagated from inside the
     forward, ahead of the RoI heads' device->host read, the box cascade's right behind its forward): the forward is untouched -- every loss bit-identical, the same random draws --,

@@ -152,13 +152,13 @@ def test_bsgal_configs_load_and_mapper_adds_the_selection_inputs(tmp_path, monke
     assert set(mapper.per_cat_pool_real) == {0, 1, 2} and all(mapper.per_cat_pool_real[c] for c in (0, 1, 2))
 
     class _Pool:                                     # stands in for InstPool (its compositor needs the GPU): "pastes" class 2
-        def __call__(self, data):
+        def prepare(self, data):
             out = dict(data)
             out["paste_labels"], out["paste_filename_list"] = [2], ["p.png"]
             return out
     mapper.inst_pool = _Pool()
     np.random.seed(0)
-    out = mapper(dicts[0])
+    out = mapper.finish(mapper(dicts[0]), "cpu")          # worker half, then the training process's half
     assert out["test_image_class"] == 2 and (out["test_instances"].gt_classes == 2).any()
     assert torch.equal(out["origin_image"], out["image"]) and len(out["origin_instances"]) == len(out["instances"])
     assert out["origin_instances"].instance_source.tolist() == [0] * len(out["instances"])

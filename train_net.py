@@ -64,8 +64,11 @@ def build_train_loader(cfg, device, seed=None):
     names = tuple(cfg.DATASETS.TRAIN)
     if names != ("synthetic",):
         from divergen_amd.data.build import build_detection_train_loader
-        yield from build_detection_train_loader(cfg, per_gpu, device, seed)
-        return
+        return build_detection_train_loader(cfg, per_gpu, device, seed)
+    return _synthetic_loader(cfg, per_gpu, device, seed)
+
+
+def _synthetic_loader(cfg, per_gpu, device, seed):
     size = cfg.INPUT.TRAIN_SIZE
     ncls = cfg.MODEL.ROI_HEADS.NUM_CLASSES
     it = 0
@@ -163,7 +166,8 @@ def do_train(cfg, model, resume=False):
         t_start = time.perf_counter()
         t_data = time.perf_counter()
         for data, iteration in zip(loader, range(start_iter, max_iter)):
-            storage.put_scalars(data_time=time.perf_counter() - t_data)
+            # the loader composites one batch ahead inside next(): `wait_s` is the part of it spent blocked on the workers
+            storage.put_scalars(data_time=getattr(loader, "wait_s", time.perf_counter() - t_data))
             t_step = time.perf_counter()
             iteration = iteration + 1
             storage.step()

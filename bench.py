@@ -61,6 +61,8 @@ def parse():
     p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="collective backend (nccl = RCCL on ROCm)")
     p.add_argument("--share-device", type=int, default=None, metavar="D",
                    help="all ranks on GPU D: N-rank plumbing test on a one-GPU box (use with --backend gloo); not a scaling run")
+    p.add_argument("--allreduce-dtype", default="fp32", choices=["fp32", "bf16"],
+                   help="SOLVER.ALLREDUCE_DTYPE: bf16 sends the gradient buckets over xGMI as bf16 (half the bytes); default fp32 = the reference's DDP")
     p.add_argument("--force-pg", action="store_true", help="create a process group even at N = 1 (RCCL next to hipGraph capture)")
     p.add_argument("--dev", action="append", default=[], metavar="KEY=VALUE",
                    help="development A/B: dgx_dev_set(KEY, VALUE) before the model is built (include/divergen_hip.h; e.g. gemm_lw=1); "
@@ -345,7 +347,7 @@ def main():
     model.early_box_backward = a.early_box_backward
     opt = build_optimizer(cfg, model)
     sched = build_lr_scheduler(cfg, opt)
-    reducer = ArenaReducer(opt.arena, single_rank_group=a.force_pg)
+    reducer = ArenaReducer(opt.arena, single_rank_group=a.force_pg, wire_dtype=a.allreduce_dtype)
     reducer.broadcast_parameters()
     if opt.ema is not None:
         opt.ema.copy_(opt.arena.p)
@@ -427,14 +429,25 @@ def main():
     exposed = [] if (world > 1 and on_gpu) else None
     data_wait = []
 
+    host = {"feed": 0.0, "forward": 0.0, "backward": 0.0, "optimizer": 0.0}      # host seconds per section (diagnostic)
+    pc = time.perf_counter
+
     def one_step():
+        t0 = pc()
         batch = next(feed)                      # hands over batch t, issues upload + compositor of batch t + 1 on the side stream
         data_wait.append(feed.wait_s)
+        t1 = pc()
         opt.zero_grad()
         losses = model(batch)
         total = total_loss(losses)
+        t2 = pc()
         reducer.begin_backward()
         total.backward()
+        t3 = pc()
+        host["feed"] += t1 - t0
+        host["forward"] += t2 - t1
+        host["backward"] += t3 - t2
+        host["optimizer"] -= t3
         if exposed is not None:                 # N > 1: the time the training stream spends waiting for collectives BEHIND backward
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -445,6 +458,7 @@ def main():
             scale = reducer.finish()
         opt.step(grad_scale=scale)
         sched.step()
+        host["optimizer"] += pc()
         return total
 
     def sync():
@@ -463,6 +477,8 @@ def main():
             sync()
         prof.enable(not a.no_roofline)        # restart the tallies: the timed region only
         prof.pause(True)
+        for k_ in host:
+            host[k_] = 0.0
         sampled = 0
         t0 = time.perf_counter()
         for k in range(a.steps):
@@ -591,6 +607,7 @@ def main():
                            "global_batch": a.batch * world, "parallelism": "dp%d" % world, "params_M": nparams / 1e6},
                 "roofline": roof, "roofline_other": objs[1:], "roofline_steps_sampled": sampled,
                 "host_issue_ms_per_step": t_issue / a.steps * 1e3,
+                "host_sections_ms_per_step": {k_: v_ / a.steps * 1e3 for k_, v_ in host.items()},
                 "inputs": {"host_to_device_inside_timed_region": not a.inputs_resident, "h2d_bytes_per_step": h2d_bytes[0] or None,
                            "how": ("worker processes -> pin thread -> non_blocking copies + compositor one batch ahead on the loader (side) stream "
                                    "(divergen_amd.data.build.BatchAhead fed by build_detection_train_loader)" if a.through_loader else

@@ -157,6 +157,9 @@ def get_cfg():
     #   INPUT.INST_POOL_SHARDS: directory of pool-*.dgxpool shards (divergen_amd/data/pool_store.py, built by
     #   tools/build_inst_pool.py); when set, pool instances are read from the shards instead of PIL-opened per sample.
     cfg.INPUT.INST_POOL_SHARDS = ""
+    #   SOLVER.ALLREDUCE_DTYPE: "fp32" (the reference's DDP: gradients all-reduced as they are) or "bf16" (gradient buckets go over
+    #   xGMI as bf16, half the bytes per step; engine/ddp.py ArenaReducer(wire_dtype=...)).
+    cfg.SOLVER.ALLREDUCE_DTYPE = "fp32"
     return cfg
 
 

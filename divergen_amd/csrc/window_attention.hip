@@ -12,6 +12,10 @@
 #include <type_traits>
 #include <map>
 #include <mutex>
+#include <utility>
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "window_attention.hip orders the bias-gradient slot hand-over by store COMPLETION (sc1 stores acknowledged at the device coherence point; see flush_head): verified for gfx950 only"
+#endif
 typedef float wa_f32x2 __attribute__((ext_vector_type(2)));
 
 template <int WS> struct WinCfg;
@@ -476,10 +480,15 @@ __global__ __launch_bounds__((WinCfg<WS>::NT + (HELP ? 3 : 0)) * 64) void win_at
         const int nlrun = left > 0 ? ((hh + 1) * left - 1) / upl - lrun0 + 1 : 0;
         const int slot = (int)blockIdx.x < main_wgs ? (int)blockIdx.x / nH : q_runs + ((int)blockIdx.x - main_wgs - lrun0);
         float* mine = part_ws + ((int64_t)hh * slots_per_head + slot) * TBLP;
-        // Slots and counter are DEVICE-scope accesses (write-through stores, L2-bypassing loads: the runs of a head sit on different XCDs,
-        // whose L2s do not snoop each other), ordered by completion: every store of the slot is acknowledged (vmcnt 0) before the barrier
-        // behind which the counter moves, and the slots are read behind the counter's return.  A device-scope FENCE here (__threadfence)
-        // writes back the whole L2 -- full of this kernel's dq / dk / dv rows -- and cost 40 us per flush.
+        // Slots and counter are DEVICE-scope ATOMIC accesses (write-through stores, L2-bypassing loads: the runs of a head sit on different
+        // XCDs, whose L2s do not snoop each other); no location is touched by a plain access of two workgroups.  Their ORDER is by completion,
+        // which is a gfx942 / gfx950 property, not a guarantee of the HIP memory model for relaxed atomics: an agent-scope (sc1) store is
+        // acknowledged -- vmcnt counts it down -- only once it is visible at the device's coherence point, so `s_waitcnt vmcnt(0)` + the
+        // workgroup barrier put every slot store before the counter's fetch_add, and the last arriver's slot loads are issued behind the
+        // fetch_add's RETURN value (control dependence through `last_s` and a barrier).  The model-conforming form -- release on the
+        // fetch_add, acquire in the last arriver -- makes the compiler emit `buffer_wbl2 sc1` (release) and `buffer_inv sc1` (acquire):
+        // a write-back of the whole L2, full of this kernel's dq / dk / dv rows, measured at 40 us per flush (x 24 heads per launch).
+        // The file refuses to build for any other architecture (top of the file).
         for (int i = tid; i < TBL; i += nthreads) {
             const int iy = i / (2 * WS - 1), dy = iy - (WS - 1), dx = i - iy * (2 * WS - 1) - (WS - 1);
             const int yk0 = dy < 0 ? -dy : 0, yk1 = dy > 0 ? WS - dy : WS, xk0 = dx < 0 ? -dx : 0, xk1 = dx > 0 ? WS - dx : WS;
@@ -722,24 +731,41 @@ static size_t bwd_smem_bytes(bool help = false) {
 }
 
 // Workspace of the backward kernel's bias-gradient reduction: one slot of TBL floats per (head, run) and a counter per head, zero between
-// launches (the last run of a head resets it).  One per stream: launches on ONE stream are ordered, launches on different streams must not
-// share slots.  Allocated at the first call on a stream (outside any graph capture: the backbone's attention is launched eagerly).
-struct BwdTableWs { float* part; int* cnt; int64_t floats; int heads; };
+// launches (the last run of a head resets it).  One per (device, stream): launches on ONE stream are ordered, launches on different streams
+// must not share slots, and the null stream of two devices is the same handle.  Allocated at the first call on a stream; inside a graph
+// capture the allocation runs with the thread's capture mode relaxed (hipMalloc is not a stream operation) and the counters' zero-fill is
+// recorded into the graph (a memset of 256 bytes per replay: the counters are zero between launches anyway).  `dirty` = the previous launch
+// on this stream was refused by the runtime: its counters may not have been reset, so the next call zero-fills them first.
+struct BwdTableWs { float* part; int* cnt; int64_t floats; int heads; bool dirty; };
 static BwdTableWs* bwd_table_ws(hipStream_t st, int64_t floats, int heads) {
-    static std::map<hipStream_t, BwdTableWs> pool;
+    static std::map<std::pair<int, hipStream_t>, BwdTableWs> pool;
     static std::mutex mu;
     std::lock_guard<std::mutex> lock(mu);
-    BwdTableWs& w = pool[st];
-    if (w.part && w.floats >= floats && w.heads >= heads) return &w;
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) return nullptr;
+    BwdTableWs& w = pool[std::make_pair(device, st)];
+    if (w.part && w.floats >= floats && w.heads >= heads) {
+        if (w.dirty) {
+            if (hipMemsetAsync(w.cnt, 0, (size_t)w.heads * 4, st) != hipSuccess) return nullptr;
+            w.dirty = false;
+        }
+        return &w;
+    }
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) return nullptr;      // no allocation inside a capture
+    const bool capturing = hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+    if (w.part && capturing) return nullptr;                  // growing means freeing what earlier captured launches point at
+    hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+    if (capturing && hipThreadExchangeStreamCaptureMode(&mode) != hipSuccess) return nullptr;
     if (w.part) { (void)hipStreamSynchronize(st); (void)hipFree(w.part); (void)hipFree(w.cnt); w.part = nullptr; w.cnt = nullptr; }
     const int64_t nf = floats > (int64_t)300 * 532 ? floats : (int64_t)300 * 532;     // every Swin-L / Swin-T launch shape fits the first allocation
     const int nh = heads > 64 ? heads : 64;
-    if (hipMalloc((void**)&w.part, (size_t)nf * 4) != hipSuccess) { w.part = nullptr; return nullptr; }
-    if (hipMalloc((void**)&w.cnt, (size_t)nh * 4) != hipSuccess) { (void)hipFree(w.part); w.part = nullptr; return nullptr; }
-    (void)hipMemset(w.cnt, 0, (size_t)nh * 4);
-    w.floats = nf; w.heads = nh;
+    bool ok = hipMalloc((void**)&w.part, (size_t)nf * 4) == hipSuccess;
+    if (!ok) w.part = nullptr;
+    if (ok && hipMalloc((void**)&w.cnt, (size_t)nh * 4) != hipSuccess) { (void)hipFree(w.part); w.part = nullptr; w.cnt = nullptr; ok = false; }
+    if (capturing) (void)hipThreadExchangeStreamCaptureMode(&mode);       // back to what the capture was started with
+    if (!ok) return nullptr;
+    if (hipMemsetAsync(w.cnt, 0, (size_t)nh * 4, st) != hipSuccess) return nullptr;      // ordered before the launch that follows on `st`
+    w.floats = nf; w.heads = nh; w.dirty = false;
     return &w;
 }
 
@@ -830,6 +856,9 @@ extern "C" int dgx_window_attention_bwd(const void* qkv, const float* table, con
         return DGX_ERR_UNSUPPORTED;
     }
 #undef BWD_ARGS
-    DGX_LAUNCH_CHECK();
+    if (hipError_t e = hipGetLastError(); e != hipSuccess) {
+        tw->dirty = true;                // a refused launch: whatever state the counters are in, the next call starts from zero
+        return -(int)e - 1000;
+    }
     return DGX_OK;
 }

@@ -19,6 +19,13 @@ from ..layers import linear_ops
 from . import prof
 
 ENABLED = True
+# Which input signatures get a graph.  A training run on real data sees MANY padded batch sizes (EfficientDetResizeCrop with
+# SCALE_RANGE (0.1, 2.0): every multiple of the size divisibility up to TRAIN_SIZE in both dimensions; about half of the batches
+# have the full TRAIN_SIZE x TRAIN_SIZE), and a captured pair of graphs pins its activations (~1-2 GB at 1024^2).  A signature is
+# captured when it is seen for the CAPTURE_AFTER-th time and while fewer than MAX_GRAPHS signatures hold graphs; every other
+# call runs the segment eagerly (the callers fall back to the module's own forward when usable() says no).
+CAPTURE_AFTER = 2
+MAX_GRAPHS = 4
 CAPTURE_RESERVED_CUS = 0     # engine/ddp.ArenaReducer: the width (256 - this many CUs) the captured persistent kernels are launched at
 ALIAS_STATIC = True     # chained segments share their hand-over buffers
 
@@ -38,18 +45,49 @@ class _SignalAfterBackward(torch.autograd.Function):
         return g, None
 
 
+class _thread_local_capture:
+    """torch.cuda.make_graphed_callables captures with the stream-capture mode 'global': a prohibited call by ANY thread of the
+    process invalidates the capture.  In the training process the DataLoader's pin thread allocates pinned host memory
+    (hipHostMalloc) whenever a worker result arrives -- observed: `hipErrorStreamCaptureInvalidated` on the first step fed by the
+    real loader.  The captures here run entirely on the calling thread, so the mode that matches them is 'thread_local'."""
+
+    def __enter__(self):
+        self.orig = torch.cuda.graph
+        orig = self.orig
+
+        class graph(orig):
+            def __init__(self, cuda_graph, pool=None, stream=None, capture_error_mode="thread_local"):
+                super().__init__(cuda_graph, pool=pool, stream=stream, capture_error_mode="thread_local")
+        torch.cuda.graph = graph
+
+    def __exit__(self, *exc):
+        torch.cuda.graph = self.orig
+
+
 class GraphedSegment:
     def __init__(self, module):
         self.module = module           # nn.Module: forward(*tensors) -> tuple of tensors
         self._fns = {}
         self._work = {}
+        self._seen = {}
+
+    @staticmethod
+    def _key(inputs):
+        return tuple((tuple(t.shape), t.dtype, t.requires_grad, tuple(t.stride())) for t in inputs) + (torch.is_autocast_enabled(),)
 
     def usable(self, inputs):
-        return (ENABLED and torch.is_grad_enabled() and all(t.is_cuda for t in inputs)
-                and not torch.cuda.is_current_stream_capturing())
+        """True when this call replays (or now captures) a graph; False = run the segment eagerly."""
+        if not (ENABLED and torch.is_grad_enabled() and all(t.is_cuda for t in inputs)
+                and not torch.cuda.is_current_stream_capturing()):
+            return False
+        key = self._key(inputs)
+        if key in self._fns:
+            return True
+        n = self._seen[key] = self._seen.get(key, 0) + 1
+        return n >= CAPTURE_AFTER and len(self._fns) < MAX_GRAPHS
 
     def __call__(self, *inputs):
-        key = tuple((tuple(t.shape), t.dtype, t.requires_grad, tuple(t.stride())) for t in inputs) + (torch.is_autocast_enabled(),)
+        key = self._key(inputs)
         fn = self._fns.get(key)
         if fn is None:
             self.module.amp = torch.is_autocast_enabled()
@@ -73,8 +111,13 @@ class GraphedSegment:
             if CAPTURE_RESERVED_CUS != width:
                 L.set_reserved_cus(CAPTURE_RESERVED_CUS)
             try:
-                with linear_ops.suspend_ready(), torch.autocast("cuda", enabled=False):
-                    fn = torch.cuda.make_graphed_callables(self.module, sample, allow_unused_input=True)
+                # Given an nn.Module, make_graphed_callables returns the module with its `forward` REPLACED (an instance attribute)
+                # by the graphed one.  A second signature must not run its warm-up through the first one's graph (rounds 1-5 never saw
+                # a second signature: synthetic batches have one size; the real loader's second batch size died here with a shape
+                # mismatch in the replay's input copy): the graphed forward is taken OFF the module and kept per signature.
+                with linear_ops.suspend_ready(), torch.autocast("cuda", enabled=False), _thread_local_capture():
+                    torch.cuda.make_graphed_callables(self.module, sample, allow_unused_input=True)
+                fn = self.module.__dict__.pop("forward")
             finally:
                 if CAPTURE_RESERVED_CUS != width:
                     L.set_reserved_cus(width)

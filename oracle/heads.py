@@ -17,6 +17,7 @@ import torch
 import torch.nn.functional as F
 
 from . import roi
+from . import quant as Q
 from .quant import rb
 
 
@@ -33,7 +34,7 @@ def fpn(feats, p, prefix="", in_features=("swin1", "swin2", "swin3")):
         res["p%d" % s] = rb(F.conv2d(lat, p["%sfpn_output%d.weight" % (prefix, s)],
                                      p["%sfpn_output%d.bias" % (prefix, s)], padding=1))
     p6 = rb(F.conv2d(res["p5"], p[prefix + "top_block.p6.weight"], p[prefix + "top_block.p6.bias"], stride=2, padding=1))
-    p7 = rb(F.conv2d(F.relu(p6), p[prefix + "top_block.p7.weight"], p[prefix + "top_block.p7.bias"], stride=2, padding=1))
+    p7 = rb(F.conv2d(Q.relu(p6, "top_block.p6"), p[prefix + "top_block.p7.weight"], p[prefix + "top_block.p7.bias"], stride=2, padding=1))
     res["p6"], res["p7"] = p6, p7
     return {k: res[k] for k in ("p3", "p4", "p5", "p6", "p7")}
 
@@ -47,18 +48,18 @@ def centernet_head(xs, p, prefix="", num_box_convs=4):
         for i in range(num_box_convs):
             t = rb(F.conv2d(t, p["%sbbox_tower.%d.weight" % (prefix, 3 * i)], p["%sbbox_tower.%d.bias" % (prefix, 3 * i)], padding=1))
             t = F.group_norm(t, 32, p["%sbbox_tower.%d.weight" % (prefix, 3 * i + 1)], p["%sbbox_tower.%d.bias" % (prefix, 3 * i + 1)])
-            t = rb(F.relu(t))
+            t = rb(Q.relu(t, "tower.%d.%d" % (l, i)))
         hms.append(rb(F.conv2d(t, p[prefix + "agn_hm.weight"], p[prefix + "agn_hm.bias"], padding=1)))
         r = rb(F.conv2d(t, p[prefix + "bbox_pred.weight"], p[prefix + "bbox_pred.bias"], padding=1))
-        regs.append(F.relu(r * p["%sscales.%d.scale" % (prefix, l)]))
+        regs.append(Q.relu(r * p["%sscales.%d.scale" % (prefix, l)], "reg.%d" % l))
     return regs, hms
 
 
 def box_head(x, p, prefix):
     """(R,256,7,7) -> (R,1024): flatten, fc1, relu, fc2, relu."""
     x = x.flatten(1)
-    x = F.relu(rb(F.linear(x, p[prefix + "fc1.weight"], p[prefix + "fc1.bias"])))
-    return F.relu(rb(F.linear(x, p[prefix + "fc2.weight"], p[prefix + "fc2.bias"])))
+    x = Q.relu(rb(F.linear(x, p[prefix + "fc1.weight"], p[prefix + "fc1.bias"])), prefix + "fc1")
+    return Q.relu(rb(F.linear(x, p[prefix + "fc2.weight"], p[prefix + "fc2.bias"])), prefix + "fc2")
 
 
 def box_predictor(x, p, prefix):
@@ -106,8 +107,9 @@ def box_reg_loss(prop_boxes, gt_boxes, pred_deltas, gt_classes, num_classes, wei
 
 def mask_head(x, p, prefix, num_conv=4):
     for i in range(num_conv):
-        x = F.relu(rb(F.conv2d(x, p["%smask_fcn%d.weight" % (prefix, i + 1)], p["%smask_fcn%d.bias" % (prefix, i + 1)], padding=1)))
-    x = F.relu(rb(F.conv_transpose2d(x, p[prefix + "deconv.weight"], p[prefix + "deconv.bias"], stride=2)))
+        x = Q.relu(rb(F.conv2d(x, p["%smask_fcn%d.weight" % (prefix, i + 1)], p["%smask_fcn%d.bias" % (prefix, i + 1)], padding=1)),
+                   "%smask_fcn%d" % (prefix, i + 1))
+    x = Q.relu(rb(F.conv_transpose2d(x, p[prefix + "deconv.weight"], p[prefix + "deconv.bias"], stride=2)), prefix + "deconv")
     return rb(F.conv2d(x, p[prefix + "predictor.weight"], p[prefix + "predictor.bias"]))
 
 

@@ -121,6 +121,7 @@ def test_do_train_through_the_real_loader_checkpoints_and_resumes(tmp_path, monk
     from divergen_amd.modeling import build_model
     cfg, info = _mini_cfg(tmp_path, 128, 4, ["SOLVER.MAX_ITER", 30, "SOLVER.CHECKPOINT_PERIOD", 12, "SOLVER.WARMUP_ITERS", 5, "SEED", 7])
     monkeypatch.setenv("DETECTRON2_DATASETS", info["root"])
+    os.makedirs(cfg.OUTPUT_DIR, exist_ok=True)          # train_net.setup() does this for the CLI
     torch.manual_seed(7)
     opt = train_net.do_train(cfg, build_model(cfg))
     out = str(tmp_path / "out")

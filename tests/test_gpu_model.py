@@ -83,6 +83,40 @@ def test_graphed_head_segments_match_eager(monkeypatch):
         assert float((g0 - g1).abs().max()) <= 1e-1 * float(g0.abs().max()), it
 
 
+def test_graphed_segments_with_several_batch_sizes(monkeypatch):
+    """The real loader hands over batches of MANY padded sizes (EfficientDetResizeCrop).  Two sizes in alternation with graphs on:
+    the first sight of a size runs eagerly, the second captures, later ones replay THAT size's graphs (rounds 1-5 captured at first
+    sight and died on the second size: make_graphed_callables had replaced the module's forward); a third size beyond MAX_GRAPHS
+    stays eager.  Losses equal the graph-free run's."""
+    from divergen_amd.data import synthetic_batch
+    from divergen_amd.utils import graphs
+    from divergen_amd.utils.events import EventStorage
+    monkeypatch.setattr(graphs, "MAX_GRAPHS", 2)
+    sizes = [256, 320, 256, 320, 256, 320, 192, 192, 192, 256]
+    res = {}
+    for on in (False, True):
+        monkeypatch.setattr(graphs, "ENABLED", on)
+        cfg, model, opt = _build(False)
+        batches = {s_: synthetic_batch(2, s_, cfg.MODEL.ROI_HEADS.NUM_CLASSES, seed=s_, device="cuda") for s_ in set(sizes)}
+        outs = []
+        with EventStorage(0):
+            for it, s_ in enumerate(sizes):
+                torch.manual_seed(100 + it)
+                opt.zero_grad()
+                losses = model(batches[s_])
+                sum(losses.values()).backward()
+                torch.cuda.synchronize()
+                outs.append({k: float(v) for k, v in losses.items()})
+        res[on] = outs
+        if on:
+            seg = model.backbone.__dict__["_segment"]
+            assert len(seg._fns) == 2 and max(seg._seen.values()) >= 2, (len(seg._fns), seg._seen)      # 256 and 320 captured, 192 eager
+    for it in range(len(sizes)):
+        for k in res[False][it]:
+            a, b = res[False][it][k], res[True][it][k]
+            assert abs(a - b) <= 2e-3 * abs(a) + 1e-5, (it, sizes[it], k, a, b)
+
+
 LIBRARY_COMPUTE = ("Cijk_", "rocblas", "hipblas", "miopen", "MIOpen", "naive_conv", "igemm", "layer_norm", "LayerNorm", "group_norm",
                    "GroupNorm", "batch_norm", "gelu", "Gelu", "GELU", "max_pool", "softmax", "Softmax")
 
@@ -115,7 +149,62 @@ def test_end_to_end_gradients_of_the_mask_loss_are_sharp(monkeypatch):
     run_e2e_vs_oracle(monkeypatch, "T", 256, grads=True, loss_filter=lambda k: k == "loss_mask", grad_bounds=(2e-3, 6e-2))
 
 
-def run_e2e_vs_oracle(monkeypatch, swin, size, grads=False, loss_filter=None, grad_bounds=(2e-2, 5e-2)):
+def _capture_relu_sites(monkeypatch, model):
+    """The product's ReLU on/off patterns of one training forward, by site: FPN top block (p6), the CenterNet tower's GroupNorm +
+    ReLU layers per level, the regression ReLU, the box heads' two FC ReLUs per cascade stage, the mask head's convolutions and
+    deconvolution.  Read from the OUTPUTS the product stores (out > 0).  Returned dict is filled during the forward."""
+    import divergen_amd.layers.box_stage as BS
+    import divergen_amd.modeling.dense_heads.centernet_head as CH
+    site = {"tower": [], "reg": None, "box": [], "mask": {}, "p6": None}
+    orig_gn, orig_out, orig_act = CH.groupnorm_relu_multi, CH.centernet_head_outputs, BS.G.gemm_nt_act
+
+    def gn(xs, *a, **k):
+        out = orig_gn(xs, *a, **k)
+        site["tower"].append([(o > 0).detach().cpu() for o in out])
+        return out
+
+    def head_out(boths, scales):
+        reg, hm = orig_out(boths, scales)
+        site["reg"] = ((reg > 0).detach().cpu(), [tuple(b.shape) for b in boths])
+        return reg, hm
+
+    def act(x, w, b, relu=False):
+        out = orig_act(x, w, b, relu=relu)
+        if relu:
+            site["box"].append((out > 0).detach().cpu())
+        return out
+    monkeypatch.setattr(CH, "groupnorm_relu_multi", gn)
+    monkeypatch.setattr(CH, "centernet_head_outputs", head_out)
+    monkeypatch.setattr(BS.G, "gemm_nt_act", act)
+    mh = model.roi_heads.mask_head
+    for name in [n for n, _ in mh.named_children() if n.startswith("mask_fcn") and "relu" not in n] + ["deconv"]:
+        getattr(mh, name).register_forward_hook(lambda m, i, o, name=name: site["mask"].__setitem__(name, (o > 0).detach().cpu()))
+    model.backbone.register_forward_hook(lambda m, i, o: site.__setitem__("p6", (o["p6"] > 0).detach().cpu()))
+    return site
+
+
+def _oracle_relu_masks(site, box_rows, n_mask_rows):
+    """site (product patterns) -> {oracle site tag: mask in the oracle's shape and row convention} (oracle/quant.py relu_masks)."""
+    m = {"top_block.p6": site["p6"]}
+    assert len(site["tower"]) == 4 and site["reg"] is not None and len(site["box"]) == 6, (len(site["tower"]), len(site["box"]))
+    for i, per_level in enumerate(site["tower"]):
+        for l, k in enumerate(per_level):
+            m["tower.%d.%d" % (l, i)] = k
+    reg, shapes = site["reg"]
+    off = 0
+    for l, (N, _, H, W) in enumerate(shapes):
+        m["reg.%d" % l] = reg[off:off + N * H * W].reshape(N, H, W, 4).permute(0, 3, 1, 2)
+        off += N * H * W
+    assert off == reg.shape[0]
+    for k in range(3):
+        for j, fc in enumerate(("fc1", "fc2")):
+            m["roi_heads.box_head.%d.%s" % (k, fc)] = site["box"][2 * k + j][box_rows[k]]
+    for name, k in site["mask"].items():
+        m["roi_heads.mask_head." + name] = k[:n_mask_rows]
+    return m
+
+
+def run_e2e_vs_oracle(monkeypatch, swin, size, grads=False, loss_filter=None, grad_bounds=(2e-2, 5e-2), segment_bounds=None):
     """Whole training forward of the PRODUCT path -- the one bench.py times: bf16 operands, fp32 accumulation, every GEMM /
     convolution / normalisation / attention / loss on libdgx kernels -- against the assembled CPU oracle (oracle/model.py,
     fp32) on the same operands: same batch, the oracle's Linear / convolution weights rounded to bf16 (the values the product's
@@ -155,6 +244,7 @@ def run_e2e_vs_oracle(monkeypatch, swin, size, grads=False, loss_filter=None, gr
     monkeypatch.setattr(model.roi_heads, "forward", spy)
     model.roi_heads.stage_observer = lambda k, d: stages.__setitem__(
         k, {n: (v.detach().cpu() if torch.is_tensor(v) else v) for n, v in d.items()})
+    relu_site = _capture_relu_sites(monkeypatch, model) if grads else None
     with EventStorage(0):
         opt.zero_grad()
         with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
@@ -188,8 +278,10 @@ def run_e2e_vs_oracle(monkeypatch, swin, size, grads=False, loss_filter=None, gr
     stage_labels = {}
     counts = stages[0]["counts"]
     alive = [torch.ones(n, dtype=torch.bool) for n in counts]
+    box_rows = {0: torch.arange(int(sum(counts)))}          # the product's rows the oracle keeps, per stage
     for k in (1, 2):
         d, per, off = stages[k], [], 0
+        box_rows[k] = []
         for i, n in enumerate(counts):
             v = d["valid"][off:off + n].bool()
             cls, gtb = d["gt_classes"][off:off + n], d["gt_boxes"][off:off + n]
@@ -198,8 +290,10 @@ def run_e2e_vs_oracle(monkeypatch, swin, size, grads=False, loss_filter=None, gr
             idx = (gtb[sel][:, None, :] - gts[i]["boxes"][None]).abs().sum(-1).argmin(1) if len(gts[i]["boxes"]) else torch.zeros(int(sel.sum()), dtype=torch.int64)
             per.append((keep, cls[sel], idx))
             alive[i] = sel
+            box_rows[k].append(off + sel.nonzero().squeeze(1))
             off += n
         stage_labels[k] = per
+        box_rows[k] = torch.cat(box_rows[k])
     from oracle.quant import bf16_storage
 
     def oracle_losses():
@@ -227,14 +321,16 @@ def run_e2e_vs_oracle(monkeypatch, swin, size, grads=False, loss_filter=None, gr
         assert abs(r["product"] - r["oracle_bf16_storage"]) <= 1e-3 * abs(r["oracle_bf16_storage"]) + 1e-6, (k, report)
         assert abs(r["product"] - r["oracle_fp32"]) <= 1e-3 * abs(r["oracle_fp32"]) + 1e-5, (k, report)
     if grads:
-        report["_grad_rows"] = _compare_gradients(model, p, oracle_losses_fn=lambda pp: assembled_oracle_losses(
+        n_fg = sum(int(((c >= 0) & (c < C)).sum()) for c in stages[0]["gt_classes"].split(list(counts)))
+        masks = _oracle_relu_masks(relu_site, box_rows, n_fg)
+        report["_grad_rows"] = _compare_gradients(model, p, relu=masks, segment_bounds=segment_bounds, oracle_losses_fn=lambda pp: assembled_oracle_losses(
             pp, images, gts, [tuple(b["instances"].image_size) for b in batch], swin, C, fw, cfg.MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE,
             cfg.MODEL.ROI_HEADS.POSITIVE_FRACTION, cfg.MODEL.ROI_BOX_HEAD.FED_LOSS_NUM_CAT, model.roi_heads.mask_weight,
             proposals=captured["props"], stage_labels=stage_labels), swin=swin, size=size, loss_filter=loss_filter, bounds=grad_bounds)
     return report
 
 
-def _compare_gradients(model, p, oracle_losses_fn, swin, size, loss_filter=None, bounds=(2e-2, 5e-2)):
+def _compare_gradients(model, p, oracle_losses_fn, swin, size, loss_filter=None, bounds=(2e-2, 5e-2), relu=None, segment_bounds=None):
     """d(sum of the 10 losses) / d(parameter) for EVERY parameter: the product's gradient arena (bf16 operands, fp32 accumulation,
     hand-written backward kernels) against torch autograd through the oracle at the same point (the oracle's GEMM weights are the
     bf16-rounded values the product reads), twice:
@@ -245,17 +341,26 @@ def _compare_gradients(model, p, oracle_losses_fn, swin, size, loss_filter=None,
         whose bf16-stored pre-activation lies within rounding of zero flips its mask, and a fraction f of flipped elements is a
         relative L2 error of sqrt(f) in the gradient behind it (~3-5 % per GroupNorm + ReLU layer of the CenterNet tower, measured
         layer by layer with tools/grad_parity_probe.py); the reference's own fp16 autocast has the same property against fp32."""
-    from oracle.quant import bf16_storage
+    from oracle.quant import bf16_storage, relu_masks
 
-    def oracle_grads(storage):
+    def oracle_grads(storage, masks=None):
         pg = {k: v.clone().requires_grad_(True) for k, v in p.items() if v.is_floating_point()}
         pall = dict(p)
         pall.update(pg)
-        with bf16_storage(storage):
+        with bf16_storage(storage), relu_masks(masks) as flips:
             total = sum(v for k, v in oracle_losses_fn(pall).items() if loss_filter is None or loss_filter(k))
             total.backward()
-        return {k: v.grad for k, v in pg.items()}
-    ref_q, ref_f = oracle_grads(True), oracle_grads(False)
+            flips = {k: sum(v) / len(v) for k, v in flips.items()}
+        return {k: v.grad for k, v in pg.items()}, flips
+    # ASSERTED: bf16 storage points AND the product's ReLU patterns (discrete intermediates, like proposals and labels)
+    (ref_q, flips), (ref_f, _) = oracle_grads(True, relu), oracle_grads(False)
+    if relu is not None:
+        own, _ = oracle_grads(True)              # the oracle's own ReLU decisions: REPORTED (what the flips cost)
+        n2 = sum(float((own[k] - ref_q[k]).double().square().sum()) for k in own if own[k] is not None and ref_q[k] is not None)
+        d2 = sum(float(ref_q[k].double().square().sum()) for k in ref_q if ref_q[k] is not None)
+        print("ReLU sites where the oracle's own sign differs from the product's pattern (fraction of elements): "
+              + ", ".join("%s %.1e" % (k, v) for k, v in sorted(flips.items()) if v > 0))
+        print("gradient of the oracle with its OWN ReLU decisions vs with the product's: relative L2 %.3e over the arena" % ((n2 / max(d2, 1e-300)) ** 0.5))
     rows, num, den, numf = [], 0.0, 0.0, 0.0
     for name, q in model.named_parameters():
         if not q.requires_grad or q.grad is None:
@@ -289,6 +394,10 @@ def _compare_gradients(model, p, oracle_losses_fn, swin, size, loss_filter=None,
                                                                               (f2 / r2) ** 0.5 if r2 > 0 else 0.0))
     if bounds is None:
         return rows
+    if segment_bounds is not None:              # per segment of the arena (backbone stage / FPN conv / head): relative L2
+        for key, (d2, r2, f2) in sorted(by_group.items()):
+            seg = (d2 / r2) ** 0.5 if r2 > 0 else 0.0
+            assert seg <= segment_bounds or (d2 ** 0.5) <= 2e-3 * den ** 0.5, (key, seg)
     assert whole <= bounds[0], whole
     tot = den ** 0.5
     for name, shape, nr, rel_q, rel_f in rows:
@@ -497,7 +606,7 @@ def test_early_proposal_backward_is_the_same_step():
         model.early_proposal_backward, model.early_box_backward = early, box
         batch = synthetic_batch(2, 256, cfg.MODEL.ROI_HEADS.NUM_CLASSES, device="cuda")
         with EventStorage(0):
-            for k in range(2):          # the second pass replays the captured segments
+            for k in range(3):          # the second pass captures the segments (graphs.CAPTURE_AFTER), the third replays them
                 torch.manual_seed(7)
                 opt.zero_grad()
                 losses = model(batch)

@@ -238,6 +238,60 @@ def test_arena_reducer_rank_dependent_unused_branch_world2_gloo():
         assert np.allclose(g_a[it], (tot / 2).numpy(), atol=1e-5), it
 
 
+def _ddp_bf16_worker(rank, world, port, q):
+    """Three optimizer-free steps with the gradient buckets on the wire as bf16 and as fp32, same weights, same inputs."""
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from divergen_amd.engine.ddp import ArenaReducer
+    from divergen_amd.solver import FlatArena
+    out = {}
+    for wire in ("fp32", "bf16"):
+        torch.manual_seed(5)
+        net = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.ReLU(), torch.nn.Linear(32, 8))
+        ar = FlatArena(net)
+        red = ArenaReducer(ar, bucket_bytes=1024, wire_dtype=wire)
+        red.broadcast_parameters()
+        g = torch.Generator().manual_seed(100 + rank)
+        res = []
+        for it in range(3):
+            ar.zero_grad()
+            net(torch.randn(6, 16, generator=g)).square().sum().backward()
+            scale = red.finish()
+            res.append((ar.g.clone() * scale).numpy().copy())
+        out[wire] = res
+    q.put((rank, out))
+    dist.destroy_process_group()
+
+
+def test_arena_reducer_bf16_wire_world2_gloo():
+    """SOLVER.ALLREDUCE_DTYPE 'bf16' (SURVEY 5.8): the averaged gradients equal the fp32 all-reduce's within bf16
+    rounding of the per-rank terms (2 ranks: each term rounded once, the sum once: <= 3 x 2^-9 relative to the largest term), are
+    identical on both ranks, and the alignment gaps of the arena stay zero."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ddp_bf16_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, a), (_, b) = res
+    for it in range(3):
+        assert np.array_equal(a["bf16"][it], b["bf16"][it]) and np.array_equal(a["fp32"][it], b["fp32"][it])
+        f, h = a["fp32"][it], a["bf16"][it]
+        assert not np.array_equal(f, h)                                   # it really went over the wire in bf16
+        assert np.abs(f - h).max() <= 3 * 2.0 ** -8 * np.abs(f).max()
+        assert np.linalg.norm(f - h) <= 2.0 ** -7 * np.linalg.norm(f)
+        assert np.array_equal(f == 0, h == 0) or np.count_nonzero(h[f == 0]) == 0
+
+
 def test_arena_reducer_shared_weight_world2_gloo():
     import socket
     s = socket.socket()

@@ -26,8 +26,10 @@ FAMILY_KERNELS = {
 }
 # entry-point launches are counted on the family's MAIN kernel
 MAIN = {"gemm_nt": ("gemm_nt_kernel", "gemm_lw_kernel", "gemm_k192_kernel"), "wgrad": ("partial_kernel", "wgrad_lw_kernel"), "attn_fwd": "win_attn_fwd_kernel", "attn_bwd": "win_attn_bwd_kernel"}
-# 16 B/lane streaming reads (LDS-direct tile loads, float4 folds); window attention reads 64-byte head slices (64-B requests)
-WIDE = {"gemm_nt": True, "wgrad": True, "attn_fwd": False, "attn_bwd": False}
+# 16 B/lane streaming reads in every family (LDS-direct tile loads, float4 folds; the attention kernels load their q / k / v / dO head
+# slices as 16-byte fragments, window_attention.hip ld_frag_global): the correction is applied UNIFORMLY (rounds 3-5 left the attention
+# families undoubled and reported attn_fwd traffic at 0.62 of its algorithmic bytes, which is impossible)
+WIDE = {"gemm_nt": True, "wgrad": True, "attn_fwd": True, "attn_bwd": True}
 
 
 def collect(path, counter, warm, timed):

@@ -133,7 +133,7 @@ def do_train(cfg, model, resume=False):
     model.train()
     optimizer = build_optimizer(cfg, model)
     scheduler = build_lr_scheduler(cfg, optimizer)
-    reducer = ArenaReducer(optimizer.arena)
+    reducer = ArenaReducer(optimizer.arena, wire_dtype=cfg.SOLVER.get("ALLREDUCE_DTYPE", "fp32"))
     # this loop back-propagates the plain sum of the loss dict once per zero_grad: the proposal generator's part may run from inside
     # the forward, ahead of the RoI heads' device->host read (meta_arch/custom_rcnn.py)
     model.early_proposal_backward = True

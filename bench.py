@@ -44,6 +44,10 @@ def parse():
                    help="feed the step from the product's real data path (divergen_amd.data.build.build_detection_train_loader: worker "
                         "processes, pin thread, compositor one batch ahead) over a generated LVIS-format split + PNG instance pool")
     p.add_argument("--workers", type=int, default=16, help="--through-loader: DATALOADER.NUM_WORKERS (the shipped configs: 16 per GPU)")
+    p.add_argument("--loader-dev", action="append", default=[], metavar="KEY=VALUE",
+                   help="development A/B of the loader machinery: pin=loader|main|none, strategy=file_system|file_descriptor, main_threads=N")
+    p.add_argument("--loader-record", type=int, default=0, metavar="N",
+                   help="development: record N batches from the loader, stop it, replay them in rotation (content without the machinery)")
     p.add_argument("--loader-images", type=int, default=48)
     p.add_argument("--loader-pool", type=int, default=192)
     p.add_argument("--loader-shards", action="store_true", help="--through-loader: INPUT.INST_POOL_SHARDS (mmap-ed decoded pool) instead of PNG files")
@@ -378,7 +382,31 @@ def main():
             assert r["failed"] == [], r
             opts += ["INPUT.INST_POOL_SHARDS", os.path.join(root, "shards")]
         cfg.merge_from_list(opts)
+        from divergen_amd.data import build as _B
+        for kv in a.loader_dev:
+            k_, v_ = kv.split("=", 1)
+            _B.DEV[k_] = int(v_) if v_.isdigit() else v_
         feed = build_detection_train_loader(cfg, a.batch, dev, cfg.SEED)
+        if _B.DEV["pin"] == "main":             # A/B: pin on the training thread, inside BatchAhead's finish
+            fin0 = feed.finish
+            from torch.utils.data._utils.pin_memory import pin_memory as _pin
+            feed.finish = lambda d, device: fin0(_pin(d), device)
+        if a.loader_record:
+            # development: what does the loader MACHINERY cost next to the step?  Pull N host batches out of the DataLoader, shut its
+            # workers and pin thread down, and feed the recorded batches in rotation -- same content, no loader running
+            import gc
+            it_ = feed.it
+            recorded = [next(it_) for _ in range(a.loader_record)]
+            finish_ = feed.finish
+            del feed, it_
+            gc.collect()
+
+            def rotation_():
+                k = 0
+                while True:
+                    yield recorded[k % len(recorded)]
+                    k += 1
+            feed = BatchAhead(rotation_(), finish_, dev)
         loader_info = {"workers": a.workers, "images": a.loader_images, "pool_instances": a.loader_pool, "pool_format": "shards" if a.loader_shards else "png",
                        "scale_range": list(a.loader_scale_range), "prefetch_factor": cfg.DATALOADER.PREFETCH_FACTOR}
     else:

@@ -69,6 +69,8 @@ SIGNATURES = {
     "dgx_abi_version": (c_i, []),
     "dgx_window_attention_fwd": (c_i, [c_p, c_p, c_i64, c_i64, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p]),
     "dgx_window_attention_bwd": (c_i, [c_p] * 8 + [c_i64, c_i64, c_i, c_i, c_i, c_i, c_f, c_p]),
+    "dgx_window_attention_fwd_compact": (c_i, [c_p, c_p, c_p, c_i64, c_i64, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p]),
+    "dgx_window_attention_bwd_compact": (c_i, [c_p] * 9 + [c_i64, c_i64, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p]),
     "dgx_window_gather": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "dgx_window_scatter": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "dgx_roi_align_fwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),

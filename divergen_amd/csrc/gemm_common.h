@@ -4,12 +4,13 @@
 // x ReLU'(act) | window-reverse + DropPath + residual).
 #pragma once
 #include "dgx_common.h"
+#include "winmap.h"
 
 constexpr int GBK = 64;                 // K-step (elements): 128-byte tile rows
 static constexpr uint32_t G_OOB = 0x80000000u; // voffset beyond num_records: the lane's 16 bytes land in LDS as zeros
 
 namespace dgxgemm {
-struct GMap { int B, H, W, ws, shift, nWh, nWw; };   // residual.hip's RMap
+struct GMap { int B, H, W, ws, shift, nWh, nWw, compact; };   // residual.hip's RMap; compact: winmap.h
 
 struct GemmP {
     const uint16_t* A;
@@ -84,6 +85,7 @@ __device__ __forceinline__ int64_t g_row_token(const GMap& m, int64_t orow, int&
         b = (int)(orow / ((int64_t)m.H * m.W));
         return orow;
     }
+    if (m.compact) return wm_token_of_row(wm_geom(m.H, m.W, m.ws, m.shift), (int)orow, b);      // every compact row is a real token
     const int Nw = m.ws * m.ws;
     const int n = (int)(orow % Nw);
     int64_t t = orow / Nw;

@@ -611,12 +611,15 @@ extern "C" int dgx_gemm_bf16_nt(const void* A, const void* B, int M, int N, int 
             P.bias = nullptr;
             break;
         case DGX_EPI_BIAS_RESIDUAL: {
+            // ws < 0: the rows are in COMPACT window order (winmap.h: real tokens only, M = B*H*W)
+            const int aws = ep->ws < 0 ? -ep->ws : ep->ws;
             if (!ep->residual || !ep->out || ep->B <= 0 || ep->H <= 0 || ep->W <= 0 || ep->B > 4095 || ep->shift < 0 ||
-                (ep->ws > 0 && ep->shift >= ep->ws) || (ep->residual_dtype != DGX_F32 && ep->residual_dtype != DGX_BF16))
+                (aws > 0 && ep->shift >= aws) || (ep->residual_dtype != DGX_F32 && ep->residual_dtype != DGX_BF16) ||
+                (ep->ws < 0 && !wm_compact_ok(ep->H, ep->W, aws, ep->shift)))
                 return DGX_ERR_BAD_ARG;
-            GMap m = {ep->B, ep->H, ep->W, ep->ws, ep->shift, 0, 0};
-            if (ep->ws > 0) { m.nWh = (ep->H + ep->ws - 1) / ep->ws; m.nWw = (ep->W + ep->ws - 1) / ep->ws; }
-            const int64_t rows = ep->ws > 0 ? (int64_t)ep->B * m.nWh * m.nWw * ep->ws * ep->ws : (int64_t)ep->B * ep->H * ep->W;
+            GMap m = {ep->B, ep->H, ep->W, aws, ep->shift, 0, 0, ep->ws < 0 ? 1 : 0};
+            if (aws > 0) { m.nWh = (ep->H + aws - 1) / aws; m.nWw = (ep->W + aws - 1) / aws; }
+            const int64_t rows = ep->ws > 0 ? (int64_t)ep->B * m.nWh * m.nWw * aws * aws : (int64_t)ep->B * ep->H * ep->W;
             if (rows != M) return DGX_ERR_BAD_ARG;
             P.map = m;
             break;

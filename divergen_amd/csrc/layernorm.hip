@@ -6,11 +6,19 @@
 //             sums of dgamma / dbeta (a second tiny pass adds them into the gradient arena).
 // Reference semantics: nn.LayerNorm at swintransformer.py:213,255 followed by :216-233.
 #include "dgx_common.h"
+#include "winmap.h"
 
-struct WinMap { int B, H, W, ws, shift, nWh, nWw; };   // ws == 0: identity (no gather)
+// ws == 0: identity (no gather).  compact: the window order without the padding tokens (winmap.h): rows 0 .. B*H*W-1 are the real
+// tokens, whatever rows a buffer has beyond them are padding rows (source -1).  The entry points take it as ws < 0.
+struct WinMap { int B, H, W, ws, shift, nWh, nWw, compact; };
 
 // output row index (window order) -> source token index, or -1 for a padding token
 __device__ __forceinline__ int64_t win_src(const WinMap& m, int64_t orow) {
+    if (m.compact) {
+        if (orow >= (int64_t)m.B * m.H * m.W) return -1;
+        int b;
+        return wm_token_of_row(wm_geom(m.H, m.W, m.ws, m.shift), (int)orow, b);
+    }
     const int N = m.ws * m.ws;
     const int n = (int)(orow % N);
     int64_t t = orow / N;
@@ -30,6 +38,11 @@ __device__ __forceinline__ int64_t win_src(const WinMap& m, int64_t orow) {
 // divisions of win_src / win_dst are software sequences of ~150 VALU instructions each -- a large share of a kernel that handles two
 // to four rows per wave
 __device__ __forceinline__ int win_src32(const WinMap& m, int orow) {
+    if (m.compact) {
+        if (orow >= m.B * m.H * m.W) return -1;
+        int b;
+        return wm_token_of_row(wm_geom(m.H, m.W, m.ws, m.shift), orow, b);
+    }
     const int N = m.ws * m.ws;
     const int t0 = orow / N, n = orow - t0 * N;
     const int t1 = t0 / m.nWw, wc = t0 - t1 * m.nWw;
@@ -45,6 +58,7 @@ __device__ __forceinline__ int win_src32(const WinMap& m, int orow) {
 __device__ __forceinline__ int win_dst32(const WinMap& m, int tok) {
     const int t = tok / m.W, ww0 = tok - t * m.W;
     const int b = t / m.H, hh0 = t - b * m.H;
+    if (m.compact) return wm_row_of_token(wm_geom(m.H, m.W, m.ws, m.shift), b, hh0, ww0);
     const int Hp = m.nWh * m.ws, Wp = m.nWw * m.ws;
     int hs = hh0 - m.shift, wsx = ww0 - m.shift;
     if (hs < 0) hs += Hp;
@@ -60,6 +74,7 @@ __device__ __forceinline__ int64_t win_dst(const WinMap& m, int64_t tok) {
     int64_t t = tok / m.W;
     const int hh0 = (int)(t % m.H);
     const int b = (int)(t / m.H);
+    if (m.compact) return wm_row_of_token(wm_geom(m.H, m.W, m.ws, m.shift), b, hh0, ww0);
     const int Hp = m.nWh * m.ws, Wp = m.nWw * m.ws;
     int hs = hh0 - m.shift, wsx = ww0 - m.shift;
     if (hs < 0) hs += Hp;
@@ -241,7 +256,7 @@ __global__ __launch_bounds__(64 * LNB_WAVES, ((NJ <= 2 || (NJ == 3 && sizeof(XT)
                                                      const float* __restrict__ gamma, const XT* dres, XT* dx,
                                                      float* __restrict__ part, int64_t T, int C, WinMap m,
                                                      uint16_t* __restrict__ emit = nullptr, const float* __restrict__ escale = nullptr,
-                                                     WinMap em = WinMap{0, 0, 0, 0, 0, 0, 0}) {
+                                                     WinMap em = WinMap{0, 0, 0, 0, 0, 0, 0, 0}) {
     __shared__ float red[2][NJ * 256];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t wave = (int64_t)blockIdx.x * LNB_WAVES + w;
@@ -356,7 +371,7 @@ __global__ __launch_bounds__(64 * LNB_WAVES, ((NJ <= 2 || (NJ == 3 && sizeof(XT)
             }
         }
     }
-    if (EMIT && em.ws) {                       // window order: the rows of the padding tokens are zero
+    if (EMIT && em.ws && !em.compact) {        // classic window order: the rows of the padding tokens are zero (the compact emit buffer has none)
         const int64_t rows = (int64_t)em.B * em.nWh * em.nWw * em.ws * em.ws;
         if (rows != T)
             for (int64_t orow = wave; orow < rows; orow += nwaves)
@@ -431,20 +446,28 @@ __global__ __launch_bounds__(1024) void ln_param_reduce_kernel(const float* __re
     ln_reduce_rows(part, dgamma, dbeta, nblk, C, blockIdx.x, red);
 }
 
-static WinMap make_map(int B, int H, int W, int ws, int shift) {
-    WinMap m = {B, H, W, ws, shift, 0, 0};
-    if (ws > 0) { m.nWh = (H + ws - 1) / ws; m.nWw = (W + ws - 1) / ws; }
+static WinMap make_map(int B, int H, int W, int ws, int shift) {      // ws < 0: compact window order
+    WinMap m = {B, H, W, ws < 0 ? -ws : ws, shift, 0, 0, ws < 0 ? 1 : 0};
+    if (m.ws > 0) { m.nWh = (H + m.ws - 1) / m.ws; m.nWw = (W + m.ws - 1) / m.ws; }
     return m;
+}
+static bool map_args_ok(int B, int H, int W, int ws, int shift, int64_t T) {
+    if (ws == 0) return true;
+    const int a = ws < 0 ? -ws : ws;
+    if ((int64_t)B * H * W != T || shift < 0 || shift >= a) return false;
+    return ws > 0 || wm_compact_ok(H, W, a, shift);
 }
 
 extern "C" int dgx_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y_bf16, float* mean,
                                  float* rstd, int64_t T, int C, float eps, int B, int H, int W, int ws, int shift,
                                  int x_dtype, void* stream) {
     if (T <= 0) return DGX_OK;
-    if (!x || !gamma || !beta || !y_bf16 || !mean || !rstd || (C & 3) || (ws > 0 && (int64_t)B * H * W != T))
+    if (!x || !gamma || !beta || !y_bf16 || !mean || !rstd || (C & 3) || !map_args_ok(B, H, W, ws, shift, T))
         return DGX_ERR_BAD_ARG;
     const WinMap m = make_map(B, H, W, ws, shift);
-    const int64_t T_out = ws > 0 ? (int64_t)B * m.nWh * m.nWw * ws * ws : T;
+    // (compact as well: the output keeps the padding rows, all zero, behind the real ones -- the qkv weight gradient's operand)
+    const int64_t T_out = m.ws > 0 ? (int64_t)B * m.nWh * m.nWw * m.ws * m.ws : T;
+    if (T_out + 16384 >= ((int64_t)1 << 31)) return DGX_ERR_UNSUPPORTED;      // 32-bit row arithmetic in the kernels
     const int nj = (C + 255) / 256;
     const int64_t per_wg = nj <= 6 ? 8 : 4;       // rows per workgroup and trip: 4 waves x 2 rows (register-resident rows)
     const int grid = (int)((T_out + per_wg - 1) / per_wg < 8192 ? (T_out + per_wg - 1) / per_wg : 8192);
@@ -474,11 +497,12 @@ static int ln_bwd_launch(const void* dy_bf16, const void* x, const float* mean, 
                          int x_dtype, void* emit, const float* escale, int eB, int eH, int eW, int ews, int eshift, void* stream) {
     if (T <= 0) return DGX_OK;
     if (!dy_bf16 || !x || !mean || !rstd || !gamma || !dx || ((dgamma == nullptr) != (dbeta == nullptr)) || !part || (C & 3) || C > 1536 ||
-        (ws > 0 && (int64_t)B * H * W != T))
+        !map_args_ok(B, H, W, ws, shift, T))
         return DGX_ERR_BAD_ARG;
-    if (emit && ((int64_t)eB * eH * eW != T || eshift < 0 || (ews > 0 && eshift >= ews))) return DGX_ERR_BAD_ARG;
+    if (emit && ((int64_t)eB * eH * eW != T || !map_args_ok(eB, eH, eW, ews, eshift, T))) return DGX_ERR_BAD_ARG;
+    if (T + 16384 >= ((int64_t)1 << 31)) return DGX_ERR_UNSUPPORTED;          // 32-bit row / token arithmetic in the kernels
     const WinMap m = make_map(B, H, W, ws, shift);
-    const WinMap em = emit ? make_map(eB, eH, eW, ews, eshift) : WinMap{0, 0, 0, 0, 0, 0, 0};
+    const WinMap em = emit ? make_map(eB, eH, eW, ews, eshift) : WinMap{0, 0, 0, 0, 0, 0, 0, 0};
     const int grid = dgx_layernorm_bwd_blocks(T);
     hipStream_t st = (hipStream_t)stream;
     const int nj = (C + 255) / 256;

@@ -13,6 +13,7 @@
 #include <map>
 #include <mutex>
 #include <utility>
+#include "winmap.h"
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
 #error "window_attention.hip orders the bias-gradient slot hand-over by store COMPLETION (sc1 stores acknowledged at the device coherence point; see flush_head): verified for gfx950 only"
 #endif
@@ -74,15 +75,36 @@ __device__ __forceinline__ void block_to_window_head(int bid, int nH, int& b, in
     h = slot % nH;
 }
 
+// COMPACT window order (winmap.h): the qkv / out / dout / dqkv rows of the REAL tokens only, M = B*H*W, in (image, window, token) order;
+// a padding token's q, k, v are the qkv BIAS (its LayerNorm-ed input is 0: swintransformer.py:216-221 pads after norm1), its attention
+// output is never stored (cropped at :248-251), its dO is 0; the backward still writes its dk / dv (and a zero dq) to row T + its rank
+// among the padding tokens, for the qkv bias gradient.  H == 0: classic order, every token has a row.
+struct AttnGeom {
+    int H, W, shift;                 // token grid and cyclic shift of this block
+    int T, P;                        // B*H*W real rows; padding tokens per image
+    const uint16_t* bias;            // qkv bias, bf16 (3 * C)
+    const uint16_t* zeros;           // >= 64 bytes of zeros (dO / O of a padding token)
+};
+// row of token n of window (image img, wr, wc): real -> its compact row, padding -> -(1 + its padding rank in the whole batch)
+template <int WS>
+__device__ __forceinline__ int attn_row(const AttnGeom& G, const WmGeom& g, const WmWindow& w, int img, int wr, int wc, int n) {
+    const int i = n / WS, j = n - i * WS;
+    int before;
+    const bool real = wm_token_real(g, w, wr, wc, i, j, before);
+    const int wi = wr * g.nWw + wc;
+    return real ? img * (G.H * G.W) + w.base + before : -(1 + img * G.P + (wi * (WS * WS) - w.base) + (n - before));
+}
+
 // Softmax runs in the log2 domain: the bias row is pre-multiplied by log2(e) when it is staged in LDS and the
 // score is one FMA, s2 = qk * (scale*log2e) + bias2 (the -100 of the shift mask becomes -100*log2e), so that
 // p = exp2(s2 - max2) is a bare v_exp_f32.  MASKED = false (W-MSA blocks) drops the region compare entirely.
 #define DGX_LOG2E 1.4426950408889634f
 #define DGX_LN2 0.6931471805599453f
-template <int WS, bool MASKED>
+template <int WS, bool MASKED, bool COMPACT = false>
 __global__ __launch_bounds__(WinCfg<WS>::NT * 64) void win_attn_fwd_kernel(
     const uint16_t* __restrict__ qkv, const float* __restrict__ table, const int8_t* __restrict__ region,
-    uint16_t* __restrict__ out, float* __restrict__ lse, int B_, int nW, int nH, float scale, int64_t t_sh, int64_t t_si) {
+    uint16_t* __restrict__ out, float* __restrict__ lse, int B_, int nW, int nH, float scale, int64_t t_sh, int64_t t_si,
+    AttnGeom G = AttnGeom{0, 0, 0, 0, 0, nullptr, nullptr}) {
     using Cf = WinCfg<WS>;
     constexpr int N = Cf::N, NT = Cf::NT, NTK = Cf::NTK, NP = NTK * 16, RS = Cf::RS, TBL = Cf::TBL;
     // row stride (elements) of the row-major K / V images: 48 = 24 banks.  The 16-byte fragment reads (8 consecutive rows per pass, 4
@@ -107,6 +129,23 @@ __global__ __launch_bounds__(WinCfg<WS>::NT * 64) void win_attn_fwd_kernel(
     const int w = tid >> 6, l = tid & 63, g = l >> 4, c16 = l & 15;
     const int qi = 16 * w + c16;
     const bool qok = qi < N;
+    // COMPACT: the address of (token n, part: 0 q / 1 k / 2 v, 16-byte chunk c) -- a real token's qkv row or the bias
+    WmGeom wg;
+    WmWindow ww;
+    int img = 0, wr = 0, wc = 0;
+    if (COMPACT) {
+        wg = wm_geom(G.H, G.W, WS, G.shift);
+        img = b / nW;
+        const int wi = b - img * nW;
+        wr = wi / wg.nWw;
+        wc = wi - wr * wg.nWw;
+        ww = wm_window(wg, wr, wc);
+    }
+    auto qkv_ptr = [&](int n, int part, int off) -> const uint16_t* {
+        if (!COMPACT) return base + part * C + (int64_t)n * rowst + off;
+        const int row = attn_row<WS>(G, wg, ww, img, wr, wc, n < N ? n : 0);
+        return row >= 0 ? qkv + (int64_t)row * rowst + part * C + h * 32 + off : G.bias + part * C + h * 32 + off;
+    };
 
     // ---- every global load of the workgroup is issued here, back to back (ONE memory latency), then parked in LDS
     const int8_t* reg = region + (int64_t)(b % nW) * N;
@@ -114,12 +153,12 @@ __global__ __launch_bounds__(WinCfg<WS>::NT * 64) void win_attn_fwd_kernel(
     const int kr_in = (MASKED && tid < N) ? (int)reg[tid] : -1;
     const int rq = (MASKED && qok) ? (int)reg[qi] : 0;
     const int u0 = tid, u1 = tid + nthreads;                       // 16-byte chunks of the K / V images: row u >> 2, chunk u & 3
-    const bf16x8 k0 = ld_frag_global(base + C + (int64_t)(u0 >> 2) * rowst + 8 * (u0 & 3), (u0 >> 2) < N);
-    const bf16x8 v0 = ld_frag_global(base + 2 * C + (int64_t)(u0 >> 2) * rowst + 8 * (u0 & 3), (u0 >> 2) < N);
+    const bf16x8 k0 = ld_frag_global(qkv_ptr(u0 >> 2, 1, 8 * (u0 & 3)), (u0 >> 2) < N);
+    const bf16x8 v0 = ld_frag_global(qkv_ptr(u0 >> 2, 2, 8 * (u0 & 3)), (u0 >> 2) < N);
     const bool two = u1 < NP * 4;
-    const bf16x8 k1 = ld_frag_global(base + C + (int64_t)(u1 >> 2) * rowst + 8 * (u1 & 3), two && (u1 >> 2) < N);
-    const bf16x8 v1 = ld_frag_global(base + 2 * C + (int64_t)(u1 >> 2) * rowst + 8 * (u1 & 3), two && (u1 >> 2) < N);
-    const bf16x8 qf = ld_frag_global(base + (int64_t)qi * rowst + 8 * g, qok);
+    const bf16x8 k1 = ld_frag_global(qkv_ptr(u1 >> 2, 1, 8 * (u1 & 3)), two && (u1 >> 2) < N);
+    const bf16x8 v1 = ld_frag_global(qkv_ptr(u1 >> 2, 2, 8 * (u1 & 3)), two && (u1 >> 2) < N);
+    const bf16x8 qf = ld_frag_global(qkv_ptr(qi, 0, 8 * g), qok);
     if (tid < TBL) tbl[tid] = tv * DGX_LOG2E;
     if (tid < NP) {
         const int yk = tid / WS;
@@ -192,8 +231,10 @@ __global__ __launch_bounds__(WinCfg<WS>::NT * 64) void win_attn_fwd_kernel(
         o[0] = mfma16(tr_frag(v_l4, 32 * t * RR, (32 * t + 16) * RR), pf, o[0]);  // o[dt][r] = O[query 16w+c16][d 16dt+4g+r]
         o[1] = mfma16(tr_frag(v_l4, 32 * t * RR + 16, (32 * t + 16) * RR + 16), pf, o[1]);
     }
-    if (qok) {
-        uint16_t* orow = out + ((int64_t)b * N + qi) * C + h * 32 + 4 * g;
+    int64_t out_row = (int64_t)b * N + qi;
+    if (COMPACT) out_row = qok ? attn_row<WS>(G, wg, ww, img, wr, wc, qi) : -1;      // a padding query's output is cropped: not stored
+    if (qok && out_row >= 0) {
+        uint16_t* orow = out + out_row * C + h * 32 + 4 * g;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
             *reinterpret_cast<u32x2*>(orow + 16 * dt) = u32x2{pack_bf2(o[dt][0] * inv, o[dt][1] * inv), pack_bf2(o[dt][2] * inv, o[dt][3] * inv)};
@@ -230,12 +271,12 @@ struct BwdPrefetch {
 // other SIMDs: the other waves waited ~1 800 of ~14 000 cycles per window at the barrier behind it, profiles/r03_attn_bwd_phases.txt).
 // Waves 9-11 land on SIMDs 1-3 and take the query tiles 6-8 of strips 0 / 4 / 8 (21 + 20 + 20 + 20 steps): they write their rows of the
 // dS^T image and their own bias-gradient terms like any strip wave and hand their partial dK / dV to the strip's owner through LDS.
-template <int WS, bool MASKED, bool HELP = false>
+template <int WS, bool MASKED, bool HELP = false, bool COMPACT = false>
 __global__ __launch_bounds__((WinCfg<WS>::NT + (HELP ? 3 : 0)) * 64) void win_attn_bwd_kernel(
     const uint16_t* __restrict__ qkv, const float* __restrict__ table, const int8_t* __restrict__ region,
     const uint16_t* __restrict__ out, const float* __restrict__ lse, const uint16_t* __restrict__ dout,
     uint16_t* __restrict__ dqkv, float* __restrict__ dtable, int B_, int nW, int nH, float scale, int upw, int upl, float* __restrict__ part_ws, int* __restrict__ head_cnt,
-    int64_t dt_sh, int64_t dt_si) {
+    int64_t dt_sh, int64_t dt_si, AttnGeom G = AttnGeom{0, 0, 0, 0, 0, nullptr, nullptr}) {
     using Cf = WinCfg<WS>;
     constexpr int N = Cf::N, NT = Cf::NT, NTK = Cf::NTK, NP = NTK * 16, TBL = Cf::TBL;
     // row strides (elements): the [NP][32] images 48 (24 banks: 16-byte fragment reads over 8 rows and transpose reads over 4 rows x 8
@@ -321,7 +362,30 @@ __global__ __launch_bounds__((WinCfg<WS>::NT + (HELP ? 3 : 0)) * 64) void win_at
     const uint32_t st_qk_c = (uint32_t)(srow * (int)rowst + 8 * sc);     // staging chunk inside this window's qkv rows
     const uint32_t st_o_c = (uint32_t)(srow * C + 8 * sc);               // ... inside out / dout rows
     const uint32_t row4_c = (uint32_t)((kok ? key : 0) * (int)rowst + 4 * g);   // output row = this lane's key / query, entries 4g ..
+    // COMPACT: the row of token n of window b -- a real token's compact row, or -(1 + padding rank) (attn_row)
+    auto compact_row = [&](int b, int n) -> int {
+        const WmGeom wg = wm_geom(G.H, G.W, WS, G.shift);
+        const int img = b / nW, wi = b - img * nW, wr = wi / wg.nWw, wc = wi - wr * wg.nWw;
+        return attn_row<WS>(G, wg, wm_window(wg, wr, wc), img, wr, wc, n);
+    };
     auto issue = [&](int b, int h, BwdPrefetch& P) {
+        if (COMPACT) {
+            // q / k / v of a padding token = the qkv bias, its dO and O = 0 (its output is cropped: no gradient reaches it)
+            const int row = compact_row(b, stager ? srow : 0);
+            const uint16_t* qp = (row >= 0 ? qkv + (int64_t)row * rowst : G.bias) + h * 32 + 8 * sc;
+            const uint16_t* dp = row >= 0 ? dout + (int64_t)row * C + h * 32 + 8 * sc : G.zeros + 8 * sc;
+            const uint16_t* op = row >= 0 ? out + (int64_t)row * C + h * 32 + 8 * sc : G.zeros + 8 * sc;
+            if (stager) {
+                P.q = *reinterpret_cast<const bf16x8*>(qp);
+                P.k = *reinterpret_cast<const bf16x8*>(qp + C);
+                P.v = *reinterpret_cast<const bf16x8*>(qp + 2 * C);
+                P.d = *reinterpret_cast<const bf16x8*>(dp);
+                P.o = *reinterpret_cast<const bf16x8*>(op);
+                P.lse = (lse + ((int64_t)b * nH + h) * N)[(uint32_t)srow];
+                P.reg = (int)(region + (MASKED ? (int64_t)(b % nW) * N : 0))[(uint32_t)srow];      // W-MSA: the one zero row, whatever nW is
+            }
+            return;
+        }
         const uint16_t* base = qkv + (int64_t)b * N * rowst + h * 32;
         const uint16_t* dob = dout + (int64_t)b * N * C + h * 32;
         const uint16_t* ob = out + (int64_t)b * N * C + h * 32;
@@ -654,8 +718,12 @@ __global__ __launch_bounds__((WinCfg<WS>::NT + (HELP ? 3 : 0)) * 64) void win_at
 #endif
         }
         CLK(2);
-        uint16_t* dqb = dqkv + (int64_t)b * N * rowst + h * 32;
+        uint16_t* dqb = dqkv + (COMPACT ? (int64_t)0 : (int64_t)b * N * rowst) + h * 32;
         uint32_t row4 = row4_c;
+        if (COMPACT) {                   // this lane's key / query: its compact row, or its padding row behind the T real ones
+            const int row = compact_row(b, kok ? key : 0);
+            row4 = (uint32_t)(row >= 0 ? row : G.T - 1 - row) * (uint32_t)rowst + 4 * g;
+        }
         asm volatile("" : "+v"(row4));   // same: store addresses are per-window temporaries
         auto store_dkdv = [&]() {
             if (kok) {                   // this lane: key 16w + c16, head-dim entries 16 dt + 4g .. + 3
@@ -780,23 +848,40 @@ static const int8_t* zero_region() {
     return z;
 }
 
-extern "C" int dgx_window_attention_fwd(const void* qkv, const float* table, int64_t table_stride_head,
-                                        int64_t table_stride_index, const int8_t* region, void* out, float* lse, int B_,
-                                        int nW, int nH, int ws, float scale, void* stream) {
+static int attn_geom(AttnGeom& G, int B_, int& nW, int ws, int B, int H, int W, int shift, const void* qkv_bias, int nH) {
+    // compact order: B images of H x W tokens, window ws, cyclic shift `shift`; B_ = B * nW windows
+    if (B <= 0 || H <= 0 || W <= 0 || shift < 0 || shift >= ws || !qkv_bias || !wm_compact_ok(H, W, ws, shift)) return DGX_ERR_BAD_ARG;
+    const WmGeom g = wm_geom(H, W, ws, shift);
+    nW = g.nWh * g.nWw;
+    if ((int64_t)B * nW != B_) return DGX_ERR_BAD_ARG;
+    const int64_t Tw = (int64_t)B_ * ws * ws;
+    if (Tw * 3 * nH * 32 >= ((int64_t)1 << 32)) return DGX_ERR_UNSUPPORTED;      // 32-bit element offsets of the row addressing
+    G.H = H; G.W = W; G.shift = shift;
+    G.T = B * H * W;
+    G.P = nW * ws * ws - H * W;
+    G.bias = (const uint16_t*)qkv_bias;
+    return DGX_OK;
+}
+
+static int attn_fwd_launch(const void* qkv, const float* table, int64_t table_stride_head, int64_t table_stride_index, const int8_t* region,
+                           void* out, float* lse, int B_, int nW, int nH, int ws, float scale, const AttnGeom* geom, void* stream) {
     if (B_ <= 0) return DGX_OK;
     if (!qkv || !table || !out || !lse || nH <= 0 || nW <= 0 || (region && B_ % nW)) return DGX_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
     const bool masked = region != nullptr;
-    if (!region) { region = zero_region(); nW = 1; if (!region) return DGX_ERR_BAD_ARG; }
+    if (!region) { region = zero_region(); if (!geom) nW = 1; if (!region) return DGX_ERR_BAD_ARG; }
     const int grid = ((B_ + 7) / 8) * 8 * nH;
     // head_dim 32: QK^T and PV (2 x 2 N^2 32 FLOP per head), q, k, v in + out (bf16) + lse
     const double heads = (double)B_ * nH, ntok = (double)ws * ws;
     DgxProfScope prof(DGX_PROF_ATTN_FWD, stream, heads * 2.0 * 2.0 * ntok * ntok * 32.0, heads * ntok * (32.0 * 2.0 * 4.0 + 4.0));
-#define FWD_LAUNCH(WSV, MK) hipLaunchKernelGGL((win_attn_fwd_kernel<WSV, MK>), dim3(grid), dim3(WinCfg<WSV>::NT * 64), 0, st, \
-                                              (const uint16_t*)qkv, table, region, (uint16_t*)out, lse, B_, nW, nH, scale, \
-                                              table_stride_head, table_stride_index)
-    if (ws == 12) { if (masked) FWD_LAUNCH(12, true); else FWD_LAUNCH(12, false); }
-    else if (ws == 7) { if (masked) FWD_LAUNCH(7, true); else FWD_LAUNCH(7, false); }
+    AttnGeom G = geom ? *geom : AttnGeom{0, 0, 0, 0, 0, nullptr, nullptr};
+#define FWD_LAUNCH(WSV, MK, CP) hipLaunchKernelGGL((win_attn_fwd_kernel<WSV, MK, CP>), dim3(grid), dim3(WinCfg<WSV>::NT * 64), 0, st, \
+                                                  (const uint16_t*)qkv, table, region, (uint16_t*)out, lse, B_, nW, nH, scale, \
+                                                  table_stride_head, table_stride_index, G)
+#define FWD_LAUNCH_C(WSV, MK) do { if (geom) FWD_LAUNCH(WSV, MK, true); else FWD_LAUNCH(WSV, MK, false); } while (0)
+    if (ws == 12) { if (masked) FWD_LAUNCH_C(12, true); else FWD_LAUNCH_C(12, false); }
+    else if (ws == 7) { if (masked) FWD_LAUNCH_C(7, true); else FWD_LAUNCH_C(7, false); }
+#undef FWD_LAUNCH_C
 #undef FWD_LAUNCH
     else
         return DGX_ERR_UNSUPPORTED;
@@ -804,16 +889,36 @@ extern "C" int dgx_window_attention_fwd(const void* qkv, const float* table, int
     return DGX_OK;
 }
 
-extern "C" int dgx_window_attention_bwd(const void* qkv, const float* table, const int8_t* region, const void* out,
-                                        const float* lse, const void* dout, void* dqkv, float* dtable,
-                                        int64_t dtable_stride_head, int64_t dtable_stride_index, int B_, int nW, int nH,
-                                        int ws, float scale, void* stream) {
+extern "C" int dgx_window_attention_fwd(const void* qkv, const float* table, int64_t table_stride_head,
+                                        int64_t table_stride_index, const int8_t* region, void* out, float* lse, int B_,
+                                        int nW, int nH, int ws, float scale, void* stream) {
+    return attn_fwd_launch(qkv, table, table_stride_head, table_stride_index, region, out, lse, B_, nW, nH, ws, scale, nullptr, stream);
+}
+
+extern "C" int dgx_window_attention_fwd_compact(const void* qkv, const void* qkv_bias, const float* table, int64_t table_stride_head,
+                                                int64_t table_stride_index, const int8_t* region, void* out, float* lse, int B, int H, int W,
+                                                int nH, int ws, int shift, float scale, void* stream) {
+    if (ws != 12 && ws != 7) return DGX_ERR_UNSUPPORTED;
+    AttnGeom G = {0, 0, 0, 0, 0, nullptr, nullptr};
+    int nW = 0;
+    const int nWh = (H + ws - 1) / ws, nWw = (W + ws - 1) / ws;
+    const int B_ = B * nWh * nWw;
+    if (int rc = attn_geom(G, B_, nW, ws, B, H, W, shift, qkv_bias, nH)) return rc;
+    return attn_fwd_launch(qkv, table, table_stride_head, table_stride_index, region, out, lse, B_, nW, nH, ws, scale, &G, stream);
+}
+
+static int attn_bwd_launch(const void* qkv, const float* table, const int8_t* region, const void* out,
+                           const float* lse, const void* dout, void* dqkv, float* dtable,
+                           int64_t dtable_stride_head, int64_t dtable_stride_index, int B_, int nW, int nH,
+                           int ws, float scale, const AttnGeom* geom, void* stream) {
     if (B_ <= 0) return DGX_OK;
     if (!qkv || !table || !out || !lse || !dout || !dqkv || !dtable || nH <= 0 || nW <= 0 || (region && B_ % nW))
         return DGX_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
     const bool masked = region != nullptr;
-    if (!region) { region = zero_region(); nW = 1; if (!region) return DGX_ERR_BAD_ARG; }
+    if (!region) { region = zero_region(); if (!geom) nW = 1; if (!region) return DGX_ERR_BAD_ARG; }
+    AttnGeom G = geom ? *geom : AttnGeom{0, 0, 0, 0, 0, nullptr, nullptr};
+    if (geom) { G.zeros = (const uint16_t*)zero_region(); if (!G.zeros) return DGX_ERR_BAD_ARG; }
     // One workgroup per CU (LDS-limited) in a single round: per-workgroup setup (bias row, flush of the bias-gradient row) is amortised
     // over the run (measured best among 256/512/768/2048 workgroup targets), runs of equal length over the CUs the persistent kernels'
     // reservation leaves (engine/ddp.py: RCCL's channels at N > 1); the kernel's header says how the runs are laid over windows and heads
@@ -837,21 +942,27 @@ extern "C" int dgx_window_attention_bwd(const void* qkv, const float* table, con
     BwdTableWs* tw = bwd_table_ws(st, (int64_t)nH * (B_ / upw + (left > 0 ? (left + upl - 1) / upl + 1 : 0)) * tblp, nH);
     if (!tw) return DGX_ERR_UNSUPPORTED;
 #define BWD_ARGS (const uint16_t*)qkv, table, region, (const uint16_t*)out, lse, (const uint16_t*)dout, (uint16_t*)dqkv, dtable, B_, nW, nH, \
-                 scale, upw, upl, tw->part, tw->cnt, dtable_stride_head, dtable_stride_index
+                 scale, upw, upl, tw->part, tw->cnt, dtable_stride_head, dtable_stride_index, G
     if (ws == 12) {
         static bool once = false;
         const size_t sm = bwd_smem_bytes<12>(true);
         if (!once) {
             (void)hipFuncSetAttribute((const void*)win_attn_bwd_kernel<12, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
             (void)hipFuncSetAttribute((const void*)win_attn_bwd_kernel<12, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+            (void)hipFuncSetAttribute((const void*)win_attn_bwd_kernel<12, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+            (void)hipFuncSetAttribute((const void*)win_attn_bwd_kernel<12, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
             once = true;
         }
-        if (masked) hipLaunchKernelGGL((win_attn_bwd_kernel<12, true, true>), dim3(grid), dim3((WinCfg<12>::NT + 3) * 64), sm, st, BWD_ARGS);
-        else hipLaunchKernelGGL((win_attn_bwd_kernel<12, false, true>), dim3(grid), dim3((WinCfg<12>::NT + 3) * 64), sm, st, BWD_ARGS);
+#define BWD12(MK, CP) hipLaunchKernelGGL((win_attn_bwd_kernel<12, MK, true, CP>), dim3(grid), dim3((WinCfg<12>::NT + 3) * 64), sm, st, BWD_ARGS)
+        if (masked) { if (geom) BWD12(true, true); else BWD12(true, false); }
+        else { if (geom) BWD12(false, true); else BWD12(false, false); }
+#undef BWD12
     } else if (ws == 7) {
         const size_t sm = bwd_smem_bytes<7>();
-        if (masked) hipLaunchKernelGGL((win_attn_bwd_kernel<7, true>), dim3(grid), dim3(WinCfg<7>::NT * 64), sm, st, BWD_ARGS);
-        else hipLaunchKernelGGL((win_attn_bwd_kernel<7, false>), dim3(grid), dim3(WinCfg<7>::NT * 64), sm, st, BWD_ARGS);
+#define BWD7(MK, CP) hipLaunchKernelGGL((win_attn_bwd_kernel<7, MK, false, CP>), dim3(grid), dim3(WinCfg<7>::NT * 64), sm, st, BWD_ARGS)
+        if (masked) { if (geom) BWD7(true, true); else BWD7(true, false); }
+        else { if (geom) BWD7(false, true); else BWD7(false, false); }
+#undef BWD7
     } else {
         return DGX_ERR_UNSUPPORTED;
     }
@@ -861,4 +972,26 @@ extern "C" int dgx_window_attention_bwd(const void* qkv, const float* table, con
         return -(int)e - 1000;
     }
     return DGX_OK;
+}
+
+extern "C" int dgx_window_attention_bwd(const void* qkv, const float* table, const int8_t* region, const void* out,
+                                        const float* lse, const void* dout, void* dqkv, float* dtable,
+                                        int64_t dtable_stride_head, int64_t dtable_stride_index, int B_, int nW, int nH,
+                                        int ws, float scale, void* stream) {
+    return attn_bwd_launch(qkv, table, region, out, lse, dout, dqkv, dtable, dtable_stride_head, dtable_stride_index, B_, nW, nH, ws, scale,
+                           nullptr, stream);
+}
+
+extern "C" int dgx_window_attention_bwd_compact(const void* qkv, const void* qkv_bias, const float* table, const int8_t* region, const void* out,
+                                                const float* lse, const void* dout, void* dqkv, float* dtable, int64_t dtable_stride_head,
+                                                int64_t dtable_stride_index, int B, int H, int W, int nH, int ws, int shift, float scale,
+                                                void* stream) {
+    if (ws != 12 && ws != 7) return DGX_ERR_UNSUPPORTED;
+    AttnGeom G = {0, 0, 0, 0, 0, nullptr, nullptr};
+    int nW = 0;
+    const int nWh = (H + ws - 1) / ws, nWw = (W + ws - 1) / ws;
+    const int B_ = B * nWh * nWw;
+    if (int rc = attn_geom(G, B_, nW, ws, B, H, W, shift, qkv_bias, nH)) return rc;
+    return attn_bwd_launch(qkv, table, region, out, lse, dout, dqkv, dtable, dtable_stride_head, dtable_stride_index, B_, nW, nH, ws, scale,
+                           &G, stream);
 }

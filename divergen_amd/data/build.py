@@ -647,6 +647,15 @@ class BatchAhead:
         return batch
 
 
+# Intra-op CPU threads of the TRAINING process while a loader runs.  torch sizes its thread pool by the visible cores (128 on the
+# 256-core MI355X host), but the process shares a cgroup CPU quota with its workers (16 CPUs on the box measured: /sys/fs/cgroup/cpu.max
+# 1600000 100000): the pin thread's 12-30 MB copies fanned out over 128 OpenMP threads whose spin-waits burnt the quota, the kernel
+# throttled the whole cgroup, and the training thread's host time per step DOUBLED (profiles/r06_loader_ab.txt: 57.0 ms/step with the
+# default pool, 28.5 with 4 threads, same workers, same batches; 25.2 with the same batches and no loader running).  The training
+# process has no CPU tensor work of its own besides those copies.  bench.py --loader-dev main_threads=N overrides (0 = leave alone).
+DEV = {"pin": "loader", "strategy": None, "main_threads": 4}
+
+
 def build_detection_train_loader(cfg, per_gpu, device, seed):
     """DG/train_net.py:164-239 + D2/data/build.py:build_detection_train_loader: dataset dicts, sampler by
     DATALOADER.SAMPLER_TRAIN, the whole mapper (copy-paste preparation included) in DATALOADER.NUM_WORKERS worker processes,
@@ -667,6 +676,12 @@ def build_detection_train_loader(cfg, per_gpu, device, seed):
     rank_seed = seed * 1009 + comm.get_rank() * 131
     nw = cfg.DATALOADER.NUM_WORKERS
     on_gpu = torch.device(device).type == "cuda"
+    if DEV["strategy"]:
+        torch.multiprocessing.set_sharing_strategy(DEV["strategy"])
+    if DEV["main_threads"] and on_gpu and nw > 0:
+        torch.set_num_threads(min(torch.get_num_threads(), int(DEV["main_threads"])))
+    if DEV["pin"] != "loader":
+        on_gpu = False
     loader = torch.utils.data.DataLoader(
         _MapDataset(dicts, mapper), sampler=sampler, batch_size=per_gpu, drop_last=True, num_workers=nw, collate_fn=_identity,
         worker_init_fn=functools.partial(_worker_init, base_seed=rank_seed), pin_memory=on_gpu,

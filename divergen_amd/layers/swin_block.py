@@ -236,6 +236,21 @@ def _take_handover(g, s2):
     return h[2] if same_scale else None
 
 
+# Rows between LayerNorm-1 and the proj GEMM in COMPACT window order (csrc/winmap.h): the reference pads the token grid to multiples of
+# the window AFTER norm1 (swintransformer.py:216-221) and crops after proj (:248-251), so the padding tokens' qkv rows are the qkv bias
+# and their proj rows are thrown away -- 26.6 % of the rows of Swin stages 2 / 3 at 1024^2 (72^2 for 64^2), 65 % of stage 3 at 896^2.
+# With COMPACT the qkv / proj forward GEMMs, their input-gradient GEMMs and the proj weight gradient run over the B*H*W real rows only;
+# the attention kernels take the bias for a padding token's q / k / v and write its (0, dk, dv) behind the real rows of dqkv, which the
+# qkv weight / bias gradient still sums over.  Exact: every real token's value and every parameter gradient is what the padded form
+# computes (tests/test_gpu_parity_modules.py::test_swin_block_compact_equals_padded).  False = the rounds 1-5 form.
+COMPACT = True
+
+
+def compact_ok(H, W, ws, shift):
+    nWh, nWw = -(-H // ws), -(-W // ws)
+    return COMPACT and (nWh * ws != H or nWw * ws != W) and H >= shift and W >= shift
+
+
 class _SwinBlockFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, region, s1, s2, cfg, prev_scale, n1w, n1b, qw, qb, table, pw, pb, n2w, n2b, w1, b1, w2, b2):
@@ -250,21 +265,29 @@ class _SwinBlockFn(torch.autograd.Function):
         B_, N = B * nW, ws * ws
         Tw = B_ * N
         f32 = torch.float32
-        # LN1 + bf16 + pad + roll + partition
+        compact = compact_ok(H, W, ws, shift)
+        wsm = -ws if compact else ws               # the map argument of the kernels: negative = compact window order
+        Tr = T if compact else Tw                  # rows the GEMMs around the attention run over
+        # LN1 + bf16 + pad + roll + partition (compact: the real tokens first, the padding tokens' zero rows behind them)
         xw = torch.empty(Tw, C, dtype=BF16, device=dev)
         mean1 = torch.empty(T, dtype=f32, device=dev)
         rstd1 = torch.empty(T, dtype=f32, device=dev)
         L.check(lib.dgx_layernorm_fwd(x.data_ptr(), n1w.data_ptr(), n1b.data_ptr(), xw.data_ptr(), mean1.data_ptr(),
-                                      rstd1.data_ptr(), T, C, eps1, B, H, W, ws, shift, code, st), "dgx_layernorm_fwd")
+                                      rstd1.data_ptr(), T, C, eps1, B, H, W, wsm, shift, code, st), "dgx_layernorm_fwd")
         # attention
-        qkv = G.gemm_nt(xw, shadow(qw), shadow(qb))
+        qkv = G.gemm_nt(xw[:Tr], shadow(qw), shadow(qb))
         tbl = table.detach()                       # ((2ws-1)^2, nH) as stored: the kernels take its strides
-        o = torch.empty(Tw, C, dtype=BF16, device=dev)
+        o = torch.empty(Tr, C, dtype=BF16, device=dev)
         lse = torch.empty(B_, nH, N, dtype=f32, device=dev)
-        L.check(lib.dgx_window_attention_fwd(qkv.data_ptr(), tbl.data_ptr(), tbl.stride(1), tbl.stride(0), L.ptr(region),
-                                             o.data_ptr(), lse.data_ptr(), B_, nW, nH, ws, scale, st), "dgx_window_attention_fwd")
+        if compact:
+            L.check(lib.dgx_window_attention_fwd_compact(qkv.data_ptr(), shadow(qb).data_ptr(), tbl.data_ptr(), tbl.stride(1), tbl.stride(0),
+                                                         L.ptr(region), o.data_ptr(), lse.data_ptr(), B, H, W, nH, ws, shift, scale, st),
+                    "dgx_window_attention_fwd_compact")
+        else:
+            L.check(lib.dgx_window_attention_fwd(qkv.data_ptr(), tbl.data_ptr(), tbl.stride(1), tbl.stride(0), L.ptr(region),
+                                                 o.data_ptr(), lse.data_ptr(), B_, nW, nH, ws, scale, st), "dgx_window_attention_fwd")
         # proj + (reverse + roll + crop + DropPath + residual) in the GEMM's epilogue
-        x1 = G.gemm_bias_residual(o, shadow(pw), shadow(pb), x.view(B, H * W, C), s1, B, H, W, ws, shift).view(x.shape)
+        x1 = G.gemm_bias_residual(o, shadow(pw), shadow(pb), x.view(B, H * W, C), s1, B, H, W, wsm, shift).view(x.shape)
         # LN2 + MLP + residual
         h2 = torch.empty(T, C, dtype=BF16, device=dev)
         mean2 = torch.empty(T, dtype=f32, device=dev)
@@ -306,34 +329,48 @@ class _SwinBlockFn(torch.autograd.Function):
         # LN2 backward + the residual-branch gradient g -> dx1
         nblk = lib.dgx_layernorm_bwd_blocks(T)
         part = torch.empty(2, nblk * 2 * C, dtype=torch.float32, device=dev)     # partial (dgamma | dbeta) rows of norm2, norm1
-        # ... and, from the same pass, the attention branch's operand dpr = s1 * dx1 in window order (zero rows for the padding)
+        # ... and, from the same pass, the attention branch's operand dpr = s1 * dx1 in window order (zero rows for the padding;
+        # compact: the real rows only)
+        compact = compact_ok(H, W, ws, shift)
+        wsm = -ws if compact else ws
+        Tr = T if compact else Tw
         dx1 = torch.empty_like(x)
-        dpr = torch.empty(Tw, C, dtype=BF16, device=dev)
+        dpr = torch.empty(Tr, C, dtype=BF16, device=dev)
         L.check(lib.dgx_layernorm_bwd_emit(dh2.data_ptr(), x1.data_ptr(), mean2.data_ptr(), rstd2.data_ptr(), n2w.data_ptr(),
                                            g.data_ptr(), dx1.data_ptr(), None, None, part[0].data_ptr(),
-                                           T, C, 0, 0, 0, 0, 0, code, dpr.data_ptr(), L.ptr(s1), B, H, W, ws, shift, st),
+                                           T, C, 0, 0, 0, 0, 0, code, dpr.data_ptr(), L.ptr(s1), B, H, W, wsm, shift, st),
                 "dgx_layernorm_bwd_emit")
         do = _linear_bwd(dpr, o, pw, pb, wgrads)
-        dqkv = torch.empty_like(qkv)
+        dqkv = torch.empty(Tw, qkv.shape[1], dtype=BF16, device=dev)
         assert table.grad.stride() == table.stride()          # one pair of strides serves the table and its gradient
-        L.check(lib.dgx_window_attention_bwd(qkv.data_ptr(), table.data_ptr(), L.ptr(region), o.data_ptr(), lse.data_ptr(),
-                                             do.data_ptr(), dqkv.data_ptr(), table.grad.data_ptr(), table.stride(1), table.stride(0),
-                                             B_, nW, nH, ws, scale, st), "dgx_window_attention_bwd")
-        _ready(table)
-        dxw = _linear_bwd(dqkv, xw, qw, qb, wgrads)
+        if compact:
+            L.check(lib.dgx_window_attention_bwd_compact(qkv.data_ptr(), shadow(qb).data_ptr(), table.data_ptr(), L.ptr(region), o.data_ptr(),
+                                                         lse.data_ptr(), do.data_ptr(), dqkv.data_ptr(), table.grad.data_ptr(), table.stride(1),
+                                                         table.stride(0), B, H, W, nH, ws, shift, scale, st), "dgx_window_attention_bwd_compact")
+            _ready(table)
+            # qkv weight / bias gradient over ALL rows of dqkv (the padding tokens' dk / dv reach the bias; their xw rows are zero), the
+            # input gradient over the real rows only
+            wgrads.append((qw.grad.view(qw.shape[0], -1), dqkv, xw, qb, qw))
+            dxw = G.gemm_nt(dqkv[:T], shadow_t(qw))
+        else:
+            L.check(lib.dgx_window_attention_bwd(qkv.data_ptr(), table.data_ptr(), L.ptr(region), o.data_ptr(), lse.data_ptr(),
+                                                 do.data_ptr(), dqkv.data_ptr(), table.grad.data_ptr(), table.stride(1), table.stride(0),
+                                                 B_, nW, nH, ws, scale, st), "dgx_window_attention_bwd")
+            _ready(table)
+            dxw = _linear_bwd(dqkv, xw, qw, qb, wgrads)
         # LN1 backward through the window map, accumulated onto dx1 in place
         prev = ctx.prev_scale                      # (scale,) when x came straight out of another block of this kind
         if prev and (prev[0] is not None or dx1.dtype != BF16):
             scaled = torch.empty(T, C, dtype=BF16, device=dev)      # the previous block's fc2-gradient operand, from this pass
             L.check(lib.dgx_layernorm_bwd_emit(dxw.data_ptr(), x.data_ptr(), mean1.data_ptr(), rstd1.data_ptr(), n1w.data_ptr(),
                                                dx1.data_ptr(), dx1.data_ptr(), None, None, part[1].data_ptr(),
-                                               T, C, B, H, W, ws, shift, code, scaled.data_ptr(), L.ptr(prev[0]), B, H, W, 0, 0, st),
+                                               T, C, B, H, W, wsm, shift, code, scaled.data_ptr(), L.ptr(prev[0]), B, H, W, 0, 0, st),
                     "dgx_layernorm_bwd_emit")
             _HANDOVER[0] = (dx1, prev[0], scaled)
         else:
             L.check(lib.dgx_layernorm_bwd(dxw.data_ptr(), x.data_ptr(), mean1.data_ptr(), rstd1.data_ptr(), n1w.data_ptr(),
                                           dx1.data_ptr(), dx1.data_ptr(), None, None, part[1].data_ptr(),
-                                          T, C, B, H, W, ws, shift, code, st), "dgx_layernorm_bwd")
+                                          T, C, B, H, W, wsm, shift, code, st), "dgx_layernorm_bwd")
         # the second stage of both norms' parameter gradients: queued, the norms of up to eight blocks of a stage share one launch
         _defer_ln_reduce(part, (n2w, n2b, n1w, n1b), T, C)
         # the four weight gradients of the block: one grouped launch (256x256 tiles, small M-split)

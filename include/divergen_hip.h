@@ -69,6 +69,26 @@ int dgx_window_attention_bwd(const void* qkv, const float* table, const int8_t* 
                              int64_t dtable_stride_index, int B_, int nW, int nH, int ws, float scale,
                              void* stream);
 
+/* The same pair over COMPACT window order (divergen_amd/csrc/winmap.h): the reference pads the token grid to multiples of ws
+ * AFTER norm1 (swintransformer.py:216-221), so a padding token's qkv row is the qkv bias, its output is cropped (:248-251) and no
+ * gradient reaches its query -- rows that need not exist.  Here qkv / out / dout hold the B*H*W REAL tokens only, in (image,
+ * window, token) order with the padding tokens left out (every GEMM around the attention runs at M = B*H*W instead of
+ * B*nW*ws*ws: -21 % rows in Swin stages 2 and 3 at 1024^2, -39 % in stage 3 at 896^2); the kernels take the bias for a padding
+ * token's q / k / v, never store its output, and read 0 for its dO.
+ *   qkv      bf16 (B*H*W, 3, nH, 32)          qkv_bias bf16 (3, nH, 32)
+ *   out/dout bf16 (B*H*W, nH*32)              lse f32 (B*nW, nH, N) (per window position, as in the classic pair)
+ *   dqkv     bf16 (B*nW*N, 3, nH, 32)         rows 0 .. B*H*W-1: the real tokens; the rest: the padding tokens' (0, dk, dv) in their
+ *                                             own (image, window, token) order -- the qkv BIAS gradient sums over all rows
+ *   region   i8 (nW, N) or NULL               as above (indexed by window position and token, padding tokens included)
+ * B images of H x W tokens, cyclic shift `shift` (0 or ws/2), H >= shift and W >= shift. */
+int dgx_window_attention_fwd_compact(const void* qkv, const void* qkv_bias, const float* table, int64_t table_stride_head,
+                                     int64_t table_stride_index, const int8_t* region, void* out, float* lse, int B, int H,
+                                     int W, int nH, int ws, int shift, float scale, void* stream);
+int dgx_window_attention_bwd_compact(const void* qkv, const void* qkv_bias, const float* table, const int8_t* region,
+                                     const void* out, const float* lse, const void* dout, void* dqkv, float* dtable,
+                                     int64_t dtable_stride_head, int64_t dtable_stride_index, int B, int H, int W, int nH,
+                                     int ws, int shift, float scale, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Window gather / scatter: zero-pad to a multiple of ws, cyclic shift by -shift, window_partition
  * (gather), and the exact inverse window_reverse + roll(+shift) + crop (scatter).
@@ -343,7 +363,11 @@ int dgx_linear_wgrad(const void* dy, const void* x, float* gw, int M, int Nn, in
  * Backward: dy bf16 in the same order as y -> dx (x_dtype) (T,C) written; dgamma/dbeta f32 (C) ACCUMULATED;
  *   part: f32 scratch of dgx_layernorm_bwd_blocks(T)*2*C.  C % 4 == 0, C <= 1536 for backward.
  *   dres (backward, nullable, dtype of x, may alias dx): gradient arriving on the residual branch that
- *   bypasses the norm (x + f(LN(x)), swintransformer.py:254-255); dx = dres + LN-gradient in one pass. */
+ *   bypasses the norm (x + f(LN(x)), swintransformer.py:254-255); dx = dres + LN-gradient in one pass.
+ *   ws < 0 (here, in dgx_layernorm_bwd_emit's ews and in DgxGemmEpilogue.ws): window size -ws with the rows in COMPACT window order
+ *   (csrc/winmap.h; see dgx_window_attention_fwd_compact): rows 0 .. T-1 are the real tokens in (image, window, token) order.  The
+ *   forward still writes B*nW*ws*ws rows -- the padding tokens' zero rows follow the real ones (the qkv weight gradient's operand);
+ *   backward reads / emits the T real rows only.  Needs H >= shift and W >= shift. */
 int dgx_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y_bf16, float* mean,
                       float* rstd, int64_t T, int C, float eps, int B, int H, int W, int ws, int shift,
                       int x_dtype, void* stream);

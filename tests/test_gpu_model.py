@@ -1,6 +1,7 @@
 """GPU tests of the assembled model: loss keys / finiteness, eager vs hipGraph-replayed head segments, the whole training forward
 against the assembled oracle, and the fused optimizer step through the arenas."""
 import os
+import sys
 
 import pytest
 import torch
@@ -134,19 +135,33 @@ def library_compute_kernels(prof):
     return sorted(n for n in names if not any(o in n for o in own))
 
 
-def test_end_to_end_losses_vs_assembled_oracle(monkeypatch):
-    # losses within 1e-3 of both oracles; gradients of the SUM of the ten losses: whole arena <= 8 %, any parameter <= 25 % (measured
-    # 4.8 % / 17 %: the CenterNet tower's four GroupNorm + ReLU layers put ~15 % on everything upstream of them -- ReLU masks that flip
-    # within bf16 rounding of zero, see _compare_gradients and profiles/r05_tower_grad_probe.txt; the sharp check is the next test)
-    run_e2e_vs_oracle(monkeypatch, "T", 256, grads=True, grad_bounds=(8e-2, 0.25))
+# Gradient parity per LOSS GROUP.  The oracle runs with the product's bf16 storage points AND the product's ReLU
+# on/off patterns (oracle/quant.py relu_masks: a ReLU decision is a discrete intermediate like a proposal box or a matched label).
+# Round 5 asserted 8 % / 25 % and explained the distance by flipped ReLU masks; handing the patterns over shows that this IS the
+# distance: the oracle with its own decisions differs from the oracle with the product's by 5.8 % (CenterNet group: four
+# GroupNorm + ReLU tower layers), 1.3 % (box group) and 0.02 % (mask group) over the arena -- 0.3 % of the elements flip, because the
+# two pipelines' activations differ at the bf16 noise floor (~1e-3) by the time they reach the heads, and a bias / weight gradient is
+# a signed sum over the elements, so a fraction f of flips moves it by ~sqrt(2 f).  With the patterns shared what is left is
+# rounding and summation order: measured (profiles/r06_grad_parity_by_loss_group.txt) arena 0.51 / 0.64 / 0.05 / 0.54 %, worst
+# segment 1.25 / 0.97 / 0.55 / 1.24 %, worst parameter 1.4 % (relative-position tables, |g| ~ 1e-4 of the arena).
+# Bounds = measured x 1.5, per segment <= 2 % (the verdict's target); a parameter or segment whose gradient is < 2e-3 of the arena's
+# norm is bounded through its share of the whole instead.
+GRAD_GROUPS = {
+    "centernet": (lambda k: "centernet" in k, 8e-3, 2.2e-2, 2.0e-2),
+    "box": (lambda k: "stage" in k, 1.0e-2, 2.0e-2, 2.0e-2),
+    "mask": (lambda k: k == "loss_mask", 1.0e-3, 2.0e-2, 1.0e-2),
+    "all": (None, 8.5e-3, 2.2e-2, 2.0e-2),
+}
 
 
-def test_end_to_end_gradients_of_the_mask_loss_are_sharp(monkeypatch):
-    """The gradient of loss_mask alone: mask head -> RoIAlign backward (gather form) -> FPN -> the whole Swin backbone (attention
-    backward, LayerNorm backward, the grouped weight gradients, PatchMerging, PatchEmbed) without a GroupNorm + ReLU tower in the way.
-    Every parameter of the backbone within 6 % (measured <= 3.0 %, the relative-position tables; segments 1.2-1.5 %), the whole arena
-    within 2e-3 (measured 5e-4) of the oracle's autograd."""
-    run_e2e_vs_oracle(monkeypatch, "T", 256, grads=True, loss_filter=lambda k: k == "loss_mask", grad_bounds=(2e-3, 6e-2))
+@pytest.mark.parametrize("group", list(GRAD_GROUPS))
+def test_end_to_end_losses_and_gradients_vs_assembled_oracle(monkeypatch, group):
+    """All ten losses within 1e-3 of both oracles (every group runs the same forward), the group's gradient -- d(sum of the
+    group's losses) / d(every parameter) -- within the bounds above: whole arena, every segment (backbone stage / FPN conv / head),
+    every parameter.  'mask' is the path mask head -> RoIAlign gather backward -> FPN -> whole Swin backbone; 'box' the three
+    cascade stages (fused box stage, _ScaleGradient, pooler backward); 'centernet' the tower + losses + the early backward."""
+    f, arena, per_param, per_segment = GRAD_GROUPS[group]
+    run_e2e_vs_oracle(monkeypatch, "T", 256, grads=True, loss_filter=f, grad_bounds=(arena, per_param), segment_bounds=per_segment)
 
 
 def _capture_relu_sites(monkeypatch, model):
@@ -170,7 +185,7 @@ def _capture_relu_sites(monkeypatch, model):
 
     def act(x, w, b, relu=False):
         out = orig_act(x, w, b, relu=relu)
-        if relu:
+        if relu and sys._getframe(1).f_code.co_filename.endswith("box_stage.py"):      # (the mask head's deconvolution is a ReLU GEMM too)
             site["box"].append((out > 0).detach().cpu())
         return out
     monkeypatch.setattr(CH, "groupnorm_relu_multi", gn)
@@ -180,22 +195,30 @@ def _capture_relu_sites(monkeypatch, model):
     for name in [n for n, _ in mh.named_children() if n.startswith("mask_fcn") and "relu" not in n] + ["deconv"]:
         getattr(mh, name).register_forward_hook(lambda m, i, o, name=name: site["mask"].__setitem__(name, (o > 0).detach().cpu()))
     model.backbone.register_forward_hook(lambda m, i, o: site.__setitem__("p6", (o["p6"] > 0).detach().cpu()))
+    # the head called level by level (graphs off): its regression outputs per level, (N, 4, H, W)
+    model.proposal_generator.centernet_head.register_forward_hook(
+        lambda m, i, o: site.__setitem__("reg_levels", [(r > 0).detach().cpu() for r in o[1]]))
     return site
 
 
 def _oracle_relu_masks(site, box_rows, n_mask_rows):
     """site (product patterns) -> {oracle site tag: mask in the oracle's shape and row convention} (oracle/quant.py relu_masks)."""
     m = {"top_block.p6": site["p6"]}
-    assert len(site["tower"]) == 4 and site["reg"] is not None and len(site["box"]) == 6, (len(site["tower"]), len(site["box"]))
+    assert len(site["tower"]) == 4 and len(site["box"]) == 6, (len(site["tower"]), len(site["box"]))
+    assert site["reg"] is not None or site.get("reg_levels") is not None
     for i, per_level in enumerate(site["tower"]):
         for l, k in enumerate(per_level):
             m["tower.%d.%d" % (l, i)] = k
-    reg, shapes = site["reg"]
-    off = 0
-    for l, (N, _, H, W) in enumerate(shapes):
-        m["reg.%d" % l] = reg[off:off + N * H * W].reshape(N, H, W, 4).permute(0, 3, 1, 2)
-        off += N * H * W
-    assert off == reg.shape[0]
+    if site["reg"] is not None:          # the flattened tail (levels stacked in (level, image, y, x) order)
+        reg, shapes = site["reg"]
+        off = 0
+        for l, (N, _, H, W) in enumerate(shapes):
+            m["reg.%d" % l] = reg[off:off + N * H * W].reshape(N, H, W, 4).permute(0, 3, 1, 2)
+            off += N * H * W
+        assert off == reg.shape[0]
+    else:
+        for l, k in enumerate(site["reg_levels"]):
+            m["reg.%d" % l] = k
     for k in range(3):
         for j, fc in enumerate(("fc1", "fc2")):
             m["roi_heads.box_head.%d.%s" % (k, fc)] = site["box"][2 * k + j][box_rows[k]]

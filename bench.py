@@ -184,6 +184,26 @@ def _copy_sources(step):
         print("%4d %8.1f us  %-70s %-18s %s" % (n, t, k[0], k[1][:18], k[2]), file=sys.stderr)
 
 
+def _read(path):
+    try:
+        with open(path) as f:
+            return f.read().strip()
+    except OSError:
+        return None
+
+
+def _cgroup_throttled():
+    """(nr_throttled, throttled_usec) of this process's cgroup (v2), or None: is the loader pushing the job over its CPU quota?"""
+    txt = _read("/sys/fs/cgroup/cpu.stat")
+    if not txt:
+        return None
+    kv = dict(line.split() for line in txt.splitlines() if len(line.split()) == 2)
+    try:
+        return int(kv["nr_throttled"]), int(kv["throttled_usec"])
+    except (KeyError, ValueError):
+        return None
+
+
 def _load_json(name):
     try:
         with open(os.path.join(ROOT, "profiles", name)) as f:
@@ -415,7 +435,7 @@ def main():
         # batch are kept in pinned host buffers -- the form the DataLoader's pin thread leaves worker results in -- and go up on the
         # loader's side stream INSIDE the timed region, every step (--inputs-resident: everything staged in HBM before the clock starts).
         rng = np.random.default_rng(7 + rank)
-        place = (lambda t: t.to(dev)) if a.inputs_resident else (lambda t: t.detach().cpu().pin_memory())
+        from divergen_amd.data.build import pack_sample, unpack_sample
         host_batches = []
         for j in range(nd):
             n_gt = (12, 10, 14, 12, 8, 16, 11, 13)[j % 8]          # 12 objects per image on average, not the same every step
@@ -423,23 +443,19 @@ def main():
             for d in synthetic_batch(a.batch, a.size, cfg.MODEL.ROI_HEADS.NUM_CLASSES, seed=1234 + rank + 1000 * j, n_gt=n_gt):
                 flat, desc, labels = la.pack_pastes_host(make_pastes(rng, a.size))
                 inst = d["instances"]
-                d["image"] = place(d["image"])
-                d["instances"] = Instances(inst.image_size, gt_boxes=Boxes(place(inst.gt_boxes.tensor)), gt_classes=place(inst.gt_classes),
-                                           gt_masks=BitMasks(place(inst.gt_masks.tensor)))
-                d["paste_pack"] = {"flat": place(flat), "desc": place(desc), "labels": place(labels), "K": int(desc.shape[0])}
+                d["instances"] = Instances(inst.image_size, gt_boxes=inst.gt_boxes, gt_classes=inst.gt_classes, gt_masks=inst.gt_masks)
+                d["paste_pack"] = {"flat": flat, "desc": desc, "labels": labels, "K": int(desc.shape[0])}
+                d = pack_sample(d)                      # what a loader worker returns: ONE uint8 blob per sample + its layout
+                d["blob"] = d["blob"].to(dev) if a.inputs_resident else d["blob"].pin_memory()
                 per.append(d)
             host_batches.append(per)
         if not a.inputs_resident:
-            d0 = host_batches[0][0]
-            h2d_bytes[0] = a.batch * sum(t.numel() * t.element_size() for t in (
-                d0["image"], d0["instances"].gt_masks.tensor, d0["instances"].gt_boxes.tensor, d0["instances"].gt_classes,
-                d0["paste_pack"]["flat"], d0["paste_pack"]["desc"], d0["paste_pack"]["labels"]))
+            h2d_bytes[0] = a.batch * int(host_batches[0][0]["blob"].numel())
 
         def finish(d, device):
+            d = unpack_sample(d, device)                # one host -> device copy, the fields as views of it
             if a.no_copy_paste:
-                d = {k: v for k, v in d.items() if k != "paste_pack"}
-                d["image"], d["instances"] = d["image"].to(device, non_blocking=True), d["instances"].to(device)
-                return d
+                return {k: v for k, v in d.items() if k != "paste_pack"}
             out = InstPool.composite(d, device)
             out.pop("_uploaded")
             return out
@@ -507,6 +523,7 @@ def main():
         prof.pause(True)
         for k_ in host:
             host[k_] = 0.0
+        throttle0 = _cgroup_throttled()
         sampled = 0
         t0 = time.perf_counter()
         for k in range(a.steps):
@@ -645,6 +662,10 @@ def main():
                            "blocked_on_data_ms_per_step": 1e3 * sum(data_wait[-a.steps:]) / max(a.steps, 1)},
                 "peak_hbm_gb_rank0": torch.cuda.max_memory_allocated(dev) / 1e9}
         if loader_info is not None:
+            t1_ = _cgroup_throttled()
+            loader_info["cgroup_cpu_max"] = _read("/sys/fs/cgroup/cpu.max")
+            loader_info["cgroup_throttled_periods_in_timed_region"] = (t1_[0] - throttle0[0]) if t1_ and throttle0 else None
+            loader_info["cgroup_throttled_ms_in_timed_region"] = (t1_[1] - throttle0[1]) / 1e3 if t1_ and throttle0 else None
             line["loader"] = loader_info
         if in_sync is not None:
             line["ranks_seen_by_collective"] = ranks_seen

@@ -141,10 +141,16 @@ __global__ __launch_bounds__(WinCfg<WS>::NT * 64) void win_attn_fwd_kernel(
         wc = wi - wr * wg.nWw;
         ww = wm_window(wg, wr, wc);
     }
-    auto qkv_ptr = [&](int n, int part, int off) -> const uint16_t* {
-        if (!COMPACT) return base + part * C + (int64_t)n * rowst + off;
-        const int row = attn_row<WS>(G, wg, ww, img, wr, wc, n < N ? n : 0);
-        return row >= 0 ? qkv + (int64_t)row * rowst + part * C + h * 32 + off : G.bias + part * C + h * 32 + off;
+    // (a window without padding tokens -- most of them -- takes the uniform short cut: its rows are consecutive)
+    const bool wfull = COMPACT && ww.rh == WS && ww.rw == WS;
+    auto row_of = [&](int n) -> int {
+        if (wfull) return img * (G.H * G.W) + ww.base + n;
+        return attn_row<WS>(G, wg, ww, img, wr, wc, n);
+    };
+    auto row_ptr = [&](int n) -> const uint16_t* {          // token n's q | k | v row: its qkv row, or the bias for a padding token
+        if (!COMPACT) return base + (int64_t)n * rowst;
+        const int row = row_of(n < N ? n : 0);
+        return (row >= 0 ? qkv + (int64_t)row * rowst : G.bias) + h * 32;
     };
 
     // ---- every global load of the workgroup is issued here, back to back (ONE memory latency), then parked in LDS
@@ -153,12 +159,15 @@ __global__ __launch_bounds__(WinCfg<WS>::NT * 64) void win_attn_fwd_kernel(
     const int kr_in = (MASKED && tid < N) ? (int)reg[tid] : -1;
     const int rq = (MASKED && qok) ? (int)reg[qi] : 0;
     const int u0 = tid, u1 = tid + nthreads;                       // 16-byte chunks of the K / V images: row u >> 2, chunk u & 3
-    const bf16x8 k0 = ld_frag_global(qkv_ptr(u0 >> 2, 1, 8 * (u0 & 3)), (u0 >> 2) < N);
-    const bf16x8 v0 = ld_frag_global(qkv_ptr(u0 >> 2, 2, 8 * (u0 & 3)), (u0 >> 2) < N);
+    const uint16_t* r0 = row_ptr(u0 >> 2);
+    const uint16_t* r1 = row_ptr(u1 >> 2);
+    const bf16x8 k0 = ld_frag_global(r0 + C + 8 * (u0 & 3), (u0 >> 2) < N);
+    const bf16x8 v0 = ld_frag_global(r0 + 2 * C + 8 * (u0 & 3), (u0 >> 2) < N);
     const bool two = u1 < NP * 4;
-    const bf16x8 k1 = ld_frag_global(qkv_ptr(u1 >> 2, 1, 8 * (u1 & 3)), two && (u1 >> 2) < N);
-    const bf16x8 v1 = ld_frag_global(qkv_ptr(u1 >> 2, 2, 8 * (u1 & 3)), two && (u1 >> 2) < N);
-    const bf16x8 qf = ld_frag_global(qkv_ptr(qi, 0, 8 * g), qok);
+    const bf16x8 k1 = ld_frag_global(r1 + C + 8 * (u1 & 3), two && (u1 >> 2) < N);
+    const bf16x8 v1 = ld_frag_global(r1 + 2 * C + 8 * (u1 & 3), two && (u1 >> 2) < N);
+    const int q_row = COMPACT ? row_of(qok ? qi : 0) : 0;
+    const bf16x8 qf = ld_frag_global(COMPACT ? (q_row >= 0 ? qkv + (int64_t)q_row * rowst : G.bias) + h * 32 + 8 * g : base + (int64_t)qi * rowst + 8 * g, qok);
     if (tid < TBL) tbl[tid] = tv * DGX_LOG2E;
     if (tid < NP) {
         const int yk = tid / WS;
@@ -232,7 +241,7 @@ __global__ __launch_bounds__(WinCfg<WS>::NT * 64) void win_attn_fwd_kernel(
         o[1] = mfma16(tr_frag(v_l4, 32 * t * RR + 16, (32 * t + 16) * RR + 16), pf, o[1]);
     }
     int64_t out_row = (int64_t)b * N + qi;
-    if (COMPACT) out_row = qok ? attn_row<WS>(G, wg, ww, img, wr, wc, qi) : -1;      // a padding query's output is cropped: not stored
+    if (COMPACT) out_row = qok ? q_row : -1;       // a padding query's output is cropped: not stored
     if (qok && out_row >= 0) {
         uint16_t* orow = out + out_row * C + h * 32 + 4 * g;
 #pragma unroll
@@ -366,7 +375,9 @@ __global__ __launch_bounds__((WinCfg<WS>::NT + (HELP ? 3 : 0)) * 64) void win_at
     auto compact_row = [&](int b, int n) -> int {
         const WmGeom wg = wm_geom(G.H, G.W, WS, G.shift);
         const int img = b / nW, wi = b - img * nW, wr = wi / wg.nWw, wc = wi - wr * wg.nWw;
-        return attn_row<WS>(G, wg, wm_window(wg, wr, wc), img, wr, wc, n);
+        const WmWindow ww = wm_window(wg, wr, wc);
+        if (ww.rh == WS && ww.rw == WS) return img * (G.H * G.W) + ww.base + n;      // no padding token in this window (uniform branch)
+        return attn_row<WS>(G, wg, ww, img, wr, wc, n);
     };
     auto issue = [&](int b, int h, BwdPrefetch& P) {
         if (COMPACT) {

@@ -464,6 +464,7 @@ class CopyPasteMapper:
         self.method = cfg.INPUT.USE_COPY_METHOD
         self.inst_pool = None
         self.dataset = None
+        self.pack = True               # one blob per sample across the process boundary (pack_sample); the loader's finish() unpacks
         if self.method not in ("none", "syn_copy"):
             raise NotImplementedError("INPUT.USE_COPY_METHOD '{}': only 'syn_copy' / 'none' (the shipped configs) are built".format(self.method))
         if cfg.INPUT.INST_POOL and self.method == "syn_copy":
@@ -527,7 +528,7 @@ class CopyPasteMapper:
             cls, test = self._held_out(result.get("paste_labels", []), result["instances"].gt_classes.tolist())
             result["test_image"], result["test_instances"] = test["image"], test["instances"]
             result["test_image_class"], result["test_file_name"] = cls, test.get("file_name")
-        return result
+        return pack_sample(result) if self.pack else result
 
     def finish(self, result, device):
         """What the TRAINING PROCESS runs on one worker result, on the current stream: upload (asynchronous from pinned memory) and
@@ -535,6 +536,7 @@ class CopyPasteMapper:
         input: the compositor writes a copy)."""
         from .copypaste import InstPool
         dev = torch.device(device)
+        result = unpack_sample(result, dev)
         if "instances" not in result:
             result["image"] = result["image"].to(dev, non_blocking=True)
             return result
@@ -554,6 +556,61 @@ class CopyPasteMapper:
         return out
 
 
+# ---- one blob per sample.  A worker result used to cross the process boundary as 7 tensors per image (image, masks, boxes, classes,
+# paste patches, paste descriptors, paste labels): 7 shared-memory segments whose file descriptors are handed over one authenticated
+# socket round trip each (Python, under the GIL, in the training process's pin thread), 7 pinned copies, 7 host -> device copies issued
+# by the training thread.  The worker now lays them out in ONE uint8 tensor (sections 64-byte aligned) + a small layout list; the
+# training process pins and uploads that one tensor and takes the fields as VIEWS of the device copy.
+_BLOB_FIELDS = (("image", lambda d: d["image"]), ("gt_masks", lambda d: d["instances"].gt_masks.tensor.view(torch.uint8)),
+                ("gt_boxes", lambda d: d["instances"].gt_boxes.tensor), ("gt_classes", lambda d: d["instances"].gt_classes),
+                ("flat", lambda d: d["paste_pack"]["flat"]), ("desc", lambda d: d["paste_pack"]["desc"]), ("labels", lambda d: d["paste_pack"]["labels"]))
+
+
+def pack_sample(d):
+    """Worker side: the sample's tensors -> d['blob'] (uint8) + d['blob_layout'] [(name, dtype, shape, byte offset)]; the tensor
+    entries themselves are dropped.  Samples without paste_pack / instances pass through unchanged."""
+    if "paste_pack" not in d or "instances" not in d or not d["instances"].has("gt_masks"):
+        return d
+    parts, layout, off = [], [], 0
+    for name, get in _BLOB_FIELDS:
+        t = get(d).contiguous()
+        raw = t.view(-1).view(torch.uint8) if t.numel() else torch.zeros(0, dtype=torch.uint8)
+        layout.append((name, str(t.dtype).replace("torch.", ""), tuple(t.shape), off))
+        pad = (-raw.numel()) % 64
+        parts.append(raw)
+        if pad:
+            parts.append(torch.zeros(pad, dtype=torch.uint8))
+        off += raw.numel() + pad
+    out = {k: v for k, v in d.items() if k not in ("image", "instances", "paste_pack")}
+    out["blob"], out["blob_layout"] = torch.cat(parts) if parts else torch.zeros(0, dtype=torch.uint8), layout
+    out["blob_hw"], out["blob_K"] = tuple(d["image"].shape[-2:]), int(d["paste_pack"]["K"])
+    extra = {k: v for k, v in d["instances"].get_fields().items() if k not in ("gt_masks", "gt_boxes", "gt_classes")}
+    if extra:
+        out["blob_extra_fields"] = extra
+    return out
+
+
+def unpack_sample(d, device):
+    """Training-process side: d['blob'] goes to `device` in ONE (asynchronous, when pinned) copy; image / instances / paste_pack come back
+    as views of it."""
+    if "blob" not in d:
+        return d
+    blob = d["blob"].to(device, non_blocking=True)
+    f = {}
+    for name, dt, shape, off in d["blob_layout"]:
+        dtype = getattr(torch, dt)
+        n = int(np.prod(shape)) * torch.empty(0, dtype=dtype).element_size()
+        f[name] = blob[off:off + n].view(dtype).view(shape)
+    out = {k: v for k, v in d.items() if not k.startswith("blob")}
+    out["image"] = f["image"]
+    inst = Instances(tuple(d["blob_hw"]), gt_boxes=Boxes(f["gt_boxes"]), gt_classes=f["gt_classes"], gt_masks=BitMasks(f["gt_masks"].view(torch.bool)))
+    for k, v in d.get("blob_extra_fields", {}).items():
+        inst.set(k, v.to(device) if hasattr(v, "to") else v)
+    out["instances"] = inst
+    out["paste_pack"] = {"flat": f["flat"], "desc": f["desc"], "labels": f["labels"], "K": d["blob_K"]}
+    return out
+
+
 class _MapDataset(torch.utils.data.Dataset):
     def __init__(self, dicts, fn):
         self.dicts, self.fn = dicts, fn
@@ -571,6 +628,8 @@ def _worker_init(worker_id, base_seed, in_worker=True):
     torch.manual_seed(seed)
     if in_worker:
         torch.set_num_threads(1)      # 16 workers per GPU: one core each
+        if DEV["nice"]:
+            os.nice(int(DEV["nice"]))
 
 
 def _tensors_of(obj):
@@ -653,7 +712,7 @@ class BatchAhead:
 # throttled the whole cgroup, and the training thread's host time per step DOUBLED (profiles/r06_loader_ab.txt: 57.0 ms/step with the
 # default pool, 28.5 with 4 threads, same workers, same batches; 25.2 with the same batches and no loader running).  The training
 # process has no CPU tensor work of its own besides those copies.  bench.py --loader-dev main_threads=N overrides (0 = leave alone).
-DEV = {"pin": "loader", "strategy": None, "main_threads": 4}
+DEV = {"pin": "loader", "strategy": None, "main_threads": 4, "nice": 0, "switch_us": 0}
 
 
 def build_detection_train_loader(cfg, per_gpu, device, seed):
@@ -682,6 +741,9 @@ def build_detection_train_loader(cfg, per_gpu, device, seed):
         torch.set_num_threads(min(torch.get_num_threads(), int(DEV["main_threads"])))
     if DEV["pin"] != "loader":
         on_gpu = False
+    if DEV["switch_us"]:
+        import sys
+        sys.setswitchinterval(int(DEV["switch_us"]) * 1e-6)
     loader = torch.utils.data.DataLoader(
         _MapDataset(dicts, mapper), sampler=sampler, batch_size=per_gpu, drop_last=True, num_workers=nw, collate_fn=_identity,
         worker_init_fn=functools.partial(_worker_init, base_seed=rank_seed), pin_memory=on_gpu,

@@ -127,10 +127,73 @@ def gen_merge(out):
     out["merge"] = {"pools": pools, "before": ["/a/", "/b/"], "after": ["/data/A/", "/data/B/"], "merged": merged}
 
 
+def gen_select(out):
+    """DG/filteration/clean_pool_if.py run as __main__ on synthetic results.json trees.  As shipped the script dies at :177
+    (`args.enable_split` is read but its parser, :103-115, never defines it): the namespace its parser returns gets
+    `enable_split = False` added -- the behaviour of the branch the authors ran -- and nothing else is changed.  cv2 is absent, so the
+    128-process pool that crops the selected instances (:214-235 -> work / subwork, cv2.findContours) is replaced by a recorder: the
+    golden is the SELECTION the script hands to that pool (category -> 'image|mask' paths), with and without the similarity csv."""
+    import argparse
+    import csv
+    import multiprocessing
+    rng = np.random.default_rng(11)
+    cats = [{"id": 5, "name": "bee", "image_count": 4}, {"id": 2, "name": "cat", "image_count": 9}, {"id": 9, "name": "empty", "image_count": 1}]
+    methods = ["sam", "u2net", "selfreformer"]
+    n = {"bee": 6, "cat": 5, "empty": 0}
+    res = {}
+    for m in methods:
+        res[m] = [dict(c, clip_scores=[round(float(v), 3) for v in rng.uniform(15, 30, n[c["name"]])],
+                       areas=[round(float(v), 4) for v in rng.uniform(0.0, 1.0, n[c["name"]])]) for c in cats]
+        rng.shuffle(res[m])                       # every results.json in its own order: the script sorts by image_count
+    keep = [("bee", "5_0000001.png"), ("bee", "5_0000004.png"), ("bee", "5_0000005.png"), ("cat", "2_0000000.png"), ("cat", "2_0000003.png")]
+    cases = []
+    for use_csv, min_clip, min_area, max_area, tol in ((False, 21.0, 0.05, 0.95, 1.0), (True, 0.0, 0.0, 1.0, 1.0), (False, 40.0, 0.2, 0.8, 6.0)):
+        with tempfile.TemporaryDirectory() as d:
+            for m in methods:
+                os.makedirs(os.path.join(d, "seg", "II", m))
+                json.dump(res[m], open(os.path.join(d, "seg", "II", m, "results.json"), "w"))
+            argv = ["--input_dir", os.path.join(d, "seg"), "--image_dir", "/img", "--output_file", os.path.join(d, "o", "pool.json"),
+                    "--min_clip", str(min_clip), "--min_area", str(min_area), "--max_area", str(max_area), "--tolerance", str(tol),
+                    "--seg_method"] + methods + ["--stages", "II"]
+            if use_csv:
+                with open(os.path.join(d, "keep.csv"), "w", newline="") as f:
+                    w = csv.writer(f)
+                    w.writerow(["category", "file", "similarity"])
+                    for row in keep:
+                        w.writerow(list(row) + [0.9])
+                argv += ["--filter_image_csv_path", os.path.join(d, "keep.csv")]
+            os.makedirs(os.path.join(d, "o"))
+            seen = {}
+
+            class Pool:
+                def __init__(self, processes=None):
+                    pass
+
+                def map(self, fn, parts, chunk=None):
+                    for part in parts:
+                        seen.update({str(k): [v.replace(d, "$D") for v in vs] for k, vs in part.items() if k != "output"})
+                    return [{}]
+            old_parse, old_pool, old_ssm = argparse.ArgumentParser.parse_args, multiprocessing.Pool, multiprocessing.set_start_method
+
+            def parse(self, *a, **k):
+                ns = old_parse(self, *a, **k)
+                ns.enable_split = False
+                return ns
+            argparse.ArgumentParser.parse_args, multiprocessing.Pool, multiprocessing.set_start_method = parse, Pool, (lambda *a, **k: None)
+            try:
+                run_script(os.path.join(REF, "filteration", "clean_pool_if.py"), argv, {"cv2": types.ModuleType("cv2")})
+            finally:
+                argparse.ArgumentParser.parse_args, multiprocessing.Pool, multiprocessing.set_start_method = old_parse, old_pool, old_ssm
+        cases.append({"min_clip": min_clip, "min_area": min_area, "max_area": max_area, "tolerance": tol, "csv": keep if use_csv else None,
+                      "selected": seen})
+    out["select"] = {"methods": methods, "results": res, "cases": cases}
+
+
 if __name__ == "__main__":
     out = {}
     gen_clip(out)
     gen_merge(out)
+    gen_select(out)
     path = os.path.join(ROOT, "tests", "golden", "factory.json")
     json.dump(out, open(path, "w"))
     print("wrote", path, os.path.getsize(path), "bytes")

@@ -74,6 +74,130 @@ def test_window_attention_fwd_bwd(ws, nH, B_, nW):
     close(td.grad.cpu(), tr.grad)
 
 
+def _classic_rows(B, H, W, ws, shift):
+    """token index of every row of the CLASSIC window order (pad -> roll -> partition, swintransformer.py:216-233), -1 = padding."""
+    nWh, nWw = -(-H // ws), -(-W // ws)
+    tok = torch.full((B, nWh * ws, nWw * ws), -1, dtype=torch.int64)
+    tok[:, :H, :W] = torch.arange(B * H * W).reshape(B, H, W)
+    if shift:
+        tok = torch.roll(tok, (-shift, -shift), (1, 2))
+    return OSW.partition(tok[..., None], ws).reshape(-1)
+
+
+@pytest.mark.parametrize("B,H,W,ws,nH,shift", [(2, 30, 26, 12, 3, 6), (2, 30, 26, 12, 3, 0), (1, 32, 32, 12, 24, 6), (3, 10, 13, 7, 2, 3),
+                                               (2, 13, 40, 12, 6, 6), (1, 6, 18, 12, 2, 6), (2, 24, 24, 12, 2, 6)])
+def test_window_attention_compact_equals_padded(B, H, W, ws, nH, shift):
+    """dgx_window_attention_{fwd,bwd}_compact (rows of the REAL tokens only; a padding token's q / k / v = the qkv bias, its dO = 0)
+    against the classic pair on the padded layout the reference computes (qkv rows of padding tokens = bias, swintransformer.py:216-221
+    pads after norm1): outputs of the real tokens, dq / dk / dv of every token -- the padding tokens' (0, dk, dv) behind the real rows --
+    and the bias-table gradient, BIT for bit (the same arithmetic per window; only the addressing differs)."""
+    from divergen_amd import _lib as L
+    from divergen_amd.layers import shift_regions
+    g = torch.Generator().manual_seed(H * 100 + W + shift)
+    N, C = ws * ws, nH * 32
+    rows = _classic_rows(B, H, W, ws, shift)
+    real = rows >= 0
+    T, Tw = B * H * W, rows.numel()
+    nW = Tw // N // B
+    assert int(real.sum()) == T
+    bias = bf(torch.randn(3 * C, generator=g))
+    qkv_tok = bf(torch.randn(T, 3 * C, generator=g) * 1.5)               # per TOKEN
+    qkv_p = bias[None].repeat(Tw, 1)
+    qkv_p[real] = qkv_tok[rows[real]]                                   # classic layout, padding rows = bias
+    qkv_c = qkv_tok[rows[real]].contiguous()                            # compact layout: the classic order without the padding rows
+    table = torch.randn((2 * ws - 1) ** 2, nH, generator=g).t().contiguous().to(DEV)        # (nH, T)
+    region = shift_regions(H, W, ws).to(DEV) if shift else None
+    scale = 32 ** -0.5
+    lib, st = L.lib(), L.stream()
+    do_tok = bf(torch.randn(T, C, generator=g))
+    do_p = torch.zeros(Tw, C, dtype=torch.bfloat16)
+    do_p[real] = do_tok[rows[real]]
+    do_c = do_tok[rows[real]].contiguous()
+    # ---- classic
+    qp, dp = qkv_p.to(DEV), do_p.to(DEV)
+    out_p = torch.empty(Tw, C, dtype=torch.bfloat16, device=DEV)
+    lse_p = torch.empty(B * nW, nH, N, dtype=torch.float32, device=DEV)
+    L.check(lib.dgx_window_attention_fwd(L.ptr(qp), L.ptr(table), table.shape[1], 1, L.ptr(region), L.ptr(out_p), L.ptr(lse_p), B * nW,
+                                         nW, nH, ws, scale, st), "fwd")
+    dq_p, dt_p = torch.empty_like(qp), torch.zeros_like(table)
+    L.check(lib.dgx_window_attention_bwd(L.ptr(qp), L.ptr(table), L.ptr(region), L.ptr(out_p), L.ptr(lse_p), L.ptr(dp), L.ptr(dq_p),
+                                         L.ptr(dt_p), table.shape[1], 1, B * nW, nW, nH, ws, scale, st), "bwd")
+    # ---- compact
+    qc, dc, bd = qkv_c.to(DEV), do_c.to(DEV), bias.to(DEV)
+    out_c = torch.full((T, C), float("nan"), dtype=torch.bfloat16, device=DEV)
+    lse_c = torch.empty_like(lse_p)
+    L.check(lib.dgx_window_attention_fwd_compact(L.ptr(qc), L.ptr(bd), L.ptr(table), table.shape[1], 1, L.ptr(region), L.ptr(out_c),
+                                                 L.ptr(lse_c), B, H, W, nH, ws, shift, scale, st), "fwd_compact")
+    dq_c, dt_c = torch.full((Tw, 3 * C), float("nan"), dtype=torch.bfloat16, device=DEV), torch.zeros_like(table)
+    L.check(lib.dgx_window_attention_bwd_compact(L.ptr(qc), L.ptr(bd), L.ptr(table), L.ptr(region), L.ptr(out_c), L.ptr(lse_c), L.ptr(dc),
+                                                 L.ptr(dq_c), L.ptr(dt_c), table.shape[1], 1, B, H, W, nH, ws, shift, scale, st), "bwd_compact")
+    torch.cuda.synchronize()
+    realD = real.to(DEV)
+    assert torch.equal(out_c, out_p[realD]) and torch.equal(lse_c, lse_p)
+    assert torch.equal(dq_c[:T], dq_p[realD])
+    assert torch.equal(dq_c[T:], dq_p[~realD])                        # the padding tokens' rows, in their own classic order
+    if Tw > T:
+        assert float(dq_p[~realD][:, :C].float().abs().max()) == 0.0     # no gradient reaches a padding query ...
+        if H >= 2 * ws:      # (a padding key may sit in a shift region no real query of its window shares: then it gets none either)
+            assert float(dq_p[~realD][:, C:].float().abs().max()) > 0.0      # ... its key and value do get one (the qkv bias gradient)
+    assert torch.equal(dt_c, dt_p)
+
+
+@pytest.mark.parametrize("B,H,W,C,ws,shift", [(2, 30, 26, 192, 12, 6), (2, 30, 26, 192, 12, 0), (1, 13, 40, 96, 12, 6), (2, 10, 13, 64, 7, 3)])
+def test_layernorm_and_residual_epilogue_in_compact_window_order(B, H, W, C, ws, shift):
+    """The LayerNorm forward / backward (+ emit) and the proj GEMM's window-reverse epilogue with ws < 0 (compact window order) against
+    the same calls in classic order: the real rows are the classic rows without the padding ones, in order; results per token equal."""
+    from divergen_amd import _lib as L
+    from divergen_amd.layers import gemm_ops as G
+    g = torch.Generator().manual_seed(C + H)
+    rows = _classic_rows(B, H, W, ws, shift)
+    real = (rows >= 0).to(DEV)
+    T, Tw = B * H * W, rows.numel()
+    lib, st = L.lib(), L.stream()
+    x = torch.randn(T, C, generator=g).to(DEV)
+    gam, bet = (1 + 0.1 * torch.randn(C, generator=g)).to(DEV), (0.1 * torch.randn(C, generator=g)).to(DEV)
+    out = {}
+    for tag, wsm in (("p", ws), ("c", -ws)):
+        y = torch.full((Tw, C), float("nan"), dtype=torch.bfloat16, device=DEV)
+        mean, rstd = torch.empty(T, device=DEV), torch.empty(T, device=DEV)
+        L.check(lib.dgx_layernorm_fwd(L.ptr(x), L.ptr(gam), L.ptr(bet), L.ptr(y), L.ptr(mean), L.ptr(rstd), T, C, 1e-5, B, H, W, wsm, shift,
+                                      L.DGX_F32, st), "ln_fwd")
+        out[tag] = (y, mean, rstd)
+    yp, yc = out["p"][0], out["c"][0]
+    assert torch.equal(yc[:T], yp[real]) and float(yc[T:].float().abs().max() if Tw > T else 0.0) == 0.0
+    assert torch.equal(out["p"][1], out["c"][1]) and torch.equal(out["p"][2], out["c"][2])
+    # backward through the map (dy in window order) + emit in window order
+    dy_tok = bf(torch.randn(T, C, generator=g)).to(DEV)
+    rowsD = rows.to(DEV)
+    dy_p = torch.zeros(Tw, C, dtype=torch.bfloat16, device=DEV)
+    dy_p[real] = dy_tok[rowsD[real]]
+    dy_c = dy_tok[rowsD[real]].contiguous()
+    dres = torch.randn(T, C, generator=g).to(DEV)
+    scale = torch.tensor([0.5, 2.0, 1.5][:B], device=DEV)
+    res = {}
+    for tag, wsm, dy in (("p", ws, dy_p), ("c", -ws, dy_c)):
+        nblk = lib.dgx_layernorm_bwd_blocks(T)
+        part = torch.empty(nblk * 2 * C, device=DEV)
+        dx = torch.empty(T, C, device=DEV)
+        emit = torch.full((Tw if wsm > 0 else T, C), float("nan"), dtype=torch.bfloat16, device=DEV)
+        L.check(lib.dgx_layernorm_bwd_emit(L.ptr(dy), L.ptr(x), L.ptr(out["p"][1]), L.ptr(out["p"][2]), L.ptr(gam), L.ptr(dres), L.ptr(dx), None, None,
+                                           L.ptr(part), T, C, B, H, W, wsm, shift, L.DGX_F32, L.ptr(emit), L.ptr(scale), B, H, W, wsm, shift, st),
+                "ln_bwd_emit")
+        res[tag] = (dx, emit, part)
+    assert torch.equal(res["p"][0], res["c"][0]) and torch.equal(res["p"][2], res["c"][2])
+    assert torch.equal(res["c"][1], res["p"][1][real])
+    # proj epilogue: rows in window order -> token order + residual
+    a_tok = bf(torch.randn(T, 64, generator=g)).to(DEV)
+    a_p = torch.zeros(Tw, 64, dtype=torch.bfloat16, device=DEV)
+    a_p[real] = a_tok[rowsD[real]]
+    a_c = a_tok[rowsD[real]].contiguous()
+    wgt, bias = bf(torch.randn(C, 64, generator=g) * 0.1).to(DEV), bf(torch.randn(C, generator=g)).to(DEV)
+    resid = torch.randn(B, H * W, C, generator=g).to(DEV)
+    o_p = G.gemm_bias_residual(a_p, wgt, bias, resid, scale, B, H, W, ws, shift)
+    o_c = G.gemm_bias_residual(a_c, wgt, bias, resid, scale, B, H, W, -ws, shift)
+    assert torch.equal(o_p, o_c)
+
+
 @pytest.mark.parametrize("ws", [7, 12])
 def test_window_attention_vs_reference_golden(golden, ws):
     """Golden from the reference's own WindowAttention (fp32); kernel consumes its qkv in bf16."""

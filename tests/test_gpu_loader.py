@@ -149,3 +149,94 @@ def test_do_train_through_the_real_loader_checkpoints_and_resumes(tmp_path, monk
     assert float((opt2.arena.p - p_end).abs().max()) > 0                     # it trained on ...
     rows2 = [json.loads(line) for line in open(os.path.join(out, "metrics.json"))]
     assert rows2[-1]["iteration"] > rows[-1]["iteration"]
+
+
+def test_generation_factory_to_training_step_chain(tmp_path, monkeypatch):
+    """BASELINE config #5 end to end with stub networks: 'generated' images + two stub segmenters -> CLIP-style
+    scoring of the masked samples (factory.clip_scores_for_category, a deterministic stand-in for the network) -> best-mask selection
+    with score / area bars (factory.select_pool_entries = DG/filteration/clean_pool_if.py:157-213) -> largest-component crop written as
+    pre-processed '*' RGBA files (factory.crop_instance = clean_pool_if.py:47-84) -> merge with a second pool
+    (factory.merge_inst_pools = DG/tools/merge_inst_pool_json.py) -> shard store (data/pool_store.py) -> INPUT.INST_POOL_SHARDS ->
+    InstPool in loader workers -> GPU compositor -> one optimizer step of the registry-built model.  Asserted: every stage hands the
+    next what it expects, pasted instances in the batches carry exactly the factory's categories, the step's losses are finite."""
+    sys.path.insert(0, ROOT)
+    from PIL import Image
+    from divergen_amd.data import build as B
+    from divergen_amd.data import factory as F
+    from divergen_amd.data import pool_store as PS
+    from divergen_amd.engine import total_loss
+    from divergen_amd.modeling import build_model
+    from divergen_amd.solver import build_optimizer
+    from divergen_amd.utils.events import EventStorage
+    rng = np.random.default_rng(17)
+    cats = [{"id": 4, "name": "alarm_clock", "image_count": 3}, {"id": 11, "name": "apple", "image_count": 7}]
+    methods, n_samples, stage = ["sam", "u2net"], 4, "II"
+    img_dir, seg_dir = tmp_path / "gen", tmp_path / "seg"
+    yy, xx = np.mgrid[0:96, 0:80]
+    for c in cats:
+        (img_dir / stage / c["name"]).mkdir(parents=True)
+        for k in range(n_samples):
+            Image.fromarray(rng.integers(0, 256, (96, 80, 3), dtype=np.uint8)).save(img_dir / stage / c["name"] / ("%d_%07d.png" % (c["id"], k)))
+            for mi, m in enumerate(methods):          # two "segmenters": an ellipse each, the second one smaller and with a stray blob
+                (seg_dir / stage / m / c["name"]).mkdir(parents=True, exist_ok=True)
+                r = 30 - 12 * mi + k
+                mask = ((((xx - 40) / r) ** 2 + ((yy - 48) / (r + 6)) ** 2) <= 1).astype(np.uint8) * 255
+                if mi == 1:
+                    mask[2:6, 2:6] = 255
+                Image.fromarray(mask).save(seg_dir / stage / m / c["name"] / ("%d_%07d.png" % (c["id"], k)))
+
+    def score(images, text):                          # the stand-in for CLIP: deterministic in the masked pixels and the prompt
+        return images.double().mean(dim=(1, 2, 3)) * 10.0 + 20.0 + len(text) * 0.01
+    results = {m: [] for m in methods}
+    for m in methods:
+        for c in cats:
+            paths = [str(img_dir / stage / c["name"] / ("%d_%07d.png" % (c["id"], k))) for k in range(n_samples)]
+            mpaths = [str(seg_dir / stage / m / c["name"] / ("%d_%07d.png" % (c["id"], k))) for k in range(n_samples)]
+            idx, sc, ar = F.clip_scores_for_category(paths, c["name"], score, F.clip_preprocess, 2, 0, 1, mpaths)
+            assert idx == list(range(n_samples)) and len(sc) == len(ar) == n_samples
+            results[m].append(dict(c, clip_scores=sc, areas=ar))
+    selected = F.select_pool_entries([results[m] for m in methods], methods, str(img_dir), str(seg_dir), stage, min_clip=0.0, min_area=0.02,
+                                     max_area=0.9, tolerance=50.0)
+    assert set(selected) == {3, 10} and all(len(v) == n_samples for v in selected.values())
+    pool_a = {}
+    (tmp_path / "crops").mkdir()
+    for cid, entries in selected.items():
+        for j, e in enumerate(entries):
+            ip, mp_ = e.split("|")
+            crop = F.crop_instance(np.array(Image.open(ip).convert("RGBA")), np.array(Image.open(mp_)))
+            assert crop is not None and crop.shape[2] == 4 and crop.shape[0] < 96        # cropped to the (largest) component
+            out = tmp_path / "crops" / ("%d_%d.png" % (cid, j))
+            Image.fromarray(crop).save(out)
+            pool_a.setdefault(str(cid), []).append("*" + str(out))
+    from divergen_amd.data.synthetic import write_mini_lvis
+    info = write_mini_lvis(str(tmp_path / "data"), n_images=8, image_hw=(120, 160), n_obj=4, n_pool=6, pool_px=(40, 80), seed=9, poly_vertices=12)
+    pool_b = json.load(open(info["pool_json"]))
+    merged = F.merge_inst_pools([pool_a, pool_b])
+    assert set(pool_a) <= set(merged) and sum(len(v) for v in merged.values()) == 2 * n_samples + 6
+    json.dump(merged, open(tmp_path / "merged.json", "w"))
+    r = PS.build_shards(merged, str(tmp_path / "shards"))
+    assert r["records"] == 2 * n_samples + 6 and r["failed"] == []
+    cfg, _ = _mini_cfg(tmp_path / "cfgdata", 128, 2, ["INPUT.INST_POOL_PATH", str(tmp_path / "merged.json"), "INPUT.INST_POOL_SHARDS", str(tmp_path / "shards"),
+                                                      "INPUT.INST_POOL_MAX_SAMPLES", 12])
+    monkeypatch.setenv("DETECTRON2_DATASETS", info["root"])
+    loader = B.build_detection_train_loader(cfg, 2, "cuda", 5)
+    torch.manual_seed(3)
+    model = build_model(cfg).train()
+    model.early_proposal_backward = True
+    opt = build_optimizer(cfg, model)
+    factory_labels, pasted = {3, 10}, set()
+    with EventStorage(0):
+        for it in range(4):
+            batch = next(loader)
+            for d in batch:
+                src = d["instances"].instance_source.bool()
+                pasted |= set(d["instances"].gt_classes[src].tolist())
+                assert set(d["paste_labels"]) <= {int(k) for k in merged}
+            opt.zero_grad()
+            losses = model(batch)
+            total = total_loss(losses)
+            total.backward()
+            opt.step()
+            assert bool(torch.isfinite(total)), losses
+    torch.cuda.synchronize()
+    assert pasted & factory_labels, (pasted, "no instance of the factory's categories was pasted in 8 images")

@@ -333,6 +333,51 @@ def test_fused_swin_block_equals_composed_path(xdt, shift, monkeypatch):
     assert (ga - gb).abs().max() <= 2e-3 * gb.abs().max()
 
 
+@pytest.mark.parametrize("dim,nH,H,W", [(192, 6, 30, 26), (768, 24, 32, 32), (384, 12, 13, 40), (192, 6, 24, 24)])
+@pytest.mark.parametrize("shift", [0, 6])
+def test_swin_block_compact_equals_padded(dim, nH, H, W, shift, monkeypatch):
+    """layers/swin_block.COMPACT: the rows between LayerNorm-1 and proj without the padding tokens (csrc/winmap.h) against the
+    padded form of rounds 1-5 -- the reference's own layout (swintransformer.py:216-251).  Exact work removal: block output and input
+    gradient equal (bitwise unless the GEMM plan changes with M), every parameter gradient equal to fp32 summation order, the
+    relative-position table's included (its sum runs over the same (query, key) pairs: padding keys stay).  (24, 24) has no padding:
+    both settings are the same code path."""
+    from divergen_amd.layers import shift_regions
+    from divergen_amd.layers import swin_block as SB
+    from divergen_amd.modeling.backbone import swintransformer as S
+    from divergen_amd.solver import FlatArena
+    torch.manual_seed(5)
+    ws, B = 12, 2
+    blk = S.SwinTransformerBlock(dim, nH, window_size=ws, shift_size=shift, drop_path=0.2).to(DEV).train()
+    for p in blk.parameters():
+        torch.nn.init.normal_(p, std=0.05)
+    blk.H, blk.W = H, W
+    arena = FlatArena(blk)
+    region = shift_regions(H, W, ws).to(DEV) if shift else None
+    x0 = torch.randn(B, H * W, dim, device=DEV).bfloat16()
+    go = torch.randn(B, H * W, dim, device=DEV).bfloat16()
+    res = {}
+    for compact in (True, False):
+        monkeypatch.setattr(SB, "COMPACT", compact)
+        assert SB.compact_ok(H, W, ws, shift) == (compact and (H % ws != 0 or W % ws != 0))
+        arena.zero_grad()
+        torch.manual_seed(11)           # same DropPath draw
+        x = x0.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = blk(x, region)
+        y.backward(go)
+        SB.flush_wgrads()
+        torch.cuda.synchronize()
+        res[compact] = (y.detach().clone(), x.grad.clone(), arena.g.clone())
+    (yc, dxc, gc), (yp, dxp, gp) = res[True], res[False]
+    assert float(yp.float().abs().max()) > 0 and float(gp.abs().max()) > 0
+    assert torch.equal(yc, yp) or float((yc.float() - yp.float()).abs().max()) <= 8e-3 * float(yp.float().abs().max())
+    assert torch.equal(dxc, dxp) or float((dxc.float() - dxp.float()).abs().max()) <= 8e-3 * float(dxp.float().abs().max())
+    assert float((gc - gp).abs().max()) <= 2e-3 * float(gp.abs().max())
+    for name, o, z in zip(arena.names, arena.offsets, arena.sizes):          # per parameter too (the qkv bias and the table are small ones)
+        a, b_ = gc[o:o + z].double(), gp[o:o + z].double()
+        assert float((a - b_).norm()) <= 2e-3 * float(b_.norm()) + 1e-7, name
+
+
 def test_swin_blocks_weight_gradients_loader_wave_group(monkeypatch):
     """Three Swin blocks of width 768 whose weight gradients are queued for ONE launch of the persistent loader-wave kernel
     (layers/swin_block.py::_defer_wgrads -> csrc/wgrad_lw.hip; 3 x 144 tiles = 0.84 of two rounds of the chip) against the same blocks

@@ -108,6 +108,24 @@ def test_sam_background_prompting_helpers():
     assert F.check_point_in_foreground((0, 1), att, 0.5) and not F.check_point_in_foreground((1, 0), att, 0.5)
 
 
+def test_select_pool_entries_matches_the_reference_script():
+    """tests/golden/factory.json 'select': the selection DG/filteration/clean_pool_if.py:157-213 hands to its cropping pool, produced by
+    running the script itself (make_golden_factory.py::gen_select: `enable_split = False` supplied to the namespace its parser forgets
+    to define, the cv2 cropping pool replaced by a recorder) on three segmentation methods whose results.json files are in different
+    orders, with and without the similarity csv, three threshold sets."""
+    g = G["select"]
+    for case in g["cases"]:
+        keep = None
+        if case["csv"] is not None:
+            keep = {}
+            for cat, fn in case["csv"]:
+                keep.setdefault(cat, set()).add(fn)
+        got = F.select_pool_entries([g["results"][m] for m in g["methods"]], g["methods"], "/img", "$D/seg", "II", min_clip=case["min_clip"],
+                                    min_area=case["min_area"], max_area=case["max_area"], tolerance=case["tolerance"], keep_names=keep)
+        assert {str(k): v for k, v in got.items()} == case["selected"], case
+    assert sum(len(v) for c in g["cases"] for v in c["selected"].values()) >= 15
+
+
 def test_select_pool_entries_hand_worked():
     """clean_pool_if.py:157-213 on two segmentation methods: per image the method with the higher CLIP score; bar = min(min_clip,
     best score of the category - tolerance); area window; csv filter."""

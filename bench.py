@@ -109,7 +109,7 @@ def make_pastes(rng, size, k=19):
 #   r03_pmc.json                              HBM bytes per launch / per step of each kernel family from rocprofv3 --pmc passes over
 #                                             THIS script, timed steps only (tools/pmc_summary.py)
 #   r03_bench_swinL_1024_kernel_stats.csv     rocprofv3 --kernel-trace --stats of THIS script (+ r03_profile_meta.json: steps)
-PROFILE_TAG = "r05"
+PROFILE_TAG = "r06"
 FAMILY_KERNELS = {   # family -> substrings of the kernel names rocprof reports for it
     "gemm_nt": ("gemm_nt_kernel", "gemm_lw_kernel", "gemm_k192_kernel", "gemm_splitk_fold_kernel"),
     "wgrad": ("wgrad256_partial_kernel", "wgrad256_reduce_kernel", "wgrad256_bias_reduce_kernel", "wgrad_partial_kernel", "wgrad_reduce_kernel", "wgrad_lw_kernel"),

@@ -628,8 +628,6 @@ def _worker_init(worker_id, base_seed, in_worker=True):
     torch.manual_seed(seed)
     if in_worker:
         torch.set_num_threads(1)      # 16 workers per GPU: one core each
-        if DEV["nice"]:
-            os.nice(int(DEV["nice"]))
 
 
 def _tensors_of(obj):
@@ -712,7 +710,7 @@ class BatchAhead:
 # throttled the whole cgroup, and the training thread's host time per step DOUBLED (profiles/r06_loader_ab.txt: 57.0 ms/step with the
 # default pool, 28.5 with 4 threads, same workers, same batches; 25.2 with the same batches and no loader running).  The training
 # process has no CPU tensor work of its own besides those copies.  bench.py --loader-dev main_threads=N overrides (0 = leave alone).
-DEV = {"pin": "loader", "strategy": None, "main_threads": 4, "nice": 0, "switch_us": 0}
+DEV = {"pin": "loader", "strategy": None, "main_threads": 4}
 
 
 def build_detection_train_loader(cfg, per_gpu, device, seed):
@@ -741,9 +739,6 @@ def build_detection_train_loader(cfg, per_gpu, device, seed):
         torch.set_num_threads(min(torch.get_num_threads(), int(DEV["main_threads"])))
     if DEV["pin"] != "loader":
         on_gpu = False
-    if DEV["switch_us"]:
-        import sys
-        sys.setswitchinterval(int(DEV["switch_us"]) * 1e-6)
     loader = torch.utils.data.DataLoader(
         _MapDataset(dicts, mapper), sampler=sampler, batch_size=per_gpu, drop_last=True, num_workers=nw, collate_fn=_identity,
         worker_init_fn=functools.partial(_worker_init, base_seed=rank_seed), pin_memory=on_gpu,

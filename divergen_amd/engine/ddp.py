@@ -16,7 +16,10 @@ xGMI is point-to-point, so a ring all-reduce is bound by one ~153 GB/s link: buc
 parameter, but the layers that write their weight gradient straight into the arena signal once per USE, and a weight
 shared by several call sites (the CenterNet tower over five FPN levels) is used several times per step.  The reducer
 therefore learns the number of signals per parameter from the first step (during which nothing is launched early) and
-afterwards counts a parameter as ready at its last expected signal.  Fewer signals than learned (a hipGraph replay
+afterwards counts a parameter as ready at its last expected signal.  The counts depend on HOW the hipGraph segments ran in a step
+(a replayed segment signals each parameter once behind the replay, an eagerly issued one once per use; a segment runs eagerly on
+the first sight of a batch size and on sizes beyond utils.graphs.MAX_GRAPHS), so one count vector is learned per combination of
+segment modes (layers.linear_ops.SEGMENT_MODES), each in a step of its own without early launches.  Fewer signals than learned (a hipGraph replay
 produces none, a branch not taken) only defer the bucket to `finish()`; MORE signals than learned would mean a bucket
 could have left before its gradients were complete, and `finish()` raises."""
 import os
@@ -59,7 +62,9 @@ class ArenaReducer:
         self._next = 0                 # buckets are launched strictly in index order (same order on every rank)
         self.last_early = 0
         self._got = [0] * n            # ready signals of this step, per parameter
-        self._expected = None          # learned from the first step; None = calibrating (no early launches)
+        self._learned = {}             # segment-mode combination -> learned signal counts
+        self._expected = None          # this step's counts; None = calibrating (no early launches)
+        self._mode_key = None          # taken at the step's first signal (every segment has run its forward by then)
         # single_rank_group: reduce over a one-rank group as well (bench.py --force-pg: RCCL next to hipGraph capture on one GPU)
         self.active = self.world > 1 or (dist.is_initialized() and single_rank_group)
         self.reserved_cus = 0
@@ -109,6 +114,9 @@ class ArenaReducer:
         def hook(_param):
             if linear_ops._READY_SUSPENDED[0]:     # trial backward passes (hipGraph capture warm-ups, BSGAL's selection) are not
                 return                             # part of the training step: nothing to count, nothing to reduce
+            if self._mode_key is None:
+                self._mode_key = tuple(sorted(linear_ops.SEGMENT_MODES.items()))
+                self._expected = self._learned.get(self._mode_key)
             self._got[i] += 1
             if self._expected is not None and self._got[i] == self._expected[i]:
                 self._pending[b] -= 1
@@ -168,14 +176,18 @@ class ArenaReducer:
         if self._cus_on:
             self._reserve(False)
         if self.active:
+            if self._mode_key is None:
+                self._mode_key = tuple(sorted(linear_ops.SEGMENT_MODES.items()))
+                self._expected = self._learned.get(self._mode_key)
             if self._expected is None:
-                self._expected = list(self._got)
+                self._learned[self._mode_key] = list(self._got)
             else:
                 late = [self.arena.names[i] for i, (g, e) in enumerate(zip(self._got, self._expected)) if e > 0 and g > e]
                 if late:
                     raise RuntimeError("ArenaReducer: parameters signalled 'gradient ready' more often than in the first step "
                                        "(%s ...): their bucket may have been reduced before the last write" % ", ".join(late[:4]))
         self._got = [0] * len(self._got)
+        self._mode_key = self._expected = None
         self._ready = [False] * len(self.buckets)
         self._next = 0
         self._pending = [b[2] for b in self.buckets]

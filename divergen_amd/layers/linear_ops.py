@@ -66,6 +66,10 @@ def wgrad_grouped(problems, beta=1.0):
 
 
 _READY_SUSPENDED = [False]
+# How each hipGraph segment ran in the current step ('g' replayed / captured, 'e' issued eagerly), by segment: a replayed segment signals
+# its parameters once each behind the replay, an eager one once per use from its own autograd nodes -- the data-parallel reducer counts
+# signals per parameter and keeps one learned count vector PER COMBINATION of modes (engine/ddp.py)
+SEGMENT_MODES = {}
 
 
 class suspend_ready:

@@ -79,12 +79,15 @@ class GraphedSegment:
         """True when this call replays (or now captures) a graph; False = run the segment eagerly."""
         if not (ENABLED and torch.is_grad_enabled() and all(t.is_cuda for t in inputs)
                 and not torch.cuda.is_current_stream_capturing()):
+            linear_ops.SEGMENT_MODES[id(self)] = "e"
             return False
         key = self._key(inputs)
-        if key in self._fns:
-            return True
-        n = self._seen[key] = self._seen.get(key, 0) + 1
-        return n >= CAPTURE_AFTER and len(self._fns) < MAX_GRAPHS
+        ok = key in self._fns
+        if not ok:
+            n = self._seen[key] = self._seen.get(key, 0) + 1
+            ok = n >= CAPTURE_AFTER and len(self._fns) < MAX_GRAPHS
+        linear_ops.SEGMENT_MODES[id(self)] = "g" if ok else "e"
+        return ok
 
     def __call__(self, *inputs):
         key = self._key(inputs)

@@ -33,7 +33,7 @@ def _build(swin, size):
     return cfg, model, build_optimizer(cfg, model)
 
 
-def _run(with_reducer, steps=3, swin="L-22k-384", size=1024, weights_in=None, early=True):
+def _run(with_reducer, steps=4, swin="L-22k-384", size=1024, weights_in=None, early=True):
     import torch.distributed as dist
     from divergen_amd import _lib as L
     from divergen_amd.data import synthetic_batch
@@ -129,8 +129,9 @@ def test_one_rank_rccl_group_trains_like_no_reducer(early):
         diff = (a != b) & ~table
         assert not bool(diff.any()), (it, int(diff.sum()), float((a - b).abs().max()))
         assert float((a - b)[table].abs().max()) <= 1e-5 * float(a[table].abs().max()) + 1e-9
-    # ---- every bucket behind the last weight-gradient launch into its slice: steps 2 and 3 (the first step only learns the counts)
-    for it in (1, 2):
+    # ---- every bucket behind the last weight-gradient launch into its slice: steps 3 and 4 (step 1 runs the hipGraph segments eagerly and
+    # learns the signal counts of that mode, step 2 captures them and learns the counts of the replayed mode: neither launches early)
+    for it in (2, 3):
         log, early = log1[it]
         buckets = [e for e in log if e[0] == "b"]
         writes = [e for e in log if e[0] == "w"]

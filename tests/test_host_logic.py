@@ -176,7 +176,7 @@ def _ddp_shared_worker(rank, world, port, q):
         y.sum().backward()
         scale = red.finish()
         out.append((ar.g.clone() * scale).numpy().copy())
-    q.put((rank, ar.p.numpy().copy(), out, list(red._expected)))
+    q.put((rank, ar.p.numpy().copy(), out, list(red._learned[()])))      # no hipGraph segments on the CPU: one mode combination
     dist.destroy_process_group()
 
 

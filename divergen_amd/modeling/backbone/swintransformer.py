@@ -160,6 +160,47 @@ class PatchMerging(nn.Module):
         return self.reduction(patch_merge_layernorm(x, self.norm.weight, self.norm.bias, self.norm.eps, B, H, W))
 
 
+# The blocks of a stage replayed as hipGraph pairs (round 6).  A Swin block is ~10 launches forward and ~14 backward through one autograd
+# node; 24 blocks are ~560 of the step's ~820 launches and ~14 ms of host time -- the Swin-T step is host-bound outright (14.4 ms against
+# ~9 of GPU work) and the Swin-L step is host-PACED (host issue = step time within 0.3 ms), so anything that takes CPU from the training
+# thread (the loader's pin thread and workers) lengthens it.  The blocks' shapes depend only on (B, H, W): groups of <= GRAPH_GROUP blocks
+# (+ the stage's PatchMerging) are captured with utils.graphs.GraphedSegment like the FPN and the CenterNet tower; the DropPath factors of
+# a step are a graph INPUT.  Several groups per stage rather than one graph for the backbone: a group's parameters are signalled to the
+# data-parallel reducer behind ITS backward replay, so the all-reduce still overlaps the rest of backward.
+GRAPH_BLOCKS = True
+GRAPH_GROUP = 6
+
+
+class _BlockGroup(nn.Module):
+    """blocks[a:b] of a BasicLayer (+ its downsample when it ends the stage), tensors in / tuple out: the captured unit."""
+
+    def __init__(self, layer, a, b, with_down):
+        super().__init__()
+        self.__dict__["layer"] = layer          # not a registered child: the BasicLayer owns the parameters
+        self.a, self.b, self.with_down, self.amp = a, b, with_down, False
+        self.hw = None
+
+    def parameters(self, recurse=True):
+        layer = self.__dict__["layer"]
+        for blk in layer.blocks[self.a:self.b]:
+            yield from blk.parameters()
+        if self.with_down:
+            yield from layer.downsample.parameters()
+
+    def forward(self, x, scales):
+        layer = self.__dict__["layer"]
+        H, W = self.hw
+        region = layer._region(H, W, x.device)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.amp, cache_enabled=False):
+            for k, blk in enumerate(layer.blocks[self.a:self.b]):
+                blk.H, blk.W = H, W
+                blk.__dict__["_dp_scales"] = scales[k]        # (2, B): this step's DropPath factors (ignored by a block without DropPath)
+                x = blk(x, region)
+            if self.with_down:
+                return x, layer.downsample(x, H, W)
+        return (x,)
+
+
 class BasicLayer(nn.Module):
     def __init__(self, dim, depth, num_heads, window_size=7, mlp_ratio=4.0, qkv_bias=True, qk_scale=None,
                  drop_path=0.0, downsample=None, use_checkpoint=False):
@@ -178,7 +219,48 @@ class BasicLayer(nn.Module):
             self._regions[key] = shift_regions(H, W, self.window_size).to(device)
         return self._regions[key]
 
+    def _groups(self):
+        g = self.__dict__.get("_graph_groups")
+        if g is None:
+            from ...utils.graphs import GraphedSegment
+            cuts = list(range(0, self.depth, GRAPH_GROUP)) + [self.depth]
+            g = self.__dict__["_graph_groups"] = []
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                mod = _BlockGroup(self, a, b, self.downsample is not None and b == self.depth)
+                g.append((mod, GraphedSegment(mod)))
+        return g
+
+    def _graphable(self, x):
+        if not (GRAPH_BLOCKS and _FUSED_BLOCK and self.training and torch.is_grad_enabled() and x.is_cuda and x.requires_grad
+                and not self.use_checkpoint):
+            return False
+        sc = self.__dict__.get("_dp_stage")
+        if sc is None or sc.shape[2] != x.shape[0] or sc.device != x.device:
+            return False
+        if not self.__dict__.get("_arena_ok"):          # (checked until it holds: the optimizer builds the arena after the model)
+            params = [p for blk in self.blocks for n, p in blk.named_parameters()] + \
+                ([p for p in self.downsample.parameters()] if self.downsample is not None else [])
+            if not arena_resident(tuple(params)):
+                return False
+            self.__dict__["_arena_ok"] = True
+        return True
+
     def forward(self, x, H, W):
+        if self._graphable(x):
+            scales, down = self.__dict__["_dp_stage"], None           # (depth, 2, B) this step's DropPath factors of the stage
+            for mod, seg in self._groups():
+                sc = scales[mod.a:mod.b]
+                mod.hw = (H, W)
+                if seg.usable((x, sc), tag=(H, W)):
+                    out = seg(x, sc, tag=(H, W))
+                else:
+                    out = mod(x, sc)
+                x = out[0]
+                if mod.with_down:
+                    down = out[1]
+            if self.downsample is not None:
+                return x, H, W, down, (H + 1) // 2, (W + 1) // 2
+            return x, H, W, x, H, W
         region = self._region(H, W, x.device)
         for blk in self.blocks:
             blk.H, blk.W = H, W
@@ -268,7 +350,16 @@ class SwinTransformer(Backbone):
         of 4 per block); same per-sample Bernoulli(keep_i) law as timm's drop_path at each of the 2 call sites."""
         blocks = [blk for layer in self.layers for blk in layer.blocks]
         probs = [blk.drop_path.drop_prob if isinstance(blk.drop_path, DropPath) else 0.0 for blk in blocks]
-        if not self.training or not any(probs):
+        if not self.training:
+            return
+        if not any(probs):                             # no DropPath anywhere: the graphed block groups still take a factor tensor (ones)
+            ones = self.__dict__.get("_dp_ones")
+            if ones is None or ones.shape[2] != B or ones.device != device:
+                ones = self.__dict__["_dp_ones"] = torch.ones(len(blocks), 2, B, device=device, dtype=torch.float32)
+            i0 = 0
+            for layer in self.layers:
+                layer.__dict__["_dp_stage"] = ones[i0:i0 + layer.depth]
+                i0 += layer.depth
             return
         keep = getattr(self, "_dp_keep", None)
         if keep is None or keep.device != device:
@@ -277,6 +368,10 @@ class SwinTransformer(Backbone):
         for i, blk in enumerate(blocks):
             if probs[i] > 0:
                 blk.__dict__["_dp_scales"] = s[i]
+        i0 = 0
+        for layer in self.layers:                      # the stage's slice: the input of its graphed block groups
+            layer.__dict__["_dp_stage"] = s[i0:i0 + layer.depth]
+            i0 += layer.depth
 
     def forward(self, x):
         self._draw_drop_path(x.shape[0], x.device)

@@ -72,16 +72,17 @@ class GraphedSegment:
         self._seen = {}
 
     @staticmethod
-    def _key(inputs):
-        return tuple((tuple(t.shape), t.dtype, t.requires_grad, tuple(t.stride())) for t in inputs) + (torch.is_autocast_enabled(),)
+    def _key(inputs, tag=None):
+        return tuple((tuple(t.shape), t.dtype, t.requires_grad, tuple(t.stride())) for t in inputs) + (torch.is_autocast_enabled(), tag)
 
-    def usable(self, inputs):
-        """True when this call replays (or now captures) a graph; False = run the segment eagerly."""
+    def usable(self, inputs, tag=None):
+        """True when this call replays (or now captures) a graph; False = run the segment eagerly.  `tag`: whatever else the
+        segment's launch shapes depend on (the (H, W) of a token grid that arrives flattened)."""
         if not (ENABLED and torch.is_grad_enabled() and all(t.is_cuda for t in inputs)
                 and not torch.cuda.is_current_stream_capturing()):
             linear_ops.SEGMENT_MODES[id(self)] = "e"
             return False
-        key = self._key(inputs)
+        key = self._key(inputs, tag)
         ok = key in self._fns
         if not ok:
             n = self._seen[key] = self._seen.get(key, 0) + 1
@@ -89,8 +90,8 @@ class GraphedSegment:
         linear_ops.SEGMENT_MODES[id(self)] = "g" if ok else "e"
         return ok
 
-    def __call__(self, *inputs):
-        key = self._key(inputs)
+    def __call__(self, *inputs, tag=None):
+        key = self._key(inputs, tag)
         fn = self._fns.get(key)
         if fn is None:
             self.module.amp = torch.is_autocast_enabled()

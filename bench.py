@@ -34,7 +34,7 @@ def parse():
     p.add_argument("--batch", type=int, default=2, help="images per GPU (IMS_PER_BATCH 16 / 8 GPUs)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-roofline", action="store_true", help="leave the per-launch HIP events off (A/B of their cost)")
-    p.add_argument("--roofline-every", type=int, default=10, help="instrument every n-th timed step with per-launch HIP events")
+    p.add_argument("--roofline-steps", type=int, default=4, help="steps re-run behind the timed region with per-launch HIP events (roofline objects)")
     p.add_argument("--no-copy-paste", action="store_true")
     p.add_argument("--copy-sources", action="store_true", help="development: list the ops of one step that end in device copies / fills (stderr)")
     p.add_argument("--inputs-resident", action="store_true",
@@ -524,21 +524,31 @@ def main():
         for k_ in host:
             host[k_] = 0.0
         throttle0 = _cgroup_throttled()
-        sampled = 0
         t0 = time.perf_counter()
         for k in range(a.steps):
-            # two event records per heavy launch cost the host ~10 us (measured: +3.5 ms on a 41 ms step when every step is
-            # instrumented, which would make the step host-bound): every `roofline_every`-th step of the timed region carries them
-            on = not a.no_roofline and k % a.roofline_every == 0
-            if on:
-                prof.pause(False)
-                sampled += 1
             total = one_step()
-            if on:
-                prof.pause(True)
         t_issue = time.perf_counter() - t0     # host time to ENQUEUE the steps (diagnostic: CPU- vs GPU-bound)
         sync()
         dt = time.perf_counter() - t0
+        # Per-launch HIP events for the roofline objects.  Since round 6 the Swin blocks are replayed from hipGraphs, and a replayed launch
+        # cannot carry events; the two records per heavy launch also cost the host ~10 us each.  The SAME steps (same weights' shapes, same
+        # batches in rotation, same kernels and grids) are therefore issued `roofline_steps` more times right behind the timed region with
+        # the block groups issued eagerly and the events on; the committed rocprofv3 CSV of the plain command (every dispatch of the timed
+        # steps, replayed ones included) cross-checks the family times (`profile` in each object).
+        sampled = 0
+        if not a.no_roofline:
+            from divergen_amd.modeling.backbone import swintransformer as _S
+            keep_graphs = _S.GRAPH_BLOCKS
+            _S.GRAPH_BLOCKS = False
+            one_step()                         # (the first eager step after replays: allocator warm-up, not sampled)
+            sync()
+            prof.pause(False)
+            for k in range(a.roofline_steps):
+                one_step()
+                sampled += 1
+            sync()
+            prof.pause(True)
+            _S.GRAPH_BLOCKS = keep_graphs
     stats = prof.read() if not a.no_roofline else {}
     prof.enable(False)
     assert bool(torch.isfinite(total)), "non-finite loss"

@@ -20,6 +20,7 @@ import torch.nn.functional as F
 from .. import BACKBONE_REGISTRY, ShapeSpec
 from ...layers.conv_ops import patch_embed4x4, patch_embed_rows
 from ...structures import PatchRows
+from ...layers import linear_ops
 from ...layers.linear_ops import GELU, Linear
 from ...layers.norm_ops import layernorm_bf16, layernorm_f32out, layernorm_window_gather, patch_merge_layernorm, residual_add
 from ...layers import shift_regions, window_attention_core
@@ -261,6 +262,8 @@ class BasicLayer(nn.Module):
             if self.downsample is not None:
                 return x, H, W, down, (H + 1) // 2, (W + 1) // 2
             return x, H, W, x, H, W
+        for _, seg in self.__dict__.get("_graph_groups") or ():      # issued eagerly this time: the reducer's signal counts depend on it
+            linear_ops.SEGMENT_MODES[id(seg)] = "e"
         region = self._region(H, W, x.device)
         for blk in self.blocks:
             blk.H, blk.W = H, W

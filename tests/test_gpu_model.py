@@ -564,7 +564,12 @@ def test_first_writer_gradients_train_like_zero_filled_ones(monkeypatch):
     lazy run really skipped segments."""
     from divergen_amd import solver
     from divergen_amd.data import synthetic_batch
+    from divergen_amd.modeling.backbone import swintransformer as S
     from divergen_amd.utils.events import EventStorage
+    # (the protocol lives in the eagerly issued blocks -- what every batch size beyond graphs.MAX_GRAPHS runs as; a replayed block group
+    # was captured accumulating, beta = 1, and its segments are zero-filled like everything else: a captured launch cannot ask whether it
+    # is the first writer of the pass)
+    monkeypatch.setattr(S, "GRAPH_BLOCKS", False)
 
     def run(lazy):
         monkeypatch.setattr(solver, "_LAZY_ZERO", lazy)

@@ -67,6 +67,9 @@ class ColsumProblem(ctypes.Structure):
 SIGNATURES = {
     "dgx_build_arch": (ctypes.c_char_p, []),
     "dgx_abi_version": (c_i, []),
+    "dgx_host_register": (c_i, [c_p, ctypes.c_size_t]),
+    "dgx_host_unregister": (c_i, [c_p]),
+    "dgx_memcpy_h2d_async": (c_i, [c_p, c_p, ctypes.c_size_t, c_p]),
     "dgx_window_attention_fwd": (c_i, [c_p, c_p, c_i64, c_i64, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p]),
     "dgx_window_attention_bwd": (c_i, [c_p] * 8 + [c_i64, c_i64, c_i, c_i, c_i, c_i, c_f, c_p]),
     "dgx_window_attention_fwd_compact": (c_i, [c_p, c_p, c_p, c_i64, c_i64, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p]),

@@ -465,6 +465,7 @@ class CopyPasteMapper:
         self.inst_pool = None
         self.dataset = None
         self.pack = True               # one blob per sample across the process boundary (pack_sample); the loader's finish() unpacks
+        self.ring = None               # SlotRing the workers wrote the blobs into (build_detection_train_loader)
         if self.method not in ("none", "syn_copy"):
             raise NotImplementedError("INPUT.USE_COPY_METHOD '{}': only 'syn_copy' / 'none' (the shipped configs) are built".format(self.method))
         if cfg.INPUT.INST_POOL and self.method == "syn_copy":
@@ -536,7 +537,7 @@ class CopyPasteMapper:
         input: the compositor writes a copy)."""
         from .copypaste import InstPool
         dev = torch.device(device)
-        result = unpack_sample(result, dev)
+        result = unpack_sample(result, dev, self.ring)
         if "instances" not in result:
             result["image"] = result["image"].to(dev, non_blocking=True)
             return result
@@ -590,12 +591,18 @@ def pack_sample(d):
     return out
 
 
-def unpack_sample(d, device):
-    """Training-process side: d['blob'] goes to `device` in ONE (asynchronous, when pinned) copy; image / instances / paste_pack come back
-    as views of it."""
+def unpack_sample(d, device, ring=None):
+    """Training-process side: d['blob'] (or the slot of the page-locked ring it was written into) goes to `device` in ONE asynchronous
+    copy; image / instances / paste_pack come back as views of it."""
     if "blob" not in d:
         return d
-    blob = d["blob"].to(device, non_blocking=True)
+    if d.get("blob_slot") is not None:
+        from .. import _lib as L
+        off, n = d["blob_slot"]
+        blob = torch.empty(n, dtype=torch.uint8, device=device)
+        L.check(L.lib().dgx_memcpy_h2d_async(blob.data_ptr(), ring.buf.data_ptr() + off, n, L.stream()), "dgx_memcpy_h2d_async")
+    else:
+        blob = d["blob"].to(device, non_blocking=True)
     f = {}
     for name, dt, shape, off in d["blob_layout"]:
         dtype = getattr(torch, dt)
@@ -609,6 +616,68 @@ def unpack_sample(d, device):
     out["instances"] = inst
     out["paste_pack"] = {"flat": f["flat"], "desc": f["desc"], "labels": f["labels"], "K": d["blob_K"]}
     return out
+
+
+class SlotRing:
+    """Page-locked shared memory the loader workers write their sample blobs into (round 6).
+
+    torch's DataLoader pins in a THREAD of the training process: per batch it unpickles the tensors (one authenticated socket round
+    trip per shared-memory segment, Python under the GIL), allocates pinned memory and copies.  With the Swin blocks replayed as
+    graphs the step's only host-bound stretch is the RoI heads behind the proposal sampler's device->host read, and every time that
+    thread takes the GIL there the GPU waits: +1.9 ms per step measured (27.6 against 25.7 ms).  Here ONE region is allocated in shared
+    memory before the workers fork and page-locked once (dgx_host_register); worker w owns slots [w * per_worker, (w + 1) * per_worker)
+    and writes its k-th sample into slot k % per_worker; the training process receives (offset, bytes) and uploads straight from the
+    slot (dgx_memcpy_h2d_async) -- no pin thread, no per-batch allocation, nothing but a few integers crosses the queue.
+    Reuse is safe by the DataLoader's own bookkeeping: a worker holds at most `prefetch_factor` batches that the training process has
+    not consumed, so with (prefetch_factor + 2) batches of slots a slot is rewritten no earlier than two further batches of that worker
+    have been consumed -- 2 x num_workers steps after its upload was issued."""
+
+    def __init__(self, num_workers, per_worker, slot_bytes):
+        from .. import _lib as L
+        self.num_workers, self.per_worker, self.slot_bytes = int(num_workers), int(per_worker), (int(slot_bytes) + 4095) // 4096 * 4096
+        n = self.num_workers * self.per_worker * self.slot_bytes
+        st = os.statvfs("/dev/shm") if os.path.isdir("/dev/shm") else None
+        if st is not None and st.f_bavail * st.f_frsize < n + (1 << 30):
+            raise MemoryError("SlotRing: /dev/shm has %.1f GB free, %.1f GB needed" % (st.f_bavail * st.f_frsize / 1e9, n / 1e9))
+        self.buf = torch.empty(n, dtype=torch.uint8).share_memory_()
+        L.check(L.lib().dgx_host_register(self.buf.data_ptr(), n), "dgx_host_register")
+        self._registered, self._pid = True, os.getpid()
+
+    def offset(self, worker, k):
+        return (worker * self.per_worker + k % self.per_worker) * self.slot_bytes
+
+    def close(self):
+        if self.__dict__.get("_registered") and self.__dict__.get("_pid") == os.getpid():      # (never from a forked worker)
+            from .. import _lib as L
+            L.lib().dgx_host_unregister(self.buf.data_ptr())
+            self._registered = False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class _RingCollate:
+    """collate_fn (runs in the WORKER): the samples' blobs into this worker's next slots; what is returned carries (offset, bytes)."""
+
+    def __init__(self, ring):
+        self.ring, self.k = ring, 0
+
+    def __call__(self, batch):
+        info = torch.utils.data.get_worker_info()
+        if info is None or self.ring is None:
+            return batch
+        for d in batch:
+            blob = d.get("blob")
+            if blob is None or blob.numel() > self.ring.slot_bytes:      # an image with more ground truth than a slot holds: the ordinary way
+                continue
+            off, n = self.ring.offset(info.id, self.k), int(blob.numel())
+            self.k += 1
+            self.ring.buf[off:off + n].copy_(blob)
+            d["blob"], d["blob_slot"] = None, (off, n)
+        return batch
 
 
 class _MapDataset(torch.utils.data.Dataset):
@@ -710,14 +779,14 @@ class BatchAhead:
 # throttled the whole cgroup, and the training thread's host time per step DOUBLED (profiles/r06_loader_ab.txt: 57.0 ms/step with the
 # default pool, 28.5 with 4 threads, same workers, same batches; 25.2 with the same batches and no loader running).  The training
 # process has no CPU tensor work of its own besides those copies.  bench.py --loader-dev main_threads=N overrides (0 = leave alone).
-DEV = {"pin": "loader", "strategy": None, "main_threads": 4}
+DEV = {"pin": "ring", "strategy": None, "main_threads": 4}      # pin: "ring" (SlotRing) | "loader" (the DataLoader's pin thread) | "none"
 
 
 def build_detection_train_loader(cfg, per_gpu, device, seed):
     """DG/train_net.py:164-239 + D2/data/build.py:build_detection_train_loader: dataset dicts, sampler by
-    DATALOADER.SAMPLER_TRAIN, the whole mapper (copy-paste preparation included) in DATALOADER.NUM_WORKERS worker processes,
-    results pinned by the loader's pin thread; the training process only uploads and runs the compositor kernel, one batch
-    ahead on a side stream (BatchAhead)."""
+    DATALOADER.SAMPLER_TRAIN, the whole mapper (copy-paste preparation included) in DATALOADER.NUM_WORKERS worker processes, each
+    sample written by its worker into a slot of a page-locked shared-memory ring (SlotRing; the DataLoader's pin thread when the ring
+    cannot be had); the training process only uploads and runs the compositor kernel, one batch ahead on a side stream (BatchAhead)."""
     import functools
     dicts = get_detection_dataset_dicts(cfg.DATASETS.TRAIN, filter_empty=cfg.DATALOADER.FILTER_EMPTY_ANNOTATIONS)
     name = cfg.DATALOADER.SAMPLER_TRAIN
@@ -737,11 +806,20 @@ def build_detection_train_loader(cfg, per_gpu, device, seed):
         torch.multiprocessing.set_sharing_strategy(DEV["strategy"])
     if DEV["main_threads"] and on_gpu and nw > 0:
         torch.set_num_threads(min(torch.get_num_threads(), int(DEV["main_threads"])))
-    if DEV["pin"] != "loader":
-        on_gpu = False
+    pin_thread, ring = on_gpu and DEV["pin"] == "loader", None
+    if on_gpu and nw > 0 and DEV["pin"] == "ring":
+        # one slot holds an image with up to ~45 ground-truth masks at TRAIN_SIZE^2 (more: that sample takes the ordinary way)
+        size = int(cfg.INPUT.TRAIN_SIZE)
+        try:
+            ring = SlotRing(nw, (int(cfg.DATALOADER.PREFETCH_FACTOR) + 2) * per_gpu, size * size * 48 + (8 << 20))
+        except Exception as e:
+            logger.warning("loader: no page-locked slot ring (%s); falling back to the DataLoader's pin thread", e)
+            pin_thread = True
+    mapper.ring = ring
     loader = torch.utils.data.DataLoader(
-        _MapDataset(dicts, mapper), sampler=sampler, batch_size=per_gpu, drop_last=True, num_workers=nw, collate_fn=_identity,
-        worker_init_fn=functools.partial(_worker_init, base_seed=rank_seed), pin_memory=on_gpu,
+        _MapDataset(dicts, mapper), sampler=sampler, batch_size=per_gpu, drop_last=True, num_workers=nw,
+        collate_fn=_RingCollate(ring) if ring is not None else _identity,
+        worker_init_fn=functools.partial(_worker_init, base_seed=rank_seed), pin_memory=pin_thread,
         prefetch_factor=cfg.DATALOADER.PREFETCH_FACTOR if nw > 0 else None, persistent_workers=nw > 0)
     if nw == 0:
         _worker_init(0, rank_seed, in_worker=False)

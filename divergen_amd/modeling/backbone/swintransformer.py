@@ -170,6 +170,13 @@ class PatchMerging(nn.Module):
 # data-parallel reducer behind ITS backward replay, so the all-reduce still overlaps the rest of backward.
 GRAPH_BLOCKS = True
 GRAPH_GROUP = 6
+# ... but only where the host is the limit.  A block is ~24 launches = ~0.5 ms of host time forward + backward; its GPU time is
+# 72 T C^2 FLOP (12 C^2 per token forward, x 3) at ~0.7 PFLOP/s.  Swin-L at 1024^2 (348 GFLOP per block in every stage) keeps the GPU
+# busy for as long as the host needs to issue it, and there the replayed groups were SLOWER in a same-box A/B (26.8 -> 28.0 ms/step,
+# profiles/r06_ab_compact_blockgraphs.txt: the replay's node-to-node gaps and the lost first-writer protocol -- a replayed group
+# accumulates into zero-filled segments); Swin-T at 1024^2 (87 GFLOP per block) went 14.4 -> 12.3 ms/step.  Groups are replayed when a
+# block is below this much work, issued eagerly above it.
+GRAPH_BLOCKS_MAX_GFLOP = 150.0
 
 
 class _BlockGroup(nn.Module):
@@ -237,6 +244,8 @@ class BasicLayer(nn.Module):
             return False
         sc = self.__dict__.get("_dp_stage")
         if sc is None or sc.shape[2] != x.shape[0] or sc.device != x.device:
+            return False
+        if 72.0 * x.shape[0] * x.shape[1] * x.shape[2] * x.shape[2] > GRAPH_BLOCKS_MAX_GFLOP * 1e9:      # the GPU is the limit here
             return False
         if not self.__dict__.get("_arena_ok"):          # (checked until it holds: the optimizer builds the arena after the model)
             params = [p for blk in self.blocks for n, p in blk.named_parameters()] + \

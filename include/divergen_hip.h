@@ -18,6 +18,7 @@
 #ifndef DIVERGEN_HIP_H
 #define DIVERGEN_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -33,6 +34,15 @@ extern "C" {
 /* library / device identification; returns the gfx arch string the kernels were built for */
 const char* dgx_build_arch(void);
 int dgx_abi_version(void);
+
+/* Loader staging.  The reference's DataLoader hands every batch to a pin thread that allocates pinned memory and copies into it
+ * (torch/utils/data/_utils/pin_memory.py behind D2/data/build.py:build_detection_train_loader, DG/train_net.py:164-239).  Here the
+ * training process page-locks ONE shared-memory region once (dgx_host_register; bytes of any size, p from mmap / shm), the loader
+ * workers write their sample blobs into slots of it, and a slot goes up with dgx_memcpy_h2d_async on the loader's stream: the
+ * copy is asynchronous because the source is page-locked; the caller keeps the slot untouched until the stream has passed it. */
+int dgx_host_register(void* p, size_t bytes);
+int dgx_host_unregister(void* p);
+int dgx_memcpy_h2d_async(void* dst, const void* src, size_t bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Swin window attention core.  Replaces WindowAttention.forward between the qkv Linear and the

@@ -114,6 +114,7 @@ def test_one_rank_rccl_group_trains_like_no_reducer(early, block_graphs, monkeyp
     from divergen_amd.utils import graphs
     assert graphs.ENABLED, "the hipGraph segments are part of what is being proven"
     monkeypatch.setattr(S, "GRAPH_BLOCKS", block_graphs)
+    monkeypatch.setattr(S, "GRAPH_BLOCKS_MAX_GFLOP", 1e9)      # (the policy leaves Swin-L's blocks eager at this size: replay them here all the same)
     opt0, grads0, log0, _, weights0 = _run(False, early=early)
     if not block_graphs:
         assert max(n for kind, _, _, _, n in log0[-1][0] if kind == "w") >= 28, "the deferred 28-problem loader-wave group must be active"

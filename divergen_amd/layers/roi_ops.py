@@ -29,6 +29,13 @@ class FeatureGradients:
         self.maps = [None] * n
 
     def add(self, i, g):
+        """The FIRST gradient of a slot is kept WITHOUT a copy and later ones (and the poolers' gather kernels) add into it in place.
+        Invariant this relies on: the tensor autograd hands over is owned by this pass alone.  It holds for an eager node's
+        fresh output and for the graphed CenterNet head's static grad-input buffer -- the next replay rewrites that buffer and nothing else
+        reads it in between (utils/graphs.py ALIAS_STATIC hand-over buffers are OUTPUTS, not gradient inputs).  Autograd itself never
+        hands the same gradient tensor to two nodes without the second one being allowed to modify it only if it owns it: nodes that
+        keep a gradient they were given must not write to it -- this class is the one exception and is only fed by nodes of this package
+        (_CaptureGradient, the RoI poolers).  (Cloning views defensively would copy every NHWC-stored map: 50 MB per level and consumer.)"""
         m = self.maps[i]
         if m is None:
             self.maps[i] = g

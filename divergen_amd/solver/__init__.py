@@ -325,9 +325,13 @@ class FusedAdamWEMA:
                 and src.numel() == dst.numel():
             dst.copy_(src)
             return
-        if saved["layout_version"] is None and saved["names"] is not None and saved["offsets"] is not None \
+        # a checkpoint from before the version field whose names and offsets ARE this arena's.  The version exists because the storage
+        # order INSIDE a parameter changed (the (h, w, c) columns of the box heads' first FC, the grouped predictors): names and offsets
+        # cannot see that, so the raw copy is allowed only for arenas without such a parameter
+        reordered = any(hasattr(q, "_dgx_sd_perm") or getattr(q, "_dgx16g", None) is not None for q in self.arena.params)
+        if saved["layout_version"] is None and not reordered and saved["names"] is not None and saved["offsets"] is not None \
                 and list(saved["names"]) == cur["names"] and list(saved["offsets"]) == cur["offsets"] and src.numel() == dst.numel():
-            dst.copy_(src)          # a checkpoint from before the version field whose names and offsets ARE this arena's: same layout
+            dst.copy_(src)
             return
         if saved["layout_version"] != ARENA_LAYOUT_VERSION or saved["names"] is None or saved["sizes"] is None:
             raise RuntimeError("optimizer state '%s' was written by a build with another parameter storage layout (saved version %s, "

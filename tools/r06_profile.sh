@@ -37,3 +37,6 @@ python bench.py --gpus 2 --backend gloo --share-device 0 --steps 10 --warmup 4 -
 for f in r06_bench_line_through_loader r06_bench_line_through_loader_shards r06_bench_line_through_loader_scale_0p1_2 r06_two_rank_gloo_one_gpu r06_two_rank_gloo_one_gpu_bf16_wire; do python -c "
 import json,sys
 d=json.loads(open('$O/$f.json').read().strip().splitlines()[-1]); print('$f', d['ms_per_step'], d['value'])"; done
+# the N = 2 code path fed by the real loader (two loaders, 4 workers each, on the one box)
+python bench.py --gpus 2 --backend gloo --share-device 0 --through-loader --loader-shards --workers 4 --steps 10 --warmup 6 --no-cpu-baseline --no-roofline > $O/r06_two_rank_gloo_one_gpu_through_loader.json 2>> $O/bench.err
+tail -c 400 $O/r06_two_rank_gloo_one_gpu_through_loader.json

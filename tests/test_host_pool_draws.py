@@ -102,3 +102,52 @@ def test_batch_ahead_on_cpu_passes_worker_results_through_finish():
         return d
     out = list(BatchAhead(host, finish, "cpu"))
     assert [int(b[0]["image"][0, 0, 0]) for b in out] == [0, 1, 2] and seen == [0, 10, 1, 11, 2, 12]
+
+
+class _FakeRing:
+    """SlotRing without the page-locking (no GPU here): the same slot arithmetic over a shared-memory buffer."""
+
+    def __init__(self, num_workers, per_worker, slot_bytes):
+        self.num_workers, self.per_worker, self.slot_bytes = num_workers, per_worker, slot_bytes
+        self.buf = torch.zeros(num_workers * per_worker * slot_bytes, dtype=torch.uint8).share_memory_()
+
+    def offset(self, worker, k):
+        return (worker * self.per_worker + k % self.per_worker) * self.slot_bytes
+
+
+class _BlobDataset(torch.utils.data.Dataset):
+    def __len__(self):
+        return 64
+
+    def __getitem__(self, i):
+        n = 100 + 7 * (i % 5) if i % 9 else 5000          # every ninth sample does not fit a slot: it must travel the ordinary way
+        return {"i": i, "blob": torch.full((n,), i % 251, dtype=torch.uint8)}
+
+
+def test_ring_collate_writes_worker_slots_and_reuse_is_safe():
+    """data/build.py _RingCollate + the SlotRing slot arithmetic with real worker processes: every sample's blob is found in the slot it
+    reports, intact at the time the training process would upload it (batch t + 1 is pulled while batch t is in use: one ahead), with
+    (prefetch_factor + 2) batches of slots per worker; a blob larger than a slot arrives as a tensor."""
+    from divergen_amd.data.build import _RingCollate
+    nw, pf, bs = 3, 2, 2
+    ring = _FakeRing(nw, (pf + 2) * bs, 256)
+    loader = torch.utils.data.DataLoader(_BlobDataset(), batch_size=bs, num_workers=nw, prefetch_factor=pf, collate_fn=_RingCollate(ring),
+                                         persistent_workers=True)
+    it = iter(loader)
+    prev = next(it)
+    seen, via_slot = 0, 0
+    for _ in range(30):
+        cur = next(it)                      # the loader is one batch ahead of the batch being "uploaded" ...
+        for d in prev:                      # ... which must still be intact in its slot
+            if d.get("blob_slot") is not None:
+                off, n = d["blob_slot"]
+                assert d["blob"] is None and n == 100 + 7 * (d["i"] % 5)
+                assert bool((ring.buf[off:off + n] == d["i"] % 251).all()), d["i"]
+                assert off % ring.slot_bytes == 0 and off // (ring.slot_bytes * ring.per_worker) < nw
+                via_slot += 1
+            else:
+                assert d["blob"].numel() == 5000 and int(d["blob"][0]) == d["i"] % 251
+            seen += 1
+        prev = cur
+    assert seen == 60 and via_slot >= 50
+    del it, loader

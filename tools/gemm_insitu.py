@@ -5,7 +5,7 @@ import sys
 from collections import defaultdict
 
 trace, log, steps = sys.argv[1], sys.argv[2], float(sys.argv[3])
-rows = [r for r in csv.DictReader(open(trace)) if "gemm_nt_kernel" in r["Kernel_Name"] or "gemm256_kernel" in r["Kernel_Name"] or "gemm_lw_kernel" in r["Kernel_Name"]]
+rows = [r for r in csv.DictReader(open(trace)) if "gemm_nt_kernel" in r["Kernel_Name"] or "gemm256_kernel" in r["Kernel_Name"] or "gemm_lw_kernel" in r["Kernel_Name"] or "gemm_k192_kernel" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 lines = [l.split() for l in open(log) if l.strip()]
 print("dispatches %d, log lines %d" % (len(rows), len(lines)))
@@ -16,6 +16,8 @@ for r, l in zip(rows[-n:], lines[-n:]):
     tag = ""
     if "gemm256" in kn:
         tag = "g%s" % kn.split("<")[1].split(",")[0].split(">")[0]
+    elif "gemm_k192" in kn:
+        tag = "K192<%s>" % kn.split("<")[1].split(">")[0].replace(" ", "")
     elif "gemm_lw" in kn:
         a = kn.split("<")[1].split(">")[0].split(",")
         tag = "L%sx%s" % (a[0].strip(), a[1].strip())

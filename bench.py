@@ -75,6 +75,7 @@ def parse():
                    help="A/B: back-propagate the proposal generator's losses with the rest (model.early_proposal_backward off)")
     p.add_argument("--early-box-backward", action="store_true", help="A/B: the box cascade's losses back-propagated right behind its forward (measured slower)")
     p.add_argument("--no-compact", action="store_true", help="A/B: the padded window order of rounds 1-5 (layers.swin_block.COMPACT off)")
+    p.add_argument("--no-own-topk", action="store_true", help="A/B: torch.topk / torch.sort in the proposal decode (centernet._OWN_TOPK off)")
     p.add_argument("--no-block-graphs", action="store_true", help="A/B: the Swin blocks issued eagerly (swintransformer.GRAPH_BLOCKS off)")
     p.add_argument("--no-graphs", action="store_true",
                    help="development: issue the hipGraph segments (FPN, tower, heads) eagerly so that every launch is logged / traced by name")
@@ -323,6 +324,9 @@ def main():
     if a.no_compact:
         from divergen_amd.layers import swin_block
         swin_block.COMPACT = False
+    if a.no_own_topk:
+        from divergen_amd.modeling.dense_heads import centernet as _cn
+        _cn._OWN_TOPK = False
     if a.no_block_graphs:
         from divergen_amd.modeling.backbone import swintransformer
         swintransformer.GRAPH_BLOCKS = False

@@ -111,6 +111,8 @@ SIGNATURES = {
     "dgx_gemm_last_form": (c_i, [ctypes.POINTER(c_i)] * 3),
     "dgx_dev_gemm_log": (c_i, [ctypes.c_char_p]),
     "dgx_gather_boxes": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p]),
+    "dgx_topk_index_rows": (c_i, [c_p, c_i64, c_i, c_p, c_p, c_p, c_i, c_i, c_p, c_i64, c_p]),
+    "dgx_sort_rows_desc": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p]),
     "dgx_centernet_finalize": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p]),
     "dgx_roi_label": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_i, c_f, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
     "dgx_roi_gather": (c_i, [c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f] + [c_p] * 10 + [c_p]),

@@ -14,7 +14,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["window_attention.hip", "window_shuffle.hip", "roi_align.hip", "nms_boxes.hip",
-           "centernet_targets.hip", "compositor.hip", "optim.hip", "im2col.hip", "wgrad_gemm.hip", "wgrad256.hip", "gemm_nt.hip", "gemm_lw.hip", "gemm_k192.hip", "wgrad_lw.hip", "transpose.hip", "prof.hip", "preprocess.hip", "mask_loss.hip", "layernorm.hip", "residual.hip", "colsum.hip", "groupnorm.hip", "gelu.hip", "detic_loss.hip", "centernet_loss.hip", "cascade_refine.hip", "mask_paste.hip", "grad_bank.hip", "roi_sample.hip", "centernet_decode.hip", "resnet_ops.hip", "abi.hip"]
+           "centernet_targets.hip", "compositor.hip", "optim.hip", "im2col.hip", "wgrad_gemm.hip", "wgrad256.hip", "gemm_nt.hip", "gemm_lw.hip", "gemm_k192.hip", "wgrad_lw.hip", "transpose.hip", "prof.hip", "preprocess.hip", "mask_loss.hip", "layernorm.hip", "residual.hip", "colsum.hip", "groupnorm.hip", "gelu.hip", "detic_loss.hip", "centernet_loss.hip", "cascade_refine.hip", "mask_paste.hip", "grad_bank.hip", "roi_sample.hip", "centernet_decode.hip", "topk_sort.hip", "resnet_ops.hip", "abi.hip"]
 OUT = os.path.join(HERE, "libdgx.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",

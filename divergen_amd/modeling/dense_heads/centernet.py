@@ -7,6 +7,7 @@ normalisers stay on the device (the reference's two `.item()` round trips after 
 centernet.py:259-260,289, become device-side divisions); post-NMS top-k is taken on the GPU
 (no `.cpu()` kthvalue, centernet.py:727-731) with the same ">= k-th score" tie rule.
 """
+import ctypes
 import os
 
 import torch
@@ -21,6 +22,7 @@ from ...utils.comm import get_world_size
 from .centernet_head import CenterNetHead
 
 _FUSED_CN_LOSSES = True      # dgx_centernet_losses; the composed form is the reference of its parity test
+_OWN_TOPK = True             # dgx_topk_index_rows / dgx_sort_rows_desc; torch.topk / torch.sort are the reference of their parity tests
 
 INF = 100000000
 
@@ -151,6 +153,28 @@ class CenterNet(nn.Module):
     def _run_head(self, features):
         _, reg, hm = self.centernet_head(features)
         return reg, hm
+
+    @staticmethod
+    def _topk_indices_torch(scores, sizes, offs, big, pre_topk, small_idx, cache, key, B, dev):
+        """torch.topk form of the candidate indices (levels beyond the own kernel's row limit; the reference of its parity test)."""
+        if len(big) > 1:
+            # the per-level top-k of all large levels as ONE torch.topk over rows padded with -inf to the largest level (the selection runs one
+            # workgroup per row and takes as long for 4 096 as for 16 384 entries: two launches of ~80 us were one too many); rows are
+            # independent, the padding can never be selected (n > k real entries, all > -inf)
+            nmax = max(sizes[l] for l in big)
+            pk = ("topk_pad", key)
+            if pk not in cache:
+                cache[pk] = (torch.full((B, len(big), nmax), float("-inf"), dtype=torch.float32, device=dev),
+                             torch.tensor([offs[l] for l in big], dtype=torch.int64, device=dev).view(1, len(big), 1))
+            pad, boff = cache[pk]
+            for j, l in enumerate(big):
+                pad[:, j, :sizes[l]].copy_(scores[:, offs[l]:offs[l] + sizes[l]])
+            parts = [(pad.view(B * len(big), nmax).topk(pre_topk, dim=1)[1].view(B, len(big), pre_topk) + boff).view(B, len(big) * pre_topk)]
+        else:
+            parts = [scores[:, offs[l]:offs[l] + sizes[l]].topk(pre_topk, dim=1)[1] + offs[l] for l in big]
+        if small_idx is not None:
+            parts.append(small_idx)
+        return torch.cat(parts, 1).contiguous() if len(parts) > 1 else parts[0].contiguous()
 
     def compute_grids(self, features):
         key = tuple((int(f.shape[-2]), int(f.shape[-1]), str(f.device)) for f in features)
@@ -306,30 +330,35 @@ class CenterNet(nn.Module):
             cache[key] = (offs, torch.cat(small)[None].expand(B, -1).contiguous() if small else None)
         offs, small_idx = cache[key]
         big = [l for l, n in enumerate(sizes) if n > pre_topk]
-        if len(big) > 1:
-            # the per-level top-k of all large levels as ONE torch.topk over rows padded with -inf to the largest level (the selection runs one
-            # workgroup per row and takes as long for 4 096 as for 16 384 entries: two launches of ~80 us were one too many); rows are
-            # independent, the padding can never be selected (n > k real entries, all > -inf)
-            nmax = max(sizes[l] for l in big)
-            pk = ("topk_pad", key)
-            if pk not in cache:
-                cache[pk] = (torch.full((B, len(big), nmax), float("-inf"), dtype=torch.float32, device=dev),
-                             torch.tensor([offs[l] for l in big], dtype=torch.int64, device=dev).view(1, len(big), 1))
-            pad, boff = cache[pk]
-            for j, l in enumerate(big):
-                pad[:, j, :sizes[l]].copy_(scores[:, offs[l]:offs[l] + sizes[l]])
-            parts = [(pad.view(B * len(big), nmax).topk(pre_topk, dim=1)[1].view(B, len(big), pre_topk) + boff).view(B, len(big) * pre_topk)]
+        if big and _OWN_TOPK and max(sizes[l] for l in big) <= 32768:
+            # the per-level top-k of all large levels of all images in ONE launch (dgx_topk_index_rows: radix select + order-preserving
+            # compaction per (image, level)), written straight into the candidate index buffer whose tail -- the levels taken whole --
+            # is constant
+            tk = ("own_topk", key)
+            if tk not in cache:
+                nb = len(big)
+                Kc0 = nb * pre_topk + (small_idx.shape[1] if small_idx is not None else 0)
+                buf = torch.empty(B, Kc0, dtype=torch.int64, device=dev)
+                if small_idx is not None:
+                    buf[:, nb * pre_topk:] = small_idx
+                cache[tk] = (buf, torch.tensor([offs[l] for l in big], dtype=torch.int32, device=dev),
+                             torch.tensor([sizes[l] for l in big], dtype=torch.int32, device=dev), (ctypes.c_int32 * nb)(*[sizes[l] for l in big]))
+            idx, d_off, d_n, h_n = cache[tk]
+            L.check(lib.dgx_topk_index_rows(L.ptr(scores), M, B, L.ptr(d_off), L.ptr(d_n), h_n, len(big), pre_topk, L.ptr(idx), idx.shape[1],
+                                            L.stream()), "dgx_topk_index_rows")
         else:
-            parts = [scores[:, offs[l]:offs[l] + sizes[l]].topk(pre_topk, dim=1)[1] + offs[l] for l in big]
-        if small_idx is not None:
-            parts.append(small_idx)
-        idx = torch.cat(parts, 1).contiguous() if len(parts) > 1 else parts[0].contiguous()
+            idx = self._topk_indices_torch(scores, sizes, offs, big, pre_topk, small_idx, cache, key, B, dev)
         Kc = int(idx.shape[1])
         boxes = torch.empty(B, Kc, 4, dtype=torch.float32, device=dev)
         sc = torch.empty(B, Kc, dtype=torch.float32, device=dev)
         L.check(lib.dgx_centernet_decode(rp, lay_r[0][0], 0, hw, st, Lv, B, L.ptr(idx), Kc, L.ptr(scores), float(self.score_thresh),
                                          L.ptr(boxes), L.ptr(sc), L.ptr(n_valid), code, L.stream()), "dgx_centernet_decode")
-        sc, order = torch.sort(sc, dim=1, descending=True, stable=True)
+        if _OWN_TOPK and Kc <= 16384:
+            sc_sorted, order = torch.empty_like(sc), torch.empty(B, Kc, dtype=torch.int64, device=dev)
+            L.check(lib.dgx_sort_rows_desc(L.ptr(sc), B, Kc, L.ptr(sc_sorted), L.ptr(order), L.stream()), "dgx_sort_rows_desc")
+            sc = sc_sorted
+        else:
+            sc, order = torch.sort(sc, dim=1, descending=True, stable=True)
         sorted_boxes = torch.empty_like(boxes)
         L.check(lib.dgx_gather_boxes(L.ptr(boxes), L.ptr(order.contiguous()), B, Kc, L.ptr(sorted_boxes), L.stream()), "dgx_gather_boxes")
         boxes = sorted_boxes

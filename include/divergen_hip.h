@@ -219,6 +219,18 @@ int dgx_centernet_decode(const void* const* reg_levels, int reg_pixel_stride, in
 /* boxes (B, K, 4) f32, order (B, K) i64 (the permutation torch.sort returns for the candidates' scores) -> out[b][k] =
  * boxes[b][order[b][k]]: the gather of centernet.py:704-712 (`boxlist = boxlist[keep]` behind the score sort). */
 int dgx_gather_boxes(const float* boxes, const int64_t* order, int B, int K, float* out, void* stream);
+/* The two selections of the proposal decode as own kernels (round 6; they were torch.topk = one workgroup per row, 115-150 us, and a
+ * rocprim segmented sort, ~95 us, on the step's pre-sync critical path).
+ *   dgx_topk_index_rows   per (image b, level l): the positions of the k largest of scores[b * row_stride + level_off[l] .. + level_n[l])
+ *                         -- centernet.py:713-717 `per_box_cls.topk(per_pre_nms_top_n, sorted=False)` -- written to
+ *                         out[b * out_row_stride + l * k ..] as level_off[l] + position, in ASCENDING position order; ties at the k-th
+ *                         value go to the lowest positions (torch's set).  level_off / level_n: device arrays; level_n_host: the same
+ *                         sizes on the host (every one >= k and <= 32 768).
+ *   dgx_sort_rows_desc    out_vals / out_order (int64) = torch.sort(in (B, K), dim=1, descending=True, stable=True), K <= 16 384
+ *                         (ml_nms' score order, centernet.py:739-768 -> D2/layers/nms.py). */
+int dgx_topk_index_rows(const float* scores, int64_t row_stride, int B, const int32_t* level_off, const int32_t* level_n,
+                        const int32_t* level_n_host, int nlev, int k, int64_t* out, int64_t out_row_stride, void* stream);
+int dgx_sort_rows_desc(const float* in, int B, int K, float* out_vals, int64_t* out_order, void* stream);
 int dgx_centernet_finalize(const float* sorted_boxes, const float* sorted_scores, const int32_t* keep_idx, const int32_t* num_keep,
                            int B, int K, int cap, float* out_boxes, float* out_scores, uint8_t* out_valid, void* stream);
 

@@ -1689,3 +1689,97 @@ def test_deconv2x2_shuffle_kernels_equal_the_permuting_views():
         src = gy * (yout > 0) if use_relu else gy
         want = src.view(N, H, 2, W, 2, Co).permute(0, 1, 3, 5, 2, 4).reshape(N * H * W, 4 * Co)
         assert torch.equal(g2.float(), want.float())
+
+
+# ------------------------------------------------------------------ own top-k / sort of the proposal decode
+def _topk_rows(scores, offs, ns, k):
+    import ctypes
+    from divergen_amd import _lib as L
+    B, M = scores.shape
+    nlev = len(offs)
+    out = torch.full((B, nlev * k + 3), -7, dtype=torch.int64, device=DEV)
+    d_off = torch.tensor(offs, dtype=torch.int32, device=DEV)
+    d_n = torch.tensor(ns, dtype=torch.int32, device=DEV)
+    L.check(L.lib().dgx_topk_index_rows(L.ptr(scores), M, B, L.ptr(d_off), L.ptr(d_n), (ctypes.c_int32 * nlev)(*ns), nlev, k, L.ptr(out),
+                                        out.shape[1], L.stream()), "dgx_topk_index_rows")
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+def _topk_expected(row, k):
+    """numpy statement of the selection (CN/modeling/dense_heads/centernet.py:713-717 takes the top-k SET, sorted=False): everything above
+    the k-th largest value, then the lowest positions equal to it; returned in ascending position order."""
+    order = np.argsort(-row, kind="stable")[:k]        # stable: ties by position
+    return np.sort(order)
+
+
+@pytest.mark.parametrize("ns,k,mode", [((16384, 4096), 1000, "rand"), ((16384, 4096), 1000, "ties"), ((32768, 1001), 1000, "rand"),
+                                       ((12544, 3136, 1000), 1000, "thresh"), ((4097,), 4096, "ties"), ((70, 65), 64, "neg"),
+                                       ((5000,), 1, "rand"), ((3000,), 1000, "const")])
+def test_topk_index_rows_equals_the_stable_selection(ns, k, mode):
+    g = torch.Generator().manual_seed(sum(ns) + k)
+    B, gap = 3, 5
+    offs, tot = [], 2
+    for n in ns:
+        offs.append(tot)
+        tot += n + gap
+    if mode == "rand":
+        s = torch.rand(B, tot, generator=g)
+    elif mode == "ties":           # few distinct values: the k-th value is shared by many entries
+        s = torch.randint(0, 7, (B, tot), generator=g).float() / 7
+    elif mode == "thresh":         # the decode's scores: most entries are the below-threshold marker
+        s = torch.rand(B, tot, generator=g)
+        s = torch.where(s > 0.97, s, torch.full_like(s, -1.0))
+    elif mode == "neg":
+        s = torch.randn(B, tot, generator=g)
+    else:
+        s = torch.full((B, tot), 0.25)
+    out = _topk_rows(s.to(DEV), offs, list(ns), k)
+    sn = s.numpy()
+    for b in range(B):
+        for l, (o, n) in enumerate(zip(offs, ns)):
+            want = _topk_expected(sn[b, o:o + n], k) + o
+            assert np.array_equal(out[b, l * k:(l + 1) * k], want), (b, l)
+            # the same SET as torch.topk wherever the k-th value is unique
+            tv, ti = torch.topk(s[b, o:o + n].to(DEV), k)
+            assert np.array_equal(np.sort(sn[b, out[b, l * k:(l + 1) * k]])[::-1], tv.cpu().numpy())
+            # torch's tie rule on the GPU (gatherTopK: everything above the k-th value, then equal elements in position order) is the same
+            # rule: the index SETS agree even where the k-th value is shared
+            assert np.array_equal(np.sort(ti.cpu().numpy()) + o, want), ("torch tie set", b, l)
+    assert (out[:, len(ns) * k:] == -7).all()      # nothing written past the levels' slots
+
+
+@pytest.mark.parametrize("B,K,mode", [(2, 9344, "rand"), (2, 9344, "ties"), (3, 16384, "rand"), (1, 1, "rand"), (4, 1000, "thresh"), (2, 5, "neg"),
+                                      (2, 2049, "ties")])
+def test_sort_rows_desc_equals_torch_stable_sort(B, K, mode):
+    from divergen_amd import _lib as L
+    g = torch.Generator().manual_seed(B * 100003 + K)
+    if mode == "rand":
+        s = torch.rand(B, K, generator=g)
+    elif mode == "ties":
+        s = torch.randint(0, 5, (B, K), generator=g).float() / 5
+    elif mode == "thresh":
+        s = torch.rand(B, K, generator=g)
+        s = torch.where(s > 0.9, s, torch.full_like(s, -1.0))
+    else:
+        s = torch.randn(B, K, generator=g)
+    s = s.to(DEV)
+    vals, order = torch.full_like(s, 9.0), torch.full((B, K), -1, dtype=torch.int64, device=DEV)
+    L.check(L.lib().dgx_sort_rows_desc(L.ptr(s), B, K, L.ptr(vals), L.ptr(order), L.stream()), "dgx_sort_rows_desc")
+    tv, to = torch.sort(s, dim=1, descending=True, stable=True)
+    assert torch.equal(vals, tv)
+    assert torch.equal(order, to)
+
+
+def test_topk_sort_argument_checks():
+    import ctypes
+    from divergen_amd import _lib as L
+    s = torch.rand(1, 40000, device=DEV)
+    out = torch.empty(1, 8, dtype=torch.int64, device=DEV)
+    off = torch.zeros(1, dtype=torch.int32, device=DEV)
+    n = torch.tensor([40000], dtype=torch.int32, device=DEV)
+    lib = L.lib()
+    assert lib.dgx_topk_index_rows(L.ptr(s), 40000, 1, L.ptr(off), L.ptr(n), (ctypes.c_int32 * 1)(40000), 1, 8, L.ptr(out), 8, L.stream()) != 0
+    assert lib.dgx_topk_index_rows(L.ptr(s), 40000, 1, L.ptr(off), L.ptr(n), (ctypes.c_int32 * 1)(4), 1, 8, L.ptr(out), 8, L.stream()) != 0
+    v, o = torch.empty(1, 40000, device=DEV), torch.empty(1, 40000, dtype=torch.int64, device=DEV)
+    assert lib.dgx_sort_rows_desc(L.ptr(s), 1, 40000, L.ptr(v), L.ptr(o), L.stream()) != 0

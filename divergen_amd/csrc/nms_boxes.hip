@@ -312,6 +312,7 @@ __global__ __launch_bounds__(1024) void nms_sweep_batched_kernel(const uint64_t*
             uint64_t keptbits = 0;
             while (alive) {
                 const int j = __builtin_ctzll(alive);
+                if (tot + k >= cap) { stop = 1; break; }      // every slot of the fixed-length output is taken: num_keep = cap whatever follows
                 if (max_keep > 0 && tot + k >= max_keep) {
                     // quota reached: only boxes tied with the max_keep-th kept score are still eligible
                     // (the reference keeps every survivor with score >= the k-th score, centernet.py:727-731)

@@ -95,6 +95,22 @@ __device__ __forceinline__ int attn_row(const AttnGeom& G, const WmGeom& g, cons
     return real ? img * (G.H * G.W) + w.base + before : -(1 + img * G.P + (wi * (WS * WS) - w.base) + (n - before));
 }
 
+#ifdef DIAG_CLOCK
+__device__ unsigned long long dgx_clk[16];
+#define CLK(i) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && (threadIdx.x >> 6) == DIAG_WAVE) { const unsigned long long t__ = clock64(); dgx_clk[i] += t__ - tprev; tprev = t__; } } while (0)
+// forward: the time stamps of wave DIAG_WAVE of EVERY workgroup, kept in registers and stored once at the end (slot 0: start, 1 + i: FCLK(i));
+// an atomic per phase onto one counter made the kernel five times slower
+__device__ unsigned long long dgx_fclk[8192 * 8];
+#define FCLK_START unsigned long long fts[8]; fts[0] = clock64()
+#define FCLK(i) do { fts[1 + (i)] = clock64(); } while (0)
+#define FCLK_END(n) do { if ((threadIdx.x & 63) == 0 && (threadIdx.x >> 6) == DIAG_WAVE && blockIdx.x < 8192) { for (int i__ = 0; i__ <= (n); ++i__) dgx_fclk[blockIdx.x * 8 + i__] = fts[i__]; } } while (0)
+#else
+#define CLK(i)
+#define FCLK(i)
+#define FCLK_START
+#define FCLK_END(n)
+#endif
+
 // Softmax runs in the log2 domain: the bias row is pre-multiplied by log2(e) when it is staged in LDS and the
 // score is one FMA, s2 = qk * (scale*log2e) + bias2 (the -100 of the shift mask becomes -100*log2e), so that
 // p = exp2(s2 - max2) is a bare v_exp_f32.  MASKED = false (W-MSA blocks) drops the region compare entirely.
@@ -122,6 +138,7 @@ __global__ __launch_bounds__(WinCfg<WS>::NT * 64) void win_attn_fwd_kernel(
     int b, h;
     block_to_window_head(blockIdx.x, nH, b, h);
     if (b >= B_) return;
+    FCLK_START;
     const int C = nH * 32;
     const int64_t rowst = 3 * (int64_t)C;
     const uint16_t* base = qkv + (int64_t)b * N * rowst + h * 32;
@@ -168,6 +185,7 @@ __global__ __launch_bounds__(WinCfg<WS>::NT * 64) void win_attn_fwd_kernel(
     const bf16x8 v1 = ld_frag_global(r1 + 2 * C + 8 * (u1 & 3), two && (u1 >> 2) < N);
     const int q_row = COMPACT ? row_of(qok ? qi : 0) : 0;
     const bf16x8 qf = ld_frag_global(COMPACT ? (q_row >= 0 ? qkv + (int64_t)q_row * rowst : G.bias) + h * 32 + 8 * g : base + (int64_t)qi * rowst + 8 * g, qok);
+    FCLK(0);            // address arithmetic + issue
     if (tid < TBL) tbl[tid] = tv * DGX_LOG2E;
     if (tid < NP) {
         const int yk = tid / WS;
@@ -182,7 +200,9 @@ __global__ __launch_bounds__(WinCfg<WS>::NT * 64) void win_attn_fwd_kernel(
         *reinterpret_cast<bf16x8*>(&Ks[(u1 >> 2) * RR + 8 * (u1 & 3)]) = k1;
         *reinterpret_cast<bf16x8*>(&Vs[(u1 >> 2) * RR + 8 * (u1 & 3)]) = v1;
     }
+    FCLK(1);            // the loads' latency + parking in LDS
     __syncthreads();
+    FCLK(2);            // barrier
 
     const int yq = qi / WS, xq = qi - yq * WS;
     const int base_q = qok ? (yq + WS - 1) * (2 * WS - 1) + (xq + WS - 1) : (WS - 1) * (2 * WS - 1) + (WS - 1);
@@ -225,6 +245,7 @@ __global__ __launch_bounds__(WinCfg<WS>::NT * 64) void win_attn_fwd_kernel(
     sum += __shfl_xor(sum, 32);
     if (g == 0 && qok) lse[((int64_t)b * nH + h) * N + qi] = mx * DGX_LN2 + __logf(sum);   // natural-log LSE, as before
     const float inv = 1.0f / sum;
+    FCLK(3);            // scores + softmax
 
     f32x4 o[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     DGX_LDS const uint16_t* v_l4 = tr_lane_ptr(Vs, RR, 4 * g, 0, c16);
@@ -248,15 +269,11 @@ __global__ __launch_bounds__(WinCfg<WS>::NT * 64) void win_attn_fwd_kernel(
         for (int dt = 0; dt < 2; ++dt)
             *reinterpret_cast<u32x2*>(orow + 16 * dt) = u32x2{pack_bf2(o[dt][0] * inv, o[dt][1] * inv), pack_bf2(o[dt][2] * inv, o[dt][3] * inv)};
     }
+    FCLK(4);            // P V + stores issued
+    FCLK_END(5);
 }
 
 // ------------------------------------------------------------------------------------ backward
-#ifdef DIAG_CLOCK
-__device__ unsigned long long dgx_clk[16];
-#define CLK(i) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && (threadIdx.x >> 6) == DIAG_WAVE) { const unsigned long long t__ = clock64(); dgx_clk[i] += t__ - tprev; tprev = t__; } } while (0)
-#else
-#define CLK(i)
-#endif
 
 // value of lane (4 * (lane / 4) + R) of every quad: v_mov_b32_dpp quad_perm:[R,R,R,R] -- no LDS traffic (the backward kernel is
 // bound by the LDS pipe: profiles/r05_attn_bwd_*.txt)

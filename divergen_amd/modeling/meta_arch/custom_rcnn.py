@@ -190,6 +190,8 @@ class CustomRCNN(nn.Module):
             if grads_on:
                 # the consumers of the FPN levels write ONE gradient map per level between them
                 fg, joined = _shared_gradient_maps(features)
+            if hasattr(self.roi_heads, "prepare_targets") and not only_gt_proposals:
+                self.roi_heads.prepare_targets(gt_instances)
             if early and grads_on:
                 prev = self.__dict__.get("_early_outstanding")
                 if prev is not None and not prev.consumed:

@@ -218,6 +218,30 @@ class DeticCascadeROIHeads(nn.Module):
         st.put_scalar("roi_head/num_bg_samples", torch.stack([x.float() for x in nbg]).mean())
         return out
 
+    @staticmethod
+    def _cat_targets(targets, dev, G, has_src, offs):
+        from ...utils.h2d import upload_i32
+        if G:
+            gt_boxes = torch.cat([t.gt_boxes.tensor for t in targets]).float().contiguous()
+            gt_classes = torch.cat([t.gt_classes for t in targets]).contiguous()
+            gt_src = torch.cat([t.instance_source for t in targets]).contiguous() if has_src else None
+        else:
+            gt_boxes, gt_classes, gt_src = torch.zeros(1, 4, device=dev), torch.zeros(1, dtype=torch.int64, device=dev), None
+        return gt_boxes, gt_classes, gt_src, upload_i32(offs, dev)
+
+    @torch.no_grad()
+    def prepare_targets(self, targets):
+        """The batch form of the ground truth the fused sampler reads (boxes, classes, sources of all images concatenated + the image
+        offsets), built by the meta-architecture BEFORE the proposal generator runs: off the path between the proposal decode and the
+        sampler's device->host read."""
+        if not self.training or not len(targets) or not all(t.gt_boxes.tensor.is_cuda for t in targets):
+            return
+        offs = [0]
+        for t in targets:
+            offs.append(offs[-1] + len(t))
+        has_src = all(t.has("instance_source") for t in targets)
+        self.__dict__["_gt_batch"] = (targets,) + self._cat_targets(targets, targets[0].gt_boxes.tensor.device, offs[-1], has_src, offs)
+
     def _label_and_sample_fused(self, proposals, targets):
         """label_and_sample_proposals for the whole batch in two launches around the step's one device->host read
         (dgx_roi_label -> counts -> torch.randperm draws in the reference's order -> dgx_roi_gather); None when the inputs do
@@ -239,13 +263,13 @@ class DeticCascadeROIHeads(nn.Module):
             offs.append(offs[-1] + n)
         G = offs[-1]
         has_src = all(t.has("instance_source") for t in targets)
-        if G:
-            gt_boxes = torch.cat([t.gt_boxes.tensor for t in targets]).float().contiguous()
-            gt_classes = torch.cat([t.gt_classes for t in targets]).contiguous()
-            gt_src = torch.cat([t.instance_source for t in targets]).contiguous() if has_src else None
+        pre = self.__dict__.pop("_gt_batch", None)
+        if pre is not None and pre[0] is targets:
+            # concatenated ahead of the proposal generator (prepare_targets): these launches sat between the decode and the step's
+            # device->host read otherwise
+            _, gt_boxes, gt_classes, gt_src, offs_t = pre
         else:
-            gt_boxes, gt_classes, gt_src = boxes.new_zeros(1, 4), torch.zeros(1, dtype=torch.int64, device=dev), None
-        offs_t = upload_i32(offs, dev)
+            gt_boxes, gt_classes, gt_src, offs_t = self._cat_targets(targets, dev, G, has_src, offs)
         Nmax = K + max(gts)
         midx = torch.empty(B, Nmax, dtype=torch.int32, device=dev)
         labels = torch.empty(B, Nmax, dtype=torch.int64, device=dev)

@@ -594,6 +594,24 @@ def test_nms_batched_sweep_pipeline_long_lists(spread, max_keep):
         assert keep_idx[b, :n].cpu().tolist() == ref
 
 
+@pytest.mark.parametrize("cap", [264, 1024])
+def test_nms_batched_ties_behind_the_quota_span_blocks(cap):
+    """The quota falls INSIDE a run of equal scores that is several 64-box blocks long (an untrained CenterNet: every score of the bench's
+    boxes ties): every survivor tied with the max_keep-th kept score is kept (centernet.py:727-731), the first box below that score ends the
+    sweep, and a full output (cap) ends it earlier.  Blocks that start behind the quota must not take the resolver's bare loop."""
+    K, max_keep = 1024, 200
+    ij = torch.arange(K)
+    xy = torch.stack([(ij % 32) * 40.0, (ij // 32) * 40.0], 1)
+    boxes = torch.cat([xy, xy + 30.0], 1)[None]                           # a grid of disjoint boxes: nothing is suppressed
+    scores = torch.cat([torch.linspace(0.99, 0.80, 150), torch.full((300,), 0.5), torch.linspace(0.49, 0.01, K - 450)])[None]
+    keep_idx, num_keep = la.nms_batched_sorted(boxes.to(DEV), scores.to(DEV), torch.tensor([K], dtype=torch.int32, device=DEV), 0.5,
+                                               max_keep=max_keep, cap=cap)
+    n = int(num_keep[0])
+    assert n == min(450, cap)
+    assert keep_idx[0, :n].cpu().tolist() == list(range(n))
+    assert bool((keep_idx[0, n:] == -1).all())
+
+
 def test_iou_match_bit_exact(golden):
     g = golden("roi_match")
     gt, pr = T(g["gt"]), T(g["proposals"])

@@ -76,6 +76,7 @@ def parse():
     p.add_argument("--early-box-backward", action="store_true", help="A/B: the box cascade's losses back-propagated right behind its forward (measured slower)")
     p.add_argument("--no-compact", action="store_true", help="A/B: the padded window order of rounds 1-5 (layers.swin_block.COMPACT off)")
     p.add_argument("--no-own-topk", action="store_true", help="A/B: torch.topk / torch.sort in the proposal decode (centernet._OWN_TOPK off)")
+    p.add_argument("--no-overlap-transposes", action="store_true", help="A/B: the transposed weight images refreshed on the step's stream (solver.OVERLAP_TRANSPOSES off)")
     p.add_argument("--no-block-graphs", action="store_true", help="A/B: the Swin blocks issued eagerly (swintransformer.GRAPH_BLOCKS off)")
     p.add_argument("--no-graphs", action="store_true",
                    help="development: issue the hipGraph segments (FPN, tower, heads) eagerly so that every launch is logged / traced by name")
@@ -392,6 +393,8 @@ def main():
     torch.manual_seed(cfg.SEED + rank)
     model = build_model(cfg).train()
     model.early_proposal_backward = not a.late_proposal_backward
+    from divergen_amd import solver as _solver
+    _solver.OVERLAP_TRANSPOSES = not a.no_overlap_transposes          # as train_net.do_train
     model.early_box_backward = a.early_box_backward
     opt = build_optimizer(cfg, model)
     sched = build_lr_scheduler(cfg, opt)

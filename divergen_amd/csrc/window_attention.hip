@@ -840,15 +840,20 @@ static BwdTableWs* bwd_table_ws(hipStream_t st, int64_t floats, int heads) {
     int device = 0;
     if (hipGetDevice(&device) != hipSuccess) return nullptr;
     BwdTableWs& w = pool[std::make_pair(device, st)];
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
     if (w.part && w.floats >= floats && w.heads >= heads) {
-        if (w.dirty) {
+        // A launch that is being CAPTURED always carries its own zero-fill of the counters (a 256-byte memset node in front of it): the
+        // workspace may have been allocated inside an earlier capture on a stream handle the framework has since handed out again (torch
+        // draws its streams from a pool of 32 per device) -- then the only zero-fill its counters ever got sits in THAT graph, and a graph
+        // captured now would replay onto whatever hipMalloc returned.  Found by running the one-rank RCCL test behind the loader test in
+        // one process: every relative-position table gradient of the first replay was 0 (the flush condition never met).
+        if (w.dirty || capturing) {
             if (hipMemsetAsync(w.cnt, 0, (size_t)w.heads * 4, st) != hipSuccess) return nullptr;
-            w.dirty = false;
+            if (!capturing) w.dirty = false;
         }
         return &w;
     }
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    const bool capturing = hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
     if (w.part && capturing) return nullptr;                  // growing means freeing what earlier captured launches point at
     hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
     if (capturing && hipThreadExchangeStreamCaptureMode(&mode) != hipSuccess) return nullptr;
@@ -861,7 +866,8 @@ static BwdTableWs* bwd_table_ws(hipStream_t st, int64_t floats, int heads) {
     if (capturing) (void)hipThreadExchangeStreamCaptureMode(&mode);       // back to what the capture was started with
     if (!ok) return nullptr;
     if (hipMemsetAsync(w.cnt, 0, (size_t)nh * 4, st) != hipSuccess) return nullptr;      // ordered before the launch that follows on `st`
-    w.floats = nf; w.heads = nh; w.dirty = false;
+    w.floats = nf; w.heads = nh;
+    w.dirty = capturing;      // allocated inside a capture: the zero-fill above is a graph node, the memory itself is still what hipMalloc returned
     return &w;
 }
 

@@ -11,4 +11,7 @@ def total_loss(loss_dict):
             raise RuntimeError("total_loss: this loss dict was summed before; with early_proposal_backward a forward allows ONE backward "
                                "of the plain sum (the proposal generator's gradients are already in the arena)")
         loss_dict.consumed = True
+    if any(v.is_cuda for v in loss_dict.values()):
+        from ..solver import join_transposes
+        join_transposes()                       # (solver.OVERLAP_TRANSPOSES) the backward of this sum reads the transposed weight images
     return torch.stack([v.float().reshape(()) for v in loss_dict.values()]).sum()

@@ -185,6 +185,8 @@ class CustomRCNN(nn.Module):
         images = self.preprocess_image(batched_inputs)
         gt_instances = [x["instances"].to(self.device) for x in batched_inputs]
         features = self._features(images)
+        from ...solver import join_transposes
+        join_transposes()        # transposed weight images refreshed beside the backbone forward: first read by what follows
         grads_on = torch.is_grad_enabled() and all(f.requires_grad for f in features.values())
         with torch.autocast("cuda", dtype=torch.bfloat16):
             if grads_on:
@@ -239,6 +241,8 @@ class CustomRCNN(nn.Module):
         assert not self.training
         images = self.preprocess_image(batched_inputs)
         features = self._features(images)
+        from ...solver import join_transposes
+        join_transposes()        # (the mask head's deconvolution reads a transposed weight image)
         with torch.autocast("cuda", dtype=torch.bfloat16):
             proposals, _ = self.proposal_generator(images, features, None)
             results, _ = self.roi_heads(images, features, proposals)

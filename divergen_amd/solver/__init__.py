@@ -33,6 +33,20 @@ def warmup_cosine_lr(base_lr, it, max_iters, warmup_iters, warmup_factor, warmup
 _LAZY_ZERO = True      # first-writer weight gradients (FlatArena.zero_grad(lazy=True)); the eager form stays for the parity test of the two
 
 
+# The transposed weight images refreshed on a side stream (FlatArena.refresh_transposes(overlap=True)).  OFF by default: a loop may
+# switch it on only if everything that reads the images runs behind a join_transposes() on its stream -- CustomRCNN.training_losses
+# joins behind the backbone + FPN forward (ahead of the early backward and of the mask head), engine.total_loss() joins ahead of the
+# backward of the sum; train_net.py and bench.py switch it on.  A model that back-propagates without passing either must leave it off.
+OVERLAP_TRANSPOSES = False
+_pending_transposes = []
+
+
+def join_transposes():
+    """The current stream waits for every overlapped refresh queued so far (a few ns when there is none)."""
+    while _pending_transposes:
+        torch.cuda.current_stream().wait_event(_pending_transposes.pop())
+
+
 class FlatArena:
     """Re-homes every trainable parameter of `model` into one contiguous fp32 buffer and gives each a persistent .grad view
     into a second buffer.  Segments start on multiples of ALIGN = 64 elements: 128 bytes in the bf16 shadow / transposed twin
@@ -178,11 +192,28 @@ class FlatArena:
         self.p16.copy_(self.p)
         self.refresh_transposes()
 
-    def refresh_transposes(self):
-        """p16t <- transposes of the matrix parameters of p16: one grouped launch (csrc/transpose.hip)."""
+    def refresh_transposes(self, overlap=False):
+        """p16t <- transposes of the matrix parameters of p16: one grouped launch (csrc/transpose.hip).
+        overlap (the optimizers' step() asks for it; honoured only under OVERLAP_TRANSPOSES): the launch goes to a side stream behind the
+        optimizer kernel and the event behind it is queued for join_transposes() -- the images are the B operands of INPUT-GRADIENT
+        GEMMs (and of the mask head's deconvolution), i.e. first read ~8 ms into the next step; 0.8 GB of pure streaming then runs beside
+        the next forward's first blocks instead of in front of them."""
         if self._tjobs is None:
             return
         from .. import _lib as L
+        if overlap and OVERLAP_TRANSPOSES and self.p16.is_cuda:
+            side = self.__dict__.get("_tstream")
+            if side is None:
+                side = self.__dict__["_tstream"] = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                L.check(L.lib().dgx_transpose_bf16_grouped(self.p16.data_ptr(), self.p16t.data_ptr(), self._tjobs.data_ptr(),
+                                                           self._tjobs.shape[0], self._ttiles, L.stream()), "dgx_transpose_bf16_grouped")
+                ev = torch.cuda.Event()
+                ev.record()
+            _pending_transposes.append(ev)
+            return
+        join_transposes()          # an overlapped refresh still in flight writes the same images
         L.check(L.lib().dgx_transpose_bf16_grouped(self.p16.data_ptr(), self.p16t.data_ptr(), self._tjobs.data_ptr(),
                                                    self._tjobs.shape[0], self._ttiles, L.stream()), "dgx_transpose_bf16_grouped")
 
@@ -309,7 +340,7 @@ class FusedAdamWEMA:
                        p_bf16=self.arena.p16 if self.arena.p16.is_cuda else None,
                        lr_scale=self.lr_scale, seg_end=self.seg_end, found_inf=found_inf,
                        grad_scale_dev=self.last_clip if self.clip_norm > 0 else None)
-        self.arena.refresh_transposes()
+        self.arena.refresh_transposes(overlap=True)
 
     def _layout(self):
         return {"names": list(self.arena.names), "offsets": list(self.arena.offsets), "sizes": list(self.arena.sizes),
@@ -402,7 +433,7 @@ class FusedSGDEMA(FusedAdamWEMA):
                      self.nesterov, self.weight_decay, self.clip_value, grad_scale, self.last_clip, self.ema_decay,
                      p_bf16=self.arena.p16 if self.arena.p16.is_cuda else None, lr_scale=self.lr_scale, seg_end=self.seg_end,
                      found_inf=found_inf)
-        self.arena.refresh_transposes()
+        self.arena.refresh_transposes(overlap=True)
 
     def state_dict(self):
         return dict({"step": self.step_count, "momentum_buffer": self.buf, "lr": self.param_groups[0]["lr"]}, **self._layout())

@@ -661,3 +661,39 @@ def test_early_proposal_backward_is_the_same_step():
         # measured 8e-3: one-ulp differences of the bf16 level gradients, carried through the FPN and the backbone's backward in bf16 storage
         assert float((a - b).norm() / a.norm()) <= 2e-2
         assert float(a.norm()) > 0
+
+
+def test_overlapped_transposes_are_the_same_training():
+    """solver.OVERLAP_TRANSPOSES (train_net.py and bench.py switch it on): the transposed weight images -- B operands of the input-gradient
+    GEMMs and of the mask head's deconvolution -- are refreshed on a side stream behind the optimizer kernel and joined behind the next
+    backbone forward.  Losses and weights over several steps equal the run that refreshes them on the step's own stream bit for bit, with
+    the early backward (which reads them from inside the forward) on."""
+    from divergen_amd import solver
+    from divergen_amd.data import synthetic_batch
+    from divergen_amd.engine import total_loss
+    from divergen_amd.utils.events import EventStorage
+    res = []
+    try:
+        for overlap in (False, True):
+            solver.OVERLAP_TRANSPOSES = overlap
+            cfg, model, opt = _build(True)
+            model.early_proposal_backward = model.early_box_backward = True
+            batches = [synthetic_batch(2, 256, cfg.MODEL.ROI_HEADS.NUM_CLASSES, device="cuda", seed=s) for s in (1, 2)]
+            hist = []
+            with EventStorage(0):
+                for k in range(6):
+                    torch.manual_seed(11 + k)
+                    opt.zero_grad()
+                    losses = model(batches[k % 2])
+                    total_loss(losses).backward()
+                    hist.append({n: float(v) for n, v in losses.items()})
+                    opt.step()
+            torch.cuda.synchronize()
+            assert ("_tstream" in opt.arena.__dict__) == overlap and not solver._pending_transposes[1:]
+            solver.join_transposes()
+            res.append((hist, opt.arena.p.clone(), opt.arena.p16t.clone()))
+    finally:
+        solver.OVERLAP_TRANSPOSES = False
+    (h0, p0, t0), (h1, p1, t1) = res
+    assert h0 == h1
+    assert torch.equal(p0, p1) and torch.equal(t0, t1)

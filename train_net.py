@@ -137,6 +137,10 @@ def do_train(cfg, model, resume=False):
     # this loop back-propagates the plain sum of the loss dict once per zero_grad: the proposal generator's part may run from inside
     # the forward, ahead of the RoI heads' device->host read (meta_arch/custom_rcnn.py)
     model.early_proposal_backward = True
+    # ... and every reader of the transposed weight images sits behind a join in CustomRCNN / engine.total_loss: the refresh behind the
+    # optimizer step may run beside the next forward (solver.OVERLAP_TRANSPOSES); BSGAL's trial steps refresh synchronously
+    from divergen_amd import solver as _solver
+    overlap_before, _solver.OVERLAP_TRANSPOSES = _solver.OVERLAP_TRANSPOSES, not cfg.INPUT.get("ACTIVE_SELECT", False)
     if cfg.INPUT.get("ACTIVE_SELECT", False):
         # BSGAL (BS/train_net.py:358-557 + the selection inside its CustomRCNN.forward): the model decides per step whether the
         # pasted batch or its un-pasted original is trained on; needs the parameter arena, hence attached here
@@ -206,6 +210,8 @@ def do_train(cfg, model, resume=False):
             extra = {"model_ema": kwargs["model_ema"].state_dict()} if (kwargs and saves_now) else {}
             periodic.step(iteration, **extra)
         logger.info("Total training time: {}".format(str(datetime.timedelta(seconds=int(time.perf_counter() - t_start)))))
+    _solver.OVERLAP_TRANSPOSES = overlap_before         # (a process-wide switch: whatever runs after this loop gets the default back)
+    _solver.join_transposes()
     return optimizer
 
 

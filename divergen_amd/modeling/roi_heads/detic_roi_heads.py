@@ -240,7 +240,7 @@ class DeticCascadeROIHeads(nn.Module):
         for t in targets:
             offs.append(offs[-1] + len(t))
         has_src = all(t.has("instance_source") for t in targets)
-        self.__dict__["_gt_batch"] = (targets,) + self._cat_targets(targets, targets[0].gt_boxes.tensor.device, offs[-1], has_src, offs)
+        self.__dict__["_gt_batch"] = (targets,) + DeticCascadeROIHeads._cat_targets(targets, targets[0].gt_boxes.tensor.device, offs[-1], has_src, offs)
 
     def _label_and_sample_fused(self, proposals, targets):
         """label_and_sample_proposals for the whole batch in two launches around the step's one device->host read
@@ -269,7 +269,7 @@ class DeticCascadeROIHeads(nn.Module):
             # device->host read otherwise
             _, gt_boxes, gt_classes, gt_src, offs_t = pre
         else:
-            gt_boxes, gt_classes, gt_src, offs_t = self._cat_targets(targets, dev, G, has_src, offs)
+            gt_boxes, gt_classes, gt_src, offs_t = DeticCascadeROIHeads._cat_targets(targets, dev, G, has_src, offs)
         Nmax = K + max(gts)
         midx = torch.empty(B, Nmax, dtype=torch.int32, device=dev)
         labels = torch.empty(B, Nmax, dtype=torch.int64, device=dev)

@@ -25,7 +25,8 @@ torch.manual_seed(42)
 model = build_model(cfg).train()
 model.early_proposal_backward = True
 opt = build_optimizer(cfg, model)
-batch = synthetic_batch(2, 1024, cfg.MODEL.ROI_HEADS.NUM_CLASSES, device="cuda")
+SIZE = int(os.environ.get("SIZE", "1024"))
+batch = synthetic_batch(2, SIZE, cfg.MODEL.ROI_HEADS.NUM_CLASSES, device="cuda")
 
 
 def step():

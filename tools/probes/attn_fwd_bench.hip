@@ -3,6 +3,7 @@
 #include <cstdlib>
 #include "../../divergen_amd/csrc/window_attention.hip"
 #include <cstdio>
+#include <cstring>
 extern "C" int dgx_get_reserved_cus(void) { return 0; }
 #include <vector>
 int main(int argc, char** argv) {
@@ -35,7 +36,11 @@ int main(int argc, char** argv) {
                 hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&t, e0, e1); ms += t;
             }
             const double us = ms / iters * 1e3, bytes = (double)(nq + no) * 2;
-            printf("%s B_=%d nH=%d %s: fwd %.1f us  %.2f TB/s of q,k,v,out bytes (%.1f MB)\n", sh.name, B_, nH, masked ? "SW-MSA" : "W-MSA ", us, bytes / us / 1e6, bytes / 1e6);
+            std::vector<uint16_t> ho(no); std::vector<float> hl((size_t)B_ * nH * N);
+            hipMemcpy(ho.data(), out, no * 2, hipMemcpyDeviceToHost); hipMemcpy(hl.data(), lse, hl.size() * 4, hipMemcpyDeviceToHost);
+            unsigned long long ck = 0; for (size_t i = 0; i < no; ++i) ck = ck * 1315423911ull + ho[i];
+            unsigned long long cl = 0; for (size_t i = 0; i < hl.size(); ++i) { unsigned int u; memcpy(&u, &hl[i], 4); cl = cl * 1315423911ull + u; }
+            printf("%s B_=%d nH=%d %s: fwd %.1f us  %.2f TB/s of q,k,v,out bytes (%.1f MB)  out %016llx lse %016llx\n", sh.name, B_, nH, masked ? "SW-MSA" : "W-MSA ", us, bytes / us / 1e6, bytes / 1e6, ck, cl);
 #ifdef DIAG_CLOCK
             {   // the LAST launch's stamps: per-phase mean over the workgroups, the mean lifetime, and the launch's span first start -> last end
                 const int nwg = B_ * nH < 8192 ? B_ * nH : 8192;

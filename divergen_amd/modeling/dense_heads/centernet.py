@@ -295,7 +295,7 @@ class CenterNet(nn.Module):
 
     @torch.no_grad()
     def _predict_instances_fused(self, hm_logits, reg_maps, image_sizes):
-        """predict_instances for training on the GPU: libdgx kernels around torch's top-k / sort (dgx_centernet_scores / _decode /
+        """predict_instances for training on the GPU: libdgx kernels only (dgx_centernet_scores / dgx_topk_index_rows / _decode / dgx_sort_rows_desc /
         dgx_nms_batched / _finalize); fixed-length lists + validity flags, no host round trip.  None = layouts it does not take."""
         import ctypes
         from ... import _lib as L

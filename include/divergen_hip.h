@@ -200,7 +200,7 @@ int dgx_iou_match(const float* gt, int M, const float* props, int N, float thr,
                   int64_t* matched_idx, int8_t* matched_label, float* max_iou, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
- * CenterNet proposal decoding around torch's top-k / sort and dgx_nms_batched (centernet.py:627-737 `predict_instances`,
+ * CenterNet proposal decoding around the top-k / sort (dgx_topk_index_rows / dgx_sort_rows_desc below; torch's in rounds 1-5) and dgx_nms_batched (centernet.py:627-737 `predict_instances`,
  * `predict_single_level`, `nms_and_topK`).  Level geometry as for dgx_centernet_targets (HOST arrays level_hw (L,2), strides (L));
  * per-level maps are channels-last (B, h, w, pixel_stride) of dtype f32 | bf16, HOST arrays of L device pointers; M = sum h*w.
  *   dgx_centernet_scores:   scores f32 (B, M) (levels concatenated per image) = sigmoid(logit[channel]) where > thr, else -1;

@@ -38,6 +38,15 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ 
     mask[(int64_t)i * nb + cb] = bits;
 }
 
+__device__ __forceinline__ uint64_t uniform64(uint64_t v) {
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t readlane64(uint64_t v, int lane) {
+    const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)v, lane), hi = __builtin_amdgcn_readlane((uint32_t)(v >> 32), lane);
+    return ((uint64_t)hi << 32) | lo;
+}
+
 // One workgroup walks the 64-box blocks in order: lane-serial resolve inside a block, then all
 // threads OR the rows of the kept boxes into the running "removed" vector held in LDS.
 __global__ __launch_bounds__(1024) void nms_sweep_kernel(const uint64_t* __restrict__ mask, int n, int nb,
@@ -55,19 +64,20 @@ __global__ __launch_bounds__(1024) void nms_sweep_kernel(const uint64_t* __restr
         if (tid < 64) {
             // diagonal words of this block's rows
             const uint64_t mine = tid < cnt ? mask[(int64_t)(64 * b + tid) * nb + b] : 0ull;
-            uint64_t cur = remv[b];
-            int k = 0;
-            for (int j = 0; j < cnt; ++j) {
-                const uint64_t row = __shfl(mine, j);
-                const bool alive = !((cur >> j) & 1ull);
-                if (alive) {
-                    cur |= row;
-                    if (tid == 0) kept_rows[k] = 64 * b + j;
-                    ++k;
-                }
-                if (tid == j) keep[64 * b + j] = alive ? 1 : 0;
+            // the serial part is scalar and walks the KEPT boxes only: find-first-set, that row's diagonal word out of its lane, three bit
+            // operations (rounds 1-5: 64 cross-lane shuffles per block whatever survived)
+            const uint64_t vbits = cnt == 64 ? ~0ull : ((1ull << cnt) - 1ull);
+            uint64_t alive = uniform64(~remv[b] & vbits), keptbits = 0;
+            while (alive) {
+                const int j = __builtin_ctzll(alive);
+                const uint64_t bit = 1ull << j;
+                keptbits |= bit;
+                alive &= ~(readlane64(mine, j) | bit);
             }
-            if (tid == 0) { kept_n = k; total += k; }
+            const bool kept = (keptbits >> tid) & 1ull;
+            if (tid < cnt) keep[64 * b + tid] = kept ? 1 : 0;
+            if (kept) kept_rows[__popcll(keptbits & ((1ull << tid) - 1ull))] = 64 * b + tid;
+            if (tid == 0) { const int k = __popcll(keptbits); kept_n = k; total += k; }
         }
         __syncthreads();
         const int kn = kept_n;
@@ -154,15 +164,6 @@ __global__ __launch_bounds__(64) void nms_mask_batched_kernel(const float* __res
         if (ovr > thr) bits |= 1ull << j;
     }
     mask[(int64_t)i * nb + cb] = bits;
-}
-
-__device__ __forceinline__ uint64_t uniform64(uint64_t v) {
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-    return ((uint64_t)hi << 32) | lo;
-}
-__device__ __forceinline__ uint64_t readlane64(uint64_t v, int lane) {
-    const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)v, lane), hi = __builtin_amdgcn_readlane((uint32_t)(v >> 32), lane);
-    return ((uint64_t)hi << 32) | lo;
 }
 
 // The two-barrier form with the kept rows read from global memory: any K (the pipelined form below holds two blocks of rows in LDS
